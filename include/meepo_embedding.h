@@ -1,0 +1,128 @@
+/*
+ * meepo_embedding.h — C-ABI of the MI355X (gfx950) GPU backend for a dynamic lookup-table embedding.
+ *
+ * Drop-in boundary.  The reference snapshot defines NO interface for this path: its only functional
+ * statement is /root/reference/README.md:2 ("A distributed high-performance dynamic lookuptable-style
+ * Embedding … Supports GPU, CPU, remote distributed KV (such as Redis), SSD, and other backends").  The verbs
+ * below (find / insert / assign / export + sparse Adagrad/Adam apply) are the ones BASELINE.json's north_star
+ * names for the GPU backend; each entry point cites README.md:2 as the (only) reference anchor and SPEC.md
+ * for the semantics it implements.  A maintainer's binding stub is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no C++/torch types.  `stream` is a hipStream_t passed as void*
+ *    (NULL = the default stream).
+ *  - Every `d_*` pointer is DEVICE memory on the table's device, caller-owned, and must stay valid until the
+ *    stream reaches the op.  The library never frees or retains caller buffers.
+ *  - All ops are asynchronous and stream-ordered unless marked [syncs].  No op allocates device memory after
+ *    mee_table_create() (safe for hipGraph capture except the [syncs] ones).
+ *  - Return value: MEE_OK or a negative error code; mee_last_error() gives a thread-local message.
+ *    Device-side conditions (table full, reserved key in a batch) set sticky bits read by mee_status().
+ *  - Mutators (insert/assign/find_or_insert/apply_*) on ONE table must be ordered by the caller (same stream
+ *    or events); concurrent mee_find calls on different streams are safe.  n must be ≤ config.max_batch for
+ *    every op except mee_find (any n).
+ *  - There is no CPU fallback: creating a table without a usable gfx950 device fails with MEE_ERR_NO_DEVICE.
+ */
+#ifndef MEEPO_EMBEDDING_H
+#define MEEPO_EMBEDDING_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MEE_ABI_VERSION 1
+
+#define MEE_EMPTY_KEY     INT64_MIN       /* SPEC.md §2: reserved, never stored */
+#define MEE_RECLAIMED_KEY (INT64_MIN + 1) /* SPEC.md §2: reserved for a later remove() */
+#define MEE_BUCKET_WIDTH  16              /* keys per bucket = one 128-byte line */
+
+enum { MEE_OK = 0, MEE_ERR_INVALID_ARG = -1, MEE_ERR_OUT_OF_MEMORY = -2, MEE_ERR_HIP = -3,
+       MEE_ERR_NO_DEVICE = -4, MEE_ERR_BATCH_TOO_LARGE = -5, MEE_ERR_UNSUPPORTED = -6 };
+
+enum { MEE_OPT_NONE = 0, MEE_OPT_ADAGRAD = 1, MEE_OPT_ADAM = 2 };
+enum { MEE_INIT_CONSTANT = 0, MEE_INIT_UNIFORM = 1 };
+enum { MEE_STATUS_TABLE_FULL = 1u, MEE_STATUS_RESERVED_KEY = 2u };
+
+typedef struct mee_table  mee_table;  /* one HBM-resident hash table (one shard) */
+typedef struct mee_router mee_router; /* workspace for the shard partition / un-permute kernels */
+
+typedef struct mee_config {
+    uint32_t struct_size;         /* = sizeof(mee_config); ABI guard */
+    int32_t  device;              /* HIP device ordinal */
+    uint64_t capacity;            /* requested slots; rounded up to a multiple of 16 (SPEC.md §2) */
+    uint32_t dim;                 /* floats per row: multiple of 4, 4..1024 */
+    uint32_t optimizer;           /* MEE_OPT_*: which state planes to allocate */
+    uint64_t max_batch;           /* largest n of any mutating op (sizes the workspace) */
+    float    default_value;       /* fill for rows of absent keys */
+    float    initial_accumulator; /* Adagrad acc of a newly inserted key */
+    uint32_t initializer;         /* MEE_INIT_*: initial row for find_or_insert */
+    float    init_scale;
+    uint64_t init_seed;
+} mee_config;
+
+typedef struct mee_table_info {
+    uint64_t capacity, n_buckets, max_batch;
+    uint32_t dim, optimizer;
+    uint64_t table_bytes;     /* keys + all planes resident in HBM */
+    uint64_t workspace_bytes;
+} mee_table_info;
+
+int         mee_abi_version(void);
+const char* mee_last_error(void);
+
+/* ---- table lifetime (README.md:2 "GPU … backend"; SPEC.md §2) ------------------------------------------ */
+int mee_table_create(const mee_config* cfg, mee_table** out);
+int mee_table_destroy(mee_table* t);
+int mee_table_info_get(const mee_table* t, mee_table_info* out);
+int mee_clear(mee_table* t, void* stream);
+
+/* ---- lookup-table operators (README.md:2 "lookuptable-style"; SPEC.md §3) ------------------------------ */
+/* out[i,:] = row of keys[i] or default_value; found nullable. */
+int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
+/* upsert; duplicate keys: last occurrence wins. */
+int mee_insert(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, void* stream);
+/* overwrite only if present; d_found nullable; duplicates: last occurrence wins. */
+int mee_assign(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found, void* stream);
+/* find, inserting absent keys with their initial row first; d_found (nullable) = present before the call. */
+int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
+/* [syncs] all stored pairs, unspecified order; d_state1/d_state2 (nullable) receive acc|m and v rows in the
+ * same order.  At most `cap` pairs are written; *n_out = number stored in the table. */
+int mee_export(const mee_table* t, int64_t* d_keys_out, float* d_values_out, float* d_state1_out,
+               float* d_state2_out, size_t cap, size_t* n_out, void* stream);
+int mee_size(const mee_table* t, size_t* n_out, void* stream);        /* [syncs] */
+int mee_status(const mee_table* t, uint32_t* bits_out, void* stream); /* [syncs] */
+int mee_clear_status(mee_table* t, void* stream);
+
+/* ---- sparse optimizers (north_star "sparse-optimizer (Adagrad/Adam) scatter-update"; SPEC.md §4) -------- */
+int mee_apply_adagrad(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps,
+                      void* stream);
+int mee_apply_adam(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float beta1,
+                   float beta2, float eps, uint64_t step, void* stream);
+/* [syncs] duplicate-key reduction on its own (SPEC.md §4): unique keys (unspecified order), their summed
+ * grads (nullable with d_grads), occurrence counts (nullable) and inverse[i] = index into the unique list
+ * (nullable; -1 for reserved keys).  Outputs sized for n.  *n_unique_out on the host. */
+int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, int64_t* d_uniq_out,
+                  float* d_gsum_out, uint32_t* d_counts_out, int64_t* d_inverse_out, size_t* n_unique_out,
+                  void* stream);
+
+/* ---- hashing and shard routing (README.md:2 "distributed"; SPEC.md §1, §5) ----------------------------- */
+/* any output nullable: mix64(key), bucket(key, n_buckets), owner(key, n_shards). */
+int mee_hash_batch(const int64_t* d_keys, size_t n, uint64_t n_buckets, uint32_t n_shards, uint64_t* d_mix_out,
+                   uint64_t* d_bucket_out, uint32_t* d_owner_out, void* stream);
+int mee_router_create(int32_t device, uint64_t max_batch, uint32_t n_shards, mee_router** out);
+int mee_router_destroy(mee_router* r);
+/* stable partition by owner: d_send_keys[n], d_counts[n_shards] (uint64), d_perm[n] (batch position). */
+int mee_partition(mee_router* r, const int64_t* d_keys, size_t n, int64_t* d_send_keys, uint64_t* d_counts,
+                  int64_t* d_perm, void* stream);
+/* out[perm[q], :] = rows[q, :] (row_bytes multiple of 4); inverse of the partition for returned rows/masks. */
+int mee_scatter_rows(const void* d_rows, const int64_t* d_perm, size_t n, size_t row_bytes, void* d_out,
+                     void* stream);
+/* out[q, :] = rows[perm[q], :] — forward permutation of per-key payloads (values / grads) into send order. */
+int mee_gather_rows(const void* d_rows, const int64_t* d_perm, size_t n, size_t row_bytes, void* d_out,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEEPO_EMBEDDING_H */

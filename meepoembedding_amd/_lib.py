@@ -1,0 +1,103 @@
+"""ctypes loader for libmeepo_hip.so — the C-ABI declared in include/meepo_embedding.h.
+
+There is no CPU fallback: if the HIP extension is missing this module raises, and every operator raises
+`MeepoError` if the library reports an error (e.g. no gfx950 device).  torch is imported first on purpose:
+the extension's `libamdhip64.so.7` dependency must resolve to the HIP runtime torch already loaded, so that
+torch's streams and device pointers are valid inside the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL: see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmeepo_hip.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_NO_DEVICE, ERR_BATCH_TOO_LARGE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+OPT_NONE, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
+INIT_CONSTANT, INIT_UNIFORM = 0, 1
+STATUS_TABLE_FULL, STATUS_RESERVED_KEY = 1, 2
+EMPTY_KEY = -(1 << 63)
+RECLAIMED_KEY = EMPTY_KEY + 1
+BUCKET_WIDTH = 16
+
+
+class MeepoError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"meepo error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32), ("capacity", C.c_uint64), ("dim", C.c_uint32),
+        ("optimizer", C.c_uint32), ("max_batch", C.c_uint64), ("default_value", C.c_float),
+        ("initial_accumulator", C.c_float), ("initializer", C.c_uint32), ("init_scale", C.c_float),
+        ("init_seed", C.c_uint64),
+    ]
+
+
+class TableInfo(C.Structure):
+    _fields_ = [
+        ("capacity", C.c_uint64), ("n_buckets", C.c_uint64), ("max_batch", C.c_uint64), ("dim", C.c_uint32),
+        ("optimizer", C.c_uint32), ("table_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64),
+    ]
+
+
+_vp, _sz, _u64, _u32, _i32, _f32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int32, C.c_float
+
+# name -> (restype, argtypes); this is the full export list of include/meepo_embedding.h
+PROTOTYPES = {
+    "mee_abi_version": (C.c_int, []),
+    "mee_last_error": (C.c_char_p, []),
+    "mee_table_create": (C.c_int, [C.POINTER(Config), C.POINTER(_vp)]),
+    "mee_table_destroy": (C.c_int, [_vp]),
+    "mee_table_info_get": (C.c_int, [_vp, C.POINTER(TableInfo)]),
+    "mee_clear": (C.c_int, [_vp, _vp]),
+    "mee_find": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "mee_insert": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "mee_assign": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "mee_find_or_insert": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "mee_export": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), _vp]),
+    "mee_size": (C.c_int, [_vp, C.POINTER(_sz), _vp]),
+    "mee_status": (C.c_int, [_vp, C.POINTER(_u32), _vp]),
+    "mee_clear_status": (C.c_int, [_vp, _vp]),
+    "mee_apply_adagrad": (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _vp]),
+    "mee_apply_adam": (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
+    "mee_dedup_sum": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_sz), _vp]),
+    "mee_hash_batch": (C.c_int, [_vp, _sz, _u64, _u32, _vp, _vp, _vp, _vp]),
+    "mee_router_create": (C.c_int, [_i32, _u64, _u32, C.POINTER(_vp)]),
+    "mee_router_destroy": (C.c_int, [_vp]),
+    "mee_partition": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "mee_scatter_rows": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "mee_gather_rows": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP extension (once).  Raises ImportError loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). meepoembedding_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if L.mee_abi_version() != 1:
+            raise ImportError(f"{LIB_PATH}: ABI version {L.mee_abi_version()} != 1")
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise MeepoError(rc, lib().mee_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,120 @@
+// meepo_device.h — device-side building blocks shared by the gfx950 kernels (wave64 only).
+//
+// Geometry used everywhere: a wave (64 lanes) is split into 4 "tiles" of 16 lanes.  One tile serves one key:
+// its 16 lanes load the 16 keys of a bucket (one 128-byte line, 8 B per lane), a wave-wide __ballot turns the
+// compares into a 64-bit mask of which each tile reads its own 16 bits, and the same 16 lanes then move the
+// embedding row as float4 (16 lanes x 16 B = 256 B per instruction for dim 64).
+//
+// Reference anchor: /root/reference/README.md:2 (no code upstream); semantics: SPEC.md §1-§4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mee {
+
+constexpr int64_t kEmpty = INT64_MIN;
+constexpr int64_t kReclaimed = INT64_MIN + 1;
+constexpr int kW = 16;                                   // bucket width == tile width
+constexpr unsigned long long kBias = 0x8000000000000000ull;  // scratch stores key^kBias so that 0 == empty
+constexpr uint32_t kNoGroup = 0xFFFFFFFFu;
+
+// SPEC.md §1
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31; return x;
+}
+__host__ __device__ __forceinline__ uint64_t mix64b(uint64_t x) {
+    x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull;
+    x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull;
+    x ^= x >> 33; return x;
+}
+__device__ __forceinline__ uint64_t bucket_of(int64_t key, uint64_t nb) { return __umul64hi(mix64((uint64_t)key), nb); }
+__device__ __forceinline__ uint32_t owner_of(int64_t key, uint32_t g) { return (uint32_t)__umul64hi(mix64b((uint64_t)key), (uint64_t)g); }
+__device__ __forceinline__ bool reserved_key(int64_t k) { return k <= kReclaimed; }
+
+// Table keys are read with plain loads by read-only kernels (find/assign/apply: no key changes while they run)
+// and with agent-scope relaxed atomic loads (global_load … sc1: bypasses the per-CU L1) by kernels that claim
+// slots concurrently, so a retry after a lost CAS never re-reads a stale L1 line.
+template <bool COHERENT>
+__device__ __forceinline__ int64_t load_table_key(const int64_t* p) {
+    if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+
+__device__ __forceinline__ uint32_t tile_bits(uint64_t wave_mask, int tile) {
+    return (uint32_t)(wave_mask >> (tile * kW)) & 0xFFFFu;
+}
+
+// Locate `key` (SPEC.md §2 probe sequence); with CLAIM also place it when absent (CAS on the first EMPTY slot of
+// the first bucket that has one).  Must be called by ALL 64 lanes in convergent control flow; tiles without
+// work pass active=false.  Returns the slot or -1.
+template <bool CLAIM, bool COHERENT>
+__device__ __forceinline__ int64_t tile_locate(int64_t* __restrict__ tkeys, uint64_t nb, int64_t key, bool active,
+                                               int tile, int tl, bool& is_new, bool& full) {
+    uint64_t b = bucket_of(key, nb);
+    uint64_t steps = 0;
+    uint32_t retries = 0;  // lost-CAS re-reads of one bucket; bounded so that every wave reaches the exit
+    bool pend = active;
+    int64_t slot = -1;
+    is_new = false; full = false;
+    while (__any(pend)) {
+        const int64_t k = pend ? load_table_key<COHERENT>(tkeys + b * kW + tl) : kEmpty;
+        const uint32_t tm = tile_bits(__ballot(pend && k == key), tile);
+        const uint32_t te = tile_bits(__ballot(pend && k == kEmpty), tile);
+        const int e = __ffs(te) - 1;
+        long long cas_old = 0;
+        if constexpr (CLAIM) {
+            if (pend && !tm && te && tl == 0)
+                cas_old = (long long)atomicCAS((unsigned long long*)(tkeys + b * kW + e), (unsigned long long)kEmpty,
+                                               (unsigned long long)key);
+            cas_old = __shfl(cas_old, tile * kW);
+        }
+        if (pend) {
+            if (tm) { slot = (int64_t)(b * kW) + (__ffs(tm) - 1); pend = false; }
+            else if (te) {
+                if constexpr (CLAIM) {
+                    if (cas_old == kEmpty) { slot = (int64_t)(b * kW) + e; is_new = true; pend = false; }
+                    else if (cas_old == key) { slot = (int64_t)(b * kW) + e; pend = false; }
+                    else if (++retries > (1u << 20)) { full = true; pend = false; }
+                    // else: another key took that slot — re-read the same bucket
+                } else pend = false;  // absent
+            } else if (++steps >= nb) { full = true; pend = false; }
+            else b = (b + 1 == nb) ? 0 : b + 1;
+        }
+    }
+    return slot;
+}
+
+// SPEC.md §3 "Initial row", four consecutive elements starting at j0
+__device__ __forceinline__ float4 initial_row4(int64_t key, uint32_t j0, uint32_t initializer, float init_scale,
+                                               uint64_t init_seed, float default_value) {
+    if (initializer == 0) return make_float4(default_value, default_value, default_value, default_value);
+    float r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint64_t h = mix64((uint64_t)key ^ mix64(init_seed + j0 + q));
+        const float u = (float)(h >> 40) * 0x1p-24f;
+        r[q] = init_scale * (2.0f * u - 1.0f);
+    }
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+
+// SPEC.md §4 (explicit fma only where the spec writes it; file is compiled with -ffp-contract=off)
+__device__ __forceinline__ void adagrad1(float& w, float& a, float g, float lr, float eps) {
+    const float an = __builtin_fmaf(g, g, a);
+    const float q = __fdiv_rn(g, __fsqrt_rn(an) + eps);
+    w = __builtin_fmaf(-lr, q, w);
+    a = an;
+}
+__device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, float step_size, float omb1, float omb2,
+                                      float eps) {
+    const float mn = __builtin_fmaf(omb1, g - m, m);
+    const float gg = g * g;
+    const float vn = __builtin_fmaf(omb2, gg - v, v);
+    const float q = __fdiv_rn(mn, __fsqrt_rn(vn) + eps);
+    w = __builtin_fmaf(-step_size, q, w);
+    m = mn; v = vn;
+}
+
+}  // namespace mee

@@ -1,0 +1,48 @@
+// meepo_host.h — host-side plumbing shared by the C-ABI translation units (error slot, device guard).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/meepo_embedding.h"
+
+namespace mee {
+
+char* last_error_buf();  // thread-local, 512 bytes (defined in meepo_table.hip)
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define MEE_HIP(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return ::mee::fail(e_ == hipErrorOutOfMemory ? MEE_ERR_OUT_OF_MEMORY : MEE_ERR_HIP,           \
+                               "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// Makes `device` current for the scope of one API call and restores the caller's device afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) { err = hipSetDevice(device); switched = (err == hipSuccess); }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+inline unsigned grid_for(size_t work_items, unsigned per_block, unsigned cap) {
+    size_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+}  // namespace mee

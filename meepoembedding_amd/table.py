@@ -1,0 +1,234 @@
+"""Host-side lookup-table interface over the C-ABI (include/meepo_embedding.h).
+
+Mirrors the operator set BASELINE.json's north_star names for the reference's GPU backend — find / insert /
+assign / export (+ find_or_insert, size, sparse Adagrad/Adam apply).  The reference snapshot defines no
+interface (only /root/reference/README.md:2, "dynamic lookuptable-style Embedding"); semantics are SPEC.md §3-§4.
+
+torch is plumbing only: it owns the device buffers and the stream.  Every method takes/returns CUDA(HIP)
+tensors on the table's device and enqueues on torch's current stream; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (INIT_CONSTANT, INIT_UNIFORM, OPT_ADAGRAD, OPT_ADAM, OPT_NONE, STATUS_RESERVED_KEY,  # noqa: F401
+                   STATUS_TABLE_FULL, MeepoError, check)
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class LookupTable:
+    """One HBM-resident shard: int64 key -> fp32[dim] row (+ optimizer state planes)."""
+
+    def __init__(self, capacity: int, dim: int, *, device: int | torch.device = 0, optimizer: int = OPT_NONE,
+                 max_batch: int = 1 << 20, default_value: float = 0.0, initial_accumulator: float = 0.0,
+                 initializer: int = INIT_CONSTANT, init_scale: float = 0.0, init_seed: int = 0):
+        L = _lib.lib()
+        dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        if dev.type != "cuda":
+            raise MeepoError(_lib.ERR_NO_DEVICE, "LookupTable needs a HIP device; there is no CPU fallback")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        cfg = _lib.Config(struct_size=C.sizeof(_lib.Config), device=self.device.index, capacity=capacity, dim=dim,
+                          optimizer=optimizer, max_batch=max_batch, default_value=default_value,
+                          initial_accumulator=initial_accumulator, initializer=initializer, init_scale=init_scale,
+                          init_seed=init_seed)
+        h = C.c_void_p()
+        self._h = None
+        check(L.mee_table_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        info = _lib.TableInfo()
+        check(L.mee_table_info_get(self._h, C.byref(info)))
+        self.capacity, self.n_buckets, self.max_batch = info.capacity, info.n_buckets, info.max_batch
+        self.dim, self.optimizer = info.dim, info.optimizer
+        self.table_bytes, self.workspace_bytes = info.table_bytes, info.workspace_bytes
+
+    # -- lifetime ----------------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _lib.lib().mee_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers -----------------------------------------------------------------------------------------
+    def _keys(self, keys: torch.Tensor) -> torch.Tensor:
+        if keys.dtype != torch.int64 or keys.device != self.device:
+            raise MeepoError(_lib.ERR_INVALID_ARG, f"keys must be int64 on {self.device}")
+        return keys.contiguous().view(-1)
+
+    def _rows(self, rows: torch.Tensor, n: int) -> torch.Tensor:
+        if rows.dtype != torch.float32 or rows.device != self.device or rows.numel() != n * self.dim:
+            raise MeepoError(_lib.ERR_INVALID_ARG, f"rows must be float32 [{n},{self.dim}] on {self.device}")
+        return rows.contiguous()
+
+    def _s(self) -> int:
+        return _stream_ptr(self.device)
+
+    # -- operators (SPEC.md §3) ----------------------------------------------------------------------------
+    def find(self, keys: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None,
+             want_found: bool = True):
+        k = self._keys(keys)
+        n = k.numel()
+        if out is None:
+            out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        if found is None and want_found:
+            found = torch.empty(n, dtype=torch.uint8, device=self.device)
+        check(_lib.lib().mee_find(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr() if found is not None else None,
+                                  self._s()))
+        return out, found
+
+    def insert(self, keys: torch.Tensor, values: torch.Tensor) -> None:
+        k = self._keys(keys)
+        v = self._rows(values, k.numel())
+        check(_lib.lib().mee_insert(self._h, k.data_ptr(), v.data_ptr(), k.numel(), self._s()))
+
+    def assign(self, keys: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
+        k = self._keys(keys)
+        v = self._rows(values, k.numel())
+        found = torch.empty(k.numel(), dtype=torch.uint8, device=self.device)
+        check(_lib.lib().mee_assign(self._h, k.data_ptr(), v.data_ptr(), k.numel(), found.data_ptr(), self._s()))
+        return found
+
+    def find_or_insert(self, keys: torch.Tensor):
+        k = self._keys(keys)
+        n = k.numel()
+        out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        found = torch.empty(n, dtype=torch.uint8, device=self.device)
+        check(_lib.lib().mee_find_or_insert(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), self._s()))
+        return out, found
+
+    def size(self) -> int:
+        n = C.c_size_t()
+        check(_lib.lib().mee_size(self._h, C.byref(n), self._s()))
+        return n.value
+
+    def status(self) -> int:
+        b = C.c_uint32()
+        check(_lib.lib().mee_status(self._h, C.byref(b), self._s()))
+        return b.value
+
+    def clear_status(self) -> None:
+        check(_lib.lib().mee_clear_status(self._h, self._s()))
+
+    def clear(self) -> None:
+        check(_lib.lib().mee_clear(self._h, self._s()))
+
+    def export(self, with_state: bool = False):
+        """All (key, row) pairs in unspecified order; with_state also returns the optimizer planes."""
+        n = self.size()
+        keys = torch.empty(n, dtype=torch.int64, device=self.device)
+        vals = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        s1 = torch.empty((n, self.dim), dtype=torch.float32, device=self.device) if with_state and self.optimizer != OPT_NONE else None
+        s2 = torch.empty((n, self.dim), dtype=torch.float32, device=self.device) if with_state and self.optimizer == OPT_ADAM else None
+        m = C.c_size_t()
+        check(_lib.lib().mee_export(self._h, keys.data_ptr(), vals.data_ptr(), s1.data_ptr() if s1 is not None else None,
+                                    s2.data_ptr() if s2 is not None else None, n, C.byref(m), self._s()))
+        if m.value != n:
+            raise MeepoError(_lib.ERR_HIP, f"export wrote {m.value} pairs, size() said {n}")
+        return (keys, vals, s1, s2) if with_state else (keys, vals)
+
+    # -- sparse optimizers (SPEC.md §4) --------------------------------------------------------------------
+    def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10) -> None:
+        k = self._keys(keys)
+        g = self._rows(grads, k.numel())
+        check(_lib.lib().mee_apply_adagrad(self._h, k.data_ptr(), g.data_ptr(), k.numel(), lr, eps, self._s()))
+
+    def apply_adam(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999,
+                   eps: float = 1e-8, step: int = 1) -> None:
+        k = self._keys(keys)
+        g = self._rows(grads, k.numel())
+        check(_lib.lib().mee_apply_adam(self._h, k.data_ptr(), g.data_ptr(), k.numel(), lr, beta1, beta2, eps, step, self._s()))
+
+    def dedup_sum(self, keys: torch.Tensor, grads: torch.Tensor | None = None):
+        """Duplicate-key reduction alone: (unique keys, summed grads | None, counts, inverse)."""
+        k = self._keys(keys)
+        n = k.numel()
+        g = self._rows(grads, n) if grads is not None else None
+        uniq = torch.empty(n, dtype=torch.int64, device=self.device)
+        gs = torch.empty((n, self.dim), dtype=torch.float32, device=self.device) if g is not None else None
+        cnt = torch.empty(n, dtype=torch.int32, device=self.device)
+        inv = torch.empty(n, dtype=torch.int64, device=self.device)
+        nu = C.c_size_t()
+        check(_lib.lib().mee_dedup_sum(self._h, k.data_ptr(), g.data_ptr() if g is not None else None, n, uniq.data_ptr(),
+                                       gs.data_ptr() if gs is not None else None, cnt.data_ptr(), inv.data_ptr(), C.byref(nu),
+                                       self._s()))
+        U = nu.value
+        return uniq[:U], (gs[:U] if gs is not None else None), cnt[:U], inv
+
+
+def hash_batch(keys: torch.Tensor, n_buckets: int, n_shards: int):
+    """SPEC.md §1 on device: (mix64, bucket, owner) as int64/int64/int32 tensors (bit patterns of the unsigned values)."""
+    k = keys.contiguous().view(-1)
+    n = k.numel()
+    mix = torch.empty(n, dtype=torch.int64, device=k.device)
+    bkt = torch.empty(n, dtype=torch.int64, device=k.device)
+    own = torch.empty(n, dtype=torch.int32, device=k.device)
+    with torch.cuda.device(k.device):
+        check(_lib.lib().mee_hash_batch(k.data_ptr(), n, n_buckets, n_shards, mix.data_ptr(), bkt.data_ptr(), own.data_ptr(),
+                                        _stream_ptr(k.device)))
+    return mix, bkt, own
+
+
+class Router:
+    """Shard partition / un-permute kernels (SPEC.md §5) with their workspace."""
+
+    def __init__(self, n_shards: int, max_batch: int, device: int | torch.device = 0):
+        dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.n_shards, self.max_batch = n_shards, max_batch
+        h = C.c_void_p()
+        self._h = None
+        check(_lib.lib().mee_router_create(self.device.index, max_batch, n_shards, C.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _lib.lib().mee_router_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def partition(self, keys: torch.Tensor):
+        k = keys.contiguous().view(-1)
+        n = k.numel()
+        send = torch.empty_like(k)
+        counts = torch.empty(self.n_shards, dtype=torch.int64, device=self.device)
+        perm = torch.empty(n, dtype=torch.int64, device=self.device)
+        check(_lib.lib().mee_partition(self._h, k.data_ptr(), n, send.data_ptr(), counts.data_ptr(), perm.data_ptr(),
+                                       _stream_ptr(self.device)))
+        return send, counts, perm
+
+    def scatter_rows(self, rows: torch.Tensor, perm: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """out[perm[q]] = rows[q]"""
+        r = rows.contiguous()
+        n = perm.numel()
+        if out is None:
+            out = torch.empty_like(r)
+        rb = r.numel() * r.element_size() // max(n, 1)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mee_scatter_rows(r.data_ptr(), perm.data_ptr(), n, rb, out.data_ptr(), _stream_ptr(self.device)))
+        return out
+
+    def gather_rows(self, rows: torch.Tensor, perm: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """out[q] = rows[perm[q]]"""
+        r = rows.contiguous()
+        n = perm.numel()
+        if out is None:
+            out = torch.empty_like(r)
+        rb = r.numel() * r.element_size() // max(n, 1)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mee_gather_rows(r.data_ptr(), perm.data_ptr(), n, rb, out.data_ptr(), _stream_ptr(self.device)))
+        return out

@@ -1,0 +1,191 @@
+"""ctypes binding of the CPU oracle (oracle/libmeepo_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg —
+never by meepoembedding_amd.  PARITY UNPINNED (reference snapshot has no implementation; see
+oracle/meepo_oracle.h).  The class mirrors the product's host interface (meepoembedding_amd.table.LookupTable)
+on numpy arrays so parity tests can drive both with the same calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmeepo_oracle.so")
+
+OPT_NONE, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
+INIT_CONSTANT, INIT_UNIFORM = 0, 1
+STATUS_TABLE_FULL, STATUS_RESERVED_KEY = 1, 2
+EMPTY_KEY = -(1 << 63)
+RECLAIMED_KEY = EMPTY_KEY + 1
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "meepo_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libmeepo_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        vp, u64, u32, f32, sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_float, C.c_size_t
+        L.meo_mix64.restype = u64; L.meo_mix64.argtypes = [u64]
+        L.meo_mix64b.restype = u64; L.meo_mix64b.argtypes = [u64]
+        L.meo_mulhi64.restype = u64; L.meo_mulhi64.argtypes = [u64, u64]
+        L.meo_bucket.restype = u64; L.meo_bucket.argtypes = [C.c_int64, u64]
+        L.meo_owner.restype = u32; L.meo_owner.argtypes = [C.c_int64, u32]
+        L.meo_hash_batch.restype = None; L.meo_hash_batch.argtypes = [vp, sz, u64, u32, vp, vp, vp]
+        L.meo_create.restype = vp; L.meo_create.argtypes = [u64, u32, u32, f32, f32, u32, f32, u64]
+        L.meo_destroy.restype = None; L.meo_destroy.argtypes = [vp]
+        L.meo_capacity.restype = u64; L.meo_capacity.argtypes = [vp]
+        L.meo_size.restype = u64; L.meo_size.argtypes = [vp]
+        L.meo_status.restype = u32; L.meo_status.argtypes = [vp]
+        L.meo_clear_status.restype = None; L.meo_clear_status.argtypes = [vp]
+        L.meo_clear.restype = None; L.meo_clear.argtypes = [vp]
+        L.meo_initial_row.restype = None; L.meo_initial_row.argtypes = [vp, C.c_int64, vp]
+        L.meo_find.restype = None; L.meo_find.argtypes = [vp, vp, sz, vp, vp]
+        L.meo_find_mt.restype = None; L.meo_find_mt.argtypes = [vp, vp, sz, vp, vp, C.c_int]
+        L.meo_insert.restype = None; L.meo_insert.argtypes = [vp, vp, vp, sz]
+        L.meo_assign.restype = None; L.meo_assign.argtypes = [vp, vp, vp, sz, vp]
+        L.meo_find_or_insert.restype = None; L.meo_find_or_insert.argtypes = [vp, vp, sz, vp, vp]
+        L.meo_export.restype = u64; L.meo_export.argtypes = [vp, vp, vp, vp, vp, u64]
+        L.meo_apply_adagrad.restype = None; L.meo_apply_adagrad.argtypes = [vp, vp, vp, sz, f32, f32]
+        L.meo_apply_adam.restype = None; L.meo_apply_adam.argtypes = [vp, vp, vp, sz, f32, f32, f32, f32, u64]
+        L.meo_dedup_sum.restype = u64; L.meo_dedup_sum.argtypes = [vp, vp, sz, u32, vp, vp, vp, vp]
+        L.meo_partition.restype = None; L.meo_partition.argtypes = [vp, sz, u32, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _keys(k) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(k, dtype=np.int64))
+
+
+def _rows(v, n, dim) -> np.ndarray:
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.float32)).reshape(n, dim)
+    return a
+
+
+def hash_batch(keys, n_buckets: int, n_shards: int):
+    k = _keys(keys)
+    mix = np.empty(k.size, np.uint64); bkt = np.empty(k.size, np.uint64); own = np.empty(k.size, np.uint32)
+    lib().meo_hash_batch(_p(k), k.size, n_buckets, n_shards, _p(mix), _p(bkt), _p(own))
+    return mix, bkt, own
+
+
+def partition(keys, n_shards: int):
+    k = _keys(keys)
+    send = np.empty_like(k); counts = np.zeros(n_shards, np.uint64); perm = np.empty(k.size, np.int64)
+    lib().meo_partition(_p(k), k.size, n_shards, _p(send), _p(counts), _p(perm))
+    return send, counts.astype(np.int64), perm
+
+
+def dedup_sum(keys, grads, dim: int):
+    k = _keys(keys)
+    g = None if grads is None else _rows(grads, k.size, dim)
+    uniq = np.empty(k.size, np.int64); gs = np.empty((k.size, dim), np.float32)
+    inv = np.empty(k.size, np.int64); cnt = np.empty(k.size, np.uint32)
+    U = lib().meo_dedup_sum(_p(k), _p(g), k.size, dim, _p(uniq), _p(gs), _p(inv), _p(cnt))
+    return uniq[:U].copy(), gs[:U].copy(), inv, cnt[:U].copy()
+
+
+class OracleTable:
+    """Numpy-facing mirror of the operator API, backed by the C oracle."""
+
+    def __init__(self, capacity: int, dim: int, optimizer: int = OPT_NONE, default_value: float = 0.0,
+                 initial_accumulator: float = 0.0, initializer: int = INIT_CONSTANT, init_scale: float = 0.0,
+                 init_seed: int = 0):
+        self._h = lib().meo_create(capacity, dim, optimizer, default_value, initial_accumulator, initializer,
+                                   init_scale, init_seed)
+        if not self._h:
+            raise ValueError("meo_create: invalid arguments or out of memory")
+        self.dim = dim
+        self.optimizer = optimizer
+
+    def close(self):
+        if self._h:
+            lib().meo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def capacity(self) -> int:
+        return lib().meo_capacity(self._h)
+
+    def size(self) -> int:
+        return lib().meo_size(self._h)
+
+    def status(self) -> int:
+        return lib().meo_status(self._h)
+
+    def clear_status(self):
+        lib().meo_clear_status(self._h)
+
+    def clear(self):
+        lib().meo_clear(self._h)
+
+    def initial_row(self, key: int) -> np.ndarray:
+        r = np.empty(self.dim, np.float32)
+        lib().meo_initial_row(self._h, key, _p(r))
+        return r
+
+    def find(self, keys, threads: int = 1):
+        k = _keys(keys)
+        out = np.empty((k.size, self.dim), np.float32); found = np.empty(k.size, np.uint8)
+        if threads > 1:
+            lib().meo_find_mt(self._h, _p(k), k.size, _p(out), _p(found), threads)
+        else:
+            lib().meo_find(self._h, _p(k), k.size, _p(out), _p(found))
+        return out, found
+
+    def insert(self, keys, values):
+        k = _keys(keys); v = _rows(values, k.size, self.dim)
+        lib().meo_insert(self._h, _p(k), _p(v), k.size)
+
+    def assign(self, keys, values):
+        k = _keys(keys); v = _rows(values, k.size, self.dim)
+        found = np.empty(k.size, np.uint8)
+        lib().meo_assign(self._h, _p(k), _p(v), k.size, _p(found))
+        return found
+
+    def find_or_insert(self, keys):
+        k = _keys(keys)
+        out = np.empty((k.size, self.dim), np.float32); found = np.empty(k.size, np.uint8)
+        lib().meo_find_or_insert(self._h, _p(k), k.size, _p(out), _p(found))
+        return out, found
+
+    def export(self, with_state: bool = False):
+        n = self.size()
+        keys = np.empty(n, np.int64); vals = np.empty((n, self.dim), np.float32)
+        s1 = np.empty((n, self.dim), np.float32) if with_state and self.optimizer != OPT_NONE else None
+        s2 = np.empty((n, self.dim), np.float32) if with_state and self.optimizer == OPT_ADAM else None
+        m = lib().meo_export(self._h, _p(keys), _p(vals), _p(s1), _p(s2), n)
+        assert m == n
+        return (keys, vals, s1, s2) if with_state else (keys, vals)
+
+    def apply_adagrad(self, keys, grads, lr: float, eps: float):
+        k = _keys(keys); g = _rows(grads, k.size, self.dim)
+        lib().meo_apply_adagrad(self._h, _p(k), _p(g), k.size, lr, eps)
+
+    def apply_adam(self, keys, grads, lr: float, beta1: float, beta2: float, eps: float, step: int):
+        k = _keys(keys); g = _rows(grads, k.size, self.dim)
+        lib().meo_apply_adam(self._h, _p(k), _p(g), k.size, lr, beta1, beta2, eps, step)

@@ -1,0 +1,291 @@
+"""GPU parity: every operator of the HIP backend through the C-ABI vs the CPU oracle on the same seeded inputs.
+Bar: bit-exact for hashing / found-masks / copied rows / size / key-sorted export; ≤1e-6 relative (atol 1e-9) for
+fp32 optimizer state (SPEC.md §4)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from meepoembedding_amd import (INIT_UNIFORM, OPT_ADAGRAD, OPT_ADAM, STATUS_RESERVED_KEY, STATUS_TABLE_FULL, LookupTable,
+                                MeepoError, Router, hash_batch, synth)
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+RTOL, ATOL = 1e-6, 1e-9
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def sorted_export(keys, *planes):
+    order = np.argsort(keys)
+    return (keys[order],) + tuple(p[order] for p in planes)
+
+
+def test_hash_kat_on_device(dev):
+    kat = json.load(open(os.path.join(GOLDEN, "hash_kat.json")))
+    keys = np.array([int(k) for k in kat["keys"]], dtype=np.int64)
+    for nb, exp_b in kat["bucket"].items():
+        for g, exp_o in kat["owner"].items():
+            mix, bkt, own = hash_batch(T(keys, dev), int(nb), int(g))
+            assert [str(int(x)) for x in mix.cpu().numpy().view(np.uint64)] == kat["mix64"]
+            assert [str(int(x)) for x in bkt.cpu().numpy().view(np.uint64)] == exp_b
+            assert [int(x) for x in own.cpu().numpy()] == exp_o
+
+
+@pytest.mark.parametrize("dim,n,load", [(16, 20000, 0.75), (64, 50000, 0.75), (128, 8192, 0.9), (4, 1000, 0.5), (40, 3000, 0.75),
+                                        (256, 2000, 0.75)])
+def test_insert_find_assign_export(dev, dim, n, load):
+    keys = synth.keys_np(1, 0, 2 * n)
+    present, absent = keys[:n], keys[n:]
+    rows = synth.rows_np(present, dim, 2)
+    cap = int(n / load)
+    t = LookupTable(cap, dim, device=dev, max_batch=2 * n, default_value=-3.5)
+    o = oracle.OracleTable(cap, dim, default_value=-3.5)
+    assert t.capacity == o.capacity
+    t.insert(T(present, dev), T(rows, dev)); o.insert(present, rows)
+    assert t.size() == o.size() == n and t.status() == 0
+    # mixed hit/miss lookup, shuffled
+    rng = np.random.default_rng(5)
+    q = np.concatenate([present, absent])[rng.permutation(2 * n)]
+    out, found = t.find(T(q, dev))
+    eo, ef = o.find(q)
+    assert np.array_equal(found.cpu().numpy(), ef)
+    assert np.array_equal(out.cpu().numpy(), eo)
+    # assign half (with misses mixed in)
+    sub = np.concatenate([present[::2], absent[:100]])
+    new = synth.rows_np(sub, dim, 9)
+    fa = t.assign(T(sub, dev), T(new, dev)); fo = o.assign(sub, new)
+    assert np.array_equal(fa.cpu().numpy(), fo)
+    out, found = t.find(T(q, dev)); eo, ef = o.find(q)
+    assert np.array_equal(out.cpu().numpy(), eo) and np.array_equal(found.cpu().numpy(), ef)
+    gk, gv = t.export(); ok, ov = o.export()
+    gk, gv = sorted_export(gk.cpu().numpy(), gv.cpu().numpy()); ok, ov = sorted_export(ok, ov)
+    assert np.array_equal(gk, ok) and np.array_equal(gv, ov)
+    t.clear()
+    assert t.size() == 0 and not t.find(T(q[:100], dev))[1].any()
+
+
+def test_find_edge_cases(dev):
+    t = LookupTable(1000, 64, device=dev, max_batch=4096)
+    out, found = t.find(torch.empty(0, dtype=torch.int64, device=dev))   # empty batch
+    assert out.shape == (0, 64) and found.numel() == 0
+    out, found = t.find(T(np.array([1, 2, 3], np.int64), dev))            # empty table, ragged (n % 4 != 0)
+    assert not found.any() and not out.any()
+    out, _ = t.find(T(np.array([7], np.int64), dev), want_found=False)     # found mask optional
+    assert out.shape == (1, 64)
+    t.insert(T(np.array([7], np.int64), dev), torch.ones(1, 64, device=dev))
+    for n in (1, 2, 3, 5, 63, 64, 65, 257):
+        q = np.full(n, 7, np.int64)
+        out, found = t.find(T(q, dev))
+        assert found.all() and (out == 1).all()
+    with pytest.raises(MeepoError):
+        t.insert(T(np.arange(5000, dtype=np.int64), dev), torch.zeros(5000, 64, device=dev))  # > max_batch
+    with pytest.raises(MeepoError):
+        t.find(torch.zeros(4, dtype=torch.int32, device=dev))
+
+
+def test_duplicates_last_wins(dev):
+    dim, n = 64, 30000
+    rng = np.random.default_rng(11)
+    keys = rng.integers(0, 500, size=n).astype(np.int64)          # ~60 occurrences per key
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    t = LookupTable(2048, dim, device=dev, max_batch=n); o = oracle.OracleTable(2048, dim)
+    t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
+    assert t.size() == o.size()
+    q = np.arange(-5, 505, dtype=np.int64)
+    out, found = t.find(T(q, dev)); eo, ef = o.find(q)
+    assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
+    rows2 = rng.standard_normal((n, dim)).astype(np.float32)
+    keys2 = rng.integers(400, 700, size=n).astype(np.int64)
+    fa = t.assign(T(keys2, dev), T(rows2, dev)); fo = o.assign(keys2, rows2)
+    assert np.array_equal(fa.cpu().numpy(), fo)
+    q = np.arange(350, 750, dtype=np.int64)
+    out, found = t.find(T(q, dev)); eo, ef = o.find(q)
+    assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
+
+
+def test_reserved_keys_and_table_full(dev):
+    t = LookupTable(32, 4, device=dev, max_batch=256); o = oracle.OracleTable(32, 4)
+    keys = np.array([oracle.EMPTY_KEY, 5, oracle.RECLAIMED_KEY, 6], dtype=np.int64)
+    ones = np.ones((4, 4), np.float32)
+    t.insert(T(keys, dev), T(ones, dev)); o.insert(keys, ones)
+    assert t.size() == o.size() == 2 and t.status() == o.status() == STATUS_RESERVED_KEY
+    out, found = t.find(T(keys, dev)); eo, ef = o.find(keys)
+    assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
+    t.clear_status()
+    many = synth.keys_np(4, 0, 100)
+    t.insert(T(many, dev), torch.zeros(100, 4, device=dev))
+    assert t.size() == 32 and t.status() & STATUS_TABLE_FULL
+    _, found = t.find(T(many, dev))
+    assert int(found.sum()) == 30      # which 30 is placement-order dependent (not observable), the count is not
+
+
+def test_high_load_long_probes(dev):
+    """Load factor 0.97: multi-bucket probe chains, every key still found, absent keys still absent."""
+    dim, cap = 16, 16 * 256
+    n = int(cap * 0.97)
+    keys = synth.keys_np(13, 0, 2 * n); rows = synth.rows_np(keys[:n], dim, 1)
+    t = LookupTable(cap, dim, device=dev, max_batch=2 * n); o = oracle.OracleTable(cap, dim)
+    t.insert(T(keys[:n], dev), T(rows, dev)); o.insert(keys[:n], rows)
+    out, found = t.find(T(keys, dev)); eo, ef = o.find(keys)
+    assert t.size() == n and np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
+
+
+def test_find_or_insert(dev):
+    dim = 64
+    kw = dict(initializer=INIT_UNIFORM, init_scale=0.05, init_seed=17, initial_accumulator=0.25)
+    t = LookupTable(4096, dim, device=dev, max_batch=8192, optimizer=OPT_ADAGRAD, **kw)
+    o = oracle.OracleTable(4096, dim, optimizer=oracle.OPT_ADAGRAD, **kw)
+    rng = np.random.default_rng(3)
+    for rnd in range(3):
+        keys = rng.integers(0, 1500, size=3000).astype(np.int64) + 1000 * rnd
+        out, found = t.find_or_insert(T(keys, dev)); eo, ef = o.find_or_insert(keys)
+        assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
+        assert t.size() == o.size()
+    gk, gv, ga, _ = t.export(with_state=True); ok, ov, oa, _ = o.export(with_state=True)
+    gk, gv, ga = sorted_export(gk.cpu().numpy(), gv.cpu().numpy(), ga.cpu().numpy()); ok, ov, oa = sorted_export(ok, ov, oa)
+    assert np.array_equal(gk, ok) and np.array_equal(gv, ov) and np.array_equal(ga, oa)
+
+
+def test_dedup_sum(dev):
+    dim, n = 64, 40000
+    rng = np.random.default_rng(7)
+    keys = np.concatenate([rng.integers(0, 3000, size=n - 5000), np.full(5000, 77)]).astype(np.int64)  # one heavy key
+    keys[123] = oracle.EMPTY_KEY
+    grads = rng.standard_normal((n, dim)).astype(np.float32)
+    t = LookupTable(64, dim, device=dev, max_batch=n)
+    uniq, gs, cnt, inv = t.dedup_sum(T(keys, dev), T(grads, dev))
+    uniq, gs, cnt, inv = uniq.cpu().numpy(), gs.cpu().numpy(), cnt.cpu().numpy(), inv.cpu().numpy()
+    ou, ogs, oinv, ocnt = oracle.dedup_sum(keys, grads, dim)
+    order, oorder = np.argsort(uniq), np.argsort(ou)
+    assert np.array_equal(uniq[order], ou[oorder]) and np.array_equal(cnt[order], ocnt[oorder])
+    np.testing.assert_allclose(gs[order], ogs[oorder], rtol=RTOL, atol=ATOL)
+    assert inv[123] == -1 and np.array_equal(uniq[inv[inv >= 0]], keys[inv >= 0])
+    # group table left clean: a second, different batch gives a correct answer too
+    u2, _, c2, _ = t.dedup_sum(T(keys[:100], dev))
+    assert int(c2.sum()) == 100 - (1 if 123 < 100 else 0) and len(np.unique(u2.cpu().numpy())) == u2.numel()
+
+
+@pytest.mark.parametrize("opt", ["adagrad", "adam"])
+@pytest.mark.parametrize("dim", [16, 64, 128])
+def test_optimizer_parity(dev, opt, dim):
+    n_keys, steps, batch = 20000, 4, 30000
+    keys = synth.keys_np(31, 0, n_keys); rows = synth.rows_np(keys, dim, 2)
+    kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
+    t = LookupTable(32768, dim, device=dev, optimizer=kind, max_batch=batch, initial_accumulator=0.1)
+    o = oracle.OracleTable(32768, dim, optimizer=okind, initial_accumulator=0.1)
+    t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
+    rng = np.random.default_rng(41)
+    for s in range(steps):
+        # zipf-ish skew: many duplicates incl. a few heavy keys, plus absent keys that must be ignored
+        idx = np.minimum(rng.zipf(1.3, size=batch) - 1, n_keys - 1)
+        bk = keys[idx]
+        bk[rng.integers(0, batch, 50)] = synth.keys_np(77, s * 50, 50)
+        g = (rng.standard_normal((batch, dim)) * 0.01).astype(np.float32)
+        if opt == "adagrad":
+            t.apply_adagrad(T(bk, dev), T(g, dev), lr=0.01, eps=1e-10); o.apply_adagrad(bk, g, 0.01, 1e-10)
+        else:
+            t.apply_adam(T(bk, dev), T(g, dev), lr=0.001, step=s + 1); o.apply_adam(bk, g, 0.001, 0.9, 0.999, 1e-8, s + 1)
+    assert t.size() == o.size() == n_keys
+    g_ = [x.cpu().numpy() if x is not None else None for x in t.export(with_state=True)]
+    o_ = o.export(with_state=True)
+    order, oorder = np.argsort(g_[0]), np.argsort(o_[0])
+    assert np.array_equal(g_[0][order], o_[0][oorder])
+    for a, b in zip(g_[1:], o_[1:]):
+        if b is not None:
+            np.testing.assert_allclose(a[order], b[oorder], rtol=RTOL, atol=ATOL)
+
+
+def test_optimizer_unique_keys_bit_exact(dev):
+    """No duplicates -> no reduction-order freedom: the HIP update must equal the oracle bit for bit."""
+    dim, n = 64, 10000
+    keys = synth.keys_np(5, 0, n); rows = synth.rows_np(keys, dim, 2)
+    g = (synth.rows_np(keys, dim, 6) * 0.02).astype(np.float32)
+    for kind, okind in ((OPT_ADAGRAD, oracle.OPT_ADAGRAD), (OPT_ADAM, oracle.OPT_ADAM)):
+        t = LookupTable(16384, dim, device=dev, optimizer=kind, max_batch=n); o = oracle.OracleTable(16384, dim, optimizer=okind)
+        t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
+        for s in range(3):
+            if kind == OPT_ADAGRAD:
+                t.apply_adagrad(T(keys, dev), T(g, dev), lr=0.01); o.apply_adagrad(keys, g, 0.01, 1e-10)
+            else:
+                t.apply_adam(T(keys, dev), T(g, dev), lr=0.001, step=s + 1); o.apply_adam(keys, g, 0.001, 0.9, 0.999, 1e-8, s + 1)
+        out, _ = t.find(T(keys, dev)); eo, _ = o.find(keys)
+        assert np.array_equal(out.cpu().numpy(), eo)
+
+
+def test_optimizer_vs_torch_golden_on_gpu(dev):
+    z = np.load(os.path.join(GOLDEN, "optimizer_golden.npz"))
+    for dim in (16, 64):
+        w0, idx, grads = z[f"w0_{dim}"], z[f"idx_{dim}"], z[f"grads_{dim}"]
+        keys = synth.keys_np(21, 0, w0.shape[0])
+        for name in ("adagrad", "adam"):
+            t = LookupTable(1024, dim, device=dev, optimizer=OPT_ADAGRAD if name == "adagrad" else OPT_ADAM, max_batch=1024,
+                            initial_accumulator=0.1 if name == "adagrad" else 0.0)
+            t.insert(T(keys, dev), T(w0, dev))
+            for s in range(idx.shape[0]):
+                if name == "adagrad":
+                    t.apply_adagrad(T(keys[idx[s]], dev), T(grads[s], dev), lr=0.05, eps=1e-10)
+                else:
+                    t.apply_adam(T(keys[idx[s]], dev), T(grads[s], dev), lr=0.01, step=s + 1)
+            got, _ = t.find(T(keys, dev))
+            np.testing.assert_allclose(got.cpu().numpy(), z[f"{name}_w_{dim}"], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("g", [1, 2, 3, 8])
+def test_partition_and_permute(dev, g):
+    n = 100_003
+    keys = synth.keys_np(8, 0, n)
+    r = Router(g, n, device=dev)
+    send, counts, perm = r.partition(T(keys, dev))
+    os_, oc, op = oracle.partition(keys, g)
+    assert np.array_equal(send.cpu().numpy(), os_) and np.array_equal(counts.cpu().numpy(), oc) and np.array_equal(perm.cpu().numpy(), op)
+    rows = synth.rows_np(keys, 16, 3)
+    fwd = r.gather_rows(T(rows, dev), perm)
+    assert np.array_equal(fwd.cpu().numpy(), rows[op])
+    back = r.scatter_rows(fwd, perm)
+    assert np.array_equal(back.cpu().numpy(), rows)
+    mask = (keys & 1).astype(np.uint8)
+    assert np.array_equal(r.scatter_rows(r.gather_rows(T(mask, dev), perm), perm).cpu().numpy(), mask)
+
+
+def test_concurrent_insert_stress(dev):
+    """Many waves claim slots in few buckets at once: no key stored twice, none lost (SURVEY §5 race row)."""
+    dim, n = 4, 60000
+    keys = synth.keys_np(19, 0, n)
+    t = LookupTable(n + 64, dim, device=dev, max_batch=n)       # load ~1.0: heavy CAS contention and long probes
+    rows = synth.rows_np(keys, dim, 1)
+    t.insert(T(keys, dev), T(rows, dev))
+    assert t.status() == 0 and t.size() == n
+    gk, gv = t.export()
+    gk = gk.cpu().numpy()
+    assert len(np.unique(gk)) == n and np.array_equal(np.sort(gk), np.sort(keys))
+    out, found = t.find(T(keys, dev))
+    assert found.all() and np.array_equal(out.cpu().numpy(), rows)
+
+
+def test_large_round_trip_properties(dev):
+    """Size-independent properties at a bench-like size (8M keys, dim 64): insert -> find returns exactly the
+    key-derived rows; absent stream all-miss; export is a permutation of the inserted set (checksum of keys)."""
+    dim, n, chunk = 64, 8_000_000, 1_000_000
+    t = LookupTable(int(n / 0.75), dim, device=dev, max_batch=chunk)
+    for s in range(0, n, chunk):
+        k = synth.keys_t(1, s, chunk, dev)
+        t.insert(k, synth.rows_t(k, dim, 2))
+    assert t.size() == n and t.status() == 0
+    for s in (0, 3_000_000, 7_000_000):
+        k = synth.keys_t(1, s, chunk, dev)
+        out, found = t.find(k)
+        assert bool(found.all()) and torch.equal(out, synth.rows_t(k, dim, 2))
+    k = synth.keys_t(2, 0, chunk, dev)
+    out, found = t.find(k)
+    assert not bool(found.any()) and not bool(out.any())
+    gk, gv = t.export()
+    assert gk.numel() == n
+    allk = torch.cat([synth.keys_t(1, s, chunk, dev) for s in range(0, n, chunk)])
+    assert int(gk.sum()) == int(allk.sum()) and int((gk ^ (gk >> 7)).sum()) == int((allk ^ (allk >> 7)).sum())
+    assert torch.equal(gv[:chunk], synth.rows_t(gk[:chunk], dim, 2))
