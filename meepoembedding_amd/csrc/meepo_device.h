@@ -103,7 +103,7 @@ __device__ __forceinline__ float4 initial_row4(int64_t key, uint32_t j0, uint32_
 // SPEC.md §4 (explicit fma only where the spec writes it; file is compiled with -ffp-contract=off)
 __device__ __forceinline__ void adagrad1(float& w, float& a, float g, float lr, float eps) {
     const float an = __builtin_fmaf(g, g, a);
-    const float q = __fdiv_rn(g, __fsqrt_rn(an) + eps);
+    const float q = g / (__builtin_sqrtf(an) + eps);
     w = __builtin_fmaf(-lr, q, w);
     a = an;
 }
@@ -112,7 +112,7 @@ __device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, flo
     const float mn = __builtin_fmaf(omb1, g - m, m);
     const float gg = g * g;
     const float vn = __builtin_fmaf(omb2, gg - v, v);
-    const float q = __fdiv_rn(mn, __fsqrt_rn(vn) + eps);
+    const float q = mn / (__builtin_sqrtf(vn) + eps);
     w = __builtin_fmaf(-step_size, q, w);
     m = mn; v = vn;
 }
