@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py — key-lookups/sec of the HIP find path (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W        configs[1]: 100M keys, dim 64, forward find, 256K-key batches
+    python -m torch.distributed.run --nproc-per-node N … bench.py --gpus N …
+                                                          row-sharded: 125M keys per GPU (N=8: the 1B-key table), dim 64,
+                                                          1M lookups per rank per step, RCCL all-to-all of keys / rows
+
+A step = one pass of the hot path over one batch of synthetic keys already resident in HBM.  N=1: one mee_find
+launch.  N>1: one sharded find (partition, all-to-all counts+keys, local find, all-to-all rows back, un-permute).
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (find_kernel) from HIP events around the
+timed launches; `cpu_baseline` is the in-repo CPU oracle ("port"; the reference snapshot has no implementation)
+on a bounded sample, rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+
+
+def algorithmic_bytes_per_lookup(dim: int) -> int:
+    """batch key 8 + matched table key 8 + row read dim*4 + dense row write dim*4."""
+    return 16 + 8 * dim
+
+
+def populate(table, synth, n_keys, dim, dev, chunk, owner_rank=None, world=1, hash_batch=None, log=None):
+    """Insert keys_t(seed=1, 0..n_keys) with rows_t(seed=2); sharded: only the keys this rank owns."""
+    t0 = time.time()
+    for s in range(0, n_keys, chunk):
+        c = min(chunk, n_keys - s)
+        k = synth.keys_t(1, s, c, dev)
+        if owner_rank is not None and world > 1:
+            own = hash_batch(k, 1, world)[2]
+            k = k[own == owner_rank].contiguous()
+        if k.numel():
+            table.insert(k, synth.rows_t(k, dim, 2))
+        if log and (s // chunk) % 50 == 0:
+            log(f"populate {s + c}/{n_keys} keys ({time.time() - t0:.1f}s)")
+    torch.cuda.synchronize(dev)
+
+
+def lookup_batches(synth, n_keys, batch, n_batches, dist_name, dev, seed):
+    """Pre-generate lookup batches over the inserted key set (uniform or Zipf(1.05) by key index)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    out = []
+    for _ in range(n_batches):
+        if dist_name == "zipf":
+            # inverse-CDF sampling of a truncated Zipf(alpha=1.05) over ranks 1..n_keys (continuous approximation)
+            a = 1.05
+            u = torch.rand(batch, device=dev, generator=g, dtype=torch.float64)
+            hi = float(n_keys) ** (1 - a)
+            r = (1 + u * (hi - 1)) ** (1 / (1 - a))
+            idx = (r.floor().to(torch.int64) - 1).clamp_(0, n_keys - 1)
+        else:
+            idx = torch.randint(0, n_keys, (batch,), device=dev, generator=g)
+        out.append(synth.mix64_t((idx + 1) * synth._s64(synth._GOLDEN) + synth._s64(1)))
+    return out
+
+
+def cpu_baseline(synth, dim, batch, budget_s=12.0):
+    """In-repo CPU oracle find on a bounded sample: 8M-key table (2 GB of rows, DRAM-resident), 256K-key batches."""
+    import oracle
+    n_keys = 8_000_000
+    cores = max(1, min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0))))  # a 1-GPU box's CPU share is 16 cores
+    t = oracle.OracleTable(int(n_keys / 0.75), dim)
+    for s in range(0, n_keys, 1_000_000):
+        k = synth.keys_np(1, s, 1_000_000)
+        t.insert(k, synth.rows_np(k, dim, 2))
+    rng = np.random.default_rng(3)
+    batches = [synth.keys_np(1, 0, n_keys)[rng.integers(0, n_keys, batch)] for _ in range(8)]
+    res = {}
+    for threads in (1, cores):
+        t.find(batches[0], threads=threads)  # warm-up
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s / 2:
+            t.find(batches[done % len(batches)], threads=threads)
+            done += 1
+        res[threads] = done * batch / (time.perf_counter() - t0)
+    t.close()
+    return {"value": res[cores], "unit": "key-lookups/s", "cores": cores, "kind": "port",
+            "single_thread_value": res[1],
+            "sample": f"in-repo CPU oracle (reference snapshot has no implementation): find on an {n_keys // 1_000_000}M-key dim-{dim} "
+                      f"table (load 0.75), uniform {batch}-key batches, ~{budget_s / 2:.0f}s per thread count"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--keys", type=int, default=None, help="keys per GPU (default 100M at N=1, 125M sharded)")
+    ap.add_argument("--batch", type=int, default=None, help="lookups per rank per step (default 256K at N=1, 1M sharded)")
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--load", type=float, default=0.75)
+    ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    from meepoembedding_amd import LookupTable, Router, hash_batch, synth
+    from meepoembedding_amd.sharded import ShardedLookupTable
+
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def log(msg):
+        if args.verbose and rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    sharded = world > 1
+    keys_per_gpu = args.keys or (125_000_000 if sharded else 100_000_000)
+    batch = args.batch or ((1 << 20) if sharded else (1 << 18))
+    n_keys = keys_per_gpu * world
+    dim = args.dim
+    chunk = 1 << 20
+    cap = int(keys_per_gpu / args.load * (1.02 if sharded else 1.0))  # shard sizes fluctuate a little around n/world
+    table = LookupTable(cap, dim, device=dev, max_batch=max(chunk, batch * 2))
+    log(f"table: {table.capacity} slots, {table.table_bytes / 1e9:.1f} GB")
+    populate(table, synth, n_keys, dim, dev, chunk, owner_rank=rank, world=world, hash_batch=hash_batch, log=log)
+    local_size = table.size()
+    assert table.status() == 0, "table full / reserved key during populate"
+    n_batches = 16 if sharded else 64
+    batches = lookup_batches(synth, n_keys, batch, n_batches, args.dist, dev, seed=3 + rank)
+    out = torch.empty((batch, dim), dtype=torch.float32, device=dev)
+    found = torch.empty(batch, dtype=torch.uint8, device=dev)
+
+    if sharded:
+        sh = ShardedLookupTable(table, Router(world, batch, device=dev))
+
+        def step(i):
+            return sh.find(batches[i % n_batches])
+    else:
+        def step(i):
+            return table.find(batches[i % n_batches], out=out, found=found)
+
+    for i in range(args.warmup):
+        r = step(i)
+    torch.cuda.synchronize(dev)
+    # correctness guard on the last warm-up batch: every looked-up key was inserted, rows are key-derived
+    chk_keys = batches[(args.warmup - 1) % n_batches][:4096] if args.warmup else None
+    if chk_keys is not None:
+        o_rows, o_found = r
+        assert bool(o_found.all()), "bench lookup missed an inserted key"
+        assert torch.equal(o_rows[:4096], synth.rows_t(chk_keys, dim, 2)), "bench lookup returned wrong rows"
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if sharded:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(i)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    if sharded:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if sharded:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # dominant kernel (find_kernel) alone, HIP events on the launch stream, for the roofline object
+    if sharded:
+        kk = batches[0]
+        for _ in range(5):
+            table.find(kk)
+        torch.cuda.synchronize(dev)
+        ev0.record()
+        for i in range(50):
+            table.find(batches[i % n_batches], out=out, found=found)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        kern_s = ev0.elapsed_time(ev1) / 1e3 / 50
+    else:
+        kern_s = ev_ms / 1e3 / args.steps
+    bpl = algorithmic_bytes_per_lookup(dim)
+    achieved = batch * bpl / kern_s / 1e9
+
+    if rank == 0:
+        value = world * batch * args.steps / elapsed
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "find_traffic.json")  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+        if os.path.exists(tpath) and not sharded:
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("batch") == batch and tj.get("dim") == dim and tj.get("keys") == keys_per_gpu:
+                    traffic = tj["bytes_per_launch"]
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "key-lookups/sec", "value": value, "unit": "key-lookups/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int64 keys / fp32 rows (copy)", "data": "synthetic",
+            "config": {"workload": (f"row-sharded find: {n_keys // 1_000_000}M keys over {world} GPUs ({keys_per_gpu // 1_000_000}M/GPU), dim {dim}, "
+                                    f"{batch} lookups per rank per step, RCCL all-to-all keys out / rows back" if sharded else
+                                    f"configs[1]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim} fp32, forward find only, {batch}-key batches"),
+                       "keys_per_gpu": keys_per_gpu, "local_size": local_size, "dim": dim, "batch_per_rank": batch, "load_factor": args.load,
+                       "key_distribution": args.dist, "table_gb": round(table.table_bytes / 1e9, 2),
+                       "parallelism": f"row-shard x{world}" if sharded else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "find_kernel", "avg_launch_us": kern_s * 1e6,
+                         "algorithmic_bytes_per_lookup": bpl, "lookups_per_launch": batch},
+        }
+        if not sharded and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(synth, dim, batch)
+        print(json.dumps(res), flush=True)
+    if sharded:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,9 @@ int mee_table_create(const mee_config* cfg, mee_table** out);
 int mee_table_destroy(mee_table* t);
 int mee_table_info_get(const mee_table* t, mee_table_info* out);
 int mee_clear(mee_table* t, void* stream);
+/* performance knobs; never change results.  "find_rounds" (keys in flight per 16-lane tile: 1/2/4/8),
+ * "find_grid_cap" (max blocks of the find grid, 0 = unbounded). */
+int mee_set_tuning(mee_table* t, const char* name, int value);
 
 /* ---- lookup-table operators (README.md:2 "lookuptable-style"; SPEC.md §3) ------------------------------ */
 /* out[i,:] = row of keys[i] or default_value; found nullable. */

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "mee_table_destroy": (C.c_int, [_vp]),
     "mee_table_info_get": (C.c_int, [_vp, C.POINTER(TableInfo)]),
     "mee_clear": (C.c_int, [_vp, _vp]),
+    "mee_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mee_find": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_insert": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "mee_assign": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),

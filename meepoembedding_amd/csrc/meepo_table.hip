@@ -63,7 +63,10 @@ struct mee_table {
     mee::Counters* h_ctr;       // pinned staging for read-backs
     mee::OpCounters* h_op;
     uint64_t table_bytes, workspace_bytes;
-    int find_rounds;            // keys in flight per tile in the find kernel (tuning knob, MEE_FIND_ROUNDS)
+    // performance knobs (never change results): see mee_set_tuning()
+    int find_rounds;            // keys in flight per tile in the find kernel: 1, 2, 4 or 8
+    int find_grid_cap;          // max blocks of the find grid (0 = one pass, no grid-stride loop)
+    int find_nt;                // bit0: non-temporal row loads, bit1: non-temporal bucket loads
 };
 
 namespace mee {
@@ -81,7 +84,7 @@ __global__ void fill_i64_kernel(int64_t* p, uint64_t n, int64_t v) {
 // DIM4 = dim/4 when it is a multiple of 16 (each lane moves DIM4/16 float4 per row), 0 = any dim at run time.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int DIM4, int R>
+template <int DIM4, int R, int NT>
 __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values,
                                                    uint64_t nb, const int64_t* __restrict__ keys, uint64_t n,
                                                    f32x4* __restrict__ out, uint8_t* __restrict__ found, float defv,
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             b[r] = bucket_of(key[r], nb);
-            kb[r] = act[r] ? tkeys[b[r] * kW + tl] : kEmpty;
+            kb[r] = act[r] ? ((NT & 2) ? __builtin_nontemporal_load(&tkeys[b[r] * kW + tl]) : tkeys[b[r] * kW + tl]) : kEmpty;
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int c = 0; c < C; ++c)
-                    row[r][c] = slot[r] >= 0 ? values[(uint64_t)slot[r] * DIM4 + c * 16 + tl] : def4;
+                    row[r][c] = slot[r] >= 0 ? ((NT & 1) ? __builtin_nontemporal_load(&values[(uint64_t)slot[r] * DIM4 + c * 16 + tl]) : values[(uint64_t)slot[r] * DIM4 + c * 16 + tl]) : def4;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint64_t i = base + r * 4 + tile;
@@ -617,8 +620,9 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     uint64_t S = 1024;
     while (S < 2 * cfg->max_batch) S <<= 1;
     t->S = S; t->smask = S - 1;
-    const char* fr = getenv("MEE_FIND_ROUNDS");
-    t->find_rounds = fr ? atoi(fr) : 2;
+    t->find_rounds = 2;
+    t->find_grid_cap = 0;
+    t->find_nt = 1;
 
     const uint64_t plane = t->capacity * (uint64_t)t->dim * sizeof(float);
     const uint64_t mb = t->max_batch;
@@ -671,6 +675,15 @@ int mee_table_info_get(const mee_table* t, mee_table_info* o) {
     return MEE_OK;
 }
 
+int mee_set_tuning(mee_table* t, const char* name, int value) {
+    if (!t || !name) return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: null argument");
+    if (!strcmp(name, "find_rounds")) t->find_rounds = value;
+    else if (!strcmp(name, "find_grid_cap")) t->find_grid_cap = value;
+    else if (!strcmp(name, "find_nt")) t->find_nt = value;
+    else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);
+    return MEE_OK;
+}
+
 int mee_clear(mee_table* t, void* stream) {
     if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_clear: null table");
     DeviceGuard g(t->device);
@@ -685,13 +698,18 @@ int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, 
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
-    const int R = t->find_rounds;
-    const unsigned grid = grid_for(n, 4u * 4u * (unsigned)(R > 0 ? R : 1), 1u << 20);
-#define FIND(D4, RR) find_kernel<D4, RR><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)t->values, t->nb, d_keys, n, (f32x4*)d_out, d_found, t->default_value, t->dim4)
-    if (t->dim4 == 16) { if (R >= 4) FIND(16, 4); else if (R == 2) FIND(16, 2); else FIND(16, 1); }
-    else if (t->dim4 == 32) { if (R >= 2) FIND(32, 2); else FIND(32, 1); }
-    else { if (R >= 2) FIND(0, 2); else FIND(0, 1); }
+    int R = t->find_rounds;
+    if (t->dim4 != 16 && R > 4) R = 4;
+    if (t->dim4 != 16 && t->dim4 != 32 && R > 2) R = 2;
+    R = R >= 8 ? 8 : R >= 4 ? 4 : R >= 2 ? 2 : 1;
+    const unsigned grid = grid_for(n, 4u * 4u * (unsigned)R, t->find_grid_cap > 0 ? (unsigned)t->find_grid_cap : (1u << 22));
+#define FIND1(D4, RR, NT) find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)t->values, t->nb, d_keys, n, (f32x4*)d_out, d_found, t->default_value, t->dim4)
+#define FIND(D4, RR) do { switch (t->find_nt & 3) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; default: FIND1(D4, RR, 3); } } while (0)
+    if (t->dim4 == 16) { if (R == 8) FIND(16, 8); else if (R == 4) FIND(16, 4); else if (R == 2) FIND(16, 2); else FIND(16, 1); }
+    else if (t->dim4 == 32) { if (R == 4) FIND(32, 4); else if (R == 2) FIND(32, 2); else FIND(32, 1); }
+    else { if (R == 2) FIND(0, 2); else FIND(0, 1); }
 #undef FIND
+#undef FIND1
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }

@@ -1,0 +1,97 @@
+"""Row-sharded lookup table over one node's GPUs: owner(key) routing + all-to-all exchange (SPEC.md §5).
+
+One process per GPU; `torch.distributed` carries the exchange (backend "nccl" is RCCL over xGMI on ROCm; "gloo"
+is used by the CPU tests of this host logic).  Per sharded find:
+
+    partition(keys) by owner  ->  all-to-all counts  ->  all-to-all keys (8 B each)
+    local find on the received keys (HIP kernel)     ->  all-to-all rows (dim*4 B each) + found-mask back
+    scatter through perm into batch order
+
+Reference anchor: /root/reference/README.md:2 ("A distributed … Embedding"); the snapshot has no code.
+
+This module is host logic only: `local` is any object with the LookupTable operator methods and `router` any
+object with partition / gather_rows / scatter_rows (the HIP-backed LookupTable / Router in production).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class ShardedLookupTable:
+    def __init__(self, local, router, group=None):
+        self.local, self.router, self.group = local, router, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.dim = local.dim
+        if router.n_shards != self.world:
+            raise ValueError(f"router has {router.n_shards} shards, process group has {self.world} ranks")
+
+    # -- exchange plumbing -------------------------------------------------------------------------------
+    def _route(self, keys: torch.Tensor):
+        """partition + counts exchange. Returns (send_keys, perm, send_splits, recv_splits)."""
+        send_keys, counts, perm = self.router.partition(keys)
+        recv_counts = torch.empty_like(counts)
+        dist.all_to_all_single(recv_counts, counts, group=self.group)
+        both = torch.stack([counts, recv_counts]).cpu()  # the one host sync of the exchange
+        return send_keys, perm, both[0].tolist(), both[1].tolist()
+
+    def _a2a(self, t: torch.Tensor, in_splits, out_splits) -> torch.Tensor:
+        out = torch.empty((sum(out_splits),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_to_all_single(out, t.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+        return out
+
+    # -- operators ---------------------------------------------------------------------------------------
+    def _lookup(self, keys: torch.Tensor, insert_missing: bool):
+        keys = keys.contiguous().view(-1)
+        send_keys, perm, ss, rs = self._route(keys)
+        recv_keys = self._a2a(send_keys, ss, rs)
+        if insert_missing:
+            rows, found = self.local.find_or_insert(recv_keys)
+        else:
+            rows, found = self.local.find(recv_keys)
+        rows_back = self._a2a(rows, rs, ss)
+        found_back = self._a2a(found, rs, ss)
+        return self.router.scatter_rows(rows_back, perm), self.router.scatter_rows(found_back, perm)
+
+    def find(self, keys: torch.Tensor):
+        return self._lookup(keys, False)
+
+    def find_or_insert(self, keys: torch.Tensor):
+        return self._lookup(keys, True)
+
+    def _push(self, keys: torch.Tensor, payload: torch.Tensor):
+        """Route (key, row) pairs to their owners; received pairs are ordered by source rank, then batch position."""
+        keys = keys.contiguous().view(-1)
+        send_keys, perm, ss, rs = self._route(keys)
+        send_rows = self.router.gather_rows(payload.contiguous().view(keys.numel(), -1), perm)
+        return self._a2a(send_keys, ss, rs), self._a2a(send_rows, ss, rs), perm, ss, rs
+
+    def insert(self, keys: torch.Tensor, values: torch.Tensor) -> None:
+        rk, rv, *_ = self._push(keys, values)
+        self.local.insert(rk, rv)
+
+    def assign(self, keys: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
+        rk, rv, perm, ss, rs = self._push(keys, values)
+        found = self.local.assign(rk, rv)
+        return self.router.scatter_rows(self._a2a(found, rs, ss), perm)
+
+    def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10) -> None:
+        rk, rg, *_ = self._push(keys, grads)
+        self.local.apply_adagrad(rk, rg, lr, eps)
+
+    def apply_adam(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999,
+                   eps: float = 1e-8, step: int = 1) -> None:
+        rk, rg, *_ = self._push(keys, grads)
+        self.local.apply_adam(rk, rg, lr, beta1, beta2, eps, step)
+
+    def size(self) -> int:
+        t = torch.tensor([self.local.size()], dtype=torch.int64, device=self._dev())
+        dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+    def export_local(self, with_state: bool = False):
+        return self.local.export(with_state=with_state)
+
+    def _dev(self):
+        return getattr(self.local, "device", torch.device("cpu"))

@@ -122,6 +122,10 @@ class LookupTable:
     def clear(self) -> None:
         check(_lib.lib().mee_clear(self._h, self._s()))
 
+    def set_tuning(self, name: str, value: int) -> None:
+        """Performance knob (never changes results): see mee_set_tuning in the header."""
+        check(_lib.lib().mee_set_tuning(self._h, name.encode(), int(value)))
+
     def export(self, with_state: bool = False):
         """All (key, row) pairs in unspecified order; with_state also returns the optimizer planes."""
         n = self.size()

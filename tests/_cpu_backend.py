@@ -1,0 +1,56 @@
+"""Test-only adapters: the CPU oracle behind the LookupTable / Router method names, on CPU torch tensors, so the
+sharded host logic (meepoembedding_amd/sharded.py) can run under gloo without a GPU.  Never used by the product."""
+import numpy as np
+import torch
+
+import oracle
+
+
+class CpuTable:
+    def __init__(self, capacity, dim, **kw):
+        self.o = oracle.OracleTable(capacity, dim, **kw)
+        self.dim = dim
+        self.device = torch.device("cpu")
+
+    def find(self, keys):
+        out, found = self.o.find(keys.numpy())
+        return torch.from_numpy(out), torch.from_numpy(found)
+
+    def find_or_insert(self, keys):
+        out, found = self.o.find_or_insert(keys.numpy())
+        return torch.from_numpy(out), torch.from_numpy(found)
+
+    def insert(self, keys, values):
+        self.o.insert(keys.numpy(), values.numpy())
+
+    def assign(self, keys, values):
+        return torch.from_numpy(self.o.assign(keys.numpy(), values.numpy()))
+
+    def apply_adagrad(self, keys, grads, lr, eps=1e-10):
+        self.o.apply_adagrad(keys.numpy(), grads.numpy(), lr, eps)
+
+    def apply_adam(self, keys, grads, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=1):
+        self.o.apply_adam(keys.numpy(), grads.numpy(), lr, beta1, beta2, eps, step)
+
+    def size(self):
+        return self.o.size()
+
+    def export(self, with_state=False):
+        return tuple(torch.from_numpy(x) if x is not None else None for x in self.o.export(with_state=with_state))
+
+
+class CpuRouter:
+    def __init__(self, n_shards):
+        self.n_shards = n_shards
+
+    def partition(self, keys):
+        send, counts, perm = oracle.partition(keys.numpy(), self.n_shards)
+        return torch.from_numpy(send), torch.from_numpy(counts), torch.from_numpy(perm)
+
+    def scatter_rows(self, rows, perm):
+        out = torch.empty_like(rows)
+        out[perm] = rows
+        return out
+
+    def gather_rows(self, rows, perm):
+        return rows[perm].contiguous()

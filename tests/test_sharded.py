@@ -1,0 +1,116 @@
+"""Row-sharded path (SPEC.md §5).  CPU: world_size-2 gloo run of the host logic with oracle-backed shards, checked
+against ONE global oracle table.  GPU: the same logic on the HIP backend through RCCL (world_size 1 on the 1-GPU
+box: partition, all-to-all plumbing, local find, un-permute)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from meepoembedding_amd import synth
+from meepoembedding_amd.sharded import ShardedLookupTable
+
+DIM, NKEYS, BATCH = 16, 6000, 4000
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _batches(world):
+    """Per-rank batches with cross-rank and in-batch duplicates."""
+    rng = np.random.default_rng(100)
+    keys = synth.keys_np(1, 0, NKEYS)
+    out = []
+    for r in range(world):
+        idx = rng.integers(0, NKEYS, size=BATCH)
+        out.append((keys[idx], rng.standard_normal((BATCH, DIM)).astype(np.float32),
+                    (rng.standard_normal((BATCH, DIM)) * 0.01).astype(np.float32)))
+    return out
+
+
+def _global_reference(world):
+    """One table, batches applied in rank order == SPEC §5 'ordered by source rank then batch position'."""
+    o = oracle.OracleTable(16384, DIM, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
+    b = _batches(world)
+    o.insert(np.concatenate([x[0] for x in b]), np.concatenate([x[1] for x in b]))
+    o.apply_adagrad(np.concatenate([x[0] for x in b]), np.concatenate([x[2] for x in b]), 0.05, 1e-10)
+    return o
+
+
+def _run_rank(rank, world, port, backend, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if backend == "gloo":
+        from _cpu_backend import CpuRouter, CpuTable
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = torch.device("cpu")
+        local = CpuTable(16384, DIM, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
+        router = CpuRouter(world)
+    else:
+        from meepoembedding_amd import OPT_ADAGRAD, LookupTable, Router
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        local = LookupTable(16384, DIM, device=dev, optimizer=OPT_ADAGRAD, initial_accumulator=0.1, max_batch=world * BATCH)
+        router = Router(world, BATCH, device=dev)
+    try:
+        sh = ShardedLookupTable(local, router)
+        keys, rows, grads = (torch.from_numpy(x).to(dev) for x in _batches(world)[rank])
+        sh.insert(keys, rows)
+        sh.apply_adagrad(keys, grads, lr=0.05, eps=1e-10)
+        probe = torch.from_numpy(np.concatenate([synth.keys_np(1, 0, NKEYS)[rank::3], synth.keys_np(9, rank * 50, 50)])).to(dev)
+        out, found = sh.find(probe)
+        total = sh.size()
+        ek, ev, ea, _ = sh.export_local(with_state=True)
+        q.put((rank, probe.cpu().numpy(), out.cpu().numpy(), found.cpu().numpy(), total, ek.cpu().numpy(), ev.cpu().numpy(), ea.cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _check(results, world):
+    o = _global_reference(world)
+    allk, allv, alla = [], [], []
+    for rank, probe, out, found, total, ek, ev, ea in results:
+        eo, ef = o.find(probe)
+        assert np.array_equal(found, ef)
+        np.testing.assert_allclose(out, eo, rtol=1e-6, atol=1e-9)
+        assert total == o.size()
+        assert (oracle.hash_batch(ek, 1, world)[2] == rank).all(), "shard holds a key it does not own"
+        allk.append(ek); allv.append(ev); alla.append(ea)
+    gk, gv, ga = np.concatenate(allk), np.concatenate(allv), np.concatenate(alla)
+    ok, ov, oa, _ = o.export(with_state=True)
+    a, b = np.argsort(gk), np.argsort(ok)
+    assert np.array_equal(gk[a], ok[b])
+    np.testing.assert_allclose(gv[a], ov[b], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(ga[a], oa[b], rtol=1e-6, atol=1e-9)
+
+
+def _launch(world, backend):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_rank, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(results, key=lambda x: x[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gloo_cpu(built, world):
+    _check(_launch(world, "gloo"), world)
+
+
+@pytest.mark.gpu
+def test_sharded_rccl_single_gpu(dev):
+    _check(_launch(1, "nccl"), 1)
