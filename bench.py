@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--load", type=float, default=0.75)
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even at N=1 (rehearsal of the N>1 code)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -126,14 +127,16 @@ def main():
 
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    if world > 1 or args.force_sharded:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     def log(msg):
         if args.verbose and rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    sharded = world > 1
+    sharded = world > 1 or args.force_sharded
     keys_per_gpu = args.keys or (125_000_000 if sharded else 100_000_000)
     batch = args.batch or ((1 << 20) if sharded else (1 << 18))
     n_keys = keys_per_gpu * world
