@@ -28,15 +28,32 @@ char* last_error_buf() {
 }
 
 struct Counters {            // device-resident, persistent
-    unsigned long long size; // stored keys
     uint32_t status;         // sticky MEE_STATUS_* bits
-    uint32_t pad;
+    uint32_t pad[3];
 };
 struct OpCounters {          // device-resident, zeroed at the start of each op that uses them
-    uint32_t n_uniq;
-    uint32_t n_occ;
-    unsigned long long n_export;
+    uint32_t n_uniq;         // distinct keys appended to the unique list
+    uint32_t n_occ;          // occurrence-list entries reserved
+    uint32_t n_big;          // groups with more than kChunk occurrences
+    uint32_t n_work;         // chunk leaders listed for apply_chunk_kernel
+    unsigned long long n_export;  // pairs exported / keys counted
 };
+struct GroupTable {            // S entries, indexed by h
+    unsigned long long* skeys; // key ^ kBias, 0 = empty
+    uint32_t* sval;            // COUNT: occurrences added by blocks other than the claimer's | LAST: 1 + highest position
+    uint32_t* sval0;           // COUNT: occurrences inside the block whose CAS claimed the entry (plain store, no atomic)
+    uint32_t* soffs;           // start of the group's slice of the occurrence list
+    uint32_t* sbig;            // fp64 accumulator row of a group with more than kChunk occurrences
+    uint32_t* sgrp;            // index of the group in the unique list (standalone dedup)
+    long long* sres;           // find_or_insert: slot | present<<62, -1 = not stored
+    uint64_t smask;
+};
+struct BatchScratch {          // max_batch entries, indexed by batch position unless noted
+    uint32_t *hidx, *rank, *pcnt, *occ, *uniq_h, *work;
+    uint32_t* bigh;            // [max_big] group-table index of each big group
+    double* gacc;              // [max_big][dim] fp64 accumulator rows, all-zero between ops
+};
+
 
 }  // namespace mee
 
@@ -49,15 +66,10 @@ struct mee_table {
     // table planes
     int64_t* keys;
     float *values, *s1, *s2;
-    // group table (scratch), S entries
-    uint64_t S, smask;
-    unsigned long long* skeys;  // key ^ kBias, 0 = empty
-    uint32_t* sval;             // occurrence count | winner index+1
-    uint32_t* soffs;            // start of the group's occurrence list
-    uint32_t* sgrp;             // index of the group in the unique list
-    long long* sres;            // find_or_insert: slot | present<<62, -1 = not stored
-    // per batch position
-    uint32_t *hidx, *rank, *occ, *uniq_h;
+    // per-batch scratch: group table (S entries) and per-position arrays (max_batch entries)
+    uint64_t S, max_big;
+    mee::GroupTable g;
+    mee::BatchScratch bs;
     mee::Counters* ctr;
     mee::OpCounters* op;
     mee::Counters* h_ctr;       // pinned staging for read-backs
@@ -168,95 +180,143 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
 }
 
 // ---- group table: one entry per distinct key of the batch ---------------------------------------------------
-__device__ __forceinline__ uint32_t group_claim(unsigned long long* skeys, uint64_t smask, int64_t key) {
+__device__ __forceinline__ uint32_t group_claim(const GroupTable& g, int64_t key, bool& claimed) {
     const unsigned long long bk = (unsigned long long)key ^ kBias;  // != 0 because key != kEmpty
-    uint32_t h = (uint32_t)(mix64b((uint64_t)key) & smask);
+    uint32_t h = (uint32_t)(mix64b((uint64_t)key) & g.smask);
     while (true) {
-        unsigned long long cur = __hip_atomic_load(&skeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == 0) cur = atomicCAS(&skeys[h], 0ull, bk);
+        unsigned long long cur = __hip_atomic_load(&g.skeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        claimed = false;
+        if (cur == 0) { cur = atomicCAS(&g.skeys[h], 0ull, bk); claimed = cur == 0; }
         if (cur == 0 || cur == bk) return h;
-        h = (h + 1) & (uint32_t)smask;
+        h = (h + 1) & (uint32_t)g.smask;
     }
 }
 
-// COUNT: sval = occurrence count, rank[i] = arrival order inside the group, leaders append to the unique list.
-// !COUNT: sval = 1 + highest batch position (last occurrence wins).
-template <bool COUNT>
-__global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ keys, uint32_t n,
-                                                    unsigned long long* skeys, uint64_t smask, uint32_t* sval,
-                                                    uint32_t* sgrp, uint32_t* hidx, uint32_t* rank, uint32_t* uniq_h,
-                                                    Counters* ctr, OpCounters* op) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+constexpr int kGroupLast = 0;   // sval = 1 + highest batch position of the key (last occurrence wins)
+constexpr int kGroupCount = 1;  // sval0 + sval = occurrence count, rank[i] = arrival order (finalised by the plan pass)
+constexpr uint32_t kRankRemote = 0x80000000u;  // rank was handed out by an atomic on sval: add sval0 to finalise
+constexpr int kLds = 512;       // block-local aggregation table (256 threads -> at most 256 distinct keys)
+
+// One lane per batch position.  Occurrences of the same key inside a 256-thread block are first combined in an
+// LDS hash table keyed by the key itself; ONE lane per (block, key) then talks to the global group table.  A hot key
+// that is 8 % of the batch costs ~n/256 global accesses instead of 0.08 n serialised on one L2 line, and the block
+// whose CAS claimed the entry needs no counting atomic at all.
+template <int MODE>
+__global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ keys, uint32_t n, GroupTable g, BatchScratch bs,
+                                                    Counters* ctr) {
+    __shared__ unsigned long long lkey[kLds];
+    __shared__ uint32_t lval[kLds], lh[kLds], lbase[kLds];
+    for (int j = threadIdx.x; j < kLds; j += 256) { lkey[j] = 0; lval[j] = 0; }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool inb = i < n;
     const int64_t key = inb ? keys[i] : 0;
     const bool valid = inb && !reserved_key(key);
-    uint32_t h = kNoGroup;
-    bool leader = false;
+    uint32_t slot = 0, r_local = 0;
+    bool inserter = false;
     if (valid) {
-        h = group_claim(skeys, smask, key);
-        if constexpr (COUNT) {
-            const uint32_t r = atomicAdd(&sval[h], 1u);
-            rank[i] = r;
-            leader = r == 0;
+        const unsigned long long bk = (unsigned long long)key ^ kBias;
+        slot = (uint32_t)(mix64((uint64_t)key) >> 55);  // 9 bits
+        while (true) {
+            const unsigned long long old = atomicCAS(&lkey[slot], 0ull, bk);
+            if (old == 0) { inserter = true; break; }
+            if (old == bk) break;
+            slot = (slot + 1) & (kLds - 1);
+        }
+        if (MODE == kGroupCount) r_local = atomicAdd(&lval[slot], 1u);
+        else atomicMax(&lval[slot], i + 1);
+    }
+    __syncthreads();
+    if (inserter) {
+        bool claimed;
+        const uint32_t h = group_claim(g, key, claimed);
+        lh[slot] = h;
+        if constexpr (MODE == kGroupCount) {
+            const uint32_t total = lval[slot];
+            if (claimed) { g.sval0[h] = total; lbase[slot] = 0; }
+            else lbase[slot] = atomicAdd(&g.sval[h], total) | kRankRemote;
         } else {
-            atomicMax(&sval[h], i + 1);
+            atomicMax(&g.sval[h], lval[slot]);
         }
     }
+    __syncthreads();
     if (inb) {
-        hidx[i] = h;
+        bs.hidx[i] = valid ? lh[slot] : kNoGroup;
+        if (MODE == kGroupCount && valid) bs.rank[i] = lbase[slot] + r_local;
         if (!valid) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);
-    }
-    if constexpr (COUNT) {
-        const uint64_t lm = __ballot(leader);
-        if (lm) {  // wave-uniform
-            const int first = __ffsll((unsigned long long)lm) - 1;
-            uint32_t basev = 0;
-            if (lane == first) basev = atomicAdd(&op->n_uniq, (uint32_t)__popcll(lm));
-            basev = __shfl(basev, first);
-            if (leader) {
-                const uint32_t u = basev + (uint32_t)__popcll(lm & ((1ull << lane) - 1));
-                uniq_h[u] = h;
-                sgrp[h] = u;
-            }
-        }
     }
 }
 
-// Allocate each group's slice of the occurrence list: wave prefix-sum + one atomic per wave.
-// ALL = every group gets a slice (standalone dedup); otherwise only groups with ≥2 occurrences.
-template <bool ALL>
-__global__ __launch_bounds__(256) void group_offsets_kernel(const uint32_t* __restrict__ uniq_h,
-                                                            const uint32_t* __restrict__ sval, uint32_t* soffs,
-                                                            OpCounters* op) {
-    const uint32_t nu = op->n_uniq;
-    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    if (blockIdx.x * blockDim.x >= nu) return;  // block-uniform
-    const uint32_t h = u < nu ? uniq_h[u] : 0;
-    const uint32_t c = u < nu ? sval[h] : 0;
-    const uint32_t need = (ALL || c > 1) ? c : 0;
-    uint32_t incl = need;
+// exclusive prefix sum of v over a 1024-thread block (wave shuffles + LDS); returns the block total in `total`
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum /*[16]*/, uint32_t& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t t = __shfl_up(incl, d);
         if (lane >= d) incl += t;
     }
-    const uint32_t total = __shfl(incl, 63);
-    uint32_t basev = 0;
-    if (total) {
-        if (lane == 63) basev = atomicAdd(&op->n_occ, total);
-        basev = __shfl(basev, 63);
-    }
-    if (u < nu && need) soffs[h] = basev + incl - need;
+    __syncthreads();  // wsum may still be read from the previous call
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int ww = 0; ww < 16; ++ww) { const uint32_t x = wsum[ww]; if (ww < w) pre += x; tot += x; }
+    total = tot;
+    return pre + incl - v;
 }
 
-__global__ __launch_bounds__(256) void group_reset_kernel(const uint32_t* __restrict__ hidx, uint32_t n,
-                                                          unsigned long long* skeys, uint32_t* sval) {
+constexpr uint32_t kChunk = 32;  // occurrences summed by one tile
+
+// Plan pass, one lane per batch position: finalise rank and count, then (leaders only) reserve the group's slice of
+// the occurrence list, list the chunk leaders as work items, give big groups an fp64 accumulator row, and — for the
+// standalone dedup (ALL) — append the group to the unique list.  Every reservation is a block-wide prefix sum plus
+// ONE atomic per 1024-thread block.
+template <bool ALL>
+__global__ __launch_bounds__(1024) void group_plan_kernel(uint32_t n, GroupTable g, BatchScratch bs, OpCounters* op) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t base_occ, base_uniq, base_work;
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t h = i < n ? bs.hidx[i] : kNoGroup;
+    const bool valid = h != kNoGroup;
+    uint32_t cnt = 0, r = 0;
+    if (valid) {
+        const uint32_t c0 = g.sval0[h], rk = bs.rank[i];
+        cnt = c0 + g.sval[h];
+        r = (rk & ~kRankRemote) + ((rk & kRankRemote) ? c0 : 0);
+        bs.rank[i] = r;
+    }
+    if (i < n) bs.pcnt[i] = cnt;
+    const bool leader = valid && r == 0;
+    const uint32_t need = (leader && (ALL || cnt > 1)) ? cnt : 0;
+    uint32_t tot_occ, tot_b;
+    const uint32_t ex_occ = block_scan_1024(need, wsum, tot_occ);
+    const bool flag_b = ALL ? leader : (valid && cnt > 1 && (r % kChunk) == 0);  // unique-list entry | chunk leader
+    const uint32_t ex_b = block_scan_1024(flag_b ? 1u : 0u, wsum, tot_b);
+    if (threadIdx.x == 0) {
+        base_occ = tot_occ ? atomicAdd(&op->n_occ, tot_occ) : 0;
+        if (ALL) base_uniq = tot_b ? atomicAdd(&op->n_uniq, tot_b) : 0;
+        else base_work = tot_b ? atomicAdd(&op->n_work, tot_b) : 0;
+    }
+    __syncthreads();
+    if (need) g.soffs[h] = base_occ + ex_occ;
+    if (ALL) {
+        if (leader) { const uint32_t u = base_uniq + ex_b; bs.uniq_h[u] = h; g.sgrp[h] = u; }
+    } else {
+        if (flag_b) bs.work[base_work + ex_b] = i;
+        if (leader && cnt > kChunk) {  // rare: at most n / kChunk groups per batch
+            const uint32_t b = atomicAdd(&op->n_big, 1u);
+            g.sbig[h] = b;
+            bs.bigh[b] = h;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void group_reset_kernel(const uint32_t* __restrict__ hidx, uint32_t n, GroupTable g) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t h = hidx[i];
-    if (h != kNoGroup) { skeys[h] = 0; sval[h] = 0; }
+    if (h != kNoGroup) { g.skeys[h] = 0; g.sval[h] = 0; }
 }
 
 // ---- insert / assign (SPEC.md §3) --------------------------------------------------------------------------
@@ -295,9 +355,7 @@ __global__ __launch_bounds__(256) void upsert_kernel(int64_t* tkeys, float4* val
         }
         if (!CLAIM && found && inb && tl == 0) found[i] = slot >= 0;
         if constexpr (CLAIM) {
-            const uint64_t nm = __ballot(is_new && tl == 0);
             const uint64_t fm = __ballot(full);
-            if (lane == 0 && nm) atomicAdd(&ctr->size, (unsigned long long)__popcll(nm));
             if (lane == 0 && fm) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_TABLE_FULL);
         }
     }
@@ -334,9 +392,7 @@ __global__ __launch_bounds__(256) void ensure_kernel(int64_t* tkeys, float4* val
             }
         }
         if (winner && tl == 0) sres[h] = slot < 0 ? -1ll : ((long long)slot | (is_new ? 0ll : kPresentBit));
-        const uint64_t nm = __ballot(is_new && tl == 0);
         const uint64_t fm = __ballot(full);
-        if (lane == 0 && nm) atomicAdd(&ctr->size, (unsigned long long)__popcll(nm));
         if (lane == 0 && fm) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_TABLE_FULL);
     }
 }
@@ -379,16 +435,23 @@ __device__ __forceinline__ void opt_update4(const OptArgs& a, float4& w, float4&
     }
 }
 
+__device__ __forceinline__ void update_row(const OptArgs& a, float4* values, float4* s1, float4* s2, uint64_t o, const float4 g) {
+    float4 w = values[o], x1 = s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.kind == MEE_OPT_ADAM) x2 = s2[o];
+    opt_update4(a, w, x1, x2, g);
+    values[o] = w; s1[o] = x1;
+    if (a.kind == MEE_OPT_ADAM) s2[o] = x2;
+}
+__device__ __forceinline__ void group_release(const GroupTable& g, uint32_t h) { g.skeys[h] = 0; g.sval[h] = 0; g.sval0[h] = 0; }
+
 // Pass 1 over batch positions: a key that occurs once is updated right here from its own grad row (the common
-// case); occurrences of multi-keys are filed into their group's occurrence list for pass 2.
+// case) and its group-table entry is returned to empty; occurrences of multi-keys are filed into their group's
+// occurrence list for pass 2.
 __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1,
                                                            float4* s2, uint64_t nb, uint32_t dim4,
                                                            const int64_t* __restrict__ keys,
-                                                           const float4* __restrict__ grads, uint32_t n,
-                                                           const uint32_t* __restrict__ hidx,
-                                                           const uint32_t* __restrict__ rank,
-                                                           const uint32_t* __restrict__ sval,
-                                                           const uint32_t* __restrict__ soffs, uint32_t* occ, OptArgs a) {
+                                                           const float4* __restrict__ grads, uint32_t n, GroupTable g,
+                                                           BatchScratch bs, OptArgs a) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
@@ -396,85 +459,122 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
         const uint32_t i = base + tile;
         const bool inb = i < n;
         const int64_t key = inb ? keys[i] : kEmpty;
-        const uint32_t h = inb ? hidx[i] : kNoGroup;
-        const uint32_t cnt = h != kNoGroup ? sval[h] : 0;
+        const uint32_t cnt = inb ? bs.pcnt[i] : 0;
         bool is_new, full;
         const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, cnt == 1, tile, tl, is_new, full);
-        if (cnt == 1 && slot >= 0) {
-            for (uint32_t c = tl; c < dim4; c += 16) {
-                const uint64_t o = (uint64_t)slot * dim4 + c;
-                const float4 g = grads[(uint64_t)i * dim4 + c];
-                float4 w = values[o], x1 = s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.kind == MEE_OPT_ADAM) x2 = s2[o];
-                opt_update4(a, w, x1, x2, g);
-                values[o] = w; s1[o] = x1;
-                if (a.kind == MEE_OPT_ADAM) s2[o] = x2;
-            }
+        if (cnt == 1) {
+            if (slot >= 0)
+                for (uint32_t c = tl; c < dim4; c += 16) update_row(a, values, s1, s2, (uint64_t)slot * dim4 + c, grads[(uint64_t)i * dim4 + c]);
+            if (tl == 0) group_release(g, bs.hidx[i]);  // this tile is the only user of the entry
         } else if (cnt > 1 && tl == 0) {
-            occ[soffs[h] + rank[i]] = i;
+            bs.occ[g.soffs[bs.hidx[i]] + bs.rank[i]] = i;
         }
     }
 }
 
-// Pass 2 over distinct keys: sum the occurrence list of each multi-key in fp64, round once, update once.
-// Also returns every group-table entry to the empty state (the table must be clean for the next op).
-__global__ __launch_bounds__(256) void apply_multi_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1,
+// fp64 sum of `count` rows of an occurrence list, up to 8 rows in flight per lane.  All 16 lanes of the tile call it
+// with the same arguments (c differs per lane).
+__device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, const uint32_t* __restrict__ occ, uint32_t first,
+                                          uint32_t count, uint32_t dim4, uint32_t c, double& sx, double& sy, double& sz,
+                                          double& sw) {
+    uint32_t o = 0;
+    for (; o + 8 <= count; o += 8) {
+        uint32_t idx[8];
+        float4 gq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) idx[q] = occ[first + o + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gq[q] = grads[(uint64_t)idx[q] * dim4 + c];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { sx += (double)gq[q].x; sy += (double)gq[q].y; sz += (double)gq[q].z; sw += (double)gq[q].w; }
+    }
+    for (; o < count; ++o) {
+        const float4 gg = grads[(uint64_t)occ[first + o] * dim4 + c];
+        sx += (double)gg.x; sy += (double)gg.y; sz += (double)gg.z; sw += (double)gg.w;
+    }
+}
+
+// Pass 2 over the work list (chunk leaders: the occurrences with rank 0, kChunk, 2*kChunk, ... of each multi-key).
+// A tile sums its chunk of the group's occurrence list in fp64.  Groups of <= kChunk occurrences are finished here
+// (one update, entry released); larger groups add their chunk sums into the group's fp64 accumulator row with f64
+// atomics (order-insensitive to <= 1 fp32 ulp, SPEC.md §4) and are finished by apply_big_kernel.
+__global__ __launch_bounds__(256) void apply_chunk_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1,
                                                           float4* s2, uint64_t nb, uint32_t dim4,
-                                                          const float4* __restrict__ grads,
-                                                          const uint32_t* __restrict__ uniq_h, unsigned long long* skeys,
-                                                          uint32_t* sval, const uint32_t* __restrict__ soffs,
-                                                          const uint32_t* __restrict__ occ, const OpCounters* op, OptArgs a) {
+                                                          const int64_t* __restrict__ keys,
+                                                          const float4* __restrict__ grads, GroupTable g, BatchScratch bs,
+                                                          const OpCounters* op, OptArgs a) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t nu = op->n_uniq;
-    for (uint32_t base = wave * 4; base < nu; base += n_waves * 4) {
-        const uint32_t u = base + tile;
-        const bool inb = u < nu;
-        const uint32_t h = inb ? uniq_h[u] : 0;
-        const uint32_t cnt = inb ? sval[h] : 0;
-        const int64_t key = inb ? (int64_t)(skeys[h] ^ kBias) : kEmpty;
+    const uint32_t n_work = op->n_work;
+    for (uint32_t base = wave * 4; base < n_work; base += n_waves * 4) {
+        const uint32_t w = base + tile;
+        const bool inb = w < n_work;
+        const uint32_t i = inb ? bs.work[w] : 0;
+        const uint32_t cnt = inb ? bs.pcnt[i] : 0;
+        const uint32_t r = inb ? bs.rank[i] : 0;
+        const bool small = inb && cnt <= kChunk;  // then r == 0
+        const int64_t key = small ? keys[i] : kEmpty;
         bool is_new, full;
-        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, cnt > 1, tile, tl, is_new, full);
-        if (cnt > 1 && slot >= 0) {
-            const uint32_t off = soffs[h];
-            for (uint32_t c = tl; c < dim4; c += 16) {
-                double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-                for (uint32_t o = 0; o < cnt; ++o) {
-                    const float4 g = grads[(uint64_t)occ[off + o] * dim4 + c];
-                    sx += (double)g.x; sy += (double)g.y; sz += (double)g.z; sw += (double)g.w;
-                }
-                const float4 g = make_float4((float)sx, (float)sy, (float)sz, (float)sw);
-                const uint64_t oo = (uint64_t)slot * dim4 + c;
-                float4 w = values[oo], x1 = s1[oo], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.kind == MEE_OPT_ADAM) x2 = s2[oo];
-                opt_update4(a, w, x1, x2, g);
-                values[oo] = w; s1[oo] = x1;
-                if (a.kind == MEE_OPT_ADAM) s2[oo] = x2;
+        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, small, tile, tl, is_new, full);
+        if (!inb) continue;
+        const uint32_t h = bs.hidx[i];
+        const uint32_t first = g.soffs[h] + r;
+        const uint32_t count = min(kChunk, cnt - r);
+        const uint32_t big = small ? 0 : g.sbig[h];
+        for (uint32_t c = tl; c < dim4; c += 16) {
+            double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+            chunk_sum(grads, bs.occ, first, count, dim4, c, sx, sy, sz, sw);
+            if (small) {
+                if (slot >= 0) update_row(a, values, s1, s2, (uint64_t)slot * dim4 + c, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
+            } else {
+                double* dst = bs.gacc + ((uint64_t)big * dim4 + c) * 4;
+                atomicAdd(dst + 0, sx); atomicAdd(dst + 1, sy); atomicAdd(dst + 2, sz); atomicAdd(dst + 3, sw);
             }
         }
-        if (inb && tl == 0) { skeys[h] = 0; sval[h] = 0; }
+        if (small && tl == 0) group_release(g, h);
+    }
+}
+
+// Pass 3 over the (few) groups with more than kChunk occurrences: read the accumulated fp64 sums, round once,
+// update once, zero the accumulator row and release the group-table entry.
+__global__ __launch_bounds__(256) void apply_big_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1,
+                                                        float4* s2, uint64_t nb, uint32_t dim4, GroupTable g, BatchScratch bs,
+                                                        const OpCounters* op, OptArgs a) {
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t n_big = op->n_big;
+    for (uint32_t base = wave * 4; base < n_big; base += n_waves * 4) {
+        const uint32_t b = base + tile;
+        const bool inb = b < n_big;
+        const uint32_t h = inb ? bs.bigh[b] : 0;
+        const int64_t key = inb ? (int64_t)(g.skeys[h] ^ kBias) : kEmpty;
+        bool is_new, full;
+        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, inb, tile, tl, is_new, full);
+        if (!inb) continue;
+        for (uint32_t c = tl; c < dim4; c += 16) {
+            double* src = bs.gacc + ((uint64_t)b * dim4 + c) * 4;
+            const float4 gs = make_float4((float)src[0], (float)src[1], (float)src[2], (float)src[3]);
+            src[0] = 0.0; src[1] = 0.0; src[2] = 0.0; src[3] = 0.0;
+            if (slot >= 0) update_row(a, values, s1, s2, (uint64_t)slot * dim4 + c, gs);
+        }
+        if (tl == 0) group_release(g, h);
     }
 }
 
 // ---- standalone duplicate-key reduction (SPEC.md §4) -------------------------------------------------------
-__global__ __launch_bounds__(256) void dedup_fill_kernel(uint32_t n, const uint32_t* __restrict__ hidx,
-                                                         const uint32_t* __restrict__ rank,
-                                                         const uint32_t* __restrict__ soffs,
-                                                         const uint32_t* __restrict__ sgrp, uint32_t* occ,
-                                                         int64_t* inverse) {
+__global__ __launch_bounds__(256) void dedup_fill_kernel(uint32_t n, GroupTable g, BatchScratch bs, int64_t* inverse) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t h = hidx[i];
-    if (h != kNoGroup) occ[soffs[h] + rank[i]] = i;
-    if (inverse) inverse[i] = h != kNoGroup ? (int64_t)sgrp[h] : -1;
+    const uint32_t h = bs.hidx[i];
+    if (h != kNoGroup) bs.occ[g.soffs[h] + bs.rank[i]] = i;
+    if (inverse) inverse[i] = h != kNoGroup ? (int64_t)g.sgrp[h] : -1;
 }
 
-__global__ __launch_bounds__(256) void dedup_emit_kernel(uint32_t dim4, const float4* __restrict__ grads,
-                                                         const uint32_t* __restrict__ uniq_h, unsigned long long* skeys,
-                                                         uint32_t* sval, const uint32_t* __restrict__ soffs,
-                                                         const uint32_t* __restrict__ occ, const OpCounters* op,
-                                                         int64_t* uniq_out, float4* gsum_out, uint32_t* counts_out) {
+__global__ __launch_bounds__(256) void dedup_emit_kernel(uint32_t dim4, const float4* __restrict__ grads, GroupTable g,
+                                                         BatchScratch bs, const OpCounters* op, int64_t* uniq_out,
+                                                         float4* gsum_out, uint32_t* counts_out) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
@@ -482,30 +582,46 @@ __global__ __launch_bounds__(256) void dedup_emit_kernel(uint32_t dim4, const fl
     for (uint32_t base = wave * 4; base < nu; base += n_waves * 4) {
         const uint32_t u = base + tile;
         if (u >= nu) continue;
-        const uint32_t h = uniq_h[u];
-        const uint32_t cnt = sval[h];
-        const uint32_t off = soffs[h];
+        const uint32_t h = bs.uniq_h[u];
+        const uint32_t cnt = g.sval0[h] + g.sval[h];
+        const uint32_t off = g.soffs[h];
         if (grads && gsum_out) {
             for (uint32_t c = tl; c < dim4; c += 16) {
                 double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-                for (uint32_t o = 0; o < cnt; ++o) {
-                    const float4 g = grads[(uint64_t)occ[off + o] * dim4 + c];
-                    sx += (double)g.x; sy += (double)g.y; sz += (double)g.z; sw += (double)g.w;
-                }
+                chunk_sum(grads, bs.occ, off, cnt, dim4, c, sx, sy, sz, sw);
                 gsum_out[(uint64_t)u * dim4 + c] = make_float4((float)sx, (float)sy, (float)sz, (float)sw);
             }
         }
         if (tl == 0) {
-            if (uniq_out) uniq_out[u] = (int64_t)(skeys[h] ^ kBias);
+            if (uniq_out) uniq_out[u] = (int64_t)(g.skeys[h] ^ kBias);
             if (counts_out) counts_out[u] = cnt;
-            skeys[h] = 0; sval[h] = 0;
+            group_release(g, h);
         }
     }
 }
 
+// ---- size (SPEC.md §3): count stored keys by scanning the key plane (keeps every atomic off the insert path) ----
+__global__ __launch_bounds__(256) void count_kernel(const int64_t* __restrict__ tkeys, uint64_t capacity, OpCounters* op) {
+    __shared__ uint32_t wsum[4];
+    uint32_t c = 0;
+    for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < capacity; s += (uint64_t)gridDim.x * blockDim.x)
+        c += !reserved_key(tkeys[s]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (tot) atomicAdd(&op->n_export, (unsigned long long)tot);
+    }
+}
+
 // ---- export (SPEC.md §3) -----------------------------------------------------------------------------------
-// A wave inspects 64 consecutive slots, compacts the occupied ones with ballot + popcount and reserves its
-// output range with one atomic; rows are then copied four at a time (one per tile).
+// A wave owns a chunk of 1024 consecutive slots.  Pass A: 16 coalesced key loads, ballot + popcount -> occupied
+// count, ONE atomic reserves the chunk's output range.  Pass B: per 64-slot group, ranks from the ballot mask;
+// keys are written by their own lane, rows are copied four at a time (one per 16-lane tile).
+constexpr int kExportGroups = 16;
+
 __global__ __launch_bounds__(256) void export_kernel(const int64_t* __restrict__ tkeys, const float4* __restrict__ values,
                                                      const float4* __restrict__ s1, const float4* __restrict__ s2,
                                                      uint64_t capacity, uint32_t dim4, int64_t* keys_out, float4* values_out,
@@ -513,38 +629,50 @@ __global__ __launch_bounds__(256) void export_kernel(const int64_t* __restrict__
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    for (uint64_t s0 = wave * 64; s0 < capacity; s0 += n_waves * 64) {
-        const uint64_t s = s0 + lane;
-        const int64_t k = s < capacity ? tkeys[s] : kEmpty;
-        const uint64_t m = __ballot(!reserved_key(k));
-        if (!m) continue;  // wave-uniform
-        unsigned long long basev = 0;
-        if (lane == 0) basev = atomicAdd(&op->n_export, (unsigned long long)__popcll(m));
-        basev = __shfl(basev, 0);
-        if (!reserved_key(k)) {
-            const uint64_t pos = basev + (uint64_t)__popcll(m & ((1ull << lane) - 1));
-            if (keys_out && pos < cap) keys_out[pos] = k;
-        }
-        uint64_t rest = m;
-        uint64_t done = 0;
-        while (rest) {  // wave-uniform
-            uint64_t mm = rest;
-            int p = -1;
-            for (int q = 0; q <= tile; ++q) {
-                if (mm) { p = __ffsll((unsigned long long)mm) - 1; mm &= mm - 1; } else p = -1;
-            }
-            const uint64_t pos = basev + done + tile;
-            if (p >= 0 && pos < cap) {
-                const uint64_t src = (s0 + p) * dim4, dst = pos * dim4;
-                for (uint32_t c = tl; c < dim4; c += 16) {
-                    if (values_out) values_out[dst + c] = values[src + c];
-                    if (s1_out) s1_out[dst + c] = s1[src + c];
-                    if (s2_out) s2_out[dst + c] = s2[src + c];
-                }
-            }
+    constexpr uint64_t kSpan = 64ull * kExportGroups;
+    for (uint64_t c0 = wave * kSpan; c0 < capacity; c0 += n_waves * kSpan) {
+        int64_t k[kExportGroups];
+        uint64_t m[kExportGroups];
+        uint32_t total = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rest &= rest - 1;  // x & (x-1) of 0 stays 0
-            done += 4;
+        for (int j = 0; j < kExportGroups; ++j) {
+            const uint64_t s = c0 + (uint64_t)j * 64 + lane;
+            k[j] = s < capacity ? tkeys[s] : kEmpty;
+            m[j] = __ballot(!reserved_key(k[j]));
+            total += (uint32_t)__popcll(m[j]);
+        }
+        if (!total) continue;  // wave-uniform
+        unsigned long long pos0 = 0;
+        if (lane == 0) pos0 = atomicAdd(&op->n_export, (unsigned long long)total);
+        pos0 = __shfl(pos0, 0);
+#pragma unroll
+        for (int j = 0; j < kExportGroups; ++j) {
+            if (!reserved_key(k[j])) {
+                const uint64_t pos = pos0 + (uint64_t)__popcll(m[j] & ((1ull << lane) - 1));
+                if (keys_out && pos < cap) keys_out[pos] = k[j];
+            }
+            uint64_t rest = m[j];
+            uint64_t done = 0;
+            while (rest) {  // wave-uniform
+                uint64_t mm = rest;
+                int p = -1;
+                for (int q = 0; q <= tile; ++q) {
+                    if (mm) { p = __ffsll((unsigned long long)mm) - 1; mm &= mm - 1; } else p = -1;
+                }
+                const uint64_t pos = pos0 + done + tile;
+                if (p >= 0 && pos < cap) {
+                    const uint64_t src = (c0 + (uint64_t)j * 64 + p) * dim4, dst = pos * dim4;
+                    for (uint32_t c = tl; c < dim4; c += 16) {
+                        if (values_out) values_out[dst + c] = values[src + c];
+                        if (s1_out) s1_out[dst + c] = s1[src + c];
+                        if (s2_out) s2_out[dst + c] = s2[src + c];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rest &= rest - 1;  // x & (x-1) of 0 stays 0
+                done += 4;
+            }
+            pos0 += (uint64_t)__popcll(m[j]);
         }
     }
 }
@@ -573,8 +701,8 @@ int mee_table_destroy(mee_table* t) {
     if (!t) return MEE_OK;
     DeviceGuard g(t->device);
     (void)hipDeviceSynchronize();
-    void* dev[] = {t->keys, t->values, t->s1, t->s2, t->skeys, t->sval, t->soffs, t->sgrp, t->sres,
-                   t->hidx, t->rank, t->occ, t->uniq_h, t->ctr, t->op};
+    void* dev[] = {t->keys, t->values, t->s1, t->s2, t->g.skeys, t->g.sval, t->g.sval0, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
+                   t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.work, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (t->h_ctr) (void)hipHostFree(t->h_ctr);
     if (t->h_op) (void)hipHostFree(t->h_op);
@@ -619,7 +747,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     t->init_scale = cfg->init_scale; t->init_seed = cfg->init_seed;
     uint64_t S = 1024;
     while (S < 2 * cfg->max_batch) S <<= 1;
-    t->S = S; t->smask = S - 1;
+    t->S = S; t->g.smask = S - 1;
     t->find_rounds = 2;
     t->find_grid_cap = 0;
     t->find_nt = 1;
@@ -640,11 +768,17 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     t->table_bytes = t->capacity * sizeof(int64_t) + plane;
     if (t->optimizer != MEE_OPT_NONE) { ALLOC(t->s1, plane); t->table_bytes += plane; }
     if (t->optimizer == MEE_OPT_ADAM) { ALLOC(t->s2, plane); t->table_bytes += plane; }
-    ALLOC(t->skeys, S * 8); ALLOC(t->sval, S * 4); ALLOC(t->soffs, S * 4); ALLOC(t->sgrp, S * 4); ALLOC(t->sres, S * 8);
-    ALLOC(t->hidx, mb * 4); ALLOC(t->rank, mb * 4); ALLOC(t->occ, mb * 4); ALLOC(t->uniq_h, mb * 4);
+    ALLOC(t->g.skeys, S * 8); ALLOC(t->g.sval, S * 4); ALLOC(t->g.sval0, S * 4); ALLOC(t->g.soffs, S * 4); ALLOC(t->g.sgrp, S * 4);
+    ALLOC(t->g.sbig, S * 4); ALLOC(t->g.sres, S * 8);
+    ALLOC(t->bs.hidx, mb * 4); ALLOC(t->bs.rank, mb * 4); ALLOC(t->bs.pcnt, mb * 4); ALLOC(t->bs.occ, mb * 4); ALLOC(t->bs.uniq_h, mb * 4);
+    ALLOC(t->bs.work, mb * 4);
+    t->max_big = mb / kChunk + 1;  // a batch of n keys has at most n / (kChunk + 1) groups larger than kChunk
+    ALLOC(t->bs.bigh, t->max_big * 4);
+    if (t->optimizer != MEE_OPT_NONE) ALLOC(t->bs.gacc, t->max_big * (uint64_t)t->dim * sizeof(double));
     ALLOC(t->ctr, sizeof(Counters)); ALLOC(t->op, sizeof(OpCounters));
 #undef ALLOC
-    t->workspace_bytes = S * 28 + mb * 16 + sizeof(Counters) + sizeof(OpCounters);
+    t->workspace_bytes = S * 36 + mb * 24 + t->max_big * 4 + (t->bs.gacc ? t->max_big * (uint64_t)t->dim * sizeof(double) : 0) +
+                         sizeof(Counters) + sizeof(OpCounters);
     if (hipHostMalloc((void**)&t->h_ctr, sizeof(Counters)) != hipSuccess || hipHostMalloc((void**)&t->h_op, sizeof(OpCounters)) != hipSuccess) {
         rc = fail(MEE_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
         goto bad;
@@ -653,8 +787,10 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
         hipError_t e = hipSuccess;
         fill_i64_kernel<<<2048, 256, 0, 0>>>(t->keys, t->capacity, kEmpty);
         if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemsetAsync(t->skeys, 0, S * 8, 0);
-        if (e == hipSuccess) e = hipMemsetAsync(t->sval, 0, S * 4, 0);
+        if (e == hipSuccess) e = hipMemsetAsync(t->g.skeys, 0, S * 8, 0);
+        if (e == hipSuccess) e = hipMemsetAsync(t->g.sval, 0, S * 4, 0);
+        if (e == hipSuccess) e = hipMemsetAsync(t->g.sval0, 0, S * 4, 0);
+        if (e == hipSuccess && t->bs.gacc) e = hipMemsetAsync(t->bs.gacc, 0, t->max_big * (uint64_t)t->dim * sizeof(double), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->ctr, 0, sizeof(Counters), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->op, 0, sizeof(OpCounters), 0);
         if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -689,7 +825,6 @@ int mee_clear(mee_table* t, void* stream) {
     DeviceGuard g(t->device);
     fill_i64_kernel<<<2048, 256, 0, as_stream(stream)>>>(t->keys, t->capacity, kEmpty);
     MEE_HIP(hipGetLastError());
-    MEE_HIP(hipMemsetAsync(&t->ctr->size, 0, sizeof(unsigned long long), as_stream(stream)));
     return MEE_OK;
 }
 
@@ -723,14 +858,14 @@ static int upsert_common(mee_table* t, const int64_t* d_keys, const float* d_val
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
-    group_kernel<false><<<gl, 256, 0, st>>>(d_keys, nn, t->skeys, t->smask, t->sval, t->sgrp, t->hidx, t->rank, t->uniq_h, t->ctr, t->op);
+    group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr);
     if (claim)
         upsert_kernel<true><<<gt, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
-                                                (const float4*)d_values, nn, t->hidx, t->sval, nullptr, t->optimizer, t->init_acc, t->ctr);
+                                                (const float4*)d_values, nn, t->bs.hidx, t->g.sval, nullptr, t->optimizer, t->init_acc, t->ctr);
     else
         upsert_kernel<false><<<gt, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
-                                                 (const float4*)d_values, nn, t->hidx, t->sval, d_found, t->optimizer, t->init_acc, t->ctr);
-    group_reset_kernel<<<gl, 256, 0, st>>>(t->hidx, nn, t->skeys, t->sval);
+                                                 (const float4*)d_values, nn, t->bs.hidx, t->g.sval, d_found, t->optimizer, t->init_acc, t->ctr);
+    group_reset_kernel<<<gl, 256, 0, st>>>(t->bs.hidx, nn, t->g);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
@@ -750,12 +885,12 @@ int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_o
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
-    group_kernel<false><<<gl, 256, 0, st>>>(d_keys, nn, t->skeys, t->smask, t->sval, t->sgrp, t->hidx, t->rank, t->uniq_h, t->ctr, t->op);
-    ensure_kernel<<<gt, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys, nn, t->hidx,
-                                      t->sval, t->sres, t->optimizer, t->init_acc, t->initializer, t->init_scale, t->init_seed,
+    group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr);
+    ensure_kernel<<<gt, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys, nn, t->bs.hidx,
+                                      t->g.sval, t->g.sres, t->optimizer, t->init_acc, t->initializer, t->init_scale, t->init_seed,
                                       t->default_value, t->ctr);
-    gather_group_kernel<<<gt, 256, 0, st>>>((const float4*)t->values, t->dim4, nn, t->hidx, t->sres, (float4*)d_out, d_found, t->default_value);
-    group_reset_kernel<<<gl, 256, 0, st>>>(t->hidx, nn, t->skeys, t->sval);
+    gather_group_kernel<<<gt, 256, 0, st>>>((const float4*)t->values, t->dim4, nn, t->bs.hidx, t->g.sres, (float4*)d_out, d_found, t->default_value);
+    group_reset_kernel<<<gl, 256, 0, st>>>(t->bs.hidx, nn, t->g);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
@@ -766,7 +901,7 @@ int mee_export(const mee_table* t, int64_t* d_keys_out, float* d_values_out, flo
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
     MEE_HIP(hipMemsetAsync(&t->op->n_export, 0, sizeof(unsigned long long), st));
-    export_kernel<<<grid_for(t->capacity, 256, 256 * 16), 256, 0, st>>>(
+    export_kernel<<<grid_for(t->capacity, 4 * 64 * kExportGroups, 256 * 16), 256, 0, st>>>(
         t->keys, (const float4*)t->values, (const float4*)t->s1, (const float4*)t->s2, t->capacity, t->dim4, d_keys_out,
         (float4*)d_values_out, t->s1 ? (float4*)d_state1_out : nullptr, t->s2 ? (float4*)d_state2_out : nullptr, cap, t->op);
     MEE_HIP(hipGetLastError());
@@ -784,8 +919,14 @@ static int read_counters(const mee_table* t, void* stream) {
 }
 int mee_size(const mee_table* t, size_t* n_out, void* stream) {
     if (!t || !n_out) return fail(MEE_ERR_INVALID_ARG, "mee_size: null argument");
-    if (int rc = read_counters(t, stream)) return rc;
-    *n_out = (size_t)t->h_ctr->size;
+    DeviceGuard g(t->device);
+    hipStream_t st = as_stream(stream);
+    MEE_HIP(hipMemsetAsync(&t->op->n_export, 0, sizeof(unsigned long long), st));
+    count_kernel<<<grid_for(t->capacity, 256 * 16, 2048), 256, 0, st>>>(t->keys, t->capacity, t->op);
+    MEE_HIP(hipGetLastError());
+    MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
+    MEE_HIP(hipStreamSynchronize(st));
+    *n_out = (size_t)t->h_op->n_export;
     return MEE_OK;
 }
 int mee_status(const mee_table* t, uint32_t* bits_out, void* stream) {
@@ -811,13 +952,17 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
-    MEE_HIP(hipMemsetAsync(t->op, 0, 8, st));  // n_uniq, n_occ
-    group_kernel<true><<<gl, 256, 0, st>>>(d_keys, nn, t->skeys, t->smask, t->sval, t->sgrp, t->hidx, t->rank, t->uniq_h, t->ctr, t->op);
-    group_offsets_kernel<false><<<gl, 256, 0, st>>>(t->uniq_h, t->sval, t->soffs, t->op);
+    const unsigned gp = grid_for(n, 1024, 1u << 22);
+    MEE_HIP(hipMemsetAsync(t->op, 0, 16, st));  // n_uniq, n_occ, n_big, n_work
+    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr);
+    group_plan_kernel<false><<<gp, 1024, 0, st>>>(nn, t->g, t->bs, t->op);
     apply_single_kernel<<<gt, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
-                                            (const float4*)d_grads, nn, t->hidx, t->rank, t->sval, t->soffs, t->occ, a);
-    apply_multi_kernel<<<gt, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
-                                           (const float4*)d_grads, t->uniq_h, t->skeys, t->sval, t->soffs, t->occ, t->op, a);
+                                            (const float4*)d_grads, nn, t->g, t->bs, a);
+    // the work list (chunk leaders) and the big-group list have device-side lengths: fixed grids that loop
+    apply_chunk_kernel<<<grid_for(n, 16, 2048), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
+                                                            d_keys, (const float4*)d_grads, t->g, t->bs, t->op, a);
+    apply_big_kernel<<<grid_for(n / kChunk + 1, 16, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,
+                                                                       t->dim4, t->g, t->bs, t->op, a);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
@@ -848,12 +993,11 @@ int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, siz
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
-    MEE_HIP(hipMemsetAsync(t->op, 0, 8, st));
-    group_kernel<true><<<gl, 256, 0, st>>>(d_keys, nn, t->skeys, t->smask, t->sval, t->sgrp, t->hidx, t->rank, t->uniq_h, t->ctr, t->op);
-    group_offsets_kernel<true><<<gl, 256, 0, st>>>(t->uniq_h, t->sval, t->soffs, t->op);
-    dedup_fill_kernel<<<gl, 256, 0, st>>>(nn, t->hidx, t->rank, t->soffs, t->sgrp, t->occ, d_inverse_out);
-    dedup_emit_kernel<<<gt, 256, 0, st>>>(t->dim4, (const float4*)d_grads, t->uniq_h, t->skeys, t->sval, t->soffs, t->occ, t->op,
-                                          d_uniq_out, (float4*)d_gsum_out, d_counts_out);
+    MEE_HIP(hipMemsetAsync(t->op, 0, 16, st));
+    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr);
+    group_plan_kernel<true><<<grid_for(n, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
+    dedup_fill_kernel<<<gl, 256, 0, st>>>(nn, t->g, t->bs, d_inverse_out);
+    dedup_emit_kernel<<<gt, 256, 0, st>>>(t->dim4, (const float4*)d_grads, t->g, t->bs, t->op, d_uniq_out, (float4*)d_gsum_out, d_counts_out);
     MEE_HIP(hipGetLastError());
     MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
     MEE_HIP(hipStreamSynchronize(st));

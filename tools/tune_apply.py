@@ -1,0 +1,49 @@
+"""GPU timing harness for the sparse-optimizer path (configs[2]): find + apply_adagrad/adam per step.
+usage: python tools/tune_apply.py [--keys N] [--batch B] [--opt adagrad|adam] [--dist uniform|zipf] [--launches L]"""
+import argparse, os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from meepoembedding_amd import LookupTable, OPT_ADAGRAD, OPT_ADAM, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--keys", type=int, default=100_000_000)
+ap.add_argument("--batch", type=int, default=1 << 18)
+ap.add_argument("--dim", type=int, default=64)
+ap.add_argument("--opt", default="adagrad")
+ap.add_argument("--dist", default="uniform")
+ap.add_argument("--launches", type=int, default=100)
+ap.add_argument("--rounds", type=int, default=3)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+kind = OPT_ADAGRAD if a.opt == "adagrad" else OPT_ADAM
+t = LookupTable(int(a.keys / 0.75), a.dim, device=dev, max_batch=1 << 20, optimizer=kind)
+bench.populate(t, synth, a.keys, a.dim, dev, 1 << 20)
+NB = 16
+batches = bench.lookup_batches(synth, a.keys, a.batch, NB, a.dist, dev, seed=3)
+uniq = [int(torch.unique(b).numel()) for b in batches]
+grads = [torch.randn(a.batch, a.dim, device=dev) * 0.01 for _ in range(4)]
+out = torch.empty((a.batch, a.dim), dtype=torch.float32, device=dev); found = torch.empty(a.batch, dtype=torch.uint8, device=dev)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+def apply(i):
+    if kind == OPT_ADAGRAD: t.apply_adagrad(batches[i % NB], grads[i % 4], lr=0.01, eps=1e-10)
+    else: t.apply_adam(batches[i % NB], grads[i % 4], lr=0.001, step=i + 1)
+
+def timeit(fn):
+    ts = []
+    for r in range(a.rounds):
+        for i in range(5): fn(i)
+        torch.cuda.synchronize(); e0.record()
+        for i in range(a.launches): fn(i)
+        e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3 / a.launches)
+    return statistics.median(ts)
+
+U = statistics.mean(uniq); B = a.batch
+per_u = 1032 if kind == OPT_ADAGRAD else 1544
+t_apply = timeit(apply)
+t_find = timeit(lambda i: t.find(batches[i % NB], out=out, found=found))
+t_step = timeit(lambda i: (t.find(batches[i % NB], out=out, found=found), apply(i)))
+ab = 264 * B + per_u * U
+print(f"{a.opt} {a.dist} batch {B} unique {U:.0f}: apply {t_apply:.1f} us ({ab / t_apply / 1e3:.0f} GB/s algorithmic = {ab / t_apply / 1e3 / 8000:.3f}), "
+      f"find {t_find:.1f} us, find+apply step {t_step:.1f} us -> {B / t_step / 1e3:.2f} Gkeys/s ({(528 * B + ab) / t_step / 1e3 / 8000:.3f} of roofline)")
