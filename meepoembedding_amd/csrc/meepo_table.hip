@@ -78,7 +78,9 @@ struct mee_table {
     // performance knobs (never change results): see mee_set_tuning()
     int find_rounds;            // keys in flight per tile in the find kernel: 1, 2, 4 or 8
     int find_grid_cap;          // max blocks of the find grid (0 = one pass, no grid-stride loop)
-    int find_nt;                // bit0: non-temporal row loads, bit1: non-temporal bucket loads
+    int find_nt;                // bit0: non-temporal row loads, bit1: non-temporal bucket loads, bit2: plain (cached) out stores;
+                                // -1 = auto: cached loads (hot rows of skewed streams stay in L2), cached stores while the
+                                // dense output fits the Infinity Cache (<= 128 MB), streaming stores beyond
 };
 
 namespace mee {
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
                 const uint64_t i = base + r * 4 + tile;
                 if (inb[r]) {
 #pragma unroll
-                    for (int c = 0; c < C; ++c) __builtin_nontemporal_store(row[r][c], &out[i * DIM4 + c * 16 + tl]);
+                    for (int c = 0; c < C; ++c) { if (NT & 4) out[i * DIM4 + c * 16 + tl] = row[r][c]; else __builtin_nontemporal_store(row[r][c], &out[i * DIM4 + c * 16 + tl]); }
                 }
             }
         } else {
@@ -183,10 +185,9 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
 __device__ __forceinline__ uint32_t group_claim(const GroupTable& g, int64_t key, bool& claimed) {
     const unsigned long long bk = (unsigned long long)key ^ kBias;  // != 0 because key != kEmpty
     uint32_t h = (uint32_t)(mix64b((uint64_t)key) & g.smask);
-    while (true) {
-        unsigned long long cur = __hip_atomic_load(&g.skeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        claimed = false;
-        if (cur == 0) { cur = atomicCAS(&g.skeys[h], 0ull, bk); claimed = cur == 0; }
+    while (true) {  // one CAS per probe step: callers are already one lane per (block, key), so no pre-read is needed
+        const unsigned long long cur = atomicCAS(&g.skeys[h], 0ull, bk);
+        claimed = cur == 0;
         if (cur == 0 || cur == bk) return h;
         h = (h + 1) & (uint32_t)g.smask;
     }
@@ -748,9 +749,9 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     uint64_t S = 1024;
     while (S < 2 * cfg->max_batch) S <<= 1;
     t->S = S; t->g.smask = S - 1;
-    t->find_rounds = 2;
+    t->find_rounds = 0;  // auto: 2 for dim 64, 1 for wider rows
     t->find_grid_cap = 0;
-    t->find_nt = 1;
+    t->find_nt = -1;  // auto
 
     const uint64_t plane = t->capacity * (uint64_t)t->dim * sizeof(float);
     const uint64_t mb = t->max_batch;
@@ -833,13 +834,14 @@ int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, 
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
-    int R = t->find_rounds;
+    int R = t->find_rounds > 0 ? t->find_rounds : (t->dim4 == 16 ? 2 : 1);
     if (t->dim4 != 16 && R > 4) R = 4;
     if (t->dim4 != 16 && t->dim4 != 32 && R > 2) R = 2;
     R = R >= 8 ? 8 : R >= 4 ? 4 : R >= 2 ? 2 : 1;
     const unsigned grid = grid_for(n, 4u * 4u * (unsigned)R, t->find_grid_cap > 0 ? (unsigned)t->find_grid_cap : (1u << 22));
 #define FIND1(D4, RR, NT) find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)t->values, t->nb, d_keys, n, (f32x4*)d_out, d_found, t->default_value, t->dim4)
-#define FIND(D4, RR) do { switch (t->find_nt & 3) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; default: FIND1(D4, RR, 3); } } while (0)
+    const int nt = t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
+#define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
     if (t->dim4 == 16) { if (R == 8) FIND(16, 8); else if (R == 4) FIND(16, 4); else if (R == 2) FIND(16, 2); else FIND(16, 1); }
     else if (t->dim4 == 32) { if (R == 4) FIND(32, 4); else if (R == 2) FIND(32, 2); else FIND(32, 1); }
     else { if (R == 2) FIND(0, 2); else FIND(0, 1); }

@@ -13,16 +13,18 @@ ap.add_argument("--dim", type=int, default=64)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--launches", type=int, default=200)
 ap.add_argument("--dist", default="uniform")
+ap.add_argument("--no-found", action="store_true")
+ap.add_argument("--load", type=float, default=0.75)
 ap.add_argument("variants", nargs="*", default=["find_rounds=1", "find_rounds=2", "find_rounds=4", "find_rounds=8"])
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
-t = LookupTable(int(a.keys / 0.75), a.dim, device=dev, max_batch=1 << 20)
+t = LookupTable(int(a.keys / a.load), a.dim, device=dev, max_batch=1 << 20)
 bench.populate(t, synth, a.keys, a.dim, dev, 1 << 20)
 batches = bench.lookup_batches(synth, a.keys, a.batch, 64, a.dist, dev, seed=3)
-out = torch.empty((a.batch, a.dim), dtype=torch.float32, device=dev); found = torch.empty(a.batch, dtype=torch.uint8, device=dev)
+out = torch.empty((a.batch, a.dim), dtype=torch.float32, device=dev); found = None if a.no_found else torch.empty(a.batch, dtype=torch.uint8, device=dev)
 times = {v: [] for v in a.variants}
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-defaults = {"find_rounds": 2, "find_grid_cap": 0, "find_nt": 1}
+defaults = {"find_rounds": 2, "find_grid_cap": 0, "find_nt": -1}
 for r in range(a.rounds + 1):
     for v in a.variants:
         for k, d in defaults.items():
@@ -30,11 +32,11 @@ for r in range(a.rounds + 1):
         for kv in v.split(","):
             k, val = kv.split("="); t.set_tuning(k, int(val))
         for i in range(10):
-            t.find(batches[i % 64], out=out, found=found)
+            t.find(batches[i % 64], out=out, found=found, want_found=not a.no_found)
         torch.cuda.synchronize()
         e0.record()
         for i in range(a.launches):
-            t.find(batches[i % 64], out=out, found=found)
+            t.find(batches[i % 64], out=out, found=found, want_found=not a.no_found)
         e1.record(); torch.cuda.synchronize()
         if r:
             times[v].append(e0.elapsed_time(e1) * 1e3 / a.launches)
