@@ -34,7 +34,7 @@ extern "C" {
 #define MEE_ABI_VERSION 1
 
 #define MEE_EMPTY_KEY     INT64_MIN       /* SPEC.md §2: reserved, never stored */
-#define MEE_RECLAIMED_KEY (INT64_MIN + 1) /* SPEC.md §2: reserved for a later remove() */
+#define MEE_RECLAIMED_KEY (INT64_MIN + 1) /* SPEC.md §2: reserved, the tombstone mee_remove leaves */
 #define MEE_BUCKET_WIDTH  16              /* keys per bucket = one 128-byte line */
 
 enum { MEE_OK = 0, MEE_ERR_INVALID_ARG = -1, MEE_ERR_OUT_OF_MEMORY = -2, MEE_ERR_HIP = -3,
@@ -87,6 +87,8 @@ int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, 
 int mee_insert(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, void* stream);
 /* overwrite only if present; d_found nullable; duplicates: last occurrence wins. */
 int mee_assign(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found, void* stream);
+/* delete present keys (their slots become RECLAIMED and are reused by later inserts); d_found nullable. */
+int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream);
 /* find, inserting absent keys with their initial row first; d_found (nullable) = present before the call. */
 int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
 /* [syncs] all stored pairs, unspecified order; d_state1/d_state2 (nullable) receive acc|m and v rows in the

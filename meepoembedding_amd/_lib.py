@@ -61,6 +61,7 @@ PROTOTYPES = {
     "mee_find": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_insert": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "mee_assign": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "mee_remove": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "mee_find_or_insert": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_export": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), _vp]),
     "mee_size": (C.c_int, [_vp, C.POINTER(_sz), _vp]),

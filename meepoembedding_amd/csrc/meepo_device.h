@@ -46,15 +46,17 @@ __device__ __forceinline__ uint32_t tile_bits(uint64_t wave_mask, int tile) {
     return (uint32_t)(wave_mask >> (tile * kW)) & 0xFFFFu;
 }
 
-// Locate `key` (SPEC.md §2 probe sequence); with CLAIM also place it when absent (CAS on the first EMPTY slot of
-// the first bucket that has one).  Must be called by ALL 64 lanes in convergent control flow; tiles without
-// work pass active=false.  Returns the slot or -1.
+// Locate `key` (SPEC.md §2 probe sequence); with CLAIM also place it when absent: CAS into the first RECLAIMED slot
+// met on the way if there is one, else into the first EMPTY slot of the bucket that ended the probe.  Must be called
+// by ALL 64 lanes in convergent control flow; tiles without work pass active=false.  Returns the slot or -1.
 template <bool CLAIM, bool COHERENT>
 __device__ __forceinline__ int64_t tile_locate(int64_t* __restrict__ tkeys, uint64_t nb, int64_t key, bool active,
                                                int tile, int tl, bool& is_new, bool& full) {
-    uint64_t b = bucket_of(key, nb);
+    const uint64_t b0 = bucket_of(key, nb);
+    uint64_t b = b0;
     uint64_t steps = 0;
-    uint32_t retries = 0;  // lost-CAS re-reads of one bucket; bounded so that every wave reaches the exit
+    uint32_t retries = 0;  // lost-CAS re-reads; bounded so that every wave reaches the exit
+    int64_t tomb = -1;     // first RECLAIMED slot seen on this probe
     bool pend = active;
     int64_t slot = -1;
     is_new = false; full = false;
@@ -62,24 +64,32 @@ __device__ __forceinline__ int64_t tile_locate(int64_t* __restrict__ tkeys, uint
         const int64_t k = pend ? load_table_key<COHERENT>(tkeys + b * kW + tl) : kEmpty;
         const uint32_t tm = tile_bits(__ballot(pend && k == key), tile);
         const uint32_t te = tile_bits(__ballot(pend && k == kEmpty), tile);
-        const int e = __ffs(te) - 1;
         long long cas_old = 0;
+        int64_t target = -1;
+        long long expect = kEmpty;
         if constexpr (CLAIM) {
-            if (pend && !tm && te && tl == 0)
-                cas_old = (long long)atomicCAS((unsigned long long*)(tkeys + b * kW + e), (unsigned long long)kEmpty,
-                                               (unsigned long long)key);
+            const uint32_t tr = tile_bits(__ballot(pend && k == kReclaimed), tile);
+            if (pend && tomb < 0 && tr) tomb = (int64_t)(b * kW) + (__ffs(tr) - 1);
+            const bool last = steps + 1 >= nb;  // the whole sequence has been scanned after this bucket
+            if (pend && !tm && (te || (last && tomb >= 0))) {
+                target = tomb >= 0 ? tomb : (int64_t)(b * kW) + (__ffs(te) - 1);
+                expect = tomb >= 0 ? kReclaimed : kEmpty;
+                if (tl == 0)
+                    cas_old = (long long)atomicCAS((unsigned long long*)(tkeys + target), (unsigned long long)expect,
+                                                   (unsigned long long)key);
+            }
             cas_old = __shfl(cas_old, tile * kW);
         }
         if (pend) {
             if (tm) { slot = (int64_t)(b * kW) + (__ffs(tm) - 1); pend = false; }
-            else if (te) {
-                if constexpr (CLAIM) {
-                    if (cas_old == kEmpty) { slot = (int64_t)(b * kW) + e; is_new = true; pend = false; }
-                    else if (cas_old == key) { slot = (int64_t)(b * kW) + e; pend = false; }
-                    else if (++retries > (1u << 20)) { full = true; pend = false; }
-                    // else: another key took that slot — re-read the same bucket
-                } else pend = false;  // absent
-            } else if (++steps >= nb) { full = true; pend = false; }
+            else if (CLAIM && target >= 0) {
+                if (cas_old == expect) { slot = target; is_new = true; pend = false; }
+                else if (cas_old == key) { slot = target; pend = false; }
+                else if (++retries > (1u << 20)) { full = true; pend = false; }
+                else if (expect == kReclaimed) { tomb = -1; b = b0; steps = 0; }  // lost a tombstone: start over
+                // else: another key took that EMPTY slot — re-read the same bucket
+            } else if (te) pend = false;  // absent
+            else if (++steps >= nb) { full = true; pend = false; }
             else b = (b + 1 == nb) ? 0 : b + 1;
         }
     }

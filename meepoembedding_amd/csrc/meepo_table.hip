@@ -362,6 +362,34 @@ __global__ __launch_bounds__(256) void upsert_kernel(int64_t* tkeys, float4* val
     }
 }
 
+// ---- remove (SPEC.md §3) -----------------------------------------------------------------------------------
+// Two kernels so that every occurrence of a duplicate key reports the state before the call: locate (read-only,
+// found + slot per position), then tombstone (idempotent stores of RECLAIMED).
+__global__ __launch_bounds__(256) void remove_locate_kernel(const int64_t* __restrict__ tkeys, uint64_t nb,
+                                                            const int64_t* __restrict__ keys, uint32_t n, long long* slot_out,
+                                                            uint8_t* found, Counters* ctr) {
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t base = wave * 4; base < n; base += n_waves * 4) {
+        const uint32_t i = base + tile;
+        const bool inb = i < n;
+        const int64_t key = inb ? keys[i] : kEmpty;
+        const bool valid = inb && !reserved_key(key);
+        bool is_new, full;
+        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, valid, tile, tl, is_new, full);
+        if (inb && tl == 0) {
+            slot_out[i] = slot;
+            if (found) found[i] = slot >= 0;
+            if (!valid) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void remove_mark_kernel(int64_t* tkeys, const long long* __restrict__ slot_in, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && slot_in[i] >= 0) tkeys[slot_in[i]] = kReclaimed;
+}
+
 // ---- find_or_insert (SPEC.md §3) ---------------------------------------------------------------------------
 constexpr long long kPresentBit = 1ll << 62;
 
@@ -877,6 +905,20 @@ int mee_insert(mee_table* t, const int64_t* d_keys, const float* d_values, size_
 }
 int mee_assign(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found, void* stream) {
     return upsert_common(t, d_keys, d_values, n, d_found, stream, false, "mee_assign");
+}
+
+int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream) {
+    if (!t || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_remove: null argument");
+    if (int rc = check_batch(t, n, "mee_remove")) return rc;
+    if (n == 0) return MEE_OK;
+    DeviceGuard g(t->device);
+    hipStream_t st = as_stream(stream);
+    const uint32_t nn = (uint32_t)n;
+    long long* slots = t->g.sres;  // S >= 2 * max_batch entries: reused as the per-position slot list
+    remove_locate_kernel<<<grid_for(n, 16, 1u << 16), 256, 0, st>>>(t->keys, t->nb, d_keys, nn, slots, d_found, t->ctr);
+    remove_mark_kernel<<<grid_for(n, 256, 1u << 22), 256, 0, st>>>(t->keys, slots, nn);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
 }
 
 int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {

@@ -60,6 +60,12 @@ class ShardedLookupTable:
     def find_or_insert(self, keys: torch.Tensor):
         return self._lookup(keys, True)
 
+    def remove(self, keys: torch.Tensor) -> torch.Tensor:
+        keys = keys.contiguous().view(-1)
+        send_keys, perm, ss, rs = self._route(keys)
+        found = self.local.remove(self._a2a(send_keys, ss, rs))
+        return self.router.scatter_rows(self._a2a(found, rs, ss), perm)
+
     def _push(self, keys: torch.Tensor, payload: torch.Tensor):
         """Route (key, row) pairs to their owners; received pairs are ordered by source rank, then batch position."""
         keys = keys.contiguous().view(-1)

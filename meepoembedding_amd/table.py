@@ -98,6 +98,12 @@ class LookupTable:
         check(_lib.lib().mee_assign(self._h, k.data_ptr(), v.data_ptr(), k.numel(), found.data_ptr(), self._s()))
         return found
 
+    def remove(self, keys: torch.Tensor) -> torch.Tensor:
+        k = self._keys(keys)
+        found = torch.empty(k.numel(), dtype=torch.uint8, device=self.device)
+        check(_lib.lib().mee_remove(self._h, k.data_ptr(), k.numel(), found.data_ptr(), self._s()))
+        return found
+
     def find_or_insert(self, keys: torch.Tensor):
         k = self._keys(keys)
         n = k.numel()

@@ -57,6 +57,7 @@ def lib() -> C.CDLL:
         L.meo_find_mt.restype = None; L.meo_find_mt.argtypes = [vp, vp, sz, vp, vp, C.c_int]
         L.meo_insert.restype = None; L.meo_insert.argtypes = [vp, vp, vp, sz]
         L.meo_assign.restype = None; L.meo_assign.argtypes = [vp, vp, vp, sz, vp]
+        L.meo_remove.restype = None; L.meo_remove.argtypes = [vp, vp, sz, vp]
         L.meo_find_or_insert.restype = None; L.meo_find_or_insert.argtypes = [vp, vp, sz, vp, vp]
         L.meo_export.restype = u64; L.meo_export.argtypes = [vp, vp, vp, vp, vp, u64]
         L.meo_apply_adagrad.restype = None; L.meo_apply_adagrad.argtypes = [vp, vp, vp, sz, f32, f32]
@@ -165,6 +166,12 @@ class OracleTable:
         k = _keys(keys); v = _rows(values, k.size, self.dim)
         found = np.empty(k.size, np.uint8)
         lib().meo_assign(self._h, _p(k), _p(v), k.size, _p(found))
+        return found
+
+    def remove(self, keys):
+        k = _keys(keys)
+        found = np.empty(k.size, np.uint8)
+        lib().meo_remove(self._h, _p(k), k.size, _p(found))
         return found
 
     def find_or_insert(self, keys):

@@ -5,7 +5,7 @@
  * this path (README.md:2 is the only functional statement); every function below cites the SPEC.md section
  * it restates instead of a reference file:line.
  *
- * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma; fma() only where SPEC.md writes it).
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; fmaf() only where SPEC.md writes fma).
  */
 #include "meepo_oracle.h"
 
@@ -85,20 +85,24 @@ void meo_clear(meo_table* t) {
     t->size = 0;
 }
 
-/* SPEC §2 probe sequence. Returns slot or -1. If empty_out, *empty_out = first EMPTY slot met (or -1). */
-static int64_t probe(const meo_table* t, int64_t key, int64_t* empty_out) {
+/* SPEC §2 probe sequence. Returns slot or -1. If free_out, *free_out = the slot a new key would take: the first
+ * RECLAIMED slot met before the probe ended, else the first EMPTY slot of the bucket that ended it (or -1). */
+static int64_t probe(const meo_table* t, int64_t key, int64_t* free_out) {
     uint64_t b = meo_bucket(key, t->n_buckets);
-    if (empty_out) *empty_out = -1;
+    int64_t first_tomb = -1;
+    if (free_out) *free_out = -1;
     for (uint64_t step = 0; step < t->n_buckets; ++step) {
         const int64_t* kb = t->keys + b * MEO_BUCKET_W;
         int64_t first_empty = -1;
         for (int j = 0; j < MEO_BUCKET_W; ++j) {
             if (kb[j] == key) return (int64_t)(b * MEO_BUCKET_W + j);
             if (kb[j] == MEO_EMPTY_KEY && first_empty < 0) first_empty = (int64_t)(b * MEO_BUCKET_W + j);
+            if (kb[j] == MEO_RECLAIMED_KEY && first_tomb < 0) first_tomb = (int64_t)(b * MEO_BUCKET_W + j);
         }
-        if (first_empty >= 0) { if (empty_out) *empty_out = first_empty; return -1; }
+        if (first_empty >= 0) { if (free_out) *free_out = first_tomb >= 0 ? first_tomb : first_empty; return -1; }
         if (++b == t->n_buckets) b = 0;
     }
+    if (free_out) *free_out = first_tomb;
     return -1;
 }
 
@@ -185,6 +189,16 @@ void meo_assign(meo_table* t, const int64_t* keys, const float* values, size_t n
         int64_t s = has_reserved(t, keys[i]) ? -1 : probe(t, keys[i], NULL);
         if (s >= 0) memcpy(t->values + s * d, values + i * d, d * sizeof(float));
         if (found) found[i] = s >= 0;
+    }
+}
+void meo_remove(meo_table* t, const int64_t* keys, size_t n, uint8_t* found) {
+    /* pass 1: found-mask as of before the call (duplicates all report the same) */
+    if (found)
+        for (size_t i = 0; i < n; ++i) found[i] = !reserved(keys[i]) && probe(t, keys[i], NULL) >= 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (has_reserved(t, keys[i])) continue;
+        int64_t s = probe(t, keys[i], NULL);
+        if (s >= 0) { t->keys[s] = MEO_RECLAIMED_KEY; t->size--; }
     }
 }
 void meo_find_or_insert(meo_table* t, const int64_t* keys, size_t n, float* out, uint8_t* found) {

@@ -85,20 +85,36 @@ class DictTable:
         self.rows: dict[int, list[float]] = {}
         self.full = False
 
+    TOMB = "tomb"
+
     def _probe(self, key: int):
+        """(slot of key | None, slot a new key would take | None) — SPEC §2 incl. RECLAIMED reuse."""
         b = bucket(key, self.n_buckets)
+        tomb = None
         for _ in range(self.n_buckets):
             base = b * BUCKET_W
             empty = None
             for j in range(BUCKET_W):
-                if self.slots[base + j] == key:
+                v = self.slots[base + j]
+                if v == key and v is not self.TOMB:
                     return base + j, None
-                if self.slots[base + j] is None and empty is None:
+                if v is None and empty is None:
                     empty = base + j
+                if v is self.TOMB and tomb is None:
+                    tomb = base + j
             if empty is not None:
-                return None, empty
+                return None, (tomb if tomb is not None else empty)
             b = (b + 1) % self.n_buckets
-        return None, None
+        return None, tomb
+
+    def remove(self, keys):
+        before = [k in self.rows for k in keys]
+        for k in keys:
+            if k in self.rows:
+                s, _ = self._probe(k)
+                self.slots[s] = self.TOMB
+                del self.rows[k]
+        return before
 
     def insert(self, keys, rows):
         for k, r in zip(keys, rows):

@@ -16,6 +16,9 @@ class CpuTable:
         out, found = self.o.find(keys.numpy())
         return torch.from_numpy(out), torch.from_numpy(found)
 
+    def remove(self, keys):
+        return torch.from_numpy(self.o.remove(keys.numpy()))
+
     def find_or_insert(self, keys):
         out, found = self.o.find_or_insert(keys.numpy())
         return torch.from_numpy(out), torch.from_numpy(found)

@@ -136,6 +136,35 @@ def test_high_load_long_probes(dev):
     assert t.size() == n and np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
 
 
+def test_remove_and_churn(dev):
+    """remove + tombstone reuse vs the oracle: found-masks, survivors, re-insertion, a table kept ~full under churn."""
+    dim, cap = 16, 16 * 300
+    n = int(cap * 0.95)
+    t = LookupTable(cap, dim, device=dev, max_batch=2 * n, optimizer=OPT_ADAGRAD, initial_accumulator=0.5)
+    o = oracle.OracleTable(cap, dim, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.5)
+    keys = synth.keys_np(14, 0, n); rows = synth.rows_np(keys, dim, 1)
+    t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
+    rng = np.random.default_rng(2)
+    live = keys.copy()
+    for rnd in range(6):
+        victims = np.concatenate([rng.choice(live, size=n // 3, replace=False), synth.keys_np(500 + rnd, 0, 40), live[:5], live[:5]])
+        fg = t.remove(T(victims, dev)); fo = o.remove(victims)
+        assert np.array_equal(fg.cpu().numpy(), fo)
+        live = np.setdiff1d(live, victims)
+        assert t.size() == o.size() == live.size
+        fresh = synth.keys_np(900 + rnd, 0, n - live.size)          # refill to the same fill level: must reuse tombstones
+        fr = synth.rows_np(fresh, dim, 3 + rnd)
+        t.insert(T(fresh, dev), T(fr, dev)); o.insert(fresh, fr)
+        live = np.concatenate([live, fresh])
+        assert t.size() == o.size() == live.size and t.status() == o.status() == 0
+        q = np.concatenate([live[rng.permutation(live.size)[:2000]], victims[:500]])
+        out, found = t.find(T(q, dev)); eo, ef = o.find(q)
+        assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
+    g_ = [x.cpu().numpy() for x in t.export(with_state=True)[:3]]; o_ = o.export(with_state=True)[:3]
+    a, b = np.argsort(g_[0]), np.argsort(o_[0])
+    assert np.array_equal(g_[0][a], o_[0][b]) and np.array_equal(g_[1][a], o_[1][b]) and np.array_equal(g_[2][a], o_[2][b])
+
+
 def test_find_or_insert(dev):
     dim = 64
     kw = dict(initializer=INIT_UNIFORM, init_scale=0.05, init_seed=17, initial_accumulator=0.25)

@@ -112,7 +112,7 @@ def test_reserved_keys_and_table_full():
 
 
 @settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.too_slow])
-@given(st.lists(st.tuples(st.sampled_from(["insert", "assign", "find"]),
+@given(st.lists(st.tuples(st.sampled_from(["insert", "assign", "find", "remove", "insert"]),
                           st.lists(st.integers(min_value=-40, max_value=40), min_size=0, max_size=30)),
                 min_size=1, max_size=12),
        st.sampled_from([16, 48, 96]))
@@ -132,6 +132,9 @@ def test_model_vs_dict(ops, capacity):
         elif op == "assign":
             got = t.assign(ka, ra); exp = m.assign(ks, rows)
             assert list(got.astype(bool)) == exp
+        elif op == "remove":
+            got = t.remove(ka); exp = m.remove(ks)
+            assert list(got.astype(bool)) == exp
         else:
             out, found = t.find(ka); eo, ef = m.find(ks)
             assert list(found.astype(bool)) == ef
@@ -142,6 +145,27 @@ def test_model_vs_dict(ops, capacity):
     mk, mv = m.export_sorted()
     assert list(ek[order]) == mk
     assert np.array_equal(ev[order], np.array(mv, np.float32).reshape(len(mk), dim))
+
+
+def test_remove_and_slot_reuse_cpu():
+    """remove -> RECLAIMED tombstones; later inserts reuse them, so a full table can churn forever."""
+    cap, dim = 64, 4
+    t = oracle.OracleTable(cap, dim)
+    keys = synth.keys_np(6, 0, 64)
+    t.insert(keys, synth.rows_np(keys, dim, 1))
+    assert t.size() == 64 and t.status() == 0
+    for rnd in range(5):
+        old = keys[rnd * 8:(rnd + 1) * 8]
+        assert t.remove(old).all() and not t.remove(old).any()
+        assert t.size() == 56 and not t.find(old)[1].any()
+        new = synth.keys_np(100 + rnd, 0, 8)
+        t.insert(new, synth.rows_np(new, dim, 2))
+        assert t.size() == 64 and t.status() == 0, "tombstones must be reused"
+        out, found = t.find(new)
+        assert found.all() and np.array_equal(out, synth.rows_np(new, dim, 2))
+    rest = keys[40:]
+    out, found = t.find(rest)
+    assert found.all() and np.array_equal(out, synth.rows_np(rest, dim, 1))
 
 
 def test_find_or_insert_cpu():

@@ -41,7 +41,13 @@ def _global_reference(world):
     b = _batches(world)
     o.insert(np.concatenate([x[0] for x in b]), np.concatenate([x[1] for x in b]))
     o.apply_adagrad(np.concatenate([x[0] for x in b]), np.concatenate([x[2] for x in b]), 0.05, 1e-10)
+    for r in range(world):
+        o.remove(_removed(r))
     return o
+
+
+def _removed(rank):
+    return synth.keys_np(1, 0, NKEYS)[rank * 7::101]
 
 
 def _run_rank(rank, world, port, backend, q):
@@ -64,6 +70,9 @@ def _run_rank(rank, world, port, backend, q):
         keys, rows, grads = (torch.from_numpy(x).to(dev) for x in _batches(world)[rank])
         sh.insert(keys, rows)
         sh.apply_adagrad(keys, grads, lr=0.05, eps=1e-10)
+        dist.barrier()
+        sh.remove(torch.from_numpy(_removed(rank)).to(dev))
+        dist.barrier()
         probe = torch.from_numpy(np.concatenate([synth.keys_np(1, 0, NKEYS)[rank::3], synth.keys_np(9, rank * 50, 50)])).to(dev)
         out, found = sh.find(probe)
         total = sh.size()
