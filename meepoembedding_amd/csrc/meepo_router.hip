@@ -23,7 +23,7 @@ struct mee_router {
 
 namespace mee {
 
-constexpr int kPartBlock = 256;  // keys per block in the partition kernels (one per thread)
+constexpr int kPartBlock = 1024;  // keys per block in the partition kernels (one per thread): 4x fewer rows for the scan
 constexpr int kMaxShards = 64;
 
 __global__ void hash_batch_kernel(const int64_t* __restrict__ keys, uint64_t n, uint64_t nb, uint32_t g, uint64_t* mix_out,
