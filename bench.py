@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--load", type=float, default=0.75)
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["find", "train"], default="find",
+                    help="find = configs[1] (the driver's metric); train = configs[2]: find + sparse-Adagrad apply per step (N=1 only)")
     ap.add_argument("--pipeline", type=int, default=1, help="sharded only: steps in flight on separate HIP streams (1 = off)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even at N=1 (rehearsal of the N>1 code)")
     ap.add_argument("--verbose", action="store_true")
@@ -149,7 +151,11 @@ def main():
     dim = args.dim
     chunk = 1 << 20
     cap = int(keys_per_gpu / args.load * (1.02 if sharded else 1.0))  # shard sizes fluctuate a little around n/world
-    table = LookupTable(cap, dim, device=dev, max_batch=max(chunk, batch * 2))
+    train = args.mode == "train"
+    if train and (world > 1 or args.force_sharded):
+        raise SystemExit("--mode train is a single-GPU mode")
+    from meepoembedding_amd import OPT_ADAGRAD, OPT_NONE
+    table = LookupTable(cap, dim, device=dev, max_batch=max(chunk, batch * 2), optimizer=OPT_ADAGRAD if train else OPT_NONE)
     log(f"table: {table.capacity} slots, {table.table_bytes / 1e9:.1f} GB")
     populate(table, synth, n_keys, dim, dev, chunk, owner_rank=rank, world=world, hash_batch=hash_batch, log=log)
     local_size = table.size()
@@ -171,6 +177,13 @@ def main():
                 return shs[0].find(batches[i % n_batches])
             with torch.cuda.stream(streams[i % depth]):
                 return shs[i % depth].find(batches[i % n_batches])
+    elif train:
+        grads = [torch.randn(batch, dim, device=dev) * 0.01 for _ in range(4)]   # N(0, 1e-2), SURVEY §8d config 3
+
+        def step(i):
+            r_ = table.find(batches[i % n_batches], out=out, found=found)
+            table.apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10)
+            return r_
     else:
         def step(i):
             return table.find(batches[i % n_batches], out=out, found=found)
@@ -183,7 +196,8 @@ def main():
     if chk_keys is not None:
         o_rows, o_found = r
         assert bool(o_found.all()), "bench lookup missed an inserted key"
-        assert torch.equal(o_rows[:4096], synth.rows_t(chk_keys, dim, 2)), "bench lookup returned wrong rows"
+        if not train:   # in train mode the rows have been updated by earlier warm-up steps
+            assert torch.equal(o_rows[:4096], synth.rows_t(chk_keys, dim, 2)), "bench lookup returned wrong rows"
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if sharded:
@@ -219,7 +233,13 @@ def main():
     else:
         kern_s = ev_ms / 1e3 / args.steps
     bpl = algorithmic_bytes_per_lookup(dim)
-    achieved = batch * bpl / kern_s / 1e9
+    if train:
+        # fwd 528 B/lookup + bwd 264 B/lookup + 1032 B per unique key (Adagrad); here the whole step is priced
+        uniq = sum(int(torch.unique(b_).numel()) for b_ in batches[:8]) / 8
+        step_bytes = (bpl + 8 + 4 * dim) * batch + (8 + 16 * dim) * uniq
+        achieved = step_bytes / kern_s / 1e9
+    else:
+        achieved = batch * bpl / kern_s / 1e9
 
     if rank == 0:
         value = world * batch * args.steps / elapsed
@@ -233,18 +253,20 @@ def main():
             except Exception:
                 traffic = None
         res = {
-            "metric": "key-lookups/sec", "value": value, "unit": "key-lookups/s", "n_gpus": world, "steps": args.steps,
+            "metric": "key-lookups/sec" if not train else "train-step keys/sec (find + sparse Adagrad apply)", "value": value, "unit": "key-lookups/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int64 keys / fp32 rows (copy)", "data": "synthetic",
             "config": {"workload": (f"row-sharded find: {n_keys // 1_000_000}M keys over {world} GPUs ({keys_per_gpu // 1_000_000}M/GPU), dim {dim}, "
                                     f"{batch} lookups per rank per step, RCCL all-to-all keys out / rows back" if sharded else
+                                    f"configs[2]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim}, forward find + sparse-Adagrad scatter-update, {batch}-key batches" if train else
                                     f"configs[1]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim} fp32, forward find only, {batch}-key batches"),
                        "keys_per_gpu": keys_per_gpu, "local_size": local_size, "dim": dim, "batch_per_rank": batch, "load_factor": args.load,
                        "key_distribution": args.dist, "table_gb": round(table.table_bytes / 1e9, 2),
                        "parallelism": (f"row-shard x{world}" + (f", {args.pipeline} steps in flight" if args.pipeline > 1 else "")) if sharded else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "find_kernel", "avg_launch_us": kern_s * 1e6,
-                         "algorithmic_bytes_per_lookup": bpl, "lookups_per_launch": batch},
+                         "traffic": traffic if not train else None, "kernel": "find_kernel" if not train else "whole step (find + 5 apply kernels)",
+                         "avg_launch_us": kern_s * 1e6, "algorithmic_bytes_per_lookup": bpl if not train else step_bytes / batch,
+                         "lookups_per_launch": batch},
         }
         if not sharded and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(synth, dim, batch)

@@ -78,6 +78,7 @@ struct mee_table {
     // performance knobs (never change results): see mee_set_tuning()
     int find_rounds;            // keys in flight per tile in the find kernel: 1, 2, 4 or 8
     int find_grid_cap;          // max blocks of the find grid (0 = one pass, no grid-stride loop)
+    int apply_rounds;           // batch positions in flight per tile in apply_single_kernel: 1 or 2 (0 = auto)
     int find_nt;                // bit0: non-temporal row loads, bit1: non-temporal bucket loads, bit2: plain (cached) out stores;
                                 // -1 = auto: cached loads (hot rows of skewed streams stay in L2), cached stores while the
                                 // dense output fits the Infinity Cache (<= 128 MB), streaming stores beyond
@@ -475,28 +476,59 @@ __device__ __forceinline__ void group_release(const GroupTable& g, uint32_t h) {
 
 // Pass 1 over batch positions: a key that occurs once is updated right here from its own grad row (the common
 // case) and its group-table entry is returned to empty; occurrences of multi-keys are filed into their group's
-// occurrence list for pass 2.
+// occurrence list for pass 2.  R positions in flight per tile; the grad rows are requested before the probe so that
+// they travel beside the bucket lines.  DIM4 = dim/4 when it is 16 or 32 (rows held in registers), 0 = any dim.
+template <int KIND, int DIM4, int R>
 __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1,
-                                                           float4* s2, uint64_t nb, uint32_t dim4,
+                                                           float4* s2, uint64_t nb, uint32_t dim4_rt,
                                                            const int64_t* __restrict__ keys,
                                                            const float4* __restrict__ grads, uint32_t n, GroupTable g,
                                                            BatchScratch bs, OptArgs a) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t base = wave * 4; base < n; base += n_waves * 4) {
-        const uint32_t i = base + tile;
-        const bool inb = i < n;
-        const int64_t key = inb ? keys[i] : kEmpty;
-        const uint32_t cnt = inb ? bs.pcnt[i] : 0;
-        bool is_new, full;
-        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, cnt == 1, tile, tl, is_new, full);
-        if (cnt == 1) {
-            if (slot >= 0)
-                for (uint32_t c = tl; c < dim4; c += 16) update_row(a, values, s1, s2, (uint64_t)slot * dim4 + c, grads[(uint64_t)i * dim4 + c]);
-            if (tl == 0) group_release(g, bs.hidx[i]);  // this tile is the only user of the entry
-        } else if (cnt > 1 && tl == 0) {
-            bs.occ[g.soffs[bs.hidx[i]] + bs.rank[i]] = i;
+    const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
+    constexpr int C = DIM4 ? DIM4 / 16 : 1;
+    a.kind = KIND;  // lets the compiler drop the other optimizer's code
+    for (uint32_t base = wave * 4 * R; base < n; base += n_waves * 4 * R) {
+        int64_t key[R], slot[R];
+        uint32_t cnt[R];
+        float4 gr[R][C];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + r * 4 + tile;
+            const bool inb = i < n;
+            key[r] = inb ? keys[i] : kEmpty;
+            cnt[r] = inb ? bs.pcnt[i] : 0;
+        }
+        if constexpr (DIM4 != 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (cnt[r] == 1) gr[r][c] = grads[(uint64_t)(base + r * 4 + tile) * DIM4 + c * 16 + tl];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            bool is_new, full;
+            slot[r] = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key[r], cnt[r] == 1, tile, tl, is_new, full);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + r * 4 + tile;
+            if (cnt[r] == 1) {
+                if (slot[r] >= 0) {
+                    if constexpr (DIM4 != 0) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) update_row(a, values, s1, s2, (uint64_t)slot[r] * DIM4 + c * 16 + tl, gr[r][c]);
+                    } else {
+                        for (uint32_t c = tl; c < dim4; c += 16) update_row(a, values, s1, s2, (uint64_t)slot[r] * dim4 + c, grads[(uint64_t)i * dim4 + c]);
+                    }
+                }
+                if (tl == 0) group_release(g, bs.hidx[i]);  // this tile is the only user of the entry
+            } else if (cnt[r] > 1 && tl == 0) {
+                bs.occ[g.soffs[bs.hidx[i]] + bs.rank[i]] = i;
+            }
         }
     }
 }
@@ -779,6 +811,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     t->S = S; t->g.smask = S - 1;
     t->find_rounds = 0;  // auto: 2 for dim 64, 1 for wider rows
     t->find_grid_cap = 0;
+    t->apply_rounds = 0;
     t->find_nt = -1;  // auto
 
     const uint64_t plane = t->capacity * (uint64_t)t->dim * sizeof(float);
@@ -845,6 +878,7 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     if (!strcmp(name, "find_rounds")) t->find_rounds = value;
     else if (!strcmp(name, "find_grid_cap")) t->find_grid_cap = value;
     else if (!strcmp(name, "find_nt")) t->find_nt = value;
+    else if (!strcmp(name, "apply_rounds")) t->apply_rounds = value;
     else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);
     return MEE_OK;
 }
@@ -1000,8 +1034,18 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     MEE_HIP(hipMemsetAsync(t->op, 0, 16, st));  // n_uniq, n_occ, n_big, n_work
     group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr);
     group_plan_kernel<false><<<gp, 1024, 0, st>>>(nn, t->g, t->bs, t->op);
-    apply_single_kernel<<<gt, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
-                                            (const float4*)d_grads, nn, t->g, t->bs, a);
+    {
+        const int R = t->apply_rounds > 0 ? t->apply_rounds : 2;
+        const unsigned gs = grid_for(n, 16u * (R >= 2 ? 2u : 1u), 1u << 16);
+#define SINGLE(K, D4, RR) apply_single_kernel<K, D4, RR><<<gs, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, \
+                                                                            d_keys, (const float4*)d_grads, nn, t->g, t->bs, a)
+#define SINGLE_D(K) do { if (t->dim4 == 16) { if (R >= 2) SINGLE(K, 16, 2); else SINGLE(K, 16, 1); } \
+                         else if (t->dim4 == 32) { if (R >= 2) SINGLE(K, 32, 2); else SINGLE(K, 32, 1); } \
+                         else { if (R >= 2) SINGLE(K, 0, 2); else SINGLE(K, 0, 1); } } while (0)
+        if (a.kind == MEE_OPT_ADAGRAD) SINGLE_D(MEE_OPT_ADAGRAD); else SINGLE_D(MEE_OPT_ADAM);
+#undef SINGLE_D
+#undef SINGLE
+    }
     // the work list (chunk leaders) and the big-group list have device-side lengths: fixed grids that loop
     apply_chunk_kernel<<<grid_for(n, 16, 2048), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
                                                             d_keys, (const float4*)d_grads, t->g, t->bs, t->op, a);

@@ -14,11 +14,13 @@ ap.add_argument("--opt", default="adagrad")
 ap.add_argument("--dist", default="uniform")
 ap.add_argument("--launches", type=int, default=100)
 ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--apply-rounds", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 kind = OPT_ADAGRAD if a.opt == "adagrad" else OPT_ADAM
 t = LookupTable(int(a.keys / 0.75), a.dim, device=dev, max_batch=1 << 20, optimizer=kind)
 bench.populate(t, synth, a.keys, a.dim, dev, 1 << 20)
+t.set_tuning('apply_rounds', a.apply_rounds)
 NB = 16
 batches = bench.lookup_batches(synth, a.keys, a.batch, NB, a.dist, dev, seed=3)
 uniq = [int(torch.unique(b).numel()) for b in batches]
