@@ -43,6 +43,9 @@ enum { MEE_OK = 0, MEE_ERR_INVALID_ARG = -1, MEE_ERR_OUT_OF_MEMORY = -2, MEE_ERR
 enum { MEE_OPT_NONE = 0, MEE_OPT_ADAGRAD = 1, MEE_OPT_ADAM = 2 };
 enum { MEE_INIT_CONSTANT = 0, MEE_INIT_UNIFORM = 1 };
 enum { MEE_STATUS_TABLE_FULL = 1u, MEE_STATUS_RESERVED_KEY = 2u };
+/* MEE_MEM_HOST_PINNED: rows in pinned, device-mapped host DRAM, read and written by the same kernels over PCIe — the
+ * cold tier of a hot/cold pair (BASELINE configs[4]); see meepoembedding_amd/tiered.py. */
+enum { MEE_MEM_HBM = 0, MEE_MEM_HOST_PINNED = 1 };
 
 typedef struct mee_table  mee_table;  /* one HBM-resident hash table (one shard) */
 typedef struct mee_router mee_router; /* workspace for the shard partition / un-permute kernels */
@@ -59,6 +62,8 @@ typedef struct mee_config {
     uint32_t initializer;         /* MEE_INIT_*: initial row for find_or_insert */
     float    init_scale;
     uint64_t init_seed;
+    uint32_t value_memory;        /* MEE_MEM_*: where the value/state planes live (the key plane is always in HBM) */
+    uint32_t reserved;            /* must be 0 */
 } mee_config;
 
 typedef struct mee_table_info {
@@ -87,6 +92,12 @@ int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, 
 int mee_insert(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, void* stream);
 /* overwrite only if present; d_found nullable; duplicates: last occurrence wins. */
 int mee_assign(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found, void* stream);
+/* the same two verbs on one plane of the table: 0 = values, 1 = acc | m, 2 = v (state planes read 0 for absent keys).
+ * They let a caller move a key together with its optimizer state between tables (hot/cold tiers, re-sharding). */
+int mee_find_plane(const mee_table* t, uint32_t plane, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found,
+                   void* stream);
+int mee_assign_plane(mee_table* t, uint32_t plane, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found,
+                     void* stream);
 /* delete present keys (their slots become RECLAIMED and are reused by later inserts); d_found nullable. */
 int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream);
 /* find, inserting absent keys with their initial row first; d_found (nullable) = present before the call. */

@@ -20,6 +20,7 @@ ERR_INVALID_ARG, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_NO_DEVICE, ERR_BATCH_TOO_LARGE,
 OPT_NONE, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
 INIT_CONSTANT, INIT_UNIFORM = 0, 1
 STATUS_TABLE_FULL, STATUS_RESERVED_KEY = 1, 2
+MEM_HBM, MEM_HOST_PINNED = 0, 1
 EMPTY_KEY = -(1 << 63)
 RECLAIMED_KEY = EMPTY_KEY + 1
 BUCKET_WIDTH = 16
@@ -36,7 +37,7 @@ class Config(C.Structure):
         ("struct_size", C.c_uint32), ("device", C.c_int32), ("capacity", C.c_uint64), ("dim", C.c_uint32),
         ("optimizer", C.c_uint32), ("max_batch", C.c_uint64), ("default_value", C.c_float),
         ("initial_accumulator", C.c_float), ("initializer", C.c_uint32), ("init_scale", C.c_float),
-        ("init_seed", C.c_uint64),
+        ("init_seed", C.c_uint64), ("value_memory", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -61,6 +62,8 @@ PROTOTYPES = {
     "mee_find": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_insert": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "mee_assign": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "mee_find_plane": (C.c_int, [_vp, _u32, _vp, _sz, _vp, _vp, _vp]),
+    "mee_assign_plane": (C.c_int, [_vp, _u32, _vp, _vp, _sz, _vp, _vp]),
     "mee_remove": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "mee_find_or_insert": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_export": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), _vp]),

@@ -60,7 +60,7 @@ struct BatchScratch {          // max_batch entries, indexed by batch position u
 struct mee_table {
     int device;
     uint64_t capacity, nb, max_batch;
-    uint32_t dim, dim4, optimizer, initializer;
+    uint32_t dim, dim4, optimizer, initializer, value_memory;
     float default_value, init_acc, init_scale;
     uint64_t init_seed;
     // table planes
@@ -762,7 +762,10 @@ int mee_table_destroy(mee_table* t) {
     if (!t) return MEE_OK;
     DeviceGuard g(t->device);
     (void)hipDeviceSynchronize();
-    void* dev[] = {t->keys, t->values, t->s1, t->s2, t->g.skeys, t->g.sval, t->g.sval0, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
+    float* planes[] = {t->values, t->s1, t->s2};
+    for (float* p : planes)
+        if (p) { if (t->value_memory == MEE_MEM_HOST_PINNED) (void)hipHostFree(p); else (void)hipFree(p); }
+    void* dev[] = {t->keys, t->g.skeys, t->g.sval, t->g.sval0, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
                    t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.work, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (t->h_ctr) (void)hipHostFree(t->h_ctr);
@@ -778,8 +781,8 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
         return fail(MEE_ERR_INVALID_ARG, "mee_table_create: struct_size %u != %zu (ABI mismatch)", cfg->struct_size, sizeof(mee_config));
     if (cfg->capacity == 0 || cfg->dim < 4 || cfg->dim > 1024 || (cfg->dim & 3))
         return fail(MEE_ERR_INVALID_ARG, "mee_table_create: capacity must be >0 and dim a multiple of 4 in [4,1024]");
-    if (cfg->optimizer > MEE_OPT_ADAM || cfg->initializer > MEE_INIT_UNIFORM)
-        return fail(MEE_ERR_INVALID_ARG, "mee_table_create: bad optimizer/initializer");
+    if (cfg->optimizer > MEE_OPT_ADAM || cfg->initializer > MEE_INIT_UNIFORM || cfg->value_memory > MEE_MEM_HOST_PINNED || cfg->reserved != 0)
+        return fail(MEE_ERR_INVALID_ARG, "mee_table_create: bad optimizer/initializer/value_memory");
     if (cfg->max_batch == 0 || cfg->max_batch > (1ull << 30))
         return fail(MEE_ERR_INVALID_ARG, "mee_table_create: max_batch must be in [1, 2^30]");
     int ndev = 0;
@@ -802,7 +805,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     t->nb = (cfg->capacity + kW - 1) / kW;
     t->capacity = t->nb * kW;
     t->dim = cfg->dim; t->dim4 = cfg->dim / 4;
-    t->optimizer = cfg->optimizer; t->initializer = cfg->initializer;
+    t->optimizer = cfg->optimizer; t->initializer = cfg->initializer; t->value_memory = cfg->value_memory;
     t->max_batch = cfg->max_batch;
     t->default_value = cfg->default_value; t->init_acc = cfg->initial_accumulator;
     t->init_scale = cfg->init_scale; t->init_seed = cfg->init_seed;
@@ -825,11 +828,24 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
             goto bad;                                                                                         \
         }                                                                                                     \
     } while (0)
+    // value/state planes: HBM, or pinned device-mapped host DRAM for a cold tier (same kernels, rows travel over PCIe)
+#define ALLOC_PLANE(ptr)                                                                                      \
+    do {                                                                                                      \
+        if (t->value_memory == MEE_MEM_HOST_PINNED) {                                                         \
+            hipError_t e_ = hipHostMalloc((void**)&(ptr), plane, hipHostMallocMapped | hipHostMallocPortable); \
+            if (e_ != hipSuccess) {                                                                           \
+                rc = fail(MEE_ERR_OUT_OF_MEMORY, "hipHostMalloc(%llu bytes) for %s: %s", (unsigned long long)plane, #ptr, hipGetErrorString(e_)); \
+                goto bad;                                                                                     \
+            }                                                                                                 \
+        } else ALLOC(ptr, plane);                                                                             \
+        t->table_bytes += plane;                                                                              \
+    } while (0)
     ALLOC(t->keys, t->capacity * sizeof(int64_t));
-    ALLOC(t->values, plane);
-    t->table_bytes = t->capacity * sizeof(int64_t) + plane;
-    if (t->optimizer != MEE_OPT_NONE) { ALLOC(t->s1, plane); t->table_bytes += plane; }
-    if (t->optimizer == MEE_OPT_ADAM) { ALLOC(t->s2, plane); t->table_bytes += plane; }
+    t->table_bytes = t->capacity * sizeof(int64_t);
+    ALLOC_PLANE(t->values);
+    if (t->optimizer != MEE_OPT_NONE) ALLOC_PLANE(t->s1);
+    if (t->optimizer == MEE_OPT_ADAM) ALLOC_PLANE(t->s2);
+#undef ALLOC_PLANE
     ALLOC(t->g.skeys, S * 8); ALLOC(t->g.sval, S * 4); ALLOC(t->g.sval0, S * 4); ALLOC(t->g.soffs, S * 4); ALLOC(t->g.sgrp, S * 4);
     ALLOC(t->g.sbig, S * 4); ALLOC(t->g.sres, S * 8);
     ALLOC(t->bs.hidx, mb * 4); ALLOC(t->bs.rank, mb * 4); ALLOC(t->bs.pcnt, mb * 4); ALLOC(t->bs.occ, mb * 4); ALLOC(t->bs.uniq_h, mb * 4);
@@ -891,8 +907,12 @@ int mee_clear(mee_table* t, void* stream) {
     return MEE_OK;
 }
 
-int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
-    if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find: null argument");
+static const float* plane_of(const mee_table* t, uint32_t plane) {
+    return plane == 0 ? t->values : plane == 1 ? t->s1 : plane == 2 ? t->s2 : nullptr;
+}
+
+static int find_plane(const mee_table* t, const float* plane, float miss_value, const int64_t* d_keys, size_t n, float* d_out,
+                      uint8_t* d_found, void* stream) {
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -901,7 +921,7 @@ int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, 
     if (t->dim4 != 16 && t->dim4 != 32 && R > 2) R = 2;
     R = R >= 8 ? 8 : R >= 4 ? 4 : R >= 2 ? 2 : 1;
     const unsigned grid = grid_for(n, 4u * 4u * (unsigned)R, t->find_grid_cap > 0 ? (unsigned)t->find_grid_cap : (1u << 22));
-#define FIND1(D4, RR, NT) find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)t->values, t->nb, d_keys, n, (f32x4*)d_out, d_found, t->default_value, t->dim4)
+#define FIND1(D4, RR, NT) find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4)
     const int nt = t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
 #define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
     if (t->dim4 == 16) { if (R == 8) FIND(16, 8); else if (R == 4) FIND(16, 4); else if (R == 2) FIND(16, 2); else FIND(16, 1); }
@@ -913,9 +933,21 @@ int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, 
     return MEE_OK;
 }
 
-static int upsert_common(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found,
+int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
+    if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find: null argument");
+    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream);
+}
+
+int mee_find_plane(const mee_table* t, uint32_t plane, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
+    if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_plane: null argument");
+    const float* p = plane_of(t, plane);
+    if (!p) return fail(MEE_ERR_UNSUPPORTED, "mee_find_plane: plane %u does not exist (optimizer=%u)", plane, t->optimizer);
+    return find_plane(t, p, plane == 0 ? t->default_value : 0.0f, d_keys, n, d_out, d_found, stream);
+}
+
+static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found,
                          void* stream, bool claim, const char* name) {
-    if (!t || (n && (!d_keys || !d_values))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
+    if (!t || !plane || (n && (!d_keys || !d_values))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
     if (int rc = check_batch(t, n, name)) return rc;
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
@@ -924,10 +956,10 @@ static int upsert_common(mee_table* t, const int64_t* d_keys, const float* d_val
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
     group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr);
     if (claim)
-        upsert_kernel<true><<<gt, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
+        upsert_kernel<true><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
                                                 (const float4*)d_values, nn, t->bs.hidx, t->g.sval, nullptr, t->optimizer, t->init_acc, t->ctr);
     else
-        upsert_kernel<false><<<gt, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
+        upsert_kernel<false><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
                                                  (const float4*)d_values, nn, t->bs.hidx, t->g.sval, d_found, t->optimizer, t->init_acc, t->ctr);
     group_reset_kernel<<<gl, 256, 0, st>>>(t->bs.hidx, nn, t->g);
     MEE_HIP(hipGetLastError());
@@ -935,10 +967,17 @@ static int upsert_common(mee_table* t, const int64_t* d_keys, const float* d_val
 }
 
 int mee_insert(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, void* stream) {
-    return upsert_common(t, d_keys, d_values, n, nullptr, stream, true, "mee_insert");
+    return upsert_common(t, t ? t->values : nullptr, d_keys, d_values, n, nullptr, stream, true, "mee_insert");
 }
 int mee_assign(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found, void* stream) {
-    return upsert_common(t, d_keys, d_values, n, d_found, stream, false, "mee_assign");
+    return upsert_common(t, t ? t->values : nullptr, d_keys, d_values, n, d_found, stream, false, "mee_assign");
+}
+int mee_assign_plane(mee_table* t, uint32_t plane, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found,
+                     void* stream) {
+    if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_assign_plane: null table");
+    float* p = const_cast<float*>(plane_of(t, plane));
+    if (!p) return fail(MEE_ERR_UNSUPPORTED, "mee_assign_plane: plane %u does not exist (optimizer=%u)", plane, t->optimizer);
+    return upsert_common(t, p, d_keys, d_values, n, d_found, stream, false, "mee_assign_plane");
 }
 
 int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream) {

@@ -27,7 +27,7 @@ class LookupTable:
 
     def __init__(self, capacity: int, dim: int, *, device: int | torch.device = 0, optimizer: int = OPT_NONE,
                  max_batch: int = 1 << 20, default_value: float = 0.0, initial_accumulator: float = 0.0,
-                 initializer: int = INIT_CONSTANT, init_scale: float = 0.0, init_seed: int = 0):
+                 initializer: int = INIT_CONSTANT, init_scale: float = 0.0, init_seed: int = 0, value_memory: int = 0):
         L = _lib.lib()
         dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
         if dev.type != "cuda":
@@ -36,7 +36,7 @@ class LookupTable:
         cfg = _lib.Config(struct_size=C.sizeof(_lib.Config), device=self.device.index, capacity=capacity, dim=dim,
                           optimizer=optimizer, max_batch=max_batch, default_value=default_value,
                           initial_accumulator=initial_accumulator, initializer=initializer, init_scale=init_scale,
-                          init_seed=init_seed)
+                          init_seed=init_seed, value_memory=value_memory)
         h = C.c_void_p()
         self._h = None
         check(L.mee_table_create(C.byref(cfg), C.byref(h)))
@@ -96,6 +96,22 @@ class LookupTable:
         v = self._rows(values, k.numel())
         found = torch.empty(k.numel(), dtype=torch.uint8, device=self.device)
         check(_lib.lib().mee_assign(self._h, k.data_ptr(), v.data_ptr(), k.numel(), found.data_ptr(), self._s()))
+        return found
+
+    def find_plane(self, plane: int, keys: torch.Tensor):
+        """find on one plane: 0 = values, 1 = acc | m, 2 = v."""
+        k = self._keys(keys)
+        n = k.numel()
+        out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        found = torch.empty(n, dtype=torch.uint8, device=self.device)
+        check(_lib.lib().mee_find_plane(self._h, plane, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), self._s()))
+        return out, found
+
+    def assign_plane(self, plane: int, keys: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
+        k = self._keys(keys)
+        v = self._rows(values, k.numel())
+        found = torch.empty(k.numel(), dtype=torch.uint8, device=self.device)
+        check(_lib.lib().mee_assign_plane(self._h, plane, k.data_ptr(), v.data_ptr(), k.numel(), found.data_ptr(), self._s()))
         return found
 
     def remove(self, keys: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,155 @@
+"""Hot/cold tiering of one shard: an HBM table for hot keys in front of a table whose rows live in pinned host DRAM.
+
+BASELINE.json configs[4] ("hot/cold tier: HBM + pinned host-DRAM spill"); reference anchor /root/reference/README.md:2
+("Supports GPU, CPU … backends" — a GPU backend backed by a CPU-memory one).  The snapshot has no code for it.
+
+Design (host logic only; every row still moves through the HIP kernels):
+  * `hot`  = LookupTable(value_memory=MEM_HBM)          keys + rows in HBM
+  * `cold` = LookupTable(value_memory=MEM_HOST_PINNED)  keys (the index) in HBM, rows/state in pinned, device-mapped host
+             DRAM — the same find/insert/apply kernels read and write them over PCIe (zero-copy), asynchronously on the
+             caller's stream, so a cold access costs PCIe bandwidth but no host thread and no staging copy.
+  * a key lives in exactly ONE tier, so the pair behaves like one table (tests compare it with a single oracle table).
+  * new keys go to the hot tier while it has room (`hot_key_limit`), else to the cold tier; `promote` / `demote` move
+    keys (values AND optimizer state) between tiers — which keys to move is the caller's policy (e.g. the top of a
+    frequency sketch), typically issued on a side stream between steps.
+
+`hot` / `cold` are any objects with the LookupTable methods, so the logic also runs on the CPU test adapters.
+"""
+from __future__ import annotations
+
+import torch
+
+
+class TieredLookupTable:
+    def __init__(self, hot, cold, hot_key_limit: int | None = None):
+        if hot.dim != cold.dim:
+            raise ValueError("hot and cold tables must have the same dim")
+        self.hot, self.cold, self.dim = hot, cold, hot.dim
+        self.optimizer = getattr(hot, "optimizer", 0)
+        # keep the hot table at a load it probes fast at (SPEC.md §2: probe length grows with load)
+        self.hot_key_limit = int(hot_key_limit if hot_key_limit is not None else getattr(hot, "capacity", 0) * 0.75)
+        self._hot_keys_ub = 0  # upper bound on hot.size(), maintained without synchronising
+
+    # -- helpers -----------------------------------------------------------------------------------------
+    @staticmethod
+    def _idx(mask: torch.Tensor) -> torch.Tensor:
+        return torch.nonzero(mask, as_tuple=False).view(-1)
+
+    def _room_for(self, n_new: int) -> bool:
+        if self._hot_keys_ub + n_new > self.hot_key_limit:
+            self._hot_keys_ub = self.hot.size()  # refresh the bound (synchronises; only when the bound is hit)
+        return self._hot_keys_ub + n_new <= self.hot_key_limit
+
+    # -- operators (SPEC.md §3 on the union of both tiers) ---------------------------------------------------
+    def find(self, keys: torch.Tensor):
+        keys = keys.contiguous().view(-1)
+        out, found = self.hot.find(keys)
+        miss = self._idx(found == 0)
+        if miss.numel():
+            rows_c, found_c = self.cold.find(keys[miss])
+            out[miss] = rows_c
+            found[miss] = found_c
+        return out, found
+
+    def insert(self, keys: torch.Tensor, values: torch.Tensor) -> None:
+        keys = keys.contiguous().view(-1)
+        values = values.contiguous().view(keys.numel(), self.dim)
+        in_hot = self.hot.assign(keys, values)           # present in hot: overwritten there (last occurrence wins)
+        rest = self._idx(in_hot == 0)
+        if not rest.numel():
+            return
+        k2, v2 = keys[rest], values[rest]
+        in_cold = self.cold.assign(k2, v2)               # present in cold: overwritten there
+        new = self._idx(in_cold == 0)
+        if not new.numel():
+            return
+        k3, v3 = k2[new], v2[new]                        # absent everywhere: all occurrences of a key land in one tier
+        if self._room_for(k3.numel()):
+            self.hot.insert(k3, v3)
+            self._hot_keys_ub += k3.numel()
+        else:
+            self.cold.insert(k3, v3)
+
+    def assign(self, keys: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
+        keys = keys.contiguous().view(-1)
+        values = values.contiguous().view(keys.numel(), self.dim)
+        found = self.hot.assign(keys, values)
+        rest = self._idx(found == 0)
+        if rest.numel():
+            found[rest] = self.cold.assign(keys[rest], values[rest])
+        return found
+
+    def remove(self, keys: torch.Tensor) -> torch.Tensor:
+        keys = keys.contiguous().view(-1)
+        found = self.hot.remove(keys)
+        rest = self._idx(found == 0)
+        if rest.numel():
+            found[rest] = self.cold.remove(keys[rest])
+        return found
+
+    def find_or_insert(self, keys: torch.Tensor):
+        keys = keys.contiguous().view(-1)
+        out, found = self.find(keys)
+        miss = self._idx(found == 0)
+        if miss.numel():
+            km = keys[miss]
+            tier = self.hot if self._room_for(km.numel()) else self.cold
+            rows, _ = tier.find_or_insert(km)            # inserts the hashed initial row once per distinct key
+            if tier is self.hot:
+                self._hot_keys_ub += km.numel()
+            out[miss] = rows
+        return out, found
+
+    def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10) -> None:
+        # a key lives in one tier and each table ignores keys it does not hold: both see the whole batch
+        self.hot.apply_adagrad(keys, grads, lr, eps)
+        self.cold.apply_adagrad(keys, grads, lr, eps)
+
+    def apply_adam(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999,
+                   eps: float = 1e-8, step: int = 1) -> None:
+        self.hot.apply_adam(keys, grads, lr, beta1, beta2, eps, step)
+        self.cold.apply_adam(keys, grads, lr, beta1, beta2, eps, step)
+
+    def size(self) -> int:
+        return self.hot.size() + self.cold.size()
+
+    def export(self, with_state: bool = False):
+        a, b = self.hot.export(with_state=with_state), self.cold.export(with_state=with_state)
+        return tuple(None if x is None else torch.cat([x, y]) for x, y in zip(a, b))
+
+    # -- tier migration ------------------------------------------------------------------------------------
+    def _move(self, src, dst, keys: torch.Tensor) -> int:
+        """Move the keys that `src` holds into `dst`, rows and optimizer state; returns how many were moved."""
+        keys = torch.unique(keys.contiguous().view(-1))
+        vals, found = src.find(keys)
+        idx = self._idx(found != 0)
+        if not idx.numel():
+            return 0
+        k = keys[idx]
+        dst.insert(k, vals[idx])                         # state planes of new keys start at their initial values …
+        n_planes = {0: 0, 1: 1, 2: 2}[self.optimizer]
+        for plane in range(1, n_planes + 1):             # … and are then overwritten with the migrated state
+            st, _ = src.find_plane(plane, k)
+            dst.assign_plane(plane, k, st)
+        src.remove(k)
+        return int(k.numel())
+
+    def promote(self, keys: torch.Tensor) -> int:
+        """cold -> hot for the given keys (those that are cold), as many as the hot tier has room for."""
+        keys = torch.unique(keys.contiguous().view(-1))
+        _, in_cold = self.cold.find(keys)
+        cand = keys[self._idx(in_cold != 0)]
+        if not cand.numel():
+            return 0
+        self._hot_keys_ub = self.hot.size()
+        room = max(0, self.hot_key_limit - self._hot_keys_ub)
+        cand = cand[:room]
+        moved = self._move(self.cold, self.hot, cand) if cand.numel() else 0
+        self._hot_keys_ub += moved
+        return moved
+
+    def demote(self, keys: torch.Tensor) -> int:
+        """hot -> cold for the given keys (those that are hot)."""
+        moved = self._move(self.hot, self.cold, keys)
+        self._hot_keys_ub = max(0, self._hot_keys_ub - moved)
+        return moved

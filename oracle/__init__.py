@@ -57,6 +57,8 @@ def lib() -> C.CDLL:
         L.meo_find_mt.restype = None; L.meo_find_mt.argtypes = [vp, vp, sz, vp, vp, C.c_int]
         L.meo_insert.restype = None; L.meo_insert.argtypes = [vp, vp, vp, sz]
         L.meo_assign.restype = None; L.meo_assign.argtypes = [vp, vp, vp, sz, vp]
+        L.meo_find_plane.restype = None; L.meo_find_plane.argtypes = [vp, u32, vp, sz, vp, vp]
+        L.meo_assign_plane.restype = None; L.meo_assign_plane.argtypes = [vp, u32, vp, vp, sz, vp]
         L.meo_remove.restype = None; L.meo_remove.argtypes = [vp, vp, sz, vp]
         L.meo_find_or_insert.restype = None; L.meo_find_or_insert.argtypes = [vp, vp, sz, vp, vp]
         L.meo_export.restype = u64; L.meo_export.argtypes = [vp, vp, vp, vp, vp, u64]
@@ -166,6 +168,18 @@ class OracleTable:
         k = _keys(keys); v = _rows(values, k.size, self.dim)
         found = np.empty(k.size, np.uint8)
         lib().meo_assign(self._h, _p(k), _p(v), k.size, _p(found))
+        return found
+
+    def find_plane(self, plane, keys):
+        k = _keys(keys)
+        out = np.empty((k.size, self.dim), np.float32); found = np.empty(k.size, np.uint8)
+        lib().meo_find_plane(self._h, plane, _p(k), k.size, _p(out), _p(found))
+        return out, found
+
+    def assign_plane(self, plane, keys, values):
+        k = _keys(keys); v = _rows(values, k.size, self.dim)
+        found = np.empty(k.size, np.uint8)
+        lib().meo_assign_plane(self._h, plane, _p(k), _p(v), k.size, _p(found))
         return found
 
     def remove(self, keys):

@@ -191,6 +191,26 @@ void meo_assign(meo_table* t, const int64_t* keys, const float* values, size_t n
         if (found) found[i] = s >= 0;
     }
 }
+static float* plane_ptr(const meo_table* t, uint32_t plane) { return plane == 0 ? t->values : plane == 1 ? t->s1 : plane == 2 ? t->s2 : NULL; }
+void meo_find_plane(const meo_table* t, uint32_t plane, const int64_t* keys, size_t n, float* out, uint8_t* found) {
+    const uint32_t d = t->dim;
+    const float* p = plane_ptr(t, plane);
+    for (size_t i = 0; i < n; ++i) {
+        int64_t s = (!p || reserved(keys[i])) ? -1 : probe(t, keys[i], NULL);
+        if (s >= 0) memcpy(out + i * d, p + s * d, d * sizeof(float));
+        else fill_f32(out + i * d, d, plane == 0 ? t->default_value : 0.0f);
+        if (found) found[i] = s >= 0;
+    }
+}
+void meo_assign_plane(meo_table* t, uint32_t plane, const int64_t* keys, const float* values, size_t n, uint8_t* found) {
+    const uint32_t d = t->dim;
+    float* p = plane_ptr(t, plane);
+    for (size_t i = 0; i < n; ++i) {
+        int64_t s = (!p || has_reserved(t, keys[i])) ? -1 : probe(t, keys[i], NULL);
+        if (s >= 0) memcpy(p + s * d, values + i * d, d * sizeof(float));
+        if (found) found[i] = s >= 0;
+    }
+}
 void meo_remove(meo_table* t, const int64_t* keys, size_t n, uint8_t* found) {
     /* pass 1: found-mask as of before the call (duplicates all report the same) */
     if (found)

@@ -62,6 +62,8 @@ void meo_find(const meo_table* t, const int64_t* keys, size_t n, float* out, uin
 void meo_find_mt(const meo_table* t, const int64_t* keys, size_t n, float* out, uint8_t* found, int nthreads);
 void meo_insert(meo_table* t, const int64_t* keys, const float* values, size_t n);
 void meo_assign(meo_table* t, const int64_t* keys, const float* values, size_t n, uint8_t* found);
+void meo_find_plane(const meo_table* t, uint32_t plane, const int64_t* keys, size_t n, float* out, uint8_t* found);
+void meo_assign_plane(meo_table* t, uint32_t plane, const int64_t* keys, const float* values, size_t n, uint8_t* found);
 void meo_remove(meo_table* t, const int64_t* keys, size_t n, uint8_t* found);
 void meo_find_or_insert(meo_table* t, const int64_t* keys, size_t n, float* out, uint8_t* found);
 /* plane: 0 values, 1 acc|m, 2 v.  Returns number written (≤ cap pairs). state_out planes nullable. */

@@ -10,11 +10,20 @@ class CpuTable:
     def __init__(self, capacity, dim, **kw):
         self.o = oracle.OracleTable(capacity, dim, **kw)
         self.dim = dim
+        self.optimizer = kw.get("optimizer", 0)
         self.device = torch.device("cpu")
+        self.capacity = self.o.capacity
 
     def find(self, keys):
         out, found = self.o.find(keys.numpy())
         return torch.from_numpy(out), torch.from_numpy(found)
+
+    def find_plane(self, plane, keys):
+        out, found = self.o.find_plane(plane, keys.numpy())
+        return torch.from_numpy(out), torch.from_numpy(found)
+
+    def assign_plane(self, plane, keys, values):
+        return torch.from_numpy(self.o.assign_plane(plane, keys.numpy(), values.numpy()))
 
     def remove(self, keys):
         return torch.from_numpy(self.o.remove(keys.numpy()))

@@ -28,7 +28,7 @@ def test_header_symbols_exported(built):
 
 def test_config_struct_layout(built):
     from meepoembedding_amd import _lib
-    assert C.sizeof(_lib.Config) == 56 and C.sizeof(_lib.TableInfo) == 48
+    assert C.sizeof(_lib.Config) == 64 and C.sizeof(_lib.TableInfo) == 48
 
 
 def test_no_cpu_fallback(built):

@@ -1,0 +1,85 @@
+"""Hot/cold tier (meepoembedding_amd/tiered.py): the pair must behave like ONE table.  CPU: the host logic over two
+oracle-backed tiers vs a single oracle table.  GPU: hot tier in HBM + cold tier with rows in pinned host DRAM (the HIP
+kernels read/write them over PCIe) vs the same single oracle table."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from meepoembedding_amd import synth
+from meepoembedding_amd.tiered import TieredLookupTable
+
+DIM = 16
+KW = dict(default_value=0.5, initial_accumulator=0.1, initializer=oracle.INIT_UNIFORM, init_scale=0.05, init_seed=9)
+
+
+def _sorted(exp):
+    keys = exp[0]
+    order = np.argsort(keys)
+    return [None if x is None else x[order] for x in exp]
+
+
+def _drive(tiered, ref, dev, opt, n_iter=40, seed=0):
+    rng = np.random.default_rng(seed)
+    universe = synth.keys_np(70 + seed, 0, 3000)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    step = 0
+    for it in range(n_iter):
+        n = int(rng.integers(1, 900))
+        idx = np.minimum(rng.zipf(1.3, size=n) - 1, universe.size - 1) if rng.random() < 0.5 else rng.integers(0, universe.size, n)
+        keys = universe[idx]
+        rows = rng.standard_normal((n, DIM)).astype(np.float32)
+        op = rng.choice(["insert", "insert", "assign", "remove", "find", "find_or_insert", "apply", "promote", "demote"])
+        if op == "insert":
+            tiered.insert(T(keys), T(rows)); ref.insert(keys, rows)
+        elif op == "assign":
+            assert np.array_equal(tiered.assign(T(keys), T(rows)).cpu().numpy(), ref.assign(keys, rows))
+        elif op == "remove":
+            keys = keys[: max(1, n // 5)]
+            assert np.array_equal(tiered.remove(T(keys)).cpu().numpy(), ref.remove(keys))
+        elif op == "find":
+            out, found = tiered.find(T(keys)); eo, ef = ref.find(keys)
+            assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
+        elif op == "find_or_insert":
+            out, found = tiered.find_or_insert(T(keys)); eo, ef = ref.find_or_insert(keys)
+            assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
+        elif op == "apply":
+            step += 1
+            g = (rows * 0.01).astype(np.float32)
+            if opt == oracle.OPT_ADAGRAD:
+                tiered.apply_adagrad(T(keys), T(g), lr=0.02, eps=1e-10); ref.apply_adagrad(keys, g, 0.02, 1e-10)
+            else:
+                tiered.apply_adam(T(keys), T(g), lr=0.002, step=step); ref.apply_adam(keys, g, 0.002, 0.9, 0.999, 1e-8, step)
+        elif op == "promote":
+            tiered.promote(T(keys[:200]))      # migration must not change anything observable
+        else:
+            tiered.demote(T(keys[:200]))
+        assert tiered.size() == ref.size(), (it, op)
+    got = _sorted([None if x is None else x.cpu().numpy() for x in tiered.export(with_state=True)])
+    exp = _sorted(list(ref.export(with_state=True)))
+    assert np.array_equal(got[0], exp[0])
+    for a, b in zip(got[1:], exp[1:]):
+        if b is not None:
+            np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-9)
+    return tiered
+
+
+@pytest.mark.parametrize("opt", [oracle.OPT_ADAGRAD, oracle.OPT_ADAM])
+def test_tiered_cpu_logic(built, opt):
+    from _cpu_backend import CpuTable
+    hot = CpuTable(1024, DIM, optimizer=opt, **KW)
+    cold = CpuTable(8192, DIM, optimizer=opt, **KW)
+    ref = oracle.OracleTable(16384, DIM, optimizer=opt, **KW)
+    t = _drive(TieredLookupTable(hot, cold, hot_key_limit=600), ref, torch.device("cpu"), opt, seed=int(opt))
+    assert 0 < hot.size() <= 600 and cold.size() > 0, "both tiers must have been used"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt", [oracle.OPT_ADAGRAD, oracle.OPT_ADAM])
+def test_tiered_hbm_plus_pinned_host(dev, opt):
+    from meepoembedding_amd import LookupTable, _lib
+    hot = LookupTable(1024, DIM, device=dev, optimizer=opt, max_batch=4096, **KW)
+    cold = LookupTable(8192, DIM, device=dev, optimizer=opt, max_batch=4096, value_memory=_lib.MEM_HOST_PINNED, **KW)
+    ref = oracle.OracleTable(16384, DIM, optimizer=opt, **KW)
+    _drive(TieredLookupTable(hot, cold, hot_key_limit=600), ref, dev, opt, seed=10 + int(opt))
+    assert 0 < hot.size() <= 600 and cold.size() > 0
