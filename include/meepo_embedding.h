@@ -88,6 +88,10 @@ int mee_set_tuning(mee_table* t, const char* name, int value);
 /* ---- lookup-table operators (README.md:2 "lookuptable-style"; SPEC.md §3) ------------------------------ */
 /* out[i,:] = row of keys[i] or default_value; found nullable. */
 int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
+/* second-tier pass after a mee_find on another table (same keys/out/found buffers): positions with d_found[i] == 0
+ * that THIS table holds get their row and d_found[i] = 1; every other position is left untouched.  No host sync, no
+ * compaction: this is how a hot (HBM) table is backed by a cold (pinned host) one inside one stream. */
+int mee_find_missing(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
 /* upsert; duplicate keys: last occurrence wins. */
 int mee_insert(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, void* stream);
 /* overwrite only if present; d_found nullable; duplicates: last occurrence wins. */

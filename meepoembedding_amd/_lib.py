@@ -60,6 +60,7 @@ PROTOTYPES = {
     "mee_clear": (C.c_int, [_vp, _vp]),
     "mee_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mee_find": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "mee_find_missing": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_insert": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "mee_assign": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "mee_find_plane": (C.c_int, [_vp, _u32, _vp, _sz, _vp, _vp, _vp]),

@@ -123,6 +123,9 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
             inb[r] = i < n;
             key[r] = inb[r] ? keys[i] : kEmpty;
             act[r] = inb[r] && !reserved_key(key[r]);
+            if constexpr ((NT & 8) != 0) {  // second-tier pass: only positions an earlier find left as missing
+                inb[r] = act[r] = act[r] && found[i] == 0;
+            }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint64_t i = base + r * 4 + tile;
-                if (inb[r]) {
+                if (inb[r] && (!(NT & 8) || slot[r] >= 0)) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) { if (NT & 4) out[i * DIM4 + c * 16 + tl] = row[r][c]; else __builtin_nontemporal_store(row[r][c], &out[i * DIM4 + c * 16 + tl]); }
                 }
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint64_t i = base + r * 4 + tile;
-                if (inb[r])
+                if (inb[r] && (!(NT & 8) || slot[r] >= 0))
                     for (uint32_t c = tl; c < dim4; c += 16)
                         out[i * dim4 + c] = slot[r] >= 0 ? values[(uint64_t)slot[r] * dim4 + c] : def4;
             }
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint64_t i = base + r * 4 + tile;
-                if (inb[r] && tl == 0) found[i] = slot[r] >= 0;
+                if (inb[r] && tl == 0 && (!(NT & 8) || slot[r] >= 0)) found[i] = slot[r] >= 0;
             }
         }
     }
@@ -912,7 +915,7 @@ static const float* plane_of(const mee_table* t, uint32_t plane) {
 }
 
 static int find_plane(const mee_table* t, const float* plane, float miss_value, const int64_t* d_keys, size_t n, float* d_out,
-                      uint8_t* d_found, void* stream) {
+                      uint8_t* d_found, void* stream, bool missing_only = false) {
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -924,6 +927,12 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
 #define FIND1(D4, RR, NT) find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4)
     const int nt = t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
 #define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
+    if (missing_only) {  // sparse second pass over a batch most of which is already resolved: one key in flight per tile
+        const unsigned g1 = grid_for(n, 16, 1u << 22);
+        if (t->dim4 == 16) find_kernel<16, 1, 12><<<g1, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4);
+        else if (t->dim4 == 32) find_kernel<32, 1, 12><<<g1, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4);
+        else find_kernel<0, 1, 12><<<g1, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4);
+    } else
     if (t->dim4 == 16) { if (R == 8) FIND(16, 8); else if (R == 4) FIND(16, 4); else if (R == 2) FIND(16, 2); else FIND(16, 1); }
     else if (t->dim4 == 32) { if (R == 4) FIND(32, 4); else if (R == 2) FIND(32, 2); else FIND(32, 1); }
     else { if (R == 2) FIND(0, 2); else FIND(0, 1); }
@@ -936,6 +945,11 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
 int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
     if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find: null argument");
     return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream);
+}
+
+int mee_find_missing(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
+    if (!t || (n && (!d_keys || !d_out || !d_found))) return fail(MEE_ERR_INVALID_ARG, "mee_find_missing: null argument");
+    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, true);
 }
 
 int mee_find_plane(const mee_table* t, uint32_t plane, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {

@@ -86,6 +86,11 @@ class LookupTable:
                                   self._s()))
         return out, found
 
+    def find_missing(self, keys: torch.Tensor, out: torch.Tensor, found: torch.Tensor) -> None:
+        """Second-tier pass: fill the positions an earlier find (on another table) left with found == 0."""
+        k = self._keys(keys)
+        check(_lib.lib().mee_find_missing(self._h, k.data_ptr(), k.numel(), out.data_ptr(), found.data_ptr(), self._s()))
+
     def insert(self, keys: torch.Tensor, values: torch.Tensor) -> None:
         k = self._keys(keys)
         v = self._rows(values, k.numel())

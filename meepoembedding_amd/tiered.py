@@ -44,11 +44,8 @@ class TieredLookupTable:
     def find(self, keys: torch.Tensor):
         keys = keys.contiguous().view(-1)
         out, found = self.hot.find(keys)
-        miss = self._idx(found == 0)
-        if miss.numel():
-            rows_c, found_c = self.cold.find(keys[miss])
-            out[miss] = rows_c
-            found[miss] = found_c
+        # second pass on the same buffers: the cold table fills what the hot one missed — no host sync, no compaction
+        self.cold.find_missing(keys, out, found)
         return out, found
 
     def insert(self, keys: torch.Tensor, values: torch.Tensor) -> None:

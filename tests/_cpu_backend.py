@@ -28,6 +28,14 @@ class CpuTable:
     def remove(self, keys):
         return torch.from_numpy(self.o.remove(keys.numpy()))
 
+    def find_missing(self, keys, out, found):
+        miss = torch.nonzero(found == 0).view(-1)
+        if miss.numel():
+            rows, f = self.find(keys[miss])
+            hit = f != 0
+            out[miss[hit]] = rows[hit]
+            found[miss[hit]] = 1
+
     def find_or_insert(self, keys):
         out, found = self.o.find_or_insert(keys.numpy())
         return torch.from_numpy(out), torch.from_numpy(found)
