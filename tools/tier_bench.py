@@ -11,11 +11,13 @@ ap.add_argument("--hot-keys", type=int, default=50_000_000)
 ap.add_argument("--cold-keys", type=int, default=20_000_000)
 ap.add_argument("--batch", type=int, default=1 << 18)
 ap.add_argument("--dim", type=int, default=64)
+ap.add_argument("--load", type=float, default=0.75)
+ap.add_argument("--fracs", default="0,0.01,0.05,0.2,1.0")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 t0 = time.time()
-hot = LookupTable(int(a.hot_keys / 0.75), a.dim, device=dev, max_batch=1 << 20)
-cold = LookupTable(int(a.cold_keys / 0.75), a.dim, device=dev, max_batch=1 << 20, value_memory=_lib.MEM_HOST_PINNED)
+hot = LookupTable(int(a.hot_keys / a.load), a.dim, device=dev, max_batch=1 << 20)
+cold = LookupTable(int(a.cold_keys / a.load), a.dim, device=dev, max_batch=1 << 20, value_memory=_lib.MEM_HOST_PINNED)
 print(f"tables created in {time.time() - t0:.1f}s: hot {hot.table_bytes / 1e9:.1f} GB (HBM), cold {cold.table_bytes / 1e9:.1f} GB (keys in HBM, rows in pinned host)", flush=True)
 chunk = 1 << 20
 t0 = time.time()
@@ -29,7 +31,7 @@ print(f"populate: hot {a.hot_keys / (t1 - t0) / 1e6:.0f} M keys/s, cold {a.cold_
 tiered = TieredLookupTable(hot, cold, hot_key_limit=a.hot_keys)
 g = torch.Generator(device=dev); g.manual_seed(1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for cold_frac in (0.0, 0.01, 0.05, 0.2, 1.0):
+for cold_frac in [float(x) for x in a.fracs.split(',')]:
     batches = []
     for _ in range(8):
         nh = int(a.batch * (1 - cold_frac)); nc = a.batch - nh
