@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--mode", choices=["find", "train"], default="find",
                     help="find = configs[1] (the driver's metric); train = configs[2]: find + sparse-Adagrad apply per step (N=1 only)")
     ap.add_argument("--pipeline", type=int, default=1, help="sharded only: steps in flight on separate HIP streams (1 = off)")
+    ap.add_argument("--dedup", action="store_true", help="sharded only: exchange only the batch's distinct keys (pays off on skewed streams)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even at N=1 (rehearsal of the N>1 code)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -174,9 +175,9 @@ def main():
 
         def step(i):
             if depth == 1:
-                return shs[0].find(batches[i % n_batches])
+                return shs[0].find(batches[i % n_batches], dedup=args.dedup)
             with torch.cuda.stream(streams[i % depth]):
-                return shs[i % depth].find(batches[i % n_batches])
+                return shs[i % depth].find(batches[i % n_batches], dedup=args.dedup)
     elif train:
         grads = [torch.randn(batch, dim, device=dev) * 0.01 for _ in range(4)]   # N(0, 1e-2), SURVEY §8d config 3
 
@@ -262,7 +263,7 @@ def main():
                                     f"configs[1]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim} fp32, forward find only, {batch}-key batches"),
                        "keys_per_gpu": keys_per_gpu, "local_size": local_size, "dim": dim, "batch_per_rank": batch, "load_factor": args.load,
                        "key_distribution": args.dist, "table_gb": round(table.table_bytes / 1e9, 2),
-                       "parallelism": (f"row-shard x{world}" + (f", {args.pipeline} steps in flight" if args.pipeline > 1 else "")) if sharded else "single GPU"},
+                       "parallelism": (f"row-shard x{world}" + (f", {args.pipeline} steps in flight" if args.pipeline > 1 else "") + (", pre-exchange dedup" if args.dedup else "")) if sharded else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic if not train else None, "kernel": "find_kernel" if not train else "whole step (find + 5 apply kernels)",
                          "avg_launch_us": kern_s * 1e6, "algorithmic_bytes_per_lookup": bpl if not train else step_bytes / batch,

@@ -42,8 +42,10 @@ class ShardedLookupTable:
         return out
 
     # -- operators ---------------------------------------------------------------------------------------
-    def _lookup(self, keys: torch.Tensor, insert_missing: bool):
+    def _lookup(self, keys: torch.Tensor, insert_missing: bool, dedup: bool = False):
         keys = keys.contiguous().view(-1)
+        if dedup:
+            return self._lookup_dedup(keys, insert_missing)
         send_keys, perm, ss, rs = self._route(keys)
         recv_keys = self._a2a(send_keys, ss, rs)
         if insert_missing:
@@ -54,11 +56,24 @@ class ShardedLookupTable:
         found_back = self._a2a(found, rs, ss)
         return self.router.scatter_rows(rows_back, perm), self.router.scatter_rows(found_back, perm)
 
-    def find(self, keys: torch.Tensor):
-        return self._lookup(keys, False)
+    def _lookup_dedup(self, keys: torch.Tensor, insert_missing: bool):
+        """Pre-exchange duplicate elimination: only the batch's DISTINCT keys cross xGMI (keys out, rows back); every
+        occurrence is then served from its distinct key's row.  On skewed streams the link traffic scales with the
+        number of unique keys while the metric counts lookups (SURVEY §7 hard part 1)."""
+        uniq, _, _, inverse = self.local.dedup_sum(keys)       # the local table's group table does the grouping
+        rows_u, found_u = self._lookup(uniq, insert_missing)
+        # reserved keys have inverse -1: point them at an extra all-default "missing" row
+        miss_row, _ = self.local.find(keys.new_full((1,), -(1 << 63)))
+        rows_u = torch.cat([rows_u, miss_row])
+        found_u = torch.cat([found_u, found_u.new_zeros(1)])
+        inverse = torch.where(inverse < 0, torch.full_like(inverse, uniq.numel()), inverse)
+        return self.router.gather_rows(rows_u, inverse, n_out=keys.numel()), self.router.gather_rows(found_u, inverse, n_out=keys.numel())
 
-    def find_or_insert(self, keys: torch.Tensor):
-        return self._lookup(keys, True)
+    def find(self, keys: torch.Tensor, dedup: bool = False):
+        return self._lookup(keys, False, dedup)
+
+    def find_or_insert(self, keys: torch.Tensor, dedup: bool = False):
+        return self._lookup(keys, True, dedup)
 
     def remove(self, keys: torch.Tensor) -> torch.Tensor:
         keys = keys.contiguous().view(-1)

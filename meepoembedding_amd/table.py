@@ -253,13 +253,13 @@ class Router:
             check(_lib.lib().mee_scatter_rows(r.data_ptr(), perm.data_ptr(), n, rb, out.data_ptr(), _stream_ptr(self.device)))
         return out
 
-    def gather_rows(self, rows: torch.Tensor, perm: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        """out[q] = rows[perm[q]]"""
+    def gather_rows(self, rows: torch.Tensor, perm: torch.Tensor, out: torch.Tensor | None = None, n_out: int | None = None) -> torch.Tensor:
+        """out[q] = rows[perm[q]] for q < perm.numel(); `rows` may have a different number of rows than `perm`."""
         r = rows.contiguous()
         n = perm.numel()
+        rb = r.numel() * r.element_size() // max(r.shape[0], 1) if r.dim() >= 1 and r.shape[0] else 0
         if out is None:
-            out = torch.empty_like(r)
-        rb = r.numel() * r.element_size() // max(n, 1)
+            out = torch.empty((n,) + tuple(r.shape[1:]), dtype=r.dtype, device=r.device)
         with torch.cuda.device(self.device):
             check(_lib.lib().mee_gather_rows(r.data_ptr(), perm.data_ptr(), n, rb, out.data_ptr(), _stream_ptr(self.device)))
         return out

@@ -28,6 +28,10 @@ class CpuTable:
     def remove(self, keys):
         return torch.from_numpy(self.o.remove(keys.numpy()))
 
+    def dedup_sum(self, keys, grads=None):
+        uniq, gs, inv, cnt = oracle.dedup_sum(keys.numpy(), None if grads is None else grads.numpy(), self.dim)
+        return torch.from_numpy(uniq), (None if grads is None else torch.from_numpy(gs)), torch.from_numpy(cnt.astype(np.int32)), torch.from_numpy(inv)
+
     def find_missing(self, keys, out, found):
         miss = torch.nonzero(found == 0).view(-1)
         if miss.numel():
@@ -72,5 +76,5 @@ class CpuRouter:
         out[perm] = rows
         return out
 
-    def gather_rows(self, rows, perm):
+    def gather_rows(self, rows, perm, n_out=None):
         return rows[perm].contiguous()

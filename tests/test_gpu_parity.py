@@ -380,3 +380,31 @@ def test_random_op_sequences(dev, seed, dim, opt):
     for x, y in zip(g_[1:], o_[1:]):
         if y is not None:
             np.testing.assert_allclose(x[a], y[b], rtol=RTOL, atol=ATOL)
+
+
+def test_ops_are_graph_capturable(dev):
+    """The header promises that the hot ops neither allocate nor synchronise: capture find + Adagrad apply + insert in a
+    hipGraph (torch.cuda.graph on a side stream), replay it twice, and check the table against the oracle."""
+    dim, n = 64, 5000
+    keys = synth.keys_np(61, 0, n); rows = synth.rows_np(keys, dim, 2)
+    extra = synth.keys_np(62, 0, 100); extra_rows = synth.rows_np(extra, dim, 3)
+    g = (synth.rows_np(keys, dim, 6) * 0.02).astype(np.float32)
+    t = LookupTable(16384, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=n); o = oracle.OracleTable(16384, dim, optimizer=oracle.OPT_ADAGRAD)
+    dk, dr, dg, dek, der = T(keys, dev), T(rows, dev), T(g, dev), T(extra, dev), T(extra_rows, dev)
+    t.insert(dk, dr); o.insert(keys, rows)
+    out = torch.empty((n, dim), dtype=torch.float32, device=dev); found = torch.empty(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        t.find(dk, out=out, found=found)
+        t.apply_adagrad(dk, dg, lr=0.01, eps=1e-10)
+        t.insert(dek, der)
+    for _ in range(2):
+        eo, ef = o.find(keys)
+        o.apply_adagrad(keys, g, 0.01, 1e-10); o.insert(extra, extra_rows)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), eo) and np.array_equal(found.cpu().numpy(), ef)
+    assert t.size() == o.size() == n + 100
+    got, _ = t.find(dk); exp, _ = o.find(keys)
+    assert np.array_equal(got.cpu().numpy(), exp)

@@ -75,6 +75,11 @@ def _run_rank(rank, world, port, backend, q):
         dist.barrier()
         probe = torch.from_numpy(np.concatenate([synth.keys_np(1, 0, NKEYS)[rank::3], synth.keys_np(9, rank * 50, 50)])).to(dev)
         out, found = sh.find(probe)
+        # the same lookup with pre-exchange dedup on a duplicate-heavy batch (+ a reserved key) must give the same answer
+        dup = torch.cat([probe[:500].repeat(7), probe[-60:], torch.tensor([oracle.EMPTY_KEY], device=dev)])
+        o1, f1 = sh.find(dup)
+        o2, f2 = sh.find(dup, dedup=True)
+        assert torch.equal(o1, o2) and torch.equal(f1, f2)
         total = sh.size()
         ek, ev, ea, _ = sh.export_local(with_state=True)
         q.put((rank, probe.cpu().numpy(), out.cpu().numpy(), found.cpu().numpy(), total, ek.cpu().numpy(), ev.cpu().numpy(), ea.cpu().numpy()))
