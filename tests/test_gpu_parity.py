@@ -408,3 +408,32 @@ def test_ops_are_graph_capturable(dev):
     assert t.size() == o.size() == n + 100
     got, _ = t.find(dk); exp, _ = o.find(keys)
     assert np.array_equal(got.cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("dim", [64, 128, 24])
+def test_find_parity_under_every_tuning_knob(dev, dim):
+    """Performance knobs must never change results: every rounds / cache-policy / grid-cap variant of find_kernel
+    (and both apply_single variants) against the oracle, with misses, a reserved key and a ragged batch size."""
+    n = 30011
+    keys = synth.keys_np(81, 0, 2 * n); rows = synth.rows_np(keys[:n], dim, 2)
+    t = LookupTable(int(n / 0.8), dim, device=dev, max_batch=2 * n, default_value=1.5, optimizer=OPT_ADAGRAD)
+    o = oracle.OracleTable(int(n / 0.8), dim, default_value=1.5, optimizer=oracle.OPT_ADAGRAD)
+    t.insert(T(keys[:n], dev), T(rows, dev)); o.insert(keys[:n], rows)
+    q = keys[np.random.default_rng(0).permutation(2 * n)][: n + 7].copy()
+    q[5] = oracle.RECLAIMED_KEY
+    eo, ef = o.find(q)
+    dq = T(q, dev)
+    for rounds in (0, 1, 2, 4, 8):
+        for nt in (-1, 0, 1, 2, 3, 4, 5, 6, 7):
+            for cap in (0, 64):
+                t.set_tuning("find_rounds", rounds); t.set_tuning("find_nt", nt); t.set_tuning("find_grid_cap", cap)
+                out, found = t.find(dq)
+                assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo), (rounds, nt, cap)
+    with pytest.raises(MeepoError):
+        t.set_tuning("no_such_knob", 1)
+    g = (synth.rows_np(keys[:n], dim, 6) * 0.02).astype(np.float32)
+    for ar in (1, 2):
+        t.set_tuning("apply_rounds", ar)
+        t.apply_adagrad(T(keys[:n], dev), T(g, dev), lr=0.01); o.apply_adagrad(keys[:n], g, 0.01, 1e-10)
+        out, _ = t.find(T(keys[:n], dev)); exp, _ = o.find(keys[:n])
+        assert np.array_equal(out.cpu().numpy(), exp), ar

@@ -50,13 +50,16 @@ def _removed(rank):
     return synth.keys_np(1, 0, NKEYS)[rank * 7::101]
 
 
-def _run_rank(rank, world, port, backend, q):
+def _run_rank(rank, world, port, backend, q, tiered=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     if backend == "gloo":
         from _cpu_backend import CpuRouter, CpuTable
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dev = torch.device("cpu")
         local = CpuTable(16384, DIM, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
+        if tiered:   # BASELINE configs[4]: every shard is a hot/cold pair
+            from meepoembedding_amd.tiered import TieredLookupTable
+            local = TieredLookupTable(CpuTable(2048, DIM, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1), local, hot_key_limit=1200)
         router = CpuRouter(world)
     else:
         from meepoembedding_amd import OPT_ADAGRAD, LookupTable, Router
@@ -78,8 +81,9 @@ def _run_rank(rank, world, port, backend, q):
         # the same lookup with pre-exchange dedup on a duplicate-heavy batch (+ a reserved key) must give the same answer
         dup = torch.cat([probe[:500].repeat(7), probe[-60:], torch.tensor([oracle.EMPTY_KEY], device=dev)])
         o1, f1 = sh.find(dup)
-        o2, f2 = sh.find(dup, dedup=True)
-        assert torch.equal(o1, o2) and torch.equal(f1, f2)
+        if not tiered:
+            o2, f2 = sh.find(dup, dedup=True)
+            assert torch.equal(o1, o2) and torch.equal(f1, f2)
         total = sh.size()
         ek, ev, ea, _ = sh.export_local(with_state=True)
         q.put((rank, probe.cpu().numpy(), out.cpu().numpy(), found.cpu().numpy(), total, ek.cpu().numpy(), ev.cpu().numpy(), ea.cpu().numpy()))
@@ -106,11 +110,11 @@ def _check(results, world):
     np.testing.assert_allclose(ga[a], oa[b], rtol=1e-6, atol=1e-9)
 
 
-def _launch(world, backend):
+def _launch(world, backend, tiered=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_rank, args=(r, world, port, backend, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run_rank, args=(r, world, port, backend, q, tiered)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in range(world)]
@@ -123,6 +127,11 @@ def _launch(world, backend):
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_gloo_cpu(built, world):
     _check(_launch(world, "gloo"), world)
+
+
+def test_sharded_tiered_gloo_cpu(built):
+    """configs[4] shape: row-sharded, every shard a hot/cold pair — still one logical table."""
+    _check(_launch(2, "gloo", tiered=True), 2)
 
 
 @pytest.mark.gpu
