@@ -178,8 +178,17 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
         if (found) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const uint64_t i = base + r * 4 + tile;
-                if (inb[r] && tl == 0 && (!(NT & 8) || slot[r] >= 0)) found[i] = slot[r] >= 0;
+                const uint64_t i0 = base + r * 4;
+                if ((NT & 8) == 0 && i0 + 4 <= n && (reinterpret_cast<uintptr_t>(found) & 3) == 0) {
+                    // the four tiles' found bytes of this round leave as ONE aligned 4-byte store
+                    const uint64_t m = __ballot(slot[r] >= 0);
+                    const uint32_t w = (uint32_t)(m & 1) | ((uint32_t)((m >> 16) & 1) << 8) | ((uint32_t)((m >> 32) & 1) << 16) |
+                                       ((uint32_t)((m >> 48) & 1) << 24);
+                    if (lane == 0) *reinterpret_cast<uint32_t*>(found + i0) = w;
+                } else {
+                    const uint64_t i = i0 + tile;
+                    if (inb[r] && tl == 0 && (!(NT & 8) || slot[r] >= 0)) found[i] = slot[r] >= 0;
+                }
             }
         }
     }
