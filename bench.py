@@ -128,18 +128,20 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
 
-    import __graft_entry__
-    if rank == 0:
-        __graft_entry__.build()
-    from meepoembedding_amd import LookupTable, Router, hash_batch, synth
-    from meepoembedding_amd.sharded import ShardedLookupTable
-
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     if world > 1 or args.force_sharded:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
+    # rank 0 (re)builds the native library if it is stale; nobody loads it before that is done
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if dist.is_initialized():
+        dist.barrier()
+    from meepoembedding_amd import LookupTable, Router, hash_batch, synth
+    from meepoembedding_amd.sharded import ShardedLookupTable
 
     def log(msg):
         if args.verbose and rank == 0:

@@ -1091,7 +1091,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
-    const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
+    const unsigned gl = grid_for(n, 256, 1u << 22);
     const unsigned gp = grid_for(n, 1024, 1u << 22);
     MEE_HIP(hipMemsetAsync(t->op, 0, 16, st));  // n_uniq, n_occ, n_big, n_work
     group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr);

@@ -23,6 +23,9 @@ class ShardedLookupTable:
         self.local, self.router, self.group = local, router, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # a gloo group cannot move device tensors: stage them through host memory (rehearsals of the multi-rank GPU
+        # path on a single-GPU box; production uses the "nccl" backend = RCCL over xGMI, no staging)
+        self._stage = dist.get_backend(group) == "gloo"
         self.dim = local.dim
         if router.n_shards != self.world:
             raise ValueError(f"router has {router.n_shards} shards, process group has {self.world} ranks")
@@ -31,12 +34,22 @@ class ShardedLookupTable:
     def _route(self, keys: torch.Tensor):
         """partition + counts exchange. Returns (send_keys, perm, send_splits, recv_splits)."""
         send_keys, counts, perm = self.router.partition(keys)
+        if self._stage and counts.is_cuda:
+            c_host = counts.cpu()
+            r_host = torch.empty_like(c_host)
+            dist.all_to_all_single(r_host, c_host, group=self.group)
+            return send_keys, perm, c_host.tolist(), r_host.tolist()
         recv_counts = torch.empty_like(counts)
         dist.all_to_all_single(recv_counts, counts, group=self.group)
         both = torch.stack([counts, recv_counts]).cpu()  # the one host sync of the exchange
         return send_keys, perm, both[0].tolist(), both[1].tolist()
 
     def _a2a(self, t: torch.Tensor, in_splits, out_splits) -> torch.Tensor:
+        if self._stage and t.is_cuda:
+            src = t.contiguous().cpu()
+            dst = torch.empty((sum(out_splits),) + tuple(t.shape[1:]), dtype=t.dtype)
+            dist.all_to_all_single(dst, src, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+            return dst.to(t.device)
         out = torch.empty((sum(out_splits),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_to_all_single(out, t.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
         return out
@@ -107,7 +120,7 @@ class ShardedLookupTable:
         self.local.apply_adam(rk, rg, lr, beta1, beta2, eps, step)
 
     def size(self) -> int:
-        t = torch.tensor([self.local.size()], dtype=torch.int64, device=self._dev())
+        t = torch.tensor([self.local.size()], dtype=torch.int64, device="cpu" if self._stage else self._dev())
         dist.all_reduce(t, group=self.group)
         return int(t.item())
 

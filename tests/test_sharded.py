@@ -61,6 +61,15 @@ def _run_rank(rank, world, port, backend, q, tiered=False):
             from meepoembedding_amd.tiered import TieredLookupTable
             local = TieredLookupTable(CpuTable(2048, DIM, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1), local, hot_key_limit=1200)
         router = CpuRouter(world)
+    elif backend == "gloo-gpu":
+        # several ranks share ONE GPU; the exchange is staged through host memory over gloo — every HIP kernel of the
+        # multi-rank path (partition with G > 1, find on received keys, un-permute) runs for real
+        from meepoembedding_amd import OPT_ADAGRAD, LookupTable, Router
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        local = LookupTable(16384, DIM, device=dev, optimizer=OPT_ADAGRAD, initial_accumulator=0.1, max_batch=world * BATCH)
+        router = Router(world, BATCH, device=dev)
     else:
         from meepoembedding_amd import OPT_ADAGRAD, LookupTable, Router
         dev = torch.device("cuda", rank)
@@ -132,6 +141,12 @@ def test_sharded_gloo_cpu(built, world):
 def test_sharded_tiered_gloo_cpu(built):
     """configs[4] shape: row-sharded, every shard a hot/cold pair — still one logical table."""
     _check(_launch(2, "gloo", tiered=True), 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_multi_rank_on_one_gpu(dev, world):
+    _check(_launch(world, "gloo-gpu"), world)
 
 
 @pytest.mark.gpu
