@@ -37,13 +37,15 @@ struct OpCounters {          // device-resident, zeroed at the start of each op 
     uint32_t n_big;          // groups with more than kChunk occurrences
     uint32_t n_work;         // chunk leaders listed for apply_chunk_kernel
     unsigned long long n_export;  // pairs exported / keys counted
+    uint32_t n_part;         // fp64 partial-sum rows reserved by big groups
+    uint32_t pad;
 };
 struct GroupTable {            // S entries, indexed by h
     unsigned long long* skeys; // key ^ kBias, 0 = empty
     uint32_t* sval;            // COUNT: occurrences added by blocks other than the claimer's | LAST: 1 + highest position
     uint32_t* sval0;           // COUNT: occurrences inside the block whose CAS claimed the entry (plain store, no atomic)
     uint32_t* soffs;           // start of the group's slice of the occurrence list
-    uint32_t* sbig;            // fp64 accumulator row of a group with more than kChunk occurrences
+    uint32_t* sbig;            // first fp64 partial-sum row of a group with more than kChunk occurrences
     uint32_t* sgrp;            // index of the group in the unique list (standalone dedup)
     long long* sres;           // find_or_insert: slot | present<<62, -1 = not stored
     uint64_t smask;
@@ -51,7 +53,7 @@ struct GroupTable {            // S entries, indexed by h
 struct BatchScratch {          // max_batch entries, indexed by batch position unless noted
     uint32_t *hidx, *rank, *pcnt, *occ, *uniq_h, *work;
     uint32_t* bigh;            // [max_big] group-table index of each big group
-    double* gacc;              // [max_big][dim] fp64 accumulator rows, all-zero between ops
+    double* gacc;              // [max_big][dim] fp64 partial-sum rows: one per chunk of a big group, a group's rows contiguous
 };
 
 
@@ -319,9 +321,8 @@ __global__ __launch_bounds__(1024) void group_plan_kernel(uint32_t n, GroupTable
     } else {
         if (flag_b) bs.work[base_work + ex_b] = i;
         if (leader && cnt > kChunk) {  // rare: at most n / kChunk groups per batch
-            const uint32_t b = atomicAdd(&op->n_big, 1u);
-            g.sbig[h] = b;
-            bs.bigh[b] = h;
+            bs.bigh[atomicAdd(&op->n_big, 1u)] = h;
+            g.sbig[h] = atomicAdd(&op->n_part, (cnt + kChunk - 1) / kChunk);  // one partial-sum row per chunk
         }
     }
 }
@@ -569,8 +570,8 @@ __device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, cons
 
 // Pass 2 over the work list (chunk leaders: the occurrences with rank 0, kChunk, 2*kChunk, ... of each multi-key).
 // A tile sums its chunk of the group's occurrence list in fp64.  Groups of <= kChunk occurrences are finished here
-// (one update, entry released); larger groups add their chunk sums into the group's fp64 accumulator row with f64
-// atomics (order-insensitive to <= 1 fp32 ulp, SPEC.md §4) and are finished by apply_big_kernel.
+// (one update, entry released); a chunk of a larger group stores its fp64 sums as one row of the group's partial-sum
+// block (plain stores: f64 atomics on a hot key's row serialise on four L2 lines) and apply_big_kernel finishes it.
 __global__ __launch_bounds__(256) void apply_chunk_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1,
                                                           float4* s2, uint64_t nb, uint32_t dim4,
                                                           const int64_t* __restrict__ keys,
@@ -594,45 +595,68 @@ __global__ __launch_bounds__(256) void apply_chunk_kernel(const int64_t* __restr
         const uint32_t h = bs.hidx[i];
         const uint32_t first = g.soffs[h] + r;
         const uint32_t count = min(kChunk, cnt - r);
-        const uint32_t big = small ? 0 : g.sbig[h];
+        const uint32_t part = small ? 0 : g.sbig[h] + r / kChunk;  // this chunk's row in the group's partial-sum block
         for (uint32_t c = tl; c < dim4; c += 16) {
             double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
             chunk_sum(grads, bs.occ, first, count, dim4, c, sx, sy, sz, sw);
             if (small) {
                 if (slot >= 0) update_row(a, values, s1, s2, (uint64_t)slot * dim4 + c, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
             } else {
-                double* dst = bs.gacc + ((uint64_t)big * dim4 + c) * 4;
-                atomicAdd(dst + 0, sx); atomicAdd(dst + 1, sy); atomicAdd(dst + 2, sz); atomicAdd(dst + 3, sw);
+                double* dst = bs.gacc + ((uint64_t)part * dim4 + c) * 4;
+                dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = sw;
             }
         }
         if (small && tl == 0) group_release(g, h);
     }
 }
 
-// Pass 3 over the (few) groups with more than kChunk occurrences: read the accumulated fp64 sums, round once,
-// update once, zero the accumulator row and release the group-table entry.
+// Pass 3, one 256-thread block per group with more than kChunk occurrences: the 16 tiles sum the group's partial-sum
+// rows (tile t takes rows t, t+16, ...; 4 rows in flight), the tile totals are combined through LDS in fixed order
+// (so the result does not depend on scheduling), then one rounding, one update, and the entry is released.
 __global__ __launch_bounds__(256) void apply_big_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1,
                                                         float4* s2, uint64_t nb, uint32_t dim4, GroupTable g, BatchScratch bs,
                                                         const OpCounters* op, OptArgs a) {
+    __shared__ double lsum[16][16][4];
+    __shared__ long long lslot;
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const int bt = (threadIdx.x >> 6) * 4 + tile;  // tile index inside the block, 0..15
     const uint32_t n_big = op->n_big;
-    for (uint32_t base = wave * 4; base < n_big; base += n_waves * 4) {
-        const uint32_t b = base + tile;
-        const bool inb = b < n_big;
-        const uint32_t h = inb ? bs.bigh[b] : 0;
-        const int64_t key = inb ? (int64_t)(g.skeys[h] ^ kBias) : kEmpty;
+    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {  // block-uniform
+        const uint32_t h = bs.bigh[b];
+        const uint32_t cnt = g.sval0[h] + g.sval[h];
+        const uint32_t n_rows = (cnt + kChunk - 1) / kChunk, row0 = g.sbig[h];
+        const int64_t key = (int64_t)(g.skeys[h] ^ kBias);
         bool is_new, full;
-        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, inb, tile, tl, is_new, full);
-        if (!inb) continue;
-        for (uint32_t c = tl; c < dim4; c += 16) {
-            double* src = bs.gacc + ((uint64_t)b * dim4 + c) * 4;
-            const float4 gs = make_float4((float)src[0], (float)src[1], (float)src[2], (float)src[3]);
-            src[0] = 0.0; src[1] = 0.0; src[2] = 0.0; src[3] = 0.0;
-            if (slot >= 0) update_row(a, values, s1, s2, (uint64_t)slot * dim4 + c, gs);
+        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, threadIdx.x < 16, tile, tl, is_new, full);
+        if (threadIdx.x == 0) lslot = slot;
+        for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {  // block-uniform trip count: there are barriers inside
+            const uint32_t c = c0 + tl;
+            const bool live = c < dim4;
+            double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+            for (uint32_t rr = bt; live && rr < n_rows; rr += 64) {
+                double v[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t row = rr + q * 16;
+                    const double* src = bs.gacc + ((uint64_t)(row0 + row) * dim4 + c) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[q][e] = row < n_rows ? src[e] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { sx += v[q][0]; sy += v[q][1]; sz += v[q][2]; sw += v[q][3]; }
+            }
+            lsum[bt][tl][0] = sx; lsum[bt][tl][1] = sy; lsum[bt][tl][2] = sz; lsum[bt][tl][3] = sw;
+            __syncthreads();
+            if (bt == 0) {
+                double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { t0 += lsum[q][tl][0]; t1 += lsum[q][tl][1]; t2 += lsum[q][tl][2]; t3 += lsum[q][tl][3]; }
+                if (live && lslot >= 0) update_row(a, values, s1, s2, (uint64_t)lslot * dim4 + c, make_float4((float)t0, (float)t1, (float)t2, (float)t3));
+            }
+            __syncthreads();
         }
-        if (tl == 0) group_release(g, h);
+        if (threadIdx.x == 0) group_release(g, h);
+        __syncthreads();
     }
 }
 
@@ -1093,7 +1117,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22);
     const unsigned gp = grid_for(n, 1024, 1u << 22);
-    MEE_HIP(hipMemsetAsync(t->op, 0, 16, st));  // n_uniq, n_occ, n_big, n_work
+    MEE_HIP(hipMemsetAsync(t->op, 0, sizeof(OpCounters), st));
     group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr);
     group_plan_kernel<false><<<gp, 1024, 0, st>>>(nn, t->g, t->bs, t->op);
     {
@@ -1111,7 +1135,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     // the work list (chunk leaders) and the big-group list have device-side lengths: fixed grids that loop
     apply_chunk_kernel<<<grid_for(n, 16, 2048), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
                                                             d_keys, (const float4*)d_grads, t->g, t->bs, t->op, a);
-    apply_big_kernel<<<grid_for(n / kChunk + 1, 16, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,
+    apply_big_kernel<<<grid_for(n / kChunk + 1, 1, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,
                                                                        t->dim4, t->g, t->bs, t->op, a);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
@@ -1143,7 +1167,7 @@ int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, siz
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
-    MEE_HIP(hipMemsetAsync(t->op, 0, 16, st));
+    MEE_HIP(hipMemsetAsync(t->op, 0, sizeof(OpCounters), st));
     group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr);
     group_plan_kernel<true><<<grid_for(n, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
     dedup_fill_kernel<<<gl, 256, 0, st>>>(nn, t->g, t->bs, d_inverse_out);
