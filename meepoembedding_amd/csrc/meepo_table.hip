@@ -285,7 +285,7 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum /
 constexpr uint32_t kChunk = 32;  // occurrences summed by one tile
 
 // Plan pass, one lane per batch position: finalise rank and count, then (leaders only) reserve the group's slice of
-// the occurrence list, list the chunk leaders as work items, give big groups an fp64 accumulator row, and — for the
+// the occurrence list, list the chunk leaders as work items, give big groups a block of fp64 partial-sum rows, and — for the
 // standalone dedup (ALL) — append the group to the unique list.  Every reservation is a block-wide prefix sum plus
 // ONE atomic per 1024-thread block.
 template <bool ALL>
