@@ -52,6 +52,7 @@ struct GroupTable {            // S entries, indexed by h
 };
 struct BatchScratch {          // max_batch entries, indexed by batch position unless noted
     uint32_t *hidx, *rank, *pcnt, *occ, *uniq_h, *work;
+    uint8_t* fmask;            // found mask of find_or_insert's first pass when the caller passes none
     uint32_t* bigh;            // [max_big] group-table index of each big group
     double* gacc;              // [max_big][dim] fp64 partial-sum rows: one per chunk of a big group, a group's rows contiguous
 };
@@ -219,7 +220,7 @@ constexpr int kLds = 512;       // block-local aggregation table (256 threads ->
 // whose CAS claimed the entry needs no counting atomic at all.
 template <int MODE>
 __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ keys, uint32_t n, GroupTable g, BatchScratch bs,
-                                                    Counters* ctr) {
+                                                    Counters* ctr, const uint8_t* __restrict__ skip) {
     __shared__ unsigned long long lkey[kLds];
     __shared__ uint32_t lval[kLds], lh[kLds], lbase[kLds];
     for (int j = threadIdx.x; j < kLds; j += 256) { lkey[j] = 0; lval[j] = 0; }
@@ -227,7 +228,8 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool inb = i < n;
     const int64_t key = inb ? keys[i] : 0;
-    const bool valid = inb && !reserved_key(key);
+    const bool skipped = inb && skip && skip[i];  // position already served by an earlier pass (find_or_insert)
+    const bool valid = inb && !skipped && !reserved_key(key);
     uint32_t slot = 0, r_local = 0;
     bool inserter = false;
     if (valid) {
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
     if (inb) {
         bs.hidx[i] = valid ? lh[slot] : kNoGroup;
         if (MODE == kGroupCount && valid) bs.rank[i] = lbase[slot] + r_local;
-        if (!valid) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);
+        if (!valid && !skipped) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);
     }
 }
 
@@ -440,22 +442,23 @@ __global__ __launch_bounds__(256) void ensure_kernel(int64_t* tkeys, float4* val
     }
 }
 
+// second half of find_or_insert: every position that took part in the insert pass (i.e. was missing before the call)
+// copies its group's row; positions served by the first (plain find) pass are left alone
 __global__ __launch_bounds__(256) void gather_group_kernel(const float4* __restrict__ values, uint32_t dim4, uint32_t n,
                                                            const uint32_t* __restrict__ hidx,
-                                                           const long long* __restrict__ sres, float4* __restrict__ out,
-                                                           uint8_t* found, float defv) {
+                                                           const long long* __restrict__ sres, float4* __restrict__ out) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const float4 def4 = make_float4(defv, defv, defv, defv);
     for (uint32_t base = wave * 4; base < n; base += n_waves * 4) {
         const uint32_t i = base + tile;
         if (i >= n) continue;
         const uint32_t h = hidx[i];
-        const long long res = h != kNoGroup ? sres[h] : -1ll;
-        const long long slot = res < 0 ? -1ll : (res & ~kPresentBit);
-        for (uint32_t c = tl; c < dim4; c += 16) out[(uint64_t)i * dim4 + c] = slot >= 0 ? values[(uint64_t)slot * dim4 + c] : def4;
-        if (found && tl == 0) found[i] = res >= 0 && (res & kPresentBit) != 0;
+        if (h == kNoGroup) continue;
+        const long long res = sres[h];
+        if (res < 0) continue;  // table full: the default row written by the find pass stays
+        const long long slot = res & ~kPresentBit;
+        for (uint32_t c = tl; c < dim4; c += 16) out[(uint64_t)i * dim4 + c] = values[(uint64_t)slot * dim4 + c];
     }
 }
 
@@ -802,7 +805,7 @@ int mee_table_destroy(mee_table* t) {
     for (float* p : planes)
         if (p) { if (t->value_memory == MEE_MEM_HOST_PINNED) (void)hipHostFree(p); else (void)hipFree(p); }
     void* dev[] = {t->keys, t->g.skeys, t->g.sval, t->g.sval0, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
-                   t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.work, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
+                   t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.work, t->bs.fmask, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (t->h_ctr) (void)hipHostFree(t->h_ctr);
     if (t->h_op) (void)hipHostFree(t->h_op);
@@ -885,13 +888,13 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     ALLOC(t->g.skeys, S * 8); ALLOC(t->g.sval, S * 4); ALLOC(t->g.sval0, S * 4); ALLOC(t->g.soffs, S * 4); ALLOC(t->g.sgrp, S * 4);
     ALLOC(t->g.sbig, S * 4); ALLOC(t->g.sres, S * 8);
     ALLOC(t->bs.hidx, mb * 4); ALLOC(t->bs.rank, mb * 4); ALLOC(t->bs.pcnt, mb * 4); ALLOC(t->bs.occ, mb * 4); ALLOC(t->bs.uniq_h, mb * 4);
-    ALLOC(t->bs.work, mb * 4);
+    ALLOC(t->bs.work, mb * 4); ALLOC(t->bs.fmask, mb);
     t->max_big = mb / kChunk + 1;  // a batch of n keys has at most n / (kChunk + 1) groups larger than kChunk
     ALLOC(t->bs.bigh, t->max_big * 4);
     if (t->optimizer != MEE_OPT_NONE) ALLOC(t->bs.gacc, t->max_big * (uint64_t)t->dim * sizeof(double));
     ALLOC(t->ctr, sizeof(Counters)); ALLOC(t->op, sizeof(OpCounters));
 #undef ALLOC
-    t->workspace_bytes = S * 36 + mb * 24 + t->max_big * 4 + (t->bs.gacc ? t->max_big * (uint64_t)t->dim * sizeof(double) : 0) +
+    t->workspace_bytes = S * 36 + mb * 25 + t->max_big * 4 + (t->bs.gacc ? t->max_big * (uint64_t)t->dim * sizeof(double) : 0) +
                          sizeof(Counters) + sizeof(OpCounters);
     if (hipHostMalloc((void**)&t->h_ctr, sizeof(Counters)) != hipSuccess || hipHostMalloc((void**)&t->h_op, sizeof(OpCounters)) != hipSuccess) {
         rc = fail(MEE_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
@@ -1001,7 +1004,7 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
-    group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr);
+    group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr);
     if (claim)
         upsert_kernel<true><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
                                                 (const float4*)d_values, nn, t->bs.hidx, t->g.sval, nullptr, t->optimizer, t->init_acc, t->ctr);
@@ -1049,11 +1052,15 @@ int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_o
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
-    group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr);
+    // pass 1: a plain find serves every key that is already stored (the steady state of training) at find speed and
+    // yields the "present before the call" mask; pass 2 runs the insert machinery over the missing positions only.
+    uint8_t* fmask = d_found ? d_found : t->bs.fmask;
+    if (int rc = find_plane(t, t->values, t->default_value, d_keys, n, d_out, fmask, stream)) return rc;
+    group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, fmask);
     ensure_kernel<<<gt, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys, nn, t->bs.hidx,
                                       t->g.sval, t->g.sres, t->optimizer, t->init_acc, t->initializer, t->init_scale, t->init_seed,
                                       t->default_value, t->ctr);
-    gather_group_kernel<<<gt, 256, 0, st>>>((const float4*)t->values, t->dim4, nn, t->bs.hidx, t->g.sres, (float4*)d_out, d_found, t->default_value);
+    gather_group_kernel<<<gt, 256, 0, st>>>((const float4*)t->values, t->dim4, nn, t->bs.hidx, t->g.sres, (float4*)d_out);
     group_reset_kernel<<<gl, 256, 0, st>>>(t->bs.hidx, nn, t->g);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
@@ -1118,7 +1125,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     const unsigned gl = grid_for(n, 256, 1u << 22);
     const unsigned gp = grid_for(n, 1024, 1u << 22);
     MEE_HIP(hipMemsetAsync(t->op, 0, sizeof(OpCounters), st));
-    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr);
+    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr);
     group_plan_kernel<false><<<gp, 1024, 0, st>>>(nn, t->g, t->bs, t->op);
     {
         const int R = t->apply_rounds > 0 ? t->apply_rounds : 2;
@@ -1168,7 +1175,7 @@ int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, siz
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
     MEE_HIP(hipMemsetAsync(t->op, 0, sizeof(OpCounters), st));
-    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr);
+    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr);
     group_plan_kernel<true><<<grid_for(n, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
     dedup_fill_kernel<<<gl, 256, 0, st>>>(nn, t->g, t->bs, d_inverse_out);
     dedup_emit_kernel<<<gt, 256, 0, st>>>(t->dim4, (const float4*)d_grads, t->g, t->bs, t->op, d_uniq_out, (float4*)d_gsum_out, d_counts_out);
