@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--mode", choices=["find", "train"], default="find",
                     help="find = configs[1] (the driver's metric); train = configs[2]: find + sparse-Adagrad apply per step (N=1 only)")
     ap.add_argument("--pipeline", type=int, default=1, help="sharded only: steps in flight on separate HIP streams (1 = off)")
+    ap.add_argument("--transport", choices=["auto", "rccl", "p2p"], default="auto",
+                    help="sharded only: rccl = all-to-all exchange; p2p = owners store rows into the requester's peer-mapped buffer; "
+                         "auto = verify p2p against rccl, time both for a few steps, keep the faster")
     ap.add_argument("--dedup", action="store_true", help="sharded only: exchange only the batch's distinct keys (pays off on skewed streams)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even at N=1 (rehearsal of the N>1 code)")
     ap.add_argument("--verbose", action="store_true")
@@ -175,11 +178,49 @@ def main():
         shs = [ShardedLookupTable(table, Router(world, batch, device=dev)) for _ in range(depth)]
         streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(depth - 1)]
 
-        def step(i):
+        def step_rccl(i):
             if depth == 1:
                 return shs[0].find(batches[i % n_batches], dedup=args.dedup)
             with torch.cuda.stream(streams[i % depth]):
                 return shs[i % depth].find(batches[i % n_batches], dedup=args.dedup)
+
+        step, transport = step_rccl, "rccl all-to-all"
+        if args.transport in ("auto", "p2p") and not args.dedup and depth == 1:
+            from meepoembedding_amd.p2p import PeerShardedFind
+            peer = None
+            try:
+                peer = PeerShardedFind(table, Router(world, batch, device=dev), max_batch=batch)
+            except Exception as e:  # collective failure: every rank lands here together
+                log(f"p2p transport unavailable: {e}")
+            if peer is not None:
+                def step_p2p(i):
+                    return peer.find(batches[i % n_batches], check_overflow=False)
+
+                o_a, f_a = step_rccl(0)
+                o_b, f_b = step_p2p(0)
+                same = torch.tensor([int(torch.equal(o_a, o_b) and torch.equal(f_a, f_b))], device=dev)
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                peer.check()
+
+                def timed(fn, k=6):
+                    for i in range(3):
+                        fn(i)
+                    dist.barrier(); torch.cuda.synchronize(dev)
+                    t_ = time.perf_counter()
+                    for i in range(k):
+                        fn(i)
+                    torch.cuda.synchronize(dev)
+                    tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                    return float(tt_.item()) / k
+
+                if int(same.item()) == 1:
+                    t_rccl, t_p2p = timed(step_rccl), timed(step_p2p)
+                    log(f"transport probe: rccl {t_rccl * 1e3:.3f} ms/step, p2p {t_p2p * 1e3:.3f} ms/step")
+                    if args.transport == "p2p" or t_p2p < t_rccl:
+                        step, transport = step_p2p, "peer-mapped stores (no all-to-all)"
+                else:
+                    log("p2p transport disagrees with the rccl path: not used")
     elif train:
         grads = [torch.randn(batch, dim, device=dev) * 0.01 for _ in range(4)]   # N(0, 1e-2), SURVEY §8d config 3
 
@@ -260,7 +301,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int64 keys / fp32 rows (copy)", "data": "synthetic",
             "config": {"workload": (f"row-sharded find: {n_keys // 1_000_000}M keys over {world} GPUs ({keys_per_gpu // 1_000_000}M/GPU), dim {dim}, "
-                                    f"{batch} lookups per rank per step, RCCL all-to-all keys out / rows back" if sharded else
+                                    f"{batch} lookups per rank per step, transport: {transport}" if sharded else
                                     f"configs[2]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim}, forward find + sparse-Adagrad scatter-update, {batch}-key batches" if train else
                                     f"configs[1]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim} fp32, forward find only, {batch}-key batches"),
                        "keys_per_gpu": keys_per_gpu, "local_size": local_size, "dim": dim, "batch_per_rank": batch, "load_factor": args.load,

@@ -49,6 +49,8 @@ enum { MEE_MEM_HBM = 0, MEE_MEM_HOST_PINNED = 1 };
 
 typedef struct mee_table  mee_table;  /* one HBM-resident hash table (one shard) */
 typedef struct mee_router mee_router; /* workspace for the shard partition / un-permute kernels */
+typedef struct mee_p2p    mee_p2p;    /* peer-mapped buffers of the all-to-all-free sharded find */
+#define MEE_IPC_HANDLE_BYTES 64
 
 typedef struct mee_config {
     uint32_t struct_size;         /* = sizeof(mee_config); ABI guard */
@@ -141,6 +143,27 @@ int mee_scatter_rows(const void* d_rows, const int64_t* d_perm, size_t n, size_t
 /* out[q, :] = rows[perm[q], :] — forward permutation of per-key payloads (values / grads) into send order. */
 int mee_gather_rows(const void* d_rows, const int64_t* d_perm, size_t n, size_t row_bytes, void* d_out,
                     void* stream);
+
+/* ---- sharded find over peer-mapped memory (README.md:2 "distributed"; SPEC.md §5) ---------------------------------
+ * One context per rank; all ranks use the same n_shards / slots_per_peer / max_batch / dim.  The five local buffers
+ * (key inbox, destination inbox, fill counts, result rows, found bytes) are exported as HIP IPC handles, the caller
+ * exchanges them (any side channel) and connects.  Per lookup, after mee_partition:
+ *   mee_p2p_push  stores this rank's keys + batch positions into their owners' inboxes            (xGMI stores)
+ *   -- barrier across ranks on the stream --
+ *   mee_p2p_find  probes what arrived and stores each row straight into the requester's buffers   (xGMI stores)
+ *   -- barrier across ranks on the stream --
+ * after which mee_p2p_buffers() rows/found [0, n) hold the result in batch order.  slots_per_peer bounds how many keys
+ * one rank may send to one owner per lookup; exceeding it drops keys and sets bit 0 of mee_p2p_status. */
+int mee_p2p_create(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t slots_per_peer, uint64_t max_batch, uint32_t dim,
+                   mee_p2p** out);
+int mee_p2p_destroy(mee_p2p* c);
+int mee_p2p_export(mee_p2p* c, void* handles /* 5 x MEE_IPC_HANDLE_BYTES */);
+int mee_p2p_connect(mee_p2p* c, const void* all_handles /* n_shards x 5 x MEE_IPC_HANDLE_BYTES, rank-major */);
+int mee_p2p_buffers(mee_p2p* c, float** d_out, uint8_t** d_found);
+int mee_p2p_push(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts, size_t n,
+                 void* stream);
+int mee_p2p_find(mee_p2p* c, const mee_table* t, void* stream);
+int mee_p2p_status(mee_p2p* c, uint32_t* bits_out, void* stream); /* [syncs] */
 
 #ifdef __cplusplus
 }

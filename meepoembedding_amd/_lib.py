@@ -78,6 +78,14 @@ PROTOTYPES = {
     "mee_router_create": (C.c_int, [_i32, _u64, _u32, C.POINTER(_vp)]),
     "mee_router_destroy": (C.c_int, [_vp]),
     "mee_partition": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "mee_p2p_create": (C.c_int, [_i32, _u32, _u32, _u64, _u64, _u32, C.POINTER(_vp)]),
+    "mee_p2p_destroy": (C.c_int, [_vp]),
+    "mee_p2p_export": (C.c_int, [_vp, _vp]),
+    "mee_p2p_connect": (C.c_int, [_vp, _vp]),
+    "mee_p2p_buffers": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "mee_p2p_push": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mee_p2p_find": (C.c_int, [_vp, _vp, _vp]),
+    "mee_p2p_status": (C.c_int, [_vp, C.POINTER(_u32), _vp]),
     "mee_scatter_rows": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "mee_gather_rows": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
 }

@@ -38,6 +38,17 @@ struct DeviceGuard {
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 
+// what other translation units may know about a table (defined in meepo_table.hip)
+struct TableView {
+    int device;
+    const int64_t* keys;
+    const float* values;
+    uint64_t nb;
+    uint32_t dim, dim4;
+    float default_value;
+};
+TableView table_view(const mee_table* t);
+
 inline unsigned grid_for(size_t work_items, unsigned per_block, unsigned cap) {
     size_t g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;

@@ -7,6 +7,7 @@
 // from the same ballots.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <new>
 
 #include "meepo_device.h"
@@ -19,6 +20,23 @@ struct mee_router {
     uint32_t max_blocks;
     uint32_t* blockcnt;  // [max_blocks][n_shards] counts, then exclusive offsets inside the shard segment
     uint64_t* base;      // [n_shards] start of each shard segment
+};
+
+struct mee_p2p {
+    int device;
+    uint32_t n_shards, rank, dim;
+    uint64_t cap, max_batch;
+    // local symmetric buffers, exported to the peers
+    int64_t* inbox_keys;   // [n_shards][cap]
+    int32_t* inbox_dst;    // [n_shards][cap]
+    uint32_t* inbox_cnt;   // [n_shards]
+    float* out;            // [max_batch][dim]
+    uint8_t* found;        // [max_batch]
+    uint32_t* status;      // bit 0: a segment overflowed `cap`
+    // device-resident pointer tables (index = rank) and their host copies
+    void** d_tables;       // 5 tables of n_shards pointers each
+    void* h_tables[5][64];
+    bool connected;
 };
 
 namespace mee {
@@ -149,6 +167,70 @@ static int permute_rows(const void* d_rows, const int64_t* d_perm, size_t n, siz
     return MEE_OK;
 }
 
+// ---- peer-to-peer sharded find (SPEC.md §5 without the all-to-alls) ---------------------------------------------
+// Every rank owns five "symmetric" buffers that its peers map through HIP IPC: an inbox of keys and of destination
+// indices with one segment per source rank, the segment fill counts, and its result rows / found bytes.  A lookup is
+//   push:  each rank's partitioned keys (+ their batch positions) are stored straight into the owners' inboxes (xGMI)
+//   find:  each owner probes what arrived and stores every row straight into the requester's result buffer (xGMI)
+// with one stream-ordered barrier after each phase.  No all-to-all, no un-permute pass, no host sync.
+struct P2PPeers {            // device-resident pointer tables, index = rank
+    int64_t** keys; int32_t** dst; uint32_t** cnt; float** out; uint8_t** found;
+};
+
+// grid: x over positions inside a segment, y = destination rank
+__global__ __launch_bounds__(256) void p2p_push_kernel(const int64_t* __restrict__ send_keys, const int64_t* __restrict__ perm,
+                                                       const uint64_t* __restrict__ counts, const uint64_t* __restrict__ base,
+                                                       P2PPeers peers, uint32_t me, uint64_t cap, uint32_t* status) {
+    const uint32_t p = blockIdx.y;
+    const uint64_t cnt = counts[p];
+    const uint64_t take = cnt < cap ? cnt : cap;
+    int64_t* __restrict__ dk = peers.keys[p] + (uint64_t)me * cap;
+    int32_t* __restrict__ dd = peers.dst[p] + (uint64_t)me * cap;
+    const uint64_t b0 = base[p];
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < take; j += (uint64_t)gridDim.x * blockDim.x) {
+        dk[j] = send_keys[b0 + j];
+        dd[j] = (int32_t)perm[b0 + j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        peers.cnt[p][me] = (uint32_t)take;
+        if (cnt > cap) atomicOr(status, 1u);
+    }
+}
+
+// One tile per inbox position; DIM4 = dim/4 when 16 or 32, else 0 (run-time dim).  Rows and found bytes go to the
+// requester's buffers (peer memory for remote sources).
+template <int DIM4>
+__global__ __launch_bounds__(256) void p2p_find_kernel(const int64_t* __restrict__ tkeys, const float4* __restrict__ values, uint64_t nb,
+                                                       uint32_t dim4_rt, float defv, const int64_t* __restrict__ in_keys,
+                                                       const int32_t* __restrict__ in_dst, const uint32_t* __restrict__ in_cnt,
+                                                       P2PPeers peers, uint32_t n_shards, uint64_t cap) {
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t total = (uint64_t)n_shards * cap;
+    const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
+    const float4 def4 = make_float4(defv, defv, defv, defv);
+    for (uint64_t base = wave * 4; base < total; base += n_waves * 4) {
+        const uint64_t i = base + tile;
+        const uint32_t s = i < total ? (uint32_t)(i / cap) : 0;
+        const uint64_t j = i - (uint64_t)s * cap;
+        const bool inb = i < total && j < in_cnt[s];
+        const int64_t key = inb ? in_keys[i] : kEmpty;
+        const int32_t dst = inb ? in_dst[i] : 0;
+        bool is_new, full;
+        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, inb && !reserved_key(key), tile, tl, is_new, full);
+        if (!inb) continue;
+        float4* __restrict__ o = reinterpret_cast<float4*>(peers.out[s]) + (uint64_t)dst * dim4;
+        if constexpr (DIM4 != 0) {
+#pragma unroll
+            for (int c = 0; c < DIM4 / 16; ++c) o[c * 16 + tl] = slot >= 0 ? values[(uint64_t)slot * DIM4 + c * 16 + tl] : def4;
+        } else {
+            for (uint32_t c = tl; c < dim4; c += 16) o[c] = slot >= 0 ? values[(uint64_t)slot * dim4 + c] : def4;
+        }
+        if (tl == 0) peers.found[s][dst] = slot >= 0;
+    }
+}
+
 }  // namespace mee
 
 using namespace mee;
@@ -209,6 +291,141 @@ int mee_partition(mee_router* r, const int64_t* d_keys, size_t n, int64_t* d_sen
     part_scan_kernel<<<1, 1024, 0, st>>>(r->blockcnt, nblk, r->n_shards, r->base, d_counts);
     if (nblk) part_scatter_kernel<<<nblk, kPartBlock, 0, st>>>(d_keys, (uint32_t)n, r->n_shards, r->blockcnt, r->base, d_send_keys, d_perm);
     MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+// ---- peer-to-peer exchange: lifetime and IPC ----------------------------------------------------------------------
+int mee_p2p_destroy(mee_p2p* c) {
+    if (!c) return MEE_OK;
+    DeviceGuard g(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->connected)
+        for (int b = 0; b < 5; ++b)
+            for (uint32_t p = 0; p < c->n_shards; ++p)
+                if (p != c->rank && c->h_tables[b][p]) (void)hipIpcCloseMemHandle(c->h_tables[b][p]);
+    void* mine[] = {c->inbox_keys, c->inbox_dst, c->inbox_cnt, c->out, c->found, c->status, c->d_tables};
+    for (void* p : mine) if (p) (void)hipFree(p);
+    delete c;
+    return MEE_OK;
+}
+
+int mee_p2p_create(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t slots_per_peer, uint64_t max_batch, uint32_t dim,
+                   mee_p2p** out) {
+    if (!out) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_create: null out");
+    *out = nullptr;
+    if (n_shards == 0 || n_shards > (uint32_t)kMaxShards || rank >= n_shards || slots_per_peer == 0 || max_batch == 0 ||
+        max_batch > (1ull << 30) || dim < 4 || (dim & 3))
+        return fail(MEE_ERR_INVALID_ARG, "mee_p2p_create: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MEE_ERR_NO_DEVICE, "mee_p2p_create: no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_create: device %d out of range", device);
+    DeviceGuard g(device);
+    mee_p2p* c = new (std::nothrow) mee_p2p();
+    if (!c) return fail(MEE_ERR_OUT_OF_MEMORY, "host allocation failed");
+    memset(c, 0, sizeof *c);
+    c->device = device; c->n_shards = n_shards; c->rank = rank; c->dim = dim; c->cap = slots_per_peer; c->max_batch = max_batch;
+    const uint64_t slots = (uint64_t)n_shards * slots_per_peer;
+    if (hipMalloc((void**)&c->inbox_keys, slots * 8) != hipSuccess || hipMalloc((void**)&c->inbox_dst, slots * 4) != hipSuccess ||
+        hipMalloc((void**)&c->inbox_cnt, n_shards * 4) != hipSuccess || hipMalloc((void**)&c->out, max_batch * (uint64_t)dim * 4) != hipSuccess ||
+        hipMalloc((void**)&c->found, max_batch) != hipSuccess || hipMalloc((void**)&c->status, 4) != hipSuccess ||
+        hipMalloc((void**)&c->d_tables, 5 * (size_t)n_shards * sizeof(void*)) != hipSuccess) {
+        mee_p2p_destroy(c);
+        return fail(MEE_ERR_OUT_OF_MEMORY, "mee_p2p_create: hipMalloc failed");
+    }
+    if (hipMemset(c->inbox_cnt, 0, n_shards * 4) != hipSuccess || hipMemset(c->status, 0, 4) != hipSuccess) {
+        mee_p2p_destroy(c);
+        return fail(MEE_ERR_HIP, "mee_p2p_create: hipMemset failed");
+    }
+    *out = c;
+    return MEE_OK;
+}
+
+static void* p2p_local(const mee_p2p* c, int b) {
+    switch (b) { case 0: return c->inbox_keys; case 1: return c->inbox_dst; case 2: return c->inbox_cnt; case 3: return c->out; default: return c->found; }
+}
+
+int mee_p2p_export(mee_p2p* c, void* handles) {
+    if (!c || !handles) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_export: null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == MEE_IPC_HANDLE_BYTES, "IPC handle size");
+    DeviceGuard g(c->device);
+    for (int b = 0; b < 5; ++b) {
+        hipIpcMemHandle_t h;
+        MEE_HIP(hipIpcGetMemHandle(&h, p2p_local(c, b)));
+        memcpy((char*)handles + b * MEE_IPC_HANDLE_BYTES, &h, MEE_IPC_HANDLE_BYTES);
+    }
+    return MEE_OK;
+}
+
+int mee_p2p_connect(mee_p2p* c, const void* all_handles) {
+    if (!c || !all_handles) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_connect: null argument");
+    if (c->connected) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_connect: already connected");
+    DeviceGuard g(c->device);
+    for (uint32_t p = 0; p < c->n_shards; ++p)
+        for (int b = 0; b < 5; ++b) {
+            if (p == c->rank) { c->h_tables[b][p] = p2p_local(c, b); continue; }
+            hipIpcMemHandle_t h;
+            memcpy(&h, (const char*)all_handles + ((size_t)p * 5 + b) * MEE_IPC_HANDLE_BYTES, MEE_IPC_HANDLE_BYTES);
+            void* ptr = nullptr;
+            MEE_HIP(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+            c->h_tables[b][p] = ptr;
+        }
+    for (int b = 0; b < 5; ++b)
+        MEE_HIP(hipMemcpy(c->d_tables + (size_t)b * c->n_shards, c->h_tables[b], c->n_shards * sizeof(void*), hipMemcpyHostToDevice));
+    c->connected = true;
+    return MEE_OK;
+}
+
+int mee_p2p_buffers(mee_p2p* c, float** d_out, uint8_t** d_found) {
+    if (!c) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_buffers: null argument");
+    if (d_out) *d_out = c->out;
+    if (d_found) *d_found = c->found;
+    return MEE_OK;
+}
+
+static P2PPeers p2p_peers(const mee_p2p* c) {
+    P2PPeers pp;
+    pp.keys = (int64_t**)(c->d_tables + 0 * (size_t)c->n_shards);
+    pp.dst = (int32_t**)(c->d_tables + 1 * (size_t)c->n_shards);
+    pp.cnt = (uint32_t**)(c->d_tables + 2 * (size_t)c->n_shards);
+    pp.out = (float**)(c->d_tables + 3 * (size_t)c->n_shards);
+    pp.found = (uint8_t**)(c->d_tables + 4 * (size_t)c->n_shards);
+    return pp;
+}
+
+int mee_p2p_push(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts, size_t n,
+                 void* stream) {
+    if (!c || !r || !d_counts || (n && (!d_send_keys || !d_perm))) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push: null argument");
+    if (!c->connected) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push: not connected");
+    if (r->n_shards != c->n_shards || n > c->max_batch) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push: router/batch mismatch");
+    DeviceGuard g(c->device);
+    const dim3 grid(grid_for(n / c->n_shards + 256, 256, 1024), c->n_shards);
+    p2p_push_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_send_keys, d_perm, d_counts, r->base, p2p_peers(c), c->rank, c->cap, c->status);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+int mee_p2p_find(mee_p2p* c, const mee_table* t, void* stream) {
+    if (!c || !t) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_find: null argument");
+    if (!c->connected) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_find: not connected");
+    const TableView v = table_view(t);
+    if (v.dim != c->dim || v.device != c->device) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_find: table dim/device mismatch");
+    DeviceGuard g(c->device);
+    const uint64_t total = (uint64_t)c->n_shards * c->cap;
+    const unsigned grid = grid_for(total, 16, 1u << 20);
+    hipStream_t st = (hipStream_t)stream;
+#define P2PFIND(D4) p2p_find_kernel<D4><<<grid, 256, 0, st>>>(v.keys, (const float4*)v.values, v.nb, v.dim4, v.default_value, c->inbox_keys, \
+                                                              c->inbox_dst, c->inbox_cnt, p2p_peers(c), c->n_shards, c->cap)
+    if (v.dim4 == 16) P2PFIND(16); else if (v.dim4 == 32) P2PFIND(32); else P2PFIND(0);
+#undef P2PFIND
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+int mee_p2p_status(mee_p2p* c, uint32_t* bits_out, void* stream) {
+    if (!c || !bits_out) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_status: null argument");
+    DeviceGuard g(c->device);
+    MEE_HIP(hipMemcpyAsync(bits_out, c->status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    MEE_HIP(hipStreamSynchronize((hipStream_t)stream));
     return MEE_OK;
 }
 

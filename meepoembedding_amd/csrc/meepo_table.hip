@@ -782,6 +782,10 @@ __global__ __launch_bounds__(256) void export_kernel(const int64_t* __restrict__
 // =========================================================================================================
 static hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
+TableView table_view(const mee_table* t) {
+    return TableView{t->device, t->keys, t->values, t->nb, t->dim, t->dim4, t->default_value};
+}
+
 static int check_batch(const mee_table* t, size_t n, const char* op) {
     if (n > t->max_batch)
         return fail(MEE_ERR_BATCH_TOO_LARGE, "%s: n=%zu exceeds config.max_batch=%llu", op, n, (unsigned long long)t->max_batch);

@@ -90,6 +90,14 @@ def _run_rank(rank, world, port, backend, q, tiered=False):
         # the same lookup with pre-exchange dedup on a duplicate-heavy batch (+ a reserved key) must give the same answer
         dup = torch.cat([probe[:500].repeat(7), probe[-60:], torch.tensor([oracle.EMPTY_KEY], device=dev)])
         o1, f1 = sh.find(dup)
+        if backend in ("gloo-gpu", "nccl"):   # the all-to-all-free path over peer-mapped memory must agree bit for bit
+            from meepoembedding_amd.p2p import PeerShardedFind
+            pf = PeerShardedFind(local, Router(world, 8192, device=dev), max_batch=8192)
+            for qk in (dup, probe, dup[:1], dup[:777]):
+                o3, f3 = pf.find(qk)
+                oe, fe = sh.find(qk)
+                assert torch.equal(o3, oe) and torch.equal(f3, fe)
+            pf.close()
         if not tiered:
             o2, f2 = sh.find(dup, dedup=True)
             assert torch.equal(o1, o2) and torch.equal(f1, f2)
