@@ -197,37 +197,84 @@ __global__ __launch_bounds__(256) void p2p_push_kernel(const int64_t* __restrict
     }
 }
 
-// One tile per inbox position; DIM4 = dim/4 when 16 or 32, else 0 (run-time dim).  Rows and found bytes go to the
-// requester's buffers (peer memory for remote sources).
-template <int DIM4>
+// grid: x over the positions of one inbox segment, y = source rank.  Same shape as find_kernel: R keys in flight per
+// 16-lane tile (bucket lines requested back to back, then the rows); DIM4 = dim/4 when 16 or 32, else 0 (run-time dim).
+// Rows and found bytes are stored into the requester's buffers — peer memory, i.e. xGMI stores, for remote sources.
+template <int DIM4, int R>
 __global__ __launch_bounds__(256) void p2p_find_kernel(const int64_t* __restrict__ tkeys, const float4* __restrict__ values, uint64_t nb,
                                                        uint32_t dim4_rt, float defv, const int64_t* __restrict__ in_keys,
                                                        const int32_t* __restrict__ in_dst, const uint32_t* __restrict__ in_cnt,
-                                                       P2PPeers peers, uint32_t n_shards, uint64_t cap) {
+                                                       P2PPeers peers, uint64_t cap) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    const uint64_t total = (uint64_t)n_shards * cap;
+    const uint32_t s = blockIdx.y;
+    const uint32_t cnt = in_cnt[s];
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const int64_t* __restrict__ seg_keys = in_keys + (uint64_t)s * cap;
+    const int32_t* __restrict__ seg_dst = in_dst + (uint64_t)s * cap;
+    float4* __restrict__ outp = reinterpret_cast<float4*>(peers.out[s]);
+    uint8_t* __restrict__ fnd = peers.found[s];
     const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
     const float4 def4 = make_float4(defv, defv, defv, defv);
-    for (uint64_t base = wave * 4; base < total; base += n_waves * 4) {
-        const uint64_t i = base + tile;
-        const uint32_t s = i < total ? (uint32_t)(i / cap) : 0;
-        const uint64_t j = i - (uint64_t)s * cap;
-        const bool inb = i < total && j < in_cnt[s];
-        const int64_t key = inb ? in_keys[i] : kEmpty;
-        const int32_t dst = inb ? in_dst[i] : 0;
-        bool is_new, full;
-        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, inb && !reserved_key(key), tile, tl, is_new, full);
-        if (!inb) continue;
-        float4* __restrict__ o = reinterpret_cast<float4*>(peers.out[s]) + (uint64_t)dst * dim4;
-        if constexpr (DIM4 != 0) {
+    for (uint32_t base = wave * 4 * R; base < cnt; base += n_waves * 4 * R) {  // wave-uniform
+        int64_t key[R], slot[R];
+        int32_t dst[R];
+        bool inb[R];
 #pragma unroll
-            for (int c = 0; c < DIM4 / 16; ++c) o[c * 16 + tl] = slot >= 0 ? values[(uint64_t)slot * DIM4 + c * 16 + tl] : def4;
-        } else {
-            for (uint32_t c = tl; c < dim4; c += 16) o[c] = slot >= 0 ? values[(uint64_t)slot * dim4 + c] : def4;
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + r * 4 + tile;
+            inb[r] = i < cnt;
+            key[r] = inb[r] ? seg_keys[i] : kEmpty;
+            dst[r] = inb[r] ? seg_dst[i] : 0;
         }
-        if (tl == 0) peers.found[s][dst] = slot >= 0;
+        uint64_t b[R];
+        int64_t kb[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            b[r] = bucket_of(key[r], nb);
+            kb[r] = (inb[r] && !reserved_key(key[r])) ? tkeys[b[r] * kW + tl] : kEmpty;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            slot[r] = -1;
+            bool pend = inb[r] && !reserved_key(key[r]);
+            uint64_t bb = b[r], steps = 0;
+            int64_t k = kb[r];
+            while (true) {
+                const uint32_t tm = tile_bits(__ballot(pend && k == key[r]), tile);
+                const uint32_t te = tile_bits(__ballot(pend && k == kEmpty), tile);
+                if (pend) {
+                    if (tm) { slot[r] = (int64_t)(bb * kW) + (__ffs(tm) - 1); pend = false; }
+                    else if (te || ++steps >= nb) pend = false;
+                    else bb = (bb + 1 == nb) ? 0 : bb + 1;
+                }
+                if (!__any(pend)) break;
+                k = pend ? tkeys[bb * kW + tl] : kEmpty;
+            }
+        }
+        if constexpr (DIM4 != 0) {
+            constexpr int C = DIM4 / 16;
+            float4 row[R][C];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int c = 0; c < C; ++c) row[r][c] = slot[r] >= 0 ? values[(uint64_t)slot[r] * DIM4 + c * 16 + tl] : def4;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (inb[r]) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) outp[(uint64_t)dst[r] * DIM4 + c * 16 + tl] = row[r][c];
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (inb[r])
+                    for (uint32_t c = tl; c < dim4; c += 16)
+                        outp[(uint64_t)dst[r] * dim4 + c] = slot[r] >= 0 ? values[(uint64_t)slot[r] * dim4 + c] : def4;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (inb[r] && tl == 0) fnd[dst[r]] = slot[r] >= 0;
     }
 }
 
@@ -410,12 +457,11 @@ int mee_p2p_find(mee_p2p* c, const mee_table* t, void* stream) {
     const TableView v = table_view(t);
     if (v.dim != c->dim || v.device != c->device) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_find: table dim/device mismatch");
     DeviceGuard g(c->device);
-    const uint64_t total = (uint64_t)c->n_shards * c->cap;
-    const unsigned grid = grid_for(total, 16, 1u << 20);
+    const dim3 grid(grid_for(c->cap, 32, 1u << 16), c->n_shards);
     hipStream_t st = (hipStream_t)stream;
-#define P2PFIND(D4) p2p_find_kernel<D4><<<grid, 256, 0, st>>>(v.keys, (const float4*)v.values, v.nb, v.dim4, v.default_value, c->inbox_keys, \
-                                                              c->inbox_dst, c->inbox_cnt, p2p_peers(c), c->n_shards, c->cap)
-    if (v.dim4 == 16) P2PFIND(16); else if (v.dim4 == 32) P2PFIND(32); else P2PFIND(0);
+#define P2PFIND(D4, RR) p2p_find_kernel<D4, RR><<<grid, 256, 0, st>>>(v.keys, (const float4*)v.values, v.nb, v.dim4, v.default_value, c->inbox_keys, \
+                                                                      c->inbox_dst, c->inbox_cnt, p2p_peers(c), c->cap)
+    if (v.dim4 == 16) P2PFIND(16, 2); else if (v.dim4 == 32) P2PFIND(32, 1); else P2PFIND(0, 1);
 #undef P2PFIND
     MEE_HIP(hipGetLastError());
     return MEE_OK;
