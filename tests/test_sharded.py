@@ -97,6 +97,18 @@ def _run_rank(rank, world, port, backend, q, tiered=False):
                 o3, f3 = pf.find(qk)
                 oe, fe = sh.find(qk)
                 assert torch.equal(o3, oe) and torch.equal(f3, fe)
+            # inbox overflow is detected, not silently wrong: 7000 copies of one key all go to one owner, whose
+            # per-source segment holds 8192/world*1.25+4096 keys
+            if world >= 4:
+                hot = probe[:1].repeat(7000)
+                pf.find(hot, check_overflow=False)
+                from meepoembedding_amd import MeepoError
+                owner_has_room = 7000 <= pf.cap
+                try:
+                    pf.check()
+                    assert owner_has_room
+                except MeepoError:
+                    assert not owner_has_room
             pf.close()
         if not tiered:
             o2, f2 = sh.find(dup, dedup=True)
