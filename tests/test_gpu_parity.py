@@ -437,3 +437,28 @@ def test_find_parity_under_every_tuning_knob(dev, dim):
         t.apply_adagrad(T(keys[:n], dev), T(g, dev), lr=0.01); o.apply_adagrad(keys[:n], g, 0.01, 1e-10)
         out, _ = t.find(T(keys[:n], dev)); exp, _ = o.find(keys[:n])
         assert np.array_equal(out.cpu().numpy(), exp), ar
+
+
+@pytest.mark.parametrize("dim", [4, 512, 1024])
+def test_extreme_row_widths(dev, dim):
+    """Narrowest and widest rows through every row-moving kernel: insert, find, find_or_insert, Adam apply with
+    duplicates (small and big groups), export with state, remove."""
+    n = 3000
+    kw = dict(initializer=INIT_UNIFORM, init_scale=0.1, init_seed=3)
+    t = LookupTable(8192, dim, device=dev, optimizer=OPT_ADAM, max_batch=8192, **kw); o = oracle.OracleTable(8192, dim, optimizer=oracle.OPT_ADAM, **kw)
+    keys = synth.keys_np(91, 0, n); rows = synth.rows_np(keys, dim, 2)
+    t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
+    rng = np.random.default_rng(dim)
+    q = np.concatenate([keys[rng.integers(0, n, 4000)], synth.keys_np(92, 0, 500)])
+    out, found = t.find_or_insert(T(q, dev)); eo, ef = o.find_or_insert(q)
+    assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
+    bk = np.concatenate([keys[np.minimum(rng.zipf(1.2, 5000) - 1, n - 1)], np.full(200, keys[7])])
+    g = (rng.standard_normal((bk.size, dim)) * 0.01).astype(np.float32)
+    for s in range(2):
+        t.apply_adam(T(bk, dev), T(g, dev), lr=0.001, step=s + 1); o.apply_adam(bk, g, 0.001, 0.9, 0.999, 1e-8, s + 1)
+    assert np.array_equal(t.remove(T(keys[:100], dev)).cpu().numpy(), o.remove(keys[:100]))
+    g_ = [x.cpu().numpy() for x in t.export(with_state=True)]; o_ = o.export(with_state=True)
+    a, b = np.argsort(g_[0]), np.argsort(o_[0])
+    assert np.array_equal(g_[0][a], o_[0][b])
+    for x, y in zip(g_[1:], o_[1:]):
+        np.testing.assert_allclose(x[a], y[b], rtol=RTOL, atol=ATOL)
