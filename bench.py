@@ -216,8 +216,14 @@ def main():
 
                 if int(same.item()) == 1:
                     t_rccl, t_p2p = timed(step_rccl), timed(step_p2p)
-                    log(f"transport probe: rccl {t_rccl * 1e3:.3f} ms/step, p2p {t_p2p * 1e3:.3f} ms/step")
-                    if args.transport == "p2p" or t_p2p < t_rccl:
+                    # second comparison AFTER the buffers have been through several steps (a stale cache line in the
+                    # peer-written result buffer would show here, not on first touch)
+                    o_a, f_a = step_rccl(5)
+                    o_b, f_b = step_p2p(5)
+                    same = torch.tensor([int(torch.equal(o_a, o_b) and torch.equal(f_a, f_b))], device=dev)
+                    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                    log(f"transport probe: rccl {t_rccl * 1e3:.3f} ms/step, p2p {t_p2p * 1e3:.3f} ms/step, re-check {'ok' if int(same.item()) else 'MISMATCH'}")
+                    if int(same.item()) == 1 and (args.transport == "p2p" or t_p2p < t_rccl):
                         step, transport = step_p2p, "peer-mapped stores (no all-to-all)"
                 else:
                     log("p2p transport disagrees with the rccl path: not used")

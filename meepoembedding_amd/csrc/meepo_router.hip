@@ -7,6 +7,7 @@
 // from the same ballots.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -372,12 +373,21 @@ int mee_p2p_create(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t sl
     memset(c, 0, sizeof *c);
     c->device = device; c->n_shards = n_shards; c->rank = rank; c->dim = dim; c->cap = slots_per_peer; c->max_batch = max_batch;
     const uint64_t slots = (uint64_t)n_shards * slots_per_peer;
-    if (hipMalloc((void**)&c->inbox_keys, slots * 8) != hipSuccess || hipMalloc((void**)&c->inbox_dst, slots * 4) != hipSuccess ||
-        hipMalloc((void**)&c->inbox_cnt, n_shards * 4) != hipSuccess || hipMalloc((void**)&c->out, max_batch * (uint64_t)dim * 4) != hipSuccess ||
-        hipMalloc((void**)&c->found, max_batch) != hipSuccess || hipMalloc((void**)&c->status, 4) != hipSuccess ||
+    // The five peer-visible buffers are FINE-GRAINED device memory: peers store into them from inside kernels and the
+    // owner reads them in its next kernel with nothing but a collective in between, so they must stay coherent across
+    // GPUs without relying on a system-scope cache invalidate at the reader's kernel start (coarse-grained hipMalloc
+    // memory is only guaranteed coherent at host-visible synchronisation points).  Set MEE_P2P_COARSE=1 to use plain
+    // hipMalloc instead (single-GPU rehearsals).
+    const bool fine = getenv("MEE_P2P_COARSE") == nullptr;
+    auto sym_alloc = [&](void** p, size_t bytes) {
+        return fine ? hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) : hipMalloc(p, bytes);
+    };
+    if (sym_alloc((void**)&c->inbox_keys, slots * 8) != hipSuccess || sym_alloc((void**)&c->inbox_dst, slots * 4) != hipSuccess ||
+        sym_alloc((void**)&c->inbox_cnt, n_shards * 4) != hipSuccess || sym_alloc((void**)&c->out, max_batch * (uint64_t)dim * 4) != hipSuccess ||
+        sym_alloc((void**)&c->found, max_batch) != hipSuccess || hipMalloc((void**)&c->status, 4) != hipSuccess ||
         hipMalloc((void**)&c->d_tables, 5 * (size_t)n_shards * sizeof(void*)) != hipSuccess) {
         mee_p2p_destroy(c);
-        return fail(MEE_ERR_OUT_OF_MEMORY, "mee_p2p_create: hipMalloc failed");
+        return fail(MEE_ERR_OUT_OF_MEMORY, "mee_p2p_create: device allocation failed (%s)", fine ? "fine-grained" : "coarse-grained");
     }
     if (hipMemset(c->inbox_cnt, 0, n_shards * 4) != hipSuccess || hipMemset(c->status, 0, 4) != hipSuccess) {
         mee_p2p_destroy(c);
