@@ -1,0 +1,149 @@
+// meepo_embedding.hpp — C++17 host-side interface over the C-ABI (include/meepo_embedding.h), header-only.
+//
+// This is the "C++ host code" BASELINE.json's north_star puts above the thin C-ABI: RAII owners and lookuptable-style
+// methods (find / insert / assign / remove / find_or_insert / export / size, sparse Adagrad/Adam apply), a hot/cold
+// pair, the shard router and the peer-mapped exchange context.  The reference snapshot defines no C++ interface
+// (/root/reference/README.md:2 is its only functional statement); names follow the verbs the north_star lists.
+// Every pointer argument is DEVICE memory; every call is asynchronous on the given stream unless noted; errors are
+// thrown as meepo::Error (code + the library's message).  tests/cabi/cabi_test.cpp drives all of it on the GPU.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+
+#include "meepo_embedding.h"
+
+namespace meepo {
+
+class Error : public std::runtime_error {
+public:
+    Error(int code, const std::string& msg) : std::runtime_error("meepo error " + std::to_string(code) + ": " + msg), code_(code) {}
+    int code() const noexcept { return code_; }
+private:
+    int code_;
+};
+
+inline void check(int rc) {
+    if (rc != MEE_OK) throw Error(rc, mee_last_error());
+}
+
+struct TableOptions {
+    int32_t device = 0;
+    uint64_t capacity = 0;      // slots (rounded up to a multiple of 16); size for load <= ~0.75-0.9
+    uint32_t dim = 64;
+    uint32_t optimizer = MEE_OPT_NONE;
+    uint64_t max_batch = 1u << 20;
+    float default_value = 0.0f;
+    float initial_accumulator = 0.0f;
+    uint32_t initializer = MEE_INIT_CONSTANT;
+    float init_scale = 0.0f;
+    uint64_t init_seed = 0;
+    uint32_t value_memory = MEE_MEM_HBM;  // MEE_MEM_HOST_PINNED = cold tier (rows in pinned host DRAM)
+};
+
+// One HBM-resident shard (SPEC.md §2-§4).  Move-only.
+class Table {
+public:
+    explicit Table(const TableOptions& o) {
+        mee_config c{};
+        c.struct_size = sizeof c; c.device = o.device; c.capacity = o.capacity; c.dim = o.dim; c.optimizer = o.optimizer;
+        c.max_batch = o.max_batch; c.default_value = o.default_value; c.initial_accumulator = o.initial_accumulator;
+        c.initializer = o.initializer; c.init_scale = o.init_scale; c.init_seed = o.init_seed; c.value_memory = o.value_memory;
+        check(mee_table_create(&c, &t_));
+    }
+    ~Table() { if (t_) mee_table_destroy(t_); }
+    Table(Table&& other) noexcept : t_(std::exchange(other.t_, nullptr)) {}
+    Table& operator=(Table&& other) noexcept { if (this != &other) { if (t_) mee_table_destroy(t_); t_ = std::exchange(other.t_, nullptr); } return *this; }
+    Table(const Table&) = delete;
+    Table& operator=(const Table&) = delete;
+
+    mee_table* handle() const noexcept { return t_; }
+    mee_table_info info() const { mee_table_info i{}; check(mee_table_info_get(t_, &i)); return i; }
+
+    void find(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream = nullptr) const { check(mee_find(t_, d_keys, n, d_out, d_found, stream)); }
+    // second-tier pass: fills only the positions an earlier find (on another table) left with d_found == 0
+    void find_missing(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream = nullptr) const { check(mee_find_missing(t_, d_keys, n, d_out, d_found, stream)); }
+    void insert(const int64_t* d_keys, const float* d_values, size_t n, void* stream = nullptr) { check(mee_insert(t_, d_keys, d_values, n, stream)); }
+    void assign(const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_assign(t_, d_keys, d_values, n, d_found, stream)); }
+    void remove(const int64_t* d_keys, size_t n, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_remove(t_, d_keys, n, d_found, stream)); }
+    void find_or_insert(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_find_or_insert(t_, d_keys, n, d_out, d_found, stream)); }
+    void find_plane(uint32_t plane, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found = nullptr, void* stream = nullptr) const { check(mee_find_plane(t_, plane, d_keys, n, d_out, d_found, stream)); }
+    void assign_plane(uint32_t plane, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_assign_plane(t_, plane, d_keys, d_values, n, d_found, stream)); }
+    void apply_adagrad(const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps = 1e-10f, void* stream = nullptr) { check(mee_apply_adagrad(t_, d_keys, d_grads, n, lr, eps, stream)); }
+    void apply_adam(const int64_t* d_keys, const float* d_grads, size_t n, float lr, uint64_t step, float beta1 = 0.9f, float beta2 = 0.999f, float eps = 1e-8f, void* stream = nullptr) {
+        check(mee_apply_adam(t_, d_keys, d_grads, n, lr, beta1, beta2, eps, step, stream));
+    }
+    // the next four synchronise the stream (they return host values)
+    size_t size(void* stream = nullptr) const { size_t n = 0; check(mee_size(t_, &n, stream)); return n; }
+    uint32_t status(void* stream = nullptr) const { uint32_t b = 0; check(mee_status(t_, &b, stream)); return b; }
+    size_t export_all(int64_t* d_keys_out, float* d_values_out, size_t cap, float* d_state1_out = nullptr, float* d_state2_out = nullptr, void* stream = nullptr) const {
+        size_t n = 0; check(mee_export(t_, d_keys_out, d_values_out, d_state1_out, d_state2_out, cap, &n, stream)); return n;
+    }
+    size_t dedup_sum(const int64_t* d_keys, const float* d_grads, size_t n, int64_t* d_uniq_out, float* d_gsum_out, uint32_t* d_counts_out, int64_t* d_inverse_out, void* stream = nullptr) {
+        size_t u = 0; check(mee_dedup_sum(t_, d_keys, d_grads, n, d_uniq_out, d_gsum_out, d_counts_out, d_inverse_out, &u, stream)); return u;
+    }
+    void clear(void* stream = nullptr) { check(mee_clear(t_, stream)); }
+    void clear_status(void* stream = nullptr) { check(mee_clear_status(t_, stream)); }
+    void set_tuning(const char* name, int value) { check(mee_set_tuning(t_, name, value)); }
+
+private:
+    mee_table* t_ = nullptr;
+};
+
+// Hot (HBM) table backed by a cold table whose rows live in pinned host DRAM: one logical table, sync-free lookup.
+class TieredTable {
+public:
+    TieredTable(Table hot, Table cold) : hot_(std::move(hot)), cold_(std::move(cold)) {}
+    Table& hot() noexcept { return hot_; }
+    Table& cold() noexcept { return cold_; }
+    void find(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream = nullptr) const {
+        hot_.find(d_keys, n, d_out, d_found, stream);          // d_found is required: the second pass reads it
+        cold_.find_missing(d_keys, n, d_out, d_found, stream);
+    }
+    void apply_adagrad(const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps = 1e-10f, void* stream = nullptr) {
+        hot_.apply_adagrad(d_keys, d_grads, n, lr, eps, stream);  // a key lives in one tier; each table ignores keys it does not hold
+        cold_.apply_adagrad(d_keys, d_grads, n, lr, eps, stream);
+    }
+    size_t size(void* stream = nullptr) const { return hot_.size(stream) + cold_.size(stream); }
+private:
+    Table hot_, cold_;
+};
+
+// Shard partition / un-permute workspace (SPEC.md §5).
+class Router {
+public:
+    Router(int32_t device, uint64_t max_batch, uint32_t n_shards) { check(mee_router_create(device, max_batch, n_shards, &r_)); }
+    ~Router() { if (r_) mee_router_destroy(r_); }
+    Router(Router&& o) noexcept : r_(std::exchange(o.r_, nullptr)) {}
+    Router(const Router&) = delete;
+    Router& operator=(const Router&) = delete;
+    mee_router* handle() const noexcept { return r_; }
+    void partition(const int64_t* d_keys, size_t n, int64_t* d_send_keys, uint64_t* d_counts, int64_t* d_perm, void* stream = nullptr) { check(mee_partition(r_, d_keys, n, d_send_keys, d_counts, d_perm, stream)); }
+    static void scatter_rows(const void* d_rows, const int64_t* d_perm, size_t n, size_t row_bytes, void* d_out, void* stream = nullptr) { check(mee_scatter_rows(d_rows, d_perm, n, row_bytes, d_out, stream)); }
+    static void gather_rows(const void* d_rows, const int64_t* d_perm, size_t n, size_t row_bytes, void* d_out, void* stream = nullptr) { check(mee_gather_rows(d_rows, d_perm, n, row_bytes, d_out, stream)); }
+private:
+    mee_router* r_ = nullptr;
+};
+
+// Peer-mapped exchange context of the all-to-all-free sharded find.  The caller moves the exported handles between
+// ranks (any side channel) and provides the two cross-rank barriers per lookup (e.g. a one-element ncclAllReduce on
+// the stream): partition -> push -> barrier -> find -> barrier -> read rows()/found().
+class PeerExchange {
+public:
+    PeerExchange(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t slots_per_peer, uint64_t max_batch, uint32_t dim) { check(mee_p2p_create(device, n_shards, rank, slots_per_peer, max_batch, dim, &c_)); }
+    ~PeerExchange() { if (c_) mee_p2p_destroy(c_); }
+    PeerExchange(const PeerExchange&) = delete;
+    PeerExchange& operator=(const PeerExchange&) = delete;
+    void export_handles(void* handles_5x64) { check(mee_p2p_export(c_, handles_5x64)); }
+    void connect(const void* all_handles_rank_major) { check(mee_p2p_connect(c_, all_handles_rank_major)); }
+    void push(Router& r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts, size_t n, void* stream = nullptr) { check(mee_p2p_push(c_, r.handle(), d_send_keys, d_perm, d_counts, n, stream)); }
+    void find(const Table& t, void* stream = nullptr) { check(mee_p2p_find(c_, t.handle(), stream)); }
+    float* rows() const { float* o = nullptr; check(mee_p2p_buffers(c_, &o, nullptr)); return o; }
+    uint8_t* found() const { uint8_t* f = nullptr; check(mee_p2p_buffers(c_, nullptr, &f)); return f; }
+    uint32_t status(void* stream = nullptr) { uint32_t b = 0; check(mee_p2p_status(c_, &b, stream)); return b; }
+private:
+    mee_p2p* c_ = nullptr;
+};
+
+}  // namespace meepo

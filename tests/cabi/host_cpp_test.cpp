@@ -1,0 +1,98 @@
+// host_cpp_test.cpp — the C++ host layer (include/meepo_embedding.hpp) end to end on one GPU, no Python:
+// Table verbs, a hot/cold TieredTable (rows of the cold half in pinned host DRAM), and the sharded pipeline
+// (Router partition -> PeerExchange push -> find -> rows in batch order) with one rank.  Exit code 0 = pass.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "meepo_embedding.hpp"
+
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+#define CHECK(c) do { if (!(c)) { fprintf(stderr, "CHECK failed: %s (line %d)\n", #c, __LINE__); return 4; } } while (0)
+
+static uint64_t mix64(uint64_t x) { x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31; return x; }
+static float row_value(int64_t key, int j) { return (float)(mix64((uint64_t)key ^ mix64(2 + j)) >> 40) * 0x1p-24f - 0.5f; }
+
+template <typename T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    explicit DevBuf(size_t n_) : n(n_) { if (hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) p = nullptr; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void up(const std::vector<T>& h) { (void)hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice); }
+    std::vector<T> down(size_t m) const { std::vector<T> h(m); (void)hipMemcpy(h.data(), p, m * sizeof(T), hipMemcpyDeviceToHost); return h; }
+};
+
+int main() try {
+    const uint32_t dim = 64;
+    const size_t n = 60000;
+    std::vector<int64_t> keys(n);
+    for (size_t i = 0; i < n; ++i) keys[i] = (int64_t)mix64(7 + (i + 1) * 0x9E3779B97F4A7C15ull);
+    std::vector<float> rows(n * dim);
+    for (size_t i = 0; i < n; ++i) for (uint32_t j = 0; j < dim; ++j) rows[i * dim + j] = row_value(keys[i], j);
+    DevBuf<int64_t> d_keys(n); DevBuf<float> d_rows(n * dim), d_out(n * dim); DevBuf<uint8_t> d_found(n);
+    CHECK(d_keys.p && d_rows.p && d_out.p && d_found.p);
+    d_keys.up(keys); d_rows.up(rows);
+
+    // ---- bad options surface as exceptions with the library's message -------------------------------------------
+    bool threw = false;
+    try { meepo::TableOptions bad; bad.capacity = 0; meepo::Table t(bad); } catch (const meepo::Error& e) { threw = e.code() == MEE_ERR_INVALID_ARG; }
+    CHECK(threw);
+
+    // ---- one table: insert, find, remove, size -------------------------------------------------------------------
+    meepo::TableOptions o; o.capacity = (uint64_t)(n / 0.75); o.dim = dim; o.max_batch = n; o.default_value = -2.0f;
+    meepo::Table table(o);
+    table.insert(d_keys.p, d_rows.p, n);
+    CHECK(table.size() == n && table.status() == 0);
+    table.find(d_keys.p, n, d_out.p, d_found.p);
+    HIPCK(hipDeviceSynchronize());
+    { auto out = d_out.down(n * dim); auto f = d_found.down(n);
+      for (size_t i = 0; i < n; ++i) CHECK(f[i] == 1);
+      CHECK(memcmp(out.data(), rows.data(), n * dim * 4) == 0); }
+    table.remove(d_keys.p, n / 2, d_found.p);
+    CHECK(table.size() == n - n / 2);
+
+    // ---- hot/cold pair: first half of the keys in HBM, second half in the pinned-host tier ------------------------
+    meepo::TableOptions ho = o; ho.capacity = (uint64_t)(n / 2 / 0.75);
+    meepo::TableOptions co = ho; co.value_memory = MEE_MEM_HOST_PINNED;
+    meepo::TieredTable tiered{meepo::Table(ho), meepo::Table(co)};
+    tiered.hot().insert(d_keys.p, d_rows.p, n / 2);
+    tiered.cold().insert(d_keys.p + n / 2, d_rows.p + (n / 2) * dim, n - n / 2);
+    CHECK(tiered.size() == n);
+    tiered.find(d_keys.p, n, d_out.p, d_found.p);
+    HIPCK(hipDeviceSynchronize());
+    { auto out = d_out.down(n * dim); auto f = d_found.down(n);
+      for (size_t i = 0; i < n; ++i) CHECK(f[i] == 1);
+      CHECK(memcmp(out.data(), rows.data(), n * dim * 4) == 0); }
+
+    // ---- sharded pipeline with one rank: partition -> peer push -> peer find -> rows already in batch order ---------
+    meepo::Table shard(o);
+    shard.insert(d_keys.p, d_rows.p, n);
+    meepo::Router router(0, n, 1);
+    meepo::PeerExchange px(0, 1, 0, n, n, dim);
+    char handles[5 * MEE_IPC_HANDLE_BYTES];
+    px.export_handles(handles);
+    px.connect(handles);
+    DevBuf<int64_t> d_send(n), d_perm(n); DevBuf<uint64_t> d_counts(1);
+    std::vector<int64_t> q(n);
+    for (size_t i = 0; i < n; ++i) q[i] = keys[(i * 7919) % n];     // a permutation of the keys
+    q[5] = (int64_t)mix64(123456789);                                // one absent key
+    DevBuf<int64_t> d_q(n); d_q.up(q);
+    router.partition(d_q.p, n, d_send.p, d_counts.p, d_perm.p);
+    px.push(router, d_send.p, d_perm.p, d_counts.p, n);
+    px.find(shard);                                                  // one rank: stream order is the barrier
+    CHECK(px.status() == 0);
+    { std::vector<float> out(n * dim); std::vector<uint8_t> f(n);
+      HIPCK(hipMemcpy(out.data(), px.rows(), n * dim * 4, hipMemcpyDeviceToHost));
+      HIPCK(hipMemcpy(f.data(), px.found(), n, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < n; ++i) {
+          if (i == 5) { CHECK(f[i] == 0 && out[i * dim] == -2.0f); continue; }
+          CHECK(f[i] == 1);
+          CHECK(memcmp(&out[i * dim], &rows[((i * 7919) % n) * dim], dim * 4) == 0);
+      } }
+    printf("host_cpp_test ok: Table, TieredTable (HBM + pinned host) and the peer-mapped sharded pipeline through meepo_embedding.hpp\n");
+    return 0;
+} catch (const std::exception& e) {
+    fprintf(stderr, "exception: %s\n", e.what());
+    return 5;
+}
