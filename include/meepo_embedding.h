@@ -121,6 +121,13 @@ int mee_apply_adagrad(mee_table* t, const int64_t* d_keys, const float* d_grads,
                       void* stream);
 int mee_apply_adam(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float beta1,
                    float beta2, float eps, uint64_t step, void* stream);
+/* Optional split of an apply: mee_apply_prepare groups the batch's keys and plans the duplicate reduction — everything
+ * that does not need the grads — so it can run early (e.g. on a side stream beside the forward lookup and the dense
+ * model); the following mee_apply_adagrad / mee_apply_adam with the SAME d_keys / n then only streams the updates.
+ * While a prepared apply is pending only mee_find*, mee_remove, mee_size/status/export and mee_apply_* are accepted;
+ * mee_apply_discard drops it.  The caller orders the two streams (event / wait). */
+int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* stream);
+int mee_apply_discard(mee_table* t, void* stream);
 /* [syncs] duplicate-key reduction on its own (SPEC.md §4): unique keys (unspecified order), their summed
  * grads (nullable with d_grads), occurrence counts (nullable) and inverse[i] = index into the unique list
  * (nullable; -1 for reserved keys).  Outputs sized for n.  *n_unique_out on the host. */

@@ -73,6 +73,8 @@ PROTOTYPES = {
     "mee_clear_status": (C.c_int, [_vp, _vp]),
     "mee_apply_adagrad": (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _vp]),
     "mee_apply_adam": (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
+    "mee_apply_prepare": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "mee_apply_discard": (C.c_int, [_vp, _vp]),
     "mee_dedup_sum": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_sz), _vp]),
     "mee_hash_batch": (C.c_int, [_vp, _sz, _u64, _u32, _vp, _vp, _vp, _vp]),
     "mee_router_create": (C.c_int, [_i32, _u64, _u32, C.POINTER(_vp)]),

@@ -78,6 +78,9 @@ struct mee_table {
     mee::Counters* h_ctr;       // pinned staging for read-backs
     mee::OpCounters* h_op;
     uint64_t table_bytes, workspace_bytes;
+    // a prepared (grouped + planned) apply waiting for its grads: mee_apply_prepare .. mee_apply_*
+    uint64_t prepared_n;
+    const int64_t* prepared_keys;
     // performance knobs (never change results): see mee_set_tuning()
     int find_rounds;            // keys in flight per tile in the find kernel: 1, 2, 4 or 8
     int find_grid_cap;          // max blocks of the find grid (0 = one pass, no grid-stride loop)
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void group_reset_kernel(const uint32_t* __rest
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t h = hidx[i];
-    if (h != kNoGroup) { g.skeys[h] = 0; g.sval[h] = 0; }
+    if (h != kNoGroup) { g.skeys[h] = 0; g.sval[h] = 0; g.sval0[h] = 0; }
 }
 
 // ---- insert / assign (SPEC.md §3) --------------------------------------------------------------------------
@@ -522,7 +525,10 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int c = 0; c < C; ++c)
-                    if (cnt[r] == 1) gr[r][c] = grads[(uint64_t)(base + r * 4 + tile) * DIM4 + c * 16 + tl];
+                    if (cnt[r] == 1) {  // the grad row is read exactly once: stream it past the caches
+                        const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grads) + (uint64_t)(base + r * 4 + tile) * DIM4 + c * 16 + tl);
+                        gr[r][c] = make_float4(gv.x, gv.y, gv.z, gv.w);
+                    }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -787,6 +793,8 @@ TableView table_view(const mee_table* t) {
 }
 
 static int check_batch(const mee_table* t, size_t n, const char* op) {
+    if (t->prepared_n && strncmp(op, "mee_apply", 9) != 0 && strcmp(op, "mee_remove") != 0)
+        return fail(MEE_ERR_INVALID_ARG, "%s: a prepared apply is pending on this table (finish it with mee_apply_* or mee_apply_discard)", op);
     if (n > t->max_batch)
         return fail(MEE_ERR_BATCH_TOO_LARGE, "%s: n=%zu exceeds config.max_batch=%llu", op, n, (unsigned long long)t->max_batch);
     return MEE_OK;
@@ -1117,6 +1125,15 @@ int mee_clear_status(mee_table* t, void* stream) {
     return MEE_OK;
 }
 
+// group the batch's keys and plan the duplicate reduction (everything that does not need the grads)
+static int apply_prepare_launch(mee_table* t, const int64_t* d_keys, uint32_t nn, hipStream_t st) {
+    MEE_HIP(hipMemsetAsync(t->op, 0, sizeof(OpCounters), st));
+    group_kernel<kGroupCount><<<grid_for(nn, 256, 1u << 22), 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr);
+    group_plan_kernel<false><<<grid_for(nn, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
 static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, const OptArgs& a, void* stream,
                         const char* name) {
     if (!t || (n && (!d_keys || !d_grads))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
@@ -1126,11 +1143,13 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
-    const unsigned gl = grid_for(n, 256, 1u << 22);
-    const unsigned gp = grid_for(n, 1024, 1u << 22);
-    MEE_HIP(hipMemsetAsync(t->op, 0, sizeof(OpCounters), st));
-    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr);
-    group_plan_kernel<false><<<gp, 1024, 0, st>>>(nn, t->g, t->bs, t->op);
+    if (t->prepared_n) {  // grouping and planning were done ahead of time (mee_apply_prepare), possibly on another stream
+        if (t->prepared_n != n || t->prepared_keys != d_keys)
+            return fail(MEE_ERR_INVALID_ARG, "%s: keys/n differ from the pending mee_apply_prepare", name);
+        t->prepared_n = 0; t->prepared_keys = nullptr;
+    } else {
+        if (int rc = apply_prepare_launch(t, d_keys, nn, st)) return rc;
+    }
     {
         const int R = t->apply_rounds > 0 ? t->apply_rounds : 2;
         const unsigned gs = grid_for(n, 16u * (R >= 2 ? 2u : 1u), 1u << 16);
@@ -1149,6 +1168,29 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     apply_big_kernel<<<grid_for(n / kChunk + 1, 1, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,
                                                                        t->dim4, t->g, t->bs, t->op, a);
     MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* stream) {
+    if (!t || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_apply_prepare: null argument");
+    if (t->optimizer == MEE_OPT_NONE) return fail(MEE_ERR_UNSUPPORTED, "mee_apply_prepare: table has no optimizer");
+    if (t->prepared_n) return fail(MEE_ERR_INVALID_ARG, "mee_apply_prepare: a prepared apply is already pending");
+    if (n > t->max_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_apply_prepare: n=%zu exceeds config.max_batch=%llu", n, (unsigned long long)t->max_batch);
+    if (n == 0) return MEE_OK;
+    DeviceGuard g(t->device);
+    if (int rc = apply_prepare_launch(t, d_keys, (uint32_t)n, as_stream(stream))) return rc;
+    t->prepared_n = n; t->prepared_keys = d_keys;
+    return MEE_OK;
+}
+
+int mee_apply_discard(mee_table* t, void* stream) {
+    if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_apply_discard: null table");
+    if (!t->prepared_n) return MEE_OK;
+    DeviceGuard g(t->device);
+    const uint32_t nn = (uint32_t)t->prepared_n;
+    group_reset_kernel<<<grid_for(nn, 256, 1u << 22), 256, 0, as_stream(stream)>>>(t->bs.hidx, nn, t->g);
+    MEE_HIP(hipGetLastError());
+    t->prepared_n = 0; t->prepared_keys = nullptr;
     return MEE_OK;
 }
 

@@ -179,6 +179,15 @@ class LookupTable:
         g = self._rows(grads, k.numel())
         check(_lib.lib().mee_apply_adam(self._h, k.data_ptr(), g.data_ptr(), k.numel(), lr, beta1, beta2, eps, step, self._s()))
 
+    def apply_prepare(self, keys: torch.Tensor) -> None:
+        """Group + plan the next apply of `keys` ahead of time (needs no grads; may run on a side stream).  The next
+        apply_adagrad / apply_adam must be given the same tensor."""
+        k = self._keys(keys)
+        check(_lib.lib().mee_apply_prepare(self._h, k.data_ptr(), k.numel(), self._s()))
+
+    def apply_discard(self) -> None:
+        check(_lib.lib().mee_apply_discard(self._h, self._s()))
+
     def dedup_sum(self, keys: torch.Tensor, grads: torch.Tensor | None = None):
         """Duplicate-key reduction alone: (unique keys, summed grads | None, counts, inverse)."""
         k = self._keys(keys)

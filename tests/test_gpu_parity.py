@@ -462,3 +462,42 @@ def test_extreme_row_widths(dev, dim):
     assert np.array_equal(g_[0][a], o_[0][b])
     for x, y in zip(g_[1:], o_[1:]):
         np.testing.assert_allclose(x[a], y[b], rtol=RTOL, atol=ATOL)
+
+
+def test_apply_prepare_split(dev):
+    """mee_apply_prepare on a side stream beside the forward find, then the apply with the same keys: same result as the
+    one-call apply / the oracle; other group-table users are refused while it is pending; discard leaves things clean."""
+    dim, n_keys, batch = 64, 20000, 30000
+    keys = synth.keys_np(71, 0, n_keys); rows = synth.rows_np(keys, dim, 2)
+    t = LookupTable(32768, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=batch, initial_accumulator=0.1)
+    o = oracle.OracleTable(32768, dim, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
+    t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
+    rng = np.random.default_rng(9)
+    side = torch.cuda.Stream(dev)
+    main = torch.cuda.current_stream(dev)
+    for s in range(3):
+        bk = keys[np.minimum(rng.zipf(1.3, size=batch) - 1, n_keys - 1)]
+        g = (rng.standard_normal((batch, dim)) * 0.01).astype(np.float32)
+        dk, dg = T(bk, dev), T(g, dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            t.apply_prepare(dk)                       # overlaps with the lookup below
+        out, found = t.find(dk)
+        eo, ef = o.find(bk)
+        with pytest.raises(MeepoError):
+            t.insert(dk[:10], torch.zeros(10, dim, device=dev))   # group table is busy
+        with pytest.raises(MeepoError):
+            t.apply_adagrad(dk[:100], dg[:100], lr=0.01)             # not the prepared batch
+        main.wait_stream(side)
+        t.apply_adagrad(dk, dg, lr=0.01, eps=1e-10); o.apply_adagrad(bk, g, 0.01, 1e-10)
+        assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
+    t.apply_prepare(T(keys[:5000], dev))
+    t.apply_discard()
+    t.insert(T(keys[:10], dev), T(rows[:10], dev)); o.insert(keys[:10], rows[:10])   # accepted again, scratch is clean
+    u, _, c, _ = t.dedup_sum(T(np.concatenate([keys[:100], keys[:50]]), dev))
+    assert u.numel() == 100 and int(c.sum()) == 150
+    g_ = [x.cpu().numpy() for x in t.export(with_state=True)[:3]]; o_ = o.export(with_state=True)[:3]
+    a, b = np.argsort(g_[0]), np.argsort(o_[0])
+    assert np.array_equal(g_[0][a], o_[0][b])
+    np.testing.assert_allclose(g_[1][a], o_[1][b], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(g_[2][a], o_[2][b], rtol=RTOL, atol=ATOL)
