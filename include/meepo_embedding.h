@@ -46,6 +46,9 @@ enum { MEE_STATUS_TABLE_FULL = 1u, MEE_STATUS_RESERVED_KEY = 2u };
 /* MEE_MEM_HOST_PINNED: rows in pinned, device-mapped host DRAM, read and written by the same kernels over PCIe — the
  * cold tier of a hot/cold pair (BASELINE configs[4]); see meepoembedding_amd/tiered.py. */
 enum { MEE_MEM_HBM = 0, MEE_MEM_HOST_PINNED = 1 };
+/* MEE_FLAG_TRACK_HITS: keep a per-slot access counter (4 B/slot) fed by mee_find_counted and read by mee_hits_scan —
+ * the statistics a hot/cold placement policy needs. */
+enum { MEE_FLAG_TRACK_HITS = 1u };
 
 typedef struct mee_table  mee_table;  /* one HBM-resident hash table (one shard) */
 typedef struct mee_router mee_router; /* workspace for the shard partition / un-permute kernels */
@@ -65,7 +68,7 @@ typedef struct mee_config {
     float    init_scale;
     uint64_t init_seed;
     uint32_t value_memory;        /* MEE_MEM_*: where the value/state planes live (the key plane is always in HBM) */
-    uint32_t reserved;            /* must be 0 */
+    uint32_t flags;               /* MEE_FLAG_* bits, 0 by default */
 } mee_config;
 
 typedef struct mee_table_info {
@@ -94,6 +97,15 @@ int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, 
  * that THIS table holds get their row and d_found[i] = 1; every other position is left untouched.  No host sync, no
  * compaction: this is how a hot (HBM) table is backed by a cold (pinned host) one inside one stream. */
 int mee_find_missing(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
+/* mee_find (missing_only = 0) or mee_find_missing (missing_only = 1) that also adds 1 to the hit counter of every key
+ * it finds.  Meant for SAMPLED calls on a hot table (one atomic per found key) and for every call on a cold table (its
+ * hits are PCIe-bound anyway).  d_found is required. */
+int mee_find_counted(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int missing_only,
+                     void* stream);
+/* [syncs] keys whose hit counter lies in [min_hits, max_hits] (at most cap are written; *n_out = how many qualified);
+ * reset != 0 zeroes every counter, which starts a new observation window. */
+int mee_hits_scan(mee_table* t, uint32_t min_hits, uint32_t max_hits, int reset, int64_t* d_keys_out, size_t cap, size_t* n_out,
+                  void* stream);
 /* upsert; duplicate keys: last occurrence wins. */
 int mee_insert(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, void* stream);
 /* overwrite only if present; d_found nullable; duplicates: last occurrence wins. */

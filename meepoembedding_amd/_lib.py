@@ -21,6 +21,7 @@ OPT_NONE, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
 INIT_CONSTANT, INIT_UNIFORM = 0, 1
 STATUS_TABLE_FULL, STATUS_RESERVED_KEY = 1, 2
 MEM_HBM, MEM_HOST_PINNED = 0, 1
+FLAG_TRACK_HITS = 1
 EMPTY_KEY = -(1 << 63)
 RECLAIMED_KEY = EMPTY_KEY + 1
 BUCKET_WIDTH = 16
@@ -37,7 +38,7 @@ class Config(C.Structure):
         ("struct_size", C.c_uint32), ("device", C.c_int32), ("capacity", C.c_uint64), ("dim", C.c_uint32),
         ("optimizer", C.c_uint32), ("max_batch", C.c_uint64), ("default_value", C.c_float),
         ("initial_accumulator", C.c_float), ("initializer", C.c_uint32), ("init_scale", C.c_float),
-        ("init_seed", C.c_uint64), ("value_memory", C.c_uint32), ("reserved", C.c_uint32),
+        ("init_seed", C.c_uint64), ("value_memory", C.c_uint32), ("flags", C.c_uint32),
     ]
 
 
@@ -61,6 +62,8 @@ PROTOTYPES = {
     "mee_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mee_find": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_find_missing": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "mee_find_counted": (C.c_int, [_vp, _vp, _sz, _vp, _vp, C.c_int, _vp]),
+    "mee_hits_scan": (C.c_int, [_vp, _u32, _u32, C.c_int, _vp, _sz, C.POINTER(_sz), _vp]),
     "mee_insert": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "mee_assign": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "mee_find_plane": (C.c_int, [_vp, _u32, _vp, _sz, _vp, _vp, _vp]),

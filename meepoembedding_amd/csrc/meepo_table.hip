@@ -69,6 +69,7 @@ struct mee_table {
     // table planes
     int64_t* keys;
     float *values, *s1, *s2;
+    uint32_t* hits;             // per-slot access counter (config.flags & MEE_FLAG_TRACK_HITS), else null
     // per-batch scratch: group table (S entries) and per-position arrays (max_batch entries)
     uint64_t S, max_big;
     mee::GroupTable g;
@@ -109,7 +110,7 @@ template <int DIM4, int R, int NT>
 __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values,
                                                    uint64_t nb, const int64_t* __restrict__ keys, uint64_t n,
                                                    f32x4* __restrict__ out, uint8_t* __restrict__ found, float defv,
-                                                   uint32_t dim4_rt) {
+                                                   uint32_t dim4_rt, uint32_t* hits) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -155,6 +156,11 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
                 if (!__any(pend)) break;
                 k = pend ? tkeys[bb * kW + tl] : kEmpty;
             }
+        }
+        if constexpr ((NT & 16) != 0) {  // access statistics for the hot/cold policy (sampled calls only)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (slot[r] >= 0 && tl == 0) atomicAdd(&hits[slot[r]], 1u);
         }
         if constexpr (DIM4 != 0) {
             constexpr int C = DIM4 / 16;
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(256) void upsert_kernel(int64_t* tkeys, float4* val
                                                      uint32_t dim4, const int64_t* __restrict__ keys,
                                                      const float4* __restrict__ vals, uint32_t n,
                                                      const uint32_t* __restrict__ hidx, const uint32_t* __restrict__ sval,
-                                                     uint8_t* found, uint32_t optimizer, float init_acc, Counters* ctr) {
+                                                     uint8_t* found, uint32_t optimizer, float init_acc, Counters* ctr, uint32_t* hits) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
@@ -361,6 +367,7 @@ __global__ __launch_bounds__(256) void upsert_kernel(int64_t* tkeys, float4* val
         // insert: only winners touch the table.  assign: every occurrence probes (keys do not change) so that
         // found[] is exact for all of them; only the winner writes.
         const int64_t slot = tile_locate<CLAIM, CLAIM>(tkeys, nb, key, CLAIM ? winner : valid, tile, tl, is_new, full);
+        if (CLAIM && hits && winner && slot >= 0 && is_new && tl == 0) hits[slot] = 0;
         if (winner && slot >= 0) {
             for (uint32_t c = tl; c < dim4; c += 16) {
                 values[(uint64_t)slot * dim4 + c] = vals[(uint64_t)i * dim4 + c];
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(256) void ensure_kernel(int64_t* tkeys, float4* val
                                                      const uint32_t* __restrict__ hidx, const uint32_t* __restrict__ sval,
                                                      long long* sres, uint32_t optimizer, float init_acc,
                                                      uint32_t initializer, float init_scale, uint64_t init_seed,
-                                                     float default_value, Counters* ctr) {
+                                                     float default_value, Counters* ctr, uint32_t* hits) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
@@ -429,6 +436,7 @@ __global__ __launch_bounds__(256) void ensure_kernel(int64_t* tkeys, float4* val
         const bool winner = h != kNoGroup && sval[h] == i + 1;
         bool is_new, full;
         const int64_t slot = tile_locate<true, true>(tkeys, nb, key, winner, tile, tl, is_new, full);
+        if (hits && winner && slot >= 0 && is_new && tl == 0) hits[slot] = 0;
         if (winner && slot >= 0 && is_new) {
             for (uint32_t c = tl; c < dim4; c += 16) {
                 values[(uint64_t)slot * dim4 + c] = initial_row4(key, c * 4, initializer, init_scale, init_seed, default_value);
@@ -706,6 +714,41 @@ __global__ __launch_bounds__(256) void dedup_emit_kernel(uint32_t dim4, const fl
     }
 }
 
+// ---- access statistics for the hot/cold policy: keys whose hit counter lies in [lo, hi], optional reset ---------------
+__global__ __launch_bounds__(256) void hits_scan_kernel(const int64_t* __restrict__ tkeys, uint32_t* hits, uint64_t capacity, uint32_t lo,
+                                                        uint32_t hi, int reset, int64_t* keys_out, uint64_t cap, OpCounters* op) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    constexpr uint64_t kSpan = 64ull * 16;
+    for (uint64_t c0 = wave * kSpan; c0 < capacity; c0 += n_waves * kSpan) {
+        int64_t k[16];
+        uint64_t m[16];
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint64_t s = c0 + (uint64_t)j * 64 + lane;
+            k[j] = s < capacity ? tkeys[s] : kEmpty;
+            const uint32_t hcount = s < capacity ? hits[s] : 0;
+            if (reset && s < capacity && hcount) hits[s] = 0;
+            m[j] = __ballot(!reserved_key(k[j]) && hcount >= lo && hcount <= hi);
+            total += (uint32_t)__popcll(m[j]);
+        }
+        if (!total) continue;  // wave-uniform
+        unsigned long long pos0 = 0;
+        if (lane == 0) pos0 = atomicAdd(&op->n_export, (unsigned long long)total);
+        pos0 = __shfl(pos0, 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if ((m[j] >> lane) & 1) {
+                const uint64_t pos = pos0 + (uint64_t)__popcll(m[j] & ((1ull << lane) - 1));
+                if (pos < cap) keys_out[pos] = k[j];
+            }
+            pos0 += (uint64_t)__popcll(m[j]);
+        }
+    }
+}
+
 // ---- size (SPEC.md §3): count stored keys by scanning the key plane (keeps every atomic off the insert path) ----
 __global__ __launch_bounds__(256) void count_kernel(const int64_t* __restrict__ tkeys, uint64_t capacity, OpCounters* op) {
     __shared__ uint32_t wsum[4];
@@ -816,7 +859,7 @@ int mee_table_destroy(mee_table* t) {
     float* planes[] = {t->values, t->s1, t->s2};
     for (float* p : planes)
         if (p) { if (t->value_memory == MEE_MEM_HOST_PINNED) (void)hipHostFree(p); else (void)hipFree(p); }
-    void* dev[] = {t->keys, t->g.skeys, t->g.sval, t->g.sval0, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
+    void* dev[] = {t->keys, t->hits, t->g.skeys, t->g.sval, t->g.sval0, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
                    t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.work, t->bs.fmask, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (t->h_ctr) (void)hipHostFree(t->h_ctr);
@@ -832,7 +875,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
         return fail(MEE_ERR_INVALID_ARG, "mee_table_create: struct_size %u != %zu (ABI mismatch)", cfg->struct_size, sizeof(mee_config));
     if (cfg->capacity == 0 || cfg->dim < 4 || cfg->dim > 1024 || (cfg->dim & 3))
         return fail(MEE_ERR_INVALID_ARG, "mee_table_create: capacity must be >0 and dim a multiple of 4 in [4,1024]");
-    if (cfg->optimizer > MEE_OPT_ADAM || cfg->initializer > MEE_INIT_UNIFORM || cfg->value_memory > MEE_MEM_HOST_PINNED || cfg->reserved != 0)
+    if (cfg->optimizer > MEE_OPT_ADAM || cfg->initializer > MEE_INIT_UNIFORM || cfg->value_memory > MEE_MEM_HOST_PINNED || (cfg->flags & ~(uint32_t)MEE_FLAG_TRACK_HITS) != 0)
         return fail(MEE_ERR_INVALID_ARG, "mee_table_create: bad optimizer/initializer/value_memory");
     if (cfg->max_batch == 0 || cfg->max_batch > (1ull << 30))
         return fail(MEE_ERR_INVALID_ARG, "mee_table_create: max_batch must be in [1, 2^30]");
@@ -893,6 +936,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     } while (0)
     ALLOC(t->keys, t->capacity * sizeof(int64_t));
     t->table_bytes = t->capacity * sizeof(int64_t);
+    if (cfg->flags & MEE_FLAG_TRACK_HITS) { ALLOC(t->hits, t->capacity * sizeof(uint32_t)); t->table_bytes += t->capacity * sizeof(uint32_t); }
     ALLOC_PLANE(t->values);
     if (t->optimizer != MEE_OPT_NONE) ALLOC_PLANE(t->s1);
     if (t->optimizer == MEE_OPT_ADAM) ALLOC_PLANE(t->s2);
@@ -916,6 +960,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
         hipError_t e = hipSuccess;
         fill_i64_kernel<<<2048, 256, 0, 0>>>(t->keys, t->capacity, kEmpty);
         if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess && t->hits) e = hipMemsetAsync(t->hits, 0, t->capacity * sizeof(uint32_t), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.skeys, 0, S * 8, 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.sval, 0, S * 4, 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.sval0, 0, S * 4, 0);
@@ -963,7 +1008,7 @@ static const float* plane_of(const mee_table* t, uint32_t plane) {
 }
 
 static int find_plane(const mee_table* t, const float* plane, float miss_value, const int64_t* d_keys, size_t n, float* d_out,
-                      uint8_t* d_found, void* stream, bool missing_only = false) {
+                      uint8_t* d_found, void* stream, bool missing_only = false, bool counted = false) {
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -972,14 +1017,16 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
     if (t->dim4 != 16 && t->dim4 != 32 && R > 2) R = 2;
     R = R >= 8 ? 8 : R >= 4 ? 4 : R >= 2 ? 2 : 1;
     const unsigned grid = grid_for(n, 4u * 4u * (unsigned)R, t->find_grid_cap > 0 ? (unsigned)t->find_grid_cap : (1u << 22));
-#define FIND1(D4, RR, NT) find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4)
+#define FIND1(D4, RR, NT) find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr)
     const int nt = t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
 #define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
-    if (missing_only) {  // sparse second pass over a batch most of which is already resolved: one key in flight per tile
+    if (missing_only || counted) {  // sparse second pass / sampled statistics pass: one key in flight per tile
         const unsigned g1 = grid_for(n, 16, 1u << 22);
-        if (t->dim4 == 16) find_kernel<16, 1, 12><<<g1, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4);
-        else if (t->dim4 == 32) find_kernel<32, 1, 12><<<g1, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4);
-        else find_kernel<0, 1, 12><<<g1, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4);
+#define FINDX(D4, NT) find_kernel<D4, 1, NT><<<g1, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, t->hits)
+#define FINDX_D(NT) do { if (t->dim4 == 16) FINDX(16, NT); else if (t->dim4 == 32) FINDX(32, NT); else FINDX(0, NT); } while (0)
+        if (missing_only && counted) FINDX_D(28); else if (missing_only) FINDX_D(12); else FINDX_D(20);
+#undef FINDX_D
+#undef FINDX
     } else
     if (t->dim4 == 16) { if (R == 8) FIND(16, 8); else if (R == 4) FIND(16, 4); else if (R == 2) FIND(16, 2); else FIND(16, 1); }
     else if (t->dim4 == 32) { if (R == 4) FIND(32, 4); else if (R == 2) FIND(32, 2); else FIND(32, 1); }
@@ -998,6 +1045,27 @@ int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, 
 int mee_find_missing(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
     if (!t || (n && (!d_keys || !d_out || !d_found))) return fail(MEE_ERR_INVALID_ARG, "mee_find_missing: null argument");
     return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, true);
+}
+
+int mee_find_counted(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int missing_only, void* stream) {
+    if (!t || (n && (!d_keys || !d_out || !d_found))) return fail(MEE_ERR_INVALID_ARG, "mee_find_counted: null argument");
+    if (!t->hits) return fail(MEE_ERR_UNSUPPORTED, "mee_find_counted: table was created without MEE_FLAG_TRACK_HITS");
+    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, missing_only != 0, true);
+}
+
+int mee_hits_scan(mee_table* t, uint32_t min_hits, uint32_t max_hits, int reset, int64_t* d_keys_out, size_t cap, size_t* n_out,
+                  void* stream) {
+    if (!t || !n_out || (cap && !d_keys_out)) return fail(MEE_ERR_INVALID_ARG, "mee_hits_scan: null argument");
+    if (!t->hits) return fail(MEE_ERR_UNSUPPORTED, "mee_hits_scan: table was created without MEE_FLAG_TRACK_HITS");
+    DeviceGuard g(t->device);
+    hipStream_t st = as_stream(stream);
+    MEE_HIP(hipMemsetAsync(&t->op->n_export, 0, sizeof(unsigned long long), st));
+    hits_scan_kernel<<<grid_for(t->capacity, 4 * 1024, 4096), 256, 0, st>>>(t->keys, t->hits, t->capacity, min_hits, max_hits, reset, d_keys_out, cap, t->op);
+    MEE_HIP(hipGetLastError());
+    MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
+    MEE_HIP(hipStreamSynchronize(st));
+    *n_out = (size_t)t->h_op->n_export;  // how many keys qualified; min(*n_out, cap) were written
+    return MEE_OK;
 }
 
 int mee_find_plane(const mee_table* t, uint32_t plane, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
@@ -1019,10 +1087,10 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
     group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr);
     if (claim)
         upsert_kernel<true><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
-                                                (const float4*)d_values, nn, t->bs.hidx, t->g.sval, nullptr, t->optimizer, t->init_acc, t->ctr);
+                                                (const float4*)d_values, nn, t->bs.hidx, t->g.sval, nullptr, t->optimizer, t->init_acc, t->ctr, t->hits);
     else
         upsert_kernel<false><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
-                                                 (const float4*)d_values, nn, t->bs.hidx, t->g.sval, d_found, t->optimizer, t->init_acc, t->ctr);
+                                                 (const float4*)d_values, nn, t->bs.hidx, t->g.sval, d_found, t->optimizer, t->init_acc, t->ctr, t->hits);
     group_reset_kernel<<<gl, 256, 0, st>>>(t->bs.hidx, nn, t->g);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
@@ -1071,7 +1139,7 @@ int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_o
     group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, fmask);
     ensure_kernel<<<gt, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys, nn, t->bs.hidx,
                                       t->g.sval, t->g.sres, t->optimizer, t->init_acc, t->initializer, t->init_scale, t->init_seed,
-                                      t->default_value, t->ctr);
+                                      t->default_value, t->ctr, t->hits);
     gather_group_kernel<<<gt, 256, 0, st>>>((const float4*)t->values, t->dim4, nn, t->bs.hidx, t->g.sres, (float4*)d_out);
     group_reset_kernel<<<gl, 256, 0, st>>>(t->bs.hidx, nn, t->g);
     MEE_HIP(hipGetLastError());

@@ -27,7 +27,7 @@ class LookupTable:
 
     def __init__(self, capacity: int, dim: int, *, device: int | torch.device = 0, optimizer: int = OPT_NONE,
                  max_batch: int = 1 << 20, default_value: float = 0.0, initial_accumulator: float = 0.0,
-                 initializer: int = INIT_CONSTANT, init_scale: float = 0.0, init_seed: int = 0, value_memory: int = 0):
+                 initializer: int = INIT_CONSTANT, init_scale: float = 0.0, init_seed: int = 0, value_memory: int = 0, track_hits: bool = False):
         L = _lib.lib()
         dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
         if dev.type != "cuda":
@@ -36,7 +36,8 @@ class LookupTable:
         cfg = _lib.Config(struct_size=C.sizeof(_lib.Config), device=self.device.index, capacity=capacity, dim=dim,
                           optimizer=optimizer, max_batch=max_batch, default_value=default_value,
                           initial_accumulator=initial_accumulator, initializer=initializer, init_scale=init_scale,
-                          init_seed=init_seed, value_memory=value_memory)
+                          init_seed=init_seed, value_memory=value_memory, flags=_lib.FLAG_TRACK_HITS if track_hits else 0)
+        self.track_hits = track_hits
         h = C.c_void_p()
         self._h = None
         check(L.mee_table_create(C.byref(cfg), C.byref(h)))
@@ -90,6 +91,25 @@ class LookupTable:
         """Second-tier pass: fill the positions an earlier find (on another table) left with found == 0."""
         k = self._keys(keys)
         check(_lib.lib().mee_find_missing(self._h, k.data_ptr(), k.numel(), out.data_ptr(), found.data_ptr(), self._s()))
+
+    def find_counted(self, keys: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None,
+                     missing_only: bool = False):
+        """find (or find_missing) that also bumps the hit counter of every key it finds (track_hits tables)."""
+        k = self._keys(keys)
+        n = k.numel()
+        if out is None:
+            out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        if found is None:
+            found = torch.empty(n, dtype=torch.uint8, device=self.device)
+        check(_lib.lib().mee_find_counted(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), int(missing_only), self._s()))
+        return out, found
+
+    def hits_scan(self, min_hits: int, max_hits: int, cap: int, reset: bool = False) -> torch.Tensor:
+        """Keys whose hit counter lies in [min_hits, max_hits] (at most cap); reset zeroes all counters."""
+        out = torch.empty(max(cap, 1), dtype=torch.int64, device=self.device)
+        n = C.c_size_t()
+        check(_lib.lib().mee_hits_scan(self._h, min_hits, min(max_hits, 0xFFFFFFFF), int(reset), out.data_ptr(), cap, C.byref(n), self._s()))
+        return out[: min(n.value, cap)]
 
     def insert(self, keys: torch.Tensor, values: torch.Tensor) -> None:
         k = self._keys(keys)

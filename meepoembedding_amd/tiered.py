@@ -10,8 +10,11 @@ Design (host logic only; every row still moves through the HIP kernels):
              caller's stream, so a cold access costs PCIe bandwidth but no host thread and no staging copy.
   * a key lives in exactly ONE tier, so the pair behaves like one table (tests compare it with a single oracle table).
   * new keys go to the hot tier while it has room (`hot_key_limit`), else to the cold tier; `promote` / `demote` move
-    keys (values AND optimizer state) between tiers — which keys to move is the caller's policy (e.g. the top of a
-    frequency sketch), typically issued on a side stream between steps.
+    keys (values AND optimizer state) between tiers.
+  * placement policy (tables created with track_hits=True): every cold hit and every `sample_every`-th hot lookup bumps
+    a per-slot counter inside the find kernel; `rebalance()` promotes the cold keys that were hit at least
+    `promote_threshold` times in the window and, when the hot tier is full, first demotes hot keys that no sampled
+    lookup touched.  It is meant to run between steps (on a side stream if the caller wants it off the critical path).
 
 `hot` / `cold` are any objects with the LookupTable methods, so the logic also runs on the CPU test adapters.
 """
@@ -21,7 +24,7 @@ import torch
 
 
 class TieredLookupTable:
-    def __init__(self, hot, cold, hot_key_limit: int | None = None):
+    def __init__(self, hot, cold, hot_key_limit: int | None = None, sample_every: int = 8, promote_threshold: int = 2):
         if hot.dim != cold.dim:
             raise ValueError("hot and cold tables must have the same dim")
         self.hot, self.cold, self.dim = hot, cold, hot.dim
@@ -29,6 +32,9 @@ class TieredLookupTable:
         # keep the hot table at a load it probes fast at (SPEC.md §2: probe length grows with load)
         self.hot_key_limit = int(hot_key_limit if hot_key_limit is not None else getattr(hot, "capacity", 0) * 0.75)
         self._hot_keys_ub = 0  # upper bound on hot.size(), maintained without synchronising
+        self.policy = bool(getattr(hot, "track_hits", False) and getattr(cold, "track_hits", False))
+        self.sample_every, self.promote_threshold = max(1, sample_every), promote_threshold
+        self._calls = 0
 
     # -- helpers -----------------------------------------------------------------------------------------
     @staticmethod
@@ -43,10 +49,37 @@ class TieredLookupTable:
     # -- operators (SPEC.md §3 on the union of both tiers) ---------------------------------------------------
     def find(self, keys: torch.Tensor):
         keys = keys.contiguous().view(-1)
-        out, found = self.hot.find(keys)
-        # second pass on the same buffers: the cold table fills what the hot one missed — no host sync, no compaction
-        self.cold.find_missing(keys, out, found)
+        if not self.policy:
+            out, found = self.hot.find(keys)
+            # second pass on the same buffers: the cold table fills what the hot one missed — no host sync, no compaction
+            self.cold.find_missing(keys, out, found)
+            return out, found
+        self._calls += 1
+        if self._calls % self.sample_every == 0:
+            out, found = self.hot.find_counted(keys)          # sampled: hot keys that are still in use get marked
+        else:
+            out, found = self.hot.find(keys)
+        self.cold.find_counted(keys, out, found, missing_only=True)  # cold hits are always counted (they are PCIe-bound anyway)
         return out, found
+
+    def rebalance(self, max_moves: int = 1 << 20) -> tuple[int, int]:
+        """One policy step: promote cold keys hit >= promote_threshold times since the last call, demoting untouched hot
+        keys first if the hot tier is full.  Returns (promoted, demoted).  Starts a new observation window."""
+        if not self.policy:
+            raise RuntimeError("rebalance() needs both tiers created with track_hits=True")
+        cand = self.cold.hits_scan(self.promote_threshold, 0xFFFFFFFF, max_moves, reset=True)
+        self._hot_keys_ub = self.hot.size()
+        room = max(0, self.hot_key_limit - self._hot_keys_ub)
+        need = max(0, int(cand.numel()) - room)
+        demoted = 0
+        victims = self.hot.hits_scan(0, 0, need, reset=True)   # also restarts the hot tier's window
+        if need and victims.numel():
+            demoted = self._move(self.hot, self.cold, victims)
+            self._hot_keys_ub -= demoted
+            room += demoted
+        promoted = self._move(self.cold, self.hot, cand[:room]) if room and cand.numel() else 0
+        self._hot_keys_ub += promoted
+        return promoted, demoted
 
     def insert(self, keys: torch.Tensor, values: torch.Tensor) -> None:
         keys = keys.contiguous().view(-1)

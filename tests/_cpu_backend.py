@@ -8,11 +8,15 @@ import oracle
 
 class CpuTable:
     def __init__(self, capacity, dim, **kw):
+        track = kw.pop("track_hits", False)
         self.o = oracle.OracleTable(capacity, dim, **kw)
+        kw["track_hits"] = track
         self.dim = dim
         self.optimizer = kw.get("optimizer", 0)
         self.device = torch.device("cpu")
         self.capacity = self.o.capacity
+        self.track_hits = bool(kw.pop("track_hits", False)) if "track_hits" in kw else False
+        self.hits = {}
 
     def find(self, keys):
         out, found = self.o.find(keys.numpy())
@@ -31,6 +35,25 @@ class CpuTable:
     def dedup_sum(self, keys, grads=None):
         uniq, gs, inv, cnt = oracle.dedup_sum(keys.numpy(), None if grads is None else grads.numpy(), self.dim)
         return torch.from_numpy(uniq), (None if grads is None else torch.from_numpy(gs)), torch.from_numpy(cnt.astype(np.int32)), torch.from_numpy(inv)
+
+    def find_counted(self, keys, out=None, found=None, missing_only=False):
+        if missing_only:
+            before = found.clone()
+            self.find_missing(keys, out, found)
+            hit = (before == 0) & (found != 0)
+        else:
+            out, found = self.find(keys)
+            hit = found != 0
+        for k in keys[hit].tolist():
+            self.hits[k] = self.hits.get(k, 0) + 1
+        return out, found
+
+    def hits_scan(self, min_hits, max_hits, cap, reset=False):
+        stored = self.o.export()[0].tolist()
+        out = [k for k in stored if min_hits <= self.hits.get(k, 0) <= max_hits][:cap]
+        if reset:
+            self.hits = {}
+        return torch.tensor(out, dtype=torch.int64)
 
     def find_missing(self, keys, out, found):
         miss = torch.nonzero(found == 0).view(-1)

@@ -29,7 +29,7 @@ def _drive(tiered, ref, dev, opt, n_iter=40, seed=0):
         idx = np.minimum(rng.zipf(1.3, size=n) - 1, universe.size - 1) if rng.random() < 0.5 else rng.integers(0, universe.size, n)
         keys = universe[idx]
         rows = rng.standard_normal((n, DIM)).astype(np.float32)
-        op = rng.choice(["insert", "insert", "assign", "remove", "find", "find_or_insert", "apply", "promote", "demote"])
+        op = rng.choice(["insert", "insert", "assign", "remove", "find", "find", "find_or_insert", "apply", "promote", "demote", "rebalance"])
         if op == "insert":
             tiered.insert(T(keys), T(rows)); ref.insert(keys, rows)
         elif op == "assign":
@@ -50,6 +50,9 @@ def _drive(tiered, ref, dev, opt, n_iter=40, seed=0):
                 tiered.apply_adagrad(T(keys), T(g), lr=0.02, eps=1e-10); ref.apply_adagrad(keys, g, 0.02, 1e-10)
             else:
                 tiered.apply_adam(T(keys), T(g), lr=0.002, step=step); ref.apply_adam(keys, g, 0.002, 0.9, 0.999, 1e-8, step)
+        elif op == "rebalance":
+            if tiered.policy:
+                tiered.rebalance(max_moves=300)   # policy-driven migration must not change anything observable either
         elif op == "promote":
             tiered.promote(T(keys[:200]))      # migration must not change anything observable
         else:
@@ -67,10 +70,10 @@ def _drive(tiered, ref, dev, opt, n_iter=40, seed=0):
 @pytest.mark.parametrize("opt", [oracle.OPT_ADAGRAD, oracle.OPT_ADAM])
 def test_tiered_cpu_logic(built, opt):
     from _cpu_backend import CpuTable
-    hot = CpuTable(1024, DIM, optimizer=opt, **KW)
-    cold = CpuTable(8192, DIM, optimizer=opt, **KW)
+    hot = CpuTable(1024, DIM, optimizer=opt, track_hits=True, **KW)
+    cold = CpuTable(8192, DIM, optimizer=opt, track_hits=True, **KW)
     ref = oracle.OracleTable(16384, DIM, optimizer=opt, **KW)
-    t = _drive(TieredLookupTable(hot, cold, hot_key_limit=600), ref, torch.device("cpu"), opt, seed=int(opt))
+    t = _drive(TieredLookupTable(hot, cold, hot_key_limit=600, sample_every=2), ref, torch.device("cpu"), opt, seed=int(opt))
     assert 0 < hot.size() <= 600 and cold.size() > 0, "both tiers must have been used"
 
 
@@ -78,8 +81,40 @@ def test_tiered_cpu_logic(built, opt):
 @pytest.mark.parametrize("opt", [oracle.OPT_ADAGRAD, oracle.OPT_ADAM])
 def test_tiered_hbm_plus_pinned_host(dev, opt):
     from meepoembedding_amd import LookupTable, _lib
-    hot = LookupTable(1024, DIM, device=dev, optimizer=opt, max_batch=4096, **KW)
-    cold = LookupTable(8192, DIM, device=dev, optimizer=opt, max_batch=4096, value_memory=_lib.MEM_HOST_PINNED, **KW)
+    hot = LookupTable(1024, DIM, device=dev, optimizer=opt, max_batch=4096, track_hits=True, **KW)
+    cold = LookupTable(8192, DIM, device=dev, optimizer=opt, max_batch=4096, value_memory=_lib.MEM_HOST_PINNED, track_hits=True, **KW)
     ref = oracle.OracleTable(16384, DIM, optimizer=opt, **KW)
-    _drive(TieredLookupTable(hot, cold, hot_key_limit=600), ref, dev, opt, seed=10 + int(opt))
+    _drive(TieredLookupTable(hot, cold, hot_key_limit=600, sample_every=2), ref, dev, opt, seed=10 + int(opt))
     assert 0 < hot.size() <= 600 and cold.size() > 0
+
+
+@pytest.mark.gpu
+def test_policy_moves_the_hot_set_into_hbm(dev):
+    """Skewed lookups over keys that all start cold: after a few observe + rebalance rounds the frequently used keys
+    sit in the HBM tier and the cold share of the lookups has collapsed; nothing observable changed."""
+    from meepoembedding_amd import LookupTable, _lib
+    n_keys, hot_limit = 20000, 2000
+    hot = LookupTable(4096, DIM, device=dev, max_batch=8192, track_hits=True)
+    cold = LookupTable(32768, DIM, device=dev, max_batch=32768, value_memory=_lib.MEM_HOST_PINNED, track_hits=True)
+    keys = synth.keys_np(33, 0, n_keys); rows = synth.rows_np(keys, DIM, 2)
+    cold.insert(torch.from_numpy(keys).to(dev), torch.from_numpy(rows).to(dev))
+    t = TieredLookupTable(hot, cold, hot_key_limit=hot_limit, sample_every=2, promote_threshold=2)
+    rng = np.random.default_rng(5)
+
+    def batch():
+        return keys[np.minimum(rng.zipf(1.2, size=8000) - 1, n_keys - 1)]
+
+    def cold_share(b):
+        _, f = hot.find(torch.from_numpy(b).to(dev))
+        return 1.0 - float(f.float().mean())
+
+    first = cold_share(batch())
+    for rnd in range(4):
+        for _ in range(6):
+            b = batch()
+            out, found = t.find(torch.from_numpy(b).to(dev))
+            assert bool(found.all()) and np.array_equal(out.cpu().numpy(), synth.rows_np(b, DIM, 2))
+        t.rebalance(max_moves=4000)
+    last = cold_share(batch())
+    assert first > 0.99 and last < 0.35, (first, last)
+    assert hot.size() <= hot_limit and hot.size() + cold.size() == n_keys
