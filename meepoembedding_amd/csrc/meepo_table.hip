@@ -835,8 +835,9 @@ TableView table_view(const mee_table* t) {
     return TableView{t->device, t->keys, t->values, t->nb, t->dim, t->dim4, t->default_value};
 }
 
-static int check_batch(const mee_table* t, size_t n, const char* op) {
-    if (t->prepared_n && strncmp(op, "mee_apply", 9) != 0 && strcmp(op, "mee_remove") != 0)
+// `needs_group_table`: the op would overwrite the group table, which a pending mee_apply_prepare still owns
+static int check_batch(const mee_table* t, size_t n, const char* op, bool needs_group_table = true) {
+    if (t->prepared_n && needs_group_table)
         return fail(MEE_ERR_INVALID_ARG, "%s: a prepared apply is pending on this table (finish it with mee_apply_* or mee_apply_discard)", op);
     if (n > t->max_batch)
         return fail(MEE_ERR_BATCH_TOO_LARGE, "%s: n=%zu exceeds config.max_batch=%llu", op, n, (unsigned long long)t->max_batch);
@@ -1112,7 +1113,7 @@ int mee_assign_plane(mee_table* t, uint32_t plane, const int64_t* d_keys, const 
 
 int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream) {
     if (!t || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_remove: null argument");
-    if (int rc = check_batch(t, n, "mee_remove")) return rc;
+    if (int rc = check_batch(t, n, "mee_remove", false)) return rc;
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -1206,7 +1207,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
                         const char* name) {
     if (!t || (n && (!d_keys || !d_grads))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
     if (t->optimizer != a.kind) return fail(MEE_ERR_UNSUPPORTED, "%s: table was created with optimizer=%u", name, t->optimizer);
-    if (int rc = check_batch(t, n, name)) return rc;
+    if (int rc = check_batch(t, n, name, false)) return rc;
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
