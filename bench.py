@@ -96,6 +96,35 @@ def cpu_baseline(synth, dim, batch, budget_s=12.0):
                       f"table (load 0.75), uniform {batch}-key batches, ~{budget_s / 2:.0f}s per thread count"}
 
 
+def train_step_extra(find_table, synth, n_keys, dim, dev, chunk, batches, out, found, bpl, steps=100):
+    """configs[2] on the same box, reported beside the headline: find + sparse-Adagrad apply per step."""
+    from meepoembedding_amd import OPT_ADAGRAD, LookupTable
+    find_table.close()  # free 35 GB before the 69 GB table with optimizer state
+    batch = batches[0].numel()
+    t = LookupTable(find_table.capacity, dim, device=dev, max_batch=max(chunk, 2 * batch), optimizer=OPT_ADAGRAD)
+    populate(t, synth, n_keys, dim, dev, chunk)
+    grads = [torch.randn(batch, dim, device=dev) * 0.01 for _ in range(4)]
+
+    def step(i):
+        t.find(batches[i % len(batches)], out=out, found=found)
+        t.apply_adagrad(batches[i % len(batches)], grads[i % 4], lr=0.01, eps=1e-10)
+
+    for i in range(10):
+        step(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    uniq = sum(int(torch.unique(b).numel()) for b in batches[:4]) / 4
+    step_bytes = (bpl + 8 + 4 * dim) * batch + (8 + 16 * dim) * uniq
+    t.close()
+    return {"workload": f"configs[2]: find + sparse-Adagrad apply, {batch}-key uniform batches, {n_keys // 1_000_000}M keys, dim {dim}",
+            "train_step_keys_per_s": batch / dt, "us_per_step": dt * 1e6, "steps": steps,
+            "algorithmic_bytes_per_key": step_bytes / batch, "frac_of_hbm_roofline": step_bytes / dt / 1e9 / HBM_PEAK_GBS}
+
+
 def main():
     # stdout must carry exactly ONE JSON line: native libraries (RCCL prints a version banner to stdout when the process
     # group is created) are pointed at stderr for the whole run, and the result is written to the saved descriptor.
@@ -112,6 +141,7 @@ def main():
     ap.add_argument("--load", type=float, default=0.75)
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short configs[2] (find + Adagrad) measurement appended as `also`")
     ap.add_argument("--mode", choices=["find", "train"], default="find",
                     help="find = configs[1] (the driver's metric); train = configs[2]: find + sparse-Adagrad apply per step (N=1 only)")
     ap.add_argument("--pipeline", type=int, default=1, help="sharded only: steps in flight on separate HIP streams (1 = off)")
@@ -320,6 +350,11 @@ def main():
         }
         if not sharded and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(synth, dim, batch)
+        if not sharded and not train and not args.no_extras:
+            try:  # never allowed to break the headline line
+                res["also"] = train_step_extra(table, synth, n_keys, dim, dev, chunk, batches, out, found, bpl)
+            except Exception as e:  # noqa: BLE001
+                res["also"] = {"error": repr(e)}
         os.write(result_fd, (json.dumps(res) + "\n").encode())
     if sharded:
         dist.barrier()
