@@ -120,6 +120,10 @@ int mee_assign_plane(mee_table* t, uint32_t plane, const int64_t* d_keys, const 
 int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream);
 /* find, inserting absent keys with their initial row first; d_found (nullable) = present before the call. */
 int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
+/* Tiered pairs (a key lives in exactly one of two tables): the same two mutators restricted to the positions whose
+ * d_found byte is 0, i.e. keys that an earlier pass found in NEITHER table.  d_found is only read. */
+int mee_insert_missing(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, const uint8_t* d_found, void* stream);
+int mee_find_or_insert_missing(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, const uint8_t* d_found, void* stream);
 /* [syncs] all stored pairs, unspecified order; d_state1/d_state2 (nullable) receive acc|m and v rows in the
  * same order.  At most `cap` pairs are written; *n_out = number stored in the table. */
 int mee_export(const mee_table* t, int64_t* d_keys_out, float* d_values_out, float* d_state1_out,

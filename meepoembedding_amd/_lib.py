@@ -65,6 +65,8 @@ PROTOTYPES = {
     "mee_find_counted": (C.c_int, [_vp, _vp, _sz, _vp, _vp, C.c_int, _vp]),
     "mee_hits_scan": (C.c_int, [_vp, _u32, _u32, C.c_int, _vp, _sz, C.POINTER(_sz), _vp]),
     "mee_insert": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "mee_insert_missing": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "mee_find_or_insert_missing": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_assign": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "mee_find_plane": (C.c_int, [_vp, _u32, _vp, _sz, _vp, _vp, _vp]),
     "mee_assign_plane": (C.c_int, [_vp, _u32, _vp, _vp, _sz, _vp, _vp]),

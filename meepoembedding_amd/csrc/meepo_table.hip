@@ -1076,8 +1076,9 @@ int mee_find_plane(const mee_table* t, uint32_t plane, const int64_t* d_keys, si
     return find_plane(t, p, plane == 0 ? t->default_value : 0.0f, d_keys, n, d_out, d_found, stream);
 }
 
+// `skip` (nullable): positions whose byte is non-zero take no part (they were served by another table of a tiered pair)
 static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found,
-                         void* stream, bool claim, const char* name) {
+                         void* stream, bool claim, const char* name, const uint8_t* skip = nullptr) {
     if (!t || !plane || (n && (!d_keys || !d_values))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
     if (int rc = check_batch(t, n, name)) return rc;
     if (n == 0) return MEE_OK;
@@ -1085,7 +1086,7 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
-    group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr);
+    group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, skip);
     if (claim)
         upsert_kernel<true><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
                                                 (const float4*)d_values, nn, t->bs.hidx, t->g.sval, nullptr, t->optimizer, t->init_acc, t->ctr, t->hits);
@@ -1099,6 +1100,10 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
 
 int mee_insert(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, void* stream) {
     return upsert_common(t, t ? t->values : nullptr, d_keys, d_values, n, nullptr, stream, true, "mee_insert");
+}
+int mee_insert_missing(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, const uint8_t* d_found, void* stream) {
+    if (!d_found && n) return fail(MEE_ERR_INVALID_ARG, "mee_insert_missing: null found mask");
+    return upsert_common(t, t ? t->values : nullptr, d_keys, d_values, n, nullptr, stream, true, "mee_insert_missing", d_found);
 }
 int mee_assign(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found, void* stream) {
     return upsert_common(t, t ? t->values : nullptr, d_keys, d_values, n, d_found, stream, false, "mee_assign");
@@ -1125,9 +1130,11 @@ int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, 
     return MEE_OK;
 }
 
-int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
-    if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_or_insert: null argument");
-    if (int rc = check_batch(t, n, "mee_find_or_insert")) return rc;
+// shared by mee_find_or_insert (own find pass) and mee_find_or_insert_missing (mask supplied by the caller)
+static int find_or_insert_common(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream,
+                                 bool own_find_pass, const char* name) {
+    if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
+    if (int rc = check_batch(t, n, name)) return rc;
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -1136,7 +1143,8 @@ int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_o
     // pass 1: a plain find serves every key that is already stored (the steady state of training) at find speed and
     // yields the "present before the call" mask; pass 2 runs the insert machinery over the missing positions only.
     uint8_t* fmask = d_found ? d_found : t->bs.fmask;
-    if (int rc = find_plane(t, t->values, t->default_value, d_keys, n, d_out, fmask, stream)) return rc;
+    if (own_find_pass)
+        if (int rc = find_plane(t, t->values, t->default_value, d_keys, n, d_out, fmask, stream)) return rc;
     group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, fmask);
     ensure_kernel<<<gt, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys, nn, t->bs.hidx,
                                       t->g.sval, t->g.sres, t->optimizer, t->init_acc, t->initializer, t->init_scale, t->init_seed,
@@ -1145,6 +1153,14 @@ int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_o
     group_reset_kernel<<<gl, 256, 0, st>>>(t->bs.hidx, nn, t->g);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
+}
+
+int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
+    return find_or_insert_common(t, d_keys, n, d_out, d_found, stream, true, "mee_find_or_insert");
+}
+int mee_find_or_insert_missing(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, const uint8_t* d_found, void* stream) {
+    if (!d_found && n) return fail(MEE_ERR_INVALID_ARG, "mee_find_or_insert_missing: null found mask");
+    return find_or_insert_common(t, d_keys, n, d_out, const_cast<uint8_t*>(d_found), stream, false, "mee_find_or_insert_missing");
 }
 
 int mee_export(const mee_table* t, int64_t* d_keys_out, float* d_values_out, float* d_state1_out, float* d_state2_out,

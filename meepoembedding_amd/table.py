@@ -116,6 +116,17 @@ class LookupTable:
         v = self._rows(values, k.numel())
         check(_lib.lib().mee_insert(self._h, k.data_ptr(), v.data_ptr(), k.numel(), self._s()))
 
+    def insert_missing(self, keys: torch.Tensor, values: torch.Tensor, found: torch.Tensor) -> None:
+        """insert restricted to the positions with found == 0 (tiered pairs: keys found in neither table)."""
+        k = self._keys(keys)
+        v = self._rows(values, k.numel())
+        check(_lib.lib().mee_insert_missing(self._h, k.data_ptr(), v.data_ptr(), k.numel(), found.data_ptr(), self._s()))
+
+    def find_or_insert_missing(self, keys: torch.Tensor, out: torch.Tensor, found: torch.Tensor) -> None:
+        """find_or_insert restricted to the positions with found == 0; rows of those positions are written into out."""
+        k = self._keys(keys)
+        check(_lib.lib().mee_find_or_insert_missing(self._h, k.data_ptr(), k.numel(), out.data_ptr(), found.data_ptr(), self._s()))
+
     def assign(self, keys: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
         k = self._keys(keys)
         v = self._rows(values, k.numel())

@@ -81,53 +81,39 @@ class TieredLookupTable:
         self._hot_keys_ub += promoted
         return promoted, demoted
 
+    # Mutators exploit "a key lives in exactly one tier": overwrite / delete passes simply go to BOTH tables (the one
+    # that does not hold the key ignores it) and the found masks are OR-ed; only the creation of new keys needs the
+    # combined mask, through the *_missing operators.  Nothing here synchronises except the rare refresh of the
+    # hot-tier fill bound.
     def insert(self, keys: torch.Tensor, values: torch.Tensor) -> None:
         keys = keys.contiguous().view(-1)
         values = values.contiguous().view(keys.numel(), self.dim)
-        in_hot = self.hot.assign(keys, values)           # present in hot: overwritten there (last occurrence wins)
-        rest = self._idx(in_hot == 0)
-        if not rest.numel():
-            return
-        k2, v2 = keys[rest], values[rest]
-        in_cold = self.cold.assign(k2, v2)               # present in cold: overwritten there
-        new = self._idx(in_cold == 0)
-        if not new.numel():
-            return
-        k3, v3 = k2[new], v2[new]                        # absent everywhere: all occurrences of a key land in one tier
-        if self._room_for(k3.numel()):
-            self.hot.insert(k3, v3)
-            self._hot_keys_ub += k3.numel()
+        found = self.hot.assign(keys, values) | self.cold.assign(keys, values)   # present somewhere: overwritten (last wins)
+        n = keys.numel()
+        if self._room_for(n):                                                   # n bounds the number of new keys
+            self.hot.insert_missing(keys, values, found)
+            self._hot_keys_ub += n
         else:
-            self.cold.insert(k3, v3)
+            self.cold.insert_missing(keys, values, found)
 
     def assign(self, keys: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
         keys = keys.contiguous().view(-1)
         values = values.contiguous().view(keys.numel(), self.dim)
-        found = self.hot.assign(keys, values)
-        rest = self._idx(found == 0)
-        if rest.numel():
-            found[rest] = self.cold.assign(keys[rest], values[rest])
-        return found
+        return self.hot.assign(keys, values) | self.cold.assign(keys, values)
 
     def remove(self, keys: torch.Tensor) -> torch.Tensor:
         keys = keys.contiguous().view(-1)
-        found = self.hot.remove(keys)
-        rest = self._idx(found == 0)
-        if rest.numel():
-            found[rest] = self.cold.remove(keys[rest])
-        return found
+        return self.hot.remove(keys) | self.cold.remove(keys)
 
     def find_or_insert(self, keys: torch.Tensor):
         keys = keys.contiguous().view(-1)
         out, found = self.find(keys)
-        miss = self._idx(found == 0)
-        if miss.numel():
-            km = keys[miss]
-            tier = self.hot if self._room_for(km.numel()) else self.cold
-            rows, _ = tier.find_or_insert(km)            # inserts the hashed initial row once per distinct key
-            if tier is self.hot:
-                self._hot_keys_ub += km.numel()
-            out[miss] = rows
+        n = keys.numel()
+        if self._room_for(n):
+            self.hot.find_or_insert_missing(keys, out, found)   # inserts the hashed initial row once per distinct new key
+            self._hot_keys_ub += n
+        else:
+            self.cold.find_or_insert_missing(keys, out, found)
         return out, found
 
     def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10) -> None:

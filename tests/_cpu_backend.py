@@ -55,6 +55,17 @@ class CpuTable:
             self.hits = {}
         return torch.tensor(out, dtype=torch.int64)
 
+    def insert_missing(self, keys, values, found):
+        m = torch.nonzero(found == 0).view(-1)
+        if m.numel():
+            self.insert(keys[m], values[m])
+
+    def find_or_insert_missing(self, keys, out, found):
+        m = torch.nonzero(found == 0).view(-1)
+        if m.numel():
+            rows, _ = self.find_or_insert(keys[m])
+            out[m] = rows
+
     def find_missing(self, keys, out, found):
         miss = torch.nonzero(found == 0).view(-1)
         if miss.numel():
