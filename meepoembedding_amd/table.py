@@ -198,6 +198,21 @@ class LookupTable:
             raise MeepoError(_lib.ERR_HIP, f"export wrote {m.value} pairs, size() said {n}")
         return (keys, vals, s1, s2) if with_state else (keys, vals)
 
+    def import_(self, keys: torch.Tensor, values: torch.Tensor, state1: torch.Tensor | None = None,
+                state2: torch.Tensor | None = None) -> None:
+        """Inverse of export(with_state=True): bulk-load pairs (and optimizer state) of any length, max_batch at a time.
+        The on-disk checkpoint format is exactly export's arrays: int64 keys[N], fp32 values[N, dim] (+ state planes)."""
+        k = self._keys(keys)
+        n = k.numel()
+        v = self._rows(values, n)
+        planes = [(1, state1), (2, state2)]
+        for s in range(0, n, self.max_batch):
+            e = min(n, s + self.max_batch)
+            self.insert(k[s:e], v[s:e])
+            for plane, st in planes:
+                if st is not None:
+                    self.assign_plane(plane, k[s:e], self._rows(st, n)[s:e])
+
     # -- sparse optimizers (SPEC.md §4) --------------------------------------------------------------------
     def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10) -> None:
         k = self._keys(keys)

@@ -501,3 +501,24 @@ def test_apply_prepare_split(dev):
     assert np.array_equal(g_[0][a], o_[0][b])
     np.testing.assert_allclose(g_[1][a], o_[1][b], rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(g_[2][a], o_[2][b], rtol=RTOL, atol=ATOL)
+
+
+def test_export_import_roundtrip_with_state(dev):
+    """export(with_state) -> import_ into a fresh table of another capacity (chunked by max_batch): identical table."""
+    dim, n = 32, 25000
+    keys = synth.keys_np(95, 0, n); rows = synth.rows_np(keys, dim, 2)
+    a = LookupTable(40000, dim, device=dev, optimizer=OPT_ADAM, max_batch=n)
+    a.insert(T(keys, dev), T(rows, dev))
+    g = (synth.rows_np(keys, dim, 6) * 0.02).astype(np.float32)
+    for s in range(2):
+        a.apply_adam(T(keys, dev), T(g, dev), lr=0.001, step=s + 1)
+    ek, ev, e1, e2 = a.export(with_state=True)
+    b = LookupTable(65536, dim, device=dev, optimizer=OPT_ADAM, max_batch=4096)   # forces 7 chunks
+    b.import_(ek, ev, e1, e2)
+    assert b.size() == n
+    for plane in (0, 1, 2):
+        pa, fa = a.find_plane(plane, T(keys, dev)); pb, fb = b.find_plane(plane, T(keys, dev))
+        assert bool(fa.all()) and bool(fb.all()) and torch.equal(pa, pb)
+    a.apply_adam(T(keys, dev), T(g, dev), lr=0.001, step=3); b_keys = T(keys[:4096], dev)
+    b.apply_adam(b_keys, T(g[:4096], dev), lr=0.001, step=3)       # training continues identically from the checkpoint
+    assert torch.equal(a.find(b_keys)[0], b.find(b_keys)[0])
