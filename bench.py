@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--transport", choices=["auto", "rccl", "p2p"], default="auto",
                     help="sharded only: rccl = all-to-all exchange; p2p = owners store rows into the requester's peer-mapped buffer; "
                          "auto = verify p2p against rccl, time both for a few steps, keep the faster")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = rehearsal of the N>1 flow on a box with fewer GPUs than ranks (exchange staged through host memory)")
     ap.add_argument("--dedup", action="store_true", help="sharded only: exchange only the batch's distinct keys (pays off on skewed streams)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even at N=1 (rehearsal of the N>1 code)")
     ap.add_argument("--verbose", action="store_true")
@@ -161,12 +163,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
 
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    ctrl = torch.device("cpu") if args.backend == "gloo" else dev   # where the small control tensors of collectives live
     if world > 1 or args.force_sharded:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     # rank 0 (re)builds the native library if it is stale; nobody loads it before that is done
     import __graft_entry__
     if rank == 0:
@@ -228,7 +234,7 @@ def main():
 
                 o_a, f_a = step_rccl(0)
                 o_b, f_b = step_p2p(0)
-                same = torch.tensor([int(torch.equal(o_a, o_b) and torch.equal(f_a, f_b))], device=dev)
+                same = torch.tensor([int(torch.equal(o_a, o_b) and torch.equal(f_a, f_b))], device=ctrl)
                 dist.all_reduce(same, op=dist.ReduceOp.MIN)
                 peer.check()
 
@@ -240,7 +246,7 @@ def main():
                     for i in range(k):
                         fn(i)
                     torch.cuda.synchronize(dev)
-                    tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=dev)
+                    tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=ctrl)
                     dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
                     return float(tt_.item()) / k
 
@@ -250,7 +256,7 @@ def main():
                     # peer-written result buffer would show here, not on first touch)
                     o_a, f_a = step_rccl(5)
                     o_b, f_b = step_p2p(5)
-                    same = torch.tensor([int(torch.equal(o_a, o_b) and torch.equal(f_a, f_b))], device=dev)
+                    same = torch.tensor([int(torch.equal(o_a, o_b) and torch.equal(f_a, f_b))], device=ctrl)
                     dist.all_reduce(same, op=dist.ReduceOp.MIN)
                     log(f"transport probe: rccl {t_rccl * 1e3:.3f} ms/step, p2p {t_p2p * 1e3:.3f} ms/step, re-check {'ok' if int(same.item()) else 'MISMATCH'}")
                     if int(same.item()) == 1 and (args.transport == "p2p" or t_p2p < t_rccl):
@@ -294,7 +300,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     if sharded:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctrl)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
