@@ -1,0 +1,41 @@
+"""GPU: bench.py's output contract — exactly one JSON line on stdout with the required fields — at N=1 (small table) and,
+as a rehearsal of the N>1 flow, with two ranks sharing this box's GPU over gloo (populate by owner, transport probe)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"}
+
+
+def _one_json_line(cmd):
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must be ONE line, got {len(lines)}: {r.stdout[:500]}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_contract(dev):
+    res = _one_json_line([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--keys", "2000000", "--no-extras"])
+    assert REQUIRED <= set(res) and "cpu_baseline" in res
+    assert res["n_gpus"] == 1 and res["steps"] == 20 and res["warmup"] == 5 and res["vs_baseline"] is None and res["value"] > 1e8
+    rf = res["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    cb = res["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert "workload" in res["config"] and "model" not in res["config"]
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal(dev):
+    res = _one_json_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", "bench.py", "--gpus", "2", "--backend", "gloo", "--keys", "2000000", "--batch", "65536",
+                          "--steps", "5", "--warmup", "2"])
+    assert REQUIRED <= set(res) and res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
+    assert "transport" in res["config"]["workload"]
