@@ -14,6 +14,7 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--launches", type=int, default=200)
 ap.add_argument("--dist", default="uniform")
 ap.add_argument("--no-found", action="store_true")
+ap.add_argument("--miss", type=float, default=0.0, help="fraction of looked-up keys that are absent")
 ap.add_argument("--load", type=float, default=0.75)
 ap.add_argument("variants", nargs="*", default=["find_rounds=1", "find_rounds=2", "find_rounds=4", "find_rounds=8"])
 a = ap.parse_args()
@@ -21,6 +22,11 @@ dev = torch.device("cuda", 0)
 t = LookupTable(int(a.keys / a.load), a.dim, device=dev, max_batch=1 << 20)
 bench.populate(t, synth, a.keys, a.dim, dev, 1 << 20)
 batches = bench.lookup_batches(synth, a.keys, a.batch, 64, a.dist, dev, seed=3)
+if a.miss > 0:
+    g_ = torch.Generator(device=dev); g_.manual_seed(5)
+    for b in batches:
+        m = torch.rand(a.batch, device=dev, generator=g_) < a.miss
+        b[m] = synth.keys_t(99, 0, a.batch, dev)[m]   # keys of another stream: absent
 out = torch.empty((a.batch, a.dim), dtype=torch.float32, device=dev); found = None if a.no_found else torch.empty(a.batch, dtype=torch.uint8, device=dev)
 times = {v: [] for v in a.variants}
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
