@@ -5,7 +5,7 @@
 // pair, the shard router and the peer-mapped exchange context.  The reference snapshot defines no C++ interface
 // (/root/reference/README.md:2 is its only functional statement); names follow the verbs the north_star lists.
 // Every pointer argument is DEVICE memory; every call is asynchronous on the given stream unless noted; errors are
-// thrown as meepo::Error (code + the library's message).  tests/cabi/cabi_test.cpp drives all of it on the GPU.
+// thrown as meepo::Error (code + the library's message).  tests/cabi/host_cpp_test.cpp drives all of it on the GPU.
 #pragma once
 #include <cstdint>
 #include <stdexcept>
