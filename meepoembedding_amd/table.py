@@ -42,6 +42,9 @@ class LookupTable:
         self._h = None
         check(L.mee_table_create(C.byref(cfg), C.byref(h)))
         self._h = h
+        self._opts = dict(device=self.device, optimizer=optimizer, max_batch=max_batch, default_value=default_value,
+                          initial_accumulator=initial_accumulator, initializer=initializer, init_scale=init_scale, init_seed=init_seed,
+                          value_memory=value_memory, track_hits=track_hits)
         info = _lib.TableInfo()
         check(L.mee_table_info_get(self._h, C.byref(info)))
         self.capacity, self.n_buckets, self.max_batch = info.capacity, info.n_buckets, info.max_batch
@@ -212,6 +215,15 @@ class LookupTable:
             for plane, st in planes:
                 if st is not None:
                     self.assign_plane(plane, k[s:e], self._rows(st, n)[s:e])
+
+    def resized(self, capacity: int, chunk: int = 1 << 22) -> "LookupTable":
+        """Rehash into a NEW table of another capacity (same options): export -> import_, state planes included.
+        The table itself never resizes (SPEC.md §2); growing is this explicit copy, which needs both tables to fit."""
+        opts = self._opts.copy()
+        new = LookupTable(capacity, self.dim, **opts)
+        ek, ev, e1, e2 = self.export(with_state=True)
+        new.import_(ek, ev, e1, e2)
+        return new
 
     # -- sparse optimizers (SPEC.md §4) --------------------------------------------------------------------
     def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10) -> None:

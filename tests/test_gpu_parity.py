@@ -522,3 +522,23 @@ def test_export_import_roundtrip_with_state(dev):
     a.apply_adam(T(keys, dev), T(g, dev), lr=0.001, step=3); b_keys = T(keys[:4096], dev)
     b.apply_adam(b_keys, T(g[:4096], dev), lr=0.001, step=3)       # training continues identically from the checkpoint
     assert torch.equal(a.find(b_keys)[0], b.find(b_keys)[0])
+
+
+def test_resized_rehash(dev):
+    """Growing = an explicit rehash into a new table: a table filled to load 0.95 (long probe chains) is rehashed to load
+    0.5; every key, row and Adagrad accumulator survives and lookups agree with the oracle."""
+    dim, cap = 16, 16 * 512
+    n = int(cap * 0.95)
+    keys = synth.keys_np(97, 0, n); rows = synth.rows_np(keys, dim, 2)
+    t = LookupTable(cap, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=n, initial_accumulator=0.1)
+    o = oracle.OracleTable(cap, dim, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
+    t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
+    g = (synth.rows_np(keys, dim, 6) * 0.02).astype(np.float32)
+    t.apply_adagrad(T(keys, dev), T(g, dev), lr=0.01); o.apply_adagrad(keys, g, 0.01, 1e-10)
+    big = t.resized(2 * cap)
+    assert big.capacity == 2 * cap and big.size() == n and big.status() == 0
+    q = np.concatenate([keys, synth.keys_np(98, 0, 100)])
+    out, found = big.find(T(q, dev)); eo, ef = o.find(q)
+    assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
+    acc, _ = big.find_plane(1, T(keys, dev)); acc0, _ = t.find_plane(1, T(keys, dev))
+    assert torch.equal(acc, acc0)
