@@ -1,0 +1,48 @@
+"""GPU: the table as a torch layer (forward = find_or_insert, backward = the table's sparse Adagrad) trains a small
+model exactly like torch.nn.Embedding(sparse=True) + torch.optim.Adagrad on the CPU (third-party reference math)."""
+import numpy as np
+import pytest
+import torch
+
+from meepoembedding_amd import OPT_ADAGRAD, LookupTable, synth
+from meepoembedding_amd.nn import DynamicEmbedding
+
+
+@pytest.mark.gpu
+def test_dynamic_embedding_trains_like_torch_sparse_adagrad(dev):
+    torch.manual_seed(0)
+    vocab, dim, steps, batch, bag = 500, 16, 6, 64, 5
+    ids_all = torch.randint(0, vocab, (steps, batch, bag))
+    ids_all[:, :, 0] = ids_all[:, :, 1]                      # duplicates inside every sample
+    keys = torch.from_numpy(synth.keys_np(44, 0, vocab))     # id r <-> int64 key keys[r]
+    w0 = torch.rand(vocab, dim) - 0.5
+    head_w = torch.randn(dim, 1) * 0.1
+    target = torch.randn(steps, batch, 1)
+
+    # reference: torch on the CPU
+    emb = torch.nn.Embedding(vocab, dim, sparse=True)
+    with torch.no_grad():
+        emb.weight.copy_(w0)
+    opt = torch.optim.Adagrad(emb.parameters(), lr=0.05, eps=1e-10, initial_accumulator_value=0.1)
+    for s in range(steps):
+        opt.zero_grad()
+        loss = ((emb(ids_all[s]).sum(1) @ head_w - target[s]) ** 2).mean()
+        loss.backward()
+        opt.step()
+
+    # the table as a layer on the GPU
+    table = LookupTable(4096, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=4096, initial_accumulator=0.1)
+    table.insert(keys.to(dev), w0.to(dev))
+    layer = DynamicEmbedding(table, optimizer="adagrad", lr=0.05, eps=1e-10).to(dev)
+    hw = head_w.to(dev)
+    for s in range(steps):
+        k = keys[ids_all[s]].to(dev)
+        loss = ((layer(k).sum(1) @ hw - target[s].to(dev)) ** 2).mean()
+        loss.backward()
+    got, found = table.find(keys.to(dev))
+    assert bool(found.all())
+    np.testing.assert_allclose(got.cpu().numpy(), emb.weight.detach().numpy(), rtol=2e-5, atol=1e-6)
+    # unseen ids in training mode are created with the initial row; in eval mode they are not
+    new = torch.tensor([[123456789, 987654321]], device=dev)
+    layer.eval(); layer(new); assert table.size() == vocab
+    layer.train(); layer(new); assert table.size() == vocab + 2
