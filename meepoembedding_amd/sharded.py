@@ -91,7 +91,8 @@ class ShardedLookupTable:
     def remove(self, keys: torch.Tensor) -> torch.Tensor:
         keys = keys.contiguous().view(-1)
         send_keys, perm, ss, rs = self._route(keys)
-        found = self.local.remove(self._a2a(send_keys, ss, rs))
+        rk = self._a2a(send_keys, ss, rs)
+        found = torch.cat([self.local.remove(rk[s:e]) for s, e in self._chunks(rk.numel())])
         return self.router.scatter_rows(self._a2a(found, rs, ss), perm)
 
     def _push(self, keys: torch.Tensor, payload: torch.Tensor):
@@ -101,13 +102,22 @@ class ShardedLookupTable:
         send_rows = self.router.gather_rows(payload.contiguous().view(keys.numel(), -1), perm)
         return self._a2a(send_keys, ss, rs), self._a2a(send_rows, ss, rs), perm, ss, rs
 
+    # An owner may receive more pairs than its table's max_batch (skew, or simply world x batch).  insert / assign /
+    # remove are sequentially consistent, so the received pairs are applied max_batch at a time (order preserved =
+    # last-wins preserved).  apply_* is ONE update per distinct key and cannot be chunked: size the local table's
+    # max_batch for the largest received batch (<= world x per-rank batch).
+    def _chunks(self, n: int):
+        step = int(getattr(self.local, "max_batch", n) or n) or 1
+        return [(s, min(n, s + step)) for s in range(0, n, step)] or [(0, 0)]
+
     def insert(self, keys: torch.Tensor, values: torch.Tensor) -> None:
         rk, rv, *_ = self._push(keys, values)
-        self.local.insert(rk, rv)
+        for s, e in self._chunks(rk.numel()):
+            self.local.insert(rk[s:e], rv[s:e])
 
     def assign(self, keys: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
         rk, rv, perm, ss, rs = self._push(keys, values)
-        found = self.local.assign(rk, rv)
+        found = torch.cat([self.local.assign(rk[s:e], rv[s:e]) for s, e in self._chunks(rk.numel())])
         return self.router.scatter_rows(self._a2a(found, rs, ss), perm)
 
     def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10) -> None:
