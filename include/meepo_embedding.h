@@ -58,7 +58,7 @@ typedef struct mee_p2p    mee_p2p;    /* peer-mapped buffers of the all-to-all-f
 typedef struct mee_config {
     uint32_t struct_size;         /* = sizeof(mee_config); ABI guard */
     int32_t  device;              /* HIP device ordinal */
-    uint64_t capacity;            /* requested slots; rounded up to a multiple of 16 (SPEC.md §2) */
+    uint64_t capacity;            /* requested slots; rounded up to 16 x (smallest prime >= capacity/16) (SPEC.md §2) */
     uint32_t dim;                 /* floats per row: multiple of 4, 4..1024 */
     uint32_t optimizer;           /* MEE_OPT_*: which state planes to allocate */
     uint64_t max_batch;           /* largest n of any mutating op (sizes the workspace) */

@@ -30,7 +30,7 @@ inline void check(int rc) {
 
 struct TableOptions {
     int32_t device = 0;
-    uint64_t capacity = 0;      // slots (rounded up to a multiple of 16); size for load <= 0.8
+    uint64_t capacity = 0;      // slots (rounded up to 16 x a prime); size for load <= 0.85
     uint32_t dim = 64;
     uint32_t optimizer = MEE_OPT_NONE;
     uint64_t max_batch = 1u << 20;

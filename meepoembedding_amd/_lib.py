@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmeepo_hip.so")
+LIB_PATH = os.environ.get("MEE_LIB_PATH") or os.path.join(_HERE, "libmeepo_hip.so")  # MEE_LIB_PATH: A/B against another build
 
 OK = 0
 ERR_INVALID_ARG, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_NO_DEVICE, ERR_BATCH_TOO_LARGE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6

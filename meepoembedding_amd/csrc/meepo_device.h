@@ -30,6 +30,9 @@ __host__ __device__ __forceinline__ uint64_t mix64b(uint64_t x) {
     x ^= x >> 33; return x;
 }
 __device__ __forceinline__ uint64_t bucket_of(int64_t key, uint64_t nb) { return __umul64hi(mix64((uint64_t)key), nb); }
+// SPEC.md §1/§2: stride (in buckets) of a key's probe sequence — double hashing, 1 <= stride < nb
+__device__ __forceinline__ uint64_t step_of(int64_t key, uint64_t nb) { return nb > 1 ? 1 + __umul64hi(mix64b((uint64_t)key), nb - 1) : 1; }
+__device__ __forceinline__ uint64_t next_bucket(uint64_t b, uint64_t stride, uint64_t nb) { b += stride; return b >= nb ? b - nb : b; }
 __device__ __forceinline__ uint32_t owner_of(int64_t key, uint32_t g) { return (uint32_t)__umul64hi(mix64b((uint64_t)key), (uint64_t)g); }
 __device__ __forceinline__ bool reserved_key(int64_t k) { return k <= kReclaimed; }
 
@@ -52,7 +55,7 @@ __device__ __forceinline__ uint32_t tile_bits(uint64_t wave_mask, int tile) {
 template <bool CLAIM, bool COHERENT>
 __device__ __forceinline__ int64_t tile_locate(int64_t* __restrict__ tkeys, uint64_t nb, int64_t key, bool active,
                                                int tile, int tl, bool& is_new, bool& full) {
-    const uint64_t b0 = bucket_of(key, nb);
+    const uint64_t b0 = bucket_of(key, nb), stride = step_of(key, nb);
     uint64_t b = b0;
     uint64_t steps = 0;
     uint32_t retries = 0;  // lost-CAS re-reads; bounded so that every wave reaches the exit
@@ -90,7 +93,7 @@ __device__ __forceinline__ int64_t tile_locate(int64_t* __restrict__ tkeys, uint
                 // else: another key took that EMPTY slot — re-read the same bucket
             } else if (te) pend = false;  // absent
             else if (++steps >= nb) { full = true; pend = false; }
-            else b = (b + 1 == nb) ? 0 : b + 1;
+            else b = next_bucket(b, stride, nb);
         }
     }
     return slot;

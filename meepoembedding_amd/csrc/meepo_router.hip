@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void p2p_find_kernel(const int64_t* __restrict
                 if (pend) {
                     if (tm) { slot[r] = (int64_t)(bb * kW) + (__ffs(tm) - 1); pend = false; }
                     else if (te || ++steps >= nb) pend = false;
-                    else bb = (bb + 1 == nb) ? 0 : bb + 1;
+                    else bb = next_bucket(bb, step_of(key[r], nb), nb);
                 }
                 if (!__any(pend)) break;
                 k = pend ? tkeys[bb * kW + tl] : kEmpty;

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
                 if (pend) {
                     if (tm) { slot[r] = (int64_t)(bb * kW) + (__ffs(tm) - 1); pend = false; }
                     else if (te || ++steps >= nb) pend = false;
-                    else bb = (bb + 1 == nb) ? 0 : bb + 1;
+                    else bb = next_bucket(bb, step_of(key[r], nb), nb);
                 }
                 if (!__any(pend)) break;
                 k = pend ? tkeys[bb * kW + tl] : kEmpty;
@@ -835,6 +835,18 @@ TableView table_view(const mee_table* t) {
     return TableView{t->device, t->keys, t->values, t->nb, t->dim, t->dim4, t->default_value};
 }
 
+// SPEC.md §2: the bucket count is prime, so every double-hashing stride visits all buckets
+static uint64_t next_prime(uint64_t n) {
+    if (n <= 2) return 2;
+    if (!(n & 1)) ++n;
+    for (;; n += 2) {
+        bool prime = true;
+        for (uint64_t d = 3; d * d <= n; d += 2)
+            if (n % d == 0) { prime = false; break; }
+        if (prime) return n;
+    }
+}
+
 // `needs_group_table`: the op would overwrite the group table, which a pending mee_apply_prepare still owns
 static int check_batch(const mee_table* t, size_t n, const char* op, bool needs_group_table = true) {
     if (t->prepared_n && needs_group_table)
@@ -897,7 +909,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     if (!t) return fail(MEE_ERR_OUT_OF_MEMORY, "host allocation failed");
     memset(t, 0, sizeof *t);
     t->device = cfg->device;
-    t->nb = (cfg->capacity + kW - 1) / kW;
+    t->nb = next_prime((cfg->capacity + kW - 1) / kW);
     t->capacity = t->nb * kW;
     t->dim = cfg->dim; t->dim4 = cfg->dim / 4;
     t->optimizer = cfg->optimizer; t->initializer = cfg->initializer; t->value_memory = cfg->value_memory;

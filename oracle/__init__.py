@@ -43,6 +43,8 @@ def lib() -> C.CDLL:
         L.meo_mix64b.restype = u64; L.meo_mix64b.argtypes = [u64]
         L.meo_mulhi64.restype = u64; L.meo_mulhi64.argtypes = [u64, u64]
         L.meo_bucket.restype = u64; L.meo_bucket.argtypes = [C.c_int64, u64]
+        L.meo_next_prime.restype = u64; L.meo_next_prime.argtypes = [u64]
+        L.meo_step.restype = u64; L.meo_step.argtypes = [C.c_int64, u64]
         L.meo_owner.restype = u32; L.meo_owner.argtypes = [C.c_int64, u32]
         L.meo_hash_batch.restype = None; L.meo_hash_batch.argtypes = [vp, sz, u64, u32, vp, vp, vp]
         L.meo_create.restype = vp; L.meo_create.argtypes = [u64, u32, u32, f32, f32, u32, f32, u64]

@@ -36,6 +36,7 @@ uint64_t meo_mix64b(uint64_t x) {
 }
 uint64_t meo_mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 uint64_t meo_bucket(int64_t key, uint64_t n_buckets) { return meo_mulhi64(meo_mix64((uint64_t)key), n_buckets); }
+uint64_t meo_step(int64_t key, uint64_t n_buckets) { return n_buckets > 1 ? 1 + meo_mulhi64(meo_mix64b((uint64_t)key), n_buckets - 1) : 1; }
 uint32_t meo_owner(int64_t key, uint32_t n_shards) { return (uint32_t)meo_mulhi64(meo_mix64b((uint64_t)key), n_shards); }
 
 void meo_hash_batch(const int64_t* keys, size_t n, uint64_t n_buckets, uint32_t n_shards, uint64_t* mix_out,
@@ -52,12 +53,24 @@ static int reserved(int64_t k) { return k == MEO_EMPTY_KEY || k == MEO_RECLAIMED
 
 static void fill_f32(float* p, uint64_t n, float v) { for (uint64_t i = 0; i < n; ++i) p[i] = v; }
 
+/* SPEC §2: smallest prime >= n */
+uint64_t meo_next_prime(uint64_t n) {
+    if (n <= 2) return 2;
+    if (!(n & 1)) ++n;
+    for (;; n += 2) {
+        int prime = 1;
+        for (uint64_t d = 3; d * d <= n; d += 2)
+            if (n % d == 0) { prime = 0; break; }
+        if (prime) return n;
+    }
+}
+
 meo_table* meo_create(uint64_t capacity, uint32_t dim, uint32_t optimizer, float default_value,
                       float initial_accumulator, uint32_t initializer, float init_scale, uint64_t init_seed) {
     if (capacity == 0 || dim < 4 || dim > 1024 || (dim & 3) || optimizer > MEO_OPT_ADAM) return NULL;
     meo_table* t = (meo_table*)calloc(1, sizeof *t);
     if (!t) return NULL;
-    t->n_buckets = (capacity + MEO_BUCKET_W - 1) / MEO_BUCKET_W;
+    t->n_buckets = meo_next_prime((capacity + MEO_BUCKET_W - 1) / MEO_BUCKET_W);
     t->capacity = t->n_buckets * MEO_BUCKET_W;
     t->dim = dim; t->optimizer = optimizer; t->initializer = initializer;
     t->default_value = default_value; t->initial_accumulator = initial_accumulator;
@@ -89,6 +102,7 @@ void meo_clear(meo_table* t) {
  * RECLAIMED slot met before the probe ended, else the first EMPTY slot of the bucket that ended it (or -1). */
 static int64_t probe(const meo_table* t, int64_t key, int64_t* free_out) {
     uint64_t b = meo_bucket(key, t->n_buckets);
+    const uint64_t stride = meo_step(key, t->n_buckets);
     int64_t first_tomb = -1;
     if (free_out) *free_out = -1;
     for (uint64_t step = 0; step < t->n_buckets; ++step) {
@@ -100,7 +114,7 @@ static int64_t probe(const meo_table* t, int64_t key, int64_t* free_out) {
             if (kb[j] == MEO_RECLAIMED_KEY && first_tomb < 0) first_tomb = (int64_t)(b * MEO_BUCKET_W + j);
         }
         if (first_empty >= 0) { if (free_out) *free_out = first_tomb >= 0 ? first_tomb : first_empty; return -1; }
-        if (++b == t->n_buckets) b = 0;
+        b += stride; if (b >= t->n_buckets) b -= t->n_buckets;
     }
     if (free_out) *free_out = first_tomb;
     return -1;

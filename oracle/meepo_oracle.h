@@ -42,6 +42,8 @@ uint64_t meo_mix64(uint64_t x);
 uint64_t meo_mix64b(uint64_t x);
 uint64_t meo_mulhi64(uint64_t a, uint64_t b);
 uint64_t meo_bucket(int64_t key, uint64_t n_buckets);
+uint64_t meo_step(int64_t key, uint64_t n_buckets);
+uint64_t meo_next_prime(uint64_t n);
 uint32_t meo_owner(int64_t key, uint32_t n_shards);
 void     meo_hash_batch(const int64_t* keys, size_t n, uint64_t n_buckets, uint32_t n_shards,
                         uint64_t* mix_out, uint64_t* bucket_out, uint32_t* owner_out);

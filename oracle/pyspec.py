@@ -47,6 +47,19 @@ def bucket(key: int, n_buckets: int) -> int:
     return mulhi64(mix64(u64(key)), n_buckets)
 
 
+def next_prime(n: int) -> int:
+    """SPEC §2: smallest prime >= n."""
+    n = max(n, 2)
+    while True:
+        if n < 4 or (n % 2 and all(n % d for d in range(3, int(n ** 0.5) + 1, 2))):
+            return n
+        n += 1
+
+
+def step(key: int, n_buckets: int) -> int:
+    return 1 + mulhi64(mix64b(u64(key)), n_buckets - 1) if n_buckets > 1 else 1
+
+
 def owner(key: int, n_shards: int) -> int:
     return mulhi64(mix64b(u64(key)), n_shards)
 
@@ -77,7 +90,7 @@ class DictTable:
     bucketised placement rule, so TABLE_FULL behaviour is modelled too)."""
 
     def __init__(self, capacity: int, dim: int, default_value: float = 0.0):
-        self.n_buckets = (capacity + BUCKET_W - 1) // BUCKET_W
+        self.n_buckets = next_prime((capacity + BUCKET_W - 1) // BUCKET_W)
         self.capacity = self.n_buckets * BUCKET_W
         self.dim = dim
         self.default_value = default_value
@@ -90,6 +103,7 @@ class DictTable:
     def _probe(self, key: int):
         """(slot of key | None, slot a new key would take | None) — SPEC §2 incl. RECLAIMED reuse."""
         b = bucket(key, self.n_buckets)
+        stride = step(key, self.n_buckets)
         tomb = None
         for _ in range(self.n_buckets):
             base = b * BUCKET_W
@@ -104,7 +118,7 @@ class DictTable:
                     tomb = base + j
             if empty is not None:
                 return None, (tomb if tomb is not None else empty)
-            b = (b + 1) % self.n_buckets
+            b = (b + stride) % self.n_buckets
         return None, tomb
 
     def remove(self, keys):

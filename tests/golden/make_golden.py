@@ -33,6 +33,7 @@ def hash_kat():
            "mix64b": [str(pyspec.mix64b(pyspec.u64(k))) for k in keys],
            "bucket": {str(nb): [str(pyspec.bucket(k, nb)) for k in keys] for nb in nbs},
            "owner": {str(g): [pyspec.owner(k, g) for k in keys] for g in gs},
+           "step": {str(nb): [str(pyspec.step(k, nb)) for k in keys] for nb in nbs},
            "initial_row": {"seed": 11, "scale": 0.05, "dim": 8,
                            "rows": [[float(x) for x in pyspec.initial_row(k, 8, 0.05, 11)] for k in keys[:64]]}}
     # second implementation must agree before anything is written
@@ -43,6 +44,7 @@ def hash_kat():
             assert [str(int(x)) for x in mix] == kat["mix64"]
             assert [str(int(x)) for x in bkt] == kat["bucket"][str(nb)]
             assert [int(x) for x in own] == kat["owner"][str(g)]
+        assert [str(oracle.lib().meo_step(int(k), nb)) for k in keys] == kat["step"][str(nb)]
     t = oracle.OracleTable(64, 8, initializer=oracle.INIT_UNIFORM, init_scale=0.05, init_seed=11)
     for k, row in zip(keys[:64], kat["initial_row"]["rows"]):
         assert np.array_equal(t.initial_row(k), np.array(row, np.float32)), k

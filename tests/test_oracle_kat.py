@@ -40,6 +40,9 @@ def test_hash_kat_pyspec(kat):
             assert str(pyspec.bucket(k, int(nb))) == exp[i]
         for g, exp in kat["owner"].items():
             assert pyspec.owner(k, int(g)) == exp[i]
+        for nb, exp in kat["step"].items():
+            assert str(pyspec.step(k, int(nb))) == exp[i] and str(oracle.lib().meo_step(k, int(nb))) == exp[i]
+            assert 1 <= int(exp[i]) < max(2, int(nb))
 
 
 def test_hash_ranges(kat):
@@ -103,6 +106,7 @@ def test_reserved_keys_and_table_full():
     out, found = t.find(keys)
     assert list(found) == [0, 1, 0, 1]
     t.clear_status()
+    assert t.capacity == 32                 # 2 buckets: 2 is prime
     many = synth.keys_np(4, 0, 100)
     t.insert(many, np.zeros((100, 4), np.float32))
     assert t.size() == 32 and t.status() & oracle.STATUS_TABLE_FULL
@@ -149,18 +153,20 @@ def test_model_vs_dict(ops, capacity):
 
 def test_remove_and_slot_reuse_cpu():
     """remove -> RECLAIMED tombstones; later inserts reuse them, so a full table can churn forever."""
-    cap, dim = 64, 4
-    t = oracle.OracleTable(cap, dim)
-    keys = synth.keys_np(6, 0, 64)
+    dim = 4
+    t = oracle.OracleTable(70, dim)
+    cap = t.capacity                        # 5 buckets (prime) x 16 = 80 slots
+    assert cap == 80
+    keys = synth.keys_np(6, 0, cap)
     t.insert(keys, synth.rows_np(keys, dim, 1))
-    assert t.size() == 64 and t.status() == 0
+    assert t.size() == cap and t.status() == 0     # prime bucket count: every stride reaches every bucket, 100 % fill works
     for rnd in range(5):
         old = keys[rnd * 8:(rnd + 1) * 8]
         assert t.remove(old).all() and not t.remove(old).any()
-        assert t.size() == 56 and not t.find(old)[1].any()
+        assert t.size() == cap - 8 and not t.find(old)[1].any()
         new = synth.keys_np(100 + rnd, 0, 8)
         t.insert(new, synth.rows_np(new, dim, 2))
-        assert t.size() == 64 and t.status() == 0, "tombstones must be reused"
+        assert t.size() == cap and t.status() == 0, "tombstones must be reused"
         out, found = t.find(new)
         assert found.all() and np.array_equal(out, synth.rows_np(new, dim, 2))
     rest = keys[40:]
