@@ -167,7 +167,10 @@ def main():
     ap.add_argument("--load", type=float, default=0.75)
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the short configs[2] (find + Adagrad) measurement appended as `also`")
+    ap.add_argument("--extras", action="store_true",
+                    help="append an `also` object: the same find launches on two caller streams, and a configs[2] (find + Adagrad) step. "
+                         "Off by default so that a rocprofv3 profile of the default command contains only the headline launches")
+    ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)  # accepted for older command lines
     ap.add_argument("--mode", choices=["find", "train"], default="find",
                     help="find = configs[1] (the driver's metric); train = configs[2]: find + sparse-Adagrad apply per step (N=1 only)")
     ap.add_argument("--pipeline", type=int, default=1, help="sharded only: steps in flight on separate HIP streams (1 = off)")
@@ -382,7 +385,7 @@ def main():
         }
         if not sharded and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(synth, dim, batch)
-        if not sharded and not train and not args.no_extras:
+        if not sharded and not train and args.extras:
             try:  # never allowed to break the headline line
                 res["also"] = {"two_caller_streams": two_stream_extra(table, batches, dim, dev, bpl)}
                 res["also"]["configs2_train_step"] = train_step_extra(table, synth, n_keys, dim, dev, chunk, batches, out, found, bpl)
