@@ -2,6 +2,7 @@
 as a rehearsal of the N>1 flow, with two ranks sharing this box's GPU over gloo (populate by owner, transport probe)."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -10,6 +11,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline"}
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def _one_json_line(cmd):
@@ -35,7 +42,7 @@ def test_bench_single_gpu_contract(dev):
 @pytest.mark.gpu
 def test_bench_two_rank_rehearsal(dev):
     res = _one_json_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29533", "bench.py", "--gpus", "2", "--backend", "gloo", "--keys", "2000000", "--batch", "65536",
+                          "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--backend", "gloo", "--keys", "2000000", "--batch", "65536",
                           "--steps", "5", "--warmup", "2"])
     assert REQUIRED <= set(res) and res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
     assert "transport" in res["config"]["workload"]
