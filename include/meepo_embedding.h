@@ -33,7 +33,7 @@ extern "C" {
 
 #define MEE_ABI_VERSION 1
 
-#define MEE_EMPTY_KEY     INT64_MIN       /* SPEC.md §2: reserved, never stored */
+#define MEE_EMPTY_KEY     INT64_MIN       /* SPEC.md §2: reserved, never stored; in a batch it is padding (skipped silently) */
 #define MEE_RECLAIMED_KEY (INT64_MIN + 1) /* SPEC.md §2: reserved, the tombstone mee_remove leaves */
 #define MEE_BUCKET_WIDTH  16              /* keys per bucket = one 128-byte line */
 
@@ -178,14 +178,22 @@ int mee_gather_rows(const void* d_rows, const int64_t* d_perm, size_t n, size_t 
  * after which mee_p2p_buffers() rows/found [0, n) hold the result in batch order.  slots_per_peer bounds how many keys
  * one rank may send to one owner per lookup; exceeding it drops keys and sets bit 0 of mee_p2p_status. */
 int mee_p2p_create(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t slots_per_peer, uint64_t max_batch, uint32_t dim,
-                   mee_p2p** out);
+                   int with_payload, mee_p2p** out);
 int mee_p2p_destroy(mee_p2p* c);
-int mee_p2p_export(mee_p2p* c, void* handles /* 5 x MEE_IPC_HANDLE_BYTES */);
-int mee_p2p_connect(mee_p2p* c, const void* all_handles /* n_shards x 5 x MEE_IPC_HANDLE_BYTES, rank-major */);
+#define MEE_P2P_BUFFERS 6
+int mee_p2p_export(mee_p2p* c, void* handles /* MEE_P2P_BUFFERS x MEE_IPC_HANDLE_BYTES */);
+int mee_p2p_connect(mee_p2p* c, const void* all_handles /* n_shards x MEE_P2P_BUFFERS x MEE_IPC_HANDLE_BYTES, rank-major */);
 int mee_p2p_buffers(mee_p2p* c, float** d_out, uint8_t** d_found);
 int mee_p2p_push(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts, size_t n,
                  void* stream);
 int mee_p2p_find(mee_p2p* c, const mee_table* t, void* stream);
+/* Mutators over peer-mapped memory (contexts created with with_payload != 0): push (key, row) pairs into the owners'
+ * inboxes; every segment is padded to slots_per_peer with MEE_EMPTY_KEY (= padding, SPEC.md §2), so after the barrier
+ * the owner hands its WHOLE inbox — mee_p2p_inbox(): n_shards x slots_per_peer keys and rows, ordered by source rank then
+ * batch position — to mee_insert / mee_assign / mee_apply_* with a fixed n; a second barrier frees the inbox. */
+int mee_p2p_push_rows(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts,
+                      const float* d_rows, size_t n, void* stream);
+int mee_p2p_inbox(mee_p2p* c, int64_t** d_keys, float** d_rows, uint64_t* n_slots);
 int mee_p2p_status(mee_p2p* c, uint32_t* bits_out, void* stream); /* [syncs] */
 
 #ifdef __cplusplus

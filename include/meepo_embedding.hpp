@@ -131,14 +131,22 @@ private:
 // the stream): partition -> push -> barrier -> find -> barrier -> read rows()/found().
 class PeerExchange {
 public:
-    PeerExchange(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t slots_per_peer, uint64_t max_batch, uint32_t dim) { check(mee_p2p_create(device, n_shards, rank, slots_per_peer, max_batch, dim, &c_)); }
+    PeerExchange(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t slots_per_peer, uint64_t max_batch, uint32_t dim, bool with_payload = false) {
+        check(mee_p2p_create(device, n_shards, rank, slots_per_peer, max_batch, dim, with_payload ? 1 : 0, &c_));
+    }
     ~PeerExchange() { if (c_) mee_p2p_destroy(c_); }
     PeerExchange(const PeerExchange&) = delete;
     PeerExchange& operator=(const PeerExchange&) = delete;
-    void export_handles(void* handles_5x64) { check(mee_p2p_export(c_, handles_5x64)); }
+    void export_handles(void* handles_6x64) { check(mee_p2p_export(c_, handles_6x64)); }
     void connect(const void* all_handles_rank_major) { check(mee_p2p_connect(c_, all_handles_rank_major)); }
     void push(Router& r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts, size_t n, void* stream = nullptr) { check(mee_p2p_push(c_, r.handle(), d_send_keys, d_perm, d_counts, n, stream)); }
     void find(const Table& t, void* stream = nullptr) { check(mee_p2p_find(c_, t.handle(), stream)); }
+    void push_rows(Router& r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts, const float* d_rows, size_t n, void* stream = nullptr) {
+        check(mee_p2p_push_rows(c_, r.handle(), d_send_keys, d_perm, d_counts, d_rows, n, stream));
+    }
+    int64_t* inbox_keys() const { int64_t* k = nullptr; check(mee_p2p_inbox(c_, &k, nullptr, nullptr)); return k; }
+    float* inbox_rows() const { float* r = nullptr; check(mee_p2p_inbox(c_, nullptr, &r, nullptr)); return r; }
+    uint64_t inbox_slots() const { uint64_t n = 0; check(mee_p2p_inbox(c_, nullptr, nullptr, &n)); return n; }
     float* rows() const { float* o = nullptr; check(mee_p2p_buffers(c_, &o, nullptr)); return o; }
     uint8_t* found() const { uint8_t* f = nullptr; check(mee_p2p_buffers(c_, nullptr, &f)); return f; }
     uint32_t status(void* stream = nullptr) { uint32_t b = 0; check(mee_p2p_status(c_, &b, stream)); return b; }

@@ -33,10 +33,11 @@ struct mee_p2p {
     uint32_t* inbox_cnt;   // [n_shards]
     float* out;            // [max_batch][dim]
     uint8_t* found;        // [max_batch]
+    float* inbox_rows;     // [n_shards][cap][dim] payload rows of pushed (key, row) pairs; null unless created with payload
     uint32_t* status;      // bit 0: a segment overflowed `cap`
     // device-resident pointer tables (index = rank) and their host copies
-    void** d_tables;       // 5 tables of n_shards pointers each
-    void* h_tables[5][64];
+    void** d_tables;       // kP2PBuffers tables of n_shards pointers each
+    void* h_tables[6][64];
     bool connected;
 };
 
@@ -174,14 +175,15 @@ static int permute_rows(const void* d_rows, const int64_t* d_perm, size_t n, siz
 //   push:  each rank's partitioned keys (+ their batch positions) are stored straight into the owners' inboxes (xGMI)
 //   find:  each owner probes what arrived and stores every row straight into the requester's result buffer (xGMI)
 // with one stream-ordered barrier after each phase.  No all-to-all, no un-permute pass, no host sync.
+constexpr int kP2PBuffers = 6;  // inbox keys, inbox dst, inbox counts, result rows, result found bytes, inbox payload rows
 struct P2PPeers {            // device-resident pointer tables, index = rank
-    int64_t** keys; int32_t** dst; uint32_t** cnt; float** out; uint8_t** found;
+    int64_t** keys; int32_t** dst; uint32_t** cnt; float** out; uint8_t** found; float** rows;
 };
 
 // grid: x over positions inside a segment, y = destination rank
 __global__ __launch_bounds__(256) void p2p_push_kernel(const int64_t* __restrict__ send_keys, const int64_t* __restrict__ perm,
                                                        const uint64_t* __restrict__ counts, const uint64_t* __restrict__ base,
-                                                       P2PPeers peers, uint32_t me, uint64_t cap, uint32_t* status) {
+                                                       P2PPeers peers, uint32_t me, uint64_t cap, uint32_t* status, int pad) {
     const uint32_t p = blockIdx.y;
     const uint64_t cnt = counts[p];
     const uint64_t take = cnt < cap ? cnt : cap;
@@ -192,9 +194,30 @@ __global__ __launch_bounds__(256) void p2p_push_kernel(const int64_t* __restrict
         dk[j] = send_keys[b0 + j];
         dd[j] = (int32_t)perm[b0 + j];
     }
+    if (pad)  // the owner will hand the whole fixed-size inbox to an operator: unused positions become padding keys
+        for (uint64_t j = take + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < cap; j += (uint64_t)gridDim.x * blockDim.x) dk[j] = kEmpty;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         peers.cnt[p][me] = (uint32_t)take;
         if (cnt > cap) atomicOr(status, 1u);
+    }
+}
+
+// payload rows of a push: one 16-lane tile copies row perm[b0+j] of the batch into position j of the owner's segment
+__global__ __launch_bounds__(256) void p2p_push_rows_kernel(const float4* __restrict__ rows, const int64_t* __restrict__ perm,
+                                                            const uint64_t* __restrict__ counts, const uint64_t* __restrict__ base,
+                                                            P2PPeers peers, uint32_t me, uint64_t cap, uint32_t dim4) {
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const uint32_t p = blockIdx.y;
+    const uint64_t cnt = counts[p];
+    const uint64_t take = cnt < cap ? cnt : cap;
+    float4* __restrict__ dr = reinterpret_cast<float4*>(peers.rows[p]) + (uint64_t)me * cap * dim4;
+    const uint64_t b0 = base[p];
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t j0 = wave * 4; j0 < take; j0 += n_waves * 4) {
+        const uint64_t j = j0 + tile;
+        if (j >= take) continue;
+        const uint64_t src = (uint64_t)perm[b0 + j] * dim4;
+        for (uint32_t c = tl; c < dim4; c += 16) dr[j * dim4 + c] = rows[src + c];
     }
 }
 
@@ -348,17 +371,17 @@ int mee_p2p_destroy(mee_p2p* c) {
     DeviceGuard g(c->device);
     (void)hipDeviceSynchronize();
     if (c->connected)
-        for (int b = 0; b < 5; ++b)
+        for (int b = 0; b < kP2PBuffers; ++b)
             for (uint32_t p = 0; p < c->n_shards; ++p)
                 if (p != c->rank && c->h_tables[b][p]) (void)hipIpcCloseMemHandle(c->h_tables[b][p]);
-    void* mine[] = {c->inbox_keys, c->inbox_dst, c->inbox_cnt, c->out, c->found, c->status, c->d_tables};
+    void* mine[] = {c->inbox_keys, c->inbox_dst, c->inbox_cnt, c->out, c->found, c->inbox_rows, c->status, c->d_tables};
     for (void* p : mine) if (p) (void)hipFree(p);
     delete c;
     return MEE_OK;
 }
 
 int mee_p2p_create(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t slots_per_peer, uint64_t max_batch, uint32_t dim,
-                   mee_p2p** out) {
+                   int with_payload, mee_p2p** out) {
     if (!out) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_create: null out");
     *out = nullptr;
     if (n_shards == 0 || n_shards > (uint32_t)kMaxShards || rank >= n_shards || slots_per_peer == 0 || max_batch == 0 ||
@@ -384,8 +407,10 @@ int mee_p2p_create(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t sl
     };
     if (sym_alloc((void**)&c->inbox_keys, slots * 8) != hipSuccess || sym_alloc((void**)&c->inbox_dst, slots * 4) != hipSuccess ||
         sym_alloc((void**)&c->inbox_cnt, n_shards * 4) != hipSuccess || sym_alloc((void**)&c->out, max_batch * (uint64_t)dim * 4) != hipSuccess ||
-        sym_alloc((void**)&c->found, max_batch) != hipSuccess || hipMalloc((void**)&c->status, 4) != hipSuccess ||
-        hipMalloc((void**)&c->d_tables, 5 * (size_t)n_shards * sizeof(void*)) != hipSuccess) {
+        sym_alloc((void**)&c->found, max_batch) != hipSuccess ||
+        (with_payload && sym_alloc((void**)&c->inbox_rows, slots * (uint64_t)dim * 4) != hipSuccess) ||
+        hipMalloc((void**)&c->status, 4) != hipSuccess ||
+        hipMalloc((void**)&c->d_tables, kP2PBuffers * (size_t)n_shards * sizeof(void*)) != hipSuccess) {
         mee_p2p_destroy(c);
         return fail(MEE_ERR_OUT_OF_MEMORY, "mee_p2p_create: device allocation failed (%s)", fine ? "fine-grained" : "coarse-grained");
     }
@@ -398,14 +423,16 @@ int mee_p2p_create(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t sl
 }
 
 static void* p2p_local(const mee_p2p* c, int b) {
-    switch (b) { case 0: return c->inbox_keys; case 1: return c->inbox_dst; case 2: return c->inbox_cnt; case 3: return c->out; default: return c->found; }
+    switch (b) { case 0: return c->inbox_keys; case 1: return c->inbox_dst; case 2: return c->inbox_cnt; case 3: return c->out; case 4: return c->found; default: return c->inbox_rows; }
 }
 
 int mee_p2p_export(mee_p2p* c, void* handles) {
     if (!c || !handles) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_export: null argument");
     static_assert(sizeof(hipIpcMemHandle_t) == MEE_IPC_HANDLE_BYTES, "IPC handle size");
     DeviceGuard g(c->device);
-    for (int b = 0; b < 5; ++b) {
+    memset(handles, 0, (size_t)kP2PBuffers * MEE_IPC_HANDLE_BYTES);
+    for (int b = 0; b < kP2PBuffers; ++b) {
+        if (!p2p_local(c, b)) continue;  // no payload inbox
         hipIpcMemHandle_t h;
         MEE_HIP(hipIpcGetMemHandle(&h, p2p_local(c, b)));
         memcpy((char*)handles + b * MEE_IPC_HANDLE_BYTES, &h, MEE_IPC_HANDLE_BYTES);
@@ -418,15 +445,15 @@ int mee_p2p_connect(mee_p2p* c, const void* all_handles) {
     if (c->connected) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_connect: already connected");
     DeviceGuard g(c->device);
     for (uint32_t p = 0; p < c->n_shards; ++p)
-        for (int b = 0; b < 5; ++b) {
-            if (p == c->rank) { c->h_tables[b][p] = p2p_local(c, b); continue; }
+        for (int b = 0; b < kP2PBuffers; ++b) {
+            if (p == c->rank || !p2p_local(c, b)) { c->h_tables[b][p] = p2p_local(c, b); continue; }
             hipIpcMemHandle_t h;
-            memcpy(&h, (const char*)all_handles + ((size_t)p * 5 + b) * MEE_IPC_HANDLE_BYTES, MEE_IPC_HANDLE_BYTES);
+            memcpy(&h, (const char*)all_handles + ((size_t)p * kP2PBuffers + b) * MEE_IPC_HANDLE_BYTES, MEE_IPC_HANDLE_BYTES);
             void* ptr = nullptr;
             MEE_HIP(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
             c->h_tables[b][p] = ptr;
         }
-    for (int b = 0; b < 5; ++b)
+    for (int b = 0; b < kP2PBuffers; ++b)
         MEE_HIP(hipMemcpy(c->d_tables + (size_t)b * c->n_shards, c->h_tables[b], c->n_shards * sizeof(void*), hipMemcpyHostToDevice));
     c->connected = true;
     return MEE_OK;
@@ -446,6 +473,7 @@ static P2PPeers p2p_peers(const mee_p2p* c) {
     pp.cnt = (uint32_t**)(c->d_tables + 2 * (size_t)c->n_shards);
     pp.out = (float**)(c->d_tables + 3 * (size_t)c->n_shards);
     pp.found = (uint8_t**)(c->d_tables + 4 * (size_t)c->n_shards);
+    pp.rows = (float**)(c->d_tables + 5 * (size_t)c->n_shards);
     return pp;
 }
 
@@ -456,8 +484,31 @@ int mee_p2p_push(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const in
     if (r->n_shards != c->n_shards || n > c->max_batch) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push: router/batch mismatch");
     DeviceGuard g(c->device);
     const dim3 grid(grid_for(n / c->n_shards + 256, 256, 1024), c->n_shards);
-    p2p_push_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_send_keys, d_perm, d_counts, r->base, p2p_peers(c), c->rank, c->cap, c->status);
+    p2p_push_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(d_send_keys, d_perm, d_counts, r->base, p2p_peers(c), c->rank, c->cap, c->status, 0);
     MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+int mee_p2p_push_rows(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts,
+                      const float* d_rows, size_t n, void* stream) {
+    if (!c || !r || !d_counts || (n && (!d_send_keys || !d_perm || !d_rows))) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push_rows: null argument");
+    if (!c->connected || !c->inbox_rows) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push_rows: context not connected or created without payload");
+    if (r->n_shards != c->n_shards || n > c->max_batch) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push_rows: router/batch mismatch");
+    DeviceGuard g(c->device);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 gk(grid_for(c->cap, 256, 1024), c->n_shards);
+    p2p_push_kernel<<<gk, 256, 0, st>>>(d_send_keys, d_perm, d_counts, r->base, p2p_peers(c), c->rank, c->cap, c->status, 1);
+    const dim3 gr(grid_for(n / c->n_shards + 64, 16, 4096), c->n_shards);
+    p2p_push_rows_kernel<<<gr, 256, 0, st>>>((const float4*)d_rows, d_perm, d_counts, r->base, p2p_peers(c), c->rank, c->cap, c->dim / 4);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+int mee_p2p_inbox(mee_p2p* c, int64_t** d_keys, float** d_rows, uint64_t* n_slots) {
+    if (!c) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_inbox: null argument");
+    if (d_keys) *d_keys = c->inbox_keys;
+    if (d_rows) *d_rows = c->inbox_rows;
+    if (n_slots) *n_slots = (uint64_t)c->n_shards * c->cap;
     return MEE_OK;
 }
 

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
     if (inb) {
         bs.hidx[i] = valid ? lh[slot] : kNoGroup;
         if (MODE == kGroupCount && valid) bs.rank[i] = lbase[slot] + r_local;
-        if (!valid && !skipped) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);
+        if (!valid && !skipped && key == kReclaimed) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);  // EMPTY = padding, silent
     }
 }
 
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void remove_locate_kernel(const int64_t* __res
         if (inb && tl == 0) {
             slot_out[i] = slot;
             if (found) found[i] = slot >= 0;
-            if (!valid) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);
+            if (!valid && key == kReclaimed) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);
         }
     }
 }

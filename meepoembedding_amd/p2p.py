@@ -9,7 +9,12 @@ an un-permute pass, every rank maps its peers' inboxes and result buffers throug
     barrier          ->  out[0:n], found[0:n] are complete, in batch order
 
 No all-to-all, no staging buffers, no un-permute, no host sync; the two barriers are one-element all-reduces on the
-caller's stream (RCCL).  Reference anchor: /root/reference/README.md:2 ("A distributed high-performance … Embedding").
+caller's stream (RCCL).
+
+Mutators (payload=True) ride the same inboxes: push stores (key, row) pairs into the owners' key and row inboxes and pads
+every segment to its fixed capacity with EMPTY keys (padding, SPEC.md §2), so after the barrier each owner hands its
+WHOLE inbox — world x cap positions, ordered by source rank then batch position, the order the all-to-all path
+delivers — to insert / assign / apply_* with a constant n: no counts exchange, no host sync, graph-capturable per rank.  Reference anchor: /root/reference/README.md:2 ("A distributed high-performance … Embedding").
 """
 from __future__ import annotations
 
@@ -30,7 +35,7 @@ class _Raw:
 
 
 class PeerShardedFind:
-    def __init__(self, local, router, max_batch: int, group=None, slack: float = 1.25):
+    def __init__(self, local, router, max_batch: int, group=None, slack: float = 1.25, payload: bool = False):
         self.local, self.router, self.group = local, router, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.device, self.dim, self.max_batch = local.device, local.dim, max_batch
@@ -45,10 +50,14 @@ class PeerShardedFind:
         # set-up is collective: after every local step the ranks agree on success, so a rank whose HIP IPC call fails
         # makes ALL ranks raise together instead of leaving the others in a barrier
         err = None
-        mine = (C.c_char * (5 * 64))()
+        if payload and self.world * self.cap > local.max_batch:
+            raise ValueError(f"payload mode hands the owner world*cap = {self.world * self.cap} positions per operator call; "
+                             f"create the local table with max_batch >= that (it has {local.max_batch})")
+        self.payload = payload
+        mine = (C.c_char * (6 * 64))()
         try:
             h = C.c_void_p()
-            check(L.mee_p2p_create(self.device.index, self.world, self.rank, self.cap, max_batch, self.dim, C.byref(h)))
+            check(L.mee_p2p_create(self.device.index, self.world, self.rank, self.cap, max_batch, self.dim, int(payload), C.byref(h)))
             self._h = h
             check(L.mee_p2p_export(self._h, mine))
         except Exception as e:  # noqa: BLE001
@@ -62,6 +71,11 @@ class PeerShardedFind:
             check(L.mee_p2p_buffers(self._h, C.byref(po), C.byref(pf)))
             self.out = torch.as_tensor(_Raw(po.value, (max_batch, self.dim), "<f4"), device=self.device)
             self.found = torch.as_tensor(_Raw(pf.value, (max_batch,), "|u1"), device=self.device)
+            if payload:
+                pk, pr, ns = C.c_void_p(), C.c_void_p(), C.c_uint64()
+                check(L.mee_p2p_inbox(self._h, C.byref(pk), C.byref(pr), C.byref(ns)))
+                self.inbox_keys = torch.as_tensor(_Raw(pk.value, (ns.value,), "<i8"), device=self.device)
+                self.inbox_rows = torch.as_tensor(_Raw(pr.value, (ns.value, self.dim), "<f4"), device=self.device)
         except Exception as e:  # noqa: BLE001
             err = e
         self._agree(err, "connect")  # also the barrier: nobody pushes before every rank has connected
@@ -108,8 +122,53 @@ class PeerShardedFind:
             self.check()
         return self.out[:n], self.found[:n]
 
+    # -- mutators over the payload inboxes --------------------------------------------------------------------------
+    def _deliver(self, keys: torch.Tensor, rows: torch.Tensor) -> None:
+        if not self.payload:
+            raise _lib.MeepoError(_lib.ERR_INVALID_ARG, "mutators need PeerShardedFind(..., payload=True)")
+        keys = keys.contiguous().view(-1)
+        n = keys.numel()
+        rows = rows.contiguous().view(n, -1)
+        if n > self.max_batch or rows.shape[1] != self.dim or rows.dtype != torch.float32:
+            raise _lib.MeepoError(_lib.ERR_INVALID_ARG, f"need n <= {self.max_batch} float32 rows of dim {self.dim}")
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        send_keys, counts, perm = self.router.partition(keys)
+        check(_lib.lib().mee_p2p_push_rows(self._h, self.router._h, send_keys.data_ptr(), perm.data_ptr(), counts.data_ptr(),
+                                           rows.data_ptr(), n, s))
+        self._barrier()
+
+    def _done(self, check_overflow: bool) -> None:
+        self._barrier()  # the owner's operator has consumed its inbox (stream order) before any peer's next push
+        if check_overflow:
+            self.check()
+
+    def insert(self, keys: torch.Tensor, values: torch.Tensor, check_overflow: bool = True) -> None:
+        self._deliver(keys, values)
+        self.local.insert(self.inbox_keys, self.inbox_rows)
+        self._done(check_overflow)
+
+    def assign(self, keys: torch.Tensor, values: torch.Tensor, check_overflow: bool = True) -> None:
+        """assign without the found mask (nothing travels back); use ShardedLookupTable.assign when the mask is needed"""
+        self._deliver(keys, values)
+        self.local.assign(self.inbox_keys, self.inbox_rows)
+        self._done(check_overflow)
+
+    def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10, check_overflow: bool = True) -> None:
+        self._deliver(keys, grads)
+        self.local.apply_adagrad(self.inbox_keys, self.inbox_rows, lr, eps)
+        self._done(check_overflow)
+
+    def apply_adam(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999,
+                   eps: float = 1e-8, step: int = 1, check_overflow: bool = True) -> None:
+        self._deliver(keys, grads)
+        self.local.apply_adam(self.inbox_keys, self.inbox_rows, lr, beta1, beta2, eps, step)
+        self._done(check_overflow)
+
     def check(self) -> None:
         bits = C.c_uint32()
         check(_lib.lib().mee_p2p_status(self._h, C.byref(bits), torch.cuda.current_stream(self.device).cuda_stream))
         if bits.value & 1:
             raise _lib.MeepoError(_lib.ERR_BATCH_TOO_LARGE, "peer inbox overflow: a rank sent more than slots_per_peer keys to one owner")
+
+
+PeerShardedTable = PeerShardedFind  # the name for payload=True users: find + insert / assign / apply_* over peer-mapped memory

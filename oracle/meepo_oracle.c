@@ -183,8 +183,8 @@ void meo_find_mt(const meo_table* t, const int64_t* keys, size_t n, float* out, 
 }
 
 static int has_reserved(meo_table* t, int64_t k) {
-    if (reserved(k)) { t->status |= MEO_STATUS_RESERVED_KEY; return 1; }
-    return 0;
+    if (k == MEO_RECLAIMED_KEY) t->status |= MEO_STATUS_RESERVED_KEY; /* EMPTY is padding: skipped silently (SPEC §2) */
+    return reserved(k);
 }
 
 /* sequential batch order makes "last occurrence wins" fall out naturally */

@@ -70,7 +70,7 @@ int main() try {
     shard.insert(d_keys.p, d_rows.p, n);
     meepo::Router router(0, n, 1);
     meepo::PeerExchange px(0, 1, 0, n, n, dim);
-    char handles[5 * MEE_IPC_HANDLE_BYTES];
+    char handles[MEE_P2P_BUFFERS * MEE_IPC_HANDLE_BYTES];
     px.export_handles(handles);
     px.connect(handles);
     DevBuf<int64_t> d_send(n), d_perm(n); DevBuf<uint64_t> d_counts(1);

@@ -115,6 +115,10 @@ def test_reserved_keys_and_table_full(dev):
     ones = np.ones((4, 4), np.float32)
     t.insert(T(keys, dev), T(ones, dev)); o.insert(keys, ones)
     assert t.size() == o.size() == 2 and t.status() == o.status() == STATUS_RESERVED_KEY
+    t2 = LookupTable(32, 4, device=dev, max_batch=256)
+    pad = np.array([oracle.EMPTY_KEY, 9, oracle.EMPTY_KEY], dtype=np.int64)
+    t2.insert(T(pad, dev), torch.ones(3, 4, device=dev)); t2.find_or_insert(T(pad, dev)); t2.remove(T(pad[:1], dev))
+    assert t2.size() == 1 and t2.status() == 0, "EMPTY in a batch is padding: skipped silently"
     out, found = t.find(T(keys, dev)); eo, ef = o.find(keys)
     assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
     t.clear_status()

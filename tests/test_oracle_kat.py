@@ -103,6 +103,9 @@ def test_reserved_keys_and_table_full():
     keys = np.array([oracle.EMPTY_KEY, 5, oracle.RECLAIMED_KEY, 6], dtype=np.int64)
     t.insert(keys, np.ones((4, 4), np.float32))
     assert t.size() == 2 and t.status() == oracle.STATUS_RESERVED_KEY
+    t2 = oracle.OracleTable(32, 4)
+    t2.insert(np.array([oracle.EMPTY_KEY, 9], dtype=np.int64), np.ones((2, 4), np.float32))
+    assert t2.size() == 1 and t2.status() == 0, "EMPTY in a batch is padding: skipped silently"
     out, found = t.find(keys)
     assert list(found) == [0, 1, 0, 1]
     t.clear_status()

@@ -110,6 +110,30 @@ def _run_rank(rank, world, port, backend, q, tiered=False):
                 except MeepoError:
                     assert not owner_has_room
             pf.close()
+            # mutators over the payload inboxes (padded, fixed n, no all-to-all) == the all-to-all mutators
+            cap = int(BATCH / world * 1.25) + 4096
+            mk = lambda: LookupTable(16384, DIM, device=dev, optimizer=OPT_ADAGRAD, initial_accumulator=0.1, max_batch=world * cap)
+            la, lb = mk(), mk()
+            pt = PeerShardedFind(la, Router(world, BATCH, device=dev), max_batch=BATCH, payload=True)
+            sb = ShardedLookupTable(lb, router)
+            for t in (pt, sb):
+                t.insert(keys, rows)
+                t.apply_adagrad(keys, grads, lr=0.05, eps=1e-10)
+                t.assign(keys[:300], rows[300:600])
+                t.apply_adagrad(keys[::2], grads[::2], lr=0.01, eps=1e-10)
+            dist.barrier()
+            ea_, eb_ = la.export(with_state=True), lb.export(with_state=True)
+            ia, ib = torch.argsort(ea_[0]), torch.argsort(eb_[0])
+            assert torch.equal(ea_[0][ia], eb_[0][ib]) and la.status() == 0
+            for xa, xb in zip(ea_[1:3], eb_[1:3]):
+                torch.testing.assert_close(xa[ia], xb[ib], rtol=1e-6, atol=1e-9)
+            o4, f4 = pt.find(probe)
+            o5, f5 = sb.find(probe)
+            assert torch.equal(f4, f5)
+            torch.testing.assert_close(o4, o5, rtol=1e-6, atol=1e-9)
+            with pytest.raises(ValueError):
+                PeerShardedFind(local, Router(world, 1 << 16, device=dev), max_batch=1 << 16, payload=True)
+            pt.close()
         if not tiered:
             o2, f2 = sh.find(dup, dedup=True)
             assert torch.equal(o1, o2) and torch.equal(f1, f2)
