@@ -172,7 +172,7 @@ def main():
                          "Off by default so that a rocprofv3 profile of the default command contains only the headline launches")
     ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)  # accepted for older command lines
     ap.add_argument("--mode", choices=["find", "train"], default="find",
-                    help="find = configs[1] (the driver's metric); train = configs[2]: find + sparse-Adagrad apply per step (N=1 only)")
+                    help="find = configs[1] (the driver's metric); train = configs[2]: find + sparse-Adagrad apply per step (sharded: gradients travel to the owners too)")
     ap.add_argument("--pipeline", type=int, default=1, help="sharded only: steps in flight on separate HIP streams (1 = off)")
     ap.add_argument("--transport", choices=["auto", "rccl", "p2p"], default="auto",
                     help="sharded only: rccl = all-to-all exchange; p2p = owners store rows into the requester's peer-mapped buffer; "
@@ -223,8 +223,6 @@ def main():
     chunk = 1 << 20
     cap = int(keys_per_gpu / args.load * (1.02 if sharded else 1.0))  # shard sizes fluctuate a little around n/world
     train = args.mode == "train"
-    if train and (world > 1 or args.force_sharded):
-        raise SystemExit("--mode train is a single-GPU mode")
     from meepoembedding_amd import OPT_ADAGRAD, OPT_NONE
     table = LookupTable(cap, dim, device=dev, max_batch=max(chunk, batch * 2), optimizer=OPT_ADAGRAD if train else OPT_NONE)
     log(f"table: {table.capacity} slots, {table.table_bytes / 1e9:.1f} GB")
@@ -254,7 +252,7 @@ def main():
             from meepoembedding_amd.p2p import PeerShardedFind
             peer = None
             try:
-                peer = PeerShardedFind(table, Router(world, batch, device=dev), max_batch=batch)
+                peer = PeerShardedFind(table, Router(world, batch, device=dev), max_batch=batch, payload=train)
             except Exception as e:  # collective failure: every rank lands here together
                 log(f"p2p transport unavailable: {e}")
             if peer is not None:
@@ -292,6 +290,17 @@ def main():
                         step, transport = step_p2p, "peer-mapped stores (no all-to-all)"
                 else:
                     log("p2p transport disagrees with the rccl path: not used")
+        if train:   # the data-parallel training step: lookup, then every rank's gradients go to the owners, which apply
+            grads = [torch.randn(batch, dim, device=dev) * 0.01 for _ in range(4)]
+            find_step, via_peer = step, step is not step_rccl
+
+            def step(i):
+                r_ = find_step(i)
+                if via_peer:
+                    peer.apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10, check_overflow=False)
+                else:
+                    shs[0].apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10)
+                return r_
     elif train:
         grads = [torch.randn(batch, dim, device=dev) * 0.01 for _ in range(4)]   # N(0, 1e-2), SURVEY §8d config 3
 
@@ -348,7 +357,8 @@ def main():
     else:
         kern_s = ev_ms / 1e3 / args.steps
     bpl = algorithmic_bytes_per_lookup(dim)
-    if train:
+    whole = train and not sharded   # sharded runs always price the local find_kernel alone
+    if whole:
         # fwd 528 B/lookup + bwd 264 B/lookup + 1032 B per unique key (Adagrad); here the whole step is priced
         uniq = sum(int(torch.unique(b_).numel()) for b_ in batches[:8]) / 8
         step_bytes = (bpl + 8 + 4 * dim) * batch + (8 + 16 * dim) * uniq
@@ -371,7 +381,7 @@ def main():
             "metric": "key-lookups/sec" if not train else "train-step keys/sec (find + sparse Adagrad apply)", "value": value, "unit": "key-lookups/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int64 keys / fp32 rows (copy)", "data": "synthetic",
-            "config": {"workload": (f"row-sharded find: {n_keys // 1_000_000}M keys over {world} GPUs ({keys_per_gpu // 1_000_000}M/GPU), dim {dim}, "
+            "config": {"workload": (f"row-sharded {'train step (find + gradient exchange + sparse Adagrad)' if train else 'find'}: {n_keys // 1_000_000}M keys over {world} GPUs ({keys_per_gpu // 1_000_000}M/GPU), dim {dim}, "
                                     f"{batch} lookups per rank per step, transport: {transport}" if sharded else
                                     f"configs[2]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim}, forward find + sparse-Adagrad scatter-update, {batch}-key batches" if train else
                                     f"configs[1]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim} fp32, forward find only, {batch}-key batches"),
@@ -379,8 +389,8 @@ def main():
                        "key_distribution": args.dist, "table_gb": round(table.table_bytes / 1e9, 2),
                        "parallelism": (f"row-shard x{world}" + (f", {args.pipeline} steps in flight" if args.pipeline > 1 else "") + (", pre-exchange dedup" if args.dedup else "")) if sharded else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic if not train else None, "kernel": "find_kernel" if not train else "whole step (find + 5 apply kernels)",
-                         "avg_launch_us": kern_s * 1e6, "algorithmic_bytes_per_lookup": bpl if not train else step_bytes / batch,
+                         "traffic": traffic if not whole else None, "kernel": "find_kernel" if not whole else "whole step (find + 5 apply kernels)",
+                         "avg_launch_us": kern_s * 1e6, "algorithmic_bytes_per_lookup": bpl if not whole else step_bytes / batch,
                          "lookups_per_launch": batch},
         }
         if not sharded and not args.no_cpu_baseline:
