@@ -128,6 +128,11 @@ int mee_find_or_insert_missing(mee_table* t, const int64_t* d_keys, size_t n, fl
  * same order.  At most `cap` pairs are written; *n_out = number stored in the table. */
 int mee_export(const mee_table* t, int64_t* d_keys_out, float* d_values_out, float* d_state1_out,
                float* d_state2_out, size_t cap, size_t* n_out, void* stream);
+/* [syncs] the same over the slot range [slot_begin, min(slot_end, capacity)): checkpointing / rehashing a table that
+ * fills most of HBM walks it in ranges with bounded scratch (a range of S slots holds at most S pairs); the union over a
+ * partition of [0, capacity) is mee_export's set.  *n_out = pairs stored in the range. */
+int mee_export_range(const mee_table* t, uint64_t slot_begin, uint64_t slot_end, int64_t* d_keys_out, float* d_values_out,
+                     float* d_state1_out, float* d_state2_out, size_t cap, size_t* n_out, void* stream);
 int mee_size(const mee_table* t, size_t* n_out, void* stream);        /* [syncs] */
 int mee_status(const mee_table* t, uint32_t* bits_out, void* stream); /* [syncs] */
 int mee_clear_status(mee_table* t, void* stream);

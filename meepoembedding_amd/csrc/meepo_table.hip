@@ -773,13 +773,14 @@ constexpr int kExportGroups = 16;
 
 __global__ __launch_bounds__(256) void export_kernel(const int64_t* __restrict__ tkeys, const float4* __restrict__ values,
                                                      const float4* __restrict__ s1, const float4* __restrict__ s2,
-                                                     uint64_t capacity, uint32_t dim4, int64_t* keys_out, float4* values_out,
+                                                     uint64_t begin, uint64_t capacity /* = end of the slot range */, uint32_t dim4,
+                                                     int64_t* keys_out, float4* values_out,
                                                      float4* s1_out, float4* s2_out, uint64_t cap, OpCounters* op) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
     constexpr uint64_t kSpan = 64ull * kExportGroups;
-    for (uint64_t c0 = wave * kSpan; c0 < capacity; c0 += n_waves * kSpan) {
+    for (uint64_t c0 = begin + wave * kSpan; c0 < capacity; c0 += n_waves * kSpan) {
         int64_t k[kExportGroups];
         uint64_t m[kExportGroups];
         uint32_t total = 0;
@@ -1177,12 +1178,20 @@ int mee_find_or_insert_missing(mee_table* t, const int64_t* d_keys, size_t n, fl
 
 int mee_export(const mee_table* t, int64_t* d_keys_out, float* d_values_out, float* d_state1_out, float* d_state2_out,
                size_t cap, size_t* n_out, void* stream) {
+    if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_export: null argument");
+    return mee_export_range(t, 0, t->capacity, d_keys_out, d_values_out, d_state1_out, d_state2_out, cap, n_out, stream);
+}
+
+int mee_export_range(const mee_table* t, uint64_t slot_begin, uint64_t slot_end, int64_t* d_keys_out, float* d_values_out,
+                     float* d_state1_out, float* d_state2_out, size_t cap, size_t* n_out, void* stream) {
     if (!t || !n_out) return fail(MEE_ERR_INVALID_ARG, "mee_export: null argument");
+    if (slot_end > t->capacity) slot_end = t->capacity;
+    if (slot_begin > slot_end) return fail(MEE_ERR_INVALID_ARG, "mee_export_range: slot_begin %llu > slot_end %llu", (unsigned long long)slot_begin, (unsigned long long)slot_end);
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
     MEE_HIP(hipMemsetAsync(&t->op->n_export, 0, sizeof(unsigned long long), st));
-    export_kernel<<<grid_for(t->capacity, 4 * 64 * kExportGroups, 256 * 16), 256, 0, st>>>(
-        t->keys, (const float4*)t->values, (const float4*)t->s1, (const float4*)t->s2, t->capacity, t->dim4, d_keys_out,
+    export_kernel<<<grid_for(slot_end - slot_begin, 4 * 64 * kExportGroups, 256 * 16), 256, 0, st>>>(
+        t->keys, (const float4*)t->values, (const float4*)t->s1, (const float4*)t->s2, slot_begin, slot_end, t->dim4, d_keys_out,
         (float4*)d_values_out, t->s1 ? (float4*)d_state1_out : nullptr, t->s2 ? (float4*)d_state2_out : nullptr, cap, t->op);
     MEE_HIP(hipGetLastError());
     MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));

@@ -134,6 +134,20 @@ class ShardedLookupTable:
         dist.all_reduce(t, group=self.group)
         return int(t.item())
 
+    def save(self, path: str, chunk_slots: int = 1 << 22) -> int:
+        """Checkpoint: every rank writes its shard under path/shard-<rank>-of-<world> (checkpoint.py); collective."""
+        from . import checkpoint
+        n = checkpoint.save_sharded(self, path, chunk_slots)
+        dist.barrier(group=self.group)
+        return n
+
+    def load(self, path: str, chunk_pairs: int | None = None) -> int:
+        """Load a checkpoint written by ANY world size: each rank keeps the pairs it owns now (re-sharding on load)."""
+        from . import checkpoint
+        n = checkpoint.load_sharded(self, path, self.router.owner, chunk_pairs)
+        dist.barrier(group=self.group)
+        return n
+
     def export_local(self, with_state: bool = False):
         return self.local.export(with_state=with_state)
 

@@ -201,6 +201,50 @@ class LookupTable:
             raise MeepoError(_lib.ERR_HIP, f"export wrote {m.value} pairs, size() said {n}")
         return (keys, vals, s1, s2) if with_state else (keys, vals)
 
+    def export_range(self, slot_begin: int, slot_end: int, with_state: bool = False):
+        """The pairs stored in slots [slot_begin, slot_end) — export in bounded pieces (checkpoints, rehash of a table
+        that fills most of HBM).  Always returns (keys, values, state1 | None, state2 | None)."""
+        slot_end = min(slot_end, self.capacity)
+        cap = max(slot_end - slot_begin, 0)
+        keys = torch.empty(cap, dtype=torch.int64, device=self.device)
+        vals = torch.empty((cap, self.dim), dtype=torch.float32, device=self.device)
+        s1 = torch.empty((cap, self.dim), dtype=torch.float32, device=self.device) if with_state and self.optimizer != OPT_NONE else None
+        s2 = torch.empty((cap, self.dim), dtype=torch.float32, device=self.device) if with_state and self.optimizer == OPT_ADAM else None
+        m = C.c_size_t()
+        check(_lib.lib().mee_export_range(self._h, slot_begin, slot_end, keys.data_ptr(), vals.data_ptr(),
+                                          s1.data_ptr() if s1 is not None else None, s2.data_ptr() if s2 is not None else None,
+                                          cap, C.byref(m), self._s()))
+        n = m.value
+        return keys[:n], vals[:n], (s1[:n] if s1 is not None else None), (s2[:n] if s2 is not None else None)
+
+    def iter_export(self, chunk_slots: int = 1 << 22, with_state: bool = True):
+        """Generator over export_range pieces covering the whole table (empty pieces are skipped)."""
+        for b in range(0, self.capacity, chunk_slots):
+            piece = self.export_range(b, b + chunk_slots, with_state)
+            if piece[0].numel():
+                yield piece
+
+    def evict(self, max_hits: int = 0, limit: int = 1 << 20, reset: bool = True) -> int:
+        """Eviction by the hit counters (track_hits tables): remove up to `limit` keys looked up at most `max_hits`
+        times since the counters were last reset; returns how many were removed.  Slots become reusable tombstones."""
+        victims = self.hits_scan(0, max_hits, limit, reset=False)
+        removed = 0
+        for s in range(0, victims.numel(), self.max_batch):
+            removed += int(self.remove(victims[s:s + self.max_batch]).sum().item())
+        if reset:
+            self.hits_scan(1, 0, 0, reset=True)   # empty range: nothing listed, counters zeroed
+        return removed
+
+    def save(self, path: str, chunk_slots: int = 1 << 22, extra: dict | None = None) -> int:
+        """Write a checkpoint directory (see checkpoint.py for the format); returns the number of pairs written."""
+        from . import checkpoint
+        return checkpoint.save_table(self, path, chunk_slots, extra)
+
+    def load(self, path: str, chunk_pairs: int | None = None, keep=None) -> int:
+        """Bulk-load a checkpoint directory into this table (rows + optimizer planes); returns pairs loaded."""
+        from . import checkpoint
+        return checkpoint.load_into(self, path, chunk_pairs, keep)
+
     def import_(self, keys: torch.Tensor, values: torch.Tensor, state1: torch.Tensor | None = None,
                 state2: torch.Tensor | None = None) -> None:
         """Inverse of export(with_state=True): bulk-load pairs (and optimizer state) of any length, max_batch at a time.
@@ -218,11 +262,12 @@ class LookupTable:
 
     def resized(self, capacity: int, chunk: int = 1 << 22) -> "LookupTable":
         """Rehash into a NEW table of another capacity (same options): export -> import_, state planes included.
-        The table itself never resizes (SPEC.md §2); growing is this explicit copy, which needs both tables to fit."""
+        The table itself never resizes (SPEC.md §2); growing is this explicit copy, which needs both tables to fit
+        (plus one `chunk`-slot export piece)."""
         opts = self._opts.copy()
         new = LookupTable(capacity, self.dim, **opts)
-        ek, ev, e1, e2 = self.export(with_state=True)
-        new.import_(ek, ev, e1, e2)
+        for ek, ev, e1, e2 in self.iter_export(chunk, with_state=True):   # bounded scratch: one slot range at a time
+            new.import_(ek, ev, e1, e2)
         return new
 
     # -- sparse optimizers (SPEC.md §4) --------------------------------------------------------------------
@@ -298,6 +343,10 @@ class Router:
             self.close()
         except Exception:
             pass
+
+    def owner(self, keys: torch.Tensor) -> torch.Tensor:
+        """owner(key) under this router's shard count (SPEC.md §5), int64 per key."""
+        return hash_batch(keys, 1, self.n_shards)[2].to(torch.int64)
 
     def partition(self, keys: torch.Tensor):
         k = keys.contiguous().view(-1)

@@ -96,6 +96,17 @@ class CpuTable:
     def export(self, with_state=False):
         return tuple(torch.from_numpy(x) if x is not None else None for x in self.o.export(with_state=with_state))
 
+    def iter_export(self, chunk_slots=1 << 22, with_state=True):
+        k, v, a, b = self.export(with_state=True)
+        for s in range(0, k.numel(), 1000):   # several pieces, like a ranged export
+            yield k[s:s + 1000], v[s:s + 1000], (a[s:s + 1000] if a is not None else None), (b[s:s + 1000] if b is not None else None)
+
+    def import_(self, keys, values, state1=None, state2=None):
+        self.insert(keys, values)
+        for plane, st in ((1, state1), (2, state2)):
+            if st is not None:
+                self.assign_plane(plane, keys, st)
+
 
 class CpuRouter:
     def __init__(self, n_shards):
@@ -104,6 +115,9 @@ class CpuRouter:
     def partition(self, keys):
         send, counts, perm = oracle.partition(keys.numpy(), self.n_shards)
         return torch.from_numpy(send), torch.from_numpy(counts), torch.from_numpy(perm)
+
+    def owner(self, keys):
+        return torch.from_numpy(oracle.hash_batch(keys.numpy(), 1, self.n_shards)[2].astype(np.int64))
 
     def scatter_rows(self, rows, perm):
         out = torch.empty_like(rows)

@@ -51,6 +51,10 @@ int main() try {
       CHECK(memcmp(out.data(), rows.data(), n * dim * 4) == 0); }
     table.remove(d_keys.p, n / 2, d_found.p);
     CHECK(table.size() == n - n / 2);
+    { // ranged export: the two halves of the slot range hold all pairs between them
+      const uint64_t cap = table.info().capacity;
+      const size_t a = table.export_range(0, cap / 2, nullptr, nullptr, 0), b = table.export_range(cap / 2, cap, nullptr, nullptr, 0);
+      CHECK(a + b == n - n / 2 && a > 0 && b > 0); }
 
     // ---- hot/cold pair: first half of the keys in HBM, second half in the pinned-host tier ------------------------
     meepo::TableOptions ho = o; ho.capacity = (uint64_t)(n / 2 / 0.75);

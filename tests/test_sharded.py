@@ -56,7 +56,8 @@ def _run_rank(rank, world, port, backend, q, tiered=False):
         from _cpu_backend import CpuRouter, CpuTable
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dev = torch.device("cpu")
-        local = CpuTable(16384, DIM, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
+        mk_local = lambda: CpuTable(16384, DIM, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
+        local = mk_local()
         if tiered:   # BASELINE configs[4]: every shard is a hot/cold pair
             from meepoembedding_amd.tiered import TieredLookupTable
             local = TieredLookupTable(CpuTable(2048, DIM, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1), local, hot_key_limit=1200)
@@ -68,14 +69,16 @@ def _run_rank(rank, world, port, backend, q, tiered=False):
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        local = LookupTable(16384, DIM, device=dev, optimizer=OPT_ADAGRAD, initial_accumulator=0.1, max_batch=world * BATCH)
+        mk_local = lambda: LookupTable(16384, DIM, device=dev, optimizer=OPT_ADAGRAD, initial_accumulator=0.1, max_batch=world * BATCH)
+        local = mk_local()
         router = Router(world, BATCH, device=dev)
     else:
         from meepoembedding_amd import OPT_ADAGRAD, LookupTable, Router
         dev = torch.device("cuda", rank)
         torch.cuda.set_device(dev)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        local = LookupTable(16384, DIM, device=dev, optimizer=OPT_ADAGRAD, initial_accumulator=0.1, max_batch=world * BATCH)
+        mk_local = lambda: LookupTable(16384, DIM, device=dev, optimizer=OPT_ADAGRAD, initial_accumulator=0.1, max_batch=world * BATCH)
+        local = mk_local()
         router = Router(world, BATCH, device=dev)
     try:
         sh = ShardedLookupTable(local, router)
@@ -138,6 +141,18 @@ def _run_rank(rank, world, port, backend, q, tiered=False):
             o2, f2 = sh.find(dup, dedup=True)
             assert torch.equal(o1, o2) and torch.equal(f1, f2)
         total = sh.size()
+        if not tiered:   # checkpoint round trip of the sharded table: save, load into fresh shards, same answers
+            ck = f"/tmp/meepo_ckpt_{port}"
+            sh.save(ck)
+            fresh = ShardedLookupTable(mk_local(), router)
+            fresh.load(ck, chunk_pairs=1500)
+            assert fresh.size() == total
+            o6, f6 = fresh.find(probe)
+            assert torch.equal(o6, out) and torch.equal(f6, found)
+            dist.barrier()
+            if rank == 0:
+                import shutil
+                shutil.rmtree(ck, ignore_errors=True)
         ek, ev, ea, _ = sh.export_local(with_state=True)
         q.put((rank, probe.cpu().numpy(), out.cpu().numpy(), found.cpu().numpy(), total, ek.cpu().numpy(), ev.cpu().numpy(), ea.cpu().numpy()))
         dist.barrier()
