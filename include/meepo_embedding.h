@@ -195,7 +195,8 @@ int mee_p2p_find(mee_p2p* c, const mee_table* t, void* stream);
 /* Mutators over peer-mapped memory (contexts created with with_payload != 0): push (key, row) pairs into the owners'
  * inboxes; every segment is padded to slots_per_peer with MEE_EMPTY_KEY (= padding, SPEC.md §2), so after the barrier
  * the owner hands its WHOLE inbox — mee_p2p_inbox(): n_shards x slots_per_peer keys and rows, ordered by source rank then
- * batch position — to mee_insert / mee_assign / mee_apply_* with a fixed n; a second barrier frees the inbox. */
+ * batch position — to mee_insert / mee_assign / mee_apply_* with a fixed n; a second barrier frees the inbox.  d_rows may be
+ * null: keys only, still padded (the owner runs mee_find_or_insert over the inbox, then mee_p2p_find returns the rows). */
 int mee_p2p_push_rows(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts,
                       const float* d_rows, size_t n, void* stream);
 int mee_p2p_inbox(mee_p2p* c, int64_t** d_keys, float** d_rows, uint64_t* n_slots);

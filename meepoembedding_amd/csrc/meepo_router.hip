@@ -491,15 +491,17 @@ int mee_p2p_push(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const in
 
 int mee_p2p_push_rows(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts,
                       const float* d_rows, size_t n, void* stream) {
-    if (!c || !r || !d_counts || (n && (!d_send_keys || !d_perm || !d_rows))) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push_rows: null argument");
+    if (!c || !r || !d_counts || (n && (!d_send_keys || !d_perm))) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push_rows: null argument");
     if (!c->connected || !c->inbox_rows) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push_rows: context not connected or created without payload");
     if (r->n_shards != c->n_shards || n > c->max_batch) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push_rows: router/batch mismatch");
     DeviceGuard g(c->device);
     hipStream_t st = (hipStream_t)stream;
     const dim3 gk(grid_for(c->cap, 256, 1024), c->n_shards);
     p2p_push_kernel<<<gk, 256, 0, st>>>(d_send_keys, d_perm, d_counts, r->base, p2p_peers(c), c->rank, c->cap, c->status, 1);
-    const dim3 gr(grid_for(n / c->n_shards + 64, 16, 4096), c->n_shards);
-    p2p_push_rows_kernel<<<gr, 256, 0, st>>>((const float4*)d_rows, d_perm, d_counts, r->base, p2p_peers(c), c->rank, c->cap, c->dim / 4);
+    if (d_rows) {  // null: keys only, padded (an owner-side find_or_insert over the whole inbox)
+        const dim3 gr(grid_for(n / c->n_shards + 64, 16, 4096), c->n_shards);
+        p2p_push_rows_kernel<<<gr, 256, 0, st>>>((const float4*)d_rows, d_perm, d_counts, r->base, p2p_peers(c), c->rank, c->cap, c->dim / 4);
+    }
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }

@@ -1,34 +1,78 @@
-"""The caller side of the boundary: the lookup table as a trainable torch layer.
+"""The caller side of the boundary: the lookup table as a trainable torch layer, registered as
+`torch.library` custom ops on PyTorch-ROCm.
 
-forward  = find_or_insert (dynamic vocabulary: unseen ids get their hashed initial row)
-backward = the table's own sparse optimizer (apply_adagrad / apply_adam) fed with the dense grad of the output — the
-           update happens INSIDE backward, so the layer has no torch parameters and needs no torch optimizer.
-Works with a LookupTable, a TieredLookupTable or a ShardedLookupTable (same method names).  Plumbing only: no kernel
-lives here.  Reference anchor: /root/reference/README.md:2 ("Embedding designed for recommendation … systems").
+    meepo::lookup(keys, anchor, table_id, insert_missing) -> rows     forward  = find_or_insert (training: unseen ids get
+                                                                                 their hashed initial row) or find (eval)
+    meepo::apply_grad(keys, grad_rows, table_id)                      backward = the table's own sparse optimizer
+                                                                                 (apply_adagrad / apply_adam), fed with
+                                                                                 the dense grad of the output
+
+The update happens INSIDE backward, so the layer has no torch parameters and needs no torch optimizer.  Both ops have
+fake (meta) kernels, so a model containing the layer traces and exports; they are opaque to the tracer (the table is
+state outside the graph, addressed by `table_id`).  Works with a LookupTable, a TieredLookupTable, a ShardedLookupTable
+or a PeerShardedTable (same method names).  Plumbing only: no kernel lives here.
+Reference anchor: /root/reference/README.md:2 ("Embedding designed for recommendation … systems").
 """
 from __future__ import annotations
 
+import itertools
+import weakref
+
 import torch
 
+_LAYERS: "weakref.WeakValueDictionary[int, DynamicEmbedding]" = weakref.WeakValueDictionary()
+_IDS = itertools.count(1)
 
-class _Lookup(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, keys: torch.Tensor, anchor: torch.Tensor, layer: "DynamicEmbedding"):
-        flat = keys.reshape(-1)
-        rows, _ = layer.table.find_or_insert(flat) if layer.training else layer.table.find(flat)
-        ctx.layer, ctx.keys = layer, flat
-        return rows.view(*keys.shape, layer.table.dim)
 
-    @staticmethod
-    def backward(ctx, grad_out: torch.Tensor):
-        layer = ctx.layer
-        g = grad_out.reshape(-1, layer.table.dim).contiguous()
-        layer.step += 1
-        if layer.optimizer == "adagrad":
-            layer.table.apply_adagrad(ctx.keys, g, lr=layer.lr, eps=layer.eps)
-        else:
-            layer.table.apply_adam(ctx.keys, g, lr=layer.lr, beta1=layer.betas[0], beta2=layer.betas[1], eps=layer.eps, step=layer.step)
-        return None, None, None
+def _layer(table_id: int) -> "DynamicEmbedding":
+    try:
+        return _LAYERS[table_id]
+    except KeyError:
+        raise RuntimeError(f"meepo: no live DynamicEmbedding with table_id {table_id}") from None
+
+
+@torch.library.custom_op("meepo::lookup", mutates_args=())
+def lookup(keys: torch.Tensor, anchor: torch.Tensor, table_id: int, insert_missing: bool) -> torch.Tensor:
+    layer = _layer(table_id)
+    flat = keys.reshape(-1)
+    rows, _ = layer.table.find_or_insert(flat) if insert_missing else layer.table.find(flat)
+    return rows.reshape(*keys.shape, layer.table.dim).clone()   # never alias the table's / exchange's buffers
+
+
+@lookup.register_fake
+def _(keys, anchor, table_id, insert_missing):
+    return keys.new_empty((*keys.shape, _layer(table_id).table.dim), dtype=torch.float32)
+
+
+@torch.library.custom_op("meepo::apply_grad", mutates_args=())
+def apply_grad(keys: torch.Tensor, grad_rows: torch.Tensor, table_id: int) -> None:
+    layer = _layer(table_id)
+    g = grad_rows.reshape(-1, layer.table.dim).contiguous()
+    layer.step += 1
+    if layer.optimizer == "adagrad":
+        layer.table.apply_adagrad(keys.reshape(-1), g, lr=layer.lr, eps=layer.eps)
+    else:
+        layer.table.apply_adam(keys.reshape(-1), g, lr=layer.lr, beta1=layer.betas[0], beta2=layer.betas[1], eps=layer.eps, step=layer.step)
+
+
+@apply_grad.register_fake
+def _(keys, grad_rows, table_id):
+    return None
+
+
+def _setup(ctx, inputs, output):
+    keys, _, table_id, _ = inputs
+    ctx.save_for_backward(keys)
+    ctx.table_id = table_id
+
+
+def _backward(ctx, grad_out):
+    (keys,) = ctx.saved_tensors
+    apply_grad(keys, grad_out.contiguous(), ctx.table_id)
+    return None, None, None, None
+
+
+lookup.register_autograd(_backward, setup_context=_setup)
 
 
 class DynamicEmbedding(torch.nn.Module):
@@ -41,8 +85,10 @@ class DynamicEmbedding(torch.nn.Module):
         self.table, self.optimizer, self.lr, self.betas = table, optimizer, lr, betas
         self.eps = eps if eps is not None else (1e-10 if optimizer == "adagrad" else 1e-8)
         self.step = 0
-        # autograd only runs backward for functions with an input that requires grad
+        self.table_id = next(_IDS)
+        _LAYERS[self.table_id] = self
+        # autograd only runs backward for ops with an input that requires grad
         self._anchor = torch.nn.Parameter(torch.zeros(()), requires_grad=True)
 
     def forward(self, keys: torch.Tensor) -> torch.Tensor:
-        return _Lookup.apply(keys, self._anchor, self)
+        return lookup(keys, self._anchor, self.table_id, self.training)

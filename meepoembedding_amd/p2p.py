@@ -76,6 +76,7 @@ class PeerShardedFind:
                 check(L.mee_p2p_inbox(self._h, C.byref(pk), C.byref(pr), C.byref(ns)))
                 self.inbox_keys = torch.as_tensor(_Raw(pk.value, (ns.value,), "<i8"), device=self.device)
                 self.inbox_rows = torch.as_tensor(_Raw(pr.value, (ns.value, self.dim), "<f4"), device=self.device)
+                self._ensure_found = torch.empty(ns.value, dtype=torch.uint8, device=self.device)
         except Exception as e:  # noqa: BLE001
             err = e
         self._agree(err, "connect")  # also the barrier: nobody pushes before every rank has connected
@@ -116,6 +117,27 @@ class PeerShardedFind:
         send_keys, counts, perm = self.router.partition(keys)
         check(L.mee_p2p_push(self._h, self.router._h, send_keys.data_ptr(), perm.data_ptr(), counts.data_ptr(), n, s))
         self._barrier()
+        check(L.mee_p2p_find(self._h, self.local._h, s))
+        self._barrier()
+        if check_overflow:
+            self.check()
+        return self.out[:n], self.found[:n]
+
+    def find_or_insert(self, keys: torch.Tensor, check_overflow: bool = True):
+        """find that first creates absent keys at their owners (initial rows).  The found bytes are those of the lookup
+        AFTER creation (1 for every non-reserved key); use ShardedLookupTable.find_or_insert for the pre-existence mask."""
+        if not self.payload:
+            raise _lib.MeepoError(_lib.ERR_INVALID_ARG, "find_or_insert needs PeerShardedFind(..., payload=True)")
+        keys = keys.contiguous().view(-1)
+        n = keys.numel()
+        if n > self.max_batch:
+            raise _lib.MeepoError(_lib.ERR_BATCH_TOO_LARGE, f"n={n} exceeds max_batch={self.max_batch}")
+        L = _lib.lib()
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        send_keys, counts, perm = self.router.partition(keys)
+        check(L.mee_p2p_push_rows(self._h, self.router._h, send_keys.data_ptr(), perm.data_ptr(), counts.data_ptr(), None, n, s))
+        self._barrier()
+        self.local.find_or_insert(self.inbox_keys, out=self.inbox_rows, found=self._ensure_found)   # the row inbox is the scratch
         check(L.mee_p2p_find(self._h, self.local._h, s))
         self._barrier()
         if check_overflow:

@@ -159,11 +159,13 @@ class LookupTable:
         check(_lib.lib().mee_remove(self._h, k.data_ptr(), k.numel(), found.data_ptr(), self._s()))
         return found
 
-    def find_or_insert(self, keys: torch.Tensor):
+    def find_or_insert(self, keys: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None):
         k = self._keys(keys)
         n = k.numel()
-        out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
-        found = torch.empty(n, dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        if found is None:
+            found = torch.empty(n, dtype=torch.uint8, device=self.device)
         check(_lib.lib().mee_find_or_insert(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), self._s()))
         return out, found
 

@@ -4,12 +4,41 @@ import numpy as np
 import pytest
 import torch
 
-from meepoembedding_amd import OPT_ADAGRAD, LookupTable, synth
-from meepoembedding_amd.nn import DynamicEmbedding
+import oracle
+from meepoembedding_amd import synth
+from meepoembedding_amd.nn import DynamicEmbedding, lookup
+
+
+def test_custom_ops_on_cpu_adapter(built):
+    """The torch.library registration (schema, fake kernel, autograd formula, tracing) with an oracle-backed table."""
+    from _cpu_backend import CpuTable
+    t = CpuTable(4096, 16, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
+    layer = DynamicEmbedding(t, lr=0.05)
+    k = torch.from_numpy(synth.keys_np(1, 0, 12)).view(3, 4)
+    out = layer(k)
+    assert out.shape == (3, 4, 16) and t.size() == 12           # training mode creates unseen ids
+    w0, _ = t.find(k.view(-1))
+    out.sum().backward()                                          # backward IS the optimizer step
+    w1, _ = t.find(k.view(-1))
+    # Adagrad with g = 1, acc0 = 0.1: w -= lr / sqrt(1.1)
+    np.testing.assert_allclose((w0 - w1).numpy(), np.full((12, 16), 0.05 / np.sqrt(1.1), np.float32), rtol=1e-6)
+    torch.library.opcheck(lookup, (k, layer._anchor, layer.table_id, False),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    from torch.fx.experimental.proxy_tensor import make_fx
+    gm = make_fx(lambda kk, a: lookup(kk, a, layer.table_id, False) * 2, tracing_mode="fake")(k, layer._anchor)
+    assert "torch.ops.meepo.lookup" in gm.code
+    layer.eval()
+    layer(torch.tensor([5, 6])); assert t.size() == 12          # eval mode does not create
+    tid = layer.table_id
+    del layer, gm
+    import gc; gc.collect()
+    with pytest.raises(RuntimeError):                              # the registry holds layers weakly
+        lookup(k, torch.zeros(()), tid, False)
 
 
 @pytest.mark.gpu
 def test_dynamic_embedding_trains_like_torch_sparse_adagrad(dev):
+    from meepoembedding_amd import OPT_ADAGRAD, LookupTable
     torch.manual_seed(0)
     vocab, dim, steps, batch, bag = 500, 16, 6, 64, 5
     ids_all = torch.randint(0, vocab, (steps, batch, bag))

@@ -134,6 +134,14 @@ def _run_rank(rank, world, port, backend, q, tiered=False):
             o5, f5 = sb.find(probe)
             assert torch.equal(f4, f5)
             torch.testing.assert_close(o4, o5, rtol=1e-6, atol=1e-9)
+            # find_or_insert over the inboxes: unseen keys are created at their owners, same rows as the all-to-all path
+            fresh_keys = torch.from_numpy(synth.keys_np(77, rank * 300, 300)).to(dev)
+            mix = torch.cat([fresh_keys, probe[:200], fresh_keys[:50]])
+            o7, f7 = pt.find_or_insert(mix)
+            o8, _ = sb.find_or_insert(mix)
+            assert torch.equal(o7, o8) and bool(f7.all())
+            dist.barrier()
+            assert la.size() == lb.size()
             with pytest.raises(ValueError):
                 PeerShardedFind(local, Router(world, 1 << 16, device=dev), max_batch=1 << 16, payload=True)
             pt.close()
