@@ -133,6 +133,42 @@ class TieredLookupTable:
         a, b = self.hot.export(with_state=with_state), self.cold.export(with_state=with_state)
         return tuple(None if x is None else torch.cat([x, y]) for x, y in zip(a, b))
 
+    # -- checkpoint (checkpoint.py works on anything with iter_export / import_) ----------------------------------
+    @property
+    def device(self) -> torch.device:
+        return getattr(self.hot, "device", torch.device("cpu"))
+
+    @property
+    def max_batch(self) -> int:
+        return min(int(getattr(self.hot, "max_batch", 1 << 20)), int(getattr(self.cold, "max_batch", 1 << 20)))
+
+    def iter_export(self, chunk_slots: int = 1 << 22, with_state: bool = True):
+        yield from self.hot.iter_export(chunk_slots, with_state)
+        yield from self.cold.iter_export(chunk_slots, with_state)
+
+    def assign_plane(self, plane: int, keys: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
+        return self.hot.assign_plane(plane, keys, values) | self.cold.assign_plane(plane, keys, values)
+
+    def import_(self, keys: torch.Tensor, values: torch.Tensor, state1: torch.Tensor | None = None,
+                state2: torch.Tensor | None = None) -> None:
+        """Bulk-load pairs + optimizer planes (hot while there is room, then cold), max_batch at a time."""
+        keys = keys.contiguous().view(-1)
+        step = self.max_batch
+        for s in range(0, keys.numel(), step):
+            k = keys[s:s + step]
+            self.insert(k, values[s:s + step])
+            for plane, st in ((1, state1), (2, state2)):
+                if st is not None:
+                    self.assign_plane(plane, k, st[s:s + step])
+
+    def save(self, path: str, chunk_slots: int = 1 << 22) -> int:
+        from . import checkpoint
+        return checkpoint.save_table(self, path, chunk_slots)
+
+    def load(self, path: str, chunk_pairs: int | None = None, keep=None) -> int:
+        from . import checkpoint
+        return checkpoint.load_into(self, path, chunk_pairs, keep)
+
     # -- tier migration ------------------------------------------------------------------------------------
     def _move(self, src, dst, keys: torch.Tensor) -> int:
         """Move the keys that `src` holds into `dst`, rows and optimizer state; returns how many were moved."""

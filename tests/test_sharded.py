@@ -51,16 +51,26 @@ def _removed(rank):
 
 
 def _run_rank(rank, world, port, backend, q, tiered=False):
+    try:
+        _run_rank_body(rank, world, port, backend, q, tiered)
+    except BaseException as e:   # report at once: the parent must not sit out its queue timeout on the GPU box
+        import traceback
+        q.put(("error", rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+        raise
+
+
+def _run_rank_body(rank, world, port, backend, q, tiered=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     if backend == "gloo":
         from _cpu_backend import CpuRouter, CpuTable
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dev = torch.device("cpu")
         mk_local = lambda: CpuTable(16384, DIM, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
-        local = mk_local()
         if tiered:   # BASELINE configs[4]: every shard is a hot/cold pair
             from meepoembedding_amd.tiered import TieredLookupTable
-            local = TieredLookupTable(CpuTable(2048, DIM, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1), local, hot_key_limit=1200)
+            mk_flat = mk_local
+            mk_local = lambda: TieredLookupTable(CpuTable(2048, DIM, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1), mk_flat(), hot_key_limit=1200)
+        local = mk_local()
         router = CpuRouter(world)
     elif backend == "gloo-gpu":
         # several ranks share ONE GPU; the exchange is staged through host memory over gloo — every HIP kernel of the
@@ -70,6 +80,13 @@ def _run_rank(rank, world, port, backend, q, tiered=False):
         torch.cuda.set_device(dev)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         mk_local = lambda: LookupTable(16384, DIM, device=dev, optimizer=OPT_ADAGRAD, initial_accumulator=0.1, max_batch=world * BATCH)
+        if tiered:   # configs[4] on the real backend: HBM table in front of a pinned-host-DRAM table, per shard
+            from meepoembedding_amd import _lib
+            from meepoembedding_amd.tiered import TieredLookupTable
+            mk_local = lambda: TieredLookupTable(
+                LookupTable(2048, DIM, device=dev, optimizer=OPT_ADAGRAD, initial_accumulator=0.1, max_batch=world * BATCH),
+                LookupTable(16384, DIM, device=dev, optimizer=OPT_ADAGRAD, initial_accumulator=0.1, max_batch=world * BATCH,
+                            value_memory=_lib.MEM_HOST_PINNED), hot_key_limit=1200)
         local = mk_local()
         router = Router(world, BATCH, device=dev)
     else:
@@ -93,7 +110,7 @@ def _run_rank(rank, world, port, backend, q, tiered=False):
         # the same lookup with pre-exchange dedup on a duplicate-heavy batch (+ a reserved key) must give the same answer
         dup = torch.cat([probe[:500].repeat(7), probe[-60:], torch.tensor([oracle.EMPTY_KEY], device=dev)])
         o1, f1 = sh.find(dup)
-        if backend in ("gloo-gpu", "nccl"):   # the all-to-all-free path over peer-mapped memory must agree bit for bit
+        if backend in ("gloo-gpu", "nccl") and not tiered:   # the all-to-all-free path over peer-mapped memory must agree bit for bit
             from meepoembedding_amd.p2p import PeerShardedFind
             pf = PeerShardedFind(local, Router(world, 8192, device=dev), max_batch=8192)
             for qk in (dup, probe, dup[:1], dup[:777]):
@@ -149,7 +166,7 @@ def _run_rank(rank, world, port, backend, q, tiered=False):
             o2, f2 = sh.find(dup, dedup=True)
             assert torch.equal(o1, o2) and torch.equal(f1, f2)
         total = sh.size()
-        if not tiered:   # checkpoint round trip of the sharded table: save, load into fresh shards, same answers
+        if True:   # checkpoint round trip of the sharded table (tiered shards too): save, load into fresh shards, same answers
             ck = f"/tmp/meepo_ckpt_{port}"
             sh.save(ck)
             fresh = ShardedLookupTable(mk_local(), router)
@@ -193,7 +210,16 @@ def _launch(world, backend, tiered=False):
     procs = [ctx.Process(target=_run_rank, args=(r, world, port, backend, q, tiered)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=300) for _ in range(world)]
+    results = []
+    for _ in range(world):
+        r = q.get(timeout=300)
+        if r[0] == "error":
+            for p in procs:   # the other ranks may be waiting for the failed one in a collective
+                p.join(timeout=5)
+                if p.is_alive():
+                    p.kill()
+            pytest.fail(f"rank {r[1]} failed:\n{r[2]}")
+        results.append(r)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -214,6 +240,12 @@ def test_sharded_tiered_gloo_cpu(built):
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_multi_rank_on_one_gpu(dev, world):
     _check(_launch(world, "gloo-gpu"), world)
+
+
+@pytest.mark.gpu
+def test_sharded_tiered_multi_rank_on_one_gpu(dev):
+    """configs[4] shape on the HIP backend: two ranks, every shard an HBM table backed by a pinned-host table."""
+    _check(_launch(2, "gloo-gpu", tiered=True), 2)
 
 
 @pytest.mark.gpu
