@@ -94,6 +94,23 @@ int main() try {
           CHECK(f[i] == 1);
           CHECK(memcmp(&out[i * dim], &rows[((i * 7919) % n) * dim], dim * 4) == 0);
       } }
+    // ---- mutator over the payload inbox: (key, row) pairs pushed with padding, the owner inserts its WHOLE inbox --------
+    { const uint64_t slots_per_peer = n + 100;                       // > n: the segment's tail is padding (EMPTY keys)
+      meepo::TableOptions so = o; so.max_batch = slots_per_peer;
+      meepo::Table sink(so);
+      meepo::PeerExchange pm(0, 1, 0, slots_per_peer, n, dim, /*with_payload=*/true);
+      char hm[MEE_P2P_BUFFERS * MEE_IPC_HANDLE_BYTES];
+      pm.export_handles(hm);
+      pm.connect(hm);
+      router.partition(d_keys.p, n, d_send.p, d_counts.p, d_perm.p);
+      pm.push_rows(router, d_send.p, d_perm.p, d_counts.p, d_rows.p, n);
+      CHECK(pm.inbox_slots() == slots_per_peer);
+      sink.insert(pm.inbox_keys(), pm.inbox_rows(), pm.inbox_slots());
+      CHECK(sink.size() == n && sink.status() == 0 && pm.status() == 0);   // padding is silent
+      sink.find(d_keys.p, n, d_out.p, d_found.p);
+      HIPCK(hipDeviceSynchronize());
+      auto out = d_out.down(n * dim);
+      CHECK(memcmp(out.data(), rows.data(), n * dim * 4) == 0); }
     printf("host_cpp_test ok: Table, TieredTable (HBM + pinned host) and the peer-mapped sharded pipeline through meepo_embedding.hpp\n");
     return 0;
 } catch (const std::exception& e) {
