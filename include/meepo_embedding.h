@@ -133,6 +133,11 @@ int mee_export(const mee_table* t, int64_t* d_keys_out, float* d_values_out, flo
  * partition of [0, capacity) is mee_export's set.  *n_out = pairs stored in the range. */
 int mee_export_range(const mee_table* t, uint64_t slot_begin, uint64_t slot_end, int64_t* d_keys_out, float* d_values_out,
                      float* d_state1_out, float* d_state2_out, size_t cap, size_t* n_out, void* stream);
+/* [syncs] rehash in place to at least new_capacity slots (rounded up like mee_table_create; growing or shrinking): every
+ * stored pair, its optimizer planes and hit counter move device-to-device into new planes, then the old ones are freed —
+ * old and new planes must fit in memory together.  No observable of SPEC.md §3 changes; capacity below the number of
+ * stored keys is MEE_ERR_INVALID_ARG; on any error the table is untouched.  Not concurrent with other calls on `t`. */
+int mee_reserve(mee_table* t, uint64_t new_capacity, void* stream);
 int mee_size(const mee_table* t, size_t* n_out, void* stream);        /* [syncs] */
 int mee_status(const mee_table* t, uint32_t* bits_out, void* stream); /* [syncs] */
 int mee_clear_status(mee_table* t, void* stream);

@@ -88,6 +88,8 @@ public:
         size_t u = 0; check(mee_dedup_sum(t_, d_keys, d_grads, n, d_uniq_out, d_gsum_out, d_counts_out, d_inverse_out, &u, stream)); return u;
     }
     void clear(void* stream = nullptr) { check(mee_clear(t_, stream)); }
+    // rehash in place to at least `capacity` slots (synchronises; old and new planes must fit together)
+    void reserve(uint64_t capacity, void* stream = nullptr) { check(mee_reserve(t_, capacity, stream)); }
     void clear_status(void* stream = nullptr) { check(mee_clear_status(t_, stream)); }
     void set_tuning(const char* name, int value) { check(mee_set_tuning(t_, name, value)); }
 

@@ -765,6 +765,50 @@ __global__ __launch_bounds__(256) void count_kernel(const int64_t* __restrict__ 
     }
 }
 
+// ---- reserve / rehash (SPEC.md §3): every stored pair moves, device to device, into key/row planes of another capacity ----
+// A wave reads 64 consecutive old slots (one coalesced key load), then its four tiles take the stored keys four at a
+// time: claim a slot in the new key plane (same CAS protocol as insert: all keys are distinct, claims of different
+// waves race for slots) and copy the row, the optimizer planes and the hit counter.
+__global__ __launch_bounds__(256) void rehash_kernel(const int64_t* __restrict__ okeys, const float4* __restrict__ ov,
+                                                     const float4* __restrict__ o1, const float4* __restrict__ o2,
+                                                     const uint32_t* __restrict__ ohits, uint64_t old_capacity, int64_t* nkeys,
+                                                     float4* nv, float4* n1, float4* n2, uint32_t* nhits, uint64_t nnb,
+                                                     uint32_t dim4, Counters* ctr) {
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t c0 = wave * 64; c0 < old_capacity; c0 += n_waves * 64) {
+        const uint64_t s = c0 + lane;
+        const int64_t k = s < old_capacity ? okeys[s] : kEmpty;
+        uint64_t rest = __ballot(!reserved_key(k));
+        while (rest) {  // wave-uniform
+            uint64_t mm = rest;
+            int p = -1;
+            for (int q = 0; q <= tile; ++q) {
+                if (mm) { p = __ffsll((unsigned long long)mm) - 1; mm &= mm - 1; } else p = -1;
+            }
+            const int64_t key = __shfl(k, p >= 0 ? p : 0);
+            bool is_new, full;
+            const int64_t slot = tile_locate<true, true>(nkeys, nnb, key, p >= 0, tile, tl, is_new, full);
+            if (p >= 0) {
+                if (slot >= 0) {
+                    const uint64_t src = (c0 + (uint64_t)p) * dim4, dst = (uint64_t)slot * dim4;
+                    for (uint32_t c = tl; c < dim4; c += 16) {
+                        nv[dst + c] = ov[src + c];
+                        if (n1) n1[dst + c] = o1[src + c];
+                        if (n2) n2[dst + c] = o2[src + c];
+                    }
+                    if (nhits && tl == 0) nhits[slot] = ohits[c0 + p];
+                } else if (tl == 0) {
+                    atomicOr(&ctr->status, (uint32_t)MEE_STATUS_TABLE_FULL);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rest &= rest - 1;
+        }
+    }
+}
+
 // ---- export (SPEC.md §3) -----------------------------------------------------------------------------------
 // A wave owns a chunk of 1024 consecutive slots.  Pass A: 16 coalesced key loads, ballot + popcount -> occupied
 // count, ONE atomic reserves the chunk's output range.  Pass B: per 64-slot group, ranks from the ballot mask;
@@ -1014,6 +1058,59 @@ int mee_clear(mee_table* t, void* stream) {
     DeviceGuard g(t->device);
     fill_i64_kernel<<<2048, 256, 0, as_stream(stream)>>>(t->keys, t->capacity, kEmpty);
     MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+// Allocation of one value/state plane in the table's value memory (HBM, or pinned device-mapped host DRAM for a cold tier)
+static hipError_t plane_alloc(uint32_t value_memory, float** p, uint64_t bytes) {
+    return value_memory == MEE_MEM_HOST_PINNED ? hipHostMalloc((void**)p, bytes, hipHostMallocMapped | hipHostMallocPortable)
+                                               : hipMalloc((void**)p, bytes);
+}
+static void plane_free(uint32_t value_memory, float* p) {
+    if (p) { if (value_memory == MEE_MEM_HOST_PINNED) (void)hipHostFree(p); else (void)hipFree(p); }
+}
+
+int mee_reserve(mee_table* t, uint64_t new_capacity, void* stream) {
+    if (!t || new_capacity == 0) return fail(MEE_ERR_INVALID_ARG, "mee_reserve: null table or zero capacity");
+    size_t stored = 0;
+    if (int rc = mee_size(t, &stored, stream)) return rc;
+    const uint64_t nnb = next_prime((new_capacity + kW - 1) / kW), ncap = nnb * kW;
+    if (ncap < stored) return fail(MEE_ERR_INVALID_ARG, "mee_reserve: capacity %llu is below the %zu stored keys", (unsigned long long)ncap, stored);
+    if (nnb == t->nb) return MEE_OK;
+    DeviceGuard g(t->device);
+    hipStream_t st = as_stream(stream);
+    int64_t* nkeys = nullptr; uint32_t* nhits = nullptr;
+    float *nv = nullptr, *n1 = nullptr, *n2 = nullptr;
+    const uint64_t plane = ncap * (uint64_t)t->dim * sizeof(float);
+    hipError_t e = hipMalloc((void**)&nkeys, ncap * sizeof(int64_t));
+    if (e == hipSuccess && t->hits) e = hipMalloc((void**)&nhits, ncap * sizeof(uint32_t));
+    if (e == hipSuccess) e = plane_alloc(t->value_memory, &nv, plane);
+    if (e == hipSuccess && t->s1) e = plane_alloc(t->value_memory, &n1, plane);
+    if (e == hipSuccess && t->s2) e = plane_alloc(t->value_memory, &n2, plane);
+    if (e == hipSuccess) {
+        fill_i64_kernel<<<2048, 256, 0, st>>>(nkeys, ncap, kEmpty);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && nhits) e = hipMemsetAsync(nhits, 0, ncap * sizeof(uint32_t), st);
+    if (e == hipSuccess) {
+        rehash_kernel<<<grid_for(t->capacity, 256, 1u << 16), 256, 0, st>>>(t->keys, (const float4*)t->values, (const float4*)t->s1, (const float4*)t->s2,
+                                                                          t->hits, t->capacity, nkeys, (float4*)nv, (float4*)n1, (float4*)n2, nhits, nnb,
+                                                                          t->dim4, t->ctr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {   // the table is untouched
+        (void)hipFree(nkeys); (void)hipFree(nhits);
+        plane_free(t->value_memory, nv); plane_free(t->value_memory, n1); plane_free(t->value_memory, n2);
+        return fail(e == hipErrorOutOfMemory ? MEE_ERR_OUT_OF_MEMORY : MEE_ERR_HIP, "mee_reserve(%llu slots): %s (old and new planes must fit together)",
+                    (unsigned long long)ncap, hipGetErrorString(e));
+    }
+    (void)hipFree(t->keys); (void)hipFree(t->hits);
+    plane_free(t->value_memory, t->values); plane_free(t->value_memory, t->s1); plane_free(t->value_memory, t->s2);
+    t->keys = nkeys; t->hits = nhits; t->values = nv; t->s1 = n1; t->s2 = n2;
+    t->nb = nnb; t->capacity = ncap;
+    t->table_bytes = ncap * sizeof(int64_t) + (nhits ? ncap * sizeof(uint32_t) : 0) + plane * (1 + (n1 != nullptr) + (n2 != nullptr));
+    t->prepared_n = 0;
     return MEE_OK;
 }
 

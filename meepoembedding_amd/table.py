@@ -262,6 +262,21 @@ class LookupTable:
                 if st is not None:
                     self.assign_plane(plane, k[s:e], self._rows(st, n)[s:e])
 
+    def reserve(self, capacity: int) -> None:
+        """Rehash IN PLACE to at least `capacity` slots (device-to-device; old and new planes must fit together)."""
+        check(_lib.lib().mee_reserve(self._h, int(capacity), self._s()))
+        info = _lib.TableInfo()
+        check(_lib.lib().mee_table_info_get(self._h, C.byref(info)))
+        self.capacity, self.n_buckets, self.table_bytes = info.capacity, info.n_buckets, info.table_bytes
+
+    def maybe_grow(self, max_load: float = 0.8, factor: float = 2.0) -> bool:
+        """The 'dynamic' in dynamic table, as an explicit between-steps call: when size()/capacity exceeds max_load,
+        reserve(factor x capacity).  Synchronises (size)."""
+        if self.size() <= max_load * self.capacity:
+            return False
+        self.reserve(int(self.capacity * factor))
+        return True
+
     def resized(self, capacity: int, chunk: int = 1 << 22) -> "LookupTable":
         """Rehash into a NEW table of another capacity (same options): export -> import_, state planes included.
         The table itself never resizes (SPEC.md §2); growing is this explicit copy, which needs both tables to fit

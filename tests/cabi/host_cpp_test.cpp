@@ -54,7 +54,9 @@ int main() try {
     { // ranged export: the two halves of the slot range hold all pairs between them
       const uint64_t cap = table.info().capacity;
       const size_t a = table.export_range(0, cap / 2, nullptr, nullptr, 0), b = table.export_range(cap / 2, cap, nullptr, nullptr, 0);
-      CHECK(a + b == n - n / 2 && a > 0 && b > 0); }
+      CHECK(a + b == n - n / 2 && a > 0 && b > 0);
+      table.reserve(cap * 2);                                        // in-place rehash: capacity doubles, content stays
+      CHECK(table.info().capacity >= cap * 2 && table.size() == n - n / 2 && table.status() == 0); }
 
     // ---- hot/cold pair: first half of the keys in HBM, second half in the pinned-host tier ------------------------
     meepo::TableOptions ho = o; ho.capacity = (uint64_t)(n / 2 / 0.75);

@@ -132,3 +132,57 @@ def test_evict_by_hits_gpu(dev):
     assert t.hits_scan(1, 1 << 30, 10).numel() == 0
     t.insert(keys[1000:1500], torch.ones(500, DIM, device=dev))     # tombstones are reused
     assert t.size() == 600 and t.status() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pinned", [False, True])
+def test_reserve_rehashes_in_place_gpu(dev, pinned):
+    """mee_reserve: capacity changes, no observable does (rows, optimizer planes, hit counters, found masks)."""
+    from meepoembedding_amd import OPT_ADAM, LookupTable, MeepoError, _lib
+    t = LookupTable(4000, DIM, device=dev, optimizer=OPT_ADAM, max_batch=4096, track_hits=True,
+                    value_memory=_lib.MEM_HOST_PINNED if pinned else _lib.MEM_HBM)
+    o = oracle.OracleTable(1 << 16, DIM, optimizer=oracle.OPT_ADAM)
+    rng = np.random.default_rng(9)
+    keys = synth.keys_np(9, 0, 3000)
+    v = rng.standard_normal((3000, DIM)).astype(np.float32)
+    g = rng.standard_normal((3000, DIM)).astype(np.float32)
+    to = lambda x: torch.from_numpy(x).to(dev)
+    t.insert(to(keys), to(v)); o.insert(keys, v)
+    t.apply_adam(to(keys[:2000]), to(g[:2000]), lr=0.01, step=1); o.apply_adam(keys[:2000], g[:2000], 0.01, 0.9, 0.999, 1e-8, 1)
+    t.remove(to(keys[::7])); o.remove(keys[::7])
+    t.find_counted(to(keys[1:200]))
+    before = _sorted(t.export(with_state=True))
+    hot_before = torch.sort(t.hits_scan(1, 1 << 30, 4096))[0]
+    cap0 = t.capacity
+    t.reserve(cap0)                                   # same bucket count: nothing to do
+    assert t.capacity == cap0
+    t.reserve(20000)
+    assert t.capacity >= 20000 and t.capacity % 16 == 0 and t.status() == 0 and t.size() == o.size()
+    for a, b in zip(before, _sorted(t.export(with_state=True))):
+        assert torch.equal(a, b)
+    assert torch.equal(hot_before, torch.sort(t.hits_scan(1, 1 << 30, 4096))[0])
+    probe = np.concatenate([keys[:500], synth.keys_np(10, 0, 100)])
+    out, found = t.find(to(probe)); eo, ef = o.find(probe)
+    assert np.array_equal(found.cpu().numpy(), ef)
+    np.testing.assert_allclose(out.cpu().numpy(), eo, rtol=1e-6, atol=1e-9)
+    # the grown table takes more keys than the old capacity could hold, and keeps training
+    more = synth.keys_np(11, 0, 12000)
+    for s in range(0, 12000, 4096):
+        mv = rng.standard_normal((more[s:s + 4096].size, DIM)).astype(np.float32)
+        t.insert(to(more[s:s + 4096]), to(mv)); o.insert(more[s:s + 4096], mv)
+    t.apply_adam(to(keys[:2000]), to(g[:2000]), lr=0.01, step=2); o.apply_adam(keys[:2000], g[:2000], 0.01, 0.9, 0.999, 1e-8, 2)
+    assert t.status() == 0 and t.size() == o.size()
+    ek = _sorted(t.export(with_state=True)); ok = o.export(with_state=True); srt = np.argsort(ok[0])
+    assert np.array_equal(ek[0].numpy(), ok[0][srt])
+    for a, b in zip(ek[1:], ok[1:]):
+        np.testing.assert_allclose(a.numpy(), b[srt], rtol=1e-6, atol=1e-9)
+    # shrinking: to fit is fine (tombstones are dropped on the way), below the stored count is refused and changes nothing
+    n = t.size()
+    with pytest.raises(MeepoError):
+        t.reserve(n // 2)
+    cap1 = t.capacity
+    t.reserve(int(n / 0.8))
+    assert t.capacity < cap1 and t.size() == n and t.status() == 0
+    for a, b in zip(ek, _sorted(t.export(with_state=True))):
+        assert torch.equal(a, b)
+    assert t.maybe_grow(max_load=0.5) and t.capacity >= 2 * int(n / 0.8) and not t.maybe_grow(max_load=0.5)
