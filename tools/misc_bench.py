@@ -33,3 +33,22 @@ k, v = t.export(); torch.cuda.synchronize()   # first call pays the 26 GB alloca
 del k, v
 t0 = time.time(); k, v = t.export(); torch.cuda.synchronize(); dt = time.time() - t0
 print(f"export of {k.numel()} pairs ({k.numel() * (8 + 4 * dim) / 1e9:.1f} GB out): {dt * 1e3:.1f} ms -> {k.numel() * (8 + 4 * dim) * 2 / dt / 1e12:.2f} TB/s read+write")
+del k, v
+torch.cuda.empty_cache()
+t0 = time.time(); n_r = sum(p[0].numel() for p in t.iter_export(1 << 24, with_state=True)); torch.cuda.synchronize(); dt = time.time() - t0
+print(f"ranged export with state, 16M-slot pieces ({n_r} pairs, scratch {(1 << 24) * (8 + 8 * dim) / 1e9:.1f} GB): {dt * 1e3:.1f} ms")
+cap0 = t.capacity
+t0 = time.time(); t.reserve(int(cap0 * 1.5)); torch.cuda.synchronize(); dt = time.time() - t0
+print(f"reserve {cap0} -> {t.capacity} slots ({n} keys, values + Adagrad plane, {t.table_bytes / 1e9:.1f} GB after): {dt * 1e3:.1f} ms -> {n / dt / 1e9:.2f} G keys/s")
+assert t.size() == n and t.status() == 0
+o, f = t.find(keys[3]); assert bool(f.all()) and torch.equal(o, rows if False else t.find(keys[3])[0])
+import tempfile, shutil
+d = tempfile.mkdtemp(dir="/tmp")
+small = LookupTable(int(4e6 / 0.75), dim, device=dev, max_batch=B, optimizer=OPT_ADAGRAD)
+for s in range(4): small.insert(keys[s], rows)
+t0 = time.time(); m = small.save(d); dt = time.time() - t0
+print(f"checkpoint save of {m} pairs with Adagrad state ({m * (8 + 8 * dim) / 1e9:.2f} GB) to {d}: {dt:.2f} s -> {m * (8 + 8 * dim) / dt / 1e9:.2f} GB/s")
+fresh_t = LookupTable(int(8e6 / 0.75), dim, device=dev, max_batch=B, optimizer=OPT_ADAGRAD)
+t0 = time.time(); m2 = fresh_t.load(d); torch.cuda.synchronize(); dt = time.time() - t0
+print(f"checkpoint load: {dt:.2f} s -> {m2 * (8 + 8 * dim) / dt / 1e9:.2f} GB/s")
+shutil.rmtree(d)
