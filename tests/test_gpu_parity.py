@@ -324,12 +324,17 @@ def test_large_round_trip_properties(dev):
     assert torch.equal(gv[:chunk], synth.rows_t(gk[:chunk], dim, 2))
 
 
-@pytest.mark.parametrize("seed,dim,opt", [(0, 16, "adagrad"), (1, 64, "adam"), (2, 128, "adagrad"), (3, 8, "adam"), (4, 64, "adagrad")])
+# MEE_SOAK=N appends N more seeds (a soak run on the GPU box; the default suite keeps five)
+_SEQ = [(0, 16, "adagrad"), (1, 64, "adam"), (2, 128, "adagrad"), (3, 8, "adam"), (4, 64, "adagrad")] + \
+       [(s, [16, 64, 128, 8][s % 4], ["adagrad", "adam"][(s // 4) % 2]) for s in range(5, 5 + int(os.environ.get("MEE_SOAK", "0")))]
+
+
+@pytest.mark.parametrize("seed,dim,opt", _SEQ)
 def test_random_op_sequences(dev, seed, dim, opt):
     """Differential test: a random sequence of every operator (skewed duplicate-heavy batches, reserved keys, absent
     keys, a table that runs close to full) on the HIP backend and on the oracle; all observables compared after each op."""
     rng = np.random.default_rng(1000 + seed)
-    cap = 16 * 64
+    cap = ocap = 16 * 64
     kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
     kw = dict(default_value=0.25, initial_accumulator=0.1, initializer=INIT_UNIFORM, init_scale=0.05, init_seed=seed)
     t = LookupTable(cap, dim, device=dev, optimizer=kind, max_batch=4096, **kw)
@@ -343,9 +348,12 @@ def test_random_op_sequences(dev, seed, dim, opt):
         if rng.random() < 0.2:
             keys[rng.integers(0, n)] = oracle.EMPTY_KEY if rng.random() < 0.5 else oracle.RECLAIMED_KEY
         rows = rng.standard_normal((n, dim)).astype(np.float32)
-        op = rng.choice(["insert", "assign", "remove", "find", "find_or_insert", "apply", "apply", "dedup"])
+        op = rng.choice(["insert", "assign", "remove", "find", "find_or_insert", "apply", "apply", "dedup", "reserve"])
         full_before = bool(o.status() & STATUS_TABLE_FULL)
-        if op == "insert":
+        if op == "reserve":   # in-place rehash to a random capacity that still holds everything: no observable may change
+            t.reserve(int(rng.integers(o.size() + 64, 2 * ocap)))
+            cap = min(t.capacity, ocap)
+        elif op == "insert":
             if o.size() + len(np.unique(keys)) > cap - 16:
                 continue   # which keys get dropped on overflow is placement-order dependent; overflow has its own test
             t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
