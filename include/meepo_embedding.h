@@ -142,6 +142,19 @@ int mee_size(const mee_table* t, size_t* n_out, void* stream);        /* [syncs]
 int mee_status(const mee_table* t, uint32_t* bits_out, void* stream); /* [syncs] */
 int mee_clear_status(mee_table* t, void* stream);
 
+/* ---- table groups: one launch for the lookups of many tables (a model's embedding collection) ----------------
+ * All tables of a group live on one device and have the same dim.  The key batches of the tables are concatenated
+ * ("jagged" layout): segment j = d_keys[d_offsets[j] .. d_offsets[j+1]), d_offsets = n_tables+1 non-decreasing uint64 in
+ * DEVICE memory, n = total positions (host value; positions outside [d_offsets[0], d_offsets[n_tables]) are left
+ * untouched).  Results are identical to mee_find on each table with its segment; the launch latency floor is paid once
+ * instead of n_tables times.  Asynchronous on `stream`; after mee_reserve on a member the next call re-reads that
+ * table's planes (one stream synchronisation).  The group does not own the tables: destroy it before them. */
+typedef struct mee_group mee_group;
+int mee_group_create(mee_table* const* tables, uint32_t n_tables, mee_group** out);
+int mee_group_destroy(mee_group* g);
+int mee_find_grouped(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found,
+                     void* stream);
+
 /* ---- sparse optimizers (north_star "sparse-optimizer (Adagrad/Adam) scatter-update"; SPEC.md §4) -------- */
 int mee_apply_adagrad(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps,
                       void* stream);

@@ -97,6 +97,26 @@ private:
     mee_table* t_ = nullptr;
 };
 
+// Many tables (same device, same dim) served by ONE find launch over their concatenated ("jagged") key batches.
+class Group {
+public:
+    Group(Table* const* tables, uint32_t n) {
+        std::string h(n * sizeof(mee_table*), '\0');
+        auto** raw = reinterpret_cast<mee_table**>(&h[0]);
+        for (uint32_t j = 0; j < n; ++j) raw[j] = tables[j]->handle();
+        check(mee_group_create(raw, n, &g_));
+    }
+    ~Group() { if (g_) mee_group_destroy(g_); }
+    Group(const Group&) = delete;
+    Group& operator=(const Group&) = delete;
+    // segment j = d_keys[d_offsets[j] .. d_offsets[j+1]); d_offsets: n_tables + 1 values in DEVICE memory; n = total positions
+    void find(const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found, void* stream = nullptr) {
+        check(mee_find_grouped(g_, d_keys, d_offsets, n, d_out, d_found, stream));
+    }
+private:
+    mee_group* g_ = nullptr;
+};
+
 // Hot (HBM) table backed by a cold table whose rows live in pinned host DRAM: one logical table, sync-free lookup.
 class TieredTable {
 public:

@@ -6,7 +6,7 @@ the HIP extension or a gfx950 device is missing — there is no CPU fallback.
 """
 from ._lib import (EMPTY_KEY, INIT_CONSTANT, INIT_UNIFORM, OPT_ADAGRAD, OPT_ADAM, OPT_NONE, RECLAIMED_KEY,
                    STATUS_RESERVED_KEY, STATUS_TABLE_FULL, MeepoError)
-from .table import LookupTable, Router, hash_batch
+from .table import LookupTable, Router, TableGroup, hash_batch
 
-__all__ = ["LookupTable", "Router", "hash_batch", "MeepoError", "OPT_NONE", "OPT_ADAGRAD", "OPT_ADAM",
+__all__ = ["LookupTable", "Router", "TableGroup", "hash_batch", "MeepoError", "OPT_NONE", "OPT_ADAGRAD", "OPT_ADAM",
            "INIT_CONSTANT", "INIT_UNIFORM", "STATUS_TABLE_FULL", "STATUS_RESERVED_KEY", "EMPTY_KEY", "RECLAIMED_KEY"]

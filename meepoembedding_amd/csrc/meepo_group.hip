@@ -1,0 +1,221 @@
+// meepo_group.hip — one find launch over the batches of MANY tables (a model's embedding collection).
+//
+// A recommendation model looks up tens of tables per step, each with a small batch; a find launch has a latency floor
+// of ~7.6 us (dispatch + three dependent memory round trips, profiles/r01_find.md), so T separate launches cost T floors.
+// A group holds the tables' plane descriptors on the device; mee_find_grouped serves the concatenated key batch
+// (segment j = the keys of table j, segment bounds in a DEVICE offsets array, "jagged" layout) with ONE kernel whose
+// tiles first locate their segment (binary search over the offsets, staged in LDS) and then run the ordinary probe +
+// row gather against that table's planes.  Results are identical to calling mee_find per table (SPEC.md §3).
+//
+// Reference anchor: /root/reference/README.md:2 ("lookuptable-style … Embedding designed for recommendation systems").
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "meepo_device.h"
+#include "meepo_host.h"
+
+namespace mee {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GroupDesc {   // 32 bytes per table
+    const int64_t* tkeys;
+    const float4* values;
+    uint64_t nb;
+    float defv;
+    uint32_t pad;
+};
+
+constexpr uint32_t kMaxGroupTables = 1024;   // offsets staged in LDS: (1024 + 1) x 8 B
+
+// One tile per key, R keys in flight per tile (same shape as find_kernel).  DIM4 = dim/4 when it is 16 or 32, 0 = any.
+template <int DIM4, int R, bool STREAM_OUT>
+__global__ __launch_bounds__(256) void find_grouped_kernel(const GroupDesc* __restrict__ desc, uint32_t n_tables,
+                                                           const uint64_t* __restrict__ offsets, const int64_t* __restrict__ keys,
+                                                           uint64_t n, float4* __restrict__ out, uint8_t* __restrict__ found,
+                                                           uint32_t dim4_rt) {
+    __shared__ uint64_t loff[kMaxGroupTables + 1];
+    for (uint32_t j = threadIdx.x; j <= n_tables; j += blockDim.x) loff[j] = offsets[j];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
+    constexpr int C = DIM4 ? DIM4 / 16 : 1;
+    for (uint64_t base = wave * 4 * R; base < n; base += n_waves * 4 * R) {
+        int64_t key[R], slot[R], kb[R];
+        uint64_t b[R];
+        GroupDesc d[R];
+        bool inb[R], act[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t i = base + r * 4 + tile;
+            // segment of position i: the last j with loff[j] <= i (empty segments are skipped by the search itself)
+            uint32_t lo = 0, hi = n_tables;   // invariant: loff[lo] <= i < loff[hi] once i is inside [loff[0], loff[n_tables])
+            inb[r] = i < n && i >= loff[0] && i < loff[n_tables];
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (loff[mid] <= i) lo = mid; else hi = mid;
+            }
+            d[r] = desc[inb[r] ? lo : 0];   // 32 B, L1/L2 resident (staging the descriptors in LDS as well measured 3 % slower)
+            key[r] = inb[r] ? keys[i] : kEmpty;
+            act[r] = inb[r] && !reserved_key(key[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            b[r] = bucket_of(key[r], d[r].nb);
+            kb[r] = act[r] ? d[r].tkeys[b[r] * kW + tl] : kEmpty;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            slot[r] = -1;
+            bool pend = act[r];
+            uint64_t bb = b[r], steps = 0;
+            int64_t k = kb[r];
+            while (true) {
+                const uint32_t tm = tile_bits(__ballot(pend && k == key[r]), tile);
+                const uint32_t te = tile_bits(__ballot(pend && k == kEmpty), tile);
+                if (pend) {
+                    if (tm) { slot[r] = (int64_t)(bb * kW) + (__ffs(tm) - 1); pend = false; }
+                    else if (te || ++steps >= d[r].nb) pend = false;
+                    else bb = next_bucket(bb, step_of(key[r], d[r].nb), d[r].nb);
+                }
+                if (!__any(pend)) break;
+                k = pend ? d[r].tkeys[bb * kW + tl] : kEmpty;
+            }
+        }
+        if constexpr (DIM4 != 0) {
+            float4 row[R][C];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    row[r][c] = slot[r] >= 0 ? d[r].values[(uint64_t)slot[r] * DIM4 + c * 16 + tl]
+                                             : make_float4(d[r].defv, d[r].defv, d[r].defv, d[r].defv);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint64_t i = base + r * 4 + tile;
+                if (inb[r])
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        if constexpr (STREAM_OUT) {   // a dense output beyond the Infinity Cache: streaming stores (find_kernel's policy)
+                            const f32x4 v = {row[r][c].x, row[r][c].y, row[r][c].z, row[r][c].w};
+                            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out) + i * DIM4 + c * 16 + tl);
+                        } else {
+                            out[i * DIM4 + c * 16 + tl] = row[r][c];
+                        }
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint64_t i = base + r * 4 + tile;
+                if (inb[r])
+                    for (uint32_t c = tl; c < dim4; c += 16)
+                        out[i * dim4 + c] = slot[r] >= 0 ? d[r].values[(uint64_t)slot[r] * dim4 + c]
+                                                         : make_float4(d[r].defv, d[r].defv, d[r].defv, d[r].defv);
+            }
+        }
+        if (found) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint64_t i = base + r * 4 + tile;
+                if (inb[r] && tl == 0) found[i] = slot[r] >= 0;
+            }
+        }
+    }
+}
+
+}  // namespace mee
+
+using namespace mee;
+
+struct mee_group {
+    int device;
+    uint32_t n_tables, dim, dim4;
+    std::vector<mee_table*> tables;
+    std::vector<uint64_t> generations;   // of each table when its descriptor was last uploaded (mee_reserve moves planes)
+    GroupDesc* d_desc;
+};
+
+static int upload_descriptors(mee_group* g) {
+    std::vector<GroupDesc> h(g->n_tables);
+    for (uint32_t j = 0; j < g->n_tables; ++j) {
+        const TableView v = table_view(g->tables[j]);
+        h[j] = GroupDesc{v.keys, (const float4*)v.values, v.nb, v.default_value, 0};
+        g->generations[j] = v.generation;
+    }
+    MEE_HIP(hipMemcpy(g->d_desc, h.data(), h.size() * sizeof(GroupDesc), hipMemcpyHostToDevice));  // synchronous, rare
+    return MEE_OK;
+}
+
+extern "C" {
+
+int mee_group_create(mee_table* const* tables, uint32_t n_tables, mee_group** out) {
+    if (!tables || !out || n_tables == 0 || n_tables > kMaxGroupTables)
+        return fail(MEE_ERR_INVALID_ARG, "mee_group_create: need 1..%u tables", kMaxGroupTables);
+    *out = nullptr;
+    for (uint32_t j = 0; j < n_tables; ++j)
+        if (!tables[j]) return fail(MEE_ERR_INVALID_ARG, "mee_group_create: table %u is null", j);
+    const TableView v0 = table_view(tables[0]);
+    for (uint32_t j = 1; j < n_tables; ++j) {
+        const TableView v = table_view(tables[j]);
+        if (v.device != v0.device || v.dim != v0.dim)
+            return fail(MEE_ERR_INVALID_ARG, "mee_group_create: table %u differs from table 0 in device or dim (%d/%u vs %d/%u)", j, v.device, v.dim, v0.device, v0.dim);
+    }
+    mee_group* g = new (std::nothrow) mee_group();
+    if (!g) return fail(MEE_ERR_OUT_OF_MEMORY, "host allocation failed");
+    g->device = v0.device; g->n_tables = n_tables; g->dim = v0.dim; g->dim4 = v0.dim4; g->d_desc = nullptr;
+    g->tables.assign(tables, tables + n_tables);
+    g->generations.assign(n_tables, 0);
+    DeviceGuard guard(g->device);
+    hipError_t e = hipMalloc((void**)&g->d_desc, n_tables * sizeof(GroupDesc));
+    if (e != hipSuccess) { delete g; return fail(MEE_ERR_OUT_OF_MEMORY, "hipMalloc(group descriptors): %s", hipGetErrorString(e)); }
+    if (int rc = upload_descriptors(g)) { (void)hipFree(g->d_desc); delete g; return rc; }
+    *out = g;
+    return MEE_OK;
+}
+
+int mee_group_destroy(mee_group* g) {
+    if (!g) return MEE_OK;
+    DeviceGuard guard(g->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(g->d_desc);
+    delete g;
+    return MEE_OK;
+}
+
+int mee_find_grouped(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found,
+                     void* stream) {
+    if (!g || !d_offsets || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_grouped: null argument");
+    if (n == 0) return MEE_OK;
+    for (uint32_t j = 0; j < g->n_tables; ++j)
+        if (table_view(g->tables[j]).generation != g->generations[j]) {   // a table was rehashed: its planes moved
+            DeviceGuard guard(g->device);
+            MEE_HIP(hipStreamSynchronize((hipStream_t)stream));           // launches in flight may still read the old descriptors
+            if (int rc = upload_descriptors(g)) return rc;
+            break;
+        }
+    DeviceGuard guard(g->device);
+    hipStream_t st = (hipStream_t)stream;
+    const bool stream_out = (uint64_t)n * g->dim * 4 > (128ull << 20);   // find_kernel's store policy
+    // every block starts by staging the offsets in LDS (a global round trip + a barrier): blocks must live long enough to
+    // amortise it, so the grid is capped and strides (measured: 8192 blocks best from 200K to 1M positions)
+    const unsigned grid_cap = 8192;
+#define GROUPED(D4, RR, PER)                                                                                                          \
+    do {                                                                                                                              \
+        if (stream_out) find_grouped_kernel<D4, RR, true><<<grid_for(n, PER, grid_cap), 256, 0, st>>>(g->d_desc, g->n_tables, d_offsets, d_keys, n, (float4*)d_out, d_found, g->dim4); \
+        else find_grouped_kernel<D4, RR, false><<<grid_for(n, PER, grid_cap), 256, 0, st>>>(g->d_desc, g->n_tables, d_offsets, d_keys, n, (float4*)d_out, d_found, g->dim4);       \
+    } while (0)
+    if (g->dim4 == 16) GROUPED(16, 2, 32);
+    else if (g->dim4 == 32) GROUPED(32, 1, 16);
+    else GROUPED(0, 1, 16);
+#undef GROUPED
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+}  // extern "C"

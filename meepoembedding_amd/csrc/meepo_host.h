@@ -46,6 +46,7 @@ struct TableView {
     uint64_t nb;
     uint32_t dim, dim4;
     float default_value;
+    uint64_t generation;   // bumped whenever the planes move (mee_reserve)
 };
 TableView table_view(const mee_table* t);
 

@@ -79,6 +79,7 @@ struct mee_table {
     mee::Counters* h_ctr;       // pinned staging for read-backs
     mee::OpCounters* h_op;
     uint64_t table_bytes, workspace_bytes;
+    uint64_t generation;        // bumped whenever the planes move (mee_reserve): cached descriptors (mee_group) re-read them
     // a prepared (grouped + planned) apply waiting for its grads: mee_apply_prepare .. mee_apply_*
     uint64_t prepared_n;
     const int64_t* prepared_keys;
@@ -877,7 +878,7 @@ __global__ __launch_bounds__(256) void export_kernel(const int64_t* __restrict__
 static hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
 TableView table_view(const mee_table* t) {
-    return TableView{t->device, t->keys, t->values, t->nb, t->dim, t->dim4, t->default_value};
+    return TableView{t->device, t->keys, t->values, t->nb, t->dim, t->dim4, t->default_value, t->generation};
 }
 
 // SPEC.md §2: the bucket count is prime, so every double-hashing stride visits all buckets
@@ -1111,6 +1112,7 @@ int mee_reserve(mee_table* t, uint64_t new_capacity, void* stream) {
     t->nb = nnb; t->capacity = ncap;
     t->table_bytes = ncap * sizeof(int64_t) + (nhits ? ncap * sizeof(uint32_t) : 0) + plane * (1 + (n1 != nullptr) + (n2 != nullptr));
     t->prepared_n = 0;
+    ++t->generation;
     return MEE_OK;
 }
 

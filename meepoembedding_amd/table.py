@@ -325,6 +325,50 @@ class LookupTable:
         return uniq[:U], (gs[:U] if gs is not None else None), cnt[:U], inv
 
 
+class TableGroup:
+    """One find launch for the lookups of many tables (same device, same dim): mee_find_grouped.
+
+    keys = the tables' key batches concatenated, offsets = n_tables + 1 int64/uint64 bounds ON THE DEVICE (segment j =
+    keys[offsets[j]:offsets[j+1]]).  Returns (rows [n, dim], found [n]) — identical to find() per table."""
+
+    def __init__(self, tables):
+        self.tables = list(tables)
+        if not self.tables:
+            raise ValueError("a group needs at least one table")
+        self.device, self.dim = self.tables[0].device, self.tables[0].dim
+        arr = (C.c_void_p * len(self.tables))(*[t._h for t in self.tables])
+        h = C.c_void_p()
+        self._h = None
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mee_group_create(arr, len(self.tables), C.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _lib.lib().mee_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def find(self, keys: torch.Tensor, offsets: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None):
+        k = self.tables[0]._keys(keys) if keys.numel() else keys
+        n = k.numel()
+        if offsets.device != self.device or offsets.dtype not in (torch.int64, torch.uint64) or offsets.numel() != len(self.tables) + 1 \
+                or not offsets.is_contiguous():
+            raise MeepoError(_lib.ERR_INVALID_ARG, f"offsets must be {len(self.tables) + 1} contiguous int64 values on {self.device}")
+        if out is None:
+            out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        if found is None:
+            found = torch.empty(n, dtype=torch.uint8, device=self.device)
+        check(_lib.lib().mee_find_grouped(self._h, k.data_ptr(), offsets.data_ptr(), n, out.data_ptr(), found.data_ptr(),
+                                          _stream_ptr(self.device)))
+        return out, found
+
+
 def hash_batch(keys: torch.Tensor, n_buckets: int, n_shards: int):
     """SPEC.md §1 on device: (mix64, bucket, owner) as int64/int64/int32 tensors (bit patterns of the unsigned values)."""
     k = keys.contiguous().view(-1)

@@ -58,6 +58,23 @@ int main() try {
       table.reserve(cap * 2);                                        // in-place rehash: capacity doubles, content stays
       CHECK(table.info().capacity >= cap * 2 && table.size() == n - n / 2 && table.status() == 0); }
 
+    // ---- group: two tables, one launch ------------------------------------------------------------------------------
+    { meepo::Table other(o);
+      other.insert(d_keys.p, d_rows.p, n / 4);                       // holds only the first quarter of the keys
+      meepo::Table* members[2] = {&other, &table};
+      meepo::Group grp(members, 2);
+      std::vector<uint64_t> offs = {0, n / 2, n};                    // first half of the batch -> `other`, second half -> `table`
+      DevBuf<uint64_t> d_offs(3); d_offs.up(offs);
+      grp.find(d_keys.p, d_offs.p, n, d_out.p, d_found.p);
+      HIPCK(hipDeviceSynchronize());
+      auto f = d_found.down(n); auto out = d_out.down(n * dim);
+      // `other` holds keys [0, n/4); `table` lost keys [0, n/2) to the remove above and still holds [n/2, n)
+      for (size_t i = 0; i < n; ++i) {
+          const bool expect = i < n / 4 || i >= n / 2;
+          CHECK(f[i] == (expect ? 1 : 0));
+          if (expect) CHECK(memcmp(&out[i * dim], &rows[i * dim], dim * 4) == 0); else CHECK(out[i * dim] == -2.0f);
+      } }
+
     // ---- hot/cold pair: first half of the keys in HBM, second half in the pinned-host tier ------------------------
     meepo::TableOptions ho = o; ho.capacity = (uint64_t)(n / 2 / 0.75);
     meepo::TableOptions co = ho; co.value_memory = MEE_MEM_HOST_PINNED;

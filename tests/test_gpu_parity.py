@@ -554,3 +554,60 @@ def test_resized_rehash(dev):
     assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
     acc, _ = big.find_plane(1, T(keys, dev)); acc0, _ = t.find_plane(1, T(keys, dev))
     assert torch.equal(acc, acc0)
+
+
+@pytest.mark.parametrize("dim", [64, 128, 24])
+def test_grouped_find_equals_per_table_find(dev, dim):
+    """mee_find_grouped: one launch over the concatenated batches of many tables == find per table (and == the oracle),
+    with ragged and empty segments, reserved keys, absent keys, different capacities / default rows, and a member that is
+    rehashed between calls."""
+    from meepoembedding_amd import TableGroup
+    rng = np.random.default_rng(dim)
+    n_tables = 7
+    tables, oracles, universes = [], [], []
+    for j in range(n_tables):
+        cap = int(rng.integers(200, 6000))
+        t = LookupTable(cap, dim, device=dev, max_batch=4096, default_value=float(j))
+        o = oracle.OracleTable(cap, dim, default_value=float(j))
+        u = synth.keys_np(300 + j, 0, int(cap * 0.7))
+        rows = rng.standard_normal((u.size, dim)).astype(np.float32)
+        for s in range(0, u.size, 4096):
+            t.insert(T(u[s:s + 4096], dev), T(rows[s:s + 4096], dev))
+        o.insert(u, rows)
+        tables.append(t); oracles.append(o); universes.append(u)
+    grp = TableGroup(tables)
+    for trial in range(4):
+        lens = [int(rng.integers(0, 3000)) if rng.random() > 0.25 else 0 for _ in range(n_tables)]
+        if trial == 3:
+            lens = [0] * n_tables; lens[4] = 1     # a single key in the whole batch
+        segs = []
+        for j, m in enumerate(lens):
+            k = universes[j][rng.integers(0, universes[j].size, m)].copy()
+            if m > 4:
+                k[1] = oracle.EMPTY_KEY; k[2] = synth.keys_np(999, j, 1)[0]; k[3] = universes[(j + 1) % n_tables][0]  # another table's key
+            segs.append(k)
+        keys = np.concatenate(segs) if sum(lens) else np.zeros(0, np.int64)
+        offs = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64, device=dev)
+        out, found = grp.find(T(keys, dev), offs)
+        out, found = out.cpu().numpy(), found.cpu().numpy()
+        p = 0
+        for j, k in enumerate(segs):
+            eo, ef = oracles[j].find(k)
+            to, tf = tables[j].find(T(k, dev)) if k.size else (torch.zeros(0, dim), torch.zeros(0, dtype=torch.uint8))
+            assert np.array_equal(found[p:p + k.size], ef) and np.array_equal(out[p:p + k.size], eo)
+            assert np.array_equal(to.cpu().numpy(), eo) and np.array_equal(tf.cpu().numpy(), ef)
+            p += k.size
+        if trial == 1:
+            tables[2].reserve(tables[2].capacity * 3)   # planes move: the group must pick up the new descriptors
+    # offsets that do not start at 0 / end before n: positions outside are left untouched
+    keys = np.concatenate([universes[0][:10], universes[1][:10]])
+    sentinel = torch.full((20, dim), -7.0, device=dev)
+    fsent = torch.full((20,), 9, dtype=torch.uint8, device=dev)
+    offs = torch.tensor([3, 10] + [10] * (n_tables - 2) + [15], dtype=torch.int64, device=dev)   # table 0: [3,10), last table: [10,15)
+    grp.find(T(keys, dev), offs, out=sentinel, found=fsent)
+    assert bool((sentinel[:3] == -7).all()) and bool((sentinel[15:] == -7).all()) and bool((fsent[:3] == 9).all())
+    assert np.array_equal(sentinel[3:10].cpu().numpy(), oracles[0].find(keys[3:10])[0])
+    assert np.array_equal(sentinel[10:15].cpu().numpy(), oracles[n_tables - 1].find(keys[10:15])[0])
+    with pytest.raises(MeepoError):
+        TableGroup([tables[0], LookupTable(100, dim + 4, device=dev)])
+    grp.close()
