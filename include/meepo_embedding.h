@@ -150,10 +150,18 @@ int mee_clear_status(mee_table* t, void* stream);
  * instead of n_tables times.  Asynchronous on `stream`; after mee_reserve on a member the next call re-reads that
  * table's planes (one stream synchronisation).  The group does not own the tables: destroy it before them. */
 typedef struct mee_group mee_group;
-int mee_group_create(mee_table* const* tables, uint32_t n_tables, mee_group** out);
+int mee_group_create(mee_table* const* tables, uint32_t n_tables, uint64_t max_apply_batch, mee_group** out);
 int mee_group_destroy(mee_group* g);
 int mee_find_grouped(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found,
                      void* stream);
+/* One sparse-optimizer step over the same jagged layout (groups created with max_apply_batch >= n; all members have the
+ * same optimizer): identical to mee_apply_* on each table with its segment of keys and grads (absent keys ignored,
+ * duplicates of a key inside its segment summed in fp64 and applied once), in a fixed number of launches whatever the
+ * number of tables. */
+int mee_group_apply_adagrad(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr,
+                            float eps, void* stream);
+int mee_group_apply_adam(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr,
+                         float beta1, float beta2, float eps, uint64_t step, void* stream);
 
 /* ---- sparse optimizers (north_star "sparse-optimizer (Adagrad/Adam) scatter-update"; SPEC.md §4) -------- */
 int mee_apply_adagrad(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps,

@@ -100,11 +100,11 @@ private:
 // Many tables (same device, same dim) served by ONE find launch over their concatenated ("jagged") key batches.
 class Group {
 public:
-    Group(Table* const* tables, uint32_t n) {
+    Group(Table* const* tables, uint32_t n, uint64_t max_apply_batch = 0) {
         std::string h(n * sizeof(mee_table*), '\0');
         auto** raw = reinterpret_cast<mee_table**>(&h[0]);
         for (uint32_t j = 0; j < n; ++j) raw[j] = tables[j]->handle();
-        check(mee_group_create(raw, n, &g_));
+        check(mee_group_create(raw, n, max_apply_batch, &g_));
     }
     ~Group() { if (g_) mee_group_destroy(g_); }
     Group(const Group&) = delete;
@@ -112,6 +112,12 @@ public:
     // segment j = d_keys[d_offsets[j] .. d_offsets[j+1]); d_offsets: n_tables + 1 values in DEVICE memory; n = total positions
     void find(const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found, void* stream = nullptr) {
         check(mee_find_grouped(g_, d_keys, d_offsets, n, d_out, d_found, stream));
+    }
+    void apply_adagrad(const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr, float eps = 1e-10f, void* stream = nullptr) {
+        check(mee_group_apply_adagrad(g_, d_keys, d_offsets, d_grads, n, lr, eps, stream));
+    }
+    void apply_adam(const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr, uint64_t step, float beta1 = 0.9f, float beta2 = 0.999f, float eps = 1e-8f, void* stream = nullptr) {
+        check(mee_group_apply_adam(g_, d_keys, d_offsets, d_grads, n, lr, beta1, beta2, eps, step, stream));
     }
 private:
     mee_group* g_ = nullptr;

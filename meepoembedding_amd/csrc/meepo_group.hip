@@ -12,7 +12,6 @@
 
 #include <cstring>
 #include <new>
-#include <vector>
 
 #include "meepo_device.h"
 #include "meepo_host.h"
@@ -21,22 +20,15 @@ namespace mee {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct GroupDesc {   // 32 bytes per table
-    const int64_t* tkeys;
-    const float4* values;
-    uint64_t nb;
-    float defv;
-    uint32_t pad;
-};
-
-constexpr uint32_t kMaxGroupTables = 1024;   // offsets staged in LDS: (1024 + 1) x 8 B
 
 // One tile per key, R keys in flight per tile (same shape as find_kernel).  DIM4 = dim/4 when it is 16 or 32, 0 = any.
-template <int DIM4, int R, bool STREAM_OUT>
+// LOCATE: no rows move; gslot[i] = member << 48 | slot of the key (kEmpty when absent / reserved / outside the segments) —
+// the first pass of a grouped apply.
+template <int DIM4, int R, bool STREAM_OUT, bool LOCATE = false>
 __global__ __launch_bounds__(256) void find_grouped_kernel(const GroupDesc* __restrict__ desc, uint32_t n_tables,
                                                            const uint64_t* __restrict__ offsets, const int64_t* __restrict__ keys,
                                                            uint64_t n, float4* __restrict__ out, uint8_t* __restrict__ found,
-                                                           uint32_t dim4_rt) {
+                                                           uint32_t dim4_rt, int64_t* __restrict__ gslot = nullptr) {
     __shared__ uint64_t loff[kMaxGroupTables + 1];
     for (uint32_t j = threadIdx.x; j <= n_tables; j += blockDim.x) loff[j] = offsets[j];
     __syncthreads();
@@ -49,6 +41,7 @@ __global__ __launch_bounds__(256) void find_grouped_kernel(const GroupDesc* __re
         int64_t key[R], slot[R], kb[R];
         uint64_t b[R];
         GroupDesc d[R];
+        uint32_t member[R];
         bool inb[R], act[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -60,6 +53,7 @@ __global__ __launch_bounds__(256) void find_grouped_kernel(const GroupDesc* __re
                 const uint32_t mid = (lo + hi) >> 1;
                 if (loff[mid] <= i) lo = mid; else hi = mid;
             }
+            member[r] = lo;
             d[r] = desc[inb[r] ? lo : 0];   // 32 B, L1/L2 resident (staging the descriptors in LDS as well measured 3 % slower)
             key[r] = inb[r] ? keys[i] : kEmpty;
             act[r] = inb[r] && !reserved_key(key[r]);
@@ -86,6 +80,14 @@ __global__ __launch_bounds__(256) void find_grouped_kernel(const GroupDesc* __re
                 if (!__any(pend)) break;
                 k = pend ? d[r].tkeys[bb * kW + tl] : kEmpty;
             }
+        }
+        if constexpr (LOCATE) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint64_t i = base + r * 4 + tile;
+                if (i < n && tl == 0) gslot[i] = slot[r] >= 0 ? (int64_t)(((uint64_t)member[r] << kGroupSlotBits) | (uint64_t)slot[r]) : kEmpty;
+            }
+            continue;
         }
         if constexpr (DIM4 != 0) {
             float4 row[R][C];
@@ -133,28 +135,38 @@ __global__ __launch_bounds__(256) void find_grouped_kernel(const GroupDesc* __re
 
 using namespace mee;
 
-struct mee_group {
-    int device;
-    uint32_t n_tables, dim, dim4;
-    std::vector<mee_table*> tables;
-    std::vector<uint64_t> generations;   // of each table when its descriptor was last uploaded (mee_reserve moves planes)
-    GroupDesc* d_desc;
-};
 
 static int upload_descriptors(mee_group* g) {
     std::vector<GroupDesc> h(g->n_tables);
     for (uint32_t j = 0; j < g->n_tables; ++j) {
         const TableView v = table_view(g->tables[j]);
-        h[j] = GroupDesc{v.keys, (const float4*)v.values, v.nb, v.default_value, 0};
+        h[j] = GroupDesc{v.keys, (float4*)v.values, (float4*)v.s1, (float4*)v.s2, v.nb, v.default_value, 0};
         g->generations[j] = v.generation;
     }
     MEE_HIP(hipMemcpy(g->d_desc, h.data(), h.size() * sizeof(GroupDesc), hipMemcpyHostToDevice));  // synchronous, rare
     return MEE_OK;
 }
 
+namespace mee {
+int group_refresh(mee_group* g, void* stream) {
+    for (uint32_t j = 0; j < g->n_tables; ++j)
+        if (table_view(g->tables[j]).generation != g->generations[j]) {   // a table was rehashed: its planes moved
+            DeviceGuard guard(g->device);
+            MEE_HIP(hipStreamSynchronize((hipStream_t)stream));           // launches in flight may still read the old descriptors
+            return upload_descriptors(g);
+        }
+    return MEE_OK;
+}
+int group_locate(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, int64_t* d_gslot, hipStream_t st) {
+    find_grouped_kernel<0, 2, false, true><<<grid_for(n, 32, 8192), 256, 0, st>>>(g->d_desc, g->n_tables, d_offsets, d_keys, n, nullptr, nullptr, g->dim4, d_gslot);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+}  // namespace mee
+
 extern "C" {
 
-int mee_group_create(mee_table* const* tables, uint32_t n_tables, mee_group** out) {
+int mee_group_create(mee_table* const* tables, uint32_t n_tables, uint64_t max_apply_batch, mee_group** out) {
     if (!tables || !out || n_tables == 0 || n_tables > kMaxGroupTables)
         return fail(MEE_ERR_INVALID_ARG, "mee_group_create: need 1..%u tables", kMaxGroupTables);
     *out = nullptr;
@@ -165,16 +177,29 @@ int mee_group_create(mee_table* const* tables, uint32_t n_tables, mee_group** ou
         const TableView v = table_view(tables[j]);
         if (v.device != v0.device || v.dim != v0.dim)
             return fail(MEE_ERR_INVALID_ARG, "mee_group_create: table %u differs from table 0 in device or dim (%d/%u vs %d/%u)", j, v.device, v.dim, v0.device, v0.dim);
+        if (max_apply_batch && v.optimizer != v0.optimizer)
+            return fail(MEE_ERR_INVALID_ARG, "mee_group_create: a group with grouped apply needs one optimizer for all members (table %u: %u vs %u)", j, v.optimizer, v0.optimizer);
     }
+    if (max_apply_batch > (1ull << 30)) return fail(MEE_ERR_INVALID_ARG, "mee_group_create: max_apply_batch must be <= 2^30");
     mee_group* g = new (std::nothrow) mee_group();
     if (!g) return fail(MEE_ERR_OUT_OF_MEMORY, "host allocation failed");
     g->device = v0.device; g->n_tables = n_tables; g->dim = v0.dim; g->dim4 = v0.dim4; g->d_desc = nullptr;
+    g->optimizer = v0.optimizer; g->max_apply_batch = max_apply_batch; g->scratch = nullptr; g->d_gslot = nullptr;
     g->tables.assign(tables, tables + n_tables);
     g->generations.assign(n_tables, 0);
     DeviceGuard guard(g->device);
     hipError_t e = hipMalloc((void**)&g->d_desc, n_tables * sizeof(GroupDesc));
     if (e != hipSuccess) { delete g; return fail(MEE_ERR_OUT_OF_MEMORY, "hipMalloc(group descriptors): %s", hipGetErrorString(e)); }
     if (int rc = upload_descriptors(g)) { (void)hipFree(g->d_desc); delete g; return rc; }
+    if (max_apply_batch && g->optimizer != MEE_OPT_NONE) {
+        // the group's own group table, per-position arrays and counters: a 16-slot table that only lends its scratch
+        mee_config c{};
+        c.struct_size = sizeof c; c.device = g->device; c.capacity = 16; c.dim = g->dim; c.optimizer = g->optimizer; c.max_batch = max_apply_batch;
+        int rc = mee_table_create(&c, &g->scratch);
+        if (rc == MEE_OK && hipMalloc((void**)&g->d_gslot, max_apply_batch * sizeof(int64_t)) != hipSuccess)
+            rc = fail(MEE_ERR_OUT_OF_MEMORY, "hipMalloc(group slot list)");
+        if (rc != MEE_OK) { mee_group_destroy(g); return rc; }
+    }
     *out = g;
     return MEE_OK;
 }
@@ -184,6 +209,8 @@ int mee_group_destroy(mee_group* g) {
     DeviceGuard guard(g->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(g->d_desc);
+    (void)hipFree(g->d_gslot);
+    if (g->scratch) mee_table_destroy(g->scratch);
     delete g;
     return MEE_OK;
 }
@@ -192,13 +219,7 @@ int mee_find_grouped(mee_group* g, const int64_t* d_keys, const uint64_t* d_offs
                      void* stream) {
     if (!g || !d_offsets || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_grouped: null argument");
     if (n == 0) return MEE_OK;
-    for (uint32_t j = 0; j < g->n_tables; ++j)
-        if (table_view(g->tables[j]).generation != g->generations[j]) {   // a table was rehashed: its planes moved
-            DeviceGuard guard(g->device);
-            MEE_HIP(hipStreamSynchronize((hipStream_t)stream));           // launches in flight may still read the old descriptors
-            if (int rc = upload_descriptors(g)) return rc;
-            break;
-        }
+    if (int rc = group_refresh(g, stream)) return rc;
     DeviceGuard guard(g->device);
     hipStream_t st = (hipStream_t)stream;
     const bool stream_out = (uint64_t)n * g->dim * 4 > (128ull << 20);   // find_kernel's store policy

@@ -47,8 +47,23 @@ struct TableView {
     uint32_t dim, dim4;
     float default_value;
     uint64_t generation;   // bumped whenever the planes move (mee_reserve)
+    float *s1, *s2;        // optimizer planes (null without)
+    uint32_t optimizer;
 };
 TableView table_view(const mee_table* t);
+
+// ---- table groups (meepo_group.hip: grouped find / locate; meepo_table.hip: grouped apply) ---------------------------------
+struct GroupDesc {   // 48 bytes per member table, device resident
+    const int64_t* tkeys;
+    float4* values;
+    float4* s1;
+    float4* s2;
+    uint64_t nb;
+    float defv;
+    uint32_t pad;
+};
+constexpr int kGroupSlotBits = 48;   // grouped apply names a row by (member << 48 | slot): unique per (table, key), never a reserved key
+constexpr uint32_t kMaxGroupTables = 1024;   // offsets staged in LDS: (1024 + 1) x 8 B
 
 inline unsigned grid_for(size_t work_items, unsigned per_block, unsigned cap) {
     size_t g = (work_items + per_block - 1) / per_block;
@@ -58,3 +73,21 @@ inline unsigned grid_for(size_t work_items, unsigned per_block, unsigned cap) {
 }
 
 }  // namespace mee
+
+#include <vector>
+struct mee_group {
+    int device;
+    uint32_t n_tables, dim, dim4, optimizer;
+    std::vector<mee_table*> tables;
+    std::vector<uint64_t> generations;   // of each table when its descriptor was last uploaded (mee_reserve moves planes)
+    mee::GroupDesc* d_desc;
+    // grouped apply (max_apply_batch > 0): a scratch-only table whose group table / per-position arrays serve the whole
+    // jagged batch, and the located rows of the batch
+    uint64_t max_apply_batch;
+    mee_table* scratch;
+    int64_t* d_gslot;
+};
+namespace mee {
+int group_refresh(mee_group* g, void* stream);   // re-upload descriptors of members whose planes moved
+int group_locate(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, int64_t* d_gslot, hipStream_t st);
+}

@@ -500,18 +500,35 @@ __device__ __forceinline__ void update_row(const OptArgs& a, float4* values, flo
     values[o] = w; s1[o] = x1;
     if (a.kind == MEE_OPT_ADAM) s2[o] = x2;
 }
+// Where the row of an apply position lives.  Plain tables: probe for the key.  GROUPED (mee_group_apply_*): the batch
+// "keys" are located rows already, member << 48 | slot (meepo_group.hip), and the planes come from the member's descriptor.
+struct RowPlanes { float4 *values, *s1, *s2; };
+template <bool GROUPED>
+__device__ __forceinline__ int64_t resolve_row(const int64_t* tkeys, uint64_t nb, const GroupDesc* __restrict__ desc, int64_t key,
+                                               bool active, int tile, int tl, RowPlanes& p) {
+    if constexpr (GROUPED) {
+        if (!active || key < 0) return -1;
+        const GroupDesc d = desc[(uint64_t)key >> kGroupSlotBits];
+        p.values = d.values; p.s1 = d.s1; p.s2 = d.s2;
+        return key & ((1ll << kGroupSlotBits) - 1);
+    } else {
+        bool is_new, full;
+        return tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, active, tile, tl, is_new, full);
+    }
+}
+
 __device__ __forceinline__ void group_release(const GroupTable& g, uint32_t h) { g.skeys[h] = 0; g.sval[h] = 0; g.sval0[h] = 0; }
 
 // Pass 1 over batch positions: a key that occurs once is updated right here from its own grad row (the common
 // case) and its group-table entry is returned to empty; occurrences of multi-keys are filed into their group's
 // occurrence list for pass 2.  R positions in flight per tile; the grad rows are requested before the probe so that
 // they travel beside the bucket lines.  DIM4 = dim/4 when it is 16 or 32 (rows held in registers), 0 = any dim.
-template <int KIND, int DIM4, int R>
+template <int KIND, int DIM4, int R, bool GROUPED = false>
 __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1,
                                                            float4* s2, uint64_t nb, uint32_t dim4_rt,
                                                            const int64_t* __restrict__ keys,
                                                            const float4* __restrict__ grads, uint32_t n, GroupTable g,
-                                                           BatchScratch bs, OptArgs a) {
+                                                           BatchScratch bs, OptArgs a, const GroupDesc* __restrict__ desc = nullptr) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
@@ -522,6 +539,7 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
         int64_t key[R], slot[R];
         uint32_t cnt[R];
         float4 gr[R][C];
+        RowPlanes pl[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t i = base + r * 4 + tile;
@@ -541,8 +559,8 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            bool is_new, full;
-            slot[r] = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key[r], cnt[r] == 1, tile, tl, is_new, full);
+            pl[r] = RowPlanes{values, s1, s2};
+            slot[r] = resolve_row<GROUPED>(tkeys, nb, desc, key[r], cnt[r] == 1, tile, tl, pl[r]);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -551,9 +569,9 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
                 if (slot[r] >= 0) {
                     if constexpr (DIM4 != 0) {
 #pragma unroll
-                        for (int c = 0; c < C; ++c) update_row(a, values, s1, s2, (uint64_t)slot[r] * DIM4 + c * 16 + tl, gr[r][c]);
+                        for (int c = 0; c < C; ++c) update_row(a, pl[r].values, pl[r].s1, pl[r].s2, (uint64_t)slot[r] * DIM4 + c * 16 + tl, gr[r][c]);
                     } else {
-                        for (uint32_t c = tl; c < dim4; c += 16) update_row(a, values, s1, s2, (uint64_t)slot[r] * dim4 + c, grads[(uint64_t)i * dim4 + c]);
+                        for (uint32_t c = tl; c < dim4; c += 16) update_row(a, pl[r].values, pl[r].s1, pl[r].s2, (uint64_t)slot[r] * dim4 + c, grads[(uint64_t)i * dim4 + c]);
                     }
                 }
                 if (tl == 0) group_release(g, bs.hidx[i]);  // this tile is the only user of the entry
@@ -590,11 +608,12 @@ __device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, cons
 // A tile sums its chunk of the group's occurrence list in fp64.  Groups of <= kChunk occurrences are finished here
 // (one update, entry released); a chunk of a larger group stores its fp64 sums as one row of the group's partial-sum
 // block (plain stores: f64 atomics on a hot key's row serialise on four L2 lines) and apply_big_kernel finishes it.
+template <bool GROUPED = false>
 __global__ __launch_bounds__(256) void apply_chunk_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1,
                                                           float4* s2, uint64_t nb, uint32_t dim4,
                                                           const int64_t* __restrict__ keys,
                                                           const float4* __restrict__ grads, GroupTable g, BatchScratch bs,
-                                                          const OpCounters* op, OptArgs a) {
+                                                          const OpCounters* op, OptArgs a, const GroupDesc* __restrict__ desc = nullptr) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
@@ -607,8 +626,8 @@ __global__ __launch_bounds__(256) void apply_chunk_kernel(const int64_t* __restr
         const uint32_t r = inb ? bs.rank[i] : 0;
         const bool small = inb && cnt <= kChunk;  // then r == 0
         const int64_t key = small ? keys[i] : kEmpty;
-        bool is_new, full;
-        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, small, tile, tl, is_new, full);
+        RowPlanes pl{values, s1, s2};
+        const int64_t slot = resolve_row<GROUPED>(tkeys, nb, desc, key, small, tile, tl, pl);
         if (!inb) continue;
         const uint32_t h = bs.hidx[i];
         const uint32_t first = g.soffs[h] + r;
@@ -618,7 +637,7 @@ __global__ __launch_bounds__(256) void apply_chunk_kernel(const int64_t* __restr
             double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
             chunk_sum(grads, bs.occ, first, count, dim4, c, sx, sy, sz, sw);
             if (small) {
-                if (slot >= 0) update_row(a, values, s1, s2, (uint64_t)slot * dim4 + c, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
+                if (slot >= 0) update_row(a, pl.values, pl.s1, pl.s2, (uint64_t)slot * dim4 + c, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
             } else {
                 double* dst = bs.gacc + ((uint64_t)part * dim4 + c) * 4;
                 dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = sw;
@@ -631,9 +650,10 @@ __global__ __launch_bounds__(256) void apply_chunk_kernel(const int64_t* __restr
 // Pass 3, one 256-thread block per group with more than kChunk occurrences: the 16 tiles sum the group's partial-sum
 // rows (tile t takes rows t, t+16, ...; 4 rows in flight), the tile totals are combined through LDS in fixed order
 // (so the result does not depend on scheduling), then one rounding, one update, and the entry is released.
+template <bool GROUPED = false>
 __global__ __launch_bounds__(256) void apply_big_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1,
                                                         float4* s2, uint64_t nb, uint32_t dim4, GroupTable g, BatchScratch bs,
-                                                        const OpCounters* op, OptArgs a) {
+                                                        const OpCounters* op, OptArgs a, const GroupDesc* __restrict__ desc = nullptr) {
     __shared__ double lsum[16][16][4];
     __shared__ long long lslot;
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
@@ -644,8 +664,8 @@ __global__ __launch_bounds__(256) void apply_big_kernel(const int64_t* __restric
         const uint32_t cnt = g.sval0[h] + g.sval[h];
         const uint32_t n_rows = (cnt + kChunk - 1) / kChunk, row0 = g.sbig[h];
         const int64_t key = (int64_t)(g.skeys[h] ^ kBias);
-        bool is_new, full;
-        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, threadIdx.x < 16, tile, tl, is_new, full);
+        RowPlanes pl{values, s1, s2};   // GROUPED: every thread decodes the same (member, slot); else tile 0 probes
+        const int64_t slot = resolve_row<GROUPED>(tkeys, nb, desc, key, GROUPED || threadIdx.x < 16, tile, tl, pl);
         if (threadIdx.x == 0) lslot = slot;
         for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {  // block-uniform trip count: there are barriers inside
             const uint32_t c = c0 + tl;
@@ -669,7 +689,7 @@ __global__ __launch_bounds__(256) void apply_big_kernel(const int64_t* __restric
                 double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { t0 += lsum[q][tl][0]; t1 += lsum[q][tl][1]; t2 += lsum[q][tl][2]; t3 += lsum[q][tl][3]; }
-                if (live && lslot >= 0) update_row(a, values, s1, s2, (uint64_t)lslot * dim4 + c, make_float4((float)t0, (float)t1, (float)t2, (float)t3));
+                if (live && lslot >= 0) update_row(a, pl.values, pl.s1, pl.s2, (uint64_t)lslot * dim4 + c, make_float4((float)t0, (float)t1, (float)t2, (float)t3));
             }
             __syncthreads();
         }
@@ -878,7 +898,7 @@ __global__ __launch_bounds__(256) void export_kernel(const int64_t* __restrict__
 static hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
 TableView table_view(const mee_table* t) {
-    return TableView{t->device, t->keys, t->values, t->nb, t->dim, t->dim4, t->default_value, t->generation};
+    return TableView{t->device, t->keys, t->values, t->nb, t->dim, t->dim4, t->default_value, t->generation, t->s1, t->s2, t->optimizer};
 }
 
 // SPEC.md §2: the bucket count is prime, so every double-hashing stride visits all buckets
@@ -1368,12 +1388,60 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
 #undef SINGLE
     }
     // the work list (chunk leaders) and the big-group list have device-side lengths: fixed grids that loop
-    apply_chunk_kernel<<<grid_for(n, 16, 2048), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
+    apply_chunk_kernel<false><<<grid_for(n, 16, 2048), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
                                                             d_keys, (const float4*)d_grads, t->g, t->bs, t->op, a);
-    apply_big_kernel<<<grid_for(n / kChunk + 1, 1, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,
+    apply_big_kernel<false><<<grid_for(n / kChunk + 1, 1, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,
                                                                        t->dim4, t->g, t->bs, t->op, a);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
+}
+
+// ---- grouped apply: ONE sparse-optimizer step over the jagged batch of a whole group (meepo_group.hip holds the group) ----
+// locate (member << 48 | slot per position) -> the ordinary group / plan passes with the located rows as "keys" (two
+// occurrences of a key of one table are the same row; keys of different tables never collide) -> the three apply passes
+// with the probe replaced by decoding the located row.  The group's scratch table lends the group table / lists / counters.
+static int group_apply_common(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n,
+                              const OptArgs& a, void* stream, const char* name) {
+    if (!g || !d_offsets || (n && (!d_keys || !d_grads))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
+    if (!g->scratch) return fail(MEE_ERR_UNSUPPORTED, "%s: group was created with max_apply_batch = 0 or its tables have no optimizer", name);
+    if (g->optimizer != a.kind) return fail(MEE_ERR_UNSUPPORTED, "%s: the group's tables were created with optimizer=%u", name, g->optimizer);
+    if (n > g->max_apply_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "%s: n=%zu exceeds the group's max_apply_batch=%llu", name, n, (unsigned long long)g->max_apply_batch);
+    if (n == 0) return MEE_OK;
+    if (int rc = group_refresh(g, stream)) return rc;
+    DeviceGuard guard(g->device);
+    hipStream_t st = as_stream(stream);
+    mee_table* t = g->scratch;
+    const uint32_t nn = (uint32_t)n;
+    if (int rc = group_locate(g, d_keys, d_offsets, n, g->d_gslot, st)) return rc;
+    if (int rc = apply_prepare_launch(t, g->d_gslot, nn, st)) return rc;
+    const unsigned gs = grid_for(n, 32, 1u << 16);
+#define GSINGLE(K, D4) apply_single_kernel<K, D4, 2, true><<<gs, 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, g->d_gslot, (const float4*)d_grads, nn, t->g, t->bs, a, g->d_desc)
+#define GSINGLE_D(K) do { if (g->dim4 == 16) GSINGLE(K, 16); else if (g->dim4 == 32) GSINGLE(K, 32); else GSINGLE(K, 0); } while (0)
+    if (a.kind == MEE_OPT_ADAGRAD) GSINGLE_D(MEE_OPT_ADAGRAD); else GSINGLE_D(MEE_OPT_ADAM);
+#undef GSINGLE_D
+#undef GSINGLE
+    apply_chunk_kernel<true><<<grid_for(n, 16, 2048), 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, g->d_gslot, (const float4*)d_grads,
+                                                                  t->g, t->bs, t->op, a, g->d_desc);
+    apply_big_kernel<true><<<grid_for(n / kChunk + 1, 1, 1024), 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, t->g, t->bs, t->op, a, g->d_desc);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+int mee_group_apply_adagrad(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr,
+                            float eps, void* stream) {
+    OptArgs a{};
+    a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps;
+    return group_apply_common(g, d_keys, d_offsets, d_grads, n, a, stream, "mee_group_apply_adagrad");
+}
+int mee_group_apply_adam(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr,
+                         float beta1, float beta2, float eps, uint64_t step, void* stream) {
+    if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adam: step must be >= 1");
+    OptArgs a{};
+    a.kind = MEE_OPT_ADAM; a.eps = eps;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.step_size = (float)((double)lr * sqrt(bc2) / bc1);  // SPEC.md §4
+    a.omb1 = 1.0f - beta1; a.omb2 = 1.0f - beta2;
+    return group_apply_common(g, d_keys, d_offsets, d_grads, n, a, stream, "mee_group_apply_adam");
 }
 
 int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* stream) {

@@ -331,7 +331,7 @@ class TableGroup:
     keys = the tables' key batches concatenated, offsets = n_tables + 1 int64/uint64 bounds ON THE DEVICE (segment j =
     keys[offsets[j]:offsets[j+1]]).  Returns (rows [n, dim], found [n]) — identical to find() per table."""
 
-    def __init__(self, tables):
+    def __init__(self, tables, max_apply_batch: int = 0):
         self.tables = list(tables)
         if not self.tables:
             raise ValueError("a group needs at least one table")
@@ -340,7 +340,7 @@ class TableGroup:
         h = C.c_void_p()
         self._h = None
         with torch.cuda.device(self.device):
-            check(_lib.lib().mee_group_create(arr, len(self.tables), C.byref(h)))
+            check(_lib.lib().mee_group_create(arr, len(self.tables), int(max_apply_batch), C.byref(h)))
         self._h = h
 
     def close(self) -> None:
@@ -354,12 +354,31 @@ class TableGroup:
         except Exception:
             pass
 
-    def find(self, keys: torch.Tensor, offsets: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None):
-        k = self.tables[0]._keys(keys) if keys.numel() else keys
-        n = k.numel()
+    def _check_offsets(self, offsets: torch.Tensor) -> None:
         if offsets.device != self.device or offsets.dtype not in (torch.int64, torch.uint64) or offsets.numel() != len(self.tables) + 1 \
                 or not offsets.is_contiguous():
             raise MeepoError(_lib.ERR_INVALID_ARG, f"offsets must be {len(self.tables) + 1} contiguous int64 values on {self.device}")
+
+    def apply_adagrad(self, keys: torch.Tensor, offsets: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10) -> None:
+        """One sparse-Adagrad step over the jagged batch == apply_adagrad per table (max_apply_batch >= keys.numel())."""
+        self._check_offsets(offsets)
+        k = self.tables[0]._keys(keys) if keys.numel() else keys
+        g = self.tables[0]._rows(grads, k.numel())
+        check(_lib.lib().mee_group_apply_adagrad(self._h, k.data_ptr(), offsets.data_ptr(), g.data_ptr(), k.numel(), lr, eps,
+                                                 _stream_ptr(self.device)))
+
+    def apply_adam(self, keys: torch.Tensor, offsets: torch.Tensor, grads: torch.Tensor, lr: float, beta1: float = 0.9,
+                   beta2: float = 0.999, eps: float = 1e-8, step: int = 1) -> None:
+        self._check_offsets(offsets)
+        k = self.tables[0]._keys(keys) if keys.numel() else keys
+        g = self.tables[0]._rows(grads, k.numel())
+        check(_lib.lib().mee_group_apply_adam(self._h, k.data_ptr(), offsets.data_ptr(), g.data_ptr(), k.numel(), lr, beta1, beta2,
+                                              eps, step, _stream_ptr(self.device)))
+
+    def find(self, keys: torch.Tensor, offsets: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None):
+        k = self.tables[0]._keys(keys) if keys.numel() else keys
+        n = k.numel()
+        self._check_offsets(offsets)
         if out is None:
             out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
         if found is None:

@@ -611,3 +611,72 @@ def test_grouped_find_equals_per_table_find(dev, dim):
     with pytest.raises(MeepoError):
         TableGroup([tables[0], LookupTable(100, dim + 4, device=dev)])
     grp.close()
+
+
+@pytest.mark.parametrize("opt,dim", [("adagrad", 64), ("adam", 128), ("adagrad", 24)])
+def test_grouped_apply_equals_per_table_apply(dev, opt, dim):
+    """mee_group_apply_*: one optimizer step over the jagged batch of a group == apply per table == the oracle, with
+    duplicate-heavy segments (hot keys beyond the chunk and big-group thresholds), absent and reserved keys, the SAME key
+    value stored in several tables, and empty segments."""
+    from meepoembedding_amd import TableGroup
+    rng = np.random.default_rng(7 + dim)
+    kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
+    n_tables = 5
+    shared = synth.keys_np(555, 0, 300)          # keys present in every table (different rows per table)
+    grouped, solo, oracles, universes = [], [], [], []
+    for j in range(n_tables):
+        cap = int(rng.integers(1500, 5000))
+        u = np.concatenate([shared, synth.keys_np(600 + j, 0, int(cap * 0.5))])
+        rows = rng.standard_normal((u.size, dim)).astype(np.float32)
+        kw = dict(initial_accumulator=0.1)
+        a = LookupTable(cap, dim, device=dev, optimizer=kind, max_batch=8192, **kw)
+        b = LookupTable(cap, dim, device=dev, optimizer=kind, max_batch=8192, **kw)
+        o = oracle.OracleTable(cap, dim, optimizer=okind, **kw)
+        a.insert(T(u, dev), T(rows, dev)); b.insert(T(u, dev), T(rows, dev)); o.insert(u, rows)
+        grouped.append(a); solo.append(b); oracles.append(o); universes.append(u)
+    grp = TableGroup(grouped, max_apply_batch=1 << 15)
+    for step in range(1, 4):
+        segs = []
+        for j in range(n_tables):
+            m = 0 if (j + step) % 4 == 0 else int(rng.integers(1, 4000))
+            u = universes[j]
+            idx = np.minimum(rng.zipf(1.15, size=m) - 1, u.size - 1) if m else np.zeros(0, np.int64)
+            k = u[idx].copy()
+            if m > 200:
+                k[:100] = u[5]                                # one key 100+ times: beyond kChunk -> partial rows + tree
+                k[100:103] = [oracle.EMPTY_KEY, oracle.RECLAIMED_KEY, synth.keys_np(998, j, 1)[0]]   # padding, reserved, absent
+            segs.append(k)
+        keys = np.concatenate(segs)
+        grads = (rng.standard_normal((keys.size, dim)) * 0.05).astype(np.float32)
+        offs = torch.tensor(np.concatenate([[0], np.cumsum([s.size for s in segs])]), dtype=torch.int64, device=dev)
+        if opt == "adagrad":
+            grp.apply_adagrad(T(keys, dev), offs, T(grads, dev), lr=0.05, eps=1e-10)
+        else:
+            grp.apply_adam(T(keys, dev), offs, T(grads, dev), lr=0.01, step=step)
+        p = 0
+        for j, k in enumerate(segs):
+            gseg = grads[p:p + k.size]; p += k.size
+            if not k.size:
+                continue
+            if opt == "adagrad":
+                solo[j].apply_adagrad(T(k, dev), T(gseg, dev), lr=0.05, eps=1e-10); oracles[j].apply_adagrad(k, gseg, 0.05, 1e-10)
+            else:
+                solo[j].apply_adam(T(k, dev), T(gseg, dev), lr=0.01, step=step); oracles[j].apply_adam(k, gseg, 0.01, 0.9, 0.999, 1e-8, step)
+    for j in range(n_tables):
+        ga = [x.cpu().numpy() for x in grouped[j].export(with_state=True) if x is not None]
+        sa = [x.cpu().numpy() for x in solo[j].export(with_state=True) if x is not None]
+        oa = [x for x in oracles[j].export(with_state=True) if x is not None]
+        ia, ib, ic = np.argsort(ga[0]), np.argsort(sa[0]), np.argsort(oa[0])
+        assert np.array_equal(ga[0][ia], sa[0][ib]) and np.array_equal(ga[0][ia], oa[0][ic])
+        for x, y, z in zip(ga[1:], sa[1:], oa[1:]):
+            np.testing.assert_allclose(x[ia], y[ib], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(x[ia], z[ic], rtol=RTOL, atol=ATOL)
+        assert grouped[j].status() == 0
+    # errors: a group without apply scratch, a batch beyond max_apply_batch, mixed optimizers
+    with pytest.raises(MeepoError):
+        TableGroup(grouped).apply_adagrad(T(keys, dev), offs, T(grads, dev), lr=0.1)
+    with pytest.raises(MeepoError):
+        TableGroup(grouped, max_apply_batch=16).apply_adagrad(T(keys, dev), offs, T(grads, dev), lr=0.1)
+    with pytest.raises(MeepoError):
+        TableGroup([grouped[0], LookupTable(100, dim, device=dev)], max_apply_batch=64)
+    grp.close()
