@@ -157,7 +157,7 @@ int mee_find_grouped(mee_group* g, const int64_t* d_keys, const uint64_t* d_offs
 /* One sparse-optimizer step over the same jagged layout (groups created with max_apply_batch >= n; all members have the
  * same optimizer): identical to mee_apply_* on each table with its segment of keys and grads (absent keys ignored,
  * duplicates of a key inside its segment summed in fp64 and applied once), in a fixed number of launches whatever the
- * number of tables. */
+ * number of tables.  Reserved keys in the batch are skipped silently (no status bit on the members). */
 int mee_group_apply_adagrad(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr,
                             float eps, void* stream);
 int mee_group_apply_adam(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr,
@@ -199,8 +199,8 @@ int mee_gather_rows(const void* d_rows, const int64_t* d_perm, size_t n, size_t 
                     void* stream);
 
 /* ---- sharded find over peer-mapped memory (README.md:2 "distributed"; SPEC.md §5) ---------------------------------
- * One context per rank; all ranks use the same n_shards / slots_per_peer / max_batch / dim.  The five local buffers
- * (key inbox, destination inbox, fill counts, result rows, found bytes) are exported as HIP IPC handles, the caller
+ * One context per rank; all ranks use the same n_shards / slots_per_peer / max_batch / dim.  The local buffers
+ * (key inbox, destination inbox, fill counts, result rows, found bytes, and the payload-row inbox if any) are exported as HIP IPC handles, the caller
  * exchanges them (any side channel) and connects.  Per lookup, after mee_partition:
  *   mee_p2p_push  stores this rank's keys + batch positions into their owners' inboxes            (xGMI stores)
  *   -- barrier across ranks on the stream --
