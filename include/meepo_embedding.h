@@ -154,10 +154,14 @@ int mee_group_create(mee_table* const* tables, uint32_t n_tables, uint64_t max_a
 int mee_group_destroy(mee_group* g);
 int mee_find_grouped(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found,
                      void* stream);
+/* mee_find_or_insert over the jagged layout (three launches): absent keys are created in their member table with that
+ * table's initial row / optimizer state first; d_found (nullable when n <= max_apply_batch) = present before the call. */
+int mee_group_find_or_insert(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found,
+                             void* stream);
 /* One sparse-optimizer step over the same jagged layout (groups created with max_apply_batch >= n; all members have the
  * same optimizer): identical to mee_apply_* on each table with its segment of keys and grads (absent keys ignored,
  * duplicates of a key inside its segment summed in fp64 and applied once), in a fixed number of launches whatever the
- * number of tables.  Reserved keys in the batch are skipped silently (no status bit on the members). */
+ * number of tables.  Status bits (RESERVED_KEY for a tombstone value in a segment) land on the member of that segment. */
 int mee_group_apply_adagrad(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr,
                             float eps, void* stream);
 int mee_group_apply_adam(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr,

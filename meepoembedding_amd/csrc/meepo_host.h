@@ -49,6 +49,12 @@ struct TableView {
     uint64_t generation;   // bumped whenever the planes move (mee_reserve)
     float *s1, *s2;        // optimizer planes (null without)
     uint32_t optimizer;
+    // what creating a key needs (find_or_insert): initial row, initial state, the sticky status word, the hit counters
+    uint32_t initializer;
+    float init_scale, init_acc;
+    uint64_t init_seed;
+    uint32_t* status;
+    uint32_t* hits;
 };
 TableView table_view(const mee_table* t);
 
@@ -61,6 +67,13 @@ struct GroupDesc {   // 48 bytes per member table, device resident
     uint64_t nb;
     float defv;
     uint32_t pad;
+};
+struct GroupInit {   // per member, device resident: what creating a key in that table needs (grouped find_or_insert)
+    uint64_t init_seed;
+    uint32_t* status;
+    uint32_t* hits;
+    uint32_t initializer, optimizer;
+    float init_scale, init_acc;
 };
 constexpr int kGroupSlotBits = 48;   // grouped apply names a row by (member << 48 | slot): unique per (table, key), never a reserved key
 constexpr uint32_t kMaxGroupTables = 1024;   // offsets staged in LDS: (1024 + 1) x 8 B
@@ -81,6 +94,8 @@ struct mee_group {
     std::vector<mee_table*> tables;
     std::vector<uint64_t> generations;   // of each table when its descriptor was last uploaded (mee_reserve moves planes)
     mee::GroupDesc* d_desc;
+    mee::GroupInit* d_init;
+    uint8_t* d_fmask;      // [max_apply_batch] found mask of grouped find_or_insert when the caller passes none
     // grouped apply (max_apply_batch > 0): a scratch-only table whose group table / per-position arrays serve the whole
     // jagged batch, and the located rows of the batch
     uint64_t max_apply_batch;

@@ -898,7 +898,8 @@ __global__ __launch_bounds__(256) void export_kernel(const int64_t* __restrict__
 static hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
 TableView table_view(const mee_table* t) {
-    return TableView{t->device, t->keys, t->values, t->nb, t->dim, t->dim4, t->default_value, t->generation, t->s1, t->s2, t->optimizer};
+    return TableView{t->device, t->keys, t->values, t->nb, t->dim, t->dim4, t->default_value, t->generation, t->s1, t->s2, t->optimizer,
+                     t->initializer, t->init_scale, t->init_acc, t->init_seed, &t->ctr->status, t->hits};
 }
 
 // SPEC.md §2: the bucket count is prime, so every double-hashing stride visits all buckets

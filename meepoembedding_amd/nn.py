@@ -75,6 +75,77 @@ def _backward(ctx, grad_out):
 lookup.register_autograd(_backward, setup_context=_setup)
 
 
+# ---- the same pair of ops over a TableGroup: the whole embedding collection of a model in one lookup / one update -------
+@torch.library.custom_op("meepo::lookup_jagged", mutates_args=())
+def lookup_jagged(keys: torch.Tensor, offsets: torch.Tensor, anchor: torch.Tensor, table_id: int, insert_missing: bool) -> torch.Tensor:
+    layer = _layer(table_id)
+    rows, _ = layer.group.find_or_insert(keys, offsets) if insert_missing else layer.group.find(keys, offsets)
+    return rows
+
+
+@lookup_jagged.register_fake
+def _(keys, offsets, anchor, table_id, insert_missing):
+    return keys.new_empty((keys.numel(), _layer(table_id).group.dim), dtype=torch.float32)
+
+
+@torch.library.custom_op("meepo::apply_grad_jagged", mutates_args=())
+def apply_grad_jagged(keys: torch.Tensor, offsets: torch.Tensor, grad_rows: torch.Tensor, table_id: int) -> None:
+    layer = _layer(table_id)
+    layer.step += 1
+    if layer.optimizer == "adagrad":
+        layer.group.apply_adagrad(keys, offsets, grad_rows.contiguous(), lr=layer.lr, eps=layer.eps)
+    else:
+        layer.group.apply_adam(keys, offsets, grad_rows.contiguous(), lr=layer.lr, beta1=layer.betas[0], beta2=layer.betas[1],
+                               eps=layer.eps, step=layer.step)
+
+
+@apply_grad_jagged.register_fake
+def _(keys, offsets, grad_rows, table_id):
+    return None
+
+
+def _setup_jagged(ctx, inputs, output):
+    keys, offsets, _, table_id, _ = inputs
+    ctx.save_for_backward(keys, offsets)
+    ctx.table_id = table_id
+
+
+def _backward_jagged(ctx, grad_out):
+    keys, offsets = ctx.saved_tensors
+    apply_grad_jagged(keys, offsets, grad_out.contiguous(), ctx.table_id)
+    return None, None, None, None, None
+
+
+lookup_jagged.register_autograd(_backward_jagged, setup_context=_setup_jagged)
+
+
+class _SparseOptimizerSettings:
+    def _init_settings(self, optimizer, lr, eps, betas):
+        if optimizer not in ("adagrad", "adam"):
+            raise ValueError("optimizer must be 'adagrad' or 'adam'")
+        self.optimizer, self.lr, self.betas = optimizer, lr, betas
+        self.eps = eps if eps is not None else (1e-10 if optimizer == "adagrad" else 1e-8)
+        self.step = 0
+        self.table_id = next(_IDS)
+        _LAYERS[self.table_id] = self
+        # autograd only runs backward for ops with an input that requires grad
+        self._anchor = torch.nn.Parameter(torch.zeros(()), requires_grad=True)
+
+
+class DynamicEmbeddingCollection(torch.nn.Module, _SparseOptimizerSettings):
+    """All embedding tables of a model behind one module: keys = the tables' id batches concatenated, offsets = the
+    n_tables + 1 segment bounds (int64, on the device) -> fp32 [len(keys), dim].  Forward is ONE grouped find_or_insert
+    (find in eval mode), backward ONE grouped optimizer step, whatever the number of tables (TableGroup in table.py)."""
+
+    def __init__(self, group, optimizer: str = "adagrad", lr: float = 0.01, eps: float | None = None, betas=(0.9, 0.999)):
+        super().__init__()
+        self.group = group
+        self._init_settings(optimizer, lr, eps, betas)
+
+    def forward(self, keys: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+        return lookup_jagged(keys, offsets, self._anchor, self.table_id, self.training)
+
+
 class DynamicEmbedding(torch.nn.Module):
     """ids (any int64 tensor) -> fp32 [..., dim].  The table must have been created with the matching optimizer planes."""
 

@@ -375,7 +375,12 @@ class TableGroup:
         check(_lib.lib().mee_group_apply_adam(self._h, k.data_ptr(), offsets.data_ptr(), g.data_ptr(), k.numel(), lr, beta1, beta2,
                                               eps, step, _stream_ptr(self.device)))
 
-    def find(self, keys: torch.Tensor, offsets: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None):
+    def find_or_insert(self, keys: torch.Tensor, offsets: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None):
+        """find that first creates absent keys in their member table (initial row / state); found = present before."""
+        return self.find(keys, offsets, out, found, _fn="mee_group_find_or_insert")
+
+    def find(self, keys: torch.Tensor, offsets: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None,
+             _fn: str = "mee_find_grouped"):
         k = self.tables[0]._keys(keys) if keys.numel() else keys
         n = k.numel()
         self._check_offsets(offsets)
@@ -383,8 +388,8 @@ class TableGroup:
             out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
         if found is None:
             found = torch.empty(n, dtype=torch.uint8, device=self.device)
-        check(_lib.lib().mee_find_grouped(self._h, k.data_ptr(), offsets.data_ptr(), n, out.data_ptr(), found.data_ptr(),
-                                          _stream_ptr(self.device)))
+        check(getattr(_lib.lib(), _fn)(self._h, k.data_ptr(), offsets.data_ptr(), n, out.data_ptr(), found.data_ptr(),
+                                       _stream_ptr(self.device)))
         return out, found
 
 

@@ -671,7 +671,7 @@ def test_grouped_apply_equals_per_table_apply(dev, opt, dim):
         for x, y, z in zip(ga[1:], sa[1:], oa[1:]):
             np.testing.assert_allclose(x[ia], y[ib], rtol=RTOL, atol=ATOL)
             np.testing.assert_allclose(x[ia], z[ic], rtol=RTOL, atol=ATOL)
-        assert grouped[j].status() == 0
+        assert grouped[j].status() == solo[j].status() == oracles[j].status()
     # errors: a group without apply scratch, a batch beyond max_apply_batch, mixed optimizers
     with pytest.raises(MeepoError):
         TableGroup(grouped).apply_adagrad(T(keys, dev), offs, T(grads, dev), lr=0.1)
@@ -679,4 +679,61 @@ def test_grouped_apply_equals_per_table_apply(dev, opt, dim):
         TableGroup(grouped, max_apply_batch=16).apply_adagrad(T(keys, dev), offs, T(grads, dev), lr=0.1)
     with pytest.raises(MeepoError):
         TableGroup([grouped[0], LookupTable(100, dim, device=dev)], max_apply_batch=64)
+    grp.close()
+
+
+@pytest.mark.parametrize("opt,dim", [("adagrad", 64), ("adam", 24), ("none", 128)])
+def test_grouped_find_or_insert_equals_per_table(dev, opt, dim):
+    """mee_group_find_or_insert == find_or_insert per table == the oracle: rows, present-before masks, the created keys'
+    hashed initial rows and optimizer state, duplicates of a new key, reserved keys, and TABLE_FULL on the right member."""
+    from meepoembedding_amd import OPT_NONE, TableGroup
+    rng = np.random.default_rng(31 + dim)
+    kind, okind = {"adagrad": (OPT_ADAGRAD, oracle.OPT_ADAGRAD), "adam": (OPT_ADAM, oracle.OPT_ADAM), "none": (OPT_NONE, oracle.OPT_NONE)}[opt]
+    n_tables = 4
+    grouped, oracles, universes = [], [], []
+    for j in range(n_tables):
+        cap = 4096 if j else 16 * 8            # member 0 is tiny: it overflows
+        kw = dict(default_value=0.5 * j, initial_accumulator=0.1 * (j + 1), initializer=INIT_UNIFORM, init_scale=0.05, init_seed=70 + j)
+        a = LookupTable(cap, dim, device=dev, optimizer=kind, max_batch=8192, **kw)
+        o = oracle.OracleTable(cap, dim, optimizer=okind, **kw)
+        u = synth.keys_np(800 + j, 0, 3000)
+        rows = rng.standard_normal((60, dim)).astype(np.float32)
+        a.insert(T(u[:60], dev), T(rows, dev)); o.insert(u[:60], rows)
+        grouped.append(a); oracles.append(o); universes.append(u)
+    grp = TableGroup(grouped, max_apply_batch=1 << 14)
+    for trial in range(3):
+        segs = []
+        for j in range(n_tables):
+            m = int(rng.integers(0, 1500)) if j else 40
+            hi = 1000 * (trial + 1) if j else 100      # member 0: at most 100 distinct keys ever asked -> within its 128 slots
+            k = universes[j][rng.integers(0, hi, m)].copy()
+            if m > 10:
+                k[3] = oracle.EMPTY_KEY; k[4] = oracle.RECLAIMED_KEY; k[5] = k[6]    # padding, reserved, a duplicate
+            segs.append(k)
+        keys = np.concatenate(segs)
+        offs = torch.tensor(np.concatenate([[0], np.cumsum([s.size for s in segs])]), dtype=torch.int64, device=dev)
+        out, found = grp.find_or_insert(T(keys, dev), offs)
+        out, found = out.cpu().numpy(), found.cpu().numpy()
+        p = 0
+        for j, k in enumerate(segs):
+            eo, ef = oracles[j].find_or_insert(k)
+            assert np.array_equal(found[p:p + k.size], ef), (trial, j)
+            assert np.array_equal(out[p:p + k.size], eo), (trial, j)
+            p += k.size
+    for j in range(n_tables):
+        ga = [x.cpu().numpy() for x in grouped[j].export(with_state=True) if x is not None]
+        oa = [x for x in oracles[j].export(with_state=True) if x is not None]
+        ia, ic = np.argsort(ga[0]), np.argsort(oa[0])
+        assert np.array_equal(ga[0][ia], oa[0][ic])
+        for x, z in zip(ga[1:], oa[1:]):
+            assert np.array_equal(x[ia], z[ic])
+        assert grouped[j].status() == oracles[j].status() == STATUS_RESERVED_KEY   # every segment carried a RECLAIMED key
+        grouped[j].clear_status()
+    # overflow lands on the member that is full, and only there
+    flood = universes[0][200:600]
+    offs = torch.tensor([0, flood.size] + [flood.size] * (n_tables - 1), dtype=torch.int64, device=dev)
+    _, f2 = grp.find_or_insert(T(flood, dev), offs)
+    assert not bool(f2.any())
+    assert grouped[0].status() & STATUS_TABLE_FULL and all(grouped[j].status() == 0 for j in range(1, n_tables))
+    assert grouped[0].size() <= grouped[0].capacity
     grp.close()

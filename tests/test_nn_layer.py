@@ -75,3 +75,33 @@ def test_dynamic_embedding_trains_like_torch_sparse_adagrad(dev):
     new = torch.tensor([[123456789, 987654321]], device=dev)
     layer.eval(); layer(new); assert table.size() == vocab
     layer.train(); layer(new); assert table.size() == vocab + 2
+
+
+@pytest.mark.gpu
+def test_collection_layer_trains_like_per_table_layers(dev):
+    """DynamicEmbeddingCollection (one grouped lookup + one grouped Adagrad step) == one DynamicEmbedding per table."""
+    from meepoembedding_amd import OPT_ADAGRAD, LookupTable, TableGroup
+    from meepoembedding_amd.nn import DynamicEmbeddingCollection
+    torch.manual_seed(1)
+    dim, n_tables, steps = 16, 3, 4
+    mk = lambda j: LookupTable(4096, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=4096, initial_accumulator=0.1,
+                               initializer=1, init_scale=0.1, init_seed=j)
+    a, b = [mk(j) for j in range(n_tables)], [mk(j) for j in range(n_tables)]
+    coll = DynamicEmbeddingCollection(TableGroup(a, max_apply_batch=4096), lr=0.05).to(dev)
+    solo = [DynamicEmbedding(t, lr=0.05).to(dev) for t in b]
+    head = torch.randn(dim, 1, device=dev) * 0.1
+    for s in range(steps):
+        lens = [int(x) for x in torch.randint(1, 200, (n_tables,))]
+        segs = [torch.from_numpy(synth.keys_np(90 + j, 0, 150))[torch.randint(0, 150, (m,))].to(dev) for j, m in enumerate(lens)]
+        keys = torch.cat(segs)
+        offs = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int64, device=dev)
+        target = torch.randn(keys.numel(), 1, device=dev)
+        ((coll(keys, offs) @ head - target) ** 2).mean().backward()
+        rows = torch.cat([layer(k) for layer, k in zip(solo, segs)])
+        ((rows @ head - target) ** 2).mean().backward()
+    for x, y in zip(a, b):
+        ex, ey = x.export(with_state=True), y.export(with_state=True)
+        ix, iy = torch.argsort(ex[0]), torch.argsort(ey[0])
+        assert torch.equal(ex[0][ix], ey[0][iy]) and x.size() > 0
+        torch.testing.assert_close(ex[1][ix], ey[1][iy], rtol=1e-6, atol=1e-9)
+        torch.testing.assert_close(ex[2][ix], ey[2][iy], rtol=1e-6, atol=1e-9)
