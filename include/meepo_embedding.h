@@ -106,6 +106,14 @@ int mee_find_counted(const mee_table* t, const int64_t* d_keys, size_t n, float*
  * reset != 0 zeroes every counter, which starts a new observation window. */
 int mee_hits_scan(mee_table* t, uint32_t min_hits, uint32_t max_hits, int reset, int64_t* d_keys_out, size_t cap, size_t* n_out,
                   void* stream);
+/* Pooled lookup ("embedding bag"): bag b = d_keys[d_bag_offsets[b] .. d_bag_offsets[b+1]) (n_bags+1 uint64 offsets in DEVICE
+ * memory); d_out[b,:] = the rows mee_find would return for the bag's positions, added in position order in fp32
+ * (MEE_POOL_SUM) and divided by the bag length (MEE_POOL_MEAN); an empty bag gives zeros.  d_found (nullable) is per KEY,
+ * indexed like d_keys; n = number of keys (a host value: it only picks the launch shape — a tile per bag, or a whole wave
+ * per bag when the average bag is long).  The sum lives in registers: one output row per bag instead of one per key. */
+enum { MEE_POOL_SUM = 0, MEE_POOL_MEAN = 1 };
+int mee_find_pooled(const mee_table* t, const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t n_bags, float* d_out,
+                    uint8_t* d_found, int mode, void* stream);
 /* upsert; duplicate keys: last occurrence wins. */
 int mee_insert(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, void* stream);
 /* overwrite only if present; d_found nullable; duplicates: last occurrence wins. */
@@ -172,6 +180,12 @@ int mee_apply_adagrad(mee_table* t, const int64_t* d_keys, const float* d_grads,
                       void* stream);
 int mee_apply_adam(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float beta1,
                    float beta2, float eps, uint64_t step, void* stream);
+/* The same with an indirection on the grads: position i takes row d_grad_index[i] of d_grads — the backward of a pooled
+ * lookup (every key of a bag receives the bag's grad row; for MEE_POOL_MEAN the caller scales the bag rows by 1/length). */
+int mee_apply_adagrad_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, const uint32_t* d_grad_index, size_t n, float lr,
+                              float eps, void* stream);
+int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, const uint32_t* d_grad_index, size_t n, float lr,
+                           float beta1, float beta2, float eps, uint64_t step, void* stream);
 /* Optional split of an apply: mee_apply_prepare groups the batch's keys and plans the duplicate reduction — everything
  * that does not need the grads — so it can run early (e.g. on a side stream beside the forward lookup and the dense
  * model); the following mee_apply_adagrad / mee_apply_adam with the SAME d_keys / n then only streams the updates.

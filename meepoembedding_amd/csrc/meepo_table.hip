@@ -207,6 +207,161 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
     }
 }
 
+// ---- pooled find (SPEC.md §3): out[b,:] = the rows of bag b's keys added up in position order (sum | mean) ----------------
+// The partial sum of a bag lives in registers, so a bag costs ONE output row instead of one per key: with L keys per bag
+// the write traffic of the lookup drops from 256 B per key to 256/L.  Additions happen in position order (bit-exact
+// against a sequential sum).  A wave takes four consecutive bags.  Short bags: one tile per bag, U keys of the bag in
+// flight (all bucket lines requested, then all rows).  Bags of kPoolLong keys or more: the four tiles work on ONE bag
+// together — tile t probes positions i + 4u + t — and every tile then adds the 4U rows in position order out of the
+// other tiles' registers (shuffles), so a long bag has 4U keys in flight instead of U.
+constexpr uint32_t kPoolLong = 16;
+
+// probe + row load of up to U keys per tile (the find_kernel pattern); row[u] is only defined where inb[u]
+template <int DIM4, int U, int C>
+__device__ __forceinline__ void pooled_fetch(const int64_t* __restrict__ tkeys, const float4* __restrict__ values, uint64_t nb,
+                                             uint32_t dim4, const int64_t* __restrict__ keys, const uint64_t (&pos)[U],
+                                             const bool (&inb)[U], int tile, int tl, float4 def4, float4 (&row)[U][C],
+                                             uint8_t* __restrict__ found) {
+    int64_t key[U], slot[U], kb[U];
+    uint64_t bk[U];
+    bool act[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        key[u] = inb[u] ? keys[pos[u]] : kEmpty;
+        act[u] = inb[u] && !reserved_key(key[u]);
+        bk[u] = bucket_of(key[u], nb);
+        kb[u] = act[u] ? tkeys[bk[u] * kW + tl] : kEmpty;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        slot[u] = -1;
+        bool pend = act[u];
+        uint64_t bb = bk[u], steps = 0;
+        int64_t k = kb[u];
+        while (true) {
+            const uint32_t tm = tile_bits(__ballot(pend && k == key[u]), tile);
+            const uint32_t te = tile_bits(__ballot(pend && k == kEmpty), tile);
+            if (pend) {
+                if (tm) { slot[u] = (int64_t)(bb * kW) + (__ffs(tm) - 1); pend = false; }
+                else if (te || ++steps >= nb) pend = false;
+                else bb = next_bucket(bb, step_of(key[u], nb), nb);
+            }
+            if (!__any(pend)) break;
+            k = pend ? tkeys[bb * kW + tl] : kEmpty;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            if (DIM4 != 0 || (uint32_t)(c * 16 + tl) < dim4)
+                row[u][c] = slot[u] >= 0 ? values[(uint64_t)slot[u] * dim4 + c * 16 + tl] : def4;
+        if (found && inb[u] && tl == 0) found[pos[u]] = slot[u] >= 0;
+    }
+}
+
+// BPW = bags per wave: 4 = the hybrid above (batches of mostly short bags), 1 = every bag gets a whole wave (batches whose
+// AVERAGE bag is long: a wave that had to walk four long bags one after the other would be latency-bound).
+template <int DIM4, int U, int BPW>
+__global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restrict__ tkeys, const float4* __restrict__ values,
+                                                          uint64_t nb, const int64_t* __restrict__ keys,
+                                                          const uint64_t* __restrict__ offsets, uint64_t n_bags,
+                                                          float4* __restrict__ out, uint8_t* __restrict__ found, float defv,
+                                                          uint32_t dim4_rt, int mean) {
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
+    constexpr int C = DIM4 ? DIM4 / 16 : 16;   // float4 per lane per row (any dim: up to 1024 floats = 16 per lane)
+    const float4 def4 = make_float4(defv, defv, defv, defv);
+    for (uint64_t b0 = wave * BPW; b0 < n_bags; b0 += n_waves * BPW) {
+        const uint64_t bag = BPW == 4 ? b0 + tile : b0;
+        const bool has = bag < n_bags;
+        const uint64_t begin = has ? offsets[bag] : 0, end = has ? offsets[bag + 1] : 0;
+        const bool is_long = BPW == 1 || end - begin >= kPoolLong;
+        float4 acc[C];
+        float4 row[U][C];
+        // ---- short bags: one tile per bag ----
+        if constexpr (BPW == 4) {
+            uint64_t i = is_long ? end : begin;
+            bool first = true;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            while (__any(i < end)) {  // wave-uniform; tiles whose bag is done idle through the ballots
+                uint64_t pos[U];
+                bool inb[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { pos[u] = i + u; inb[u] = pos[u] < end; }
+                pooled_fetch<DIM4, U, C>(tkeys, values, nb, dim4, keys, pos, inb, tile, tl, def4, row, found);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!inb[u]) continue;
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        if (DIM4 != 0 || (uint32_t)(c * 16 + tl) < dim4) {
+                            if (first) acc[c] = row[u][c];
+                            else { acc[c].x += row[u][c].x; acc[c].y += row[u][c].y; acc[c].z += row[u][c].z; acc[c].w += row[u][c].w; }
+                        }
+                    first = false;
+                }
+                i += U;
+            }
+            if (has && !is_long) {
+                const float len = (float)(end - begin);
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (DIM4 != 0 || (uint32_t)(c * 16 + tl) < dim4) {
+                        float4 v = acc[c];
+                        if (mean && end > begin) { v.x = v.x / len; v.y = v.y / len; v.z = v.z / len; v.w = v.w / len; }
+                        out[bag * dim4 + c * 16 + tl] = v;
+                    }
+            }
+        }
+        // ---- long bags: the four tiles share one bag at a time ----
+        const uint64_t long_mask = __ballot(is_long && has);
+        if (!long_mask) continue;   // wave-uniform
+        for (int q = 0; q < BPW; ++q) {
+            if (!((long_mask >> (q * 16)) & 1)) continue;   // wave-uniform
+            const uint64_t bq = __shfl(begin, q * 16), eq = __shfl(end, q * 16);
+            bool first = true;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (uint64_t i = bq; i < eq; i += 4 * U) {   // wave-uniform
+                uint64_t pos[U];
+                bool inb[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { pos[u] = i + (uint64_t)u * 4 + tile; inb[u] = pos[u] < eq; }
+                pooled_fetch<DIM4, U, C>(tkeys, values, nb, dim4, keys, pos, inb, tile, tl, def4, row, found);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int src = 0; src < 4; ++src) {
+                        if (i + (uint64_t)u * 4 + src >= eq) continue;   // wave-uniform
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            float4 v;   // every tile reads the row tile `src` fetched: all four keep the same running sum
+                            v.x = __shfl(row[u][c].x, src * 16 + tl); v.y = __shfl(row[u][c].y, src * 16 + tl);
+                            v.z = __shfl(row[u][c].z, src * 16 + tl); v.w = __shfl(row[u][c].w, src * 16 + tl);
+                            if (first) acc[c] = v;
+                            else { acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w; }
+                        }
+                        first = false;
+                    }
+            }
+            if (tile == 0) {
+                const float len = (float)(eq - bq);
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (DIM4 != 0 || (uint32_t)(c * 16 + tl) < dim4) {
+                        float4 v = acc[c];
+                        if (mean && eq > bq) { v.x = v.x / len; v.y = v.y / len; v.z = v.z / len; v.w = v.w / len; }
+                        out[(b0 + q) * dim4 + c * 16 + tl] = v;
+                    }
+            }
+        }
+    }
+}
+
 // ---- group table: one entry per distinct key of the batch ---------------------------------------------------
 __device__ __forceinline__ uint32_t group_claim(const GroupTable& g, int64_t key, bool& claimed) {
     const unsigned long long bk = (unsigned long long)key ^ kBias;  // != 0 because key != kEmpty
@@ -528,7 +683,8 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
                                                            float4* s2, uint64_t nb, uint32_t dim4_rt,
                                                            const int64_t* __restrict__ keys,
                                                            const float4* __restrict__ grads, uint32_t n, GroupTable g,
-                                                           BatchScratch bs, OptArgs a, const GroupDesc* __restrict__ desc = nullptr) {
+                                                           BatchScratch bs, OptArgs a, const GroupDesc* __restrict__ desc = nullptr,
+                                                           const uint32_t* __restrict__ gidx = nullptr) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
@@ -537,7 +693,7 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
     a.kind = KIND;  // lets the compiler drop the other optimizer's code
     for (uint32_t base = wave * 4 * R; base < n; base += n_waves * 4 * R) {
         int64_t key[R], slot[R];
-        uint32_t cnt[R];
+        uint32_t cnt[R], grow[R];   // grow = row of the grad array that belongs to the position
         float4 gr[R][C];
         RowPlanes pl[R];
 #pragma unroll
@@ -546,6 +702,7 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
             const bool inb = i < n;
             key[r] = inb ? keys[i] : kEmpty;
             cnt[r] = inb ? bs.pcnt[i] : 0;
+            grow[r] = (gidx && cnt[r] == 1) ? gidx[i] : i;
         }
         if constexpr (DIM4 != 0) {
 #pragma unroll
@@ -553,7 +710,7 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
 #pragma unroll
                 for (int c = 0; c < C; ++c)
                     if (cnt[r] == 1) {  // the grad row is read exactly once: stream it past the caches
-                        const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grads) + (uint64_t)(base + r * 4 + tile) * DIM4 + c * 16 + tl);
+                        const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grads) + (uint64_t)grow[r] * DIM4 + c * 16 + tl);
                         gr[r][c] = make_float4(gv.x, gv.y, gv.z, gv.w);
                     }
         }
@@ -571,7 +728,7 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
 #pragma unroll
                         for (int c = 0; c < C; ++c) update_row(a, pl[r].values, pl[r].s1, pl[r].s2, (uint64_t)slot[r] * DIM4 + c * 16 + tl, gr[r][c]);
                     } else {
-                        for (uint32_t c = tl; c < dim4; c += 16) update_row(a, pl[r].values, pl[r].s1, pl[r].s2, (uint64_t)slot[r] * dim4 + c, grads[(uint64_t)i * dim4 + c]);
+                        for (uint32_t c = tl; c < dim4; c += 16) update_row(a, pl[r].values, pl[r].s1, pl[r].s2, (uint64_t)slot[r] * dim4 + c, grads[(uint64_t)grow[r] * dim4 + c]);
                     }
                 }
                 if (tl == 0) group_release(g, bs.hidx[i]);  // this tile is the only user of the entry
@@ -586,20 +743,25 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
 // with the same arguments (c differs per lane).
 __device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, const uint32_t* __restrict__ occ, uint32_t first,
                                           uint32_t count, uint32_t dim4, uint32_t c, double& sx, double& sy, double& sz,
-                                          double& sw) {
+                                          double& sw, const uint32_t* __restrict__ gidx = nullptr) {
     uint32_t o = 0;
     for (; o + 8 <= count; o += 8) {
         uint32_t idx[8];
         float4 gq[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) idx[q] = occ[first + o + q];
+        if (gidx) {  // indexed apply: position -> row of the grad array (e.g. the bag of a pooled lookup)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) idx[q] = gidx[idx[q]];
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) gq[q] = grads[(uint64_t)idx[q] * dim4 + c];
 #pragma unroll
         for (int q = 0; q < 8; ++q) { sx += (double)gq[q].x; sy += (double)gq[q].y; sz += (double)gq[q].z; sw += (double)gq[q].w; }
     }
     for (; o < count; ++o) {
-        const float4 gg = grads[(uint64_t)occ[first + o] * dim4 + c];
+        const uint32_t p = occ[first + o];
+        const float4 gg = grads[(uint64_t)(gidx ? gidx[p] : p) * dim4 + c];
         sx += (double)gg.x; sy += (double)gg.y; sz += (double)gg.z; sw += (double)gg.w;
     }
 }
@@ -613,7 +775,8 @@ __global__ __launch_bounds__(256) void apply_chunk_kernel(const int64_t* __restr
                                                           float4* s2, uint64_t nb, uint32_t dim4,
                                                           const int64_t* __restrict__ keys,
                                                           const float4* __restrict__ grads, GroupTable g, BatchScratch bs,
-                                                          const OpCounters* op, OptArgs a, const GroupDesc* __restrict__ desc = nullptr) {
+                                                          const OpCounters* op, OptArgs a, const GroupDesc* __restrict__ desc = nullptr,
+                                                          const uint32_t* __restrict__ gidx = nullptr) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
@@ -635,7 +798,7 @@ __global__ __launch_bounds__(256) void apply_chunk_kernel(const int64_t* __restr
         const uint32_t part = small ? 0 : g.sbig[h] + r / kChunk;  // this chunk's row in the group's partial-sum block
         for (uint32_t c = tl; c < dim4; c += 16) {
             double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-            chunk_sum(grads, bs.occ, first, count, dim4, c, sx, sy, sz, sw);
+            chunk_sum(grads, bs.occ, first, count, dim4, c, sx, sy, sz, sw, gidx);
             if (small) {
                 if (slot >= 0) update_row(a, pl.values, pl.s1, pl.s2, (uint64_t)slot * dim4 + c, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
             } else {
@@ -1187,6 +1350,23 @@ int mee_find_counted(const mee_table* t, const int64_t* d_keys, size_t n, float*
     return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, missing_only != 0, true);
 }
 
+int mee_find_pooled(const mee_table* t, const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t n_bags, float* d_out,
+                    uint8_t* d_found, int mode, void* stream) {
+    if (!t || (n_bags && (!d_bag_offsets || !d_out || !d_keys))) return fail(MEE_ERR_INVALID_ARG, "mee_find_pooled: null argument");
+    if (mode != MEE_POOL_SUM && mode != MEE_POOL_MEAN) return fail(MEE_ERR_INVALID_ARG, "mee_find_pooled: mode must be MEE_POOL_SUM or MEE_POOL_MEAN");
+    if (n_bags == 0) return MEE_OK;
+    DeviceGuard g(t->device);
+    hipStream_t st = as_stream(stream);
+    // n (the number of keys, a host value) only picks the launch shape: mostly short bags -> four bags per wave, long average -> one
+    const bool wave_per_bag = n / n_bags >= 12;
+#define POOLED(D4, U1, U4) do { if (wave_per_bag) find_pooled_kernel<D4, U1, 1><<<grid_for(n_bags, 4, 1u << 20), 256, 0, st>>>(t->keys, (const float4*)t->values, t->nb, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, t->default_value, t->dim4, mode == MEE_POOL_MEAN); \
+                                else find_pooled_kernel<D4, U4, 4><<<grid_for(n_bags, 16, 1u << 20), 256, 0, st>>>(t->keys, (const float4*)t->values, t->nb, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, t->default_value, t->dim4, mode == MEE_POOL_MEAN); } while (0)
+    if (t->dim4 == 16) POOLED(16, 4, 2); else if (t->dim4 == 32) POOLED(32, 2, 1); else POOLED(0, 1, 1);
+#undef POOLED
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
 int mee_hits_scan(mee_table* t, uint32_t min_hits, uint32_t max_hits, int reset, int64_t* d_keys_out, size_t cap, size_t* n_out,
                   void* stream) {
     if (!t || !n_out || (cap && !d_keys_out)) return fail(MEE_ERR_INVALID_ARG, "mee_hits_scan: null argument");
@@ -1361,7 +1541,7 @@ static int apply_prepare_launch(mee_table* t, const int64_t* d_keys, uint32_t nn
 }
 
 static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, const OptArgs& a, void* stream,
-                        const char* name) {
+                        const char* name, const uint32_t* d_gidx = nullptr) {
     if (!t || (n && (!d_keys || !d_grads))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
     if (t->optimizer != a.kind) return fail(MEE_ERR_UNSUPPORTED, "%s: table was created with optimizer=%u", name, t->optimizer);
     if (int rc = check_batch(t, n, name, false)) return rc;
@@ -1380,7 +1560,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
         const int R = t->apply_rounds > 0 ? t->apply_rounds : 2;
         const unsigned gs = grid_for(n, 16u * (R >= 2 ? 2u : 1u), 1u << 16);
 #define SINGLE(K, D4, RR) apply_single_kernel<K, D4, RR><<<gs, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, \
-                                                                            d_keys, (const float4*)d_grads, nn, t->g, t->bs, a)
+                                                                            d_keys, (const float4*)d_grads, nn, t->g, t->bs, a, nullptr, d_gidx)
 #define SINGLE_D(K) do { if (t->dim4 == 16) { if (R >= 2) SINGLE(K, 16, 2); else SINGLE(K, 16, 1); } \
                          else if (t->dim4 == 32) { if (R >= 2) SINGLE(K, 32, 2); else SINGLE(K, 32, 1); } \
                          else { if (R >= 2) SINGLE(K, 0, 2); else SINGLE(K, 0, 1); } } while (0)
@@ -1390,7 +1570,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     }
     // the work list (chunk leaders) and the big-group list have device-side lengths: fixed grids that loop
     apply_chunk_kernel<false><<<grid_for(n, 16, 2048), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
-                                                            d_keys, (const float4*)d_grads, t->g, t->bs, t->op, a);
+                                                            d_keys, (const float4*)d_grads, t->g, t->bs, t->op, a, nullptr, d_gidx);
     apply_big_kernel<false><<<grid_for(n / kChunk + 1, 1, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,
                                                                        t->dim4, t->g, t->bs, t->op, a);
     MEE_HIP(hipGetLastError());
@@ -1473,15 +1653,32 @@ int mee_apply_adagrad(mee_table* t, const int64_t* d_keys, const float* d_grads,
     a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps;
     return apply_common(t, d_keys, d_grads, n, a, stream, "mee_apply_adagrad");
 }
-int mee_apply_adam(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float beta1, float beta2,
-                   float eps, uint64_t step, void* stream) {
-    if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adam: step must be >= 1");
+static OptArgs adam_args(float lr, float beta1, float beta2, float eps, uint64_t step) {
     OptArgs a{};
     a.kind = MEE_OPT_ADAM; a.eps = eps;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     a.step_size = (float)((double)lr * sqrt(bc2) / bc1);  // SPEC.md §4
     a.omb1 = 1.0f - beta1; a.omb2 = 1.0f - beta2;
-    return apply_common(t, d_keys, d_grads, n, a, stream, "mee_apply_adam");
+    return a;
+}
+int mee_apply_adam(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float beta1, float beta2,
+                   float eps, uint64_t step, void* stream) {
+    if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adam: step must be >= 1");
+    return apply_common(t, d_keys, d_grads, n, adam_args(lr, beta1, beta2, eps, step), stream, "mee_apply_adam");
+}
+// the grad of position i is row d_grad_index[i] of d_grads (pooled lookups: the bag's grad row serves every key of the bag)
+int mee_apply_adagrad_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, const uint32_t* d_grad_index, size_t n, float lr,
+                              float eps, void* stream) {
+    if (n && !d_grad_index) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adagrad_indexed: null index");
+    OptArgs a{};
+    a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps;
+    return apply_common(t, d_keys, d_grads, n, a, stream, "mee_apply_adagrad_indexed", d_grad_index);
+}
+int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, const uint32_t* d_grad_index, size_t n, float lr,
+                           float beta1, float beta2, float eps, uint64_t step, void* stream) {
+    if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adam_indexed: step must be >= 1");
+    if (n && !d_grad_index) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adam_indexed: null index");
+    return apply_common(t, d_keys, d_grads, n, adam_args(lr, beta1, beta2, eps, step), stream, "mee_apply_adam_indexed", d_grad_index);
 }
 
 int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, int64_t* d_uniq_out, float* d_gsum_out,

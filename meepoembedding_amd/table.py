@@ -90,6 +90,23 @@ class LookupTable:
                                   self._s()))
         return out, found
 
+    def find_pooled(self, keys: torch.Tensor, bag_offsets: torch.Tensor, mode: str = "sum", out: torch.Tensor | None = None,
+                    found: torch.Tensor | None = None):
+        """Embedding-bag lookup: bag b = keys[bag_offsets[b]:bag_offsets[b+1]] (int64 offsets on the device) -> ([n_bags, dim]
+        sums or means in position order, per-key found mask).  One output row per bag is written instead of one per key."""
+        k = self._keys(keys) if keys.numel() else keys
+        if bag_offsets.device != self.device or bag_offsets.dtype not in (torch.int64, torch.uint64) or not bag_offsets.is_contiguous() \
+                or bag_offsets.numel() < 1:
+            raise MeepoError(_lib.ERR_INVALID_ARG, f"bag_offsets must be contiguous int64 on {self.device} with n_bags + 1 entries")
+        n_bags = bag_offsets.numel() - 1
+        if out is None:
+            out = torch.empty((n_bags, self.dim), dtype=torch.float32, device=self.device)
+        if found is None:
+            found = torch.empty(k.numel(), dtype=torch.uint8, device=self.device)
+        check(_lib.lib().mee_find_pooled(self._h, k.data_ptr(), k.numel(), bag_offsets.data_ptr(), n_bags, out.data_ptr(), found.data_ptr(),
+                                         {"sum": 0, "mean": 1}[mode], self._s()))
+        return out, found
+
     def find_missing(self, keys: torch.Tensor, out: torch.Tensor, found: torch.Tensor) -> None:
         """Second-tier pass: fill the positions an earlier find (on another table) left with found == 0."""
         k = self._keys(keys)
@@ -288,14 +305,32 @@ class LookupTable:
         return new
 
     # -- sparse optimizers (SPEC.md §4) --------------------------------------------------------------------
-    def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10) -> None:
+    def _grad_index(self, grad_index: torch.Tensor, n: int) -> torch.Tensor:
+        if grad_index.device != self.device or grad_index.numel() != n:
+            raise MeepoError(_lib.ERR_INVALID_ARG, f"grad_index must hold one entry per key on {self.device}")
+        return grad_index.to(torch.int32).contiguous()   # read as uint32 by the kernels: indices are < 2^31
+
+    def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10,
+                      grad_index: torch.Tensor | None = None) -> None:
+        """grad_index (optional, one int per key): position i takes row grad_index[i] of grads (pooled lookups: the bag)."""
         k = self._keys(keys)
+        if grad_index is not None:
+            gi = self._grad_index(grad_index, k.numel())
+            g = grads.contiguous()
+            check(_lib.lib().mee_apply_adagrad_indexed(self._h, k.data_ptr(), g.data_ptr(), gi.data_ptr(), k.numel(), lr, eps, self._s()))
+            return
         g = self._rows(grads, k.numel())
         check(_lib.lib().mee_apply_adagrad(self._h, k.data_ptr(), g.data_ptr(), k.numel(), lr, eps, self._s()))
 
     def apply_adam(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999,
-                   eps: float = 1e-8, step: int = 1) -> None:
+                   eps: float = 1e-8, step: int = 1, grad_index: torch.Tensor | None = None) -> None:
         k = self._keys(keys)
+        if grad_index is not None:
+            gi = self._grad_index(grad_index, k.numel())
+            g = grads.contiguous()
+            check(_lib.lib().mee_apply_adam_indexed(self._h, k.data_ptr(), g.data_ptr(), gi.data_ptr(), k.numel(), lr, beta1, beta2,
+                                                    eps, step, self._s()))
+            return
         g = self._rows(grads, k.numel())
         check(_lib.lib().mee_apply_adam(self._h, k.data_ptr(), g.data_ptr(), k.numel(), lr, beta1, beta2, eps, step, self._s()))
 

@@ -212,3 +212,20 @@ class OracleTable:
     def apply_adam(self, keys, grads, lr: float, beta1: float, beta2: float, eps: float, step: int):
         k = _keys(keys); g = _rows(grads, k.size, self.dim)
         lib().meo_apply_adam(self._h, _p(k), _p(g), k.size, lr, beta1, beta2, eps, step)
+
+
+def pool_rows(rows: np.ndarray, bag_offsets: np.ndarray, mode: str = "sum") -> np.ndarray:
+    """SPEC.md §3 find_pooled, given find's rows: per bag, fp32 additions in position order (first row copied, the rest
+    added one by one), 'mean' divides by the bag length in fp32; an empty bag is zeros."""
+    off = np.asarray(bag_offsets, dtype=np.int64)
+    n_bags = off.size - 1
+    lens = off[1:] - off[:-1]
+    out = np.zeros((n_bags, rows.shape[1]), dtype=np.float32)
+    for l in range(int(lens.max()) if n_bags else 0):
+        m = lens > l
+        r = rows[off[:-1][m] + l]
+        out[m] = r if l == 0 else (out[m] + r).astype(np.float32)
+    if mode == "mean":
+        nz = lens > 0
+        out[nz] = (out[nz] / lens[nz, None].astype(np.float32)).astype(np.float32)
+    return out

@@ -737,3 +737,71 @@ def test_grouped_find_or_insert_equals_per_table(dev, opt, dim):
     assert grouped[0].status() & STATUS_TABLE_FULL and all(grouped[j].status() == 0 for j in range(1, n_tables))
     assert grouped[0].size() <= grouped[0].capacity
     grp.close()
+
+
+@pytest.mark.parametrize("dim,mode", [(64, "sum"), (128, "mean"), (24, "sum"), (1024, "mean")])
+def test_find_pooled_bit_exact(dev, dim, mode):
+    """mee_find_pooled == segment-sum (position order, fp32) of find's rows: bit-exact, with empty bags, bags of one, long
+    bags, absent and reserved keys, odd bag lengths (the kernel keeps two keys in flight)."""
+    rng = np.random.default_rng(dim)
+    n_keys = 3000
+    t = LookupTable(6000, dim, device=dev, max_batch=4096, default_value=0.125)
+    o = oracle.OracleTable(6000, dim, default_value=0.125)
+    u = synth.keys_np(41, 0, n_keys)
+    rows = rng.standard_normal((n_keys, dim)).astype(np.float32)
+    t.insert(T(u, dev), T(rows, dev)); o.insert(u, rows)
+    # two launch shapes: mostly short bags (a tile per bag, long ones shared by the wave) and a long average (a wave per bag)
+    for lens in (np.concatenate([[0, 1, 2, 3, 0, 57, 400, 1], rng.integers(0, 12, 500), [0]]),
+                 np.concatenate([[0, 1, 33], rng.integers(5, 60, 120), [0, 16, 15, 17]])):
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        keys = u[rng.integers(0, n_keys, off[-1])].copy()
+        keys[5] = oracle.EMPTY_KEY; keys[9] = synth.keys_np(777, 0, 1)[0]; keys[30] = oracle.RECLAIMED_KEY
+        out, found = t.find_pooled(T(keys, dev), T(off, dev), mode)
+        er, ef = o.find(keys)
+        assert np.array_equal(found.cpu().numpy(), ef)
+        assert np.array_equal(out.cpu().numpy(), oracle.pool_rows(er, off, mode))
+    # the unpooled find of the same keys, pooled by torch in fp64, agrees to rounding (sanity of the oracle helper itself)
+    ref = torch.zeros(lens.size, dim, dtype=torch.float64).index_add_(0, torch.repeat_interleave(torch.arange(lens.size), torch.from_numpy(lens)), torch.from_numpy(er).double())
+    if mode == "mean":
+        ref = ref / torch.from_numpy(np.maximum(lens, 1)).double()[:, None]
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    e_out, _ = t.find_pooled(T(keys[:0], dev), torch.zeros(1, dtype=torch.int64, device=dev))   # zero bags
+    assert e_out.shape == (0, dim)
+
+
+@pytest.mark.parametrize("opt", ["adagrad", "adam"])
+def test_indexed_apply_is_apply_of_gathered_grads(dev, opt):
+    """apply_*_indexed(keys, bag_grads, bag_of_position) == apply_*(keys, bag_grads[bag_of_position]) == the oracle."""
+    rng = np.random.default_rng(3)
+    dim, n_keys = 64, 2000
+    kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
+    a = LookupTable(4096, dim, device=dev, optimizer=kind, max_batch=1 << 14, initial_accumulator=0.1)
+    b = LookupTable(4096, dim, device=dev, optimizer=kind, max_batch=1 << 14, initial_accumulator=0.1)
+    o = oracle.OracleTable(4096, dim, optimizer=okind, initial_accumulator=0.1)
+    u = synth.keys_np(43, 0, n_keys)
+    rows = rng.standard_normal((n_keys, dim)).astype(np.float32)
+    for x in (a, b):
+        x.insert(T(u, dev), T(rows, dev))
+    o.insert(u, rows)
+    for step in (1, 2):
+        lens = rng.integers(0, 9, 1500)
+        n = int(lens.sum())
+        idx = np.minimum(rng.zipf(1.2, n) - 1, n_keys - 1)
+        keys = u[idx].copy(); keys[:80] = u[7]           # a hot key: chunked and tree-summed paths read through the index too
+        bag_grads = (rng.standard_normal((lens.size, dim)) * 0.05).astype(np.float32)
+        bag_of = np.repeat(np.arange(lens.size), lens).astype(np.int64)
+        if opt == "adagrad":
+            a.apply_adagrad(T(keys, dev), T(bag_grads, dev), lr=0.05, grad_index=T(bag_of, dev))
+            b.apply_adagrad(T(keys, dev), T(bag_grads[bag_of], dev), lr=0.05)
+            o.apply_adagrad(keys, bag_grads[bag_of], 0.05, 1e-10)
+        else:
+            a.apply_adam(T(keys, dev), T(bag_grads, dev), lr=0.01, step=step, grad_index=T(bag_of, dev))
+            b.apply_adam(T(keys, dev), T(bag_grads[bag_of], dev), lr=0.01, step=step)
+            o.apply_adam(keys, bag_grads[bag_of], 0.01, 0.9, 0.999, 1e-8, step)
+    ea, eb = a.export(with_state=True), b.export(with_state=True)
+    eo = o.export(with_state=True)
+    ia, ib, io = torch.argsort(ea[0]).cpu(), torch.argsort(eb[0]).cpu(), np.argsort(eo[0])
+    for x, y, z in zip(ea[1:], eb[1:], eo[1:]):
+        if x is not None:
+            np.testing.assert_allclose(x.cpu()[ia].numpy(), y.cpu()[ib].numpy(), rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(x.cpu()[ia].numpy(), z[io], rtol=RTOL, atol=ATOL)

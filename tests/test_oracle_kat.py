@@ -231,3 +231,15 @@ def test_optimizers_vs_torch_golden(dim):
         got, found = t.find(keys)
         assert found.all()
         np.testing.assert_allclose(got, z[f"{name}_w_{dim}"], rtol=2e-6, atol=1e-7)
+
+
+def test_pool_rows_known_answer():
+    """oracle.pool_rows: position-order fp32 sums per bag (hand-checked), empty bags are zeros, mean divides by the length."""
+    rows = np.array([[1.0, 1e8], [2.0, 1.0], [3.0, -1e8], [4.0, 0.5], [5.0, 0.25]], dtype=np.float32)
+    off = np.array([0, 3, 3, 4, 5])
+    s = oracle.pool_rows(rows, off, "sum")
+    # (1e8 + 1) rounds to 1e8 in fp32, then -1e8 gives 0: the ORDER is part of the definition
+    assert s.tolist() == [[6.0, 0.0], [0.0, 0.0], [4.0, 0.5], [5.0, 0.25]]
+    m = oracle.pool_rows(rows, off, "mean")
+    assert m.tolist() == [[2.0, 0.0], [0.0, 0.0], [4.0, 0.5], [5.0, 0.25]]
+    assert oracle.pool_rows(rows[:0], np.array([0]), "sum").shape == (0, 2)
