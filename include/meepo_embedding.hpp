@@ -62,6 +62,10 @@ public:
     mee_table_info info() const { mee_table_info i{}; check(mee_table_info_get(t_, &i)); return i; }
 
     void find(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream = nullptr) const { check(mee_find(t_, d_keys, n, d_out, d_found, stream)); }
+    // embedding bag: d_out[b,:] = sum (MEE_POOL_SUM) or mean (MEE_POOL_MEAN) of the rows of d_keys[d_bag_offsets[b] .. d_bag_offsets[b+1])
+    void find_pooled(const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t n_bags, float* d_out, uint8_t* d_found = nullptr, int mode = MEE_POOL_SUM, void* stream = nullptr) const {
+        check(mee_find_pooled(t_, d_keys, n, d_bag_offsets, n_bags, d_out, d_found, mode, stream));
+    }
     // second-tier pass: fills only the positions an earlier find (on another table) left with d_found == 0
     void find_missing(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream = nullptr) const { check(mee_find_missing(t_, d_keys, n, d_out, d_found, stream)); }
     void insert(const int64_t* d_keys, const float* d_values, size_t n, void* stream = nullptr) { check(mee_insert(t_, d_keys, d_values, n, stream)); }
@@ -73,6 +77,13 @@ public:
     void apply_adagrad(const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps = 1e-10f, void* stream = nullptr) { check(mee_apply_adagrad(t_, d_keys, d_grads, n, lr, eps, stream)); }
     void apply_adam(const int64_t* d_keys, const float* d_grads, size_t n, float lr, uint64_t step, float beta1 = 0.9f, float beta2 = 0.999f, float eps = 1e-8f, void* stream = nullptr) {
         check(mee_apply_adam(t_, d_keys, d_grads, n, lr, beta1, beta2, eps, step, stream));
+    }
+    // backward of find_pooled: position i takes grad row d_grad_index[i] (its bag)
+    void apply_adagrad_indexed(const int64_t* d_keys, const float* d_grads, const uint32_t* d_grad_index, size_t n, float lr, float eps = 1e-10f, void* stream = nullptr) {
+        check(mee_apply_adagrad_indexed(t_, d_keys, d_grads, d_grad_index, n, lr, eps, stream));
+    }
+    void apply_adam_indexed(const int64_t* d_keys, const float* d_grads, const uint32_t* d_grad_index, size_t n, float lr, uint64_t step, float beta1 = 0.9f, float beta2 = 0.999f, float eps = 1e-8f, void* stream = nullptr) {
+        check(mee_apply_adam_indexed(t_, d_keys, d_grads, d_grad_index, n, lr, beta1, beta2, eps, step, stream));
     }
     // the next four synchronise the stream (they return host values)
     size_t size(void* stream = nullptr) const { size_t n = 0; check(mee_size(t_, &n, stream)); return n; }

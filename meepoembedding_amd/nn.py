@@ -75,6 +75,55 @@ def _backward(ctx, grad_out):
 lookup.register_autograd(_backward, setup_context=_setup)
 
 
+# ---- pooled: sum / mean per bag fused into the lookup, the bag's grad row indexed in the update ---------------------------
+@torch.library.custom_op("meepo::lookup_pooled", mutates_args=())
+def lookup_pooled(keys: torch.Tensor, bag_offsets: torch.Tensor, anchor: torch.Tensor, table_id: int, mean: bool) -> torch.Tensor:
+    layer = _layer(table_id)
+    out, _ = layer.table.find_pooled(keys, bag_offsets, "mean" if mean else "sum")
+    return out
+
+
+@lookup_pooled.register_fake
+def _(keys, bag_offsets, anchor, table_id, mean):
+    return keys.new_empty((bag_offsets.numel() - 1, _layer(table_id).table.dim), dtype=torch.float32)
+
+
+@torch.library.custom_op("meepo::apply_grad_pooled", mutates_args=())
+def apply_grad_pooled(keys: torch.Tensor, bag_offsets: torch.Tensor, grad_bags: torch.Tensor, table_id: int, mean: bool) -> None:
+    layer = _layer(table_id)
+    lens = bag_offsets[1:] - bag_offsets[:-1]
+    bag_of = torch.repeat_interleave(torch.arange(lens.numel(), device=keys.device), lens, output_size=keys.numel())
+    g = grad_bags.contiguous()
+    if mean:   # d mean / d row = 1 / length for every member of the bag
+        g = g / lens.clamp(min=1).to(torch.float32)[:, None]
+    layer.step += 1
+    if layer.optimizer == "adagrad":
+        layer.table.apply_adagrad(keys, g, lr=layer.lr, eps=layer.eps, grad_index=bag_of)
+    else:
+        layer.table.apply_adam(keys, g, lr=layer.lr, beta1=layer.betas[0], beta2=layer.betas[1], eps=layer.eps, step=layer.step,
+                               grad_index=bag_of)
+
+
+@apply_grad_pooled.register_fake
+def _(keys, bag_offsets, grad_bags, table_id, mean):
+    return None
+
+
+def _setup_pooled(ctx, inputs, output):
+    keys, bag_offsets, _, table_id, mean = inputs
+    ctx.save_for_backward(keys, bag_offsets)
+    ctx.table_id, ctx.mean = table_id, mean
+
+
+def _backward_pooled(ctx, grad_out):
+    keys, bag_offsets = ctx.saved_tensors
+    apply_grad_pooled(keys, bag_offsets, grad_out.contiguous(), ctx.table_id, ctx.mean)
+    return None, None, None, None, None
+
+
+lookup_pooled.register_autograd(_backward_pooled, setup_context=_setup_pooled)
+
+
 # ---- the same pair of ops over a TableGroup: the whole embedding collection of a model in one lookup / one update -------
 @torch.library.custom_op("meepo::lookup_jagged", mutates_args=())
 def lookup_jagged(keys: torch.Tensor, offsets: torch.Tensor, anchor: torch.Tensor, table_id: int, insert_missing: bool) -> torch.Tensor:
@@ -144,6 +193,23 @@ class DynamicEmbeddingCollection(torch.nn.Module, _SparseOptimizerSettings):
 
     def forward(self, keys: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
         return lookup_jagged(keys, offsets, self._anchor, self.table_id, self.training)
+
+
+class DynamicEmbeddingBag(torch.nn.Module, _SparseOptimizerSettings):
+    """torch.nn.EmbeddingBag over a lookup table: (keys [n], bag_offsets [n_bags + 1], both on the device) -> [n_bags, dim]
+    sums or means; backward runs the table's sparse optimizer with the bag's grad row for every member (no [n, dim]
+    tensor exists in either direction).  Ids must be in the table (find_or_insert / insert them first): absent ids read the
+    default row and are not trained."""
+
+    def __init__(self, table, mode: str = "sum", optimizer: str = "adagrad", lr: float = 0.01, eps: float | None = None, betas=(0.9, 0.999)):
+        super().__init__()
+        if mode not in ("sum", "mean"):
+            raise ValueError("mode must be 'sum' or 'mean'")
+        self.table, self.mode = table, mode
+        self._init_settings(optimizer, lr, eps, betas)
+
+    def forward(self, keys: torch.Tensor, bag_offsets: torch.Tensor) -> torch.Tensor:
+        return lookup_pooled(keys, bag_offsets, self._anchor, self.table_id, self.mode == "mean")
 
 
 class DynamicEmbedding(torch.nn.Module):

@@ -105,3 +105,35 @@ def test_collection_layer_trains_like_per_table_layers(dev):
         assert torch.equal(ex[0][ix], ey[0][iy]) and x.size() > 0
         torch.testing.assert_close(ex[1][ix], ey[1][iy], rtol=1e-6, atol=1e-9)
         torch.testing.assert_close(ex[2][ix], ey[2][iy], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["sum", "mean"])
+def test_embedding_bag_layer_trains_like_torch_embedding_bag(dev, mode):
+    """DynamicEmbeddingBag (fused pooled lookup + indexed sparse Adagrad) == torch.nn.EmbeddingBag(sparse=True) + Adagrad."""
+    from meepoembedding_amd import OPT_ADAGRAD, LookupTable
+    from meepoembedding_amd.nn import DynamicEmbeddingBag
+    torch.manual_seed(2)
+    vocab, dim, steps, n_bags = 300, 16, 5, 40
+    keys = torch.from_numpy(synth.keys_np(45, 0, vocab))
+    w0 = torch.rand(vocab, dim) - 0.5
+    head = torch.randn(dim, 1) * 0.1
+    ref = torch.nn.EmbeddingBag(vocab, dim, mode=mode, sparse=True)
+    with torch.no_grad():
+        ref.weight.copy_(w0)
+    opt = torch.optim.Adagrad(ref.parameters(), lr=0.05, eps=1e-10, initial_accumulator_value=0.1)
+    table = LookupTable(2048, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=4096, initial_accumulator=0.1)
+    table.insert(keys.to(dev), w0.to(dev))
+    layer = DynamicEmbeddingBag(table, mode=mode, lr=0.05, eps=1e-10).to(dev)
+    for s in range(steps):
+        lens = torch.randint(1, 9, (n_bags,))          # torch's EmbeddingBag mean of an empty bag differs in backward: keep bags non-empty
+        ids = torch.randint(0, vocab, (int(lens.sum()),))
+        off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens, 0)])
+        target = torch.randn(n_bags, 1)
+        opt.zero_grad()
+        ((ref(ids, off[:-1]) @ head - target) ** 2).mean().backward()
+        opt.step()
+        ((layer(keys[ids].to(dev), off.to(dev)) @ head.to(dev) - target.to(dev)) ** 2).mean().backward()
+    got, found = table.find(keys.to(dev))
+    assert bool(found.all())
+    np.testing.assert_allclose(got.cpu().numpy(), ref.weight.detach().numpy(), rtol=2e-5, atol=1e-6)
