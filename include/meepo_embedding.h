@@ -175,6 +175,18 @@ int mee_group_apply_adagrad(mee_group* g, const int64_t* d_keys, const uint64_t*
 int mee_group_apply_adam(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr,
                          float beta1, float beta2, float eps, uint64_t step, void* stream);
 
+/* The embedding-bag collection: every member table serves `bags_per_table` bags (one per sample of the batch), bag b belongs
+ * to member b / bags_per_table, d_bag_offsets holds n_tables x bags_per_table + 1 key offsets (device) and d_out one pooled row
+ * per bag — mee_find_pooled on every member, in one launch.  Backward: mee_apply_*_indexed on every member in the usual 7
+ * launches; d_grad_index[i] = the bag of key position i, d_bag_grads = [n_bags, dim] (pre-scaled by 1/length for MEAN). */
+int mee_group_find_pooled(mee_group* g, const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t bags_per_table,
+                          float* d_out, uint8_t* d_found, int mode, void* stream);
+int mee_group_apply_adagrad_pooled(mee_group* g, const int64_t* d_keys, const uint64_t* d_bag_offsets, size_t bags_per_table,
+                                   const float* d_bag_grads, const uint32_t* d_grad_index, size_t n, float lr, float eps, void* stream);
+int mee_group_apply_adam_pooled(mee_group* g, const int64_t* d_keys, const uint64_t* d_bag_offsets, size_t bags_per_table,
+                                const float* d_bag_grads, const uint32_t* d_grad_index, size_t n, float lr, float beta1, float beta2,
+                                float eps, uint64_t step, void* stream);
+
 /* ---- sparse optimizers (north_star "sparse-optimizer (Adagrad/Adam) scatter-update"; SPEC.md §4) -------- */
 int mee_apply_adagrad(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps,
                       void* stream);

@@ -31,10 +31,10 @@ __global__ __launch_bounds__(256) void find_grouped_kernel(const GroupDesc* __re
                                                            const uint64_t* __restrict__ offsets, const int64_t* __restrict__ keys,
                                                            uint64_t n, float4* __restrict__ out, uint8_t* __restrict__ found,
                                                            uint32_t dim4_rt, int64_t* __restrict__ gslot = nullptr,
-                                                           const GroupInit* __restrict__ init = nullptr) {
+                                                           const GroupInit* __restrict__ init = nullptr, uint64_t off_stride = 1) {
     __shared__ uint64_t loff[kMaxGroupTables + 1];
-    for (uint32_t j = threadIdx.x; j <= n_tables; j += blockDim.x) loff[j] = offsets[j];
-    __syncthreads();
+    for (uint32_t j = threadIdx.x; j <= n_tables; j += blockDim.x) loff[j] = offsets[(uint64_t)j * off_stride];  // stride > 1: the
+    __syncthreads();                                                     // segment bounds are every stride-th entry of a bag-offset array
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -212,8 +212,8 @@ int group_refresh(mee_group* g, void* stream) {
         }
     return MEE_OK;
 }
-int group_locate(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, int64_t* d_gslot, hipStream_t st) {
-    find_grouped_kernel<0, 2, false, true><<<grid_for(n, 32, 8192), 256, 0, st>>>(g->d_desc, g->n_tables, d_offsets, d_keys, n, nullptr, nullptr, g->dim4, d_gslot, g->d_init);
+int group_locate(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, uint64_t off_stride, size_t n, int64_t* d_gslot, hipStream_t st) {
+    find_grouped_kernel<0, 2, false, true><<<grid_for(n, 32, 8192), 256, 0, st>>>(g->d_desc, g->n_tables, d_offsets, d_keys, n, nullptr, nullptr, g->dim4, d_gslot, g->d_init, off_stride);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }

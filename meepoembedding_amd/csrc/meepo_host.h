@@ -104,5 +104,5 @@ struct mee_group {
 };
 namespace mee {
 int group_refresh(mee_group* g, void* stream);   // re-upload descriptors of members whose planes moved
-int group_locate(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, int64_t* d_gslot, hipStream_t st);
+int group_locate(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, uint64_t off_stride, size_t n, int64_t* d_gslot, hipStream_t st);
 }

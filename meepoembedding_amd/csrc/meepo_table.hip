@@ -262,22 +262,31 @@ __device__ __forceinline__ void pooled_fetch(const int64_t* __restrict__ tkeys, 
 
 // BPW = bags per wave: 4 = the hybrid above (batches of mostly short bags), 1 = every bag gets a whole wave (batches whose
 // AVERAGE bag is long: a wave that had to walk four long bags one after the other would be latency-bound).
-template <int DIM4, int U, int BPW>
-__global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restrict__ tkeys, const float4* __restrict__ values,
-                                                          uint64_t nb, const int64_t* __restrict__ keys,
+// GROUPED (mee_group_find_pooled): bag b belongs to member table b / bags_per_table; the planes come from its descriptor.
+template <int DIM4, int U, int BPW, bool GROUPED = false>
+__global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restrict__ tkeys_, const float4* __restrict__ values_,
+                                                          uint64_t nb_, const int64_t* __restrict__ keys,
                                                           const uint64_t* __restrict__ offsets, uint64_t n_bags,
                                                           float4* __restrict__ out, uint8_t* __restrict__ found, float defv,
-                                                          uint32_t dim4_rt, int mean) {
+                                                          uint32_t dim4_rt, int mean, const GroupDesc* __restrict__ desc = nullptr,
+                                                          uint64_t bags_per_table = 1) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
     const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
     constexpr int C = DIM4 ? DIM4 / 16 : 16;   // float4 per lane per row (any dim: up to 1024 floats = 16 per lane)
-    const float4 def4 = make_float4(defv, defv, defv, defv);
     for (uint64_t b0 = wave * BPW; b0 < n_bags; b0 += n_waves * BPW) {
         const uint64_t bag = BPW == 4 ? b0 + tile : b0;
         const bool has = bag < n_bags;
         const uint64_t begin = has ? offsets[bag] : 0, end = has ? offsets[bag + 1] : 0;
+        const int64_t* tkeys = tkeys_;
+        const float4* values = values_;
+        uint64_t nb = nb_;
+        float4 def4 = make_float4(defv, defv, defv, defv);
+        if constexpr (GROUPED) {
+            const GroupDesc d = desc[(has ? bag : 0) / bags_per_table];
+            tkeys = d.tkeys; values = d.values; nb = d.nb; def4 = make_float4(d.defv, d.defv, d.defv, d.defv);
+        }
         const bool is_long = BPW == 1 || end - begin >= kPoolLong;
         float4 acc[C];
         float4 row[U][C];
@@ -323,6 +332,10 @@ __global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restr
         for (int q = 0; q < BPW; ++q) {
             if (!((long_mask >> (q * 16)) & 1)) continue;   // wave-uniform
             const uint64_t bq = __shfl(begin, q * 16), eq = __shfl(end, q * 16);
+            if constexpr (GROUPED && BPW == 4) {   // all four tiles work for bag q's table now
+                const GroupDesc d = desc[(b0 + q) / bags_per_table];
+                tkeys = d.tkeys; values = d.values; nb = d.nb; def4 = make_float4(d.defv, d.defv, d.defv, d.defv);
+            }
             bool first = true;
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1577,12 +1590,14 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     return MEE_OK;
 }
 
+static OptArgs adam_args(float lr, float beta1, float beta2, float eps, uint64_t step);
+
 // ---- grouped apply: ONE sparse-optimizer step over the jagged batch of a whole group (meepo_group.hip holds the group) ----
 // locate (member << 48 | slot per position) -> the ordinary group / plan passes with the located rows as "keys" (two
 // occurrences of a key of one table are the same row; keys of different tables never collide) -> the three apply passes
 // with the probe replaced by decoding the located row.  The group's scratch table lends the group table / lists / counters.
 static int group_apply_common(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n,
-                              const OptArgs& a, void* stream, const char* name) {
+                              const OptArgs& a, void* stream, const char* name, uint64_t off_stride = 1, const uint32_t* d_gidx = nullptr) {
     if (!g || !d_offsets || (n && (!d_keys || !d_grads))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
     if (!g->scratch) return fail(MEE_ERR_UNSUPPORTED, "%s: group was created with max_apply_batch = 0 or its tables have no optimizer", name);
     if (g->optimizer != a.kind) return fail(MEE_ERR_UNSUPPORTED, "%s: the group's tables were created with optimizer=%u", name, g->optimizer);
@@ -1593,16 +1608,16 @@ static int group_apply_common(mee_group* g, const int64_t* d_keys, const uint64_
     hipStream_t st = as_stream(stream);
     mee_table* t = g->scratch;
     const uint32_t nn = (uint32_t)n;
-    if (int rc = group_locate(g, d_keys, d_offsets, n, g->d_gslot, st)) return rc;
+    if (int rc = group_locate(g, d_keys, d_offsets, off_stride, n, g->d_gslot, st)) return rc;
     if (int rc = apply_prepare_launch(t, g->d_gslot, nn, st)) return rc;
     const unsigned gs = grid_for(n, 32, 1u << 16);
-#define GSINGLE(K, D4) apply_single_kernel<K, D4, 2, true><<<gs, 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, g->d_gslot, (const float4*)d_grads, nn, t->g, t->bs, a, g->d_desc)
+#define GSINGLE(K, D4) apply_single_kernel<K, D4, 2, true><<<gs, 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, g->d_gslot, (const float4*)d_grads, nn, t->g, t->bs, a, g->d_desc, d_gidx)
 #define GSINGLE_D(K) do { if (g->dim4 == 16) GSINGLE(K, 16); else if (g->dim4 == 32) GSINGLE(K, 32); else GSINGLE(K, 0); } while (0)
     if (a.kind == MEE_OPT_ADAGRAD) GSINGLE_D(MEE_OPT_ADAGRAD); else GSINGLE_D(MEE_OPT_ADAM);
 #undef GSINGLE_D
 #undef GSINGLE
     apply_chunk_kernel<true><<<grid_for(n, 16, 2048), 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, g->d_gslot, (const float4*)d_grads,
-                                                                  t->g, t->bs, t->op, a, g->d_desc);
+                                                                  t->g, t->bs, t->op, a, g->d_desc, d_gidx);
     apply_big_kernel<true><<<grid_for(n / kChunk + 1, 1, 1024), 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, t->g, t->bs, t->op, a, g->d_desc);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
@@ -1623,6 +1638,42 @@ int mee_group_apply_adam(mee_group* g, const int64_t* d_keys, const uint64_t* d_
     a.step_size = (float)((double)lr * sqrt(bc2) / bc1);  // SPEC.md §4
     a.omb1 = 1.0f - beta1; a.omb2 = 1.0f - beta2;
     return group_apply_common(g, d_keys, d_offsets, d_grads, n, a, stream, "mee_group_apply_adam");
+}
+
+// ---- the embedding-bag collection: pooled lookups of a whole group in one launch, and their backward -----------------------
+int mee_group_find_pooled(mee_group* g, const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t bags_per_table,
+                          float* d_out, uint8_t* d_found, int mode, void* stream) {
+    if (!g || (bags_per_table && (!d_bag_offsets || !d_out || !d_keys))) return fail(MEE_ERR_INVALID_ARG, "mee_group_find_pooled: null argument");
+    if (mode != MEE_POOL_SUM && mode != MEE_POOL_MEAN) return fail(MEE_ERR_INVALID_ARG, "mee_group_find_pooled: mode must be MEE_POOL_SUM or MEE_POOL_MEAN");
+    if (bags_per_table == 0) return MEE_OK;
+    if (int rc = group_refresh(g, stream)) return rc;
+    DeviceGuard guard(g->device);
+    hipStream_t st = as_stream(stream);
+    const uint64_t n_bags = (uint64_t)g->n_tables * bags_per_table;
+    const bool wave_per_bag = n / n_bags >= 12;
+#define GPOOLED(D4, U1, U4) do { if (wave_per_bag) find_pooled_kernel<D4, U1, 1, true><<<grid_for(n_bags, 4, 1u << 20), 256, 0, st>>>(nullptr, nullptr, 0, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, 0.f, g->dim4, mode == MEE_POOL_MEAN, g->d_desc, bags_per_table); \
+                                 else find_pooled_kernel<D4, U4, 4, true><<<grid_for(n_bags, 16, 1u << 20), 256, 0, st>>>(nullptr, nullptr, 0, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, 0.f, g->dim4, mode == MEE_POOL_MEAN, g->d_desc, bags_per_table); } while (0)
+    if (g->dim4 == 16) GPOOLED(16, 4, 2); else if (g->dim4 == 32) GPOOLED(32, 2, 1); else GPOOLED(0, 1, 1);
+#undef GPOOLED
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+int mee_group_apply_adagrad_pooled(mee_group* g, const int64_t* d_keys, const uint64_t* d_bag_offsets, size_t bags_per_table,
+                                   const float* d_bag_grads, const uint32_t* d_grad_index, size_t n, float lr, float eps, void* stream) {
+    if (n && (!d_grad_index || !bags_per_table)) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adagrad_pooled: null index / zero bags_per_table");
+    OptArgs a{};
+    a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps;
+    // the members' key segments are bounded by every bags_per_table-th bag offset
+    return group_apply_common(g, d_keys, d_bag_offsets, d_bag_grads, n, a, stream, "mee_group_apply_adagrad_pooled", bags_per_table, d_grad_index);
+}
+int mee_group_apply_adam_pooled(mee_group* g, const int64_t* d_keys, const uint64_t* d_bag_offsets, size_t bags_per_table,
+                                const float* d_bag_grads, const uint32_t* d_grad_index, size_t n, float lr, float beta1, float beta2,
+                                float eps, uint64_t step, void* stream) {
+    if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adam_pooled: step must be >= 1");
+    if (n && (!d_grad_index || !bags_per_table)) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adam_pooled: null index / zero bags_per_table");
+    return group_apply_common(g, d_keys, d_bag_offsets, d_bag_grads, n, adam_args(lr, beta1, beta2, eps, step), stream,
+                              "mee_group_apply_adam_pooled", bags_per_table, d_grad_index);
 }
 
 int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* stream) {

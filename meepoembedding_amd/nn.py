@@ -97,7 +97,10 @@ def apply_grad_pooled(keys: torch.Tensor, bag_offsets: torch.Tensor, grad_bags: 
     if mean:   # d mean / d row = 1 / length for every member of the bag
         g = g / lens.clamp(min=1).to(torch.float32)[:, None]
     layer.step += 1
-    if layer.optimizer == "adagrad":
+    if hasattr(layer.table, "apply_pooled"):   # a TableGroup: the whole collection in one step
+        layer.table.apply_pooled(keys, bag_offsets, g, bag_of, layer.optimizer, lr=layer.lr, eps=layer.eps, beta1=layer.betas[0],
+                                 beta2=layer.betas[1], step=layer.step)
+    elif layer.optimizer == "adagrad":
         layer.table.apply_adagrad(keys, g, lr=layer.lr, eps=layer.eps, grad_index=bag_of)
     else:
         layer.table.apply_adam(keys, g, lr=layer.lr, beta1=layer.betas[0], beta2=layer.betas[1], eps=layer.eps, step=layer.step,
@@ -196,8 +199,9 @@ class DynamicEmbeddingCollection(torch.nn.Module, _SparseOptimizerSettings):
 
 
 class DynamicEmbeddingBag(torch.nn.Module, _SparseOptimizerSettings):
-    """torch.nn.EmbeddingBag over a lookup table: (keys [n], bag_offsets [n_bags + 1], both on the device) -> [n_bags, dim]
-    sums or means; backward runs the table's sparse optimizer with the bag's grad row for every member (no [n, dim]
+    """torch.nn.EmbeddingBag over a lookup table — or over a TableGroup, which makes it an embedding-bag COLLECTION: bag b
+    then belongs to member b // bags_per_table and the whole model's sparse forward is one launch, its backward seven.
+    (keys [n], bag_offsets [n_bags + 1], both on the device) -> [n_bags, dim] sums or means; backward runs the table's sparse optimizer with the bag's grad row for every member (no [n, dim]
     tensor exists in either direction).  Ids must be in the table (find_or_insert / insert them first): absent ids read the
     default row and are not trained."""
 

@@ -410,6 +410,42 @@ class TableGroup:
         check(_lib.lib().mee_group_apply_adam(self._h, k.data_ptr(), offsets.data_ptr(), g.data_ptr(), k.numel(), lr, beta1, beta2,
                                               eps, step, _stream_ptr(self.device)))
 
+    # -- the embedding-bag collection: bags_per_table bags per member, bag b belongs to member b // bags_per_table ---------
+    def _check_bags(self, bag_offsets: torch.Tensor) -> int:
+        nb = bag_offsets.numel() - 1
+        if bag_offsets.device != self.device or bag_offsets.dtype not in (torch.int64, torch.uint64) or not bag_offsets.is_contiguous() \
+                or nb < 0 or nb % len(self.tables):
+            raise MeepoError(_lib.ERR_INVALID_ARG, f"bag_offsets must be contiguous int64 on {self.device} with n_tables * bags_per_table + 1 entries")
+        return nb // len(self.tables)
+
+    def find_pooled(self, keys: torch.Tensor, bag_offsets: torch.Tensor, mode: str = "sum", out: torch.Tensor | None = None,
+                    found: torch.Tensor | None = None):
+        """find_pooled of every member in one launch -> ([n_tables * bags_per_table, dim], per-key found mask)."""
+        bpt = self._check_bags(bag_offsets)
+        k = self.tables[0]._keys(keys) if keys.numel() else keys
+        if out is None:
+            out = torch.empty((bpt * len(self.tables), self.dim), dtype=torch.float32, device=self.device)
+        if found is None:
+            found = torch.empty(k.numel(), dtype=torch.uint8, device=self.device)
+        check(_lib.lib().mee_group_find_pooled(self._h, k.data_ptr(), k.numel(), bag_offsets.data_ptr(), bpt, out.data_ptr(), found.data_ptr(),
+                                               {"sum": 0, "mean": 1}[mode], _stream_ptr(self.device)))
+        return out, found
+
+    def apply_pooled(self, keys: torch.Tensor, bag_offsets: torch.Tensor, bag_grads: torch.Tensor, bag_of_position: torch.Tensor,
+                     optimizer: str, lr: float, eps: float | None = None, beta1: float = 0.9, beta2: float = 0.999, step: int = 1) -> None:
+        """Backward of find_pooled over the group: one optimizer step, position i takes row bag_of_position[i] of bag_grads."""
+        bpt = self._check_bags(bag_offsets)
+        k = self.tables[0]._keys(keys) if keys.numel() else keys
+        gi = self.tables[0]._grad_index(bag_of_position, k.numel())
+        g = bag_grads.contiguous()
+        L, s = _lib.lib(), _stream_ptr(self.device)
+        if optimizer == "adagrad":
+            check(L.mee_group_apply_adagrad_pooled(self._h, k.data_ptr(), bag_offsets.data_ptr(), bpt, g.data_ptr(), gi.data_ptr(), k.numel(),
+                                                   lr, 1e-10 if eps is None else eps, s))
+        else:
+            check(L.mee_group_apply_adam_pooled(self._h, k.data_ptr(), bag_offsets.data_ptr(), bpt, g.data_ptr(), gi.data_ptr(), k.numel(),
+                                                lr, beta1, beta2, 1e-8 if eps is None else eps, step, s))
+
     def find_or_insert(self, keys: torch.Tensor, offsets: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None):
         """find that first creates absent keys in their member table (initial row / state); found = present before."""
         return self.find(keys, offsets, out, found, _fn="mee_group_find_or_insert")

@@ -805,3 +805,66 @@ def test_indexed_apply_is_apply_of_gathered_grads(dev, opt):
         if x is not None:
             np.testing.assert_allclose(x.cpu()[ia].numpy(), y.cpu()[ib].numpy(), rtol=RTOL, atol=ATOL)
             np.testing.assert_allclose(x.cpu()[ia].numpy(), z[io], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("dim,mode,opt", [(64, "sum", "adagrad"), (128, "mean", "adam"), (24, "sum", "adagrad")])
+def test_group_pooled_equals_per_table_pooled(dev, dim, mode, opt):
+    """The embedding-bag collection: mee_group_find_pooled == find_pooled per member (bit-exact), and its backward
+    (mee_group_apply_*_pooled) == apply_*_indexed per member == the oracle."""
+    from meepoembedding_amd import TableGroup
+    rng = np.random.default_rng(dim + 1)
+    kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
+    n_tables, bpt = 4, 37
+    a, b, o, univ = [], [], [], []
+    for j in range(n_tables):
+        cap = int(rng.integers(1000, 4000))
+        u = synth.keys_np(900 + j, 0, int(cap * 0.6))
+        rows = rng.standard_normal((u.size, dim)).astype(np.float32)
+        kw = dict(default_value=0.25 * j, initial_accumulator=0.1)
+        x = LookupTable(cap, dim, device=dev, optimizer=kind, max_batch=1 << 14, **kw)
+        y = LookupTable(cap, dim, device=dev, optimizer=kind, max_batch=1 << 14, **kw)
+        z = oracle.OracleTable(cap, dim, optimizer=okind, **kw)
+        x.insert(T(u, dev), T(rows, dev)); y.insert(T(u, dev), T(rows, dev)); z.insert(u, rows)
+        a.append(x); b.append(y); o.append(z); univ.append(u)
+    grp = TableGroup(a, max_apply_batch=1 << 14)
+    for step, long_bags in ((1, False), (2, True)):          # both launch shapes of the pooled kernel
+        lens = rng.integers(8, 40, n_tables * bpt) if long_bags else rng.integers(0, 7, n_tables * bpt)
+        lens[3] = 0; lens[bpt] = 25
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        segs = []
+        for j in range(n_tables):
+            m = int(off[(j + 1) * bpt] - off[j * bpt])
+            k = univ[j][np.minimum(rng.zipf(1.3, m) - 1, univ[j].size - 1)].copy()
+            if m > 3:
+                k[1] = synth.keys_np(997, j, 1)[0]          # absent
+            segs.append(k)
+        keys = np.concatenate(segs)
+        out, found = grp.find_pooled(T(keys, dev), T(off, dev), mode)
+        out, found = out.cpu().numpy(), found.cpu().numpy()
+        for j in range(n_tables):
+            lo, hi = off[j * bpt], off[(j + 1) * bpt]
+            er, ef = o[j].find(keys[lo:hi])
+            assert np.array_equal(found[lo:hi], ef)
+            assert np.array_equal(out[j * bpt:(j + 1) * bpt], oracle.pool_rows(er, off[j * bpt:(j + 1) * bpt + 1] - lo, mode))
+        bag_grads = (rng.standard_normal((n_tables * bpt, dim)) * 0.05).astype(np.float32)
+        bag_of = np.repeat(np.arange(lens.size), lens).astype(np.int64)
+        kwargs = dict(lr=0.05) if opt == "adagrad" else dict(lr=0.01, step=step)
+        grp.apply_pooled(T(keys, dev), T(off, dev), T(bag_grads, dev), T(bag_of, dev), opt, **kwargs)
+        for j in range(n_tables):
+            lo, hi = off[j * bpt], off[(j + 1) * bpt]
+            if hi == lo:
+                continue
+            kj, gj = keys[lo:hi], bag_grads[bag_of[lo:hi]]
+            if opt == "adagrad":
+                b[j].apply_adagrad(T(kj, dev), T(bag_grads, dev), lr=0.05, grad_index=T(bag_of[lo:hi], dev)); o[j].apply_adagrad(kj, gj, 0.05, 1e-10)
+            else:
+                b[j].apply_adam(T(kj, dev), T(bag_grads, dev), lr=0.01, step=step, grad_index=T(bag_of[lo:hi], dev)); o[j].apply_adam(kj, gj, 0.01, 0.9, 0.999, 1e-8, step)
+    for j in range(n_tables):
+        ga = [x.cpu().numpy() for x in a[j].export(with_state=True) if x is not None]
+        gb = [x.cpu().numpy() for x in b[j].export(with_state=True) if x is not None]
+        go = [x for x in o[j].export(with_state=True) if x is not None]
+        ia, ib, io = np.argsort(ga[0]), np.argsort(gb[0]), np.argsort(go[0])
+        for x, y, z in zip(ga[1:], gb[1:], go[1:]):
+            np.testing.assert_allclose(x[ia], y[ib], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(x[ia], z[io], rtol=RTOL, atol=ATOL)
+    grp.close()

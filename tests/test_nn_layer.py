@@ -137,3 +137,35 @@ def test_embedding_bag_layer_trains_like_torch_embedding_bag(dev, mode):
     got, found = table.find(keys.to(dev))
     assert bool(found.all())
     np.testing.assert_allclose(got.cpu().numpy(), ref.weight.detach().numpy(), rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_embedding_bag_collection_layer(dev):
+    """DynamicEmbeddingBag over a TableGroup (one pooled launch, one grouped optimizer step) == one bag layer per table."""
+    from meepoembedding_amd import OPT_ADAGRAD, LookupTable, TableGroup
+    from meepoembedding_amd.nn import DynamicEmbeddingBag
+    torch.manual_seed(3)
+    dim, n_tables, bpt, steps = 16, 3, 20, 3
+    mk = lambda: LookupTable(2048, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=4096, initial_accumulator=0.1)
+    a, b = [mk() for _ in range(n_tables)], [mk() for _ in range(n_tables)]
+    univ = [torch.from_numpy(synth.keys_np(120 + j, 0, 200)).to(dev) for j in range(n_tables)]
+    for j in range(n_tables):
+        w = torch.rand(200, dim, device=dev) - 0.5
+        a[j].insert(univ[j], w); b[j].insert(univ[j], w)
+    coll = DynamicEmbeddingBag(TableGroup(a, max_apply_batch=4096), mode="mean", lr=0.05).to(dev)
+    solo = [DynamicEmbeddingBag(t, mode="mean", lr=0.05).to(dev) for t in b]
+    head = torch.randn(dim, 1, device=dev) * 0.1
+    for s in range(steps):
+        lens = torch.randint(1, 7, (n_tables * bpt,))
+        off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens, 0)]).to(dev)
+        segs = [univ[j][torch.randint(0, 200, (int(lens[j * bpt:(j + 1) * bpt].sum()),)).to(dev)] for j in range(n_tables)]
+        keys = torch.cat(segs)
+        target = torch.randn(n_tables * bpt, 1, device=dev)
+        ((coll(keys, off) @ head - target) ** 2).mean().backward()
+        pooled = torch.cat([solo[j](segs[j], off[j * bpt:(j + 1) * bpt + 1] - off[j * bpt]) for j in range(n_tables)])
+        ((pooled @ head - target) ** 2).mean().backward()
+    for x, y in zip(a, b):
+        ex, ey = x.export(with_state=True), y.export(with_state=True)
+        ix, iy = torch.argsort(ex[0]), torch.argsort(ey[0])
+        torch.testing.assert_close(ex[1][ix], ey[1][iy], rtol=1e-6, atol=1e-9)
+        torch.testing.assert_close(ex[2][ix], ey[2][iy], rtol=1e-6, atol=1e-9)
