@@ -122,6 +122,28 @@ def two_stream_extra(table, batches, dim, dev, bpl, launches=400):
     return {"lookups_per_s": batch / dt, "us_per_batch": dt * 1e6, "frac_of_hbm_roofline": batch * bpl / dt / 1e9 / HBM_PEAK_GBS}
 
 
+def p2p_selftest(ctrl, log, timeout=120) -> bool:
+    """tools/p2p_selftest.py in one child per rank (own gloo group, same GPUs); True only if every child exits 0."""
+    import subprocess
+    # the children rendezvous among themselves: their rank 0 hosts a store of its own (torchrun's agent store is not theirs)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29531")) + 17)
+    t0 = time.time()
+    err = b""
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "p2p_selftest.py")], env=env, timeout=timeout,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        rc, err = p.returncode, p.stderr
+    except subprocess.TimeoutExpired as e:
+        rc, err = -9, e.stderr or b""
+    if rc != 0:
+        print(f"[bench] p2p self-test child of rank {os.environ.get('RANK', '0')} rc={rc}: {err.decode(errors='replace')[-800:]}", file=sys.stderr, flush=True)
+    ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=ctrl)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    log(f"p2p self-test: rc={rc} on this rank, {'passed on all ranks' if int(ok.item()) else 'FAILED somewhere -> rccl all-to-all'} ({time.time() - t0:.1f}s)")
+    return bool(int(ok.item()))
+
+
 def train_step_extra(find_table, synth, n_keys, dim, dev, chunk, batches, out, found, bpl, steps=100):
     """configs[2] on the same box, reported beside the headline: find + sparse-Adagrad apply per step."""
     from meepoembedding_amd import OPT_ADAGRAD, LookupTable
@@ -179,6 +201,7 @@ def main():
                          "auto = verify p2p against rccl, time both for a few steps, keep the faster")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N>1 flow on a box with fewer GPUs than ranks (exchange staged through host memory)")
+    ap.add_argument("--no-selftest", action="store_true", help="sharded only: skip the child-process self-test of the peer-mapped transport")
     ap.add_argument("--dedup", action="store_true", help="sharded only: exchange only the batch's distinct keys (pays off on skewed streams)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even at N=1 (rehearsal of the N>1 code)")
     ap.add_argument("--verbose", action="store_true")
@@ -248,7 +271,12 @@ def main():
                 return shs[i % depth].find(batches[i % n_batches], dedup=args.dedup)
 
         step, transport = step_rccl, "rccl all-to-all"
-        if args.transport in ("auto", "p2p") and not args.dedup and depth == 1:
+        p2p_ok = args.transport in ("auto", "p2p") and not args.dedup and depth == 1
+        if p2p_ok and not args.no_selftest:
+            # the peer-mapped path stores into other GPUs' memory from hand-written kernels: prove it on THIS topology in
+            # throw-away child processes first, so that a fault or hang there costs the fallback, not the run
+            p2p_ok = p2p_selftest(ctrl, log)
+        if p2p_ok:
             from meepoembedding_amd.p2p import PeerShardedFind
             peer = None
             try:
