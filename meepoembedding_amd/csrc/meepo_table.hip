@@ -219,15 +219,14 @@ constexpr uint32_t kPoolLong = 16;
 // probe + row load of up to U keys per tile (the find_kernel pattern); row[u] is only defined where inb[u]
 template <int DIM4, int U, int C>
 __device__ __forceinline__ void pooled_fetch(const int64_t* __restrict__ tkeys, const float4* __restrict__ values, uint64_t nb,
-                                             uint32_t dim4, const int64_t* __restrict__ keys, const uint64_t (&pos)[U],
+                                             uint32_t dim4, const int64_t (&key)[U], const uint64_t (&pos)[U],
                                              const bool (&inb)[U], int tile, int tl, float4 def4, float4 (&row)[U][C],
                                              uint8_t* __restrict__ found) {
-    int64_t key[U], slot[U], kb[U];
+    int64_t slot[U], kb[U];
     uint64_t bk[U];
     bool act[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        key[u] = inb[u] ? keys[pos[u]] : kEmpty;
         act[u] = inb[u] && !reserved_key(key[u]);
         bk[u] = bucket_of(key[u], nb);
         kb[u] = act[u] ? tkeys[bk[u] * kW + tl] : kEmpty;
@@ -296,12 +295,18 @@ __global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restr
             bool first = true;
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            // a short bag has fewer than 16 keys: its tile fetches them all with one coalesced load, lane tl holds key begin + tl
+            const int64_t kpre = (!is_long && begin + tl < end) ? keys[begin + tl] : kEmpty;
             while (__any(i < end)) {  // wave-uniform; tiles whose bag is done idle through the ballots
                 uint64_t pos[U];
+                int64_t kv[U];
                 bool inb[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) { pos[u] = i + u; inb[u] = pos[u] < end; }
-                pooled_fetch<DIM4, U, C>(tkeys, values, nb, dim4, keys, pos, inb, tile, tl, def4, row, found);
+                for (int u = 0; u < U; ++u) {
+                    pos[u] = i + u; inb[u] = pos[u] < end;
+                    kv[u] = __shfl(kpre, tile * 16 + (int)((pos[u] - begin) & 15));
+                }
+                pooled_fetch<DIM4, U, C>(tkeys, values, nb, dim4, kv, pos, inb, tile, tl, def4, row, found);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (!inb[u]) continue;
@@ -341,10 +346,11 @@ __global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restr
             for (int c = 0; c < C; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
             for (uint64_t i = bq; i < eq; i += 4 * U) {   // wave-uniform
                 uint64_t pos[U];
+                int64_t kv[U];
                 bool inb[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) { pos[u] = i + (uint64_t)u * 4 + tile; inb[u] = pos[u] < eq; }
-                pooled_fetch<DIM4, U, C>(tkeys, values, nb, dim4, keys, pos, inb, tile, tl, def4, row, found);
+                for (int u = 0; u < U; ++u) { pos[u] = i + (uint64_t)u * 4 + tile; inb[u] = pos[u] < eq; kv[u] = inb[u] ? keys[pos[u]] : kEmpty; }
+                pooled_fetch<DIM4, U, C>(tkeys, values, nb, dim4, kv, pos, inb, tile, tl, def4, row, found);
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
