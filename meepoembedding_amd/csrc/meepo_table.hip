@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
                         out[i * dim4 + c] = slot[r] >= 0 ? values[(uint64_t)slot[r] * dim4 + c] : def4;
             }
         }
-        if (found) {
+        if (found && !(NT & 32)) {  // NT&32: rows only (last pass of find_or_insert: found keeps meaning "present before")
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint64_t i0 = base + r * 4;
@@ -203,6 +203,44 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
                     if (inb[r] && tl == 0 && (!(NT & 8) || slot[r] >= 0)) found[i] = slot[r] >= 0;
                 }
             }
+        }
+    }
+}
+
+// ---- sparse second pass (SPEC.md §3 find_missing; last pass of find_or_insert): only positions whose found byte is 0 -----
+// A wave reads 64 keys + found bytes with one coalesced load each and leaves at once when nothing is missing (the common
+// case: a hot tier that holds the working set, a trained vocabulary); the missing ones are probed four at a time.
+// FLAGS bit 0: set found[i] = 1 where the key is stored here (tier pass; off = rows only), bit 1: count the hit.
+template <int FLAGS>
+__global__ __launch_bounds__(256) void find_missing_kernel(const int64_t* __restrict__ tkeys, const float4* __restrict__ values,
+                                                           uint64_t nb, uint32_t dim4, const int64_t* __restrict__ keys, uint64_t n,
+                                                           float4* __restrict__ out, uint8_t* __restrict__ found, uint32_t* hits) {
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t base = wave * 64; base < n; base += n_waves * 64) {
+        const uint64_t i = base + lane;
+        const int64_t k = i < n ? keys[i] : kEmpty;
+        uint64_t rest = __ballot(i < n && found[i] == 0 && !reserved_key(k));
+        while (rest) {  // wave-uniform
+            uint64_t mm = rest;
+            int p = -1;
+            for (int q = 0; q <= tile; ++q) {
+                if (mm) { p = __ffsll((unsigned long long)mm) - 1; mm &= mm - 1; } else p = -1;
+            }
+            const int64_t key = __shfl(k, p >= 0 ? p : 0);
+            bool is_new, full;
+            const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, p >= 0, tile, tl, is_new, full);
+            if (p >= 0 && slot >= 0) {
+                const uint64_t dst = (base + (uint64_t)p) * dim4, src = (uint64_t)slot * dim4;
+                for (uint32_t c = tl; c < dim4; c += 16) out[dst + c] = values[src + c];
+                if (tl == 0) {
+                    if (FLAGS & 1) found[base + p] = 1;
+                    if (FLAGS & 2) atomicAdd(&hits[slot], 1u);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rest &= rest - 1;
         }
     }
 }
@@ -591,60 +629,50 @@ __global__ __launch_bounds__(256) void remove_mark_kernel(int64_t* tkeys, const 
     if (i < n && slot_in[i] >= 0) tkeys[slot_in[i]] = kReclaimed;
 }
 
-// ---- find_or_insert (SPEC.md §3) ---------------------------------------------------------------------------
-constexpr long long kPresentBit = 1ll << 62;
-
-__global__ __launch_bounds__(256) void ensure_kernel(int64_t* tkeys, float4* values, float4* s1, float4* s2, uint64_t nb,
-                                                     uint32_t dim4, const int64_t* __restrict__ keys, uint32_t n,
-                                                     const uint32_t* __restrict__ hidx, const uint32_t* __restrict__ sval,
-                                                     long long* sres, uint32_t optimizer, float init_acc,
-                                                     uint32_t initializer, float init_scale, uint64_t init_seed,
-                                                     float default_value, Counters* ctr, uint32_t* hits) {
+// ---- find_or_insert (SPEC.md §3), middle pass: every position the find pass left missing claims its key's slot (or finds
+// it, when another occurrence of the key got there first: the CAS decides the one creator); the creating tile writes the
+// hashed initial row, the initial optimizer state and a zero hit counter.  A wave with nothing missing leaves at once —
+// the steady state of a trained vocabulary costs one pass over keys + found.  The rows are read by a last find pass.
+__global__ __launch_bounds__(256) void ensure_direct_kernel(int64_t* tkeys, float4* values, float4* s1, float4* s2, uint64_t nb,
+                                                            uint32_t dim4, const int64_t* __restrict__ keys, uint32_t n,
+                                                            const uint8_t* __restrict__ found, uint32_t optimizer, float init_acc,
+                                                            uint32_t initializer, float init_scale, uint64_t init_seed,
+                                                            float default_value, Counters* ctr, uint32_t* hits) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t base = wave * 4; base < n; base += n_waves * 4) {
-        const uint32_t i = base + tile;
-        const bool inb = i < n;
-        const int64_t key = inb ? keys[i] : kEmpty;
-        const uint32_t h = inb ? hidx[i] : kNoGroup;
-        const bool winner = h != kNoGroup && sval[h] == i + 1;
-        bool is_new, full;
-        const int64_t slot = tile_locate<true, true>(tkeys, nb, key, winner, tile, tl, is_new, full);
-        if (hits && winner && slot >= 0 && is_new && tl == 0) hits[slot] = 0;
-        if (winner && slot >= 0 && is_new) {
-            for (uint32_t c = tl; c < dim4; c += 16) {
-                values[(uint64_t)slot * dim4 + c] = initial_row4(key, c * 4, initializer, init_scale, init_seed, default_value);
-                if (optimizer == MEE_OPT_ADAGRAD) s1[(uint64_t)slot * dim4 + c] = make_float4(init_acc, init_acc, init_acc, init_acc);
-                if (optimizer == MEE_OPT_ADAM) {
-                    s1[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    s2[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+    for (uint32_t base = wave * 64; base < n; base += n_waves * 64) {
+        // 64 positions per wave step: one coalesced load of keys and found bytes, then the missing ones four at a time
+        const uint32_t i = base + lane;
+        const int64_t k = i < n ? keys[i] : kEmpty;
+        const bool miss = i < n && found[i] == 0;
+        if (miss && k == kReclaimed) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);  // EMPTY = padding, silent
+        uint64_t rest = __ballot(miss && !reserved_key(k));
+        while (rest) {  // wave-uniform
+            uint64_t mm = rest;
+            int p = -1;
+            for (int q = 0; q <= tile; ++q) {
+                if (mm) { p = __ffsll((unsigned long long)mm) - 1; mm &= mm - 1; } else p = -1;
             }
+            const int64_t key = __shfl(k, p >= 0 ? p : 0);
+            bool is_new, full;
+            const int64_t slot = tile_locate<true, true>(tkeys, nb, key, p >= 0, tile, tl, is_new, full);
+            if (p >= 0 && slot >= 0 && is_new) {
+                for (uint32_t c = tl; c < dim4; c += 16) {
+                    values[(uint64_t)slot * dim4 + c] = initial_row4(key, c * 4, initializer, init_scale, init_seed, default_value);
+                    if (optimizer == MEE_OPT_ADAGRAD) s1[(uint64_t)slot * dim4 + c] = make_float4(init_acc, init_acc, init_acc, init_acc);
+                    if (optimizer == MEE_OPT_ADAM) {
+                        s1[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        s2[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+                if (hits && tl == 0) hits[slot] = 0;
+            }
+            const uint64_t fm = __ballot(full);
+            if (lane == 0 && fm) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_TABLE_FULL);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rest &= rest - 1;
         }
-        if (winner && tl == 0) sres[h] = slot < 0 ? -1ll : ((long long)slot | (is_new ? 0ll : kPresentBit));
-        const uint64_t fm = __ballot(full);
-        if (lane == 0 && fm) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_TABLE_FULL);
-    }
-}
-
-// second half of find_or_insert: every position that took part in the insert pass (i.e. was missing before the call)
-// copies its group's row; positions served by the first (plain find) pass are left alone
-__global__ __launch_bounds__(256) void gather_group_kernel(const float4* __restrict__ values, uint32_t dim4, uint32_t n,
-                                                           const uint32_t* __restrict__ hidx,
-                                                           const long long* __restrict__ sres, float4* __restrict__ out) {
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t base = wave * 4; base < n; base += n_waves * 4) {
-        const uint32_t i = base + tile;
-        if (i >= n) continue;
-        const uint32_t h = hidx[i];
-        if (h == kNoGroup) continue;
-        const long long res = sres[h];
-        if (res < 0) continue;  // table full: the default row written by the find pass stays
-        const long long slot = res & ~kPresentBit;
-        for (uint32_t c = tl; c < dim4; c += 16) out[(uint64_t)i * dim4 + c] = values[(uint64_t)slot * dim4 + c];
     }
 }
 
@@ -1324,7 +1352,7 @@ static const float* plane_of(const mee_table* t, uint32_t plane) {
 }
 
 static int find_plane(const mee_table* t, const float* plane, float miss_value, const int64_t* d_keys, size_t n, float* d_out,
-                      uint8_t* d_found, void* stream, bool missing_only = false, bool counted = false) {
+                      uint8_t* d_found, void* stream, bool missing_only = false, bool counted = false, bool rows_only = false) {
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -1336,11 +1364,16 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
 #define FIND1(D4, RR, NT) find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr)
     const int nt = t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
 #define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
-    if (missing_only || counted) {  // sparse second pass / sampled statistics pass: one key in flight per tile
+    if (missing_only) {
+        const unsigned gm = grid_for(n, 256, 8192);
+#define FMISS(F) find_missing_kernel<F><<<gm, 256, 0, st>>>(t->keys, (const float4*)plane, t->nb, t->dim4, d_keys, n, (float4*)d_out, d_found, t->hits)
+        if (rows_only) FMISS(0); else if (counted) FMISS(3); else FMISS(1);
+#undef FMISS
+    } else if (counted) {  // sampled statistics pass: one key in flight per tile
         const unsigned g1 = grid_for(n, 16, 1u << 22);
 #define FINDX(D4, NT) find_kernel<D4, 1, NT><<<g1, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, t->hits)
 #define FINDX_D(NT) do { if (t->dim4 == 16) FINDX(16, NT); else if (t->dim4 == 32) FINDX(32, NT); else FINDX(0, NT); } while (0)
-        if (missing_only && counted) FINDX_D(28); else if (missing_only) FINDX_D(12); else FINDX_D(20);
+        FINDX_D(20);
 #undef FINDX_D
 #undef FINDX
     } else
@@ -1471,20 +1504,17 @@ static int find_or_insert_common(mee_table* t, const int64_t* d_keys, size_t n, 
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
-    const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
     // pass 1: a plain find serves every key that is already stored (the steady state of training) at find speed and
     // yields the "present before the call" mask; pass 2 runs the insert machinery over the missing positions only.
     uint8_t* fmask = d_found ? d_found : t->bs.fmask;
     if (own_find_pass)
         if (int rc = find_plane(t, t->values, t->default_value, d_keys, n, d_out, fmask, stream)) return rc;
-    group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, fmask);
-    ensure_kernel<<<gt, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys, nn, t->bs.hidx,
-                                      t->g.sval, t->g.sres, t->optimizer, t->init_acc, t->initializer, t->init_scale, t->init_seed,
-                                      t->default_value, t->ctr, t->hits);
-    gather_group_kernel<<<gt, 256, 0, st>>>((const float4*)t->values, t->dim4, nn, t->bs.hidx, t->g.sres, (float4*)d_out);
-    group_reset_kernel<<<gl, 256, 0, st>>>(t->bs.hidx, nn, t->g);
+    ensure_direct_kernel<<<grid_for(n, 256, 8192), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
+                                                                d_keys, nn, fmask, t->optimizer, t->init_acc, t->initializer, t->init_scale,
+                                                                t->init_seed, t->default_value, t->ctr, t->hits);
     MEE_HIP(hipGetLastError());
-    return MEE_OK;
+    // pass 3: the positions that were missing read their (created or already racing-created) row; the mask is left alone
+    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, fmask, stream, /*missing_only=*/true, /*counted=*/false, /*rows_only=*/true);
 }
 
 int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
