@@ -156,7 +156,9 @@ int mee_clear_status(mee_table* t, void* stream);
  * DEVICE memory, n = total positions (host value; positions outside [d_offsets[0], d_offsets[n_tables]) are left
  * untouched).  Results are identical to mee_find on each table with its segment; the launch latency floor is paid once
  * instead of n_tables times.  Asynchronous on `stream`; after mee_reserve on a member the next call re-reads that
- * table's planes (one stream synchronisation).  The group does not own the tables: destroy it before them. */
+ * table's planes (one stream synchronisation).  The group does not own the tables: destroy it before them.  Calls on one
+ * group that use its scratch (mee_group_find_or_insert without d_found, mee_group_apply_*) must be ordered by the caller;
+ * mee_find_grouped / mee_group_find_pooled calls may run concurrently on several streams. */
 typedef struct mee_group mee_group;
 int mee_group_create(mee_table* const* tables, uint32_t n_tables, uint64_t max_apply_batch, mee_group** out);
 int mee_group_destroy(mee_group* g);
