@@ -42,14 +42,25 @@ struct OpCounters {          // device-resident, zeroed at the start of each op 
 };
 struct GroupTable {            // S entries, indexed by h
     unsigned long long* skeys; // key ^ kBias, 0 = empty
-    uint32_t* sval;            // COUNT: occurrences added by blocks other than the claimer's | LAST: 1 + highest position
-    uint32_t* sval0;           // COUNT: occurrences inside the block whose CAS claimed the entry (plain store, no atomic)
+    // sv[2h] ("lo"): COUNT: occurrences added by blocks other than the claimer's (atomicAdd) | LAST: 1 + highest position seen by them (atomicMax)
+    // sv[2h+1] ("hi"): the same quantity of the block whose CAS claimed the entry — a plain store, no atomic.
+    // The pair is one aligned 8-byte word: readers take both halves with ONE load and a release is ONE store, so a reader
+    // racing with a release sees either the complete pair or zeros, never a mixture.
+    uint32_t* sv;
     uint32_t* soffs;           // start of the group's slice of the occurrence list
     uint32_t* sbig;            // first fp64 partial-sum row of a group with more than kChunk occurrences
     uint32_t* sgrp;            // index of the group in the unique list (standalone dedup)
     long long* sres;           // find_or_insert: slot | present<<62, -1 = not stored
     uint64_t smask;
 };
+__device__ __forceinline__ void sv_load(const GroupTable& g, uint32_t h, uint32_t& lo, uint32_t& hi) {
+    const unsigned long long w = reinterpret_cast<const unsigned long long*>(g.sv)[h];
+    lo = (uint32_t)w; hi = (uint32_t)(w >> 32);
+}
+__device__ __forceinline__ void group_release_entry(const GroupTable& g, uint32_t h) {
+    g.skeys[h] = 0;
+    reinterpret_cast<unsigned long long*>(g.sv)[h] = 0ull;
+}
 struct BatchScratch {          // max_batch entries, indexed by batch position unless noted
     uint32_t *hidx, *rank, *pcnt, *occ, *uniq_h, *work;
     uint8_t* fmask;            // found mask of find_or_insert's first pass when the caller passes none
@@ -431,9 +442,9 @@ __device__ __forceinline__ uint32_t group_claim(const GroupTable& g, int64_t key
     }
 }
 
-constexpr int kGroupLast = 0;   // sval = 1 + highest batch position of the key (last occurrence wins)
-constexpr int kGroupCount = 1;  // sval0 + sval = occurrence count, rank[i] = arrival order (finalised by the plan pass)
-constexpr uint32_t kRankRemote = 0x80000000u;  // rank was handed out by an atomic on sval: add sval0 to finalise
+constexpr int kGroupLast = 0;   // max(lo, hi) = 1 + highest batch position of the key (last occurrence wins)
+constexpr int kGroupCount = 1;  // lo + hi = occurrence count, rank[i] = arrival order (finalised by the plan pass)
+constexpr uint32_t kRankRemote = 0x80000000u;  // rank was handed out by an atomic on lo: add hi to finalise
 constexpr int kLds = 512;       // block-local aggregation table (256 threads -> at most 256 distinct keys)
 
 // One lane per batch position.  Occurrences of the same key inside a 256-thread block are first combined in an
@@ -473,10 +484,13 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
         lh[slot] = h;
         if constexpr (MODE == kGroupCount) {
             const uint32_t total = lval[slot];
-            if (claimed) { g.sval0[h] = total; lbase[slot] = 0; }
-            else lbase[slot] = atomicAdd(&g.sval[h], total) | kRankRemote;
+            if (claimed) { g.sv[2 * h + 1] = total; lbase[slot] = 0; }
+            else lbase[slot] = atomicAdd(&g.sv[2 * h], total) | kRankRemote;
         } else {
-            atomicMax(&g.sval[h], lval[slot]);
+            // the block whose CAS created the entry parks its candidate in the hi half with a plain store; only later arrivals
+            // pay an atomic.  Readers take max(lo, hi).  (Unique keys: one atomic per key instead of two.)
+            if (claimed) g.sv[2 * h + 1] = lval[slot];
+            else atomicMax(&g.sv[2 * h], lval[slot]);
         }
     }
     __syncthreads();
@@ -521,8 +535,10 @@ __global__ __launch_bounds__(1024) void group_plan_kernel(uint32_t n, GroupTable
     const bool valid = h != kNoGroup;
     uint32_t cnt = 0, r = 0;
     if (valid) {
-        const uint32_t c0 = g.sval0[h], rk = bs.rank[i];
-        cnt = c0 + g.sval[h];
+        uint32_t lo, c0;
+        sv_load(g, h, lo, c0);
+        const uint32_t rk = bs.rank[i];
+        cnt = c0 + lo;
         r = (rk & ~kRankRemote) + ((rk & kRankRemote) ? c0 : 0);
         bs.rank[i] = r;
     }
@@ -555,7 +571,7 @@ __global__ __launch_bounds__(256) void group_reset_kernel(const uint32_t* __rest
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t h = hidx[i];
-    if (h != kNoGroup) { g.skeys[h] = 0; g.sval[h] = 0; g.sval0[h] = 0; }
+    if (h != kNoGroup) group_release_entry(g, h);
 }
 
 // ---- insert / assign (SPEC.md §3) --------------------------------------------------------------------------
@@ -564,7 +580,7 @@ template <bool CLAIM>
 __global__ __launch_bounds__(256) void upsert_kernel(int64_t* tkeys, float4* values, float4* s1, float4* s2, uint64_t nb,
                                                      uint32_t dim4, const int64_t* __restrict__ keys,
                                                      const float4* __restrict__ vals, uint32_t n,
-                                                     const uint32_t* __restrict__ hidx, const uint32_t* __restrict__ sval,
+                                                     const uint32_t* __restrict__ hidx, GroupTable g,
                                                      uint8_t* found, uint32_t optimizer, float init_acc, Counters* ctr, uint32_t* hits) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -575,7 +591,9 @@ __global__ __launch_bounds__(256) void upsert_kernel(int64_t* tkeys, float4* val
         const int64_t key = inb ? keys[i] : kEmpty;
         const uint32_t h = inb ? hidx[i] : kNoGroup;
         const bool valid = h != kNoGroup;
-        const bool winner = valid && sval[h] == i + 1;
+        uint32_t last_lo = 0, last_hi = 0;
+        if (valid) sv_load(g, h, last_lo, last_hi);   // one 8-byte load: the complete pair, or zeros once the winner released it
+        const bool winner = valid && max(last_lo, last_hi) == i + 1;
         bool is_new, full;
         // insert: only winners touch the table.  assign: every occurrence probes (keys do not change) so that
         // found[] is exact for all of them; only the winner writes.
@@ -719,7 +737,7 @@ __device__ __forceinline__ int64_t resolve_row(const int64_t* tkeys, uint64_t nb
     }
 }
 
-__device__ __forceinline__ void group_release(const GroupTable& g, uint32_t h) { g.skeys[h] = 0; g.sval[h] = 0; g.sval0[h] = 0; }
+__device__ __forceinline__ void group_release(const GroupTable& g, uint32_t h) { group_release_entry(g, h); }
 
 // Pass 1 over batch positions: a key that occurs once is updated right here from its own grad row (the common
 // case) and its group-table entry is returned to empty; occurrences of multi-keys are filed into their group's
@@ -871,7 +889,9 @@ __global__ __launch_bounds__(256) void apply_big_kernel(const int64_t* __restric
     const uint32_t n_big = op->n_big;
     for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {  // block-uniform
         const uint32_t h = bs.bigh[b];
-        const uint32_t cnt = g.sval0[h] + g.sval[h];
+        uint32_t cnt_lo, cnt_hi;
+        sv_load(g, h, cnt_lo, cnt_hi);
+        const uint32_t cnt = cnt_lo + cnt_hi;
         const uint32_t n_rows = (cnt + kChunk - 1) / kChunk, row0 = g.sbig[h];
         const int64_t key = (int64_t)(g.skeys[h] ^ kBias);
         RowPlanes pl{values, s1, s2};   // GROUPED: every thread decodes the same (member, slot); else tile 0 probes
@@ -928,7 +948,9 @@ __global__ __launch_bounds__(256) void dedup_emit_kernel(uint32_t dim4, const fl
         const uint32_t u = base + tile;
         if (u >= nu) continue;
         const uint32_t h = bs.uniq_h[u];
-        const uint32_t cnt = g.sval0[h] + g.sval[h];
+        uint32_t cnt_lo, cnt_hi;
+        sv_load(g, h, cnt_lo, cnt_hi);
+        const uint32_t cnt = cnt_lo + cnt_hi;
         const uint32_t off = g.soffs[h];
         if (grads && gsum_out) {
             for (uint32_t c = tl; c < dim4; c += 16) {
@@ -1149,7 +1171,7 @@ int mee_table_destroy(mee_table* t) {
     float* planes[] = {t->values, t->s1, t->s2};
     for (float* p : planes)
         if (p) { if (t->value_memory == MEE_MEM_HOST_PINNED) (void)hipHostFree(p); else (void)hipFree(p); }
-    void* dev[] = {t->keys, t->hits, t->g.skeys, t->g.sval, t->g.sval0, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
+    void* dev[] = {t->keys, t->hits, t->g.skeys, t->g.sv, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
                    t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.work, t->bs.fmask, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (t->h_ctr) (void)hipHostFree(t->h_ctr);
@@ -1231,7 +1253,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     if (t->optimizer != MEE_OPT_NONE) ALLOC_PLANE(t->s1);
     if (t->optimizer == MEE_OPT_ADAM) ALLOC_PLANE(t->s2);
 #undef ALLOC_PLANE
-    ALLOC(t->g.skeys, S * 8); ALLOC(t->g.sval, S * 4); ALLOC(t->g.sval0, S * 4); ALLOC(t->g.soffs, S * 4); ALLOC(t->g.sgrp, S * 4);
+    ALLOC(t->g.skeys, S * 8); ALLOC(t->g.sv, S * 8); ALLOC(t->g.soffs, S * 4); ALLOC(t->g.sgrp, S * 4);
     ALLOC(t->g.sbig, S * 4); ALLOC(t->g.sres, S * 8);
     ALLOC(t->bs.hidx, mb * 4); ALLOC(t->bs.rank, mb * 4); ALLOC(t->bs.pcnt, mb * 4); ALLOC(t->bs.occ, mb * 4); ALLOC(t->bs.uniq_h, mb * 4);
     ALLOC(t->bs.work, mb * 4); ALLOC(t->bs.fmask, mb);
@@ -1252,8 +1274,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess && t->hits) e = hipMemsetAsync(t->hits, 0, t->capacity * sizeof(uint32_t), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.skeys, 0, S * 8, 0);
-        if (e == hipSuccess) e = hipMemsetAsync(t->g.sval, 0, S * 4, 0);
-        if (e == hipSuccess) e = hipMemsetAsync(t->g.sval0, 0, S * 4, 0);
+        if (e == hipSuccess) e = hipMemsetAsync(t->g.sv, 0, S * 8, 0);
         if (e == hipSuccess && t->bs.gacc) e = hipMemsetAsync(t->bs.gacc, 0, t->max_big * (uint64_t)t->dim * sizeof(double), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->ctr, 0, sizeof(Counters), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->op, 0, sizeof(OpCounters), 0);
@@ -1454,10 +1475,13 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
     group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, skip);
     if (claim)
         upsert_kernel<true><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
-                                                (const float4*)d_values, nn, t->bs.hidx, t->g.sval, nullptr, t->optimizer, t->init_acc, t->ctr, t->hits);
+                                                (const float4*)d_values, nn, t->bs.hidx, t->g, nullptr, t->optimizer, t->init_acc, t->ctr, t->hits);
     else
         upsert_kernel<false><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
-                                                 (const float4*)d_values, nn, t->bs.hidx, t->g.sval, d_found, t->optimizer, t->init_acc, t->ctr, t->hits);
+                                                 (const float4*)d_values, nn, t->bs.hidx, t->g, d_found, t->optimizer, t->init_acc, t->ctr, t->hits);
+    // (releasing the entries from inside upsert_kernel — the winner is their last reader — was tried instead of this pass:
+    //  eager runs were clean, but a hipGraph replay of find + apply + insert faulted on its second launch; not understood,
+    //  so the separate pass stays)
     group_reset_kernel<<<gl, 256, 0, st>>>(t->bs.hidx, nn, t->g);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
