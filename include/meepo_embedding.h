@@ -180,14 +180,18 @@ int mee_group_apply_adam(mee_group* g, const int64_t* d_keys, const uint64_t* d_
 /* The embedding-bag collection: every member table serves `bags_per_table` bags (one per sample of the batch), bag b belongs
  * to member b / bags_per_table, d_bag_offsets holds n_tables x bags_per_table + 1 key offsets (device) and d_out one pooled row
  * per bag — mee_find_pooled on every member, in one launch.  Backward: mee_apply_*_indexed on every member in the usual 7
- * launches; d_grad_index[i] = the bag of key position i, d_bag_grads = [n_bags, dim] (pre-scaled by 1/length for MEAN). */
+ * launches; d_grad_index[i] = the bag of key position i, d_bag_grads = [n_bags, dim] (pre-scaled by 1/length for MEAN).
+ * d_located_out / d_located (nullable, int64[n]): the forward can hand the rows it located (opaque per-position handles) to
+ * the backward of the SAME step, which then skips its own probe pass (6 launches).  The handles are only valid while no
+ * key of the batch is removed, no member is rehashed and no slot they name is reused: i.e. forward -> backward. */
 int mee_group_find_pooled(mee_group* g, const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t bags_per_table,
-                          float* d_out, uint8_t* d_found, int mode, void* stream);
+                          float* d_out, uint8_t* d_found, int64_t* d_located_out, int mode, void* stream);
 int mee_group_apply_adagrad_pooled(mee_group* g, const int64_t* d_keys, const uint64_t* d_bag_offsets, size_t bags_per_table,
-                                   const float* d_bag_grads, const uint32_t* d_grad_index, size_t n, float lr, float eps, void* stream);
+                                   const float* d_bag_grads, const uint32_t* d_grad_index, const int64_t* d_located, size_t n, float lr,
+                                   float eps, void* stream);
 int mee_group_apply_adam_pooled(mee_group* g, const int64_t* d_keys, const uint64_t* d_bag_offsets, size_t bags_per_table,
-                                const float* d_bag_grads, const uint32_t* d_grad_index, size_t n, float lr, float beta1, float beta2,
-                                float eps, uint64_t step, void* stream);
+                                const float* d_bag_grads, const uint32_t* d_grad_index, const int64_t* d_located, size_t n, float lr,
+                                float beta1, float beta2, float eps, uint64_t step, void* stream);
 
 /* ---- sparse optimizers (north_star "sparse-optimizer (Adagrad/Adam) scatter-update"; SPEC.md §4) -------- */
 int mee_apply_adagrad(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps,

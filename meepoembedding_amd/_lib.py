@@ -74,9 +74,9 @@ PROTOTYPES = {
     "mee_find_or_insert": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_export": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), _vp]),
     "mee_group_create": (C.c_int, [C.POINTER(_vp), _u32, _u64, C.POINTER(_vp)]),
-    "mee_group_find_pooled": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, C.c_int, _vp]),
-    "mee_group_apply_adagrad_pooled": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _f32, _f32, _vp]),
-    "mee_group_apply_adam_pooled": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
+    "mee_group_find_pooled": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, C.c_int, _vp]),
+    "mee_group_apply_adagrad_pooled": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _f32, _f32, _vp]),
+    "mee_group_apply_adam_pooled": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
     "mee_group_find_or_insert": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_group_apply_adagrad": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _vp]),
     "mee_group_apply_adam": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),

@@ -270,7 +270,7 @@ template <int DIM4, int U, int C>
 __device__ __forceinline__ void pooled_fetch(const int64_t* __restrict__ tkeys, const float4* __restrict__ values, uint64_t nb,
                                              uint32_t dim4, const int64_t (&key)[U], const uint64_t (&pos)[U],
                                              const bool (&inb)[U], int tile, int tl, float4 def4, float4 (&row)[U][C],
-                                             uint8_t* __restrict__ found) {
+                                             uint8_t* __restrict__ found, int64_t* __restrict__ located = nullptr, uint64_t member = 0) {
     int64_t slot[U], kb[U];
     uint64_t bk[U];
     bool act[U];
@@ -305,6 +305,8 @@ __device__ __forceinline__ void pooled_fetch(const int64_t* __restrict__ tkeys, 
             if (DIM4 != 0 || (uint32_t)(c * 16 + tl) < dim4)
                 row[u][c] = slot[u] >= 0 ? values[(uint64_t)slot[u] * dim4 + c * 16 + tl] : def4;
         if (found && inb[u] && tl == 0) found[pos[u]] = slot[u] >= 0;
+        // the located row (member << 48 | slot, EMPTY when absent): lets the backward skip its own probe pass
+        if (located && inb[u] && tl == 0) located[pos[u]] = slot[u] >= 0 ? (int64_t)((member << kGroupSlotBits) | (uint64_t)slot[u]) : kEmpty;
     }
 }
 
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restr
                                                           const uint64_t* __restrict__ offsets, uint64_t n_bags,
                                                           float4* __restrict__ out, uint8_t* __restrict__ found, float defv,
                                                           uint32_t dim4_rt, int mean, const GroupDesc* __restrict__ desc = nullptr,
-                                                          uint64_t bags_per_table = 1) {
+                                                          uint64_t bags_per_table = 1, int64_t* __restrict__ located = nullptr) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -331,8 +333,10 @@ __global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restr
         const float4* values = values_;
         uint64_t nb = nb_;
         float4 def4 = make_float4(defv, defv, defv, defv);
+        uint64_t member = 0;
         if constexpr (GROUPED) {
-            const GroupDesc d = desc[(has ? bag : 0) / bags_per_table];
+            member = (has ? bag : 0) / bags_per_table;
+            const GroupDesc d = desc[member];
             tkeys = d.tkeys; values = d.values; nb = d.nb; def4 = make_float4(d.defv, d.defv, d.defv, d.defv);
         }
         const bool is_long = BPW == 1 || end - begin >= kPoolLong;
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restr
                     pos[u] = i + u; inb[u] = pos[u] < end;
                     kv[u] = __shfl(kpre, tile * 16 + (int)((pos[u] - begin) & 15));
                 }
-                pooled_fetch<DIM4, U, C>(tkeys, values, nb, dim4, kv, pos, inb, tile, tl, def4, row, found);
+                pooled_fetch<DIM4, U, C>(tkeys, values, nb, dim4, kv, pos, inb, tile, tl, def4, row, found, located, member);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (!inb[u]) continue;
@@ -387,7 +391,8 @@ __global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restr
             if (!((long_mask >> (q * 16)) & 1)) continue;   // wave-uniform
             const uint64_t bq = __shfl(begin, q * 16), eq = __shfl(end, q * 16);
             if constexpr (GROUPED && BPW == 4) {   // all four tiles work for bag q's table now
-                const GroupDesc d = desc[(b0 + q) / bags_per_table];
+                member = (b0 + q) / bags_per_table;
+                const GroupDesc d = desc[member];
                 tkeys = d.tkeys; values = d.values; nb = d.nb; def4 = make_float4(d.defv, d.defv, d.defv, d.defv);
             }
             bool first = true;
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restr
                 bool inb[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) { pos[u] = i + (uint64_t)u * 4 + tile; inb[u] = pos[u] < eq; kv[u] = inb[u] ? keys[pos[u]] : kEmpty; }
-                pooled_fetch<DIM4, U, C>(tkeys, values, nb, dim4, kv, pos, inb, tile, tl, def4, row, found);
+                pooled_fetch<DIM4, U, C>(tkeys, values, nb, dim4, kv, pos, inb, tile, tl, def4, row, found, located, member);
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -1657,8 +1662,9 @@ static OptArgs adam_args(float lr, float beta1, float beta2, float eps, uint64_t
 // occurrences of a key of one table are the same row; keys of different tables never collide) -> the three apply passes
 // with the probe replaced by decoding the located row.  The group's scratch table lends the group table / lists / counters.
 static int group_apply_common(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n,
-                              const OptArgs& a, void* stream, const char* name, uint64_t off_stride = 1, const uint32_t* d_gidx = nullptr) {
-    if (!g || !d_offsets || (n && (!d_keys || !d_grads))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
+                              const OptArgs& a, void* stream, const char* name, uint64_t off_stride = 1, const uint32_t* d_gidx = nullptr,
+                              const int64_t* d_located = nullptr) {
+    if (!g || (!d_located && !d_offsets) || (n && ((!d_keys && !d_located) || !d_grads))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
     if (!g->scratch) return fail(MEE_ERR_UNSUPPORTED, "%s: group was created with max_apply_batch = 0 or its tables have no optimizer", name);
     if (g->optimizer != a.kind) return fail(MEE_ERR_UNSUPPORTED, "%s: the group's tables were created with optimizer=%u", name, g->optimizer);
     if (n > g->max_apply_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "%s: n=%zu exceeds the group's max_apply_batch=%llu", name, n, (unsigned long long)g->max_apply_batch);
@@ -1668,15 +1674,20 @@ static int group_apply_common(mee_group* g, const int64_t* d_keys, const uint64_
     hipStream_t st = as_stream(stream);
     mee_table* t = g->scratch;
     const uint32_t nn = (uint32_t)n;
-    if (int rc = group_locate(g, d_keys, d_offsets, off_stride, n, g->d_gslot, st)) return rc;
-    if (int rc = apply_prepare_launch(t, g->d_gslot, nn, st)) return rc;
+    // the located rows of the batch: handed over by the forward lookup of the same step, or found by a probe pass of our own
+    const int64_t* gslot = d_located;
+    if (!gslot) {
+        if (int rc = group_locate(g, d_keys, d_offsets, off_stride, n, g->d_gslot, st)) return rc;
+        gslot = g->d_gslot;
+    }
+    if (int rc = apply_prepare_launch(t, gslot, nn, st)) return rc;
     const unsigned gs = grid_for(n, 32, 1u << 16);
-#define GSINGLE(K, D4) apply_single_kernel<K, D4, 2, true><<<gs, 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, g->d_gslot, (const float4*)d_grads, nn, t->g, t->bs, a, g->d_desc, d_gidx)
+#define GSINGLE(K, D4) apply_single_kernel<K, D4, 2, true><<<gs, 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, gslot, (const float4*)d_grads, nn, t->g, t->bs, a, g->d_desc, d_gidx)
 #define GSINGLE_D(K) do { if (g->dim4 == 16) GSINGLE(K, 16); else if (g->dim4 == 32) GSINGLE(K, 32); else GSINGLE(K, 0); } while (0)
     if (a.kind == MEE_OPT_ADAGRAD) GSINGLE_D(MEE_OPT_ADAGRAD); else GSINGLE_D(MEE_OPT_ADAM);
 #undef GSINGLE_D
 #undef GSINGLE
-    apply_chunk_kernel<true><<<grid_for(n, 16, 2048), 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, g->d_gslot, (const float4*)d_grads,
+    apply_chunk_kernel<true><<<grid_for(n, 16, 2048), 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, gslot, (const float4*)d_grads,
                                                                   t->g, t->bs, t->op, a, g->d_desc, d_gidx);
     apply_big_kernel<true><<<grid_for(n / kChunk + 1, 1, 1024), 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, t->g, t->bs, t->op, a, g->d_desc);
     MEE_HIP(hipGetLastError());
@@ -1702,7 +1713,7 @@ int mee_group_apply_adam(mee_group* g, const int64_t* d_keys, const uint64_t* d_
 
 // ---- the embedding-bag collection: pooled lookups of a whole group in one launch, and their backward -----------------------
 int mee_group_find_pooled(mee_group* g, const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t bags_per_table,
-                          float* d_out, uint8_t* d_found, int mode, void* stream) {
+                          float* d_out, uint8_t* d_found, int64_t* d_located_out, int mode, void* stream) {
     if (!g || (bags_per_table && (!d_bag_offsets || !d_out || !d_keys))) return fail(MEE_ERR_INVALID_ARG, "mee_group_find_pooled: null argument");
     if (mode != MEE_POOL_SUM && mode != MEE_POOL_MEAN) return fail(MEE_ERR_INVALID_ARG, "mee_group_find_pooled: mode must be MEE_POOL_SUM or MEE_POOL_MEAN");
     if (bags_per_table == 0) return MEE_OK;
@@ -1711,8 +1722,8 @@ int mee_group_find_pooled(mee_group* g, const int64_t* d_keys, size_t n, const u
     hipStream_t st = as_stream(stream);
     const uint64_t n_bags = (uint64_t)g->n_tables * bags_per_table;
     const bool wave_per_bag = n / n_bags >= 12;
-#define GPOOLED(D4, U1, U4) do { if (wave_per_bag) find_pooled_kernel<D4, U1, 1, true><<<grid_for(n_bags, 4, 1u << 20), 256, 0, st>>>(nullptr, nullptr, 0, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, 0.f, g->dim4, mode == MEE_POOL_MEAN, g->d_desc, bags_per_table); \
-                                 else find_pooled_kernel<D4, U4, 4, true><<<grid_for(n_bags, 16, 1u << 20), 256, 0, st>>>(nullptr, nullptr, 0, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, 0.f, g->dim4, mode == MEE_POOL_MEAN, g->d_desc, bags_per_table); } while (0)
+#define GPOOLED(D4, U1, U4) do { if (wave_per_bag) find_pooled_kernel<D4, U1, 1, true><<<grid_for(n_bags, 4, 1u << 20), 256, 0, st>>>(nullptr, nullptr, 0, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, 0.f, g->dim4, mode == MEE_POOL_MEAN, g->d_desc, bags_per_table, d_located_out); \
+                                 else find_pooled_kernel<D4, U4, 4, true><<<grid_for(n_bags, 16, 1u << 20), 256, 0, st>>>(nullptr, nullptr, 0, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, 0.f, g->dim4, mode == MEE_POOL_MEAN, g->d_desc, bags_per_table, d_located_out); } while (0)
     if (g->dim4 == 16) GPOOLED(16, 4, 2); else if (g->dim4 == 32) GPOOLED(32, 2, 1); else GPOOLED(0, 1, 1);
 #undef GPOOLED
     MEE_HIP(hipGetLastError());
@@ -1720,20 +1731,22 @@ int mee_group_find_pooled(mee_group* g, const int64_t* d_keys, size_t n, const u
 }
 
 int mee_group_apply_adagrad_pooled(mee_group* g, const int64_t* d_keys, const uint64_t* d_bag_offsets, size_t bags_per_table,
-                                   const float* d_bag_grads, const uint32_t* d_grad_index, size_t n, float lr, float eps, void* stream) {
+                                   const float* d_bag_grads, const uint32_t* d_grad_index, const int64_t* d_located, size_t n, float lr,
+                                   float eps, void* stream) {
     if (n && (!d_grad_index || !bags_per_table)) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adagrad_pooled: null index / zero bags_per_table");
     OptArgs a{};
     a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps;
     // the members' key segments are bounded by every bags_per_table-th bag offset
-    return group_apply_common(g, d_keys, d_bag_offsets, d_bag_grads, n, a, stream, "mee_group_apply_adagrad_pooled", bags_per_table, d_grad_index);
+    return group_apply_common(g, d_keys, d_bag_offsets, d_bag_grads, n, a, stream, "mee_group_apply_adagrad_pooled", bags_per_table, d_grad_index,
+                              d_located);
 }
 int mee_group_apply_adam_pooled(mee_group* g, const int64_t* d_keys, const uint64_t* d_bag_offsets, size_t bags_per_table,
-                                const float* d_bag_grads, const uint32_t* d_grad_index, size_t n, float lr, float beta1, float beta2,
-                                float eps, uint64_t step, void* stream) {
+                                const float* d_bag_grads, const uint32_t* d_grad_index, const int64_t* d_located, size_t n, float lr,
+                                float beta1, float beta2, float eps, uint64_t step, void* stream) {
     if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adam_pooled: step must be >= 1");
     if (n && (!d_grad_index || !bags_per_table)) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adam_pooled: null index / zero bags_per_table");
     return group_apply_common(g, d_keys, d_bag_offsets, d_bag_grads, n, adam_args(lr, beta1, beta2, eps, step), stream,
-                              "mee_group_apply_adam_pooled", bags_per_table, d_grad_index);
+                              "mee_group_apply_adam_pooled", bags_per_table, d_grad_index, d_located);
 }
 
 int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* stream) {

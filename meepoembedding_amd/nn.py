@@ -77,19 +77,27 @@ lookup.register_autograd(_backward, setup_context=_setup)
 
 # ---- pooled: sum / mean per bag fused into the lookup, the bag's grad row indexed in the update ---------------------------
 @torch.library.custom_op("meepo::lookup_pooled", mutates_args=())
-def lookup_pooled(keys: torch.Tensor, bag_offsets: torch.Tensor, anchor: torch.Tensor, table_id: int, mean: bool) -> torch.Tensor:
+def lookup_pooled(keys: torch.Tensor, bag_offsets: torch.Tensor, anchor: torch.Tensor, table_id: int, mean: bool) -> tuple[torch.Tensor, torch.Tensor]:
+    """-> (pooled rows [n_bags, dim], located rows [n] — per-position handles the backward of this step reuses; empty for a
+    single table, whose apply probes for itself)"""
     layer = _layer(table_id)
+    if hasattr(layer.table, "apply_pooled"):   # a TableGroup
+        located = torch.empty(keys.numel(), dtype=torch.int64, device=keys.device)
+        out, _ = layer.table.find_pooled(keys, bag_offsets, "mean" if mean else "sum", located=located)
+        return out, located
     out, _ = layer.table.find_pooled(keys, bag_offsets, "mean" if mean else "sum")
-    return out
+    return out, keys.new_empty(0)
 
 
 @lookup_pooled.register_fake
 def _(keys, bag_offsets, anchor, table_id, mean):
-    return keys.new_empty((bag_offsets.numel() - 1, _layer(table_id).table.dim), dtype=torch.float32)
+    layer = _layer(table_id)
+    return (keys.new_empty((bag_offsets.numel() - 1, layer.table.dim), dtype=torch.float32),
+            keys.new_empty(keys.numel() if hasattr(layer.table, "apply_pooled") else 0))
 
 
 @torch.library.custom_op("meepo::apply_grad_pooled", mutates_args=())
-def apply_grad_pooled(keys: torch.Tensor, bag_offsets: torch.Tensor, grad_bags: torch.Tensor, table_id: int, mean: bool) -> None:
+def apply_grad_pooled(keys: torch.Tensor, bag_offsets: torch.Tensor, grad_bags: torch.Tensor, located: torch.Tensor, table_id: int, mean: bool) -> None:
     layer = _layer(table_id)
     lens = bag_offsets[1:] - bag_offsets[:-1]
     bag_of = torch.repeat_interleave(torch.arange(lens.numel(), device=keys.device), lens, output_size=keys.numel())
@@ -97,9 +105,9 @@ def apply_grad_pooled(keys: torch.Tensor, bag_offsets: torch.Tensor, grad_bags: 
     if mean:   # d mean / d row = 1 / length for every member of the bag
         g = g / lens.clamp(min=1).to(torch.float32)[:, None]
     layer.step += 1
-    if hasattr(layer.table, "apply_pooled"):   # a TableGroup: the whole collection in one step
+    if hasattr(layer.table, "apply_pooled"):   # a TableGroup: the whole collection in one step, on the rows the forward located
         layer.table.apply_pooled(keys, bag_offsets, g, bag_of, layer.optimizer, lr=layer.lr, eps=layer.eps, beta1=layer.betas[0],
-                                 beta2=layer.betas[1], step=layer.step)
+                                 beta2=layer.betas[1], step=layer.step, located=located if located.numel() == keys.numel() else None)
     elif layer.optimizer == "adagrad":
         layer.table.apply_adagrad(keys, g, lr=layer.lr, eps=layer.eps, grad_index=bag_of)
     else:
@@ -108,19 +116,20 @@ def apply_grad_pooled(keys: torch.Tensor, bag_offsets: torch.Tensor, grad_bags: 
 
 
 @apply_grad_pooled.register_fake
-def _(keys, bag_offsets, grad_bags, table_id, mean):
+def _(keys, bag_offsets, grad_bags, located, table_id, mean):
     return None
 
 
 def _setup_pooled(ctx, inputs, output):
     keys, bag_offsets, _, table_id, mean = inputs
-    ctx.save_for_backward(keys, bag_offsets)
+    ctx.save_for_backward(keys, bag_offsets, output[1])
     ctx.table_id, ctx.mean = table_id, mean
+    ctx.mark_non_differentiable(output[1])
 
 
-def _backward_pooled(ctx, grad_out):
-    keys, bag_offsets = ctx.saved_tensors
-    apply_grad_pooled(keys, bag_offsets, grad_out.contiguous(), ctx.table_id, ctx.mean)
+def _backward_pooled(ctx, grad_out, _grad_located):
+    keys, bag_offsets, located = ctx.saved_tensors
+    apply_grad_pooled(keys, bag_offsets, grad_out.contiguous(), located, ctx.table_id, ctx.mean)
     return None, None, None, None, None
 
 
@@ -213,7 +222,7 @@ class DynamicEmbeddingBag(torch.nn.Module, _SparseOptimizerSettings):
         self._init_settings(optimizer, lr, eps, betas)
 
     def forward(self, keys: torch.Tensor, bag_offsets: torch.Tensor) -> torch.Tensor:
-        return lookup_pooled(keys, bag_offsets, self._anchor, self.table_id, self.mode == "mean")
+        return lookup_pooled(keys, bag_offsets, self._anchor, self.table_id, self.mode == "mean")[0]
 
 
 class DynamicEmbedding(torch.nn.Module):

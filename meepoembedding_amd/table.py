@@ -419,8 +419,9 @@ class TableGroup:
         return nb // len(self.tables)
 
     def find_pooled(self, keys: torch.Tensor, bag_offsets: torch.Tensor, mode: str = "sum", out: torch.Tensor | None = None,
-                    found: torch.Tensor | None = None):
-        """find_pooled of every member in one launch -> ([n_tables * bags_per_table, dim], per-key found mask)."""
+                    found: torch.Tensor | None = None, located: torch.Tensor | None = None):
+        """find_pooled of every member in one launch -> ([n_tables * bags_per_table, dim], per-key found mask).
+        located (optional int64[n] buffer) receives the located rows for apply_pooled(located=...) of the same step."""
         bpt = self._check_bags(bag_offsets)
         k = self.tables[0]._keys(keys) if keys.numel() else keys
         if out is None:
@@ -428,22 +429,26 @@ class TableGroup:
         if found is None:
             found = torch.empty(k.numel(), dtype=torch.uint8, device=self.device)
         check(_lib.lib().mee_group_find_pooled(self._h, k.data_ptr(), k.numel(), bag_offsets.data_ptr(), bpt, out.data_ptr(), found.data_ptr(),
+                                               located.data_ptr() if located is not None else None,
                                                {"sum": 0, "mean": 1}[mode], _stream_ptr(self.device)))
         return out, found
 
     def apply_pooled(self, keys: torch.Tensor, bag_offsets: torch.Tensor, bag_grads: torch.Tensor, bag_of_position: torch.Tensor,
-                     optimizer: str, lr: float, eps: float | None = None, beta1: float = 0.9, beta2: float = 0.999, step: int = 1) -> None:
-        """Backward of find_pooled over the group: one optimizer step, position i takes row bag_of_position[i] of bag_grads."""
+                     optimizer: str, lr: float, eps: float | None = None, beta1: float = 0.9, beta2: float = 0.999, step: int = 1,
+                     located: torch.Tensor | None = None) -> None:
+        """Backward of find_pooled over the group: one optimizer step, position i takes row bag_of_position[i] of bag_grads.
+        located = the buffer the forward find_pooled of this step filled: skips the probe pass."""
         bpt = self._check_bags(bag_offsets)
         k = self.tables[0]._keys(keys) if keys.numel() else keys
         gi = self.tables[0]._grad_index(bag_of_position, k.numel())
         g = bag_grads.contiguous()
         L, s = _lib.lib(), _stream_ptr(self.device)
+        loc = located.data_ptr() if located is not None else None
         if optimizer == "adagrad":
-            check(L.mee_group_apply_adagrad_pooled(self._h, k.data_ptr(), bag_offsets.data_ptr(), bpt, g.data_ptr(), gi.data_ptr(), k.numel(),
+            check(L.mee_group_apply_adagrad_pooled(self._h, k.data_ptr(), bag_offsets.data_ptr(), bpt, g.data_ptr(), gi.data_ptr(), loc, k.numel(),
                                                    lr, 1e-10 if eps is None else eps, s))
         else:
-            check(L.mee_group_apply_adam_pooled(self._h, k.data_ptr(), bag_offsets.data_ptr(), bpt, g.data_ptr(), gi.data_ptr(), k.numel(),
+            check(L.mee_group_apply_adam_pooled(self._h, k.data_ptr(), bag_offsets.data_ptr(), bpt, g.data_ptr(), gi.data_ptr(), loc, k.numel(),
                                                 lr, beta1, beta2, 1e-8 if eps is None else eps, step, s))
 
     def find_or_insert(self, keys: torch.Tensor, offsets: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None):

@@ -839,7 +839,8 @@ def test_group_pooled_equals_per_table_pooled(dev, dim, mode, opt):
                 k[1] = synth.keys_np(997, j, 1)[0]          # absent
             segs.append(k)
         keys = np.concatenate(segs)
-        out, found = grp.find_pooled(T(keys, dev), T(off, dev), mode)
+        located = torch.empty(keys.size, dtype=torch.int64, device=dev) if long_bags else None   # second step: the forward hands its located rows over
+        out, found = grp.find_pooled(T(keys, dev), T(off, dev), mode, located=located)
         out, found = out.cpu().numpy(), found.cpu().numpy()
         for j in range(n_tables):
             lo, hi = off[j * bpt], off[(j + 1) * bpt]
@@ -849,7 +850,7 @@ def test_group_pooled_equals_per_table_pooled(dev, dim, mode, opt):
         bag_grads = (rng.standard_normal((n_tables * bpt, dim)) * 0.05).astype(np.float32)
         bag_of = np.repeat(np.arange(lens.size), lens).astype(np.int64)
         kwargs = dict(lr=0.05) if opt == "adagrad" else dict(lr=0.01, step=step)
-        grp.apply_pooled(T(keys, dev), T(off, dev), T(bag_grads, dev), T(bag_of, dev), opt, **kwargs)
+        grp.apply_pooled(T(keys, dev), T(off, dev), T(bag_grads, dev), T(bag_of, dev), opt, located=located, **kwargs)
         for j in range(n_tables):
             lo, hi = off[j * bpt], off[(j + 1) * bpt]
             if hi == lo:

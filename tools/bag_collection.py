@@ -33,9 +33,10 @@ for B in (512, 2048, 8192):
     bag_grads = torch.randn(T_ * B, dim, device=dev) * 0.01
     out = torch.empty((T_ * B, dim), device=dev); found = torch.empty(n, dtype=torch.uint8, device=dev)
     rows = torch.empty((B * L, dim), device=dev)
+    located = torch.empty(n, dtype=torch.int64, device=dev)
     def grouped(i):
-        grp.find_pooled(keys, off, "sum", out=out, found=found)
-        grp.apply_pooled(keys, off, bag_grads, bag_of, "adagrad", lr=0.01)
+        grp.find_pooled(keys, off, "sum", out=out, found=found, located=located)
+        grp.apply_pooled(keys, off, bag_grads, bag_of, "adagrad", lr=0.01, located=located)
     def looped(i):
         for j, t in enumerate(tables):
             t.find_pooled(segs[j], off1, "sum", out=out[j * B:(j + 1) * B], found=found[j * B * L:(j + 1) * B * L])
