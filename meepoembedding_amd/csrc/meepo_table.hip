@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restr
                                                           const uint64_t* __restrict__ offsets, uint64_t n_bags,
                                                           float4* __restrict__ out, uint8_t* __restrict__ found, float defv,
                                                           uint32_t dim4_rt, int mean, const GroupDesc* __restrict__ desc = nullptr,
-                                                          uint64_t bags_per_table = 1, int64_t* __restrict__ located = nullptr) {
+                                                          uint64_t bags_per_table = 1, int64_t* __restrict__ located = nullptr,
+                                                          uint64_t n_keys = ~0ull) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -328,7 +329,9 @@ __global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restr
     for (uint64_t b0 = wave * BPW; b0 < n_bags; b0 += n_waves * BPW) {
         const uint64_t bag = BPW == 4 ? b0 + tile : b0;
         const bool has = bag < n_bags;
-        const uint64_t begin = has ? offsets[bag] : 0, end = has ? offsets[bag + 1] : 0;
+        uint64_t begin = has ? offsets[bag] : 0, end = has ? offsets[bag + 1] : 0;
+        end = end < n_keys ? end : n_keys;          // offsets are the caller's: never read past the key array,
+        begin = begin < end ? begin : end;          // and a decreasing pair is an empty bag
         const int64_t* tkeys = tkeys_;
         const float4* values = values_;
         uint64_t nb = nb_;
@@ -1437,8 +1440,8 @@ int mee_find_pooled(const mee_table* t, const int64_t* d_keys, size_t n, const u
     hipStream_t st = as_stream(stream);
     // n (the number of keys, a host value) only picks the launch shape: mostly short bags -> four bags per wave, long average -> one
     const bool wave_per_bag = n / n_bags >= 12;
-#define POOLED(D4, U1, U4) do { if (wave_per_bag) find_pooled_kernel<D4, U1, 1><<<grid_for(n_bags, 4, 1u << 20), 256, 0, st>>>(t->keys, (const float4*)t->values, t->nb, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, t->default_value, t->dim4, mode == MEE_POOL_MEAN); \
-                                else find_pooled_kernel<D4, U4, 4><<<grid_for(n_bags, 16, 1u << 20), 256, 0, st>>>(t->keys, (const float4*)t->values, t->nb, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, t->default_value, t->dim4, mode == MEE_POOL_MEAN); } while (0)
+#define POOLED(D4, U1, U4) do { if (wave_per_bag) find_pooled_kernel<D4, U1, 1><<<grid_for(n_bags, 4, 1u << 20), 256, 0, st>>>(t->keys, (const float4*)t->values, t->nb, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, t->default_value, t->dim4, mode == MEE_POOL_MEAN, nullptr, 1, nullptr, n); \
+                                else find_pooled_kernel<D4, U4, 4><<<grid_for(n_bags, 16, 1u << 20), 256, 0, st>>>(t->keys, (const float4*)t->values, t->nb, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, t->default_value, t->dim4, mode == MEE_POOL_MEAN, nullptr, 1, nullptr, n); } while (0)
     if (t->dim4 == 16) POOLED(16, 4, 2); else if (t->dim4 == 32) POOLED(32, 2, 1); else POOLED(0, 1, 1);
 #undef POOLED
     MEE_HIP(hipGetLastError());
@@ -1722,8 +1725,8 @@ int mee_group_find_pooled(mee_group* g, const int64_t* d_keys, size_t n, const u
     hipStream_t st = as_stream(stream);
     const uint64_t n_bags = (uint64_t)g->n_tables * bags_per_table;
     const bool wave_per_bag = n / n_bags >= 12;
-#define GPOOLED(D4, U1, U4) do { if (wave_per_bag) find_pooled_kernel<D4, U1, 1, true><<<grid_for(n_bags, 4, 1u << 20), 256, 0, st>>>(nullptr, nullptr, 0, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, 0.f, g->dim4, mode == MEE_POOL_MEAN, g->d_desc, bags_per_table, d_located_out); \
-                                 else find_pooled_kernel<D4, U4, 4, true><<<grid_for(n_bags, 16, 1u << 20), 256, 0, st>>>(nullptr, nullptr, 0, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, 0.f, g->dim4, mode == MEE_POOL_MEAN, g->d_desc, bags_per_table, d_located_out); } while (0)
+#define GPOOLED(D4, U1, U4) do { if (wave_per_bag) find_pooled_kernel<D4, U1, 1, true><<<grid_for(n_bags, 4, 1u << 20), 256, 0, st>>>(nullptr, nullptr, 0, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, 0.f, g->dim4, mode == MEE_POOL_MEAN, g->d_desc, bags_per_table, d_located_out, n); \
+                                 else find_pooled_kernel<D4, U4, 4, true><<<grid_for(n_bags, 16, 1u << 20), 256, 0, st>>>(nullptr, nullptr, 0, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, 0.f, g->dim4, mode == MEE_POOL_MEAN, g->d_desc, bags_per_table, d_located_out, n); } while (0)
     if (g->dim4 == 16) GPOOLED(16, 4, 2); else if (g->dim4 == 32) GPOOLED(32, 2, 1); else GPOOLED(0, 1, 1);
 #undef GPOOLED
     MEE_HIP(hipGetLastError());

@@ -869,3 +869,16 @@ def test_group_pooled_equals_per_table_pooled(dev, dim, mode, opt):
             np.testing.assert_allclose(x[ia], y[ib], rtol=RTOL, atol=ATOL)
             np.testing.assert_allclose(x[ia], z[io], rtol=RTOL, atol=ATOL)
     grp.close()
+
+
+def test_find_pooled_tolerates_bad_offsets(dev):
+    """Offsets are caller data: bags that run past the key array are cut at its end, a decreasing pair is an empty bag —
+    nothing is read out of bounds."""
+    dim = 64
+    t = LookupTable(1000, dim, device=dev, max_batch=1024)
+    keys = synth.keys_np(50, 0, 100)
+    rows = np.ones((100, dim), np.float32)
+    t.insert(T(keys, dev), T(rows, dev))
+    off = torch.tensor([0, 10, 5, 90, 1 << 40, 1 << 41], dtype=torch.int64, device=dev)   # [0,10) [10,5)=empty [5,90) [90,2^40)->[90,100) [2^40,2^41)=empty
+    out, _ = t.find_pooled(T(keys, dev), off, "sum")
+    assert out[:, 0].tolist() == [10.0, 0.0, 85.0, 10.0, 0.0]
