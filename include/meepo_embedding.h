@@ -198,12 +198,13 @@ int mee_apply_adagrad(mee_table* t, const int64_t* d_keys, const float* d_grads,
                       void* stream);
 int mee_apply_adam(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float beta1,
                    float beta2, float eps, uint64_t step, void* stream);
-/* The same with an indirection on the grads: position i takes row d_grad_index[i] of d_grads — the backward of a pooled
- * lookup (every key of a bag receives the bag's grad row; for MEE_POOL_MEAN the caller scales the bag rows by 1/length). */
-int mee_apply_adagrad_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, const uint32_t* d_grad_index, size_t n, float lr,
-                              float eps, void* stream);
-int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, const uint32_t* d_grad_index, size_t n, float lr,
-                           float beta1, float beta2, float eps, uint64_t step, void* stream);
+/* The same with an indirection on the grads: position i takes row d_grad_index[i] of d_grads ([n_grad_rows, dim]) — the
+ * backward of a pooled lookup (every key of a bag receives the bag's grad row; for MEE_POOL_MEAN the caller scales the bag
+ * rows by 1/length).  Indices >= n_grad_rows are clamped to the last row: bad caller data never reads out of bounds. */
+int mee_apply_adagrad_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n_grad_rows, const uint32_t* d_grad_index,
+                              size_t n, float lr, float eps, void* stream);
+int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n_grad_rows, const uint32_t* d_grad_index,
+                           size_t n, float lr, float beta1, float beta2, float eps, uint64_t step, void* stream);
 /* Optional split of an apply: mee_apply_prepare groups the batch's keys and plans the duplicate reduction — everything
  * that does not need the grads — so it can run early (e.g. on a side stream beside the forward lookup and the dense
  * model); the following mee_apply_adagrad / mee_apply_adam with the SAME d_keys / n then only streams the updates.

@@ -79,11 +79,11 @@ public:
         check(mee_apply_adam(t_, d_keys, d_grads, n, lr, beta1, beta2, eps, step, stream));
     }
     // backward of find_pooled: position i takes grad row d_grad_index[i] (its bag)
-    void apply_adagrad_indexed(const int64_t* d_keys, const float* d_grads, const uint32_t* d_grad_index, size_t n, float lr, float eps = 1e-10f, void* stream = nullptr) {
-        check(mee_apply_adagrad_indexed(t_, d_keys, d_grads, d_grad_index, n, lr, eps, stream));
+    void apply_adagrad_indexed(const int64_t* d_keys, const float* d_grads, size_t n_grad_rows, const uint32_t* d_grad_index, size_t n, float lr, float eps = 1e-10f, void* stream = nullptr) {
+        check(mee_apply_adagrad_indexed(t_, d_keys, d_grads, n_grad_rows, d_grad_index, n, lr, eps, stream));
     }
-    void apply_adam_indexed(const int64_t* d_keys, const float* d_grads, const uint32_t* d_grad_index, size_t n, float lr, uint64_t step, float beta1 = 0.9f, float beta2 = 0.999f, float eps = 1e-8f, void* stream = nullptr) {
-        check(mee_apply_adam_indexed(t_, d_keys, d_grads, d_grad_index, n, lr, beta1, beta2, eps, step, stream));
+    void apply_adam_indexed(const int64_t* d_keys, const float* d_grads, size_t n_grad_rows, const uint32_t* d_grad_index, size_t n, float lr, uint64_t step, float beta1 = 0.9f, float beta2 = 0.999f, float eps = 1e-8f, void* stream = nullptr) {
+        check(mee_apply_adam_indexed(t_, d_keys, d_grads, n_grad_rows, d_grad_index, n, lr, beta1, beta2, eps, step, stream));
     }
     // the next four synchronise the stream (they return host values)
     size_t size(void* stream = nullptr) const { size_t n = 0; check(mee_size(t_, &n, stream)); return n; }

@@ -83,8 +83,8 @@ PROTOTYPES = {
     "mee_group_destroy": (C.c_int, [_vp]),
     "mee_find_grouped": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_find_pooled": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, C.c_int, _vp]),
-    "mee_apply_adagrad_indexed": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _vp]),
-    "mee_apply_adam_indexed": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
+    "mee_apply_adagrad_indexed": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _sz, _f32, _f32, _vp]),
+    "mee_apply_adam_indexed": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
     "mee_reserve": (C.c_int, [_vp, _u64, _vp]),
     "mee_export_range": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), _vp]),
     "mee_size": (C.c_int, [_vp, C.POINTER(_sz), _vp]),

@@ -707,6 +707,7 @@ struct OptArgs {
     uint32_t kind;       // MEE_OPT_*
     float lr, eps;       // adagrad: lr; adam: lr unused (step_size)
     float step_size, omb1, omb2;
+    uint32_t grad_rows;  // indexed apply: rows of the grad array (indices are clamped to it: caller data never reads out of bounds)
 };
 
 __device__ __forceinline__ void opt_update4(const OptArgs& a, float4& w, float4& x1, float4& x2, const float4 g) {
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
             const bool inb = i < n;
             key[r] = inb ? keys[i] : kEmpty;
             cnt[r] = inb ? bs.pcnt[i] : 0;
-            grow[r] = (gidx && cnt[r] == 1) ? gidx[i] : i;
+            grow[r] = (gidx && cnt[r] == 1) ? min(gidx[i], a.grad_rows - 1) : i;
         }
         if constexpr (DIM4 != 0) {
 #pragma unroll
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
 // with the same arguments (c differs per lane).
 __device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, const uint32_t* __restrict__ occ, uint32_t first,
                                           uint32_t count, uint32_t dim4, uint32_t c, double& sx, double& sy, double& sz,
-                                          double& sw, const uint32_t* __restrict__ gidx = nullptr) {
+                                          double& sw, const uint32_t* __restrict__ gidx = nullptr, uint32_t grad_rows = 0) {
     uint32_t o = 0;
     for (; o + 8 <= count; o += 8) {
         uint32_t idx[8];
@@ -825,7 +826,7 @@ __device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, cons
         for (int q = 0; q < 8; ++q) idx[q] = occ[first + o + q];
         if (gidx) {  // indexed apply: position -> row of the grad array (e.g. the bag of a pooled lookup)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) idx[q] = gidx[idx[q]];
+            for (int q = 0; q < 8; ++q) idx[q] = min(gidx[idx[q]], grad_rows - 1);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) gq[q] = grads[(uint64_t)idx[q] * dim4 + c];
@@ -834,7 +835,7 @@ __device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, cons
     }
     for (; o < count; ++o) {
         const uint32_t p = occ[first + o];
-        const float4 gg = grads[(uint64_t)(gidx ? gidx[p] : p) * dim4 + c];
+        const float4 gg = grads[(uint64_t)(gidx ? min(gidx[p], grad_rows - 1) : p) * dim4 + c];
         sx += (double)gg.x; sy += (double)gg.y; sz += (double)gg.z; sw += (double)gg.w;
     }
 }
@@ -871,7 +872,7 @@ __global__ __launch_bounds__(256) void apply_chunk_kernel(const int64_t* __restr
         const uint32_t part = small ? 0 : g.sbig[h] + r / kChunk;  // this chunk's row in the group's partial-sum block
         for (uint32_t c = tl; c < dim4; c += 16) {
             double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-            chunk_sum(grads, bs.occ, first, count, dim4, c, sx, sy, sz, sw, gidx);
+            chunk_sum(grads, bs.occ, first, count, dim4, c, sx, sy, sz, sw, gidx, a.grad_rows);
             if (small) {
                 if (slot >= 0) update_row(a, pl.values, pl.s1, pl.s2, (uint64_t)slot * dim4 + c, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
             } else {
@@ -1739,6 +1740,7 @@ int mee_group_apply_adagrad_pooled(mee_group* g, const int64_t* d_keys, const ui
     if (n && (!d_grad_index || !bags_per_table)) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adagrad_pooled: null index / zero bags_per_table");
     OptArgs a{};
     a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps;
+    a.grad_rows = g ? (uint32_t)(g->n_tables * bags_per_table) : 0;   // one grad row per bag
     // the members' key segments are bounded by every bags_per_table-th bag offset
     return group_apply_common(g, d_keys, d_bag_offsets, d_bag_grads, n, a, stream, "mee_group_apply_adagrad_pooled", bags_per_table, d_grad_index,
                               d_located);
@@ -1748,8 +1750,10 @@ int mee_group_apply_adam_pooled(mee_group* g, const int64_t* d_keys, const uint6
                                 float beta1, float beta2, float eps, uint64_t step, void* stream) {
     if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adam_pooled: step must be >= 1");
     if (n && (!d_grad_index || !bags_per_table)) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adam_pooled: null index / zero bags_per_table");
-    return group_apply_common(g, d_keys, d_bag_offsets, d_bag_grads, n, adam_args(lr, beta1, beta2, eps, step), stream,
-                              "mee_group_apply_adam_pooled", bags_per_table, d_grad_index, d_located);
+    OptArgs a = adam_args(lr, beta1, beta2, eps, step);
+    a.grad_rows = g ? (uint32_t)(g->n_tables * bags_per_table) : 0;   // one grad row per bag
+    return group_apply_common(g, d_keys, d_bag_offsets, d_bag_grads, n, a, stream, "mee_group_apply_adam_pooled", bags_per_table, d_grad_index,
+                              d_located);
 }
 
 int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* stream) {
@@ -1794,18 +1798,25 @@ int mee_apply_adam(mee_table* t, const int64_t* d_keys, const float* d_grads, si
     return apply_common(t, d_keys, d_grads, n, adam_args(lr, beta1, beta2, eps, step), stream, "mee_apply_adam");
 }
 // the grad of position i is row d_grad_index[i] of d_grads (pooled lookups: the bag's grad row serves every key of the bag)
-int mee_apply_adagrad_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, const uint32_t* d_grad_index, size_t n, float lr,
-                              float eps, void* stream) {
-    if (n && !d_grad_index) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adagrad_indexed: null index");
+static int check_grad_rows(size_t n, const uint32_t* d_grad_index, size_t n_grad_rows, const char* name) {
+    if (n && (!d_grad_index || n_grad_rows == 0 || n_grad_rows > 0xFFFFFFFFull))
+        return fail(MEE_ERR_INVALID_ARG, "%s: null index, or n_grad_rows not in [1, 2^32)", name);
+    return MEE_OK;
+}
+int mee_apply_adagrad_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n_grad_rows, const uint32_t* d_grad_index,
+                              size_t n, float lr, float eps, void* stream) {
+    if (int rc = check_grad_rows(n, d_grad_index, n_grad_rows, "mee_apply_adagrad_indexed")) return rc;
     OptArgs a{};
-    a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps;
+    a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps; a.grad_rows = (uint32_t)n_grad_rows;
     return apply_common(t, d_keys, d_grads, n, a, stream, "mee_apply_adagrad_indexed", d_grad_index);
 }
-int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, const uint32_t* d_grad_index, size_t n, float lr,
-                           float beta1, float beta2, float eps, uint64_t step, void* stream) {
+int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n_grad_rows, const uint32_t* d_grad_index,
+                           size_t n, float lr, float beta1, float beta2, float eps, uint64_t step, void* stream) {
     if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adam_indexed: step must be >= 1");
-    if (n && !d_grad_index) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adam_indexed: null index");
-    return apply_common(t, d_keys, d_grads, n, adam_args(lr, beta1, beta2, eps, step), stream, "mee_apply_adam_indexed", d_grad_index);
+    if (int rc = check_grad_rows(n, d_grad_index, n_grad_rows, "mee_apply_adam_indexed")) return rc;
+    OptArgs a = adam_args(lr, beta1, beta2, eps, step);
+    a.grad_rows = (uint32_t)n_grad_rows;
+    return apply_common(t, d_keys, d_grads, n, a, stream, "mee_apply_adam_indexed", d_grad_index);
 }
 
 int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, int64_t* d_uniq_out, float* d_gsum_out,

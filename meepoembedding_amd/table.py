@@ -316,8 +316,8 @@ class LookupTable:
         k = self._keys(keys)
         if grad_index is not None:
             gi = self._grad_index(grad_index, k.numel())
-            g = grads.contiguous()
-            check(_lib.lib().mee_apply_adagrad_indexed(self._h, k.data_ptr(), g.data_ptr(), gi.data_ptr(), k.numel(), lr, eps, self._s()))
+            g = grads.contiguous().view(-1, self.dim)
+            check(_lib.lib().mee_apply_adagrad_indexed(self._h, k.data_ptr(), g.data_ptr(), g.shape[0], gi.data_ptr(), k.numel(), lr, eps, self._s()))
             return
         g = self._rows(grads, k.numel())
         check(_lib.lib().mee_apply_adagrad(self._h, k.data_ptr(), g.data_ptr(), k.numel(), lr, eps, self._s()))
@@ -327,8 +327,8 @@ class LookupTable:
         k = self._keys(keys)
         if grad_index is not None:
             gi = self._grad_index(grad_index, k.numel())
-            g = grads.contiguous()
-            check(_lib.lib().mee_apply_adam_indexed(self._h, k.data_ptr(), g.data_ptr(), gi.data_ptr(), k.numel(), lr, beta1, beta2,
+            g = grads.contiguous().view(-1, self.dim)
+            check(_lib.lib().mee_apply_adam_indexed(self._h, k.data_ptr(), g.data_ptr(), g.shape[0], gi.data_ptr(), k.numel(), lr, beta1, beta2,
                                                     eps, step, self._s()))
             return
         g = self._rows(grads, k.numel())

@@ -882,3 +882,19 @@ def test_find_pooled_tolerates_bad_offsets(dev):
     off = torch.tensor([0, 10, 5, 90, 1 << 40, 1 << 41], dtype=torch.int64, device=dev)   # [0,10) [10,5)=empty [5,90) [90,2^40)->[90,100) [2^40,2^41)=empty
     out, _ = t.find_pooled(T(keys, dev), off, "sum")
     assert out[:, 0].tolist() == [10.0, 0.0, 85.0, 10.0, 0.0]
+
+
+def test_indexed_apply_clamps_bad_indices(dev):
+    """grad_index is caller data: an index past the grad array is clamped to its last row instead of reading out of bounds."""
+    dim = 64
+    a = LookupTable(1000, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=1024)
+    b = LookupTable(1000, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=1024)
+    keys = synth.keys_np(51, 0, 200)
+    for t in (a, b):
+        t.insert(T(keys, dev), torch.zeros(200, dim, device=dev))
+    grads = torch.randn(10, dim, device=dev)
+    idx = torch.randint(0, 10, (200,), device=dev)
+    bad = idx.clone(); bad[::7] = 1 << 30
+    a.apply_adagrad(T(keys, dev), grads, lr=0.1, grad_index=bad)
+    b.apply_adagrad(T(keys, dev), grads, lr=0.1, grad_index=torch.where(bad >= 10, torch.full_like(bad, 9), bad))
+    assert torch.equal(a.find(T(keys, dev))[0], b.find(T(keys, dev))[0])
