@@ -4,17 +4,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from meepoembedding_amd import LookupTable, TableGroup, OPT_ADAGRAD, synth
 dev = torch.device("cuda", 0)
-T_, K, dim = int(sys.argv[1]) if len(sys.argv) > 1 else 26, 4_000_000, 64
+T_, K, dim = int(sys.argv[1]) if len(sys.argv) > 1 else 26, int(sys.argv[2]) if len(sys.argv) > 2 else 4_000_000, 64
+PERS = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else (512, 2048, 8192, 32768)
 tables = []
 for j in range(T_):
-    t = LookupTable(int(K / 0.75), dim, device=dev, max_batch=1 << 16, optimizer=OPT_ADAGRAD)
+    t = LookupTable(int(K / 0.75), dim, device=dev, max_batch=max(1 << 16, max(PERS)), optimizer=OPT_ADAGRAD)
     for s in range(0, K, 1 << 16):
         k = synth.keys_t(100 + j, s, min(1 << 16, K - s), dev)
         t.insert(k, synth.rows_t(k, dim, 2))
     tables.append(t)
 print(f"{T_} tables x {K} keys, dim {dim}, Adagrad, {sum(t.table_bytes for t in tables) / 1e9:.1f} GB")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for per in (512, 2048, 8192, 32768):
+for per in PERS:
     n = per * T_
     grp = TableGroup(tables, max_apply_batch=n)
     gen = torch.Generator(device="cpu").manual_seed(per)
