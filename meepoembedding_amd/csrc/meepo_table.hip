@@ -109,6 +109,14 @@ namespace mee {
 // kernels
 // =========================================================================================================
 
+// Zeroing of the small device-side counter blocks.  Not hipMemsetAsync: captured in a hipGraph, the memset node did not
+// reliably zero the block on later replays once other copies had run in between (counters kept their old values, the apply
+// lists then overflowed their buffers) — a kernel node of our own has no such state.
+__global__ void zero_words_kernel(uint32_t* p, uint32_t n_words) {
+    for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) p[i] = 0u;
+}
+static inline void zero_words(void* p, size_t bytes, hipStream_t st) { zero_words_kernel<<<1, 64, 0, st>>>((uint32_t*)p, (uint32_t)(bytes / 4)); }
+
 __global__ void fill_i64_kernel(int64_t* p, uint64_t n, int64_t v) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -1455,7 +1463,7 @@ int mee_hits_scan(mee_table* t, uint32_t min_hits, uint32_t max_hits, int reset,
     if (!t->hits) return fail(MEE_ERR_UNSUPPORTED, "mee_hits_scan: table was created without MEE_FLAG_TRACK_HITS");
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
-    MEE_HIP(hipMemsetAsync(&t->op->n_export, 0, sizeof(unsigned long long), st));
+    zero_words(&t->op->n_export, sizeof(unsigned long long), st);
     hits_scan_kernel<<<grid_for(t->capacity, 4 * 1024, 4096), 256, 0, st>>>(t->keys, t->hits, t->capacity, min_hits, max_hits, reset, d_keys_out, cap, t->op);
     MEE_HIP(hipGetLastError());
     MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
@@ -1571,7 +1579,7 @@ int mee_export_range(const mee_table* t, uint64_t slot_begin, uint64_t slot_end,
     if (slot_begin > slot_end) return fail(MEE_ERR_INVALID_ARG, "mee_export_range: slot_begin %llu > slot_end %llu", (unsigned long long)slot_begin, (unsigned long long)slot_end);
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
-    MEE_HIP(hipMemsetAsync(&t->op->n_export, 0, sizeof(unsigned long long), st));
+    zero_words(&t->op->n_export, sizeof(unsigned long long), st);
     export_kernel<<<grid_for(slot_end - slot_begin, 4 * 64 * kExportGroups, 256 * 16), 256, 0, st>>>(
         t->keys, (const float4*)t->values, (const float4*)t->s1, (const float4*)t->s2, slot_begin, slot_end, t->dim4, d_keys_out,
         (float4*)d_values_out, t->s1 ? (float4*)d_state1_out : nullptr, t->s2 ? (float4*)d_state2_out : nullptr, cap, t->op);
@@ -1592,7 +1600,7 @@ int mee_size(const mee_table* t, size_t* n_out, void* stream) {
     if (!t || !n_out) return fail(MEE_ERR_INVALID_ARG, "mee_size: null argument");
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
-    MEE_HIP(hipMemsetAsync(&t->op->n_export, 0, sizeof(unsigned long long), st));
+    zero_words(&t->op->n_export, sizeof(unsigned long long), st);
     count_kernel<<<grid_for(t->capacity, 256 * 16, 2048), 256, 0, st>>>(t->keys, t->capacity, t->op);
     MEE_HIP(hipGetLastError());
     MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
@@ -1609,13 +1617,13 @@ int mee_status(const mee_table* t, uint32_t* bits_out, void* stream) {
 int mee_clear_status(mee_table* t, void* stream) {
     if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_clear_status: null table");
     DeviceGuard g(t->device);
-    MEE_HIP(hipMemsetAsync(&t->ctr->status, 0, sizeof(uint32_t), as_stream(stream)));
+    zero_words(&t->ctr->status, sizeof(uint32_t), as_stream(stream));
     return MEE_OK;
 }
 
 // group the batch's keys and plan the duplicate reduction (everything that does not need the grads)
 static int apply_prepare_launch(mee_table* t, const int64_t* d_keys, uint32_t nn, hipStream_t st) {
-    MEE_HIP(hipMemsetAsync(t->op, 0, sizeof(OpCounters), st));
+    zero_words(t->op, sizeof(OpCounters), st);
     group_kernel<kGroupCount><<<grid_for(nn, 256, 1u << 22), 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr);
     group_plan_kernel<false><<<grid_for(nn, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
     MEE_HIP(hipGetLastError());
@@ -1829,7 +1837,7 @@ int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, siz
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
-    MEE_HIP(hipMemsetAsync(t->op, 0, sizeof(OpCounters), st));
+    zero_words(t->op, sizeof(OpCounters), st);
     group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr);
     group_plan_kernel<true><<<grid_for(n, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
     dedup_fill_kernel<<<gl, 256, 0, st>>>(nn, t->g, t->bs, d_inverse_out);

@@ -898,3 +898,53 @@ def test_indexed_apply_clamps_bad_indices(dev):
     a.apply_adagrad(T(keys, dev), grads, lr=0.1, grad_index=bad)
     b.apply_adagrad(T(keys, dev), grads, lr=0.1, grad_index=torch.where(bad >= 10, torch.full_like(bad, 9), bad))
     assert torch.equal(a.find(T(keys, dev))[0], b.find(T(keys, dev))[0])
+
+
+def test_group_and_pooled_ops_are_graph_capturable(dev):
+    """The grouped / pooled entry points neither allocate nor synchronise either: capture a collection step (pooled
+    lookup with located hand-over + grouped Adagrad + a find_or_insert on one member) in a hipGraph, replay it three
+    times with host work and D2H copies in between, and compare with an eager twin."""
+    from meepoembedding_amd import TableGroup
+    rng = np.random.default_rng(77)
+    dim, n_tables, bpt = 64, 3, 50
+    mk = lambda: [LookupTable(4096, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=8192, initial_accumulator=0.1) for _ in range(n_tables)]
+    a, b = mk(), mk()
+    univ = [synth.keys_np(130 + j, 0, 1500) for j in range(n_tables)]
+    for j in range(n_tables):
+        rows = rng.standard_normal((1500, dim)).astype(np.float32)
+        a[j].insert(T(univ[j], dev), T(rows, dev)); b[j].insert(T(univ[j], dev), T(rows, dev))
+    ga, gb = TableGroup(a, max_apply_batch=8192), TableGroup(b, max_apply_batch=8192)
+    lens = rng.integers(0, 9, n_tables * bpt)
+    off = T(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), dev)
+    keys = T(np.concatenate([univ[j][rng.integers(0, 1500, int(lens[j * bpt:(j + 1) * bpt].sum()))] for j in range(n_tables)]), dev)
+    bag_of = T(np.repeat(np.arange(lens.size), lens).astype(np.int64), dev)
+    grads = T((rng.standard_normal((n_tables * bpt, dim)) * 0.05).astype(np.float32), dev)
+    fresh = T(synth.keys_np(140, 0, 64), dev)
+    n = keys.numel()
+    out = torch.empty((n_tables * bpt, dim), device=dev); found = torch.empty(n, dtype=torch.uint8, device=dev)
+    located = torch.empty(n, dtype=torch.int64, device=dev)
+    fo = torch.empty((64, dim), device=dev); ff = torch.empty(64, dtype=torch.uint8, device=dev)
+
+    def step(grp, tables, o, f, loc, fo_, ff_):
+        grp.find_pooled(keys, off, "sum", out=o, found=f, located=loc)
+        grp.apply_pooled(keys, off, grads, bag_of, "adagrad", lr=0.05, located=loc)
+        tables[1].find_or_insert(fresh, out=fo_, found=ff_)
+
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step(ga, a, out, found, located, fo, ff)
+    out_b = torch.empty_like(out); found_b = torch.empty_like(found); loc_b = torch.empty_like(located)
+    fo_b = torch.empty_like(fo); ff_b = torch.empty_like(ff)
+    for it in range(3):
+        step(gb, b, out_b, found_b, loc_b, fo_b, ff_b)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), out_b.cpu().numpy()) and np.array_equal(ff.cpu().numpy(), ff_b.cpu().numpy())
+        assert bool(ff.all()) == (it > 0)          # the fresh keys exist from the second step on
+    for x, y in zip(a, b):
+        ex, ey = x.export(with_state=True), y.export(with_state=True)
+        ix, iy = torch.argsort(ex[0]), torch.argsort(ey[0])
+        assert torch.equal(ex[0][ix], ey[0][iy])
+        np.testing.assert_allclose(ex[1][ix].cpu().numpy(), ey[1][iy].cpu().numpy(), rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(ex[2][ix].cpu().numpy(), ey[2][iy].cpu().numpy(), rtol=RTOL, atol=ATOL)
