@@ -632,6 +632,9 @@ __global__ __launch_bounds__(256) void upsert_kernel(int64_t* tkeys, float4* val
             const uint64_t fm = __ballot(full);
             if (lane == 0 && fm) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_TABLE_FULL);
         }
+        // the winner is the last reader that needs the entry's value: an occurrence that looks later reads 0 != i + 1 (one
+        // 8-byte load: never a mixture) and is, correctly, not the winner.  The group table is clean when the kernel ends.
+        if (winner && tl == 0) group_release_entry(g, h);
     }
 }
 
@@ -1496,10 +1499,6 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
     else
         upsert_kernel<false><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
                                                  (const float4*)d_values, nn, t->bs.hidx, t->g, d_found, t->optimizer, t->init_acc, t->ctr, t->hits);
-    // (releasing the entries from inside upsert_kernel — the winner is their last reader — was tried instead of this pass:
-    //  eager runs were clean, but a hipGraph replay of find + apply + insert faulted on its second launch; not understood,
-    //  so the separate pass stays)
-    group_reset_kernel<<<gl, 256, 0, st>>>(t->bs.hidx, nn, t->g);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
