@@ -263,7 +263,11 @@ int mee_p2p_find(mee_p2p* c, const mee_table* t, void* stream);
 int mee_p2p_push_rows(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts,
                       const float* d_rows, size_t n, void* stream);
 int mee_p2p_inbox(mee_p2p* c, int64_t** d_keys, float** d_rows, uint64_t* n_slots);
-int mee_p2p_status(mee_p2p* c, uint32_t* bits_out, void* stream); /* [syncs] */
+/* The barrier of the sequences above without a collective library: a one-wave kernel announces this rank's arrival in a
+ * flag word on every peer and waits (bounded: 5 s, then bit 1 of mee_p2p_status) until every peer has announced its own.
+ * Collective: every rank calls it the same number of times, in the same order relative to its pushes and finds. */
+int mee_p2p_barrier(mee_p2p* c, void* stream);
+int mee_p2p_status(mee_p2p* c, uint32_t* bits_out, void* stream); /* [syncs]; bit 0: inbox overflow, bit 1: barrier time-out */
 
 #ifdef __cplusplus
 }

@@ -170,8 +170,8 @@ private:
 };
 
 // Peer-mapped exchange context of the all-to-all-free sharded find.  The caller moves the exported handles between
-// ranks (any side channel) and provides the two cross-rank barriers per lookup (e.g. a one-element ncclAllReduce on
-// the stream): partition -> push -> barrier -> find -> barrier -> read rows()/found().
+// ranks (any side channel); the two cross-rank barriers per lookup are barrier() (or any collective on the stream):
+// partition -> push -> barrier -> find -> barrier -> read rows()/found().
 class PeerExchange {
 public:
     PeerExchange(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t slots_per_peer, uint64_t max_batch, uint32_t dim, bool with_payload = false) {
@@ -184,6 +184,8 @@ public:
     void connect(const void* all_handles_rank_major) { check(mee_p2p_connect(c_, all_handles_rank_major)); }
     void push(Router& r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts, size_t n, void* stream = nullptr) { check(mee_p2p_push(c_, r.handle(), d_send_keys, d_perm, d_counts, n, stream)); }
     void find(const Table& t, void* stream = nullptr) { check(mee_p2p_find(c_, t.handle(), stream)); }
+    // the cross-rank barrier of the sequences above as a one-wave kernel over peer-mapped flags (no collective library needed)
+    void barrier(void* stream = nullptr) { check(mee_p2p_barrier(c_, stream)); }
     void push_rows(Router& r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts, const float* d_rows, size_t n, void* stream = nullptr) {
         check(mee_p2p_push_rows(c_, r.handle(), d_send_keys, d_perm, d_counts, d_rows, n, stream));
     }

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "mee_router_destroy": (C.c_int, [_vp]),
     "mee_partition": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "mee_p2p_create": (C.c_int, [_i32, _u32, _u32, _u64, _u64, _u32, C.c_int, C.POINTER(_vp)]),
+    "mee_p2p_barrier": (C.c_int, [_vp, _vp]),
     "mee_p2p_push_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mee_p2p_inbox": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u64)]),
     "mee_p2p_destroy": (C.c_int, [_vp]),

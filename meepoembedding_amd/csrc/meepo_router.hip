@@ -30,11 +30,11 @@ struct mee_p2p {
     // local symmetric buffers, exported to the peers
     int64_t* inbox_keys;   // [n_shards][cap]
     int32_t* inbox_dst;    // [n_shards][cap]
-    uint32_t* inbox_cnt;   // [n_shards]
+    uint32_t* inbox_cnt;   // [n_shards] fill counts, followed by [n_shards] barrier flags (flag q = the last epoch rank q announced here)
     float* out;            // [max_batch][dim]
     uint8_t* found;        // [max_batch]
     float* inbox_rows;     // [n_shards][cap][dim] payload rows of pushed (key, row) pairs; null unless created with payload
-    uint32_t* status;      // bit 0: a segment overflowed `cap`
+    uint32_t* status;      // [0] bit 0: a segment overflowed `cap`, bit 1: a barrier timed out; [1] barriers executed so far (the epoch)
     // device-resident pointer tables (index = rank) and their host copies
     void** d_tables;       // kP2PBuffers tables of n_shards pointers each
     void* h_tables[6][64];
@@ -199,6 +199,30 @@ __global__ __launch_bounds__(256) void p2p_push_kernel(const int64_t* __restrict
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         peers.cnt[p][me] = (uint32_t)take;
         if (cnt > cap) atomicOr(status, 1u);
+    }
+}
+
+// Cross-rank barrier over the peer-mapped flag words: every rank announces epoch e in the flag word it owns on every peer
+// (system-scope release store: the rank's earlier kernels — whose stores into peer memory were made visible by their kernel
+// end — are ordered before it), then waits until all peers have announced e here.  One wave; the wait is bounded (wall clock)
+// so the grid always drains: on time-out bit 1 of the status word is set and the caller must not trust the step.
+__global__ __launch_bounds__(64) void p2p_barrier_kernel(P2PPeers peers, uint32_t me, uint32_t n_shards, uint32_t* status,
+                                                         unsigned long long timeout_ticks) {
+    const uint32_t q = threadIdx.x;
+    // the epoch lives in device memory and is advanced by the kernel itself (every rank runs the same number of barriers),
+    // so a captured launch stays correct when it is replayed
+    uint32_t epoch = 0;
+    if (q == 0) { epoch = status[1] + 1; status[1] = epoch; }
+    epoch = __shfl(epoch, 0);
+    if (q < n_shards) {
+        uint32_t* theirs = peers.cnt[q] + n_shards + me;   // my flag word at rank q
+        __hip_atomic_store(theirs, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t* mine = peers.cnt[me] + n_shards + q;   // rank q's flag word here
+        const unsigned long long t0 = wall_clock64();
+        while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+            if (wall_clock64() - t0 > timeout_ticks) { atomicOr(status, 2u); break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
     }
 }
 
@@ -406,15 +430,15 @@ int mee_p2p_create(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t sl
         return fine ? hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) : hipMalloc(p, bytes);
     };
     if (sym_alloc((void**)&c->inbox_keys, slots * 8) != hipSuccess || sym_alloc((void**)&c->inbox_dst, slots * 4) != hipSuccess ||
-        sym_alloc((void**)&c->inbox_cnt, n_shards * 4) != hipSuccess || sym_alloc((void**)&c->out, max_batch * (uint64_t)dim * 4) != hipSuccess ||
+        sym_alloc((void**)&c->inbox_cnt, 2 * n_shards * 4) != hipSuccess || sym_alloc((void**)&c->out, max_batch * (uint64_t)dim * 4) != hipSuccess ||
         sym_alloc((void**)&c->found, max_batch) != hipSuccess ||
         (with_payload && sym_alloc((void**)&c->inbox_rows, slots * (uint64_t)dim * 4) != hipSuccess) ||
-        hipMalloc((void**)&c->status, 4) != hipSuccess ||
+        hipMalloc((void**)&c->status, 8) != hipSuccess ||
         hipMalloc((void**)&c->d_tables, kP2PBuffers * (size_t)n_shards * sizeof(void*)) != hipSuccess) {
         mee_p2p_destroy(c);
         return fail(MEE_ERR_OUT_OF_MEMORY, "mee_p2p_create: device allocation failed (%s)", fine ? "fine-grained" : "coarse-grained");
     }
-    if (hipMemset(c->inbox_cnt, 0, n_shards * 4) != hipSuccess || hipMemset(c->status, 0, 4) != hipSuccess) {
+    if (hipMemset(c->inbox_cnt, 0, 2 * n_shards * 4) != hipSuccess || hipMemset(c->status, 0, 8) != hipSuccess) {
         mee_p2p_destroy(c);
         return fail(MEE_ERR_HIP, "mee_p2p_create: hipMemset failed");
     }
@@ -526,6 +550,16 @@ int mee_p2p_find(mee_p2p* c, const mee_table* t, void* stream) {
                                                                       c->inbox_dst, c->inbox_cnt, p2p_peers(c), c->cap)
     if (v.dim4 == 16) P2PFIND(16, 2); else if (v.dim4 == 32) P2PFIND(32, 1); else P2PFIND(0, 1);
 #undef P2PFIND
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+int mee_p2p_barrier(mee_p2p* c, void* stream) {
+    if (!c) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_barrier: null argument");
+    if (!c->connected) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_barrier: not connected");
+    DeviceGuard g(c->device);
+    // wall_clock64 ticks at 100 MHz: wait at most 5 s for the slowest rank
+    p2p_barrier_kernel<<<1, 64, 0, (hipStream_t)stream>>>(p2p_peers(c), c->rank, c->n_shards, c->status, 500000000ull);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }

@@ -8,8 +8,8 @@ an un-permute pass, every rank maps its peers' inboxes and result buffers throug
                                out[batch position] of the rank that asked                       (xGMI stores)
     barrier          ->  out[0:n], found[0:n] are complete, in batch order
 
-No all-to-all, no staging buffers, no un-permute, no host sync; the two barriers are one-element all-reduces on the
-caller's stream (RCCL).
+No all-to-all, no staging buffers, no un-permute, no host sync; the two barriers are one-wave kernels over peer-mapped
+flag words (`mee_p2p_barrier`; `device_barrier=False` uses one-element all-reduces on the caller's stream instead).
 
 Mutators (payload=True) ride the same inboxes: push stores (key, row) pairs into the owners' key and row inboxes and pads
 every segment to its fixed capacity with EMPTY keys (padding, SPEC.md §2), so after the barrier each owner hands its
@@ -35,7 +35,8 @@ class _Raw:
 
 
 class PeerShardedFind:
-    def __init__(self, local, router, max_batch: int, group=None, slack: float = 1.25, payload: bool = False):
+    def __init__(self, local, router, max_batch: int, group=None, slack: float = 1.25, payload: bool = False,
+                 device_barrier: bool = True):
         self.local, self.router, self.group = local, router, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.device, self.dim, self.max_batch = local.device, local.dim, max_batch
@@ -43,7 +44,9 @@ class PeerShardedFind:
             raise ValueError("router shards != process group size")
         # room for an uneven split: mean + 25 % + a constant (uniform hashing of 1M keys over 8 owners deviates by < 0.3 %)
         self.cap = int(max_batch / self.world * slack) + 4096
-        self._staged = dist.get_backend(group) == "gloo"  # rehearsal on one GPU: host barriers instead of RCCL
+        self._staged = dist.get_backend(group) == "gloo"  # rehearsal on one GPU: no RCCL for the collective barrier
+        # per-step barriers: a one-wave kernel over peer-mapped flag words (mee_p2p_barrier) instead of a collective
+        self.device_barrier = device_barrier
         L = _lib.lib()
         self._h = None
         self._tok = torch.zeros(1, dtype=torch.int32, device="cpu" if self._staged else self.device)
@@ -100,7 +103,9 @@ class PeerShardedFind:
             self._h = None
 
     def _barrier(self) -> None:
-        if self._staged:
+        if self.device_barrier and self._h:
+            check(_lib.lib().mee_p2p_barrier(self._h, torch.cuda.current_stream(self.device).cuda_stream))
+        elif self._staged:
             torch.cuda.synchronize(self.device)
             dist.barrier(group=self.group)
         else:
@@ -189,6 +194,8 @@ class PeerShardedFind:
     def check(self) -> None:
         bits = C.c_uint32()
         check(_lib.lib().mee_p2p_status(self._h, C.byref(bits), torch.cuda.current_stream(self.device).cuda_stream))
+        if bits.value & 2:
+            raise _lib.MeepoError(_lib.ERR_HIP, "peer barrier timed out: a rank did not arrive within 5 s")
         if bits.value & 1:
             raise _lib.MeepoError(_lib.ERR_BATCH_TOO_LARGE, "peer inbox overflow: a rank sent more than slots_per_peer keys to one owner")
 

@@ -103,7 +103,9 @@ int main() try {
     DevBuf<int64_t> d_q(n); d_q.up(q);
     router.partition(d_q.p, n, d_send.p, d_counts.p, d_perm.p);
     px.push(router, d_send.p, d_perm.p, d_counts.p, n);
-    px.find(shard);                                                  // one rank: stream order is the barrier
+    px.barrier();                                                    // one rank: returns at once (its own flag)
+    px.find(shard);
+    px.barrier();
     CHECK(px.status() == 0);
     { std::vector<float> out(n * dim); std::vector<uint8_t> f(n);
       HIPCK(hipMemcpy(out.data(), px.rows(), n * dim * 4, hipMemcpyDeviceToHost));
