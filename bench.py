@@ -201,6 +201,7 @@ def main():
                          "auto = verify p2p against rccl, time both for a few steps, keep the faster")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N>1 flow on a box with fewer GPUs than ranks (exchange staged through host memory)")
+    ap.add_argument("--p2p-depth", type=int, default=2, help="sharded, peer-mapped transport: also try this many lookups in flight (own context + stream each) and keep it if faster; 1 = off")
     ap.add_argument("--no-selftest", action="store_true", help="sharded only: skip the child-process self-test of the peer-mapped transport")
     ap.add_argument("--dedup", action="store_true", help="sharded only: exchange only the batch's distinct keys (pays off on skewed streams)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even at N=1 (rehearsal of the N>1 code)")
@@ -316,6 +317,33 @@ def main():
                     log(f"transport probe: rccl {t_rccl * 1e3:.3f} ms/step, p2p {t_p2p * 1e3:.3f} ms/step, re-check {'ok' if int(same.item()) else 'MISMATCH'}")
                     if int(same.item()) == 1 and (args.transport == "p2p" or t_p2p < t_rccl):
                         step, transport = step_p2p, "peer-mapped stores (no all-to-all)"
+                        pd = max(1, args.p2p_depth)
+                        if pd > 1 and not train:
+                            # several lookups in flight: each owns a context (inboxes, result buffers, barrier flags) and a
+                            # stream, so one lookup's partition / push / barrier run beside another's row traffic
+                            try:
+                                peers = [peer] + [PeerShardedFind(table, Router(world, batch, device=dev), max_batch=batch) for _ in range(pd - 1)]
+                            except Exception as e:
+                                peers = None
+                                log(f"p2p depth {pd} unavailable: {e}")
+                            if peers is not None:
+                                pstreams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(pd - 1)]
+                                for s_ in pstreams[1:]:
+                                    s_.wait_stream(pstreams[0])
+
+                                def step_p2p_pipe(i):
+                                    with torch.cuda.stream(pstreams[i % pd]):
+                                        return peers[i % pd].find(batches[i % n_batches], check_overflow=False)
+
+                                o_c, f_c = step_p2p_pipe(1)      # runs on the second context
+                                torch.cuda.synchronize(dev)
+                                o_a, f_a = step_rccl(1)
+                                same_p = torch.tensor([int(torch.equal(o_a, o_c) and torch.equal(f_a, f_c))], device=ctrl)
+                                dist.all_reduce(same_p, op=dist.ReduceOp.MIN)
+                                t_pipe = timed(step_p2p_pipe, k=8)
+                                log(f"transport probe: p2p with {pd} lookups in flight {t_pipe * 1e3:.3f} ms/step, check {'ok' if int(same_p.item()) else 'MISMATCH'}")
+                                if int(same_p.item()) == 1 and t_pipe < t_p2p:
+                                    step, transport = step_p2p_pipe, f"peer-mapped stores (no all-to-all), {pd} lookups in flight"
                 else:
                     log("p2p transport disagrees with the rccl path: not used")
         if train:   # the data-parallel training step: lookup, then every rank's gradients go to the owners, which apply
