@@ -948,3 +948,111 @@ def test_group_and_pooled_ops_are_graph_capturable(dev):
         assert torch.equal(ex[0][ix], ey[0][iy])
         np.testing.assert_allclose(ex[1][ix].cpu().numpy(), ey[1][iy].cpu().numpy(), rtol=RTOL, atol=ATOL)
         np.testing.assert_allclose(ex[2][ix].cpu().numpy(), ey[2][iy].cpu().numpy(), rtol=RTOL, atol=ATOL)
+
+
+_GSEQ = list(range(4)) + list(range(4, 4 + int(os.environ.get("MEE_SOAK_GROUPS", "0"))))
+
+
+@pytest.mark.parametrize("seed", _GSEQ)
+def test_random_group_sequences(dev, seed):
+    """Differential test of the grouped / pooled entry points: a random sequence of grouped find, find_or_insert, apply,
+    pooled lookup and pooled apply (with and without the located hand-over) over a random collection of tables, interleaved
+    with single-table ops on the members (insert, remove, reserve); every observable against one oracle table per member."""
+    from meepoembedding_amd import TableGroup
+    rng = np.random.default_rng(5000 + seed)
+    dim = int(rng.choice([8, 24, 64, 128]))
+    opt = "adagrad" if seed % 2 == 0 else "adam"
+    kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
+    n_tables = int(rng.integers(1, 6))
+    tabs, orcs, univ = [], [], []
+    for j in range(n_tables):
+        cap = int(rng.integers(600, 3000))
+        kw = dict(default_value=0.125 * j, initial_accumulator=0.1, initializer=INIT_UNIFORM, init_scale=0.05, init_seed=seed * 10 + j)
+        tabs.append(LookupTable(cap, dim, device=dev, optimizer=kind, max_batch=1 << 14, **kw))
+        orcs.append(oracle.OracleTable(1 << 14, dim, optimizer=okind, **kw))
+        univ.append(synth.keys_np(7000 + seed * 10 + j, 0, 400))
+    grp = TableGroup(tabs, max_apply_batch=1 << 14)
+    step = 0
+
+    def batch(pooled):
+        bpt = int(rng.integers(1, 12)) if pooled else 1
+        lens = rng.integers(0, 30 if rng.random() < 0.3 else 6, n_tables * bpt) if pooled else rng.integers(0, 300, n_tables)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        segs = []
+        for j in range(n_tables):
+            m = int(off[(j + 1) * bpt] - off[j * bpt])
+            k = univ[j][np.minimum(rng.zipf(1.2, m) - 1, 399)].copy() if rng.random() < 0.5 else univ[j][rng.integers(0, 400, m)].copy()
+            if m > 6:
+                k[2] = oracle.EMPTY_KEY; k[4] = oracle.RECLAIMED_KEY
+            segs.append(k)
+        return bpt, lens, off, segs, (np.concatenate(segs) if off[-1] else np.zeros(0, np.int64))
+
+    for it in range(30):
+        op = rng.choice(["find", "foi", "apply", "pooled", "papply", "insert", "remove", "reserve"])
+        if op in ("find", "foi", "apply"):
+            _, lens, off, segs, keys = batch(False)
+            if keys.size == 0:
+                continue
+            d_off = T(off, dev)
+            if op == "find":
+                out, found = grp.find(T(keys, dev), d_off)
+                exp = [orcs[j].find(segs[j]) for j in range(n_tables)]
+            elif op == "foi":
+                if any(orcs[j].size() + len(np.unique(segs[j])) > tabs[j].capacity - 32 for j in range(n_tables)):
+                    continue
+                out, found = grp.find_or_insert(T(keys, dev), d_off)
+                exp = [orcs[j].find_or_insert(segs[j]) for j in range(n_tables)]
+            else:
+                step += 1
+                g = (rng.standard_normal((keys.size, dim)) * 0.05).astype(np.float32)
+                if opt == "adagrad":
+                    grp.apply_adagrad(T(keys, dev), d_off, T(g, dev), lr=0.05)
+                else:
+                    grp.apply_adam(T(keys, dev), d_off, T(g, dev), lr=0.01, step=step)
+                for j in range(n_tables):
+                    gj = g[off[j]:off[j + 1]]
+                    if segs[j].size:
+                        orcs[j].apply_adagrad(segs[j], gj, 0.05, 1e-10) if opt == "adagrad" else orcs[j].apply_adam(segs[j], gj, 0.01, 0.9, 0.999, 1e-8, step)
+                continue
+            assert np.array_equal(found.cpu().numpy(), np.concatenate([e[1] for e in exp]))
+            np.testing.assert_allclose(out.cpu().numpy(), np.concatenate([e[0] for e in exp]), rtol=RTOL, atol=ATOL)
+        elif op in ("pooled", "papply"):
+            bpt, lens, off, segs, keys = batch(True)
+            if keys.size == 0:
+                continue
+            mode = "sum" if rng.random() < 0.5 else "mean"
+            located = torch.empty(keys.size, dtype=torch.int64, device=dev) if rng.random() < 0.5 else None
+            out, found = grp.find_pooled(T(keys, dev), T(off, dev), mode, located=located)
+            exp_rows = np.concatenate([orcs[j].find(segs[j])[0] for j in range(n_tables)])
+            np.testing.assert_allclose(out.cpu().numpy(), oracle.pool_rows(exp_rows, off, mode), rtol=RTOL, atol=ATOL)
+            if op == "papply":
+                step += 1
+                bg = (rng.standard_normal((lens.size, dim)) * 0.05).astype(np.float32)
+                bag_of = np.repeat(np.arange(lens.size), lens).astype(np.int64)
+                kwargs = dict(lr=0.05) if opt == "adagrad" else dict(lr=0.01, step=step)
+                grp.apply_pooled(T(keys, dev), T(off, dev), T(bg, dev), T(bag_of, dev), opt, located=located, **kwargs)
+                for j in range(n_tables):
+                    lo, hi = off[j * bpt], off[(j + 1) * bpt]
+                    if hi > lo:
+                        gj = bg[bag_of[lo:hi]]
+                        orcs[j].apply_adagrad(segs[j], gj, 0.05, 1e-10) if opt == "adagrad" else orcs[j].apply_adam(segs[j], gj, 0.01, 0.9, 0.999, 1e-8, step)
+        else:
+            j = int(rng.integers(0, n_tables))
+            k = univ[j][rng.integers(0, 400, int(rng.integers(1, 200)))]
+            if op == "insert":
+                if orcs[j].size() + len(np.unique(k)) > tabs[j].capacity - 32:
+                    continue
+                rows = rng.standard_normal((k.size, dim)).astype(np.float32)
+                tabs[j].insert(T(k, dev), T(rows, dev)); orcs[j].insert(k, rows)
+            elif op == "remove":
+                assert np.array_equal(tabs[j].remove(T(k, dev)).cpu().numpy(), orcs[j].remove(k))
+            else:
+                tabs[j].reserve(int(rng.integers(orcs[j].size() + 64, 4000)))   # planes move: the group re-reads them
+    for j in range(n_tables):
+        ga = [x.cpu().numpy() for x in tabs[j].export(with_state=True) if x is not None]
+        oa = [x for x in orcs[j].export(with_state=True) if x is not None]
+        ia, io = np.argsort(ga[0]), np.argsort(oa[0])
+        assert np.array_equal(ga[0][ia], oa[0][io]), j
+        for x, z in zip(ga[1:], oa[1:]):
+            np.testing.assert_allclose(x[ia], z[io], rtol=RTOL, atol=ATOL)
+    grp.close()
