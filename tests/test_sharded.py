@@ -251,3 +251,54 @@ def test_sharded_tiered_multi_rank_on_one_gpu(dev):
 @pytest.mark.gpu
 def test_sharded_rccl_single_gpu(dev):
     _check(_launch(1, "nccl"), 1)
+
+
+def _barrier_timeout_rank(rank, world, port, q):
+    """rank 1 skips a barrier: rank 0's bounded wait must end with the time-out bit, not with a hang"""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        import time
+        from meepoembedding_amd import LookupTable, MeepoError, Router
+        from meepoembedding_amd.p2p import PeerShardedFind
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        pf = PeerShardedFind(LookupTable(1024, DIM, device=dev), Router(world, 256, device=dev), max_batch=256)
+        pf._barrier(); torch.cuda.synchronize()          # a normal barrier first: both ranks arrive
+        pf.check()
+        timed_out = False
+        if rank == 0:
+            t0 = time.time()
+            pf._barrier()                                # rank 1 never announces this epoch
+            torch.cuda.synchronize()
+            waited = time.time() - t0
+            try:
+                pf.check()
+            except MeepoError as e:
+                timed_out = "timed out" in str(e)
+            assert 3.0 < waited < 20.0, waited
+        dist.barrier()                                   # rank 1 waits here (host side) until rank 0 has timed out
+        q.put((rank, timed_out))
+        if rank == 1:
+            pf._barrier(); torch.cuda.synchronize()      # catch up, so that close()'s barrier pairs up again
+        pf.close()
+        dist.destroy_process_group()
+    except BaseException as e:
+        import traceback
+        q.put(("error", rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+        raise
+
+
+@pytest.mark.gpu
+def test_peer_barrier_times_out_instead_of_hanging(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_barrier_timeout_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[0] != "error" for r in res), res
+    assert dict((r[0], r[1]) for r in res) == {0: True, 1: False}
