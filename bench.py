@@ -272,7 +272,7 @@ def main():
                 return shs[i % depth].find(batches[i % n_batches], dedup=args.dedup)
 
         step, transport = step_rccl, "rccl all-to-all"
-        p2p_ok = args.transport in ("auto", "p2p") and not args.dedup and depth == 1
+        p2p_ok = args.transport in ("auto", "p2p") and depth == 1
         if p2p_ok and not args.no_selftest:
             # the peer-mapped path stores into other GPUs' memory from hand-written kernels: prove it on THIS topology in
             # throw-away child processes first, so that a fault or hang there costs the fallback, not the run
@@ -286,7 +286,7 @@ def main():
                 log(f"p2p transport unavailable: {e}")
             if peer is not None:
                 def step_p2p(i):
-                    return peer.find(batches[i % n_batches], check_overflow=False)
+                    return peer.find(batches[i % n_batches], check_overflow=False, dedup=args.dedup)
 
                 o_a, f_a = step_rccl(0)
                 o_b, f_b = step_p2p(0)
@@ -333,7 +333,7 @@ def main():
 
                                 def step_p2p_pipe(i):
                                     with torch.cuda.stream(pstreams[i % pd]):
-                                        return peers[i % pd].find(batches[i % n_batches], check_overflow=False)
+                                        return peers[i % pd].find(batches[i % n_batches], check_overflow=False, dedup=args.dedup)
 
                                 o_c, f_c = step_p2p_pipe(1)      # runs on the second context
                                 torch.cuda.synchronize(dev)

@@ -219,6 +219,13 @@ int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, siz
                   float* d_gsum_out, uint32_t* d_counts_out, int64_t* d_inverse_out, size_t* n_unique_out,
                   void* stream);
 
+/* The keys-only, sync-free form (what a sharded lookup of a skewed batch needs before the exchange): d_uniq_out[n] = the
+ * distinct non-reserved keys in unspecified order followed by MEE_EMPTY_KEY padding, d_inverse_out[i] = index of d_keys[i]
+ * in d_uniq_out, or miss_index for reserved keys.  The number of distinct keys never travels to the host: consumers take the
+ * padded array at its fixed length n (padding is skipped by every operator and by mee_partition_padded). */
+int mee_dedup_keys(mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_uniq_out, int64_t* d_inverse_out, int64_t miss_index,
+                   void* stream);
+
 /* ---- hashing and shard routing (README.md:2 "distributed"; SPEC.md §1, §5) ----------------------------- */
 /* any output nullable: mix64(key), bucket(key, n_buckets), owner(key, n_shards). */
 int mee_hash_batch(const int64_t* d_keys, size_t n, uint64_t n_buckets, uint32_t n_shards, uint64_t* d_mix_out,
@@ -228,6 +235,10 @@ int mee_router_destroy(mee_router* r);
 /* stable partition by owner: d_send_keys[n], d_counts[n_shards] (uint64), d_perm[n] (batch position). */
 int mee_partition(mee_router* r, const int64_t* d_keys, size_t n, int64_t* d_send_keys, uint64_t* d_counts,
                   int64_t* d_perm, void* stream);
+/* the same, dropping MEE_EMPTY_KEY positions (padding belongs to no shard): the counts add up to the non-padding keys, only the
+ * first sum(counts) entries of d_send_keys / d_perm are written. */
+int mee_partition_padded(mee_router* r, const int64_t* d_keys, size_t n, int64_t* d_send_keys, uint64_t* d_counts,
+                         int64_t* d_perm, void* stream);
 /* out[perm[q], :] = rows[q, :] (row_bytes multiple of 4); inverse of the partition for returned rows/masks. */
 int mee_scatter_rows(const void* d_rows, const int64_t* d_perm, size_t n, size_t row_bytes, void* d_out,
                      void* stream);
@@ -251,6 +262,8 @@ int mee_p2p_destroy(mee_p2p* c);
 #define MEE_P2P_BUFFERS 6
 int mee_p2p_export(mee_p2p* c, void* handles /* MEE_P2P_BUFFERS x MEE_IPC_HANDLE_BYTES */);
 int mee_p2p_connect(mee_p2p* c, const void* all_handles /* n_shards x MEE_P2P_BUFFERS x MEE_IPC_HANDLE_BYTES, rank-major */);
+/* result buffers: max_batch + 1 rows / bytes — the spare last one is never written by a lookup; a caller that expands a
+ * de-duplicated lookup through an index array parks its "no such key" positions there. */
 int mee_p2p_buffers(mee_p2p* c, float** d_out, uint8_t** d_found);
 int mee_p2p_push(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts, size_t n,
                  void* stream);

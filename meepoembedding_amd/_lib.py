@@ -85,6 +85,7 @@ PROTOTYPES = {
     "mee_find_pooled": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, C.c_int, _vp]),
     "mee_apply_adagrad_indexed": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _sz, _f32, _f32, _vp]),
     "mee_apply_adam_indexed": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
+    "mee_dedup_keys": (C.c_int, [_vp, _vp, _sz, _vp, _vp, C.c_int64, _vp]),
     "mee_reserve": (C.c_int, [_vp, _u64, _vp]),
     "mee_export_range": (C.c_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), _vp]),
     "mee_size": (C.c_int, [_vp, C.POINTER(_sz), _vp]),
@@ -98,6 +99,7 @@ PROTOTYPES = {
     "mee_hash_batch": (C.c_int, [_vp, _sz, _u64, _u32, _vp, _vp, _vp, _vp]),
     "mee_router_create": (C.c_int, [_i32, _u64, _u32, C.POINTER(_vp)]),
     "mee_router_destroy": (C.c_int, [_vp]),
+    "mee_partition_padded": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "mee_partition": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "mee_p2p_create": (C.c_int, [_i32, _u32, _u32, _u64, _u64, _u32, C.c_int, C.POINTER(_vp)]),
     "mee_p2p_barrier": (C.c_int, [_vp, _vp]),

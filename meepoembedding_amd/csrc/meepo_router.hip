@@ -56,13 +56,16 @@ __global__ void hash_batch_kernel(const int64_t* __restrict__ keys, uint64_t n, 
     }
 }
 
+// SKIP_PAD: EMPTY keys (padding, SPEC.md §2) belong to nobody: not counted, not sent
+template <bool SKIP_PAD>
 __global__ __launch_bounds__(kPartBlock) void part_count_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t g,
                                                                 uint32_t* blockcnt) {
     __shared__ uint32_t wcnt[kPartBlock / 64][kMaxShards];
     const uint32_t i = blockIdx.x * kPartBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const bool inb = i < n;
-    const uint32_t o = inb ? owner_of(keys[i], g) : 0xFFFFFFFFu;
+    const int64_t key = i < n ? keys[i] : kEmpty;
+    const bool inb = i < n && !(SKIP_PAD && key == kEmpty);
+    const uint32_t o = inb ? owner_of(key, g) : 0xFFFFFFFFu;
     for (uint32_t p = 0; p < g; ++p) {
         const uint64_t m = __ballot(o == p);
         if (lane == 0) wcnt[w][p] = (uint32_t)__popcll(m);
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(1024) void part_scan_kernel(uint32_t* blockcnt, uin
     }
 }
 
+template <bool SKIP_PAD>
 __global__ __launch_bounds__(kPartBlock) void part_scatter_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t g,
                                                                   const uint32_t* __restrict__ blockoff,
                                                                   const uint64_t* __restrict__ base, int64_t* send_keys,
@@ -115,8 +119,8 @@ __global__ __launch_bounds__(kPartBlock) void part_scatter_kernel(const int64_t*
     __shared__ uint32_t wcnt[kPartBlock / 64][kMaxShards];
     const uint32_t i = blockIdx.x * kPartBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const bool inb = i < n;
-    const int64_t key = inb ? keys[i] : 0;
+    const int64_t key = i < n ? keys[i] : kEmpty;
+    const bool inb = i < n && !(SKIP_PAD && key == kEmpty);
     const uint32_t o = inb ? owner_of(key, g) : 0xFFFFFFFFu;
     uint32_t r = 0;
     for (uint32_t p = 0; p < g; ++p) {
@@ -375,18 +379,32 @@ int mee_router_create(int32_t device, uint64_t max_batch, uint32_t n_shards, mee
     return MEE_OK;
 }
 
-int mee_partition(mee_router* r, const int64_t* d_keys, size_t n, int64_t* d_send_keys, uint64_t* d_counts, int64_t* d_perm,
-                  void* stream) {
-    if (!r || !d_counts || (n && (!d_keys || !d_send_keys || !d_perm))) return fail(MEE_ERR_INVALID_ARG, "mee_partition: null argument");
-    if (n > r->max_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_partition: n=%zu exceeds max_batch=%llu", n, (unsigned long long)r->max_batch);
+static int partition_common(mee_router* r, const int64_t* d_keys, size_t n, int64_t* d_send_keys, uint64_t* d_counts, int64_t* d_perm,
+                            void* stream, bool skip_pad, const char* name) {
+    if (!r || !d_counts || (n && (!d_keys || !d_send_keys || !d_perm))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
+    if (n > r->max_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "%s: n=%zu exceeds max_batch=%llu", name, n, (unsigned long long)r->max_batch);
     DeviceGuard g(r->device);
     hipStream_t st = (hipStream_t)stream;
     const uint32_t nblk = (uint32_t)((n + kPartBlock - 1) / kPartBlock);
-    if (nblk) part_count_kernel<<<nblk, kPartBlock, 0, st>>>(d_keys, (uint32_t)n, r->n_shards, r->blockcnt);
+    if (nblk) {
+        if (skip_pad) part_count_kernel<true><<<nblk, kPartBlock, 0, st>>>(d_keys, (uint32_t)n, r->n_shards, r->blockcnt);
+        else part_count_kernel<false><<<nblk, kPartBlock, 0, st>>>(d_keys, (uint32_t)n, r->n_shards, r->blockcnt);
+    }
     part_scan_kernel<<<1, 1024, 0, st>>>(r->blockcnt, nblk, r->n_shards, r->base, d_counts);
-    if (nblk) part_scatter_kernel<<<nblk, kPartBlock, 0, st>>>(d_keys, (uint32_t)n, r->n_shards, r->blockcnt, r->base, d_send_keys, d_perm);
+    if (nblk) {
+        if (skip_pad) part_scatter_kernel<true><<<nblk, kPartBlock, 0, st>>>(d_keys, (uint32_t)n, r->n_shards, r->blockcnt, r->base, d_send_keys, d_perm);
+        else part_scatter_kernel<false><<<nblk, kPartBlock, 0, st>>>(d_keys, (uint32_t)n, r->n_shards, r->blockcnt, r->base, d_send_keys, d_perm);
+    }
     MEE_HIP(hipGetLastError());
     return MEE_OK;
+}
+int mee_partition(mee_router* r, const int64_t* d_keys, size_t n, int64_t* d_send_keys, uint64_t* d_counts, int64_t* d_perm,
+                  void* stream) {
+    return partition_common(r, d_keys, n, d_send_keys, d_counts, d_perm, stream, false, "mee_partition");
+}
+int mee_partition_padded(mee_router* r, const int64_t* d_keys, size_t n, int64_t* d_send_keys, uint64_t* d_counts, int64_t* d_perm,
+                         void* stream) {
+    return partition_common(r, d_keys, n, d_send_keys, d_counts, d_perm, stream, true, "mee_partition_padded");
 }
 
 // ---- peer-to-peer exchange: lifetime and IPC ----------------------------------------------------------------------
@@ -430,8 +448,8 @@ int mee_p2p_create(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t sl
         return fine ? hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) : hipMalloc(p, bytes);
     };
     if (sym_alloc((void**)&c->inbox_keys, slots * 8) != hipSuccess || sym_alloc((void**)&c->inbox_dst, slots * 4) != hipSuccess ||
-        sym_alloc((void**)&c->inbox_cnt, 2 * n_shards * 4) != hipSuccess || sym_alloc((void**)&c->out, max_batch * (uint64_t)dim * 4) != hipSuccess ||
-        sym_alloc((void**)&c->found, max_batch) != hipSuccess ||
+        sym_alloc((void**)&c->inbox_cnt, 2 * n_shards * 4) != hipSuccess || sym_alloc((void**)&c->out, (max_batch + 1) * (uint64_t)dim * 4) != hipSuccess ||   // + one spare row: see mee_p2p_buffers
+        sym_alloc((void**)&c->found, max_batch + 1) != hipSuccess ||
         (with_payload && sym_alloc((void**)&c->inbox_rows, slots * (uint64_t)dim * 4) != hipSuccess) ||
         hipMalloc((void**)&c->status, 8) != hipSuccess ||
         hipMalloc((void**)&c->d_tables, kP2PBuffers * (size_t)n_shards * sizeof(void*)) != hipSuccess) {

@@ -949,12 +949,28 @@ __global__ __launch_bounds__(256) void apply_big_kernel(const int64_t* __restric
 }
 
 // ---- standalone duplicate-key reduction (SPEC.md §4) -------------------------------------------------------
-__global__ __launch_bounds__(256) void dedup_fill_kernel(uint32_t n, GroupTable g, BatchScratch bs, int64_t* inverse) {
+__global__ __launch_bounds__(256) void dedup_fill_kernel(uint32_t n, GroupTable g, BatchScratch bs, int64_t* inverse, int64_t miss = -1) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t h = bs.hidx[i];
     if (h != kNoGroup) bs.occ[g.soffs[h] + bs.rank[i]] = i;
-    if (inverse) inverse[i] = h != kNoGroup ? (int64_t)g.sgrp[h] : -1;
+    if (inverse) inverse[i] = h != kNoGroup ? (int64_t)g.sgrp[h] : miss;
+}
+
+// keys-only, sync-free form of the duplicate reduction: uniq_out[0 .. n_uniq) = the distinct keys, uniq_out[n_uniq .. n) = EMPTY
+// (padding), entries released.  The count stays on the device: consumers take the padded array with the fixed length n.
+__global__ __launch_bounds__(256) void dedup_keys_emit_kernel(uint32_t n, GroupTable g, BatchScratch bs, const OpCounters* op,
+                                                              int64_t* uniq_out) {
+    const uint32_t nu = op->n_uniq;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
+        if (u < nu) {
+            const uint32_t h = bs.uniq_h[u];
+            uniq_out[u] = (int64_t)(g.skeys[h] ^ kBias);
+            group_release(g, h);
+        } else {
+            uniq_out[u] = kEmpty;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void dedup_emit_kernel(uint32_t dim4, const float4* __restrict__ grads, GroupTable g,
@@ -1845,6 +1861,26 @@ int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, siz
     MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
     MEE_HIP(hipStreamSynchronize(st));
     *n_unique_out = t->h_op->n_uniq;
+    return MEE_OK;
+}
+
+/* sync-free duplicate elimination of a key batch: d_uniq_out[n] = the distinct non-reserved keys (unspecified order) followed by
+ * EMPTY padding, d_inverse_out[i] = index of keys[i] in d_uniq_out, or miss_index for reserved keys.  Nothing returns to the host. */
+int mee_dedup_keys(mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_uniq_out, int64_t* d_inverse_out, int64_t miss_index,
+                   void* stream) {
+    if (!t || (n && (!d_keys || !d_uniq_out || !d_inverse_out))) return fail(MEE_ERR_INVALID_ARG, "mee_dedup_keys: null argument");
+    if (int rc = check_batch(t, n, "mee_dedup_keys")) return rc;
+    if (n == 0) return MEE_OK;
+    DeviceGuard g(t->device);
+    hipStream_t st = as_stream(stream);
+    const uint32_t nn = (uint32_t)n;
+    const unsigned gl = grid_for(n, 256, 1u << 22);
+    zero_words(t->op, sizeof(OpCounters), st);
+    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr);
+    group_plan_kernel<true><<<grid_for(n, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
+    dedup_fill_kernel<<<gl, 256, 0, st>>>(nn, t->g, t->bs, d_inverse_out, miss_index);
+    dedup_keys_emit_kernel<<<grid_for(n, 256, 4096), 256, 0, st>>>(nn, t->g, t->bs, t->op, d_uniq_out);
+    MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
 

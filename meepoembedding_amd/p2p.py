@@ -72,8 +72,11 @@ class PeerShardedFind:
             check(L.mee_p2p_connect(self._h, b"".join(gathered)))
             po, pf = C.c_void_p(), C.c_void_p()
             check(L.mee_p2p_buffers(self._h, C.byref(po), C.byref(pf)))
-            self.out = torch.as_tensor(_Raw(po.value, (max_batch, self.dim), "<f4"), device=self.device)
-            self.found = torch.as_tensor(_Raw(pf.value, (max_batch,), "|u1"), device=self.device)
+            # + the spare last row / byte (never written by a lookup): where de-duplicated lookups park reserved keys
+            self.out = torch.as_tensor(_Raw(po.value, (max_batch + 1, self.dim), "<f4"), device=self.device)
+            self.found = torch.as_tensor(_Raw(pf.value, (max_batch + 1,), "|u1"), device=self.device)
+            self.out[max_batch].fill_(float(getattr(local, "default_value", 0.0)))
+            self.found[max_batch] = 0
             if payload:
                 pk, pr, ns = C.c_void_p(), C.c_void_p(), C.c_uint64()
                 check(L.mee_p2p_inbox(self._h, C.byref(pk), C.byref(pr), C.byref(ns)))
@@ -111,14 +114,30 @@ class PeerShardedFind:
         else:
             dist.all_reduce(self._tok, group=self.group)  # stream-ordered: waits for this rank's kernels, releases when all arrived
 
-    def find(self, keys: torch.Tensor, check_overflow: bool = True):
-        """Rows and found bytes of `keys` in batch order — VIEWS into the peer-mapped buffers, valid until the next find."""
+    def find(self, keys: torch.Tensor, check_overflow: bool = True, dedup: bool = False):
+        """Rows and found bytes of `keys` in batch order.  Without dedup: VIEWS into the peer-mapped buffers, valid until
+        the next find.  dedup=True (skewed batches): only the batch's DISTINCT keys cross the links — the local table's
+        group table eliminates the duplicates first (sync-free: the distinct keys are padded to the batch length with
+        EMPTY, which the partition drops), every occurrence is then served from its key's row."""
         keys = keys.contiguous().view(-1)
         n = keys.numel()
         if n > self.max_batch:
             raise _lib.MeepoError(_lib.ERR_BATCH_TOO_LARGE, f"n={n} exceeds max_batch={self.max_batch}")
         L = _lib.lib()
         s = torch.cuda.current_stream(self.device).cuda_stream
+        if dedup:
+            uniq, inverse = self.local.dedup_keys(keys, miss_index=self.max_batch)   # reserved keys -> the spare default row
+            send_keys, counts, perm = self.router.partition(uniq, skip_padding=True)
+            check(L.mee_p2p_push(self._h, self.router._h, send_keys.data_ptr(), perm.data_ptr(), counts.data_ptr(), n, s))
+            self._barrier()
+            check(L.mee_p2p_find(self._h, self.local._h, s))
+            self._barrier()
+            if check_overflow:
+                self.check()
+            # positions [0, n_distinct) of the result buffers hold the distinct keys' rows; expand through the index
+            rows = self.router.gather_rows(self.out, inverse, n_out=n)
+            found = self.router.gather_rows(self.found, inverse, n_out=n)
+            return rows, found
         send_keys, counts, perm = self.router.partition(keys)
         check(L.mee_p2p_push(self._h, self.router._h, send_keys.data_ptr(), perm.data_ptr(), counts.data_ptr(), n, s))
         self._barrier()

@@ -38,6 +38,7 @@ class LookupTable:
                           initial_accumulator=initial_accumulator, initializer=initializer, init_scale=init_scale,
                           init_seed=init_seed, value_memory=value_memory, flags=_lib.FLAG_TRACK_HITS if track_hits else 0)
         self.track_hits = track_hits
+        self.default_value = float(default_value)
         h = C.c_void_p()
         self._h = None
         check(L.mee_table_create(C.byref(cfg), C.byref(h)))
@@ -343,6 +344,16 @@ class LookupTable:
     def apply_discard(self) -> None:
         check(_lib.lib().mee_apply_discard(self._h, self._s()))
 
+    def dedup_keys(self, keys: torch.Tensor, miss_index: int = -1):
+        """Sync-free duplicate elimination: (uniq [n] = distinct keys then EMPTY padding, inverse [n] = index into uniq, or
+        miss_index for reserved keys).  How many keys are distinct stays on the device."""
+        k = self._keys(keys)
+        n = k.numel()
+        uniq = torch.empty(n, dtype=torch.int64, device=self.device)
+        inverse = torch.empty(n, dtype=torch.int64, device=self.device)
+        check(_lib.lib().mee_dedup_keys(self._h, k.data_ptr(), n, uniq.data_ptr(), inverse.data_ptr(), int(miss_index), self._s()))
+        return uniq, inverse
+
     def dedup_sum(self, keys: torch.Tensor, grads: torch.Tensor | None = None):
         """Duplicate-key reduction alone: (unique keys, summed grads | None, counts, inverse)."""
         k = self._keys(keys)
@@ -509,14 +520,16 @@ class Router:
         """owner(key) under this router's shard count (SPEC.md §5), int64 per key."""
         return hash_batch(keys, 1, self.n_shards)[2].to(torch.int64)
 
-    def partition(self, keys: torch.Tensor):
+    def partition(self, keys: torch.Tensor, skip_padding: bool = False):
+        """Stable partition by owner -> (send_keys, counts, perm).  skip_padding: EMPTY keys belong to no shard (only the first
+        counts.sum() entries of send_keys / perm are meaningful)."""
         k = keys.contiguous().view(-1)
         n = k.numel()
         send = torch.empty_like(k)
         counts = torch.empty(self.n_shards, dtype=torch.int64, device=self.device)
         perm = torch.empty(n, dtype=torch.int64, device=self.device)
-        check(_lib.lib().mee_partition(self._h, k.data_ptr(), n, send.data_ptr(), counts.data_ptr(), perm.data_ptr(),
-                                       _stream_ptr(self.device)))
+        fn = _lib.lib().mee_partition_padded if skip_padding else _lib.lib().mee_partition
+        check(fn(self._h, k.data_ptr(), n, send.data_ptr(), counts.data_ptr(), perm.data_ptr(), _stream_ptr(self.device)))
         return send, counts, perm
 
     def scatter_rows(self, rows: torch.Tensor, perm: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:

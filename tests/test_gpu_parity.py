@@ -1056,3 +1056,28 @@ def test_random_group_sequences(dev, seed):
         for x, z in zip(ga[1:], oa[1:]):
             np.testing.assert_allclose(x[ia], z[io], rtol=RTOL, atol=ATOL)
     grp.close()
+
+
+def test_dedup_keys_and_padded_partition(dev):
+    """The sync-free pieces of a de-duplicated sharded lookup: mee_dedup_keys (distinct keys + EMPTY padding + inverse) and
+    mee_partition_padded (padding belongs to no shard) against the oracle's dedup / partition of the same keys."""
+    rng = np.random.default_rng(12)
+    t = LookupTable(1024, 16, device=dev, max_batch=8192)
+    u = synth.keys_np(70, 0, 900)
+    keys = u[np.minimum(rng.zipf(1.2, 5000) - 1, 899)].copy()
+    keys[7] = oracle.EMPTY_KEY; keys[11] = oracle.RECLAIMED_KEY
+    uniq, inverse = t.dedup_keys(T(keys, dev), miss_index=8192)
+    uniq, inverse = uniq.cpu().numpy(), inverse.cpu().numpy()
+    ou = oracle.dedup_sum(keys, None, 16)[0]
+    nu = ou.size
+    assert np.array_equal(np.sort(uniq[:nu]), np.sort(ou)) and (uniq[nu:] == oracle.EMPTY_KEY).all()
+    valid = (keys != oracle.EMPTY_KEY) & (keys != oracle.RECLAIMED_KEY)
+    assert np.array_equal(uniq[inverse[valid]], keys[valid]) and (inverse[~valid] == 8192).all()
+    assert t.size() == 0 and t.status() == STATUS_RESERVED_KEY      # scratch only; the tombstone value was flagged
+    for g in (1, 3, 8):
+        r = Router(g, 8192, device=dev)
+        send, counts, perm = r.partition(T(uniq, dev), skip_padding=True)
+        send, counts, perm = send.cpu().numpy(), counts.cpu().numpy(), perm.cpu().numpy()
+        es, ec, ep = oracle.partition(uniq[:nu], g)             # the distinct keys are the first nu entries: same positions
+        assert np.array_equal(counts, ec) and counts.sum() == nu
+        assert np.array_equal(send[:nu], es) and np.array_equal(perm[:nu], ep)

@@ -117,6 +117,9 @@ def _run_rank_body(rank, world, port, backend, q, tiered=False):
                 o3, f3 = pf.find(qk)
                 oe, fe = sh.find(qk)
                 assert torch.equal(o3, oe) and torch.equal(f3, fe)
+                # sync-free pre-exchange dedup over the same transport: only distinct keys travel, same answer
+                o9, f9 = pf.find(qk, dedup=True)
+                assert torch.equal(o9, oe) and torch.equal(f9, fe)
             # inbox overflow is detected, not silently wrong: 7000 copies of one key all go to one owner, whose
             # per-source segment holds 8192/world*1.25+4096 keys
             if world >= 4:
