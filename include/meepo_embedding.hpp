@@ -98,6 +98,10 @@ public:
     size_t dedup_sum(const int64_t* d_keys, const float* d_grads, size_t n, int64_t* d_uniq_out, float* d_gsum_out, uint32_t* d_counts_out, int64_t* d_inverse_out, void* stream = nullptr) {
         size_t u = 0; check(mee_dedup_sum(t_, d_keys, d_grads, n, d_uniq_out, d_gsum_out, d_counts_out, d_inverse_out, &u, stream)); return u;
     }
+    // sync-free: d_uniq_out[n] = distinct keys then EMPTY padding, d_inverse_out[i] = index into it (miss_index for reserved keys)
+    void dedup_keys(const int64_t* d_keys, size_t n, int64_t* d_uniq_out, int64_t* d_inverse_out, int64_t miss_index = -1, void* stream = nullptr) {
+        check(mee_dedup_keys(t_, d_keys, n, d_uniq_out, d_inverse_out, miss_index, stream));
+    }
     void clear(void* stream = nullptr) { check(mee_clear(t_, stream)); }
     // rehash in place to at least `capacity` slots (synchronises; old and new planes must fit together)
     void reserve(uint64_t capacity, void* stream = nullptr) { check(mee_reserve(t_, capacity, stream)); }
@@ -163,6 +167,8 @@ public:
     Router& operator=(const Router&) = delete;
     mee_router* handle() const noexcept { return r_; }
     void partition(const int64_t* d_keys, size_t n, int64_t* d_send_keys, uint64_t* d_counts, int64_t* d_perm, void* stream = nullptr) { check(mee_partition(r_, d_keys, n, d_send_keys, d_counts, d_perm, stream)); }
+    // the same, EMPTY keys (padding) belong to no shard
+    void partition_padded(const int64_t* d_keys, size_t n, int64_t* d_send_keys, uint64_t* d_counts, int64_t* d_perm, void* stream = nullptr) { check(mee_partition_padded(r_, d_keys, n, d_send_keys, d_counts, d_perm, stream)); }
     static void scatter_rows(const void* d_rows, const int64_t* d_perm, size_t n, size_t row_bytes, void* d_out, void* stream = nullptr) { check(mee_scatter_rows(d_rows, d_perm, n, row_bytes, d_out, stream)); }
     static void gather_rows(const void* d_rows, const int64_t* d_perm, size_t n, size_t row_bytes, void* d_out, void* stream = nullptr) { check(mee_gather_rows(d_rows, d_perm, n, row_bytes, d_out, stream)); }
 private:
