@@ -18,7 +18,7 @@ n_tables, dim, batch, ids_per_bag, vocab = 26, 64, 2048, 5, 10**6
 tables = [LookupTable(2 * vocab, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=1 << 18, initializer=INIT_UNIFORM,
                       init_scale=0.05, init_seed=j) for j in range(n_tables)]
 group = TableGroup(tables, max_apply_batch=n_tables * batch * 2 * ids_per_bag)   # an upper bound on the ids of one step
-sparse = DynamicEmbeddingBag(group, mode="sum", optimizer="adagrad", lr=0.05).to(dev)     # bag b -> table b // batch
+sparse = DynamicEmbeddingBag(group, mode="sum", optimizer="adagrad", lr=0.05, create_missing=True).to(dev)   # bag b -> table b // batch; new ids enter their tables in forward
 dense = torch.nn.Sequential(torch.nn.Linear(n_tables * dim, 256), torch.nn.ReLU(), torch.nn.Linear(256, 1)).to(dev)
 dense_opt = torch.optim.SGD(dense.parameters(), lr=0.01)
 
@@ -28,9 +28,7 @@ for step in range(5):
     offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(lens, 0)])
     ids = torch.randint(0, vocab, (int(offsets[-1]),), device=dev)
     labels = torch.rand(batch, 1, device=dev)
-    # new ids enter their tables here (3 launches for the whole collection); the pooled lookup below then finds them
-    group.find_or_insert(ids, offsets[::batch].contiguous())
-    pooled = sparse(ids, offsets)                                        # [n_tables * batch, dim], ONE launch
+    pooled = sparse(ids, offsets)                                        # [n_tables * batch, dim]: 3 launches create new ids, ONE does the pooled lookup
     features = pooled.view(n_tables, batch, dim).transpose(0, 1).reshape(batch, n_tables * dim)
     loss = torch.nn.functional.binary_cross_entropy_with_logits(dense(features), labels)
     dense_opt.zero_grad()

@@ -81,6 +81,13 @@ def lookup_pooled(keys: torch.Tensor, bag_offsets: torch.Tensor, anchor: torch.T
     """-> (pooled rows [n_bags, dim], located rows [n] — per-position handles the backward of this step reuses; empty for a
     single table, whose apply probes for itself)"""
     layer = _layer(table_id)
+    if layer.create_missing and layer.training and keys.numel():
+        # dynamic vocabulary: unseen ids enter their table (hashed initial row + optimizer state) before the pooled lookup
+        if hasattr(layer.table, "apply_pooled"):
+            bpt = (bag_offsets.numel() - 1) // len(layer.table.tables)
+            layer.table.find_or_insert(keys, bag_offsets[::bpt].contiguous())
+        else:
+            layer.table.find_or_insert(keys)
     if hasattr(layer.table, "apply_pooled"):   # a TableGroup
         located = torch.empty(keys.numel(), dtype=torch.int64, device=keys.device)
         out, _ = layer.table.find_pooled(keys, bag_offsets, "mean" if mean else "sum", located=located)
@@ -211,14 +218,15 @@ class DynamicEmbeddingBag(torch.nn.Module, _SparseOptimizerSettings):
     """torch.nn.EmbeddingBag over a lookup table — or over a TableGroup, which makes it an embedding-bag COLLECTION: bag b
     then belongs to member b // bags_per_table and the whole model's sparse forward is one launch, its backward seven.
     (keys [n], bag_offsets [n_bags + 1], both on the device) -> [n_bags, dim] sums or means; backward runs the table's sparse optimizer with the bag's grad row for every member (no [n, dim]
-    tensor exists in either direction).  Ids must be in the table (find_or_insert / insert them first): absent ids read the
-    default row and are not trained."""
+    tensor exists in either direction).  create_missing=True (training mode only): unseen ids are inserted with their
+    hashed initial row first (one more pass over the ids); otherwise absent ids read the default row and are not trained."""
 
-    def __init__(self, table, mode: str = "sum", optimizer: str = "adagrad", lr: float = 0.01, eps: float | None = None, betas=(0.9, 0.999)):
+    def __init__(self, table, mode: str = "sum", optimizer: str = "adagrad", lr: float = 0.01, eps: float | None = None, betas=(0.9, 0.999),
+                 create_missing: bool = False):
         super().__init__()
         if mode not in ("sum", "mean"):
             raise ValueError("mode must be 'sum' or 'mean'")
-        self.table, self.mode = table, mode
+        self.table, self.mode, self.create_missing = table, mode, create_missing
         self._init_settings(optimizer, lr, eps, betas)
 
     def forward(self, keys: torch.Tensor, bag_offsets: torch.Tensor) -> torch.Tensor:

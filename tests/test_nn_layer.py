@@ -169,3 +169,10 @@ def test_embedding_bag_collection_layer(dev):
         ix, iy = torch.argsort(ex[0]), torch.argsort(ey[0])
         torch.testing.assert_close(ex[1][ix], ey[1][iy], rtol=1e-6, atol=1e-9)
         torch.testing.assert_close(ex[2][ix], ey[2][iy], rtol=1e-6, atol=1e-9)
+    # create_missing: unseen ids enter their member table in a training forward, not in eval
+    grow = DynamicEmbeddingBag(TableGroup(a, max_apply_batch=4096), mode="sum", lr=0.05, create_missing=True).to(dev)
+    new_ids = torch.arange(10**9, 10**9 + n_tables * 4, device=dev)
+    new_off = torch.arange(0, n_tables * 4 + 1, 2, dtype=torch.int64, device=dev)       # 2 bags of 2 ids per table
+    before = [t.size() for t in a]
+    grow.eval(); grow(new_ids, new_off); assert [t.size() for t in a] == before
+    grow.train(); grow(new_ids, new_off); assert [t.size() for t in a] == [s + 4 for s in before]
