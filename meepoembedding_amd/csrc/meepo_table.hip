@@ -469,7 +469,9 @@ constexpr int kLds = 512;       // block-local aggregation table (256 threads ->
 // whose CAS claimed the entry needs no counting atomic at all.
 template <int MODE>
 __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ keys, uint32_t n, GroupTable g, BatchScratch bs,
-                                                    Counters* ctr, const uint8_t* __restrict__ skip) {
+                                                    Counters* ctr, const uint8_t* __restrict__ skip, OpCounters* op_to_zero = nullptr) {
+    // the per-op counters are first touched by the kernel AFTER this one (plan pass): zeroing them here saves a launch
+    if (op_to_zero && blockIdx.x == 0 && threadIdx.x < sizeof(OpCounters) / 4) reinterpret_cast<uint32_t*>(op_to_zero)[threadIdx.x] = 0u;
     __shared__ unsigned long long lkey[kLds];
     __shared__ uint32_t lval[kLds], lh[kLds], lbase[kLds];
     for (int j = threadIdx.x; j < kLds; j += 256) { lkey[j] = 0; lval[j] = 0; }
@@ -1638,8 +1640,7 @@ int mee_clear_status(mee_table* t, void* stream) {
 
 // group the batch's keys and plan the duplicate reduction (everything that does not need the grads)
 static int apply_prepare_launch(mee_table* t, const int64_t* d_keys, uint32_t nn, hipStream_t st) {
-    zero_words(t->op, sizeof(OpCounters), st);
-    group_kernel<kGroupCount><<<grid_for(nn, 256, 1u << 22), 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr);
+    group_kernel<kGroupCount><<<grid_for(nn, 256, 1u << 22), 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op);
     group_plan_kernel<false><<<grid_for(nn, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
@@ -1852,8 +1853,7 @@ int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, siz
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
-    zero_words(t->op, sizeof(OpCounters), st);
-    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr);
+    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op);
     group_plan_kernel<true><<<grid_for(n, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
     dedup_fill_kernel<<<gl, 256, 0, st>>>(nn, t->g, t->bs, d_inverse_out);
     dedup_emit_kernel<<<gt, 256, 0, st>>>(t->dim4, (const float4*)d_grads, t->g, t->bs, t->op, d_uniq_out, (float4*)d_gsum_out, d_counts_out);
@@ -1875,8 +1875,7 @@ int mee_dedup_keys(mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_uni
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22);
-    zero_words(t->op, sizeof(OpCounters), st);
-    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr);
+    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op);
     group_plan_kernel<true><<<grid_for(n, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
     dedup_fill_kernel<<<gl, 256, 0, st>>>(nn, t->g, t->bs, d_inverse_out, miss_index);
     dedup_keys_emit_kernel<<<grid_for(n, 256, 4096), 256, 0, st>>>(nn, t->g, t->bs, t->op, d_uniq_out);

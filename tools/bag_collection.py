@@ -20,7 +20,8 @@ def timed(fn, reps=20):
     torch.cuda.synchronize(); e0.record()
     for i in range(reps): fn(i)
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) * 1e3 / reps
-for B in (512, 2048, 8192):
+BS = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else (512, 2048, 8192)
+for B in BS:
     n = T_ * B * L
     grp = TableGroup(tables, max_apply_batch=n)
     gen = torch.Generator(device="cpu").manual_seed(B)
