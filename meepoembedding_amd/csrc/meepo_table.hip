@@ -1463,7 +1463,7 @@ int mee_find_counted(const mee_table* t, const int64_t* d_keys, size_t n, float*
 
 int mee_find_pooled(const mee_table* t, const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t n_bags, float* d_out,
                     uint8_t* d_found, int mode, void* stream) {
-    if (!t || (n_bags && (!d_bag_offsets || !d_out || !d_keys))) return fail(MEE_ERR_INVALID_ARG, "mee_find_pooled: null argument");
+    if (!t || (n_bags && (!d_bag_offsets || !d_out)) || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_find_pooled: null argument");
     if (mode != MEE_POOL_SUM && mode != MEE_POOL_MEAN) return fail(MEE_ERR_INVALID_ARG, "mee_find_pooled: mode must be MEE_POOL_SUM or MEE_POOL_MEAN");
     if (n_bags == 0) return MEE_OK;
     DeviceGuard g(t->device);
@@ -1742,7 +1742,7 @@ int mee_group_apply_adam(mee_group* g, const int64_t* d_keys, const uint64_t* d_
 // ---- the embedding-bag collection: pooled lookups of a whole group in one launch, and their backward -----------------------
 int mee_group_find_pooled(mee_group* g, const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t bags_per_table,
                           float* d_out, uint8_t* d_found, int64_t* d_located_out, int mode, void* stream) {
-    if (!g || (bags_per_table && (!d_bag_offsets || !d_out || !d_keys))) return fail(MEE_ERR_INVALID_ARG, "mee_group_find_pooled: null argument");
+    if (!g || (bags_per_table && (!d_bag_offsets || !d_out)) || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_group_find_pooled: null argument");
     if (mode != MEE_POOL_SUM && mode != MEE_POOL_MEAN) return fail(MEE_ERR_INVALID_ARG, "mee_group_find_pooled: mode must be MEE_POOL_SUM or MEE_POOL_MEAN");
     if (bags_per_table == 0) return MEE_OK;
     if (int rc = group_refresh(g, stream)) return rc;

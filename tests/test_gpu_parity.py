@@ -767,6 +767,8 @@ def test_find_pooled_bit_exact(dev, dim, mode):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
     e_out, _ = t.find_pooled(T(keys[:0], dev), torch.zeros(1, dtype=torch.int64, device=dev))   # zero bags
     assert e_out.shape == (0, dim)
+    e_out, _ = t.find_pooled(T(keys[:0], dev), torch.zeros(4, dtype=torch.int64, device=dev))   # three bags, all empty
+    assert e_out.shape == (3, dim) and not bool(e_out.any())
 
 
 @pytest.mark.parametrize("opt", ["adagrad", "adam"])
