@@ -1083,3 +1083,26 @@ def test_dedup_keys_and_padded_partition(dev):
         es, ec, ep = oracle.partition(uniq[:nu], g)             # the distinct keys are the first nu entries: same positions
         assert np.array_equal(counts, ec) and counts.sum() == nu
         assert np.array_equal(send[:nu], es) and np.array_equal(perm[:nu], ep)
+
+
+def test_new_entry_points_accept_empty_batches(dev):
+    """n = 0 through every grouped / pooled / dedup entry point: a no-op, not an error."""
+    from meepoembedding_amd import TableGroup
+    dim = 64
+    tabs = [LookupTable(256, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=1024) for _ in range(2)]
+    grp = TableGroup(tabs, max_apply_batch=1024)
+    e_keys = torch.zeros(0, dtype=torch.int64, device=dev)
+    e_rows = torch.zeros((0, dim), device=dev)
+    off = torch.zeros(3, dtype=torch.int64, device=dev)
+    assert grp.find(e_keys, off)[0].shape == (0, dim)
+    assert grp.find_or_insert(e_keys, off)[0].shape == (0, dim)
+    grp.apply_adagrad(e_keys, off, e_rows, lr=0.1)
+    out, _ = grp.find_pooled(e_keys, torch.zeros(5, dtype=torch.int64, device=dev))      # 2 bags per table, all empty
+    assert out.shape == (4, dim) and not bool(out.any())
+    grp.apply_pooled(e_keys, torch.zeros(5, dtype=torch.int64, device=dev), torch.zeros((4, dim), device=dev), e_keys, "adagrad", lr=0.1)
+    u, inv = tabs[0].dedup_keys(e_keys)
+    assert u.numel() == 0 and inv.numel() == 0
+    s, c, p = Router(4, 64, device=dev).partition(e_keys, skip_padding=True)
+    assert c.tolist() == [0, 0, 0, 0]
+    tabs[0].apply_adagrad(e_keys, torch.zeros((3, dim), device=dev), lr=0.1, grad_index=e_keys)
+    assert all(t.size() == 0 and t.status() == 0 for t in tabs)
