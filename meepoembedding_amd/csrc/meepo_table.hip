@@ -65,7 +65,8 @@ struct BatchScratch {          // max_batch entries, indexed by batch position u
     uint32_t *hidx, *rank, *pcnt, *occ, *uniq_h, *work;
     uint8_t* fmask;            // found mask of find_or_insert's first pass when the caller passes none
     uint32_t* bigh;            // [max_big] group-table index of each big group
-    double* gacc;              // [max_big][dim] fp64 partial-sum rows: one per chunk of a big group, a group's rows contiguous
+    double* gacc;              // [max_part][dim] fp64 partial-sum rows: one per chunk of a big group, a group's rows contiguous
+    uint32_t max_part;         // rows of gacc (group_plan_kernel never hands out more)
 };
 
 
@@ -82,7 +83,7 @@ struct mee_table {
     float *values, *s1, *s2;
     uint32_t* hits;             // per-slot access counter (config.flags & MEE_FLAG_TRACK_HITS), else null
     // per-batch scratch: group table (S entries) and per-position arrays (max_batch entries)
-    uint64_t S, max_big;
+    uint64_t S, max_big, max_part;   // max_big: groups larger than kChunk; max_part: their fp64 partial-sum rows (one per chunk)
     mee::GroupTable g;
     mee::BatchScratch bs;
     mee::Counters* ctr;
@@ -578,9 +579,13 @@ __global__ __launch_bounds__(1024) void group_plan_kernel(uint32_t n, GroupTable
         if (leader) { const uint32_t u = base_uniq + ex_b; bs.uniq_h[u] = h; g.sgrp[h] = u; }
     } else {
         if (flag_b) bs.work[base_work + ex_b] = i;
-        if (leader && cnt > kChunk) {  // rare: at most n / kChunk groups per batch
+        if (leader && cnt > kChunk) {  // rare: at most n / (kChunk + 1) groups per batch
             bs.bigh[atomicAdd(&op->n_big, 1u)] = h;
-            g.sbig[h] = atomicAdd(&op->n_part, (cnt + kChunk - 1) / kChunk);  // one partial-sum row per chunk
+            // one partial-sum row per chunk: sum over big groups of ceil(cnt / kChunk) <= n / kChunk + n / (kChunk + 1) = max_part,
+            // so the reservation always fits; the clamp only keeps a violated invariant from writing out of bounds
+            const uint32_t rows = (cnt + kChunk - 1) / kChunk;
+            const uint32_t first = atomicAdd(&op->n_part, rows);
+            g.sbig[h] = first + rows <= bs.max_part ? first : 0;
         }
     }
 }
@@ -1296,11 +1301,14 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     ALLOC(t->bs.hidx, mb * 4); ALLOC(t->bs.rank, mb * 4); ALLOC(t->bs.pcnt, mb * 4); ALLOC(t->bs.occ, mb * 4); ALLOC(t->bs.uniq_h, mb * 4);
     ALLOC(t->bs.work, mb * 4); ALLOC(t->bs.fmask, mb);
     t->max_big = mb / kChunk + 1;  // a batch of n keys has at most n / (kChunk + 1) groups larger than kChunk
+    // ... and those groups need ceil(cnt / kChunk) partial-sum rows each: at most n / kChunk + n / (kChunk + 1) rows in all
+    t->max_part = mb / kChunk + mb / (kChunk + 1) + 2;
+    t->bs.max_part = (uint32_t)t->max_part;
     ALLOC(t->bs.bigh, t->max_big * 4);
-    if (t->optimizer != MEE_OPT_NONE) ALLOC(t->bs.gacc, t->max_big * (uint64_t)t->dim * sizeof(double));
+    if (t->optimizer != MEE_OPT_NONE) ALLOC(t->bs.gacc, t->max_part * (uint64_t)t->dim * sizeof(double));
     ALLOC(t->ctr, sizeof(Counters)); ALLOC(t->op, sizeof(OpCounters));
 #undef ALLOC
-    t->workspace_bytes = S * 36 + mb * 25 + t->max_big * 4 + (t->bs.gacc ? t->max_big * (uint64_t)t->dim * sizeof(double) : 0) +
+    t->workspace_bytes = S * 36 + mb * 25 + t->max_big * 4 + (t->bs.gacc ? t->max_part * (uint64_t)t->dim * sizeof(double) : 0) +
                          sizeof(Counters) + sizeof(OpCounters);
     if (hipHostMalloc((void**)&t->h_ctr, sizeof(Counters)) != hipSuccess || hipHostMalloc((void**)&t->h_op, sizeof(OpCounters)) != hipSuccess) {
         rc = fail(MEE_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
@@ -1313,7 +1321,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
         if (e == hipSuccess && t->hits) e = hipMemsetAsync(t->hits, 0, t->capacity * sizeof(uint32_t), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.skeys, 0, S * 8, 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.sv, 0, S * 8, 0);
-        if (e == hipSuccess && t->bs.gacc) e = hipMemsetAsync(t->bs.gacc, 0, t->max_big * (uint64_t)t->dim * sizeof(double), 0);
+        if (e == hipSuccess && t->bs.gacc) e = hipMemsetAsync(t->bs.gacc, 0, t->max_part * (uint64_t)t->dim * sizeof(double), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->ctr, 0, sizeof(Counters), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->op, 0, sizeof(OpCounters), 0);
         if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -1363,6 +1371,7 @@ static void plane_free(uint32_t value_memory, float* p) {
 
 int mee_reserve(mee_table* t, uint64_t new_capacity, void* stream) {
     if (!t || new_capacity == 0) return fail(MEE_ERR_INVALID_ARG, "mee_reserve: null table or zero capacity");
+    if (t->prepared_n) return fail(MEE_ERR_INVALID_ARG, "mee_reserve: a prepared apply is pending on this table (finish it with mee_apply_* or mee_apply_discard)");
     size_t stored = 0;
     if (int rc = mee_size(t, &stored, stream)) return rc;
     const uint64_t nnb = next_prime((new_capacity + kW - 1) / kW), ncap = nnb * kW;
@@ -1401,7 +1410,6 @@ int mee_reserve(mee_table* t, uint64_t new_capacity, void* stream) {
     t->keys = nkeys; t->hits = nhits; t->values = nv; t->s1 = n1; t->s2 = n2;
     t->nb = nnb; t->capacity = ncap;
     t->table_bytes = ncap * sizeof(int64_t) + (nhits ? ncap * sizeof(uint32_t) : 0) + plane * (1 + (n1 != nullptr) + (n2 != nullptr));
-    t->prepared_n = 0;
     ++t->generation;
     return MEE_OK;
 }

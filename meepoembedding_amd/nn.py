@@ -131,11 +131,15 @@ def _setup_pooled(ctx, inputs, output):
     keys, bag_offsets, _, table_id, mean = inputs
     ctx.save_for_backward(keys, bag_offsets, output[1])
     ctx.table_id, ctx.mean = table_id, mean
+    # the located handles are slot numbers: valid only while no member table removes / clears / rehashes rows
+    ctx.layout_epoch = getattr(_layer(table_id).table, "layout_epoch", None)
     ctx.mark_non_differentiable(output[1])
 
 
 def _backward_pooled(ctx, grad_out, _grad_located):
     keys, bag_offsets, located = ctx.saved_tensors
+    if getattr(_layer(ctx.table_id).table, "layout_epoch", None) != ctx.layout_epoch:
+        located = located.new_empty(0)   # a table changed between forward and backward: the apply probes for itself
     apply_grad_pooled(keys, bag_offsets, grad_out.contiguous(), located, ctx.table_id, ctx.mean)
     return None, None, None, None, None
 

@@ -51,6 +51,9 @@ class LookupTable:
         self.capacity, self.n_buckets, self.max_batch = info.capacity, info.n_buckets, info.max_batch
         self.dim, self.optimizer = info.dim, info.optimizer
         self.table_bytes, self.workspace_bytes = info.table_bytes, info.workspace_bytes
+        # bumped by every call that can move or free a stored row (remove / clear / reserve): slot handles taken before it
+        # (the `located` rows a pooled forward hands to its backward) are stale afterwards
+        self.layout_epoch = 0
 
     # -- lifetime ----------------------------------------------------------------------------------------
     def close(self) -> None:
@@ -175,6 +178,7 @@ class LookupTable:
         k = self._keys(keys)
         found = torch.empty(k.numel(), dtype=torch.uint8, device=self.device)
         check(_lib.lib().mee_remove(self._h, k.data_ptr(), k.numel(), found.data_ptr(), self._s()))
+        self.layout_epoch += 1
         return found
 
     def find_or_insert(self, keys: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None):
@@ -202,6 +206,7 @@ class LookupTable:
 
     def clear(self) -> None:
         check(_lib.lib().mee_clear(self._h, self._s()))
+        self.layout_epoch += 1
 
     def set_tuning(self, name: str, value: int) -> None:
         """Performance knob (never changes results): see mee_set_tuning in the header."""
@@ -283,6 +288,7 @@ class LookupTable:
     def reserve(self, capacity: int) -> None:
         """Rehash IN PLACE to at least `capacity` slots (device-to-device; old and new planes must fit together)."""
         check(_lib.lib().mee_reserve(self._h, int(capacity), self._s()))
+        self.layout_epoch += 1
         info = _lib.TableInfo()
         check(_lib.lib().mee_table_info_get(self._h, C.byref(info)))
         self.capacity, self.n_buckets, self.table_bytes = info.capacity, info.n_buckets, info.table_bytes
@@ -388,6 +394,11 @@ class TableGroup:
         with torch.cuda.device(self.device):
             check(_lib.lib().mee_group_create(arr, len(self.tables), int(max_apply_batch), C.byref(h)))
         self._h = h
+
+    @property
+    def layout_epoch(self):
+        """Changes whenever a member table removed, cleared or rehashed rows: located handles from before are stale."""
+        return tuple(t.layout_epoch for t in self.tables)
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -234,6 +234,46 @@ def test_optimizer_parity(dev, opt, dim):
             np.testing.assert_allclose(a[order], b[oorder], rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("opt", ["adagrad", "adam"])
+def test_optimizer_full_batch_of_medium_groups(dev, opt):
+    """n == max_batch and EVERY key repeated 33..40 times: each group is 'big' (> 32 occurrences) and needs TWO fp64
+    partial-sum rows, the worst case for the partial-sum block (about n/32 + n/33 rows; a block sized for n/32 + 1 rows
+    was overrun by exactly this shape)."""
+    dim, batch = 64, 1 << 16
+    rng = np.random.default_rng(77)
+    reps = rng.integers(33, 41, size=batch // 33 + 1)
+    reps = reps[np.cumsum(reps) <= batch]
+    n_keys = reps.size
+    keys = synth.keys_np(57, 0, n_keys + 1); rows = synth.rows_np(keys, dim, 2)
+    bk = np.repeat(keys[:n_keys], reps)
+    bk = np.concatenate([bk, np.full(batch - bk.size, keys[n_keys])])   # the remainder: one more (small or big) group
+    rng.shuffle(bk)
+    assert bk.size == batch
+    kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
+    t = LookupTable(8192, dim, device=dev, optimizer=kind, max_batch=batch, initial_accumulator=0.1)
+    o = oracle.OracleTable(8192, dim, optimizer=okind, initial_accumulator=0.1)
+    t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
+    # a canary table allocated right behind the first one's scratch: an overrun of the partial-sum block would land in it
+    canary = LookupTable(8192, dim, device=dev, optimizer=kind, max_batch=1024)
+    canary.insert(T(keys, dev), T(rows, dev))
+    for s in range(2):
+        g = (rng.standard_normal((batch, dim)) * 0.01).astype(np.float32)
+        if opt == "adagrad":
+            t.apply_adagrad(T(bk, dev), T(g, dev), lr=0.01, eps=1e-10); o.apply_adagrad(bk, g, 0.01, 1e-10)
+        else:
+            t.apply_adam(T(bk, dev), T(g, dev), lr=0.001, step=s + 1); o.apply_adam(bk, g, 0.001, 0.9, 0.999, 1e-8, s + 1)
+    assert t.status() == 0
+    g_ = [x.cpu().numpy() if x is not None else None for x in t.export(with_state=True)]
+    o_ = o.export(with_state=True)
+    order, oorder = np.argsort(g_[0]), np.argsort(o_[0])
+    assert np.array_equal(g_[0][order], o_[0][oorder])
+    for a, b in zip(g_[1:], o_[1:]):
+        if b is not None:
+            np.testing.assert_allclose(a[order], b[oorder], rtol=RTOL, atol=ATOL)
+    got, found = canary.find(T(keys, dev))
+    assert bool(found.all()) and np.array_equal(got.cpu().numpy(), rows)
+
+
 def test_optimizer_unique_keys_bit_exact(dev):
     """No duplicates -> no reduction-order freedom: the HIP update must equal the oracle bit for bit."""
     dim, n = 64, 10000

@@ -23,22 +23,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _batches(world):
+def _batches(world, dim=DIM):
     """Per-rank batches with cross-rank and in-batch duplicates."""
     rng = np.random.default_rng(100)
     keys = synth.keys_np(1, 0, NKEYS)
     out = []
     for r in range(world):
         idx = rng.integers(0, NKEYS, size=BATCH)
-        out.append((keys[idx], rng.standard_normal((BATCH, DIM)).astype(np.float32),
-                    (rng.standard_normal((BATCH, DIM)) * 0.01).astype(np.float32)))
+        out.append((keys[idx], rng.standard_normal((BATCH, dim)).astype(np.float32),
+                    (rng.standard_normal((BATCH, dim)) * 0.01).astype(np.float32)))
     return out
 
 
-def _global_reference(world):
+def _global_reference(world, dim=DIM):
     """One table, batches applied in rank order == SPEC §5 'ordered by source rank then batch position'."""
-    o = oracle.OracleTable(16384, DIM, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
-    b = _batches(world)
+    o = oracle.OracleTable(16384, dim, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
+    b = _batches(world, dim)
     o.insert(np.concatenate([x[0] for x in b]), np.concatenate([x[1] for x in b]))
     o.apply_adagrad(np.concatenate([x[0] for x in b]), np.concatenate([x[2] for x in b]), 0.05, 1e-10)
     for r in range(world):
@@ -50,16 +50,16 @@ def _removed(rank):
     return synth.keys_np(1, 0, NKEYS)[rank * 7::101]
 
 
-def _run_rank(rank, world, port, backend, q, tiered=False):
+def _run_rank(rank, world, port, backend, q, tiered=False, dim=DIM):
     try:
-        _run_rank_body(rank, world, port, backend, q, tiered)
+        _run_rank_body(rank, world, port, backend, q, tiered, dim)
     except BaseException as e:   # report at once: the parent must not sit out its queue timeout on the GPU box
         import traceback
         q.put(("error", rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
         raise
 
 
-def _run_rank_body(rank, world, port, backend, q, tiered=False):
+def _run_rank_body(rank, world, port, backend, q, tiered=False, DIM=DIM):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     if backend == "gloo":
         from _cpu_backend import CpuRouter, CpuTable
@@ -99,7 +99,7 @@ def _run_rank_body(rank, world, port, backend, q, tiered=False):
         router = Router(world, BATCH, device=dev)
     try:
         sh = ShardedLookupTable(local, router)
-        keys, rows, grads = (torch.from_numpy(x).to(dev) for x in _batches(world)[rank])
+        keys, rows, grads = (torch.from_numpy(x).to(dev) for x in _batches(world, DIM)[rank])
         sh.insert(keys, rows)
         sh.apply_adagrad(keys, grads, lr=0.05, eps=1e-10)
         dist.barrier()
@@ -188,8 +188,8 @@ def _run_rank_body(rank, world, port, backend, q, tiered=False):
         dist.destroy_process_group()
 
 
-def _check(results, world):
-    o = _global_reference(world)
+def _check(results, world, dim=DIM):
+    o = _global_reference(world, dim)
     allk, allv, alla = [], [], []
     for rank, probe, out, found, total, ek, ev, ea in results:
         eo, ef = o.find(probe)
@@ -206,11 +206,11 @@ def _check(results, world):
     np.testing.assert_allclose(ga[a], oa[b], rtol=1e-6, atol=1e-9)
 
 
-def _launch(world, backend, tiered=False):
+def _launch(world, backend, tiered=False, dim=DIM):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run_rank, args=(r, world, port, backend, q, tiered)) for r in range(world)]
+    procs = [ctx.Process(target=_run_rank, args=(r, world, port, backend, q, tiered, dim)) for r in range(world)]
     for p in procs:
         p.start()
     results = []
@@ -239,21 +239,38 @@ def test_sharded_tiered_gloo_cpu(built):
     _check(_launch(2, "gloo", tiered=True), 2)
 
 
+# dims: 16 = configs[0], 64 = the metric's / configs[4]'s, 128 = configs[3]'s
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_multi_rank_on_one_gpu(dev, world):
-    _check(_launch(world, "gloo-gpu"), world)
+@pytest.mark.parametrize("world,dim", [(2, 16), (4, 16), (2, 64), (4, 128), (2, 128)])
+def test_sharded_multi_rank_on_one_gpu(dev, world, dim):
+    _check(_launch(world, "gloo-gpu", dim=dim), world, dim)
 
 
 @pytest.mark.gpu
-def test_sharded_tiered_multi_rank_on_one_gpu(dev):
+@pytest.mark.parametrize("dim", [16, 64])
+def test_sharded_tiered_multi_rank_on_one_gpu(dev, dim):
     """configs[4] shape on the HIP backend: two ranks, every shard an HBM table backed by a pinned-host table."""
-    _check(_launch(2, "gloo-gpu", tiered=True), 2)
+    _check(_launch(2, "gloo-gpu", tiered=True, dim=dim), 2, dim)
 
 
 @pytest.mark.gpu
-def test_sharded_rccl_single_gpu(dev):
-    _check(_launch(1, "nccl"), 1)
+@pytest.mark.parametrize("dim", [16, 128])
+def test_sharded_rccl_single_gpu(dev, dim):
+    _check(_launch(1, "nccl", dim=dim), 1, dim)
+
+
+def _n_gpus():
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 GPUs: real RCCL ranks on distinct devices, peer stores over xGMI")
+@pytest.mark.parametrize("dim", [64, 128])
+def test_sharded_rccl_one_rank_per_gpu(dev, dim):
+    """world = every visible GPU (capped at 8): ShardedLookupTable over RCCL and PeerShardedFind over xGMI peer stores
+    (lookups, payload mutators, dedup) — each rank on its own device, all checked against ONE global oracle table."""
+    world = min(_n_gpus(), 8)
+    _check(_launch(world, "nccl", dim=dim), world, dim)
 
 
 def _barrier_timeout_rank(rank, world, port, q):

@@ -19,7 +19,7 @@ def _sorted(exp):
     return [None if x is None else x[order] for x in exp]
 
 
-def _drive(tiered, ref, dev, opt, n_iter=40, seed=0):
+def _drive(tiered, ref, dev, opt, n_iter=40, seed=0, DIM=DIM):
     rng = np.random.default_rng(seed)
     universe = synth.keys_np(70 + seed, 0, 3000)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
@@ -77,14 +77,16 @@ def test_tiered_cpu_logic(built, opt):
     assert 0 < hot.size() <= 600 and cold.size() > 0, "both tiers must have been used"
 
 
+# dims: 16 = configs[0], 64 = configs[4] (the hot/cold tier's stated shape), 128 = configs[3]
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim", [16, 64, 128])
 @pytest.mark.parametrize("opt", [oracle.OPT_ADAGRAD, oracle.OPT_ADAM])
-def test_tiered_hbm_plus_pinned_host(dev, opt):
+def test_tiered_hbm_plus_pinned_host(dev, opt, dim):
     from meepoembedding_amd import LookupTable, _lib
-    hot = LookupTable(1024, DIM, device=dev, optimizer=opt, max_batch=4096, track_hits=True, **KW)
-    cold = LookupTable(8192, DIM, device=dev, optimizer=opt, max_batch=4096, value_memory=_lib.MEM_HOST_PINNED, track_hits=True, **KW)
-    ref = oracle.OracleTable(16384, DIM, optimizer=opt, **KW)
-    _drive(TieredLookupTable(hot, cold, hot_key_limit=600, sample_every=2), ref, dev, opt, seed=10 + int(opt))
+    hot = LookupTable(1024, dim, device=dev, optimizer=opt, max_batch=4096, track_hits=True, **KW)
+    cold = LookupTable(8192, dim, device=dev, optimizer=opt, max_batch=4096, value_memory=_lib.MEM_HOST_PINNED, track_hits=True, **KW)
+    ref = oracle.OracleTable(16384, dim, optimizer=opt, **KW)
+    _drive(TieredLookupTable(hot, cold, hot_key_limit=600, sample_every=2), ref, dev, opt, seed=10 + int(opt), DIM=dim)
     assert 0 < hot.size() <= 600 and cold.size() > 0
 
 
