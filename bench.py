@@ -74,7 +74,8 @@ def cpu_baseline(synth, dim, batch, budget_s=12.0):
     """In-repo CPU oracle find on a bounded sample: 8M-key table (2 GB of rows, DRAM-resident), 256K-key batches."""
     import oracle
     n_keys = 8_000_000
-    cores = max(1, min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0))))  # a 1-GPU box's CPU share is 16 cores
+    # every hardware thread this process may run on (SURVEY §8d: std::thread::hardware_concurrency, here the affinity mask)
+    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
     t = oracle.OracleTable(int(n_keys / 0.75), dim)
     for s in range(0, n_keys, 1_000_000):
         k = synth.keys_np(1, s, 1_000_000)
@@ -91,9 +92,52 @@ def cpu_baseline(synth, dim, batch, budget_s=12.0):
         res[threads] = done * batch / (time.perf_counter() - t0)
     t.close()
     return {"value": res[cores], "unit": "key-lookups/s", "cores": cores, "kind": "port",
-            "single_thread_value": res[1],
+            "single_thread_value": res[1], "hardware_concurrency": os.cpu_count(),
             "sample": f"in-repo CPU oracle (reference snapshot has no implementation): find on an {n_keys // 1_000_000}M-key dim-{dim} "
                       f"table (load 0.75), uniform {batch}-key batches, ~{budget_s / 2:.0f}s per thread count"}
+
+
+def kernel_window(table, batches, out, found, dev, launches=200, regions=5, warm=20):
+    """The dominant kernel alone: `regions` windows of `launches` back-to-back mee_find launches on the launch stream, HIP events
+    around each window, no host sync inside -> (median, min) microseconds per launch.  Independent of --steps, so that the
+    roofline object of a short driver run (--steps 20) agrees with a rocprofv3 average over hundreds of launches."""
+    import statistics
+    nb = len(batches)
+    for i in range(warm):
+        table.find(batches[i % nb], out=out, found=found)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    per = []
+    for r in range(regions):
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for i in range(launches):
+            table.find(batches[(r * launches + i) % nb], out=out, found=found)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        per.append(e0.elapsed_time(e1) * 1e3 / launches)
+    return statistics.median(per), min(per)
+
+
+def stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, uniform_batches, uniform_us):
+    """the same find on (i) uniform, (ii) Zipf(1.05), (iii) 90 % hit / 10 % miss key streams — median of 5
+    windows of 200 launches each, plus mean probe length and the read-only GB/s column (272 B/key at dim 64)."""
+    rows = {}
+    streams = {"uniform": uniform_batches,
+               "zipf_1.05": lookup_batches(synth, n_keys, batch, 16, "zipf", dev, seed=4)}
+    mixed = lookup_batches(synth, n_keys, batch, 16, "uniform", dev, seed=5)
+    g_ = torch.Generator(device=dev)
+    g_.manual_seed(55)
+    for b in mixed:   # 10 % of the positions ask for keys of another stream: absent
+        m = torch.rand(batch, device=dev, generator=g_) < 0.10
+        b[m] = synth.keys_t(99, 0, batch, dev)[m]
+    streams["hit90_miss10"] = mixed
+    for name, bs in streams.items():
+        med, mn = (uniform_us if name == "uniform" and uniform_us else kernel_window(table, bs, out, found, dev))
+        rows[name] = {"us_per_launch_median": med, "us_per_launch_min": mn, "lookups_per_s": batch / med * 1e6,
+                      "algorithmic_GBps": batch * bpl / med / 1e3, "frac_of_hbm_roofline": batch * bpl / med / 1e3 / HBM_PEAK_GBS,
+                      "read_only_GBps": batch * (16 + 4 * dim) / med / 1e3,
+                      "mean_probe_length_buckets": table.probe_length(bs[0])}
+    return rows
 
 
 def two_stream_extra(table, batches, dim, dev, bpl, launches=400):
@@ -205,6 +249,9 @@ def main():
     ap.add_argument("--no-selftest", action="store_true", help="sharded only: skip the child-process self-test of the peer-mapped transport")
     ap.add_argument("--dedup", action="store_true", help="sharded only: exchange only the batch's distinct keys (pays off on skewed streams)")
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even at N=1 (rehearsal of the N>1 code)")
+    ap.add_argument("--launch", choices=["graph", "eager"], default="graph",
+                    help="N=1 find mode: how the K timed steps are issued — one hipGraph replay of K chained kernel nodes (default) or K host launch calls")
+    ap.add_argument("--no-streams", action="store_true", help="skip the SURVEY 8d key-stream table (uniform / Zipf / 90-10 hit-miss) in the JSON line")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -272,6 +319,7 @@ def main():
                 return shs[i % depth].find(batches[i % n_batches], dedup=args.dedup)
 
         step, transport = step_rccl, "rccl all-to-all"
+        peer = None
         p2p_ok = args.transport in ("auto", "p2p") and depth == 1
         if p2p_ok and not args.no_selftest:
             # the peer-mapped path stores into other GPUs' memory from hand-written kernels: prove it on THIS topology in
@@ -279,7 +327,6 @@ def main():
             p2p_ok = p2p_selftest(ctrl, log)
         if p2p_ok:
             from meepoembedding_amd.p2p import PeerShardedFind
-            peer = None
             try:
                 peer = PeerShardedFind(table, Router(world, batch, device=dev), max_batch=batch, payload=train)
             except Exception as e:  # collective failure: every rank lands here together
@@ -290,9 +337,14 @@ def main():
 
                 o_a, f_a = step_rccl(0)
                 o_b, f_b = step_p2p(0)
-                same = torch.tensor([int(torch.equal(o_a, o_b) and torch.equal(f_a, f_b))], device=ctrl)
+                ok_probe = int(torch.equal(o_a, o_b) and torch.equal(f_a, f_b))
+                try:   # an inbox overflow (skewed keys without --dedup) raises only on the ranks whose push overflowed:
+                    peer.check()   # every rank must reach the all-reduce below, or the others hang in the next collective
+                except Exception as e:  # noqa: BLE001
+                    ok_probe = 0
+                    log(f"p2p probe: {e}")
+                same = torch.tensor([ok_probe], device=ctrl)
                 dist.all_reduce(same, op=dist.ReduceOp.MIN)
-                peer.check()
 
                 def timed(fn, k=6):
                     for i in range(3):
@@ -379,14 +431,36 @@ def main():
         if not train:   # in train mode the rows have been updated by earlier warm-up steps
             assert torch.equal(o_rows[:4096], synth.rows_t(chk_keys, dim, 2)), "bench lookup returned wrong rows"
 
+    # ---- the timed region: EXACTLY --steps steps between barrier + synchronize pairs --------------------------------------
+    # N=1 find mode issues the K steps as ONE hipGraph replay (K kernel nodes chained on one stream: the same launches, the
+    # same in-order semantics, without K host-side launch calls in the region); --launch eager keeps one host call per step.
+    graph = None
+    launch_mode = "eager (one host launch call per step)"
+    if args.launch == "graph" and not sharded and not train and args.steps > 0:
+        try:
+            gs_ = torch.cuda.Stream(dev)
+            gs_.wait_stream(torch.cuda.current_stream(dev))
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_, stream=gs_):
+                for i in range(args.steps):
+                    step(i)
+            g_.replay()                       # one untimed replay: upload + first-run costs stay out of the region
+            torch.cuda.synchronize(dev)
+            graph, launch_mode = g_, f"hipGraph: the {args.steps} steps captured as {args.steps} chained kernel nodes, one replay"
+        except Exception as e:  # noqa: BLE001
+            log(f"hipGraph capture unavailable ({e!r}): eager launches")
+            graph = None
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if sharded:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     ev0.record()
-    for i in range(args.steps):
-        step(i)
+    if graph is not None:
+        graph.replay()
+    else:
+        for i in range(args.steps):
+            step(i)
     ev1.record()
     torch.cuda.synchronize(dev)
     if sharded:
@@ -397,21 +471,29 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=ctrl)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    if sharded and peer is not None and step is not step_rccl:
+        # the peer-mapped steps ran with check_overflow=False: a dropped key or a barrier time-out during the measured steps
+        # must not yield a headline number — all ranks agree on the verdict
+        ok_ = 1
+        try:
+            peer.check()
+        except Exception as e:  # noqa: BLE001
+            ok_ = 0
+            print(f"[bench] rank {rank}: peer-mapped transport reported {e} after the timed steps", file=sys.stderr, flush=True)
+        okt = torch.tensor([ok_], dtype=torch.int32, device=ctrl)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:
+            raise SystemExit("bench: the peer-mapped transport overflowed or timed out during the timed steps; rerun with --transport rccl")
 
-    # dominant kernel (find_kernel) alone, HIP events on the launch stream, for the roofline object
-    if sharded:
-        kk = batches[0]
-        for _ in range(5):
-            table.find(kk)
-        torch.cuda.synchronize(dev)
-        ev0.record()
-        for i in range(50):
-            table.find(batches[i % n_batches], out=out, found=found)
-        ev1.record()
-        torch.cuda.synchronize(dev)
-        kern_s = ev0.elapsed_time(ev1) / 1e3 / 50
-    else:
+    # dominant kernel (find_kernel) alone in its own fixed window (5 x 200 launches, HIP events on the launch stream): the
+    # roofline object does not depend on --steps
+    eager_us = None
+    if train and not sharded:
         kern_s = ev_ms / 1e3 / args.steps
+        kern_min_s = kern_s
+    else:
+        med_us, min_us = kernel_window(table, batches, out, found, dev)
+        kern_s, kern_min_s = med_us / 1e6, min_us / 1e6
     bpl = algorithmic_bytes_per_lookup(dim)
     whole = train and not sharded   # sharded runs always price the local find_kernel alone
     if whole:
@@ -430,7 +512,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 if tj.get("batch") == batch and tj.get("dim") == dim and tj.get("keys") == keys_per_gpu:
-                    traffic = tj["bytes_per_launch"]
+                    traffic = tj["bytes_per_launch"]   # measured in separate rocprofv3 --pmc passes (tools/pmc_traffic.py), not in this run
             except Exception:
                 traffic = None
         res = {
@@ -442,13 +524,33 @@ def main():
                                     f"configs[2]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim}, forward find + sparse-Adagrad scatter-update, {batch}-key batches" if train else
                                     f"configs[1]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim} fp32, forward find only, {batch}-key batches"),
                        "keys_per_gpu": keys_per_gpu, "local_size": local_size, "dim": dim, "batch_per_rank": batch, "load_factor": args.load,
-                       "key_distribution": args.dist, "table_gb": round(table.table_bytes / 1e9, 2),
+                       "key_distribution": args.dist, "table_gb": round(table.table_bytes / 1e9, 2), "launch": launch_mode,
                        "parallelism": (f"row-shard x{world}" + (f", {args.pipeline} steps in flight" if args.pipeline > 1 else "") + (", pre-exchange dedup" if args.dedup else "")) if sharded else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic if not whole else None, "kernel": "find_kernel" if not whole else "whole step (find + 5 apply kernels)",
-                         "avg_launch_us": kern_s * 1e6, "algorithmic_bytes_per_lookup": bpl if not whole else step_bytes / batch,
+                         "traffic_source": ("profiles/find_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 per the gfx950 correction)"
+                                            if traffic is not None and not whole else None),
+                         "avg_launch_us": kern_s * 1e6, "min_launch_us": kern_min_s * 1e6,
+                         "window": "median of 5 HIP-event windows of 200 back-to-back launches on the launch stream (independent of --steps)" if not whole else "the timed steps",
+                         "algorithmic_bytes_per_lookup": bpl if not whole else step_bytes / batch,
+                         "read_only_GBps": batch * (16 + 4 * dim) / kern_s / 1e9 if not whole else None,
                          "lookups_per_launch": batch},
         }
+        if not sharded and not train and not args.no_streams:
+            try:
+                res["streams"] = stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, batches, (kern_s * 1e6, kern_min_s * 1e6))
+                # north_star's batch: 1M lookups per launch on the same table (4 consecutive 256K batches concatenated)
+                big = [torch.cat(batches[i:i + 4]) for i in range(0, 16, 4)] if batch * 4 <= table.max_batch * 4 else None
+                if big is not None:
+                    obig = torch.empty((big[0].numel(), dim), dtype=torch.float32, device=dev)
+                    fbig = torch.empty(big[0].numel(), dtype=torch.uint8, device=dev)
+                    m_, n_ = kernel_window(table, big, obig, fbig, dev, launches=100)
+                    nb_ = big[0].numel()
+                    res["streams"][f"uniform_{nb_}_per_launch"] = {"us_per_launch_median": m_, "us_per_launch_min": n_, "lookups_per_s": nb_ / m_ * 1e6,
+                                                                  "algorithmic_GBps": nb_ * bpl / m_ / 1e3, "frac_of_hbm_roofline": nb_ * bpl / m_ / 1e3 / HBM_PEAK_GBS}
+                    del obig, fbig, big
+            except Exception as e:  # noqa: BLE001
+                res["streams"] = {"error": repr(e)}
         if not sharded and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(synth, dim, batch)
         if not sharded and not train and args.extras:

@@ -149,6 +149,9 @@ int mee_reserve(mee_table* t, uint64_t new_capacity, void* stream);
 int mee_size(const mee_table* t, size_t* n_out, void* stream);        /* [syncs] */
 int mee_status(const mee_table* t, uint32_t* bits_out, void* stream); /* [syncs] */
 int mee_clear_status(mee_table* t, void* stream);
+/* [syncs] measurement aid (SURVEY.md §8d "mean probe length"): the number of buckets a find visits for d_keys, summed over
+ * the batch (reserved keys visit none); divide by n for the mean.  Changes nothing. */
+int mee_probe_length(const mee_table* t, const int64_t* d_keys, size_t n, uint64_t* buckets_visited_out, void* stream);
 
 /* ---- table groups: one launch for the lookups of many tables (a model's embedding collection) ----------------
  * All tables of a group live on one device and have the same dim.  The key batches of the tables are concatenated

@@ -1045,6 +1045,34 @@ __global__ __launch_bounds__(256) void hits_scan_kernel(const int64_t* __restric
     }
 }
 
+// ---- probe-length statistics (SURVEY.md §8d "mean probe length"): buckets visited per lookup, summed over the batch ----
+__global__ __launch_bounds__(256) void probe_length_kernel(const int64_t* __restrict__ tkeys, uint64_t nb, const int64_t* __restrict__ keys,
+                                                           uint64_t n, OpCounters* op) {
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    unsigned long long visited = 0;
+    for (uint64_t base = wave * 4; base < n; base += n_waves * 4) {
+        const uint64_t i = base + tile;
+        const int64_t key = i < n ? keys[i] : kEmpty;
+        bool pend = i < n && !reserved_key(key);
+        uint64_t b = bucket_of(key, nb), steps = 0;
+        while (__any(pend)) {
+            const int64_t k = pend ? tkeys[b * kW + tl] : kEmpty;
+            const uint32_t tm = tile_bits(__ballot(pend && k == key), tile);
+            const uint32_t te = tile_bits(__ballot(pend && k == kEmpty), tile);
+            if (pend) {
+                if (tl == 0) ++visited;
+                if (tm || te || ++steps >= nb) pend = false;
+                else b = next_bucket(b, step_of(key, nb), nb);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) visited += __shfl_down(visited, d);
+    if (lane == 0 && visited) atomicAdd(&op->n_export, visited);
+}
+
 // ---- size (SPEC.md §3): count stored keys by scanning the key plane (keeps every atomic off the insert path) ----
 __global__ __launch_bounds__(256) void count_kernel(const int64_t* __restrict__ tkeys, uint64_t capacity, OpCounters* op) {
     __shared__ uint32_t wsum[4];
@@ -1631,6 +1659,20 @@ int mee_size(const mee_table* t, size_t* n_out, void* stream) {
     MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
     MEE_HIP(hipStreamSynchronize(st));
     *n_out = (size_t)t->h_op->n_export;
+    return MEE_OK;
+}
+int mee_probe_length(const mee_table* t, const int64_t* d_keys, size_t n, uint64_t* buckets_visited_out, void* stream) {
+    if (!t || !buckets_visited_out || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_probe_length: null argument");
+    *buckets_visited_out = 0;
+    if (n == 0) return MEE_OK;
+    DeviceGuard g(t->device);
+    hipStream_t st = as_stream(stream);
+    zero_words(&t->op->n_export, sizeof(unsigned long long), st);
+    probe_length_kernel<<<grid_for(n, 16, 4096), 256, 0, st>>>(t->keys, t->nb, d_keys, n, t->op);
+    MEE_HIP(hipGetLastError());
+    MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
+    MEE_HIP(hipStreamSynchronize(st));
+    *buckets_visited_out = (uint64_t)t->h_op->n_export;
     return MEE_OK;
 }
 int mee_status(const mee_table* t, uint32_t* bits_out, void* stream) {

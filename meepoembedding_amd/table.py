@@ -201,6 +201,13 @@ class LookupTable:
         check(_lib.lib().mee_status(self._h, C.byref(b), self._s()))
         return b.value
 
+    def probe_length(self, keys: torch.Tensor) -> float:
+        """Mean number of buckets a find visits for `keys` (measurement aid); synchronises."""
+        k = self._keys(keys)
+        tot = C.c_uint64()
+        check(_lib.lib().mee_probe_length(self._h, k.data_ptr(), k.numel(), C.byref(tot), self._s()))
+        return tot.value / max(1, k.numel())
+
     def clear_status(self) -> None:
         check(_lib.lib().mee_clear_status(self._h, self._s()))
 

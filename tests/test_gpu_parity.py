@@ -254,7 +254,7 @@ def test_optimizer_full_batch_of_medium_groups(dev, opt):
     o = oracle.OracleTable(8192, dim, optimizer=okind, initial_accumulator=0.1)
     t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
     # a canary table allocated right behind the first one's scratch: an overrun of the partial-sum block would land in it
-    canary = LookupTable(8192, dim, device=dev, optimizer=kind, max_batch=1024)
+    canary = LookupTable(8192, dim, device=dev, optimizer=kind, max_batch=4096)
     canary.insert(T(keys, dev), T(rows, dev))
     for s in range(2):
         g = (rng.standard_normal((batch, dim)) * 0.01).astype(np.float32)
