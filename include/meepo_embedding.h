@@ -38,7 +38,8 @@ extern "C" {
 #define MEE_BUCKET_WIDTH  16              /* keys per bucket = one 128-byte line */
 
 enum { MEE_OK = 0, MEE_ERR_INVALID_ARG = -1, MEE_ERR_OUT_OF_MEMORY = -2, MEE_ERR_HIP = -3,
-       MEE_ERR_NO_DEVICE = -4, MEE_ERR_BATCH_TOO_LARGE = -5, MEE_ERR_UNSUPPORTED = -6 };
+       MEE_ERR_NO_DEVICE = -4, MEE_ERR_BATCH_TOO_LARGE = -5, MEE_ERR_UNSUPPORTED = -6,
+       MEE_ERR_RCCL = -7 /* an RCCL call failed, or librccl.so.1 could not be loaded */ };
 
 enum { MEE_OPT_NONE = 0, MEE_OPT_ADAGRAD = 1, MEE_OPT_ADAM = 2 };
 enum { MEE_INIT_CONSTANT = 0, MEE_INIT_UNIFORM = 1 };
@@ -53,6 +54,7 @@ enum { MEE_FLAG_TRACK_HITS = 1u };
 typedef struct mee_table  mee_table;  /* one HBM-resident hash table (one shard) */
 typedef struct mee_router mee_router; /* workspace for the shard partition / un-permute kernels */
 typedef struct mee_p2p    mee_p2p;    /* peer-mapped buffers of the all-to-all-free sharded find */
+typedef struct mee_sharded mee_sharded; /* one rank's context of the row-sharded table: local shard + RCCL communicator */
 #define MEE_IPC_HANDLE_BYTES 64
 
 typedef struct mee_config {
@@ -284,6 +286,48 @@ int mee_p2p_inbox(mee_p2p* c, int64_t** d_keys, float** d_rows, uint64_t* n_slot
  * Collective: every rank calls it the same number of times, in the same order relative to its pushes and finds. */
 int mee_p2p_barrier(mee_p2p* c, void* stream);
 int mee_p2p_status(mee_p2p* c, uint32_t* bits_out, void* stream); /* [syncs]; bit 0: inbox overflow, bit 1: barrier time-out */
+
+
+/* ---- row-sharded table over RCCL (README.md:2 "distributed"; SPEC.md §5; SURVEY.md §8b "sharded variants take a communicator
+ * handle", §8e) -------------------------------------------------------------------------------------------------------------
+ * One process per GPU; every rank owns the keys with owner(key, G) == rank in its own mee_table and creates one context over
+ * an RCCL communicator of the G ranks.  Every mee_sharded_* operator below is COLLECTIVE: all ranks call it, in the same order,
+ * each with its own batch (n may differ per rank, 0 included).  On the caller's stream it runs
+ *     mee_partition -> keys (+ value / gradient rows) to their owners: ncclGroupStart, G x ncclSend/ncclRecv, ncclGroupEnd
+ *     -> the local table's operator over what arrived, ordered by source rank then batch position (so last-wins holds across
+ *     ranks) -> rows and found bytes back in ONE grouped exchange -> un-permute into batch order.
+ * Results are those of ONE table holding all shards (SPEC.md §5).  d_* pointers are device memory on the communicator's device.
+ *
+ * `nccl_comm` is an ncclComm_t passed as void*: the caller's own (borrowed, must outlive the context), or one made with the
+ * three helpers below by callers that do not link RCCL themselves (the library binds librccl.so.1 at first use).
+ *
+ * Segment layout, fixed at creation:
+ *   pad_slack = 0   exact: message sizes come from a counts exchange and ONE host synchronisation per operator [syncs].
+ *   pad_slack >= 1  padded: every (source, owner) segment holds max_batch / G * pad_slack + 1024 positions, unused ones padded
+ *                   with MEE_EMPTY_KEY; message sizes are constants and nothing returns to the host.  A batch that sends one
+ *                   owner more than that loses the surplus keys and sets bit 0 of mee_sharded_status (check it when convenient;
+ *                   skewed batches: mee_dedup_keys first, or the exact layout).  Mutators then hand the local table G x segment
+ *                   positions per call: create it with max_batch >= that. */
+#define MEE_COMM_ID_BYTES 128
+int mee_comm_unique_id(void* id_out /* MEE_COMM_ID_BYTES */);                    /* ncclGetUniqueId: one rank calls, all ranks share the bytes */
+int mee_comm_create(const void* id, uint32_t n_ranks, uint32_t rank, int32_t device, void** comm_out); /* ncclCommInitRank (collective) */
+int mee_comm_destroy(void* comm);
+int mee_sharded_create(mee_table* local, void* nccl_comm, uint64_t max_batch /* largest n of this rank per call */, double pad_slack,
+                       mee_sharded** out);
+int mee_sharded_destroy(mee_sharded* s);
+int mee_sharded_info(const mee_sharded* s, uint32_t* n_shards, uint32_t* rank, uint64_t* segment_capacity /* 0 = exact layout */);
+int mee_sharded_find(mee_sharded* s, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found /* nullable */, void* stream);
+int mee_sharded_find_or_insert(mee_sharded* s, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
+int mee_sharded_insert(mee_sharded* s, const int64_t* d_keys, const float* d_values, size_t n, void* stream);
+int mee_sharded_assign(mee_sharded* s, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found, void* stream);
+int mee_sharded_remove(mee_sharded* s, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream);
+/* one update per distinct key over everything that reaches a shard: its table needs max_batch >= the pairs arriving per call
+ * (<= G x the ranks' n), else MEE_ERR_BATCH_TOO_LARGE on that rank after the exchange has completed everywhere. */
+int mee_sharded_apply_adagrad(mee_sharded* s, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps, void* stream);
+int mee_sharded_apply_adam(mee_sharded* s, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float beta1, float beta2,
+                           float eps, uint64_t step, void* stream);
+int mee_sharded_size(mee_sharded* s, size_t* n_out, void* stream);       /* [syncs] keys stored over all shards (ncclAllReduce) */
+int mee_sharded_status(mee_sharded* s, uint32_t* bits_out, void* stream); /* [syncs]; bit 0: a padded segment overflowed */
 
 #ifdef __cplusplus
 }

@@ -205,4 +205,39 @@ private:
     mee_p2p* c_ = nullptr;
 };
 
+// An RCCL communicator made through the library (callers that link RCCL themselves pass their own ncclComm_t instead).
+class Communicator {
+public:
+    static void unique_id(void* id_128_bytes) { check(mee_comm_unique_id(id_128_bytes)); }   // one rank calls, all ranks share the bytes
+    Communicator(const void* id_128_bytes, uint32_t n_ranks, uint32_t rank, int32_t device) { check(mee_comm_create(id_128_bytes, n_ranks, rank, device, &c_)); }
+    ~Communicator() { if (c_) mee_comm_destroy(c_); }
+    Communicator(const Communicator&) = delete;
+    Communicator& operator=(const Communicator&) = delete;
+    void* handle() const noexcept { return c_; }   // an ncclComm_t
+private:
+    void* c_ = nullptr;
+};
+
+// One rank's view of the row-sharded table (SPEC.md §5): every verb is collective over the communicator's ranks and runs the
+// whole exchange — partition, grouped ncclSend/ncclRecv, the local shard's operator, rows back, un-permute — on `stream`.
+class ShardedTable {
+public:
+    // pad_slack = 0: exact message sizes (one host sync per call); >= 1: fixed EMPTY-padded segments, no host sync
+    ShardedTable(Table& local, void* nccl_comm, uint64_t max_batch, double pad_slack = 0.0) { check(mee_sharded_create(local.handle(), nccl_comm, max_batch, pad_slack, &s_)); }
+    ~ShardedTable() { if (s_) mee_sharded_destroy(s_); }
+    ShardedTable(const ShardedTable&) = delete;
+    ShardedTable& operator=(const ShardedTable&) = delete;
+    void find(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_sharded_find(s_, d_keys, n, d_out, d_found, stream)); }
+    void find_or_insert(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_sharded_find_or_insert(s_, d_keys, n, d_out, d_found, stream)); }
+    void insert(const int64_t* d_keys, const float* d_values, size_t n, void* stream = nullptr) { check(mee_sharded_insert(s_, d_keys, d_values, n, stream)); }
+    void assign(const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_sharded_assign(s_, d_keys, d_values, n, d_found, stream)); }
+    void remove(const int64_t* d_keys, size_t n, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_sharded_remove(s_, d_keys, n, d_found, stream)); }
+    void apply_adagrad(const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps = 1e-10f, void* stream = nullptr) { check(mee_sharded_apply_adagrad(s_, d_keys, d_grads, n, lr, eps, stream)); }
+    void apply_adam(const int64_t* d_keys, const float* d_grads, size_t n, float lr, float b1, float b2, float eps, uint64_t step, void* stream = nullptr) { check(mee_sharded_apply_adam(s_, d_keys, d_grads, n, lr, b1, b2, eps, step, stream)); }
+    size_t size(void* stream = nullptr) { size_t n = 0; check(mee_sharded_size(s_, &n, stream)); return n; }
+    uint32_t status(void* stream = nullptr) { uint32_t b = 0; check(mee_sharded_status(s_, &b, stream)); return b; }
+private:
+    mee_sharded* s_ = nullptr;
+};
+
 }  // namespace meepo

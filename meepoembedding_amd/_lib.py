@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MEE_LIB_PATH") or os.path.join(_HERE, "libmeepo_hip.so")  # MEE_LIB_PATH: A/B against another build
 
 OK = 0
-ERR_INVALID_ARG, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_NO_DEVICE, ERR_BATCH_TOO_LARGE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+ERR_INVALID_ARG, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_NO_DEVICE, ERR_BATCH_TOO_LARGE, ERR_UNSUPPORTED, ERR_RCCL = -1, -2, -3, -4, -5, -6, -7
 OPT_NONE, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
 INIT_CONSTANT, INIT_UNIFORM = 0, 1
 STATUS_TABLE_FULL, STATUS_RESERVED_KEY = 1, 2
@@ -115,6 +115,22 @@ PROTOTYPES = {
     "mee_p2p_status": (C.c_int, [_vp, C.POINTER(_u32), _vp]),
     "mee_scatter_rows": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "mee_gather_rows": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    # row-sharded table over RCCL (meepo_sharded.hip)
+    "mee_comm_unique_id": (C.c_int, [_vp]),
+    "mee_comm_create": (C.c_int, [_vp, _u32, _u32, _i32, C.POINTER(_vp)]),
+    "mee_comm_destroy": (C.c_int, [_vp]),
+    "mee_sharded_create": (C.c_int, [_vp, _vp, _u64, C.c_double, C.POINTER(_vp)]),
+    "mee_sharded_destroy": (C.c_int, [_vp]),
+    "mee_sharded_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u64)]),
+    "mee_sharded_find": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "mee_sharded_find_or_insert": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "mee_sharded_insert": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "mee_sharded_assign": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "mee_sharded_remove": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
+    "mee_sharded_apply_adagrad": (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _vp]),
+    "mee_sharded_apply_adam": (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
+    "mee_sharded_size": (C.c_int, [_vp, C.POINTER(_sz), _vp]),
+    "mee_sharded_status": (C.c_int, [_vp, C.POINTER(_u32), _vp]),
 }
 
 _lib = None
@@ -133,7 +149,7 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if L.mee_abi_version() != 1:
+        if L.mee_abi_version() != 1:  # noqa: PLR2004
             raise ImportError(f"{LIB_PATH}: ABI version {L.mee_abi_version()} != 1")
         _lib = L
     return _lib

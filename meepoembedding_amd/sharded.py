@@ -153,3 +153,126 @@ class ShardedLookupTable:
 
     def _dev(self):
         return getattr(self.local, "device", torch.device("cpu"))
+
+
+class RcclShardedTable:
+    """The same row-sharded table with the whole exchange behind the C-ABI (`mee_sharded_*`, csrc/meepo_sharded.hip):
+    partition, grouped ncclSend/ncclRecv of keys (+ rows), the local operator, ONE grouped exchange of rows + found bytes
+    back and the un-permute all run inside the library on the caller's stream.  `torch.distributed` is only used once, to
+    hand rank 0's ncclUniqueId to the other ranks; per step there is no Python-side collective at all.
+
+    pad_slack = 0: exact message sizes (one host synchronisation per operator, for the split sizes).
+    pad_slack >= 1: fixed-capacity EMPTY-padded segments, no host synchronisation (see include/meepo_embedding.h)."""
+
+    def __init__(self, local, max_batch: int, group=None, pad_slack: float = 0.0):
+        import ctypes as C
+
+        from . import _lib
+        from ._lib import check
+        self._lib, self._check, self._C = _lib, check, C
+        self.local, self.group = local, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device, self.dim, self.max_batch = local.device, local.dim, int(max_batch)
+        L = _lib.lib()
+        self._comm = self._h = None
+        # rank 0 makes the ncclUniqueId; everybody joins the communicator (collective)
+        ident = (C.c_char * 128)()
+        if self.rank == 0:
+            check(L.mee_comm_unique_id(ident))
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        comm = C.c_void_p()
+        check(L.mee_comm_create(box[0], self.world, self.rank, self.device.index, C.byref(comm)))
+        self._comm = comm
+        h = C.c_void_p()
+        check(L.mee_sharded_create(local._h, self._comm, self.max_batch, float(pad_slack), C.byref(h)))
+        self._h = h
+        cap = C.c_uint64()
+        check(L.mee_sharded_info(self._h, None, None, C.byref(cap)))
+        self.segment_capacity = cap.value
+
+    def close(self) -> None:
+        L = self._lib.lib()
+        if getattr(self, "_h", None):
+            L.mee_sharded_destroy(self._h)
+            self._h = None
+        if getattr(self, "_comm", None):
+            L.mee_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _s(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _k(self, keys: torch.Tensor) -> torch.Tensor:
+        if keys.dtype != torch.int64 or keys.device != self.device:
+            raise self._lib.MeepoError(self._lib.ERR_INVALID_ARG, f"keys must be int64 on {self.device}")
+        return keys.contiguous().view(-1)
+
+    def _r(self, rows: torch.Tensor, n: int) -> torch.Tensor:
+        if rows.dtype != torch.float32 or rows.device != self.device or rows.numel() != n * self.dim:
+            raise self._lib.MeepoError(self._lib.ERR_INVALID_ARG, f"rows must be float32 [{n},{self.dim}] on {self.device}")
+        return rows.contiguous()
+
+    def _lookup(self, fn, keys, out, found):
+        k = self._k(keys)
+        n = k.numel()
+        if out is None:
+            out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        if found is None:
+            found = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._check(fn(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), self._s()))
+        return out, found
+
+    def find(self, keys: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None):
+        return self._lookup(self._lib.lib().mee_sharded_find, keys, out, found)
+
+    def find_or_insert(self, keys: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None):
+        return self._lookup(self._lib.lib().mee_sharded_find_or_insert, keys, out, found)
+
+    def insert(self, keys: torch.Tensor, values: torch.Tensor) -> None:
+        k = self._k(keys)
+        v = self._r(values, k.numel())
+        self._check(self._lib.lib().mee_sharded_insert(self._h, k.data_ptr(), v.data_ptr(), k.numel(), self._s()))
+
+    def assign(self, keys: torch.Tensor, values: torch.Tensor) -> torch.Tensor:
+        k = self._k(keys)
+        v = self._r(values, k.numel())
+        found = torch.empty(k.numel(), dtype=torch.uint8, device=self.device)
+        self._check(self._lib.lib().mee_sharded_assign(self._h, k.data_ptr(), v.data_ptr(), k.numel(), found.data_ptr(), self._s()))
+        return found
+
+    def remove(self, keys: torch.Tensor) -> torch.Tensor:
+        k = self._k(keys)
+        found = torch.empty(k.numel(), dtype=torch.uint8, device=self.device)
+        self._check(self._lib.lib().mee_sharded_remove(self._h, k.data_ptr(), k.numel(), found.data_ptr(), self._s()))
+        return found
+
+    def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10) -> None:
+        k = self._k(keys)
+        g = self._r(grads, k.numel())
+        self._check(self._lib.lib().mee_sharded_apply_adagrad(self._h, k.data_ptr(), g.data_ptr(), k.numel(), lr, eps, self._s()))
+
+    def apply_adam(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999,
+                   eps: float = 1e-8, step: int = 1) -> None:
+        k = self._k(keys)
+        g = self._r(grads, k.numel())
+        self._check(self._lib.lib().mee_sharded_apply_adam(self._h, k.data_ptr(), g.data_ptr(), k.numel(), lr, beta1, beta2, eps, step, self._s()))
+
+    def size(self) -> int:
+        n = self._C.c_size_t()
+        self._check(self._lib.lib().mee_sharded_size(self._h, self._C.byref(n), self._s()))
+        return n.value
+
+    def status(self) -> int:
+        b = self._C.c_uint32()
+        self._check(self._lib.lib().mee_sharded_status(self._h, self._C.byref(b), self._s()))
+        return b.value
+
+    def export_local(self, with_state: bool = False):
+        return self.local.export(with_state=with_state)

@@ -132,7 +132,35 @@ int main() try {
       HIPCK(hipDeviceSynchronize());
       auto out = d_out.down(n * dim);
       CHECK(memcmp(out.data(), rows.data(), n * dim * 4) == 0); }
-    printf("host_cpp_test ok: Table, TieredTable (HBM + pinned host) and the peer-mapped sharded pipeline through meepo_embedding.hpp\n");
+    // ---- the RCCL exchange behind the C-ABI, one rank: communicator made through the library, exact and padded layouts ----
+    { char id[MEE_COMM_ID_BYTES];
+      meepo::Communicator::unique_id(id);
+      meepo::Communicator comm(id, 1, 0, 0);
+      for (double slack : {0.0, 1.25}) {
+          meepo::TableOptions so = o; so.optimizer = MEE_OPT_ADAGRAD; so.max_batch = 2 * n + 2048;
+          meepo::Table shard2(so);
+          meepo::ShardedTable st(shard2, comm.handle(), n, slack);
+          st.insert(d_keys.p, d_rows.p, n);
+          CHECK(st.size() == n);
+          st.find(d_q.p, n, d_out.p, d_found.p);
+          HIPCK(hipDeviceSynchronize());
+          auto out = d_out.down(n * dim); auto f = d_found.down(n);
+          for (size_t i = 0; i < n; ++i) {
+              if (i == 5) { CHECK(f[i] == 0 && out[i * dim] == -2.0f); continue; }
+              CHECK(f[i] == 1);
+              CHECK(memcmp(&out[i * dim], &rows[((i * 7919) % n) * dim], dim * 4) == 0);
+          }
+          // one Adagrad step with zero gradients leaves the rows alone; assign of the same rows reports every key present
+          HIPCK(hipMemset(d_out.p, 0, n * dim * 4));
+          st.apply_adagrad(d_keys.p, d_out.p, n, 0.1f);
+          st.assign(d_keys.p, d_rows.p, n, d_found.p);
+          st.remove(d_q.p, 1, nullptr);                                // q[0] is a stored key
+          HIPCK(hipDeviceSynchronize());
+          f = d_found.down(n);
+          for (size_t i = 0; i < n; ++i) CHECK(f[i] == 1);
+          CHECK(st.size() == n - 1 && st.status() == 0 && shard2.status() == 0);
+      } }
+    printf("host_cpp_test ok: Table, TieredTable (HBM + pinned host), the peer-mapped sharded pipeline and the RCCL-backed ShardedTable through meepo_embedding.hpp\n");
     return 0;
 } catch (const std::exception& e) {
     fprintf(stderr, "exception: %s\n", e.what());

@@ -165,6 +165,8 @@ def _run_rank_body(rank, world, port, backend, q, tiered=False, DIM=DIM):
             with pytest.raises(ValueError):
                 PeerShardedFind(local, Router(world, 1 << 16, device=dev), max_batch=1 << 16, payload=True)
             pt.close()
+        if backend == "nccl":
+            _native_rccl_checks(rank, world, dev, DIM, keys, rows, grads, probe, dup, router)
         if not tiered:
             o2, f2 = sh.find(dup, dedup=True)
             assert torch.equal(o1, o2) and torch.equal(f1, f2)
@@ -186,6 +188,57 @@ def _run_rank_body(rank, world, port, backend, q, tiered=False, DIM=DIM):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def _native_rccl_checks(rank, world, dev, dim, keys, rows, grads, probe, dup, router):
+    """The exchange behind the C-ABI (mee_sharded_*: grouped ncclSend/ncclRecv inside the library), exact and padded segment
+    layouts, against the torch.distributed path on tables of their own: same op sequence -> same exports, same lookups."""
+    from meepoembedding_amd import OPT_ADAGRAD, LookupTable
+    from meepoembedding_amd.sharded import RcclShardedTable
+    cap_pad = int(np.ceil(BATCH / world * 1.5)) + 1024
+    mk = lambda: LookupTable(16384, dim, device=dev, optimizer=OPT_ADAGRAD, initial_accumulator=0.1, max_batch=max(world * BATCH, world * cap_pad))
+    l_ref, l_exact, l_pad = mk(), mk(), mk()
+    ref = ShardedLookupTable(l_ref, router)
+    exact = RcclShardedTable(l_exact, BATCH, pad_slack=0.0)
+    padded = RcclShardedTable(l_pad, BATCH, pad_slack=1.5)
+    assert exact.segment_capacity == 0 and padded.segment_capacity == cap_pad
+    fresh_keys = torch.from_numpy(synth.keys_np(78, rank * 300, 300)).to(dev)
+    mix = torch.cat([fresh_keys, probe[:200], fresh_keys[:50]])
+    res = []
+    for t in (ref, exact, padded):
+        t.insert(keys, rows)
+        t.apply_adagrad(keys, grads, lr=0.05, eps=1e-10)
+        fa = t.assign(keys[:300], rows[300:600])
+        fr = t.remove(torch.from_numpy(_removed(rank)).to(dev))
+        t.apply_adagrad(keys[::2], grads[::2], lr=0.01, eps=1e-10)
+        o_p, f_p = t.find(probe)
+        o_d, f_d = t.find(dup[:BATCH])
+        o_m, f_m = t.find_or_insert(mix)
+        o_e, f_e = t.find(probe[:0])          # an empty batch on this rank is still a collective call
+        res.append((fa, fr, o_p, f_p, o_d, f_d, o_m, f_m, t.size()))
+        assert o_e.shape == (0, dim) and f_e.numel() == 0
+    dist.barrier()
+    assert padded.status() == 0, "a padded segment overflowed"
+    for other in res[1:]:
+        for a, b in zip(res[0][:-1], other[:-1]):
+            if a.dtype == torch.uint8:
+                assert torch.equal(a, b)
+            else:
+                torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-9)
+        assert other[-1] == res[0][-1]
+    e_ref = l_ref.export(with_state=True)
+    i_ref = torch.argsort(e_ref[0])
+    for l in (l_exact, l_pad):
+        e = l.export(with_state=True)
+        i = torch.argsort(e[0])
+        assert torch.equal(e[0][i], e_ref[0][i_ref]) and l.status() == 0
+        for xa, xb in zip(e[1:3], e_ref[1:3]):
+            torch.testing.assert_close(xa[i], xb[i_ref], rtol=1e-6, atol=1e-9)
+    # padded layout, overflow is detected: every copy of one key goes to one owner, whose segment holds cap_pad positions
+    if BATCH > cap_pad:
+        padded.find(probe[:1].repeat(BATCH))
+        assert padded.status() & 1
+    exact.close(); padded.close()
 
 
 def _check(results, world, dim=DIM):
