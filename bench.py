@@ -166,25 +166,25 @@ def two_stream_extra(table, batches, dim, dev, bpl, launches=400):
     return {"lookups_per_s": batch / dt, "us_per_batch": dt * 1e6, "frac_of_hbm_roofline": batch * bpl / dt / 1e9 / HBM_PEAK_GBS}
 
 
-def p2p_selftest(ctrl, log, timeout=120) -> bool:
-    """tools/p2p_selftest.py in one child per rank (own gloo group, same GPUs); True only if every child exits 0."""
+def p2p_selftest(ctrl, log, timeout=120, script="p2p_selftest.py", port_offset=17, what="p2p") -> bool:
+    """tools/<script> in one child per rank (own gloo group, same GPUs); True only if every child exits 0."""
     import subprocess
     # the children rendezvous among themselves: their rank 0 hosts a store of its own (torchrun's agent store is not theirs)
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
-    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29531")) + 17)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29531")) + port_offset)
     t0 = time.time()
     err = b""
     try:
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "p2p_selftest.py")], env=env, timeout=timeout,
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)], env=env, timeout=timeout,
                            stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
         rc, err = p.returncode, p.stderr
     except subprocess.TimeoutExpired as e:
         rc, err = -9, e.stderr or b""
     if rc != 0:
-        print(f"[bench] p2p self-test child of rank {os.environ.get('RANK', '0')} rc={rc}: {err.decode(errors='replace')[-800:]}", file=sys.stderr, flush=True)
+        print(f"[bench] {what} self-test child of rank {os.environ.get('RANK', '0')} rc={rc}: {err.decode(errors='replace')[-800:]}", file=sys.stderr, flush=True)
     ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=ctrl)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    log(f"p2p self-test: rc={rc} on this rank, {'passed on all ranks' if int(ok.item()) else 'FAILED somewhere -> rccl all-to-all'} ({time.time() - t0:.1f}s)")
+    log(f"{what} self-test: rc={rc} on this rank, {'passed on all ranks' if int(ok.item()) else 'FAILED somewhere -> not used'} ({time.time() - t0:.1f}s)")
     return bool(int(ok.item()))
 
 
@@ -240,9 +240,10 @@ def main():
     ap.add_argument("--mode", choices=["find", "train"], default="find",
                     help="find = configs[1] (the driver's metric); train = configs[2]: find + sparse-Adagrad apply per step (sharded: gradients travel to the owners too)")
     ap.add_argument("--pipeline", type=int, default=1, help="sharded only: steps in flight on separate HIP streams (1 = off)")
-    ap.add_argument("--transport", choices=["auto", "rccl", "p2p"], default="auto",
-                    help="sharded only: rccl = all-to-all exchange; p2p = owners store rows into the requester's peer-mapped buffer; "
-                         "auto = verify p2p against rccl, time both for a few steps, keep the faster")
+    ap.add_argument("--transport", choices=["auto", "rccl", "native", "p2p"], default="auto",
+                    help="sharded only: rccl = torch.distributed all-to-all exchange; native = the same exchange behind the C-ABI (mee_sharded_*: "
+                         "grouped ncclSend/ncclRecv inside the library; exact and padded segment layouts); p2p = owners store rows into the "
+                         "requester's peer-mapped buffer; auto = verify each against the torch.distributed path, time them for a few steps, keep the fastest")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N>1 flow on a box with fewer GPUs than ranks (exchange staged through host memory)")
     ap.add_argument("--p2p-depth", type=int, default=2, help="sharded, peer-mapped transport: also try this many lookups in flight (own context + stream each) and keep it if faster; 1 = off")
@@ -318,8 +319,52 @@ def main():
             with torch.cuda.stream(streams[i % depth]):
                 return shs[i % depth].find(batches[i % n_batches], dedup=args.dedup)
 
-        step, transport = step_rccl, "rccl all-to-all"
+        def timed(fn, k=6):
+            for i in range(3):
+                fn(i)
+            dist.barrier(); torch.cuda.synchronize(dev)
+            t_ = time.perf_counter()
+            for i in range(k):
+                fn(i)
+            torch.cuda.synchronize(dev)
+            tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=ctrl)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            return float(tt_.item()) / k
+
+        step, transport = step_rccl, "rccl all-to-all (torch.distributed)"
         peer = None
+        t_best = None        # seconds per step of `step`, once something has been timed against it
+        native = None        # the RcclShardedTable that carries `step`, if any
+        # ---- the exchange behind the C-ABI (mee_sharded_*: grouped ncclSend/ncclRecv inside the library), both layouts ----
+        native_ok = args.transport in ("auto", "native") and depth == 1 and args.backend == "nccl" and not args.dedup
+        if native_ok and not args.no_selftest:
+            native_ok = p2p_selftest(ctrl, log, script="rccl_selftest.py", port_offset=23, what="native rccl")
+        if native_ok:
+            from meepoembedding_amd.sharded import RcclShardedTable
+            t_best = timed(step_rccl)
+            log(f"transport probe: torch.distributed all-to-all {t_best * 1e3:.3f} ms/step")
+            for label, slack in (("exact segments, one host sync per lookup", 0.0), ("padded segments, no host sync", 1.04)):
+                try:
+                    nt = RcclShardedTable(table, batch, pad_slack=slack)   # collective (ncclCommInitRank): proven by the self-test
+                except Exception as e:  # noqa: BLE001
+                    log(f"native rccl ({label}) unavailable: {e}")
+                    break
+
+                def step_nat(i, nt=nt):
+                    return nt.find(batches[i % n_batches])
+
+                o_a, f_a = step_rccl(0)
+                o_b, f_b = step_nat(0)
+                okn = torch.tensor([int(torch.equal(o_a, o_b) and torch.equal(f_a, f_b) and nt.status() == 0)], device=ctrl)
+                dist.all_reduce(okn, op=dist.ReduceOp.MIN)
+                if int(okn.item()) != 1:
+                    log(f"native rccl ({label}): differs from the torch.distributed path or a segment overflowed: not used")
+                    nt.close()
+                    continue
+                t_n = timed(step_nat)
+                log(f"transport probe: native rccl ({label}) {t_n * 1e3:.3f} ms/step")
+                if t_n < t_best or (args.transport == "native" and native is None):
+                    step, transport, t_best, native = step_nat, f"RCCL grouped send/recv behind the C-ABI ({label})", t_n, nt
         p2p_ok = args.transport in ("auto", "p2p") and depth == 1
         if p2p_ok and not args.no_selftest:
             # the peer-mapped path stores into other GPUs' memory from hand-written kernels: prove it on THIS topology in
@@ -346,20 +391,9 @@ def main():
                 same = torch.tensor([ok_probe], device=ctrl)
                 dist.all_reduce(same, op=dist.ReduceOp.MIN)
 
-                def timed(fn, k=6):
-                    for i in range(3):
-                        fn(i)
-                    dist.barrier(); torch.cuda.synchronize(dev)
-                    t_ = time.perf_counter()
-                    for i in range(k):
-                        fn(i)
-                    torch.cuda.synchronize(dev)
-                    tt_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=ctrl)
-                    dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
-                    return float(tt_.item()) / k
-
                 if int(same.item()) == 1:
                     t_rccl, t_p2p = timed(step_rccl), timed(step_p2p)
+                    t_best = min(t_best, t_rccl) if t_best is not None else t_rccl
                     # second comparison AFTER the buffers have been through several steps (a stale cache line in the
                     # peer-written result buffer would show here, not on first touch)
                     o_a, f_a = step_rccl(5)
@@ -367,8 +401,8 @@ def main():
                     same = torch.tensor([int(torch.equal(o_a, o_b) and torch.equal(f_a, f_b))], device=ctrl)
                     dist.all_reduce(same, op=dist.ReduceOp.MIN)
                     log(f"transport probe: rccl {t_rccl * 1e3:.3f} ms/step, p2p {t_p2p * 1e3:.3f} ms/step, re-check {'ok' if int(same.item()) else 'MISMATCH'}")
-                    if int(same.item()) == 1 and (args.transport == "p2p" or t_p2p < t_rccl):
-                        step, transport = step_p2p, "peer-mapped stores (no all-to-all)"
+                    if int(same.item()) == 1 and (args.transport == "p2p" or t_p2p < t_best):
+                        step, transport, native = step_p2p, "peer-mapped stores (no all-to-all)", None
                         pd = max(1, args.p2p_depth)
                         if pd > 1 and not train:
                             # several lookups in flight: each owns a context (inboxes, result buffers, barrier flags) and a
@@ -400,12 +434,14 @@ def main():
                     log("p2p transport disagrees with the rccl path: not used")
         if train:   # the data-parallel training step: lookup, then every rank's gradients go to the owners, which apply
             grads = [torch.randn(batch, dim, device=dev) * 0.01 for _ in range(4)]
-            find_step, via_peer = step, step is not step_rccl
+            find_step, via_peer = step, (step is not step_rccl and native is None)
 
             def step(i):
                 r_ = find_step(i)
                 if via_peer:
                     peer.apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10, check_overflow=False)
+                elif native is not None:
+                    native.apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10)
                 else:
                     shs[0].apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10)
                 return r_
@@ -471,7 +507,9 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=ctrl)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    if sharded and peer is not None and step is not step_rccl:
+    if sharded and native is not None and native.status() != 0:
+        raise SystemExit("bench: a padded segment of the native RCCL exchange overflowed during the timed steps; rerun with --transport rccl")
+    if sharded and peer is not None and native is None and step is not step_rccl:
         # the peer-mapped steps ran with check_overflow=False: a dropped key or a barrier time-out during the measured steps
         # must not yield a headline number — all ranks agree on the verdict
         ok_ = 1
