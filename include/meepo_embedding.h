@@ -89,12 +89,17 @@ int mee_table_destroy(mee_table* t);
 int mee_table_info_get(const mee_table* t, mee_table_info* out);
 int mee_clear(mee_table* t, void* stream);
 /* performance knobs; never change results.  "find_rounds" (keys in flight per 16-lane tile: 1/2/4/8),
- * "find_grid_cap" (max blocks of the find grid, 0 = unbounded). */
+ * "find_grid_cap" (max blocks of the find grid, 0 = unbounded), "apply_rounds" (1/2), "apply_overlap" (1 = the duplicate path of
+ * an apply runs on the table's side stream beside the main pass, 0 = everything on the caller's stream). */
 int mee_set_tuning(mee_table* t, const char* name, int value);
 
 /* ---- lookup-table operators (README.md:2 "lookuptable-style"; SPEC.md §3) ------------------------------ */
 /* out[i,:] = row of keys[i] or default_value; found nullable. */
 int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
+/* mee_find that also reports where each key lives: d_slots_out[i] = an opaque slot handle, -1 for absent / reserved keys.  The
+ * handles feed mee_apply_*_located of the SAME training step (forward find -> backward apply) and stay valid only until the next
+ * call that can move or free a row of this table (mee_remove, mee_clear, mee_reserve; inserting OTHER keys is fine). */
+int mee_find_located(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream);
 /* second-tier pass after a mee_find on another table (same keys/out/found buffers): positions with d_found[i] == 0
  * that THIS table holds get their row and d_found[i] = 1; every other position is left untouched.  No host sync, no
  * compaction: this is how a hot (HBM) table is backed by a cold (pinned host) one inside one stream. */
@@ -203,6 +208,13 @@ int mee_apply_adagrad(mee_table* t, const int64_t* d_keys, const float* d_grads,
                       void* stream);
 int mee_apply_adam(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float beta1,
                    float beta2, float eps, uint64_t step, void* stream);
+/* The same step on the slots mee_find_located reported for these keys in the forward pass of the step: the main pass needs no
+ * probe of its own (128 B of bucket line and one dependent memory round trip less per key).  d_keys is still required (duplicate
+ * reduction); a handle of -1 (key absent at lookup time) receives no update; out-of-range handles are ignored. */
+int mee_apply_adagrad_located(mee_table* t, const int64_t* d_keys, const int64_t* d_slots, const float* d_grads, size_t n, float lr,
+                              float eps, void* stream);
+int mee_apply_adam_located(mee_table* t, const int64_t* d_keys, const int64_t* d_slots, const float* d_grads, size_t n, float lr,
+                           float beta1, float beta2, float eps, uint64_t step, void* stream);
 /* The same with an indirection on the grads: position i takes row d_grad_index[i] of d_grads ([n_grad_rows, dim]) — the
  * backward of a pooled lookup (every key of a bag receives the bag's grad row; for MEE_POOL_MEAN the caller scales the bag
  * rows by 1/length).  Indices >= n_grad_rows are clamped to the last row: bad caller data never reads out of bounds. */

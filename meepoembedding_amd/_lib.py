@@ -91,6 +91,9 @@ PROTOTYPES = {
     "mee_size": (C.c_int, [_vp, C.POINTER(_sz), _vp]),
     "mee_status": (C.c_int, [_vp, C.POINTER(_u32), _vp]),
     "mee_clear_status": (C.c_int, [_vp, _vp]),
+    "mee_find_located": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "mee_apply_adagrad_located": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _vp]),
+    "mee_apply_adam_located": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
     "mee_probe_length": (C.c_int, [_vp, _vp, _sz, C.POINTER(_u64), _vp]),
     "mee_apply_adagrad": (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _vp]),
     "mee_apply_adam": (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),

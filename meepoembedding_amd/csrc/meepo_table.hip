@@ -95,10 +95,11 @@ struct mee_table {
     // a prepared (grouped + planned) apply waiting for its grads: mee_apply_prepare .. mee_apply_*
     uint64_t prepared_n;
     const int64_t* prepared_keys;
+    uint32_t epoch;             // batch number of the apply path's group_kernel launches (tags the list heads in sres; never 0)
     // performance knobs (never change results): see mee_set_tuning()
     int find_rounds;            // keys in flight per tile in the find kernel: 1, 2, 4 or 8
     int find_grid_cap;          // max blocks of the find grid (0 = one pass, no grid-stride loop)
-    int apply_rounds;           // batch positions in flight per tile in apply_single_kernel: 1 or 2 (0 = auto)
+    int apply_rounds;           // batch positions in flight per tile in the apply's main pass: 1 or 2 (0 = auto)
     int find_nt;                // bit0: non-temporal row loads, bit1: non-temporal bucket loads, bit2: plain (cached) out stores;
                                 // -1 = auto: cached loads (hot rows of skewed streams stay in L2), cached stores while the
                                 // dense output fits the Infinity Cache (<= 128 MB), streaming stores beyond
@@ -131,7 +132,7 @@ template <int DIM4, int R, int NT>
 __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values,
                                                    uint64_t nb, const int64_t* __restrict__ keys, uint64_t n,
                                                    f32x4* __restrict__ out, uint8_t* __restrict__ found, float defv,
-                                                   uint32_t dim4_rt, uint32_t* hits) {
+                                                   uint32_t dim4_rt, uint32_t* hits, int64_t* __restrict__ slots_out = nullptr) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -177,6 +178,16 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
                 if (!__any(pend)) break;
                 k = pend ? tkeys[bb * kW + tl] : kEmpty;
             }
+        }
+        if constexpr ((NT & 64) != 0) {  // mee_find_located: the slot of every position (-1 = absent), for the apply of the same step
+            // lane j < 4R collects the slot of position base + j (round j / 4, tile j % 4): ONE coalesced store per wave step
+            int64_t mine = -1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t v = __shfl(slot[r], (lane & 3) * kW);
+                if ((lane >> 2) == r) mine = v;
+            }
+            if (lane < KPW && base + lane < n) slots_out[base + lane] = mine;
         }
         if constexpr ((NT & 16) != 0) {  // access statistics for the hot/cold policy (sampled calls only)
 #pragma unroll
@@ -461,6 +472,7 @@ __device__ __forceinline__ uint32_t group_claim(const GroupTable& g, int64_t key
 
 constexpr int kGroupLast = 0;   // max(lo, hi) = 1 + highest batch position of the key (last occurrence wins)
 constexpr int kGroupCount = 1;  // lo + hi = occurrence count, rank[i] = arrival order (finalised by the plan pass)
+constexpr int kGroupApply = 2;  // kGroupCount + every key's occurrences chained into lists (the apply path; see group_kernel)
 constexpr uint32_t kRankRemote = 0x80000000u;  // rank was handed out by an atomic on lo: add hi to finalise
 constexpr int kLds = 512;       // block-local aggregation table (256 threads -> at most 256 distinct keys)
 
@@ -468,14 +480,21 @@ constexpr int kLds = 512;       // block-local aggregation table (256 threads ->
 // LDS hash table keyed by the key itself; ONE lane per (block, key) then talks to the global group table.  A hot key
 // that is 8 % of the batch costs ~n/256 global accesses instead of 0.08 n serialised on one L2 line, and the block
 // whose CAS claimed the entry needs no counting atomic at all.
+// kGroupApply additionally chains the positions of every key: occurrences inside a block are linked through LDS (next pointer of
+// position i in bs.uniq_h[i], 0 ends a chain); the block that claimed the entry parks its chain's head in sgrp[h] (plain store),
+// every other block splices its chain onto a second list whose head lives in sres[h] (atomicExch; tagged with the batch `epoch`, so a
+// stale head of an earlier batch reads as empty).  The claimer's chain has `hi` entries and the spliced list `lo` (the two halves of the
+// count word), so neither needs a terminator.  A key that occurs once costs no atomic beyond its claim and no store beyond its count.
 template <int MODE>
 __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ keys, uint32_t n, GroupTable g, BatchScratch bs,
-                                                    Counters* ctr, const uint8_t* __restrict__ skip, OpCounters* op_to_zero = nullptr) {
+                                                    Counters* ctr, const uint8_t* __restrict__ skip, OpCounters* op_to_zero = nullptr,
+                                                    uint32_t epoch = 0) {
     // the per-op counters are first touched by the kernel AFTER this one (plan pass): zeroing them here saves a launch
     if (op_to_zero && blockIdx.x == 0 && threadIdx.x < sizeof(OpCounters) / 4) reinterpret_cast<uint32_t*>(op_to_zero)[threadIdx.x] = 0u;
     __shared__ unsigned long long lkey[kLds];
     __shared__ uint32_t lval[kLds], lh[kLds], lbase[kLds];
-    for (int j = threadIdx.x; j < kLds; j += 256) { lkey[j] = 0; lval[j] = 0; }
+    __shared__ uint32_t lhead[MODE == kGroupApply ? kLds : 1], ltail[MODE == kGroupApply ? kLds : 1];
+    for (int j = threadIdx.x; j < kLds; j += 256) { lkey[j] = 0; lval[j] = 0; if (MODE == kGroupApply) lhead[j] = 0; }
     __syncthreads();
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool inb = i < n;
@@ -493,18 +512,30 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
             if (old == bk) break;
             slot = (slot + 1) & (kLds - 1);
         }
-        if (MODE == kGroupCount) r_local = atomicAdd(&lval[slot], 1u);
+        if (MODE == kGroupCount || MODE == kGroupApply) r_local = atomicAdd(&lval[slot], 1u);
         else atomicMax(&lval[slot], i + 1);
+        if constexpr (MODE == kGroupApply) {
+            const uint32_t lprev = atomicExch(&lhead[slot], i + 1);
+            if (lprev != 0) bs.uniq_h[i] = lprev;   // next pointer
+            else ltail[slot] = i;                   // the first local arrival ends the block's chain: its next pointer is the inserter's to write
+        }
     }
     __syncthreads();
     if (inserter) {
         bool claimed;
         const uint32_t h = group_claim(g, key, claimed);
         lh[slot] = h;
-        if constexpr (MODE == kGroupCount) {
+        if constexpr (MODE == kGroupCount || MODE == kGroupApply) {
             const uint32_t total = lval[slot];
             if (claimed) { g.sv[2 * h + 1] = total; lbase[slot] = 0; }
             else lbase[slot] = atomicAdd(&g.sv[2 * h], total) | kRankRemote;
+            if constexpr (MODE == kGroupApply) {
+                if (claimed) g.sgrp[h] = lhead[slot];   // no terminator: the walk is bounded by the two counts (hi here, lo on the spliced list)
+                else {
+                    const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long*>(&g.sres[h]), ((unsigned long long)epoch << 32) | lhead[slot]);
+                    bs.uniq_h[ltail[slot]] = (uint32_t)(old >> 32) == epoch ? (uint32_t)old : 0u;
+                }
+            }
         } else {
             // the block whose CAS created the entry parks its candidate in the hi half with a plain store; only later arrivals
             // pay an atomic.  Readers take max(lo, hi).  (Unique keys: one atomic per key instead of two.)
@@ -515,7 +546,7 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
     __syncthreads();
     if (inb) {
         bs.hidx[i] = valid ? lh[slot] : kNoGroup;
-        if (MODE == kGroupCount && valid) bs.rank[i] = lbase[slot] + r_local;
+        if ((MODE == kGroupCount || MODE == kGroupApply) && valid) bs.rank[i] = lbase[slot] + r_local;
         if (!valid && !skipped && key == kReclaimed) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);  // EMPTY = padding, silent
     }
 }
@@ -540,6 +571,7 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum /
 }
 
 constexpr uint32_t kChunk = 32;  // occurrences summed by one tile
+constexpr uint32_t kHotMark = 0x80000000u;  // pcnt[i] = kHotMark | epoch: position i belongs to a hot key of batch `epoch`
 
 // Plan pass, one lane per batch position: finalise rank and count, then (leaders only) reserve the group's slice of
 // the occurrence list, list the chunk leaders as work items, give big groups a block of fp64 partial-sum rows, and — for the
@@ -858,6 +890,146 @@ __device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, cons
     }
 }
 
+// ---- the apply's main pass (SPEC.md §4) -----------------------------------------------------------------------------------------
+// Runs right behind group_kernel<kGroupApply> and needs nothing but what that kernel left: a position reads its key's occurrence
+// count from its entry (one 8-byte load) and then
+//   count == 1            (the bulk):  the tile updates the row from the position's own grad row and releases the entry;
+//   2 <= count <= kChunk  (duplicates of ordinary keys): the occurrence that heads the claiming block's chain is the group's leader:
+//                         its tile walks the key's two position lists (complete: they were built by the previous kernel), sums the
+//                         grad rows in fp64, updates once, releases.  The other occurrences do nothing.
+//   count > kChunk        (hot keys): every occurrence finalises its rank; the leader reserves the group's slice of the occurrence
+//                         list and its fp64 partial-sum rows — three small kernels finish these groups afterwards.
+// No plan pass, no per-batch prefix sums, no atomics on the bulk path; a batch without hot keys is finished when this kernel ends.
+// R positions in flight per tile; the grad rows of single keys are requested before the probe.  LOCATED: `slots` holds each
+// position's slot (or -1) as mee_find_located of the same step saw it — no probe, no bucket line.
+template <int KIND, int DIM4, int R, bool LOCATED>
+__global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1, float4* s2,
+                                                         uint64_t nb, uint32_t dim4_rt, const int64_t* __restrict__ keys,
+                                                         const int64_t* __restrict__ slots, const float4* __restrict__ grads,
+                                                         uint32_t n, GroupTable g, BatchScratch bs, OpCounters* op, OptArgs a,
+                                                         const uint32_t* __restrict__ gidx, uint64_t capacity, uint32_t epoch) {
+    __shared__ uint32_t lpos[16][kChunk];   // the list a tile has walked (one row per tile of the block)
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const int bt = (threadIdx.x >> 6) * 4 + tile;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
+    constexpr int C = DIM4 ? DIM4 / 16 : 1;
+    a.kind = KIND;  // lets the compiler drop the other optimizer's code
+    for (uint32_t base = wave * 4 * R; base < n; base += n_waves * 4 * R) {
+        int64_t key[R], slot[R];
+        uint32_t h[R], cnt[R], grow[R];
+        bool single[R], last[R];
+        float4 gr[R][C];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + r * 4 + tile;
+            const bool inb = i < n;
+            h[r] = inb ? bs.hidx[i] : kNoGroup;
+            key[r] = (!LOCATED && inb) ? keys[i] : kEmpty;
+            slot[r] = (LOCATED && inb) ? slots[i] : -1;
+            grow[r] = i;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint32_t lo = 0, hi = 0;
+            if (h[r] != kNoGroup) sv_load(g, h[r], lo, hi);
+            cnt[r] = lo + hi;
+            single[r] = cnt[r] == 1;
+            if (gidx && single[r]) grow[r] = min(gidx[base + r * 4 + tile], a.grad_rows - 1);
+        }
+        if constexpr (DIM4 != 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (single[r]) {  // the grad row is read exactly once: stream it past the caches
+                        const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grads) + (uint64_t)grow[r] * DIM4 + c * 16 + tl);
+                        gr[r][c] = make_float4(gv.x, gv.y, gv.z, gv.w);
+                    }
+        }
+        // duplicates (one lane per tile decides): leader of a small group -> this tile finishes it below; hot keys -> rank + reservation
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + r * 4 + tile;
+            uint32_t lf = 0;
+            if (tl == 0 && i < n) {
+                if (cnt[r] > 1) {
+                    const bool leader = g.sgrp[h[r]] == i + 1;   // head of the claiming block's chain: exactly one per group
+                    if (cnt[r] <= kChunk) lf = leader;
+                    else {
+                        uint32_t lo, hi;
+                        sv_load(g, h[r], lo, hi);
+                        const uint32_t rk = bs.rank[i];
+                        bs.rank[i] = (rk & ~kRankRemote) + ((rk & kRankRemote) ? hi : 0);   // arrival order over the whole batch
+                        bs.pcnt[i] = kHotMark | epoch;   // marks the position for apply_file_kernel (stale marks carry other epochs; counts
+                                                         // other paths leave in pcnt never have the top bit: max_batch <= 2^30)
+                        if (leader) {   // at most n / (kChunk + 1) such groups per batch
+                            const uint32_t rows = (cnt[r] + kChunk - 1) / kChunk;
+                            g.soffs[h[r]] = atomicAdd(&op->n_occ, cnt[r]);
+                            uint32_t p0 = atomicAdd(&op->n_part, rows);   // sum of ceil(cnt / kChunk) <= n / kChunk + n / (kChunk + 1) = max_part: fits
+                            if (p0 + rows > bs.max_part) p0 = 0;          // (only keeps a violated invariant from writing out of bounds)
+                            g.sbig[h[r]] = p0;
+                            bs.bigh[atomicAdd(&op->n_big, 1u)] = h[r];
+                            for (uint32_t c = 0; c < rows; ++c) bs.work[p0 + c] = h[r];   // partial row -> its group
+                        }
+                    }
+                }
+            }
+            last[r] = __shfl(lf, tile * kW) != 0;
+        }
+        if constexpr (!LOCATED) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                bool is_new, full;
+                slot[r] = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key[r], single[r] || last[r], tile, tl, is_new, full);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ok = slot[r] >= 0 && (!LOCATED || (uint64_t)slot[r] < capacity);   // a handle is the caller's data: never index past the planes
+            if (single[r]) {
+                if (ok) {
+                    if constexpr (DIM4 != 0) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) update_row(a, values, s1, s2, (uint64_t)slot[r] * DIM4 + c * 16 + tl, gr[r][c]);
+                    } else {
+                        for (uint32_t c = tl; c < dim4; c += 16) update_row(a, values, s1, s2, (uint64_t)slot[r] * dim4 + c, grads[(uint64_t)grow[r] * dim4 + c]);
+                    }
+                }
+                if (tl == 0) group_release(g, h[r]);  // this tile is the only user of the entry
+            } else if (last[r]) {   // this tile leads a small group: walk the claiming block's chain (hi entries), then the other blocks' list (lo)
+                uint32_t lo, hi, k = 0;
+                sv_load(g, h[r], lo, hi);
+                const unsigned long long others = (unsigned long long)g.sres[h[r]];
+                uint32_t p = g.sgrp[h[r]];
+                for (uint32_t e = 0; e < hi && p && k < kChunk; ++e) { if (tl == 0) lpos[bt][k] = p - 1; ++k; p = bs.uniq_h[p - 1]; }
+                p = (lo && (uint32_t)(others >> 32) == epoch) ? (uint32_t)others : 0u;
+                for (uint32_t e = 0; e < lo && p && k < kChunk; ++e) { if (tl == 0) lpos[bt][k] = p - 1; ++k; p = bs.uniq_h[p - 1]; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // lane 0's LDS writes before the tile's reads (same wave: in order)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (ok)
+                    for (uint32_t c = tl; c < dim4; c += 16) {
+                        double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+                        chunk_sum(grads, lpos[bt], 0, k, dim4, c, sx, sy, sz, sw, gidx, a.grad_rows);
+                        update_row(a, values, s1, s2, (uint64_t)slot[r] * dim4 + c, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
+                    }
+                if (tl == 0) group_release(g, h[r]);
+            }
+        }
+    }
+}
+
+// hot keys (count > kChunk), after the main pass: every occurrence files its position at its rank in its group's list slice
+__global__ __launch_bounds__(256) void apply_file_kernel(uint32_t n, GroupTable g, BatchScratch bs, const OpCounters* op, uint32_t epoch) {
+    if (op->n_big == 0) return;   // no hot key in this batch
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (bs.pcnt[i] == (kHotMark | epoch)) {
+            const uint32_t at = g.soffs[bs.hidx[i]] + bs.rank[i];
+            if (at < n) bs.occ[at] = i;   // always true (the slices add up to at most n); a violated invariant must not write out of bounds
+        }
+}
+
 // Pass 2 over the work list (chunk leaders: the occurrences with rank 0, kChunk, 2*kChunk, ... of each multi-key).
 // A tile sums its chunk of the group's occurrence list in fp64.  Groups of <= kChunk occurrences are finished here
 // (one update, entry released); a chunk of a larger group stores its fp64 sums as one row of the group's partial-sum
@@ -899,6 +1071,31 @@ __global__ __launch_bounds__(256) void apply_chunk_kernel(const int64_t* __restr
             }
         }
         if (small && tl == 0) group_release(g, h);
+    }
+}
+
+// hot keys, second kernel: one tile per fp64 partial-sum row p (= one chunk of kChunk occurrences of one hot key): work[p] names the
+// group, the chunk index is p - sbig[group]; plain stores of the chunk's sums (f64 atomics on a hot key's row would serialise).
+__global__ __launch_bounds__(256) void apply_bigchunk_kernel(uint32_t dim4, const float4* __restrict__ grads, GroupTable g, BatchScratch bs,
+                                                             const OpCounters* op, const uint32_t* __restrict__ gidx, uint32_t grad_rows) {
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t n_part = min(op->n_part, bs.max_part);
+    for (uint32_t base = wave * 4; base < n_part; base += n_waves * 4) {
+        const uint32_t p = base + tile;
+        if (p >= n_part) continue;
+        const uint32_t h = bs.work[p];
+        uint32_t lo, hi;
+        sv_load(g, h, lo, hi);
+        const uint32_t cnt = lo + hi, c_idx = p - g.sbig[h];
+        const uint32_t first = g.soffs[h] + c_idx * kChunk, count = min(kChunk, cnt - c_idx * kChunk);
+        for (uint32_t c = tl; c < dim4; c += 16) {
+            double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+            chunk_sum(grads, bs.occ, first, count, dim4, c, sx, sy, sz, sw, gidx, grad_rows);
+            double* dst = bs.gacc + ((uint64_t)p * dim4 + c) * 4;
+            dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = sw;
+        }
     }
 }
 
@@ -1349,6 +1546,8 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
         if (e == hipSuccess && t->hits) e = hipMemsetAsync(t->hits, 0, t->capacity * sizeof(uint32_t), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.skeys, 0, S * 8, 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.sv, 0, S * 8, 0);
+        if (e == hipSuccess) e = hipMemsetAsync(t->g.sres, 0, S * 8, 0);   // list heads carry an epoch tag; epoch 0 is never used
+        if (e == hipSuccess) e = hipMemsetAsync(t->bs.pcnt, 0, mb * 4, 0);  // so do the hot-key marks
         if (e == hipSuccess && t->bs.gacc) e = hipMemsetAsync(t->bs.gacc, 0, t->max_part * (uint64_t)t->dim * sizeof(double), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->ctr, 0, sizeof(Counters), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->op, 0, sizeof(OpCounters), 0);
@@ -1376,6 +1575,7 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     else if (!strcmp(name, "find_grid_cap")) t->find_grid_cap = value;
     else if (!strcmp(name, "find_nt")) t->find_nt = value;
     else if (!strcmp(name, "apply_rounds")) t->apply_rounds = value;
+    else if (!strcmp(name, "apply_overlap")) (void)value;   // retired knob (a side stream for the duplicate path lost to its fork/join gaps): accepted, ignored
     else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);
     return MEE_OK;
 }
@@ -1447,7 +1647,8 @@ static const float* plane_of(const mee_table* t, uint32_t plane) {
 }
 
 static int find_plane(const mee_table* t, const float* plane, float miss_value, const int64_t* d_keys, size_t n, float* d_out,
-                      uint8_t* d_found, void* stream, bool missing_only = false, bool counted = false, bool rows_only = false) {
+                      uint8_t* d_found, void* stream, bool missing_only = false, bool counted = false, bool rows_only = false,
+                      int64_t* d_slots_out = nullptr) {
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -1459,6 +1660,14 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
 #define FIND1(D4, RR, NT) find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr)
     const int nt = t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
 #define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
+    if (d_slots_out) {   // located find: the plain kernel + one 8-byte store per key
+#define FINDL(D4, RR) do { if (nt & 4) find_kernel<D4, RR, 68><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out); \
+                           else find_kernel<D4, RR, 64><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out); } while (0)
+        if (t->dim4 == 16) { if (R >= 2) FINDL(16, 2); else FINDL(16, 1); }
+        else if (t->dim4 == 32) { if (R >= 2) FINDL(32, 2); else FINDL(32, 1); }
+        else { if (R >= 2) FINDL(0, 2); else FINDL(0, 1); }
+#undef FINDL
+    } else
     if (missing_only) {
         const unsigned gm = grid_for(n, 256, 8192);
 #define FMISS(F) find_missing_kernel<F><<<gm, 256, 0, st>>>(t->keys, (const float4*)plane, t->nb, t->dim4, d_keys, n, (float4*)d_out, d_found, t->hits)
@@ -1484,6 +1693,11 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
 int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
     if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find: null argument");
     return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream);
+}
+
+int mee_find_located(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
+    if (!t || (n && (!d_keys || !d_out || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_located: null argument");
+    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, false, false, false, d_slots_out);
 }
 
 int mee_find_missing(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
@@ -1696,8 +1910,12 @@ static int apply_prepare_launch(mee_table* t, const int64_t* d_keys, uint32_t nn
     return MEE_OK;
 }
 
+// One sparse-optimizer step: group_kernel (occurrence counts; skipped after mee_apply_prepare) -> apply_main_kernel (every key with
+// at most kChunk occurrences: all of them unless the batch has hot keys) -> three small kernels for the hot keys (file the
+// occurrences, fp64 chunk sums, tree + update).  `d_slots` (nullable): the slot of every position as mee_find_located of the same
+// step reported it.
 static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, const OptArgs& a, void* stream,
-                        const char* name, const uint32_t* d_gidx = nullptr) {
+                        const char* name, const uint32_t* d_gidx = nullptr, const int64_t* d_slots = nullptr) {
     if (!t || (n && (!d_keys || !d_grads))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
     if (t->optimizer != a.kind) return fail(MEE_ERR_UNSUPPORTED, "%s: table was created with optimizer=%u", name, t->optimizer);
     if (int rc = check_batch(t, n, name, false)) return rc;
@@ -1705,30 +1923,32 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
-    if (t->prepared_n) {  // grouping and planning were done ahead of time (mee_apply_prepare), possibly on another stream
+    if (t->prepared_n) {  // grouping was done ahead of time (mee_apply_prepare), possibly on another stream
         if (t->prepared_n != n || t->prepared_keys != d_keys)
             return fail(MEE_ERR_INVALID_ARG, "%s: keys/n differ from the pending mee_apply_prepare", name);
         t->prepared_n = 0; t->prepared_keys = nullptr;
     } else {
-        if (int rc = apply_prepare_launch(t, d_keys, nn, st)) return rc;
+        if (++t->epoch >= kHotMark) t->epoch = 1;
+        group_kernel<kGroupApply><<<grid_for(nn, 256, 1u << 22), 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
     }
     {
         const int R = t->apply_rounds > 0 ? t->apply_rounds : 2;
         const unsigned gs = grid_for(n, 16u * (R >= 2 ? 2u : 1u), 1u << 16);
-#define SINGLE(K, D4, RR) apply_single_kernel<K, D4, RR><<<gs, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, \
-                                                                            d_keys, (const float4*)d_grads, nn, t->g, t->bs, a, nullptr, d_gidx)
-#define SINGLE_D(K) do { if (t->dim4 == 16) { if (R >= 2) SINGLE(K, 16, 2); else SINGLE(K, 16, 1); } \
-                         else if (t->dim4 == 32) { if (R >= 2) SINGLE(K, 32, 2); else SINGLE(K, 32, 1); } \
-                         else { if (R >= 2) SINGLE(K, 0, 2); else SINGLE(K, 0, 1); } } while (0)
-        if (a.kind == MEE_OPT_ADAGRAD) SINGLE_D(MEE_OPT_ADAGRAD); else SINGLE_D(MEE_OPT_ADAM);
-#undef SINGLE_D
-#undef SINGLE
+#define MAIN(K, D4, RR, LOC) apply_main_kernel<K, D4, RR, LOC><<<gs, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, \
+                                                                                  d_keys, d_slots, (const float4*)d_grads, nn, t->g, t->bs, t->op, a, d_gidx, t->capacity, t->epoch)
+#define MAIN_R(K, D4) do { if (d_slots) { if (R >= 2) MAIN(K, D4, 2, true); else MAIN(K, D4, 1, true); } \
+                           else { if (R >= 2) MAIN(K, D4, 2, false); else MAIN(K, D4, 1, false); } } while (0)
+#define MAIN_D(K) do { if (t->dim4 == 16) MAIN_R(K, 16); else if (t->dim4 == 32) MAIN_R(K, 32); else MAIN_R(K, 0); } while (0)
+        if (a.kind == MEE_OPT_ADAGRAD) MAIN_D(MEE_OPT_ADAGRAD); else MAIN_D(MEE_OPT_ADAM);
+#undef MAIN_D
+#undef MAIN_R
+#undef MAIN
     }
-    // the work list (chunk leaders) and the big-group list have device-side lengths: fixed grids that loop
-    apply_chunk_kernel<false><<<grid_for(n, 16, 2048), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
-                                                            d_keys, (const float4*)d_grads, t->g, t->bs, t->op, a, nullptr, d_gidx);
-    apply_big_kernel<false><<<grid_for(n / kChunk + 1, 1, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,
-                                                                       t->dim4, t->g, t->bs, t->op, a);
+    // hot keys only (device-side lengths: fixed small grids that loop; all three leave at once on a batch without hot keys)
+    apply_file_kernel<<<grid_for(nn, 256, 256), 256, 0, st>>>(nn, t->g, t->bs, t->op, t->epoch);
+    apply_bigchunk_kernel<<<grid_for(n / kChunk + 1, 16, 512), 256, 0, st>>>(t->dim4, (const float4*)d_grads, t->g, t->bs, t->op, d_gidx, a.grad_rows);
+    apply_big_kernel<false><<<grid_for(n / kChunk + 1, 1, 256), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,
+                                                                      t->dim4, t->g, t->bs, t->op, a);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
@@ -1837,7 +2057,9 @@ int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* strea
     if (n > t->max_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_apply_prepare: n=%zu exceeds config.max_batch=%llu", n, (unsigned long long)t->max_batch);
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
-    if (int rc = apply_prepare_launch(t, d_keys, (uint32_t)n, as_stream(stream))) return rc;
+    if (++t->epoch >= kHotMark) t->epoch = 1;
+    group_kernel<kGroupApply><<<grid_for(n, 256, 1u << 22), 256, 0, as_stream(stream)>>>(d_keys, (uint32_t)n, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
+    MEE_HIP(hipGetLastError());
     t->prepared_n = n; t->prepared_keys = d_keys;
     return MEE_OK;
 }
@@ -1870,6 +2092,20 @@ int mee_apply_adam(mee_table* t, const int64_t* d_keys, const float* d_grads, si
                    float eps, uint64_t step, void* stream) {
     if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adam: step must be >= 1");
     return apply_common(t, d_keys, d_grads, n, adam_args(lr, beta1, beta2, eps, step), stream, "mee_apply_adam");
+}
+// the same with the slots the forward lookup of this step located (mee_find_located): the main pass skips its probe
+int mee_apply_adagrad_located(mee_table* t, const int64_t* d_keys, const int64_t* d_slots, const float* d_grads, size_t n, float lr, float eps,
+                              void* stream) {
+    if (n && !d_slots) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adagrad_located: null slots");
+    OptArgs a{};
+    a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps;
+    return apply_common(t, d_keys, d_grads, n, a, stream, "mee_apply_adagrad_located", nullptr, d_slots);
+}
+int mee_apply_adam_located(mee_table* t, const int64_t* d_keys, const int64_t* d_slots, const float* d_grads, size_t n, float lr, float beta1,
+                           float beta2, float eps, uint64_t step, void* stream) {
+    if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adam_located: step must be >= 1");
+    if (n && !d_slots) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adam_located: null slots");
+    return apply_common(t, d_keys, d_grads, n, adam_args(lr, beta1, beta2, eps, step), stream, "mee_apply_adam_located", nullptr, d_slots);
 }
 // the grad of position i is row d_grad_index[i] of d_grads (pooled lookups: the bag's grad row serves every key of the bag)
 static int check_grad_rows(size_t n, const uint32_t* d_grad_index, size_t n_grad_rows, const char* name) {

@@ -324,10 +324,34 @@ class LookupTable:
             raise MeepoError(_lib.ERR_INVALID_ARG, f"grad_index must hold one entry per key on {self.device}")
         return grad_index.to(torch.int32).contiguous()   # read as uint32 by the kernels: indices are < 2^31
 
-    def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10,
-                      grad_index: torch.Tensor | None = None) -> None:
-        """grad_index (optional, one int per key): position i takes row grad_index[i] of grads (pooled lookups: the bag)."""
+    def _slots(self, slots: torch.Tensor, n: int) -> torch.Tensor:
+        if slots.dtype != torch.int64 or slots.device != self.device or slots.numel() != n:
+            raise MeepoError(_lib.ERR_INVALID_ARG, f"slots must be the int64 handles find_located returned for these keys, on {self.device}")
+        return slots.contiguous()
+
+    def find_located(self, keys: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None,
+                     slots: torch.Tensor | None = None):
+        """find() that also returns each key's slot handle (-1 = absent) for apply_*(…, slots=…) of the same training step."""
         k = self._keys(keys)
+        n = k.numel()
+        if out is None:
+            out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        if found is None:
+            found = torch.empty(n, dtype=torch.uint8, device=self.device)
+        if slots is None:
+            slots = torch.empty(n, dtype=torch.int64, device=self.device)
+        check(_lib.lib().mee_find_located(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), slots.data_ptr(), self._s()))
+        return out, found, slots
+
+    def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10,
+                      grad_index: torch.Tensor | None = None, slots: torch.Tensor | None = None) -> None:
+        """grad_index (optional, one int per key): position i takes row grad_index[i] of grads (pooled lookups: the bag).
+        slots (optional): the handles find_located returned for `keys` in this step's forward (skips the probe)."""
+        k = self._keys(keys)
+        if slots is not None:
+            g = self._rows(grads, k.numel())
+            check(_lib.lib().mee_apply_adagrad_located(self._h, k.data_ptr(), self._slots(slots, k.numel()).data_ptr(), g.data_ptr(), k.numel(), lr, eps, self._s()))
+            return
         if grad_index is not None:
             gi = self._grad_index(grad_index, k.numel())
             g = grads.contiguous().view(-1, self.dim)
@@ -337,8 +361,13 @@ class LookupTable:
         check(_lib.lib().mee_apply_adagrad(self._h, k.data_ptr(), g.data_ptr(), k.numel(), lr, eps, self._s()))
 
     def apply_adam(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999,
-                   eps: float = 1e-8, step: int = 1, grad_index: torch.Tensor | None = None) -> None:
+                   eps: float = 1e-8, step: int = 1, grad_index: torch.Tensor | None = None, slots: torch.Tensor | None = None) -> None:
         k = self._keys(keys)
+        if slots is not None:
+            g = self._rows(grads, k.numel())
+            check(_lib.lib().mee_apply_adam_located(self._h, k.data_ptr(), self._slots(slots, k.numel()).data_ptr(), g.data_ptr(), k.numel(), lr, beta1,
+                                                    beta2, eps, step, self._s()))
+            return
         if grad_index is not None:
             gi = self._grad_index(grad_index, k.numel())
             g = grads.contiguous().view(-1, self.dim)

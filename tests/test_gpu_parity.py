@@ -274,6 +274,57 @@ def test_optimizer_full_batch_of_medium_groups(dev, opt):
     assert bool(found.all()) and np.array_equal(got.cpu().numpy(), rows)
 
 
+@pytest.mark.parametrize("opt,dim", [("adagrad", 64), ("adam", 128), ("adagrad", 24)])
+def test_located_apply_equals_plain_apply(dev, opt, dim):
+    """find_located + apply_*(slots=…) — the forward's slot handles instead of a probe — must give the table the plain apply
+    gives (and the oracle's), with duplicates, absent keys (handle -1), reserved keys and both settings of the side-stream knob."""
+    n_keys, batch = 30000, 20000
+    keys = synth.keys_np(83, 0, n_keys); rows = synth.rows_np(keys, dim, 2)
+    kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
+    mk = lambda: LookupTable(65536, dim, device=dev, optimizer=kind, max_batch=n_keys, initial_accumulator=0.1)
+    ta, tb = mk(), mk()
+    o = oracle.OracleTable(65536, dim, optimizer=okind, initial_accumulator=0.1)
+    for t in (ta, tb):
+        t.insert(T(keys, dev), T(rows, dev))
+    o.insert(keys, rows)
+    rng = np.random.default_rng(3)
+    for s in range(4):
+        idx = np.minimum(rng.zipf(1.4, size=batch) - 1, n_keys - 1) if s % 2 else rng.integers(0, n_keys, batch)
+        bk = keys[idx]
+        bk[rng.integers(0, batch, 40)] = synth.keys_np(91, s * 40, 40)      # absent keys
+        bk[rng.integers(0, batch, 3)] = oracle.EMPTY_KEY                     # padding
+        g = (rng.standard_normal((batch, dim)) * 0.01).astype(np.float32)
+        tb.set_tuning("apply_overlap", s % 2)
+        out, found, slots = tb.find_located(T(bk, dev))
+        eo, ef = ta.find(T(bk, dev))
+        assert torch.equal(out, eo) and torch.equal(found, ef)
+        assert torch.equal(slots >= 0, found.bool())
+        if opt == "adagrad":
+            ta.apply_adagrad(T(bk, dev), T(g, dev), lr=0.01); tb.apply_adagrad(T(bk, dev), T(g, dev), lr=0.01, slots=slots)
+            o.apply_adagrad(bk, g, 0.01, 1e-10)
+        else:
+            ta.apply_adam(T(bk, dev), T(g, dev), lr=0.001, step=s + 1); tb.apply_adam(T(bk, dev), T(g, dev), lr=0.001, step=s + 1, slots=slots)
+            o.apply_adam(bk, g, 0.001, 0.9, 0.999, 1e-8, s + 1)
+    ea, eb = ta.export(with_state=True), tb.export(with_state=True)
+    oe = o.export(with_state=True)
+    ia, ib, io = torch.argsort(ea[0]), torch.argsort(eb[0]), np.argsort(oe[0])
+    assert torch.equal(ea[0][ia], eb[0][ib]) and np.array_equal(ea[0][ia].cpu().numpy(), oe[0][io])
+    for xa, xb, xo in zip(ea[1:], eb[1:], oe[1:]):
+        if xo is not None:
+            torch.testing.assert_close(xa[ia], xb[ib], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(xb[ib].cpu().numpy(), xo[io], rtol=RTOL, atol=ATOL)
+    # out-of-range / negative handles are ignored, never dereferenced
+    bad = torch.full((8,), 1 << 60, dtype=torch.int64, device=dev); bad[::2] = -1
+    kk = T(synth.keys_np(95, 0, 8), dev)   # absent keys, so that nothing should change
+    if opt == "adagrad":
+        tb.apply_adagrad(kk, torch.ones(8, dim, device=dev), lr=0.1, slots=bad)
+    else:
+        tb.apply_adam(kk, torch.ones(8, dim, device=dev), lr=0.1, step=9, slots=bad)
+    e2 = tb.export(with_state=True)
+    i2 = torch.argsort(e2[0])
+    assert torch.equal(e2[1][i2], eb[1][ib]) and tb.status() == 0
+
+
 def test_optimizer_unique_keys_bit_exact(dev):
     """No duplicates -> no reduction-order freedom: the HIP update must equal the oracle bit for bit."""
     dim, n = 64, 10000
