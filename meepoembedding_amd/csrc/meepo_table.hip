@@ -1932,7 +1932,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
         group_kernel<kGroupApply><<<grid_for(nn, 256, 1u << 22), 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
     }
     {
-        const int R = t->apply_rounds > 0 ? t->apply_rounds : 2;
+        const int R = t->apply_rounds > 0 ? t->apply_rounds : 1;   // one position per tile: more waves per SIMD beat more loads per wave here
         const unsigned gs = grid_for(n, 16u * (R >= 2 ? 2u : 1u), 1u << 16);
 #define MAIN(K, D4, RR, LOC) apply_main_kernel<K, D4, RR, LOC><<<gs, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, \
                                                                                   d_keys, d_slots, (const float4*)d_grads, nn, t->g, t->bs, t->op, a, d_gidx, t->capacity, t->epoch)
@@ -1944,7 +1944,11 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
 #undef MAIN_R
 #undef MAIN
     }
-    // hot keys only (device-side lengths: fixed small grids that loop; all three leave at once on a batch without hot keys)
+    // hot keys only (device-side lengths: fixed small grids that loop; all three leave at once on a batch without hot keys).
+    // Tried and dropped: the three as ONE launch with grid barriers between the steps (3.5 us less without hot keys, 33 us more on a
+    // Zipf(1.05) batch); the main pass requesting grad rows / bucket lines before a position's count is known (no faster: the pass is
+    // bound by bytes, the extra registers cost occupancy); the grouping folded into the forward find (its claim atomics do not overlap
+    // with the row traffic: same total).
     apply_file_kernel<<<grid_for(nn, 256, 256), 256, 0, st>>>(nn, t->g, t->bs, t->op, t->epoch);
     apply_bigchunk_kernel<<<grid_for(n / kChunk + 1, 16, 512), 256, 0, st>>>(t->dim4, (const float4*)d_grads, t->g, t->bs, t->op, d_gidx, a.grad_rows);
     apply_big_kernel<false><<<grid_for(n / kChunk + 1, 1, 256), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,

@@ -294,16 +294,16 @@ def test_located_apply_equals_plain_apply(dev, opt, dim):
         bk[rng.integers(0, batch, 40)] = synth.keys_np(91, s * 40, 40)      # absent keys
         bk[rng.integers(0, batch, 3)] = oracle.EMPTY_KEY                     # padding
         g = (rng.standard_normal((batch, dim)) * 0.01).astype(np.float32)
-        tb.set_tuning("apply_overlap", s % 2)
-        out, found, slots = tb.find_located(T(bk, dev))
+        bkt = T(bk, dev)
+        out, found, slots = tb.find_located(bkt)
         eo, ef = ta.find(T(bk, dev))
         assert torch.equal(out, eo) and torch.equal(found, ef)
         assert torch.equal(slots >= 0, found.bool())
         if opt == "adagrad":
-            ta.apply_adagrad(T(bk, dev), T(g, dev), lr=0.01); tb.apply_adagrad(T(bk, dev), T(g, dev), lr=0.01, slots=slots)
+            ta.apply_adagrad(T(bk, dev), T(g, dev), lr=0.01); tb.apply_adagrad(bkt, T(g, dev), lr=0.01, slots=slots)
             o.apply_adagrad(bk, g, 0.01, 1e-10)
         else:
-            ta.apply_adam(T(bk, dev), T(g, dev), lr=0.001, step=s + 1); tb.apply_adam(T(bk, dev), T(g, dev), lr=0.001, step=s + 1, slots=slots)
+            ta.apply_adam(T(bk, dev), T(g, dev), lr=0.001, step=s + 1); tb.apply_adam(bkt, T(g, dev), lr=0.001, step=s + 1, slots=slots)
             o.apply_adam(bk, g, 0.001, 0.9, 0.999, 1e-8, s + 1)
     ea, eb = ta.export(with_state=True), tb.export(with_state=True)
     oe = o.export(with_state=True)
