@@ -137,6 +137,30 @@ def stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, uniform
                       "algorithmic_GBps": batch * bpl / med / 1e3, "frac_of_hbm_roofline": batch * bpl / med / 1e3 / HBM_PEAK_GBS,
                       "read_only_GBps": batch * (16 + 4 * dim) / med / 1e3,
                       "mean_probe_length_buckets": table.probe_length(bs[0])}
+    # the same uniform stream with the caller's cache-policy hint for a stream without reuse (mee_set_tuning "find_nt" = 7: streaming row and
+    # bucket loads; the default keeps them cached because skewed streams re-read their hot rows)
+    table.set_tuning("find_nt", 7)
+    med, mn = kernel_window(table, uniform_batches, out, found, dev)
+    table.set_tuning("find_nt", -1)
+    rows["uniform_with_streaming_load_hint"] = {"us_per_launch_median": med, "us_per_launch_min": mn, "lookups_per_s": batch / med * 1e6,
+                                                "algorithmic_GBps": batch * bpl / med / 1e3, "frac_of_hbm_roofline": batch * bpl / med / 1e3 / HBM_PEAK_GBS}
+    # launch-size sweep on the uniform stream: time = floor + slope * lookups (least squares) separates the per-launch latency floor
+    # from the streaming rate the layout reaches
+    allk = torch.cat(uniform_batches[:16])
+    sizes = [1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21]
+    obig = torch.empty((sizes[-1], dim), dtype=torch.float32, device=dev)
+    fbig = torch.empty(sizes[-1], dtype=torch.uint8, device=dev)
+    pts = []
+    for sz in sizes:
+        bs_ = [allk[o:o + sz] for o in range(0, allk.numel() - sz + 1, sz)][:8]
+        m_, _ = kernel_window(table, bs_, obig[:sz], fbig[:sz], dev, launches=max(25, min(200, (200 << 18) // sz)), regions=3, warm=5)
+        pts.append((sz, m_))
+    xs, ys = np.array([p[0] for p in pts], dtype=np.float64), np.array([p[1] for p in pts])
+    slope, floor = np.polyfit(xs, ys, 1)
+    rows["launch_size_sweep"] = {"lookups_per_launch": [p[0] for p in pts], "us_per_launch": [p[1] for p in pts],
+                                 "fit_floor_us": float(floor), "fit_us_per_262144_lookups": float(slope * 262144),
+                                 "asymptotic_frac_of_hbm_roofline": float(bpl / slope / 1e3 / HBM_PEAK_GBS)}
+    del obig, fbig, allk
     return rows
 
 
@@ -196,10 +220,11 @@ def train_step_extra(find_table, synth, n_keys, dim, dev, chunk, batches, out, f
     t = LookupTable(find_table.capacity, dim, device=dev, max_batch=max(chunk, 2 * batch), optimizer=OPT_ADAGRAD)
     populate(t, synth, n_keys, dim, dev, chunk)
     grads = [torch.randn(batch, dim, device=dev) * 0.01 for _ in range(4)]
+    slots = torch.empty(batch, dtype=torch.int64, device=dev)
 
     def step(i):
-        t.find(batches[i % len(batches)], out=out, found=found)
-        t.apply_adagrad(batches[i % len(batches)], grads[i % 4], lr=0.01, eps=1e-10)
+        t.find_located(batches[i % len(batches)], out=out, found=found, slots=slots)
+        t.apply_adagrad(batches[i % len(batches)], grads[i % 4], lr=0.01, eps=1e-10, slots=slots)
 
     for i in range(10):
         step(i)
@@ -212,7 +237,7 @@ def train_step_extra(find_table, synth, n_keys, dim, dev, chunk, batches, out, f
     uniq = sum(int(torch.unique(b).numel()) for b in batches[:4]) / 4
     step_bytes = (bpl + 8 + 4 * dim) * batch + (8 + 16 * dim) * uniq
     t.close()
-    return {"workload": f"configs[2]: find + sparse-Adagrad apply, {batch}-key uniform batches, {n_keys // 1_000_000}M keys, dim {dim}",
+    return {"workload": f"configs[2]: find_located + sparse-Adagrad apply on the located slots, {batch}-key uniform batches, {n_keys // 1_000_000}M keys, dim {dim}",
             "train_step_keys_per_s": batch / dt, "us_per_step": dt * 1e6, "steps": steps,
             "algorithmic_bytes_per_key": step_bytes / batch, "frac_of_hbm_roofline": step_bytes / dt / 1e9 / HBM_PEAK_GBS}
 
@@ -448,10 +473,12 @@ def main():
     elif train:
         grads = [torch.randn(batch, dim, device=dev) * 0.01 for _ in range(4)]   # N(0, 1e-2), SURVEY §8d config 3
 
-        def step(i):
-            r_ = table.find(batches[i % n_batches], out=out, found=found)
-            table.apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10)
-            return r_
+        slots = torch.empty(batch, dtype=torch.int64, device=dev)
+
+        def step(i):   # forward gather, then the backward scatter-update on the slots the forward located (no second probe)
+            o_, f_, _ = table.find_located(batches[i % n_batches], out=out, found=found, slots=slots)
+            table.apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10, slots=slots)
+            return o_, f_
     else:
         def step(i):
             return table.find(batches[i % n_batches], out=out, found=found)
@@ -565,7 +592,7 @@ def main():
                        "key_distribution": args.dist, "table_gb": round(table.table_bytes / 1e9, 2), "launch": launch_mode,
                        "parallelism": (f"row-shard x{world}" + (f", {args.pipeline} steps in flight" if args.pipeline > 1 else "") + (", pre-exchange dedup" if args.dedup else "")) if sharded else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic if not whole else None, "kernel": "find_kernel" if not whole else "whole step (find + 5 apply kernels)",
+                         "traffic": traffic if not whole else None, "kernel": "find_kernel" if not whole else "whole step (find_kernel + the apply's group / main / three hot-key kernels)",
                          "traffic_source": ("profiles/find_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 per the gfx950 correction)"
                                             if traffic is not None and not whole else None),
                          "avg_launch_us": kern_s * 1e6, "min_launch_us": kern_min_s * 1e6,
@@ -577,16 +604,6 @@ def main():
         if not sharded and not train and not args.no_streams:
             try:
                 res["streams"] = stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, batches, (kern_s * 1e6, kern_min_s * 1e6))
-                # north_star's batch: 1M lookups per launch on the same table (4 consecutive 256K batches concatenated)
-                big = [torch.cat(batches[i:i + 4]) for i in range(0, 16, 4)] if batch * 4 <= table.max_batch * 4 else None
-                if big is not None:
-                    obig = torch.empty((big[0].numel(), dim), dtype=torch.float32, device=dev)
-                    fbig = torch.empty(big[0].numel(), dtype=torch.uint8, device=dev)
-                    m_, n_ = kernel_window(table, big, obig, fbig, dev, launches=100)
-                    nb_ = big[0].numel()
-                    res["streams"][f"uniform_{nb_}_per_launch"] = {"us_per_launch_median": m_, "us_per_launch_min": n_, "lookups_per_s": nb_ / m_ * 1e6,
-                                                                  "algorithmic_GBps": nb_ * bpl / m_ / 1e3, "frac_of_hbm_roofline": nb_ * bpl / m_ / 1e3 / HBM_PEAK_GBS}
-                    del obig, fbig, big
             except Exception as e:  # noqa: BLE001
                 res["streams"] = {"error": repr(e)}
         if not sharded and not args.no_cpu_baseline:

@@ -146,11 +146,14 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
         uint64_t b[R];
         int64_t kb[R];
         bool inb[R], act[R];
+        // ONE coalesced load brings the wave step's 4R keys (lane j reads keys[base + j]); the tiles take theirs by shuffle.  (A load per
+        // tile and round made the compiler wait for round r's key before it requested round r + 1's: a dependent memory round trip per round.)
+        const int64_t kmine = (lane < KPW && base + lane < n) ? keys[base + lane] : kEmpty;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint64_t i = base + r * 4 + tile;
             inb[r] = i < n;
-            key[r] = inb[r] ? keys[i] : kEmpty;
+            key[r] = __shfl(kmine, r * 4 + tile);
             act[r] = inb[r] && !reserved_key(key[r]);
             if constexpr ((NT & 8) != 0) {  // second-tier pass: only positions an earlier find left as missing
                 inb[r] = act[r] = act[r] && found[i] == 0;
