@@ -200,17 +200,37 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
         if constexpr (DIM4 != 0) {
             constexpr int C = DIM4 / 16;
             f32x4 row[R][C];
+            // Common case, decided per wave: every position of the wave step is inside the batch and was found.  Then the R row loads
+            // and the R stores are straight-line code and leave back to back; with a per-lane condition around each load the compiler
+            // waited for round r's row before it requested round r + 1's (seen in the ISA of the located variant: +8 us per 256K keys).
+            bool all_hit = true;
 #pragma unroll
-            for (int r = 0; r < R; ++r)
+            for (int r = 0; r < R; ++r) all_hit = all_hit && inb[r] && slot[r] >= 0;
+            if (__all(all_hit)) {
 #pragma unroll
-                for (int c = 0; c < C; ++c)
-                    row[r][c] = slot[r] >= 0 ? ((NT & 1) ? __builtin_nontemporal_load(&values[(uint64_t)slot[r] * DIM4 + c * 16 + tl]) : values[(uint64_t)slot[r] * DIM4 + c * 16 + tl]) : def4;
+                for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint64_t i = base + r * 4 + tile;
-                if (inb[r] && (!(NT & 8) || slot[r] >= 0)) {
+                    for (int c = 0; c < C; ++c)
+                        row[r][c] = (NT & 1) ? __builtin_nontemporal_load(&values[(uint64_t)slot[r] * DIM4 + c * 16 + tl]) : values[(uint64_t)slot[r] * DIM4 + c * 16 + tl];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint64_t i = base + r * 4 + tile;
 #pragma unroll
                     for (int c = 0; c < C; ++c) { if (NT & 4) out[i * DIM4 + c * 16 + tl] = row[r][c]; else __builtin_nontemporal_store(row[r][c], &out[i * DIM4 + c * 16 + tl]); }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        row[r][c] = slot[r] >= 0 ? ((NT & 1) ? __builtin_nontemporal_load(&values[(uint64_t)slot[r] * DIM4 + c * 16 + tl]) : values[(uint64_t)slot[r] * DIM4 + c * 16 + tl]) : def4;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint64_t i = base + r * 4 + tile;
+                    if (inb[r] && (!(NT & 8) || slot[r] >= 0)) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) { if (NT & 4) out[i * DIM4 + c * 16 + tl] = row[r][c]; else __builtin_nontemporal_store(row[r][c], &out[i * DIM4 + c * 16 + tl]); }
+                    }
                 }
             }
         } else {
@@ -483,11 +503,13 @@ constexpr int kLds = 512;       // block-local aggregation table (256 threads ->
 // LDS hash table keyed by the key itself; ONE lane per (block, key) then talks to the global group table.  A hot key
 // that is 8 % of the batch costs ~n/256 global accesses instead of 0.08 n serialised on one L2 line, and the block
 // whose CAS claimed the entry needs no counting atomic at all.
-// kGroupApply additionally chains the positions of every key: occurrences inside a block are linked through LDS (next pointer of
-// position i in bs.uniq_h[i], 0 ends a chain); the block that claimed the entry parks its chain's head in sgrp[h] (plain store),
-// every other block splices its chain onto a second list whose head lives in sres[h] (atomicExch; tagged with the batch `epoch`, so a
-// stale head of an earlier batch reads as empty).  The claimer's chain has `hi` entries and the spliced list `lo` (the two halves of the
-// count word), so neither needs a terminator.  A key that occurs once costs no atomic beyond its claim and no store beyond its count.
+// kGroupApply additionally chains the positions of every key, forward: inside a block every arrival is appended behind the previous
+// one through LDS (next pointer of position i in bs.uniq_h[i]), so a block's chain starts at its first arrival.  The chain of the
+// block that claimed the entry starts at the key's rank-0 occurrence — the group's leader, which therefore needs no head pointer;
+// every other block splices its chain in front of a second list whose head lives in sres[h] (atomicExch; tagged with the batch
+// `epoch`, so a stale head of an earlier batch reads as empty).  The claimer's chain has `hi` entries and the spliced list `lo` (the
+// two halves of the count word): neither needs a terminator.  A key that occurs once costs no atomic beyond its claim and no store
+// beyond its count.
 template <int MODE>
 __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ keys, uint32_t n, GroupTable g, BatchScratch bs,
                                                     Counters* ctr, const uint8_t* __restrict__ skip, OpCounters* op_to_zero = nullptr,
@@ -496,8 +518,8 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
     if (op_to_zero && blockIdx.x == 0 && threadIdx.x < sizeof(OpCounters) / 4) reinterpret_cast<uint32_t*>(op_to_zero)[threadIdx.x] = 0u;
     __shared__ unsigned long long lkey[kLds];
     __shared__ uint32_t lval[kLds], lh[kLds], lbase[kLds];
-    __shared__ uint32_t lhead[MODE == kGroupApply ? kLds : 1], ltail[MODE == kGroupApply ? kLds : 1];
-    for (int j = threadIdx.x; j < kLds; j += 256) { lkey[j] = 0; lval[j] = 0; if (MODE == kGroupApply) lhead[j] = 0; }
+    __shared__ uint32_t lhead[MODE == kGroupApply ? kLds : 1], ltail[MODE == kGroupApply ? kLds : 1], lhr[MODE == kGroupApply ? kLds : 1];
+    for (int j = threadIdx.x; j < kLds; j += 256) { lkey[j] = 0; lval[j] = 0; if (MODE == kGroupApply) ltail[j] = 0; }
     __syncthreads();
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool inb = i < n;
@@ -518,9 +540,9 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
         if (MODE == kGroupCount || MODE == kGroupApply) r_local = atomicAdd(&lval[slot], 1u);
         else atomicMax(&lval[slot], i + 1);
         if constexpr (MODE == kGroupApply) {
-            const uint32_t lprev = atomicExch(&lhead[slot], i + 1);
-            if (lprev != 0) bs.uniq_h[i] = lprev;   // next pointer
-            else ltail[slot] = i;                   // the first local arrival ends the block's chain: its next pointer is the inserter's to write
+            const uint32_t lprev = atomicExch(&ltail[slot], i + 1);   // append behind the block's latest arrival
+            if (lprev != 0) bs.uniq_h[lprev - 1] = i + 1;             // its next pointer
+            else { lhead[slot] = i + 1; lhr[slot] = r_local; }        // the block's first arrival heads the chain (and will take local rank 0)
         }
     }
     __syncthreads();
@@ -533,10 +555,9 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
             if (claimed) { g.sv[2 * h + 1] = total; lbase[slot] = 0; }
             else lbase[slot] = atomicAdd(&g.sv[2 * h], total) | kRankRemote;
             if constexpr (MODE == kGroupApply) {
-                if (claimed) g.sgrp[h] = lhead[slot];   // no terminator: the walk is bounded by the two counts (hi here, lo on the spliced list)
-                else {
+                if (!claimed) {   // (the claimer's chain starts at the rank-0 occurrence: nothing to store)
                     const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long*>(&g.sres[h]), ((unsigned long long)epoch << 32) | lhead[slot]);
-                    bs.uniq_h[ltail[slot]] = (uint32_t)(old >> 32) == epoch ? (uint32_t)old : 0u;
+                    bs.uniq_h[ltail[slot] - 1] = (uint32_t)(old >> 32) == epoch ? (uint32_t)old : 0u;   // this block's last arrival -> the list so far
                 }
             }
         } else {
@@ -549,6 +570,10 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
     __syncthreads();
     if (inb) {
         bs.hidx[i] = valid ? lh[slot] : kNoGroup;
+        if constexpr (MODE == kGroupApply) {
+            // the chain's head takes local rank 0 (the two atomics above order the block's arrivals independently): swap with whoever drew it
+            if (valid) r_local = i + 1 == lhead[slot] ? 0u : (r_local == 0 ? lhr[slot] : r_local);
+        }
         if ((MODE == kGroupCount || MODE == kGroupApply) && valid) bs.rank[i] = lbase[slot] + r_local;
         if (!valid && !skipped && key == kReclaimed) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);  // EMPTY = padding, silent
     }
@@ -958,12 +983,12 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
             uint32_t lf = 0;
             if (tl == 0 && i < n) {
                 if (cnt[r] > 1) {
-                    const bool leader = g.sgrp[h[r]] == i + 1;   // head of the claiming block's chain: exactly one per group
+                    const uint32_t rk = bs.rank[i];
+                    const bool leader = rk == 0;   // first arrival in the claiming block (ranks of other blocks carry kRankRemote): one per group
                     if (cnt[r] <= kChunk) lf = leader;
                     else {
                         uint32_t lo, hi;
                         sv_load(g, h[r], lo, hi);
-                        const uint32_t rk = bs.rank[i];
                         bs.rank[i] = (rk & ~kRankRemote) + ((rk & kRankRemote) ? hi : 0);   // arrival order over the whole batch
                         bs.pcnt[i] = kHotMark | epoch;   // marks the position for apply_file_kernel (stale marks carry other epochs; counts
                                                          // other paths leave in pcnt never have the top bit: max_batch <= 2^30)
@@ -1005,7 +1030,7 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
                 uint32_t lo, hi, k = 0;
                 sv_load(g, h[r], lo, hi);
                 const unsigned long long others = (unsigned long long)g.sres[h[r]];
-                uint32_t p = g.sgrp[h[r]];
+                uint32_t p = base + r * 4 + tile + 1;   // this position heads the claiming block's chain
                 for (uint32_t e = 0; e < hi && p && k < kChunk; ++e) { if (tl == 0) lpos[bt][k] = p - 1; ++k; p = bs.uniq_h[p - 1]; }
                 p = (lo && (uint32_t)(others >> 32) == epoch) ? (uint32_t)others : 0u;
                 for (uint32_t e = 0; e < lo && p && k < kChunk; ++e) { if (tl == 0) lpos[bt][k] = p - 1; ++k; p = bs.uniq_h[p - 1]; }

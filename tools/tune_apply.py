@@ -55,16 +55,14 @@ def located_apply(i):
     if kind == OPT_ADAGRAD: t.apply_adagrad(batches[i % NB], grads[i % 4], lr=0.01, eps=1e-10, slots=slots)
     else: t.apply_adam(batches[i % NB], grads[i % 4], lr=0.001, step=i + 1, slots=slots)
 
-for ov in (0, 1, 0, 1):
-    t.set_tuning('apply_hot_fused', ov)
+for ov in (0, 1):
     ta = timeit(apply)
     t.find_located(batches[0], out=out, found=found, slots=slots)
     tl = timeit(lambda i: (t.apply_adagrad(batches[0], grads[i % 4], lr=0.01, eps=1e-10, slots=slots) if kind == OPT_ADAGRAD else
                            t.apply_adam(batches[0], grads[i % 4], lr=0.001, step=i + 1, slots=slots)))
     ts = timeit(located_step)
-    print(f"hot_fused={ov}: apply {ta:.1f} us ({ab / ta / 1e3 / 8000:.3f}), located apply (one batch) {tl:.1f} us, find_located + located apply step {ts:.1f} us "
+    print(f"round {ov}: apply {ta:.1f} us ({ab / ta / 1e3 / 8000:.3f}), located apply (one batch) {tl:.1f} us, find_located + located apply step {ts:.1f} us "
           f"({(528 * B + ab) / ts / 1e3 / 8000:.3f} of the step roofline)")
-t.set_tuning('apply_hot_fused', 0)
 t_apply = timeit(apply)
 t_find = timeit(lambda i: t.find(batches[i % NB], out=out, found=found))
 t_step = timeit(lambda i: (t.find(batches[i % NB], out=out, found=found), apply(i)))
