@@ -29,7 +29,8 @@ char* last_error_buf() {
 
 struct Counters {            // device-resident, persistent
     uint32_t status;         // sticky MEE_STATUS_* bits
-    uint32_t pad[3];
+    uint32_t election;       // = the epoch of the latest insert whose batch had a position that found its key present (gates its election kernels)
+    uint32_t pad[2];
 };
 struct OpCounters {          // device-resident, zeroed at the start of each op that uses them
     uint32_t n_uniq;         // distinct keys appended to the unique list
@@ -497,6 +498,7 @@ constexpr int kGroupLast = 0;   // max(lo, hi) = 1 + highest batch position of t
 constexpr int kGroupCount = 1;  // lo + hi = occurrence count, rank[i] = arrival order (finalised by the plan pass)
 constexpr int kGroupApply = 2;  // kGroupCount + every key's occurrences chained into lists (the apply path; see group_kernel)
 constexpr uint32_t kRankRemote = 0x80000000u;  // rank was handed out by an atomic on lo: add hi to finalise
+constexpr uint32_t kHotMark = 0x80000000u;     // epoch tags: pcnt[i] = kHotMark | epoch marks position i as a hot key's occurrence of batch `epoch`
 constexpr int kLds = 512;       // block-local aggregation table (256 threads -> at most 256 distinct keys)
 
 // One lane per batch position.  Occurrences of the same key inside a 256-thread block are first combined in an
@@ -513,7 +515,8 @@ constexpr int kLds = 512;       // block-local aggregation table (256 threads ->
 template <int MODE>
 __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ keys, uint32_t n, GroupTable g, BatchScratch bs,
                                                     Counters* ctr, const uint8_t* __restrict__ skip, OpCounters* op_to_zero = nullptr,
-                                                    uint32_t epoch = 0) {
+                                                    uint32_t epoch = 0, const uint32_t* __restrict__ gate = nullptr) {
+    if (gate && *gate != epoch) return;   // insert: no position of this batch found its key present -> no election (grid-uniform)
     // the per-op counters are first touched by the kernel AFTER this one (plan pass): zeroing them here saves a launch
     if (op_to_zero && blockIdx.x == 0 && threadIdx.x < sizeof(OpCounters) / 4) reinterpret_cast<uint32_t*>(op_to_zero)[threadIdx.x] = 0u;
     __shared__ unsigned long long lkey[kLds];
@@ -556,8 +559,9 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
             else lbase[slot] = atomicAdd(&g.sv[2 * h], total) | kRankRemote;
             if constexpr (MODE == kGroupApply) {
                 if (!claimed) {   // (the claimer's chain starts at the rank-0 occurrence: nothing to store)
-                    const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long*>(&g.sres[h]), ((unsigned long long)epoch << 32) | lhead[slot]);
-                    bs.uniq_h[ltail[slot] - 1] = (uint32_t)(old >> 32) == epoch ? (uint32_t)old : 0u;   // this block's last arrival -> the list so far
+                    // the tag is epoch | kHotMark: sres is also lent out as a per-position slot list (insert, remove), whose values never carry it
+                    const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long*>(&g.sres[h]), ((unsigned long long)(epoch | kHotMark) << 32) | lhead[slot]);
+                    bs.uniq_h[ltail[slot] - 1] = (uint32_t)(old >> 32) == (epoch | kHotMark) ? (uint32_t)old : 0u;   // this block's last arrival -> the list so far
                 }
             }
         } else {
@@ -599,7 +603,6 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum /
 }
 
 constexpr uint32_t kChunk = 32;  // occurrences summed by one tile
-constexpr uint32_t kHotMark = 0x80000000u;  // pcnt[i] = kHotMark | epoch: position i belongs to a hot key of batch `epoch`
 
 // Plan pass, one lane per batch position: finalise rank and count, then (leaders only) reserve the group's slice of
 // the occurrence list, list the chunk leaders as work items, give big groups a block of fp64 partial-sum rows, and — for the
@@ -702,6 +705,135 @@ __global__ __launch_bounds__(256) void upsert_kernel(int64_t* tkeys, float4* val
         // the winner is the last reader that needs the entry's value: an occurrence that looks later reads 0 != i + 1 (one
         // 8-byte load: never a mixture) and is, correctly, not the winner.  The group table is clean when the kernel ends.
         if (winner && tl == 0) group_release_entry(g, h);
+    }
+}
+
+// ---- insert without an election pass for batches that need none (SPEC.md §3 insert; last occurrence of a key wins) -----------------
+// insert_direct_kernel, every position: probe with claim.  A position whose CAS CREATES its key is alone with it so far and writes its
+// row (+ initial optimizer state) at once: a batch of distinct new keys — populating a table, a growing vocabulary — is finished after
+// this one kernel with ONE atomic per key.  A position that finds its key present (stored before the batch, or created by another
+// occurrence in it) writes nothing, keeps its slot and raises the batch's election flag (ctr->election = epoch, a plain store).
+// Only then do the three gated kernels do anything: group_kernel<kGroupLast> over the "present" positions, insert_join_kernel (every
+// creator looks its key up in the group table — read-only — and joins the election if other occurrences registered there), and
+// insert_settle_kernel (the highest position of each registered key rewrites the row at the slot it kept; rows are plain overwrites
+// and the kernel boundary orders them behind the creators' optimistic writes).  `made[i]` = 1 for creators (the group pass skips them).
+template <int DIM4>
+__global__ __launch_bounds__(256) void insert_direct_kernel(int64_t* tkeys, float4* values, float4* s1, float4* s2, uint64_t nb, uint32_t dim4_rt,
+                                                            const int64_t* __restrict__ keys, const float4* __restrict__ vals, uint32_t n,
+                                                            const uint8_t* __restrict__ skip, uint8_t* __restrict__ made, long long* __restrict__ slotof,
+                                                            uint32_t* __restrict__ hidx, uint32_t optimizer, float init_acc, Counters* ctr,
+                                                            uint32_t* hits, uint32_t epoch) {
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
+    constexpr int C = DIM4 ? DIM4 / 16 : 1;
+    constexpr int R = 2;   // positions in flight per tile: keys, rows and first bucket lines of both are requested up front
+    for (uint32_t base = wave * 4 * R; base < n; base += n_waves * 4 * R) {
+        int64_t key[R], slot[R];
+        bool act[R], is_new[R];
+        float4 row[R][C];
+        const int64_t kmine = (lane < 4 * R && base + lane < n) ? keys[base + lane] : kEmpty;   // one coalesced load for the wave step
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + r * 4 + tile;
+            key[r] = __shfl(kmine, r * 4 + tile);
+            act[r] = i < n && !reserved_key(key[r]) && !(skip && skip[i]);
+            if (i < n && tl == 0 && key[r] == kReclaimed && !(skip && skip[i])) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);
+            if constexpr (DIM4 != 0) {
+                if (act[r]) {   // the row is read exactly once: stream it, and request it before the probe
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vals) + (uint64_t)i * DIM4 + c * 16 + tl);
+                        row[r][c] = make_float4(v.x, v.y, v.z, v.w);
+                    }
+                }
+            }
+        }
+        bool any_full = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            bool full;
+            slot[r] = tile_locate<true, true>(tkeys, nb, key[r], act[r], tile, tl, is_new[r], full);
+            any_full = any_full || full;
+        }
+        bool present = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + r * 4 + tile;
+            if (i >= n) continue;
+            const bool created = act[r] && slot[r] >= 0 && is_new[r];
+            if (created) {
+                const float4 ia = make_float4(init_acc, init_acc, init_acc, init_acc), z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (DIM4 != 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const uint64_t o = (uint64_t)slot[r] * DIM4 + c * 16 + tl;
+                        values[o] = row[r][c];
+                        if (optimizer == MEE_OPT_ADAGRAD) s1[o] = ia;
+                        if (optimizer == MEE_OPT_ADAM) { s1[o] = z4; s2[o] = z4; }
+                    }
+                } else {
+                    for (uint32_t c = tl; c < dim4; c += 16) {
+                        const uint64_t o = (uint64_t)slot[r] * dim4 + c;
+                        values[o] = vals[(uint64_t)i * dim4 + c];
+                        if (optimizer == MEE_OPT_ADAGRAD) s1[o] = ia;
+                        if (optimizer == MEE_OPT_ADAM) { s1[o] = z4; s2[o] = z4; }
+                    }
+                }
+            }
+            if (tl == 0) {
+                if (created && hits) hits[slot[r]] = 0;
+                made[i] = created || !act[r] || slot[r] < 0;   // 1 = takes no part in the group pass (creator, skipped, reserved key, table full)
+                slotof[i] = slot[r];
+                hidx[i] = kNoGroup;                              // the group pass fills this in for the positions it takes
+            }
+            present = present || (act[r] && slot[r] >= 0 && !is_new[r]);
+        }
+        if (__any(present) && lane == 0) ctr->election = epoch;            // plain store: every writer stores the same value
+        if (__any(any_full) && lane == 0) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_TABLE_FULL);
+    }
+}
+
+// creators join the election of their key if other occurrences registered it (read-only lookup of the group table built by the gated
+// group pass: a creator whose key nobody else holds finds an empty entry at once)
+__global__ __launch_bounds__(256) void insert_join_kernel(const int64_t* __restrict__ keys, uint32_t n, const uint8_t* __restrict__ made,
+                                                          const long long* __restrict__ slotof, GroupTable g, uint32_t* __restrict__ hidx,
+                                                          const Counters* ctr, uint32_t epoch) {
+    if (ctr->election != epoch) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !made[i] || slotof[i] < 0) return;
+    const int64_t key = keys[i];
+    if (reserved_key(key)) return;
+    const unsigned long long bk = (unsigned long long)key ^ kBias;
+    uint32_t h = (uint32_t)(mix64b((uint64_t)key) & g.smask);
+    for (uint64_t step = 0; step <= g.smask; ++step) {
+        const unsigned long long cur = g.skeys[h];
+        if (cur == 0) return;        // nobody else holds this key
+        if (cur == bk) { atomicMax(&g.sv[2 * h], i + 1); hidx[i] = h; return; }
+        h = (h + 1) & (uint32_t)g.smask;
+    }
+}
+
+// the highest registered position of each key rewrites the row at the slot it kept from insert_direct_kernel, then releases the entry
+__global__ __launch_bounds__(256) void insert_settle_kernel(float4* values, uint32_t dim4, const float4* __restrict__ vals, uint32_t n,
+                                                            const long long* __restrict__ slotof, const uint32_t* __restrict__ hidx, GroupTable g,
+                                                            const Counters* ctr, uint32_t epoch) {
+    if (ctr->election != epoch) return;
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t base = wave * 4; base < n; base += n_waves * 4) {
+        const uint32_t i = base + tile;
+        const uint32_t h = i < n ? hidx[i] : kNoGroup;
+        if (h == kNoGroup) continue;
+        uint32_t lo, hi;
+        sv_load(g, h, lo, hi);   // one 8-byte load: the complete pair, or zeros once the winner released it
+        if (max(lo, hi) != i + 1) continue;
+        const long long slot = slotof[i];
+        if (slot >= 0)
+            for (uint32_t c = tl; c < dim4; c += 16) values[(uint64_t)slot * dim4 + c] = vals[(uint64_t)i * dim4 + c];
+        if (tl == 0) group_release_entry(g, h);
     }
 }
 
@@ -1032,7 +1164,7 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
                 const unsigned long long others = (unsigned long long)g.sres[h[r]];
                 uint32_t p = base + r * 4 + tile + 1;   // this position heads the claiming block's chain
                 for (uint32_t e = 0; e < hi && p && k < kChunk; ++e) { if (tl == 0) lpos[bt][k] = p - 1; ++k; p = bs.uniq_h[p - 1]; }
-                p = (lo && (uint32_t)(others >> 32) == epoch) ? (uint32_t)others : 0u;
+                p = (lo && (uint32_t)(others >> 32) == (epoch | kHotMark)) ? (uint32_t)others : 0u;
                 for (uint32_t e = 0; e < lo && p && k < kChunk; ++e) { if (tl == 0) lpos[bt][k] = p - 1; ++k; p = bs.uniq_h[p - 1]; }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // lane 0's LDS writes before the tile's reads (same wave: in order)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1788,6 +1920,20 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
+    if (claim) {   // insert: creators write at once, an election only among positions that found their key present (see insert_direct_kernel)
+        if (++t->epoch >= kHotMark - 16) t->epoch = 1;
+        long long* slotof = t->g.sres;   // S >= 2 * max_batch entries: lent as the per-position slot list (as mee_remove does)
+        const unsigned gd = grid_for(n, 32, 1u << 16);
+#define DIRECT(D4) insert_direct_kernel<D4><<<gd, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys, (const float4*)d_values, \
+                                                               nn, skip, t->bs.fmask, slotof, t->bs.hidx, t->optimizer, t->init_acc, t->ctr, t->hits, t->epoch)
+        if (t->dim4 == 16) DIRECT(16); else if (t->dim4 == 32) DIRECT(32); else DIRECT(0);
+#undef DIRECT
+        group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, t->bs.fmask, nullptr, t->epoch, &t->ctr->election);
+        insert_join_kernel<<<gl, 256, 0, st>>>(d_keys, nn, t->bs.fmask, slotof, t->g, t->bs.hidx, t->ctr, t->epoch);
+        insert_settle_kernel<<<gt, 256, 0, st>>>((float4*)plane, t->dim4, (const float4*)d_values, nn, slotof, t->bs.hidx, t->g, t->ctr, t->epoch);
+        MEE_HIP(hipGetLastError());
+        return MEE_OK;
+    }
     group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, skip);
     if (claim)
         upsert_kernel<true><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
@@ -1956,7 +2102,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
             return fail(MEE_ERR_INVALID_ARG, "%s: keys/n differ from the pending mee_apply_prepare", name);
         t->prepared_n = 0; t->prepared_keys = nullptr;
     } else {
-        if (++t->epoch >= kHotMark) t->epoch = 1;
+        if (++t->epoch >= kHotMark - 16) t->epoch = 1;
         group_kernel<kGroupApply><<<grid_for(nn, 256, 1u << 22), 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
     }
     {
@@ -2089,7 +2235,7 @@ int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* strea
     if (n > t->max_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_apply_prepare: n=%zu exceeds config.max_batch=%llu", n, (unsigned long long)t->max_batch);
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
-    if (++t->epoch >= kHotMark) t->epoch = 1;
+    if (++t->epoch >= kHotMark - 16) t->epoch = 1;
     group_kernel<kGroupApply><<<grid_for(n, 256, 1u << 22), 256, 0, as_stream(stream)>>>(d_keys, (uint32_t)n, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
     MEE_HIP(hipGetLastError());
     t->prepared_n = n; t->prepared_keys = d_keys;
