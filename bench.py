@@ -164,6 +164,50 @@ def stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, uniform
     return rows
 
 
+def tier_1b_point(synth, dim, dev, batch, log, hot_keys=800_000_000, cold_keys=200_000_000, load=0.85):
+    """The literal 1B-key dim-64 table on ONE GPU (BASELINE metric; it does not fit 288 GB of HBM at any load factor): 800M keys in an HBM
+    table backed by 200M keys whose rows live in pinned host DRAM (the hot/cold tier of configs[4]); uniform lookups over all 1B keys
+    (20 % of them cold: PCIe-bound) and over the hot keys only."""
+    from meepoembedding_amd import LookupTable, _lib
+    from meepoembedding_amd.tiered import TieredLookupTable
+    chunk = 1 << 20
+    t0 = time.time()
+    hot = LookupTable(int(hot_keys / load), dim, device=dev, max_batch=chunk)
+    cold = LookupTable(int(cold_keys / load), dim, device=dev, max_batch=chunk, value_memory=_lib.MEM_HOST_PINNED)
+    for s_ in range(0, hot_keys, chunk):
+        k = synth.keys_t(1, s_, min(chunk, hot_keys - s_), dev)
+        hot.insert(k, synth.rows_t(k, dim, 2))
+    for s_ in range(0, cold_keys, chunk):
+        k = synth.keys_t(1, hot_keys + s_, min(chunk, cold_keys - s_), dev)
+        cold.insert(k, synth.rows_t(k, dim, 2))
+    torch.cuda.synchronize(dev)
+    log(f"tier point: {hot_keys + cold_keys} keys placed in {time.time() - t0:.1f}s (hot {hot.table_bytes / 1e9:.0f} GB HBM, cold rows {cold_keys * dim * 4 / 1e9:.0f} GB pinned host)")
+    tiered = TieredLookupTable(hot, cold, hot_key_limit=hot_keys)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    res = {"keys": hot_keys + cold_keys, "hot_keys_in_hbm": hot_keys, "cold_keys_in_pinned_host": cold_keys, "load_factor": load,
+           "hbm_gb": round((hot.table_bytes + cold_keys / load * 8) / 1e9, 1)}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for name, span in (("uniform_over_all_keys", hot_keys + cold_keys), ("uniform_over_hot_keys", hot_keys)):
+        bs = [synth.mix64_t((torch.randint(0, span, (batch,), device=dev, generator=g) + 1) * synth._s64(synth._GOLDEN) + synth._s64(1)) for _ in range(8)]
+        o_, f_ = tiered.find(bs[0])
+        assert bool(f_.all()) and torch.equal(o_[:2048], synth.rows_t(bs[0][:2048], dim, 2)), "tier lookup returned wrong rows"
+        per = []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for i in range(20):
+                tiered.find(bs[i % 8])
+            e1.record()
+            torch.cuda.synchronize(dev)
+            per.append(e0.elapsed_time(e1) * 1e3 / 20)
+        us = sorted(per)[1]
+        res[name] = {"us_per_find": us, "lookups_per_s": batch / us * 1e6, "cold_fraction": max(0.0, 1.0 - hot_keys / span),
+                     "cold_rows_over_pcie_GBps": batch * max(0.0, 1.0 - hot_keys / span) * dim * 4 / us / 1e3}
+    hot.close(); cold.close()
+    return res
+
+
 def two_stream_extra(table, batches, dim, dev, bpl, launches=400):
     """The same find launches issued round-robin on TWO caller streams (two independent request queues, own output
     buffers): consecutive launches may overlap each other's latency floor.  Informational — the headline keeps every
@@ -278,6 +322,9 @@ def main():
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph",
                     help="N=1 find mode: how the K timed steps are issued — one hipGraph replay of K chained kernel nodes (default) or K host launch calls")
     ap.add_argument("--no-streams", action="store_true", help="skip the SURVEY 8d key-stream table (uniform / Zipf / 90-10 hit-miss) in the JSON line")
+    ap.add_argument("--tier-1b", action="store_true",
+                    help="N=1 only: after the headline, also measure the LITERAL 1B-key dim-64 table on this one GPU through the hot/cold tier "
+                         "(800M keys in HBM + 200M keys with rows in pinned host DRAM; needs ~270 GB of HBM and ~55 GB of pinned host memory); result under `also`")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -614,6 +661,14 @@ def main():
                 res["also"]["configs2_train_step"] = train_step_extra(table, synth, n_keys, dim, dev, chunk, batches, out, found, bpl)
             except Exception as e:  # noqa: BLE001
                 res.setdefault("also", {})["error"] = repr(e)
+        if not sharded and args.tier_1b:
+            try:
+                table.close()
+                del out, found, batches
+                torch.cuda.empty_cache()
+                res.setdefault("also", {})["tier_1b_keys_one_gpu"] = tier_1b_point(synth, dim, dev, batch, log)
+            except Exception as e:  # noqa: BLE001
+                res.setdefault("also", {})["tier_1b_keys_one_gpu"] = {"error": repr(e)}
         os.write(result_fd, (json.dumps(res) + "\n").encode())
     if sharded:
         dist.barrier()

@@ -156,6 +156,13 @@ int mee_reserve(mee_table* t, uint64_t new_capacity, void* stream);
 int mee_size(const mee_table* t, size_t* n_out, void* stream);        /* [syncs] */
 int mee_status(const mee_table* t, uint32_t* bits_out, void* stream); /* [syncs] */
 int mee_clear_status(mee_table* t, void* stream);
+/* probe only: d_slots_out[i] = the slot handle of d_keys[i] (-1 = absent / reserved), d_found nullable.  No row is touched. */
+int mee_locate(const mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_slots_out, uint8_t* d_found, void* stream);
+/* Base address of one plane (0 = values, 1 = acc | m, 2 = v): row of slot s at ptr + s * row_stride_bytes.  A device pointer for
+ * MEE_MEM_HBM tables; for MEE_MEM_HOST_PINNED tables the address is valid on the HOST as well (pinned, device-mapped) — this is what
+ * a staged transfer (host-side gather + hipMemcpyAsync on a side stream) of a cold tier reads.  Invalidated by mee_reserve / destroy;
+ * the caller orders its accesses against the table's operators. */
+int mee_table_plane(const mee_table* t, uint32_t plane, void** ptr_out, uint64_t* row_stride_bytes, uint32_t* value_memory);
 /* [syncs] measurement aid (SURVEY.md §8d "mean probe length"): the number of buckets a find visits for d_keys, summed over
  * the batch (reserved keys visit none); divide by n for the mean.  Changes nothing. */
 int mee_probe_length(const mee_table* t, const int64_t* d_keys, size_t n, uint64_t* buckets_visited_out, void* stream);

@@ -94,6 +94,8 @@ PROTOTYPES = {
     "mee_find_located": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "mee_apply_adagrad_located": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _vp]),
     "mee_apply_adam_located": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
+    "mee_locate": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "mee_table_plane": (C.c_int, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_u32)]),
     "mee_probe_length": (C.c_int, [_vp, _vp, _sz, C.POINTER(_u64), _vp]),
     "mee_apply_adagrad": (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _vp]),
     "mee_apply_adam": (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),

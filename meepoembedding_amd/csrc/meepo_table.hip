@@ -2049,6 +2049,26 @@ int mee_size(const mee_table* t, size_t* n_out, void* stream) {
     *n_out = (size_t)t->h_op->n_export;
     return MEE_OK;
 }
+int mee_locate(const mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_slots_out, uint8_t* d_found, void* stream) {
+    if (!t || (n && (!d_keys || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_locate: null argument");
+    if (n > 0xFFFFFFFFull) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_locate: n=%zu exceeds 2^32 - 1", n);
+    if (n == 0) return MEE_OK;
+    DeviceGuard g(t->device);
+    remove_locate_kernel<<<grid_for(n, 16, 1u << 16), 256, 0, as_stream(stream)>>>(t->keys, t->nb, d_keys, (uint32_t)n, (long long*)d_slots_out, d_found, t->ctr);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+int mee_table_plane(const mee_table* t, uint32_t plane, void** ptr_out, uint64_t* row_stride_bytes, uint32_t* value_memory) {
+    if (!t || !ptr_out) return fail(MEE_ERR_INVALID_ARG, "mee_table_plane: null argument");
+    const float* p = plane_of(t, plane);
+    if (!p) return fail(MEE_ERR_UNSUPPORTED, "mee_table_plane: plane %u does not exist (optimizer=%u)", plane, t->optimizer);
+    *ptr_out = const_cast<float*>(p);
+    if (row_stride_bytes) *row_stride_bytes = (uint64_t)t->dim * sizeof(float);
+    if (value_memory) *value_memory = t->value_memory;
+    return MEE_OK;
+}
+
 int mee_probe_length(const mee_table* t, const int64_t* d_keys, size_t n, uint64_t* buckets_visited_out, void* stream) {
     if (!t || !buckets_visited_out || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_probe_length: null argument");
     *buckets_visited_out = 0;

@@ -201,6 +201,25 @@ class LookupTable:
         check(_lib.lib().mee_status(self._h, C.byref(b), self._s()))
         return b.value
 
+    def locate(self, keys: torch.Tensor):
+        """-> (slot handles [n] int64, -1 = absent; found [n] uint8).  Probe only: no row is read."""
+        k = self._keys(keys)
+        slots = torch.empty(k.numel(), dtype=torch.int64, device=self.device)
+        found = torch.empty(k.numel(), dtype=torch.uint8, device=self.device)
+        check(_lib.lib().mee_locate(self._h, k.data_ptr(), k.numel(), slots.data_ptr(), found.data_ptr(), self._s()))
+        return slots, found
+
+    def plane_host_view(self, plane: int = 0):
+        """numpy view [capacity, dim] float32 of one plane of a MEM_HOST_PINNED table (pinned host DRAM the device also maps): what a
+        staged cold-tier transfer gathers from on the host.  Valid until reserve() / close(); the caller orders its reads."""
+        import numpy as np
+        ptr, stride, mem = C.c_void_p(), C.c_uint64(), C.c_uint32()
+        check(_lib.lib().mee_table_plane(self._h, plane, C.byref(ptr), C.byref(stride), C.byref(mem)))
+        if mem.value != _lib.MEM_HOST_PINNED:
+            raise MeepoError(_lib.ERR_UNSUPPORTED, "plane_host_view: the table's planes live in HBM")
+        buf = (C.c_float * (self.capacity * self.dim)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.float32).reshape(self.capacity, self.dim)
+
     def probe_length(self, keys: torch.Tensor) -> float:
         """Mean number of buckets a find visits for `keys` (measurement aid); synchronises."""
         k = self._keys(keys)

@@ -186,8 +186,38 @@ class TieredLookupTable:
         src.remove(k)
         return int(k.numel())
 
-    def promote(self, keys: torch.Tensor) -> int:
-        """cold -> hot for the given keys (those that are cold), as many as the hot tier has room for."""
+    def _move_staged(self, keys: torch.Tensor) -> int:
+        """cold -> hot through a staged transfer (BASELINE configs[4] "async hipMemcpy side stream"): probe the cold index for the slots,
+        gather the rows (and state planes) out of the pinned host planes ON THE HOST into one contiguous pinned staging buffer, ship it with
+        ONE asynchronous copy on a side stream, insert into the hot table.  The alternative `_move` lets the find kernel read the same
+        rows straight over PCIe (zero-copy); tools/tier_bench.py measures the two against each other."""
+        import numpy as np
+        keys = torch.unique(keys.contiguous().view(-1))
+        slots, found = self.cold.locate(keys)
+        idx = self._idx(found != 0)
+        if not idx.numel():
+            return 0
+        k = keys[idx]
+        hs = slots[idx].cpu().numpy()                     # synchronises: the host needs the slot list
+        n_planes = {0: 0, 1: 1, 2: 2}[self.optimizer]
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream(self.device)
+        staged = []
+        for plane in range(0, n_planes + 1):
+            host = torch.empty((hs.size, self.dim), dtype=torch.float32, pin_memory=True)
+            np.take(self.cold.plane_host_view(plane), hs, axis=0, out=host.numpy())   # host-side gather of scattered 256-B rows
+            with torch.cuda.stream(self._side):
+                staged.append(host.to(self.device, non_blocking=True))                # one hipMemcpyAsync per plane on the side stream
+        torch.cuda.current_stream(self.device).wait_stream(self._side)
+        self.hot.insert(k, staged[0])
+        for plane in range(1, n_planes + 1):
+            self.hot.assign_plane(plane, k, staged[plane])
+        self.cold.remove(k)
+        return int(k.numel())
+
+    def promote(self, keys: torch.Tensor, staged: bool = False) -> int:
+        """cold -> hot for the given keys (those that are cold), as many as the hot tier has room for.  staged=True: host-side gather +
+        one asynchronous copy on a side stream instead of zero-copy reads by the find kernel (see _move_staged)."""
         keys = torch.unique(keys.contiguous().view(-1))
         _, in_cold = self.cold.find(keys)
         cand = keys[self._idx(in_cold != 0)]
@@ -196,7 +226,7 @@ class TieredLookupTable:
         self._hot_keys_ub = self.hot.size()
         room = max(0, self.hot_key_limit - self._hot_keys_ub)
         cand = cand[:room]
-        moved = self._move(self.cold, self.hot, cand) if cand.numel() else 0
+        moved = (self._move_staged(cand) if staged else self._move(self.cold, self.hot, cand)) if cand.numel() else 0
         self._hot_keys_ub += moved
         return moved
 

@@ -54,7 +54,12 @@ def _drive(tiered, ref, dev, opt, n_iter=40, seed=0, DIM=DIM):
             if tiered.policy:
                 tiered.rebalance(max_moves=300)   # policy-driven migration must not change anything observable either
         elif op == "promote":
-            tiered.promote(T(keys[:200]))      # migration must not change anything observable
+            # migration must not change anything observable — neither through zero-copy reads nor through the staged transfer
+            # (host-side gather + asynchronous copy on a side stream; real tables only)
+            if it % 2 and hasattr(tiered.cold, "plane_host_view"):
+                tiered.promote(T(keys[:200]), staged=True)
+            else:
+                tiered.promote(T(keys[:200]))
         else:
             tiered.demote(T(keys[:200]))
         assert tiered.size() == ref.size(), (it, op)

@@ -48,3 +48,23 @@ for cold_frac in [float(x) for x in a.fracs.split(',')]:
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3 / 20)
     us = statistics.median(ts)
     print(f"cold fraction {cold_frac:5.2f}: {us:8.1f} us per {a.batch}-key find -> {a.batch / us / 1e3:6.3f} G lookups/s; cold rows over PCIe {a.batch * cold_frac * a.dim * 4 / us / 1e3:6.1f} GB/s", flush=True)
+
+# ---- promotion (cold -> hot), zero-copy reads by the find kernel vs the staged transfer (host gather + hipMemcpyAsync on a side stream)
+hot_room = LookupTable(int(2_000_000 / a.load), a.dim, device=dev, max_batch=1 << 20)
+_w = TieredLookupTable(hot_room, cold, hot_key_limit=2_000_000)     # warm-up of both paths (allocator, pinned staging, side stream)
+_kw = synth.mix64_t((torch.arange(1000, device=dev) + 1) * synth._s64(synth._GOLDEN) + synth._s64(5))
+for st_ in (False, True):
+    _w.promote(_kw, staged=st_); _w.demote(_kw)
+for n_move in (50_000, 350_000, 50_000, 350_000):
+    for staged in (False, True):
+        tt = TieredLookupTable(hot_room, cold, hot_key_limit=2_000_000)
+        ic = torch.randperm(a.cold_keys, device=dev, generator=g)[:n_move]
+        kc = synth.mix64_t((ic + 1) * synth._s64(synth._GOLDEN) + synth._s64(5))
+        torch.cuda.synchronize(); t0 = time.time()
+        moved = tt.promote(kc, staged=staged)
+        torch.cuda.synchronize(); dt = time.time() - t0
+        o_, f_ = hot_room.find(kc)
+        assert moved == n_move and bool(f_.all()) and torch.equal(o_[:1000], synth.rows_t(kc[:1000], a.dim, 2))
+        print(f"promote {n_move} keys, {'staged (host gather + async copy on a side stream)' if staged else 'zero-copy (find kernel reads pinned host rows over PCIe)'}: "
+              f"{dt * 1e3:8.2f} ms -> {n_move * a.dim * 4 / dt / 1e9:6.2f} GB/s of rows", flush=True)
+        tt.demote(kc)      # put them back for the next round
