@@ -183,16 +183,6 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
                 k = pend ? tkeys[bb * kW + tl] : kEmpty;
             }
         }
-        if constexpr ((NT & 64) != 0) {  // mee_find_located: the slot of every position (-1 = absent), for the apply of the same step
-            // lane j < 4R collects the slot of position base + j (round j / 4, tile j % 4): ONE coalesced store per wave step
-            int64_t mine = -1;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int64_t v = __shfl(slot[r], (lane & 3) * kW);
-                if ((lane >> 2) == r) mine = v;
-            }
-            if (lane < KPW && base + lane < n) slots_out[base + lane] = mine;
-        }
         if constexpr ((NT & 16) != 0) {  // access statistics for the hot/cold policy (sampled calls only)
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -242,6 +232,16 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
                     for (uint32_t c = tl; c < dim4; c += 16)
                         out[i * dim4 + c] = slot[r] >= 0 ? values[(uint64_t)slot[r] * dim4 + c] : def4;
             }
+        }
+        if constexpr ((NT & 64) != 0) {  // mee_find_located: the slot of every position (-1 = absent), for the apply of the same step
+            // lane j < 4R collects the slot of position base + j (round j / 4, tile j % 4): ONE coalesced store per wave step
+            int64_t mine = -1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t v = __shfl(slot[r], (lane & 3) * kW);
+                if ((lane >> 2) == r) mine = v;
+            }
+            if (lane < KPW && base + lane < n) slots_out[base + lane] = mine;
         }
         if (found && !(NT & 32)) {  // NT&32: rows only (last pass of find_or_insert: found keeps meaning "present before")
 #pragma unroll
@@ -801,17 +801,18 @@ __global__ __launch_bounds__(256) void insert_join_kernel(const int64_t* __restr
                                                           const long long* __restrict__ slotof, GroupTable g, uint32_t* __restrict__ hidx,
                                                           const Counters* ctr, uint32_t epoch) {
     if (ctr->election != epoch) return;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !made[i] || slotof[i] < 0) return;
-    const int64_t key = keys[i];
-    if (reserved_key(key)) return;
-    const unsigned long long bk = (unsigned long long)key ^ kBias;
-    uint32_t h = (uint32_t)(mix64b((uint64_t)key) & g.smask);
-    for (uint64_t step = 0; step <= g.smask; ++step) {
-        const unsigned long long cur = g.skeys[h];
-        if (cur == 0) return;        // nobody else holds this key
-        if (cur == bk) { atomicMax(&g.sv[2 * h], i + 1); hidx[i] = h; return; }
-        h = (h + 1) & (uint32_t)g.smask;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!made[i] || slotof[i] < 0) continue;
+        const int64_t key = keys[i];
+        if (reserved_key(key)) continue;
+        const unsigned long long bk = (unsigned long long)key ^ kBias;
+        uint32_t h = (uint32_t)(mix64b((uint64_t)key) & g.smask);
+        for (uint64_t step = 0; step <= g.smask; ++step) {
+            const unsigned long long cur = g.skeys[h];
+            if (cur == 0) break;        // nobody else holds this key
+            if (cur == bk) { atomicMax(&g.sv[2 * h], i + 1); hidx[i] = h; break; }
+            h = (h + 1) & (uint32_t)g.smask;
+        }
     }
 }
 
@@ -1929,8 +1930,8 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
         if (t->dim4 == 16) DIRECT(16); else if (t->dim4 == 32) DIRECT(32); else DIRECT(0);
 #undef DIRECT
         group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, t->bs.fmask, nullptr, t->epoch, &t->ctr->election);
-        insert_join_kernel<<<gl, 256, 0, st>>>(d_keys, nn, t->bs.fmask, slotof, t->g, t->bs.hidx, t->ctr, t->epoch);
-        insert_settle_kernel<<<gt, 256, 0, st>>>((float4*)plane, t->dim4, (const float4*)d_values, nn, slotof, t->bs.hidx, t->g, t->ctr, t->epoch);
+        insert_join_kernel<<<grid_for(n, 256, 2048), 256, 0, st>>>(d_keys, nn, t->bs.fmask, slotof, t->g, t->bs.hidx, t->ctr, t->epoch);
+        insert_settle_kernel<<<grid_for(n, 16, 2048), 256, 0, st>>>((float4*)plane, t->dim4, (const float4*)d_values, nn, slotof, t->bs.hidx, t->g, t->ctr, t->epoch);
         MEE_HIP(hipGetLastError());
         return MEE_OK;
     }
