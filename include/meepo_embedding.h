@@ -17,8 +17,10 @@
  *    mee_table_create() (safe for hipGraph capture except the [syncs] ones).
  *  - Return value: MEE_OK or a negative error code; mee_last_error() gives a thread-local message.
  *    Device-side conditions (table full, reserved key in a batch) set sticky bits read by mee_status().
- *  - Mutators (insert/assign/find_or_insert/apply_*) on ONE table must be ordered by the caller (same stream
- *    or events); concurrent mee_find calls on different streams are safe.  n must be ≤ config.max_batch for
+ *  - Mutators (insert/assign/find_or_insert/apply_*) AND the [syncs] calls (size/status/export/hits_scan/dedup_sum/
+ *    probe_length: they share the table's counter block and its pinned read-back word) on ONE table must be ordered
+ *    by the caller (same stream or events; from several host threads: one such call at a time per table);
+ *    concurrent mee_find* calls on different streams / threads are safe.  n must be ≤ config.max_batch for
  *    every op except mee_find (any n).
  *  - There is no CPU fallback: creating a table without a usable gfx950 device fails with MEE_ERR_NO_DEVICE.
  */
@@ -229,7 +231,7 @@ int mee_apply_adagrad_indexed(mee_table* t, const int64_t* d_keys, const float* 
                               size_t n, float lr, float eps, void* stream);
 int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n_grad_rows, const uint32_t* d_grad_index,
                            size_t n, float lr, float beta1, float beta2, float eps, uint64_t step, void* stream);
-/* Optional split of an apply: mee_apply_prepare groups the batch's keys and plans the duplicate reduction — everything
+/* Optional split of an apply: mee_apply_prepare groups the batch's keys (occurrence counts, per-key position lists) — everything
  * that does not need the grads — so it can run early (e.g. on a side stream beside the forward lookup and the dense
  * model); the following mee_apply_adagrad / mee_apply_adam with the SAME d_keys / n then only streams the updates.
  * While a prepared apply is pending only mee_find*, mee_remove, mee_size/status/export and mee_apply_* are accepted;
