@@ -51,7 +51,9 @@ enum { MEE_STATUS_TABLE_FULL = 1u, MEE_STATUS_RESERVED_KEY = 2u };
 enum { MEE_MEM_HBM = 0, MEE_MEM_HOST_PINNED = 1 };
 /* MEE_FLAG_TRACK_HITS: keep a per-slot access counter (4 B/slot) fed by mee_find_counted and read by mee_hits_scan —
  * the statistics a hot/cold placement policy needs. */
-enum { MEE_FLAG_TRACK_HITS = 1u };
+/* MEE_FLAG_ADMISSION: keep a count-min sketch (3 x max(2^12, capacity / 16 rounded up to a power of two) 32-bit counters) of how
+ * often ABSENT keys were asked for — the state of the admission policy of mee_find_or_insert_admit (SPEC.md §3). */
+enum { MEE_FLAG_TRACK_HITS = 1u, MEE_FLAG_ADMISSION = 2u };
 
 typedef struct mee_table  mee_table;  /* one HBM-resident hash table (one shard) */
 typedef struct mee_router mee_router; /* workspace for the shard partition / un-permute kernels */
@@ -137,6 +139,14 @@ int mee_assign_plane(mee_table* t, uint32_t plane, const int64_t* d_keys, const 
 int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream);
 /* find, inserting absent keys with their initial row first; d_found (nullable) = present before the call. */
 int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
+/* Admission policy: mee_find_or_insert that creates an absent key only once it has been asked for often enough.  Every absent
+ * position adds 1 to its key's sketch counters; a key whose estimate — after ALL additions of this batch — is >= min_count is
+ * created (initial row, initial optimizer state) and all its occurrences return that row; other absent keys return the default
+ * row and stay absent.  d_found (nullable) = present before the call.  Deterministic per batch (SPEC.md §3); a count-min sketch
+ * only over-estimates, so a key is never admitted later than after min_count requests.  mee_admission_decay: every counter >>= shift
+ * (shift >= 32: zero) — a new observation window. */
+int mee_find_or_insert_admit(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, uint32_t min_count, void* stream);
+int mee_admission_decay(mee_table* t, uint32_t shift, void* stream);
 /* Tiered pairs (a key lives in exactly one of two tables): the same two mutators restricted to the positions whose
  * d_found byte is 0, i.e. keys that an earlier pass found in NEITHER table.  d_found is only read. */
 int mee_insert_missing(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, const uint8_t* d_found, void* stream);

@@ -21,7 +21,7 @@ OPT_NONE, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
 INIT_CONSTANT, INIT_UNIFORM = 0, 1
 STATUS_TABLE_FULL, STATUS_RESERVED_KEY = 1, 2
 MEM_HBM, MEM_HOST_PINNED = 0, 1
-FLAG_TRACK_HITS = 1
+FLAG_TRACK_HITS, FLAG_ADMISSION = 1, 2
 EMPTY_KEY = -(1 << 63)
 RECLAIMED_KEY = EMPTY_KEY + 1
 BUCKET_WIDTH = 16
@@ -94,6 +94,8 @@ PROTOTYPES = {
     "mee_find_located": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "mee_apply_adagrad_located": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _vp]),
     "mee_apply_adam_located": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
+    "mee_find_or_insert_admit": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _u32, _vp]),
+    "mee_admission_decay": (C.c_int, [_vp, _u32, _vp]),
     "mee_locate": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_table_plane": (C.c_int, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_u32)]),
     "mee_probe_length": (C.c_int, [_vp, _vp, _sz, C.POINTER(_u64), _vp]),

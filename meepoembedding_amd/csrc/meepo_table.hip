@@ -83,6 +83,8 @@ struct mee_table {
     int64_t* keys;
     float *values, *s1, *s2;
     uint32_t* hits;             // per-slot access counter (config.flags & MEE_FLAG_TRACK_HITS), else null
+    uint32_t* sketch;           // admission policy (config.flags & MEE_FLAG_ADMISSION): count-min sketch, 3 rows of 2^sketch_log2w counters
+    uint32_t sketch_log2w;
     // per-batch scratch: group table (S entries) and per-position arrays (max_batch entries)
     uint64_t S, max_big, max_part;   // max_big: groups larger than kChunk; max_part: their fp64 partial-sum rows (one per chunk)
     mee::GroupTable g;
@@ -836,6 +838,42 @@ __global__ __launch_bounds__(256) void insert_settle_kernel(float4* values, uint
             for (uint32_t c = tl; c < dim4; c += 16) values[(uint64_t)slot * dim4 + c] = vals[(uint64_t)i * dim4 + c];
         if (tl == 0) group_release_entry(g, h);
     }
+}
+
+// ---- admission policy (SPEC.md §3 find_or_insert_admit): a count-min sketch of how often ABSENT keys were asked for ------------
+__device__ __forceinline__ uint32_t sketch_index(int64_t key, int row, uint32_t log2w) {
+    constexpr uint64_t A[3] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull};
+    return (uint32_t)(mix64((uint64_t)key ^ A[row]) >> (64 - log2w)) + ((uint32_t)row << log2w);
+}
+// every position whose key is absent (found byte 0, key not reserved) adds 1 to its three counters
+__global__ __launch_bounds__(256) void sketch_add_kernel(const int64_t* __restrict__ keys, const uint8_t* __restrict__ found, uint64_t n,
+                                                         uint32_t* sketch, uint32_t log2w) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const int64_t k = keys[i];
+        if (found[i] || reserved_key(k)) continue;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) atomicAdd(&sketch[sketch_index(k, r, log2w)], 1u);
+    }
+}
+// after all additions of the batch: skip[i] = 1 unless the position's key is absent AND its estimate reached min_count
+__global__ __launch_bounds__(256) void sketch_decide_kernel(const int64_t* __restrict__ keys, const uint8_t* __restrict__ found, uint64_t n,
+                                                            const uint32_t* __restrict__ sketch, uint32_t log2w, uint32_t min_count,
+                                                            uint8_t* __restrict__ skip) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const int64_t k = keys[i];
+        uint8_t s = 1;
+        if (!found[i] && !reserved_key(k)) {
+            uint32_t est = 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) est = min(est, sketch[sketch_index(k, r, log2w)]);
+            s = est >= min_count ? 0 : 1;
+        }
+        skip[i] = s;
+    }
+}
+__global__ void sketch_decay_kernel(uint32_t* sketch, uint64_t n, uint32_t shift) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        sketch[i] = shift >= 32 ? 0u : sketch[i] >> shift;
 }
 
 // ---- remove (SPEC.md §3) -----------------------------------------------------------------------------------
@@ -1600,7 +1638,7 @@ int mee_table_destroy(mee_table* t) {
     float* planes[] = {t->values, t->s1, t->s2};
     for (float* p : planes)
         if (p) { if (t->value_memory == MEE_MEM_HOST_PINNED) (void)hipHostFree(p); else (void)hipFree(p); }
-    void* dev[] = {t->keys, t->hits, t->g.skeys, t->g.sv, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
+    void* dev[] = {t->keys, t->hits, t->sketch, t->g.skeys, t->g.sv, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
                    t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.work, t->bs.fmask, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (t->h_ctr) (void)hipHostFree(t->h_ctr);
@@ -1616,7 +1654,8 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
         return fail(MEE_ERR_INVALID_ARG, "mee_table_create: struct_size %u != %zu (ABI mismatch)", cfg->struct_size, sizeof(mee_config));
     if (cfg->capacity == 0 || cfg->dim < 4 || cfg->dim > 1024 || (cfg->dim & 3))
         return fail(MEE_ERR_INVALID_ARG, "mee_table_create: capacity must be >0 and dim a multiple of 4 in [4,1024]");
-    if (cfg->optimizer > MEE_OPT_ADAM || cfg->initializer > MEE_INIT_UNIFORM || cfg->value_memory > MEE_MEM_HOST_PINNED || (cfg->flags & ~(uint32_t)MEE_FLAG_TRACK_HITS) != 0)
+    if (cfg->optimizer > MEE_OPT_ADAM || cfg->initializer > MEE_INIT_UNIFORM || cfg->value_memory > MEE_MEM_HOST_PINNED ||
+        (cfg->flags & ~(uint32_t)(MEE_FLAG_TRACK_HITS | MEE_FLAG_ADMISSION)) != 0)
         return fail(MEE_ERR_INVALID_ARG, "mee_table_create: bad optimizer/initializer/value_memory");
     if (cfg->max_batch == 0 || cfg->max_batch > (1ull << 30))
         return fail(MEE_ERR_INVALID_ARG, "mee_table_create: max_batch must be in [1, 2^30]");
@@ -1678,6 +1717,12 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     ALLOC(t->keys, t->capacity * sizeof(int64_t));
     t->table_bytes = t->capacity * sizeof(int64_t);
     if (cfg->flags & MEE_FLAG_TRACK_HITS) { ALLOC(t->hits, t->capacity * sizeof(uint32_t)); t->table_bytes += t->capacity * sizeof(uint32_t); }
+    if (cfg->flags & MEE_FLAG_ADMISSION) {   // SPEC.md §3: W = max(2^12, 2^ceil(log2(capacity / 16)))
+        t->sketch_log2w = 12;
+        while ((1ull << t->sketch_log2w) < (t->capacity + 15) / 16 && t->sketch_log2w < 30) ++t->sketch_log2w;
+        ALLOC(t->sketch, 3ull * sizeof(uint32_t) << t->sketch_log2w);
+        t->table_bytes += 3ull * sizeof(uint32_t) << t->sketch_log2w;
+    }
     ALLOC_PLANE(t->values);
     if (t->optimizer != MEE_OPT_NONE) ALLOC_PLANE(t->s1);
     if (t->optimizer == MEE_OPT_ADAM) ALLOC_PLANE(t->s2);
@@ -1705,6 +1750,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
         fill_i64_kernel<<<2048, 256, 0, 0>>>(t->keys, t->capacity, kEmpty);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess && t->hits) e = hipMemsetAsync(t->hits, 0, t->capacity * sizeof(uint32_t), 0);
+        if (e == hipSuccess && t->sketch) e = hipMemsetAsync(t->sketch, 0, 3ull * sizeof(uint32_t) << t->sketch_log2w, 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.skeys, 0, S * 8, 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.sv, 0, S * 8, 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.sres, 0, S * 8, 0);   // list heads carry an epoch tag; epoch 0 is never used
@@ -2003,6 +2049,35 @@ static int find_or_insert_common(mee_table* t, const int64_t* d_keys, size_t n, 
 int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
     return find_or_insert_common(t, d_keys, n, d_out, d_found, stream, true, "mee_find_or_insert");
 }
+int mee_find_or_insert_admit(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, uint32_t min_count, void* stream) {
+    if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_or_insert_admit: null argument");
+    if (!t->sketch) return fail(MEE_ERR_UNSUPPORTED, "mee_find_or_insert_admit: table was created without MEE_FLAG_ADMISSION");
+    if (int rc = check_batch(t, n, "mee_find_or_insert_admit")) return rc;
+    if (n == 0) return MEE_OK;
+    DeviceGuard g(t->device);
+    hipStream_t st = as_stream(stream);
+    uint8_t* fmask = d_found ? d_found : t->bs.fmask;          // present before the call
+    uint8_t* skip = reinterpret_cast<uint8_t*>(t->bs.occ);     // max_batch x 4 bytes of scratch no other step of this call uses
+    if (int rc = find_plane(t, t->values, t->default_value, d_keys, n, d_out, fmask, stream)) return rc;
+    const unsigned gl = grid_for(n, 256, 4096);
+    sketch_add_kernel<<<gl, 256, 0, st>>>(d_keys, fmask, n, t->sketch, t->sketch_log2w);
+    sketch_decide_kernel<<<gl, 256, 0, st>>>(d_keys, fmask, n, t->sketch, t->sketch_log2w, min_count, skip);
+    ensure_direct_kernel<<<grid_for(n, 256, 8192), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
+                                                                d_keys, (uint32_t)n, skip, t->optimizer, t->init_acc, t->initializer, t->init_scale,
+                                                                t->init_seed, t->default_value, t->ctr, t->hits);
+    MEE_HIP(hipGetLastError());
+    // the admitted positions read their (created) row; everything else keeps what the first pass wrote
+    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, skip, stream, /*missing_only=*/true, /*counted=*/false, /*rows_only=*/true);
+}
+int mee_admission_decay(mee_table* t, uint32_t shift, void* stream) {
+    if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_admission_decay: null table");
+    if (!t->sketch) return fail(MEE_ERR_UNSUPPORTED, "mee_admission_decay: table was created without MEE_FLAG_ADMISSION");
+    DeviceGuard g(t->device);
+    sketch_decay_kernel<<<2048, 256, 0, as_stream(stream)>>>(t->sketch, 3ull << t->sketch_log2w, shift);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
 int mee_find_or_insert_missing(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, const uint8_t* d_found, void* stream) {
     if (!d_found && n) return fail(MEE_ERR_INVALID_ARG, "mee_find_or_insert_missing: null found mask");
     return find_or_insert_common(t, d_keys, n, d_out, const_cast<uint8_t*>(d_found), stream, false, "mee_find_or_insert_missing");

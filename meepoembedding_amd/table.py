@@ -27,7 +27,8 @@ class LookupTable:
 
     def __init__(self, capacity: int, dim: int, *, device: int | torch.device = 0, optimizer: int = OPT_NONE,
                  max_batch: int = 1 << 20, default_value: float = 0.0, initial_accumulator: float = 0.0,
-                 initializer: int = INIT_CONSTANT, init_scale: float = 0.0, init_seed: int = 0, value_memory: int = 0, track_hits: bool = False):
+                 initializer: int = INIT_CONSTANT, init_scale: float = 0.0, init_seed: int = 0, value_memory: int = 0, track_hits: bool = False,
+                 admission: bool = False):
         L = _lib.lib()
         dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
         if dev.type != "cuda":
@@ -36,7 +37,8 @@ class LookupTable:
         cfg = _lib.Config(struct_size=C.sizeof(_lib.Config), device=self.device.index, capacity=capacity, dim=dim,
                           optimizer=optimizer, max_batch=max_batch, default_value=default_value,
                           initial_accumulator=initial_accumulator, initializer=initializer, init_scale=init_scale,
-                          init_seed=init_seed, value_memory=value_memory, flags=_lib.FLAG_TRACK_HITS if track_hits else 0)
+                          init_seed=init_seed, value_memory=value_memory,
+                          flags=(_lib.FLAG_TRACK_HITS if track_hits else 0) | (_lib.FLAG_ADMISSION if admission else 0))
         self.track_hits = track_hits
         self.default_value = float(default_value)
         h = C.c_void_p()
@@ -45,7 +47,7 @@ class LookupTable:
         self._h = h
         self._opts = dict(device=self.device, optimizer=optimizer, max_batch=max_batch, default_value=default_value,
                           initial_accumulator=initial_accumulator, initializer=initializer, init_scale=init_scale, init_seed=init_seed,
-                          value_memory=value_memory, track_hits=track_hits)
+                          value_memory=value_memory, track_hits=track_hits, admission=admission)
         info = _lib.TableInfo()
         check(L.mee_table_info_get(self._h, C.byref(info)))
         self.capacity, self.n_buckets, self.max_batch = info.capacity, info.n_buckets, info.max_batch
@@ -181,15 +183,25 @@ class LookupTable:
         self.layout_epoch += 1
         return found
 
-    def find_or_insert(self, keys: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None):
+    def find_or_insert(self, keys: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None,
+                       min_count: int | None = None):
+        """min_count (tables created with admission=True): an absent key is created only once the table's count-min sketch has seen it
+        requested at least min_count times (this batch included); until then its positions return the default row."""
         k = self._keys(keys)
         n = k.numel()
         if out is None:
             out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
         if found is None:
             found = torch.empty(n, dtype=torch.uint8, device=self.device)
-        check(_lib.lib().mee_find_or_insert(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), self._s()))
+        if min_count is not None:
+            check(_lib.lib().mee_find_or_insert_admit(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), int(min_count), self._s()))
+        else:
+            check(_lib.lib().mee_find_or_insert(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), self._s()))
         return out, found
+
+    def admission_decay(self, shift: int = 1) -> None:
+        """Every counter of the admission sketch >>= shift (>= 32: reset): starts a new observation window."""
+        check(_lib.lib().mee_admission_decay(self._h, int(shift), self._s()))
 
     def size(self) -> int:
         n = C.c_size_t()

@@ -185,6 +185,48 @@ def test_find_or_insert(dev):
     assert np.array_equal(gk, ok) and np.array_equal(gv, ov) and np.array_equal(ga, oa)
 
 
+def test_admission_policy(dev):
+    """find_or_insert with an admission threshold (SPEC.md §3): an absent key is created only once the table's count-min sketch has seen
+    it requested min_count times — this batch's occurrences included, decided after all of them were counted.  The expected behaviour is
+    recomputed here: the sketch in numpy (same hashes, from oracle/pyspec.py's mix64), the table in the oracle."""
+    from oracle import pyspec
+    dim, cap, min_count = 16, 8192, 3
+    A = (0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9)
+    t = LookupTable(cap, dim, device=dev, max_batch=4096, admission=True, initializer=INIT_UNIFORM, init_scale=0.1, init_seed=5, default_value=-1.0)
+    o = oracle.OracleTable(cap, dim, initializer=oracle.INIT_UNIFORM, init_scale=0.1, init_seed=5, default_value=-1.0)
+    log2w = 12
+    while (1 << log2w) < (t.capacity + 15) // 16:
+        log2w += 1
+    sketch = np.zeros((3, 1 << log2w), dtype=np.int64)
+    idx = lambda k, r: pyspec.mix64((int(k) & (2**64 - 1)) ^ A[r]) >> (64 - log2w)   # noqa: E731
+    universe = synth.keys_np(61, 0, 600)
+    rng = np.random.default_rng(8)
+    created_total = 0
+    for step in range(12):
+        bk = universe[np.minimum(rng.zipf(1.6, size=700) - 1, universe.size - 1)]
+        bk[rng.integers(0, 700, 3)] = oracle.EMPTY_KEY
+        out, found = t.find_or_insert(T(bk, dev), min_count=min_count)
+        eo, ef = o.find(bk)                                  # present before the call
+        absent = [k for k, f in zip(bk, ef) if not f and k > oracle.EMPTY_KEY + 1]
+        for k in absent:
+            for r in range(3):
+                sketch[r, idx(k, r)] += 1
+        admit = sorted({int(k) for k in absent if min(sketch[r, idx(k, r)] for r in range(3)) >= min_count})
+        if admit:
+            o.find_or_insert(np.array(admit, dtype=np.int64))
+            created_total += len(admit)
+        eo2, _ = o.find(bk)                                  # rows after the admitted keys were created; others: default row
+        assert np.array_equal(found.cpu().numpy(), ef)
+        assert np.array_equal(out.cpu().numpy(), eo2)
+        assert t.size() == o.size()
+        if step == 7:
+            t.admission_decay(1)
+            sketch >>= 1
+    assert 0 < created_total < universe.size and t.status() == 0
+    with pytest.raises(MeepoError):                          # a table without the sketch says so
+        LookupTable(1024, dim, device=dev).find_or_insert(T(bk[:4], dev), min_count=2)
+
+
 def test_dedup_sum(dev):
     dim, n = 64, 40000
     rng = np.random.default_rng(7)
