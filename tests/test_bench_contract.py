@@ -36,7 +36,14 @@ def test_bench_single_gpu_contract(dev):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     cb = res["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
-    assert "workload" in res["config"] and "model" not in res["config"]
+    assert "workload" in res["config"] and "model" not in res["config"] and "launch" in res["config"]
+    assert rf["avg_launch_us"] > 0 and "window" in rf and "traffic_source" in rf
+    st = res["streams"]   # uniform / Zipf / 90-10 hit-miss, probe length, read-only GB/s, launch-size sweep
+    assert {"uniform", "zipf_1.05", "hit90_miss10", "uniform_with_streaming_load_hint", "launch_size_sweep"} <= set(st), st
+    for name in ("uniform", "zipf_1.05", "hit90_miss10"):
+        assert st[name]["lookups_per_s"] > 0 and st[name]["mean_probe_length_buckets"] >= 0.9 and st[name]["read_only_GBps"] > 0
+    assert st["hit90_miss10"]["mean_probe_length_buckets"] > st["zipf_1.05"]["mean_probe_length_buckets"] - 1e-9
+    assert len(st["launch_size_sweep"]["us_per_launch"]) == 6 and st["launch_size_sweep"]["fit_us_per_262144_lookups"] > 0
 
 
 @pytest.mark.gpu
