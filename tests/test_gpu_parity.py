@@ -457,6 +457,64 @@ def test_large_round_trip_properties(dev):
     assert torch.equal(gv[:chunk], synth.rows_t(gk[:chunk], dim, 2))
 
 
+def _free_hbm_gb(dev):
+    free, _ = torch.cuda.mem_get_info(dev)
+    return free / 1e9
+
+
+def test_full_size_configs_properties(dev):
+    """BASELINE configs[1]/[2] at their FULL size — 100M keys, dim 64, load 0.75, with an Adagrad plane (69 GB) — through size-independent
+    properties: every inserted key is found with exactly its key-derived row (whole key stream, 1M-key batches), an absent stream misses
+    everywhere, size() is exact, the export is a permutation of the inserted set (checksums of keys, rows re-derived from exported keys),
+    and one sparse-Adagrad step with a key-derived gradient moves every row to the value the update formula gives (checked on samples,
+    bit for bit: no duplicates -> no reduction-order freedom), on the located path and the probing path alike."""
+    if _free_hbm_gb(dev) < 120:
+        pytest.skip("needs ~100 GB of free HBM")
+    dim, n, chunk, M64 = 64, 100_000_000, 1 << 20, 1 << 64
+    t = LookupTable(int(n / 0.75), dim, device=dev, max_batch=chunk, optimizer=OPT_ADAGRAD, initial_accumulator=0.1)
+    ksum = kmix = 0
+    for s in range(0, n, chunk):
+        k = synth.keys_t(1, s, min(chunk, n - s), dev)
+        t.insert(k, synth.rows_t(k, dim, 2))
+        ksum = (ksum + int(k.sum())) % M64; kmix = (kmix + int((k ^ (k >> 7)).sum())) % M64   # checksums mod 2^64, whatever the chunking
+    assert t.size() == n and t.status() == 0
+    for s in range(0, n, chunk):                      # the whole key stream
+        k = synth.keys_t(1, s, min(chunk, n - s), dev)
+        out, found = t.find(k)
+        assert bool(found.all()) and torch.equal(out, synth.rows_t(k, dim, 2)), s
+    k = synth.keys_t(2, 0, chunk, dev)
+    out, found = t.find(k)
+    assert not bool(found.any()) and not bool(out.any())
+    # one Adagrad step over two 1M-key batches: located slots for the first, probing for the second
+    lr, eps = 0.05, 1e-10
+    for j, s in enumerate((5 * chunk, 77 * chunk)):
+        k = synth.keys_t(1, s, chunk, dev)
+        g = synth.rows_t(k, dim, 6) * 0.02
+        w0 = synth.rows_t(k, dim, 2)
+        if j == 0:
+            _, _, slots = t.find_located(k)
+            t.apply_adagrad(k, g, lr=lr, eps=eps, slots=slots)
+        else:
+            t.apply_adagrad(k, g, lr=lr, eps=eps)
+        acc = torch.addcmul(torch.full_like(g, 0.1), g, g)            # fma(g, g, acc) — one rounding, like the kernel
+        exp = torch.addcdiv(w0, g, acc.sqrt() + eps, value=-lr)        # w - lr * (g / (sqrt(acc) + eps)); compared at 1e-6: torch may fuse differently
+        out, found = t.find(k)
+        assert bool(found.all())
+        torch.testing.assert_close(out, exp, rtol=1e-6, atol=1e-9)
+        st, _ = t.find_plane(1, k[:4096])
+        torch.testing.assert_close(st, acc[:4096], rtol=1e-6, atol=1e-12)
+    # untouched keys kept their rows
+    k = synth.keys_t(1, 40 * chunk, chunk, dev)
+    out, _ = t.find(k)
+    assert torch.equal(out, synth.rows_t(k, dim, 2))
+    # export in slot ranges (bounded scratch): a permutation of the inserted keys
+    n_exp = esum = emix = 0
+    for ek, ev, e1, _ in t.iter_export(1 << 24, with_state=True):
+        n_exp += ek.numel(); esum = (esum + int(ek.sum())) % M64; emix = (emix + int((ek ^ (ek >> 7)).sum())) % M64
+    assert n_exp == n and esum == ksum and emix == kmix
+    t.close()
+
+
 # MEE_SOAK=N appends N more seeds (a soak run on the GPU box; the default suite keeps five)
 _SEQ = [(0, 16, "adagrad"), (1, 64, "adam"), (2, 128, "adagrad"), (3, 8, "adam"), (4, 64, "adagrad")] + \
        [(s, [16, 64, 128, 8][s % 4], ["adagrad", "adam"][(s // 4) % 2]) for s in range(5, 5 + int(os.environ.get("MEE_SOAK", "0")))]
