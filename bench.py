@@ -409,6 +409,7 @@ def main():
         peer = None
         t_best = None        # seconds per step of `step`, once something has been timed against it
         native = None        # the RcclShardedTable that carries `step`, if any
+        native_tables = []   # every native context created by the probe: closed (communicators destroyed) before the process group goes
         # ---- the exchange behind the C-ABI (mee_sharded_*: grouped ncclSend/ncclRecv inside the library), both layouts ----
         native_ok = args.transport in ("auto", "native") and depth == 1 and args.backend == "nccl" and not args.dedup
         if native_ok and not args.no_selftest:
@@ -423,6 +424,7 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     log(f"native rccl ({label}) unavailable: {e}")
                     break
+                native_tables.append(nt)
 
                 def step_nat(i, nt=nt):
                     return nt.find(batches[i % n_batches])
@@ -433,7 +435,6 @@ def main():
                 dist.all_reduce(okn, op=dist.ReduceOp.MIN)
                 if int(okn.item()) != 1:
                     log(f"native rccl ({label}): differs from the torch.distributed path or a segment overflowed: not used")
-                    nt.close()
                     continue
                 t_n = timed(step_nat)
                 log(f"transport probe: native rccl ({label}) {t_n * 1e3:.3f} ms/step")
@@ -673,6 +674,15 @@ def main():
                 res.setdefault("also", {})["tier_1b_keys_one_gpu"] = {"error": repr(e)}
         os.write(result_fd, (json.dumps(res) + "\n").encode())
     if sharded:
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        for nt_ in native_tables:   # every rank destroys its communicators while all peers are still alive
+            nt_.close()
+        if peer is not None:
+            try:
+                peer.close()
+            except Exception:  # noqa: BLE001
+                pass
         dist.barrier()
         dist.destroy_process_group()
 
