@@ -42,8 +42,9 @@ def timeit(fn):
     return statistics.median(ts)
 
 U = statistics.mean(uniq); B = a.batch
-per_u = 1032 if kind == OPT_ADAGRAD else 1544
-ab = 264 * B + per_u * U
+row = 4 * a.dim
+per_u = 8 + (4 if kind == OPT_ADAGRAD else 6) * row   # table key + w, state read + written (1032 / 1544 B at dim 64)
+ab = (8 + row) * B + per_u * U
 slots = torch.empty(a.batch, dtype=torch.int64, device=dev)
 
 def located_step(i):
@@ -62,9 +63,9 @@ for ov in (0, 1):
                            t.apply_adam(batches[0], grads[i % 4], lr=0.001, step=i + 1, slots=slots)))
     ts = timeit(located_step)
     print(f"round {ov}: apply {ta:.1f} us ({ab / ta / 1e3 / 8000:.3f}), located apply (one batch) {tl:.1f} us, find_located + located apply step {ts:.1f} us "
-          f"({(528 * B + ab) / ts / 1e3 / 8000:.3f} of the step roofline)")
+          f"({((16 + 2 * row) * B + ab) / ts / 1e3 / 8000:.3f} of the step roofline)")
 t_apply = timeit(apply)
 t_find = timeit(lambda i: t.find(batches[i % NB], out=out, found=found))
 t_step = timeit(lambda i: (t.find(batches[i % NB], out=out, found=found), apply(i)))
 print(f"{a.opt} {a.dist} batch {B} unique {U:.0f}: apply {t_apply:.1f} us ({ab / t_apply / 1e3:.0f} GB/s algorithmic = {ab / t_apply / 1e3 / 8000:.3f}), "
-      f"find {t_find:.1f} us, find+apply step {t_step:.1f} us -> {B / t_step / 1e3:.2f} Gkeys/s ({(528 * B + ab) / t_step / 1e3 / 8000:.3f} of roofline)")
+      f"find {t_find:.1f} us, find+apply step {t_step:.1f} us -> {B / t_step / 1e3:.2f} Gkeys/s ({((16 + 2 * row) * B + ab) / t_step / 1e3 / 8000:.3f} of roofline)")
