@@ -500,6 +500,7 @@ constexpr int kGroupLast = 0;   // max(lo, hi) = 1 + highest batch position of t
 constexpr int kGroupCount = 1;  // lo + hi = occurrence count, rank[i] = arrival order (finalised by the plan pass)
 constexpr int kGroupApply = 2;  // kGroupCount + every key's occurrences chained into lists (the apply path; see group_kernel)
 constexpr uint32_t kRankRemote = 0x80000000u;  // rank was handed out by an atomic on lo: add hi to finalise
+constexpr uint32_t kChunk = 32;                // occurrences summed by one tile; a key with more in one batch is a "hot" key
 constexpr uint32_t kHotMark = 0x80000000u;     // epoch tags: pcnt[i] = kHotMark | epoch marks position i as a hot key's occurrence of batch `epoch`
 constexpr int kLds = 512;       // block-local aggregation table (256 threads -> at most 256 distinct keys)
 
@@ -560,7 +561,11 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
             if (claimed) { g.sv[2 * h + 1] = total; lbase[slot] = 0; }
             else lbase[slot] = atomicAdd(&g.sv[2 * h], total) | kRankRemote;
             if constexpr (MODE == kGroupApply) {
-                if (!claimed) {   // (the claimer's chain starts at the rank-0 occurrence: nothing to store)
+                // (the claimer's chain starts at the rank-0 occurrence: nothing to store.)  Another block splices its chain onto the key's
+                // second list — unless the others' count it has just seen already makes the key a hot one (> kChunk occurrences): hot keys are
+                // finished through ranks, not lists, and skipping the splice spares their entry one same-address atomic per block.  A key that
+                // ends with <= kChunk occurrences had every block pass this test (the count only grows), so its list is complete.
+                if (!claimed && (lbase[slot] & ~kRankRemote) + total <= kChunk) {
                     // the tag is epoch | kHotMark: sres is also lent out as a per-position slot list (insert, remove), whose values never carry it
                     const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long*>(&g.sres[h]), ((unsigned long long)(epoch | kHotMark) << 32) | lhead[slot]);
                     bs.uniq_h[ltail[slot] - 1] = (uint32_t)(old >> 32) == (epoch | kHotMark) ? (uint32_t)old : 0u;   // this block's last arrival -> the list so far
@@ -604,7 +609,6 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum /
     return pre + incl - v;
 }
 
-constexpr uint32_t kChunk = 32;  // occurrences summed by one tile
 
 // Plan pass, one lane per batch position: finalise rank and count, then (leaders only) reserve the group's slice of
 // the occurrence list, list the chunk leaders as work items, give big groups a block of fp64 partial-sum rows, and — for the
@@ -1981,12 +1985,9 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
         MEE_HIP(hipGetLastError());
         return MEE_OK;
     }
+    // assign: an election over all positions (last occurrence wins), then the winners probe and overwrite
     group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, skip);
-    if (claim)
-        upsert_kernel<true><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
-                                                (const float4*)d_values, nn, t->bs.hidx, t->g, nullptr, t->optimizer, t->init_acc, t->ctr, t->hits);
-    else
-        upsert_kernel<false><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
+    upsert_kernel<false><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
                                                  (const float4*)d_values, nn, t->bs.hidx, t->g, d_found, t->optimizer, t->init_acc, t->ctr, t->hits);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
