@@ -244,7 +244,7 @@ int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_g
 /* Optional split of an apply: mee_apply_prepare groups the batch's keys (occurrence counts, per-key position lists) — everything
  * that does not need the grads — so it can run early (e.g. on a side stream beside the forward lookup and the dense
  * model); the following mee_apply_adagrad / mee_apply_adam with the SAME d_keys / n then only streams the updates.
- * While a prepared apply is pending only mee_find*, mee_remove, mee_size/status/export and mee_apply_* are accepted;
+ * While a prepared apply is pending only mee_find*, mee_locate, mee_size/status/export and mee_apply_* are accepted;
  * mee_apply_discard drops it.  The caller orders the two streams (event / wait). */
 int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* stream);
 int mee_apply_discard(mee_table* t, void* stream);

@@ -2013,7 +2013,7 @@ int mee_assign_plane(mee_table* t, uint32_t plane, const int64_t* d_keys, const 
 
 int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream) {
     if (!t || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_remove: null argument");
-    if (int rc = check_batch(t, n, "mee_remove", false)) return rc;
+    if (int rc = check_batch(t, n, "mee_remove")) return rc;   // lends sres as its slot list: a pending mee_apply_prepare keeps list heads there
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);

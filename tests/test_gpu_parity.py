@@ -690,6 +690,8 @@ def test_apply_prepare_split(dev):
         with pytest.raises(MeepoError):
             t.insert(dk[:10], torch.zeros(10, dim, device=dev))   # group table is busy
         with pytest.raises(MeepoError):
+            t.remove(dk[:10])                                        # would lend out the scratch the prepared batch keeps its list heads in
+        with pytest.raises(MeepoError):
             t.apply_adagrad(dk[:100], dg[:100], lr=0.01)             # not the prepared batch
         main.wait_stream(side)
         t.apply_adagrad(dk, dg, lr=0.01, eps=1e-10); o.apply_adagrad(bk, g, 0.01, 1e-10)
