@@ -233,7 +233,23 @@ def two_stream_extra(table, batches, dim, dev, bpl, launches=400):
     run(launches)
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / launches
-    return {"lookups_per_s": batch / dt, "us_per_batch": dt * 1e6, "frac_of_hbm_roofline": batch * bpl / dt / 1e9 / HBM_PEAK_GBS}
+    res = {"lookups_per_s": batch / dt, "us_per_batch": dt * 1e6, "frac_of_hbm_roofline": batch * bpl / dt / 1e9 / HBM_PEAK_GBS}
+    # four queued requests served by ONE launch (mee_find_many): the launch floor is paid once per four batches, on one stream
+    outs4 = [torch.empty((batch, dim), dtype=torch.float32, device=dev) for _ in range(4)]
+    founds4 = [torch.empty(batch, dtype=torch.uint8, device=dev) for _ in range(4)]
+
+    def run4(k):
+        for i in range(k):
+            table.find_many([(batches[(4 * i + j) % len(batches)], outs4[j], founds4[j]) for j in range(4)])
+
+    run4(5)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run4(launches // 4)
+    torch.cuda.synchronize(dev)
+    dt4 = (time.perf_counter() - t0) / (launches // 4) / 4
+    res["four_requests_per_launch"] = {"lookups_per_s": batch / dt4, "us_per_batch": dt4 * 1e6, "frac_of_hbm_roofline": batch * bpl / dt4 / 1e9 / HBM_PEAK_GBS}
+    return res
 
 
 def p2p_selftest(ctrl, log, timeout=120, script="p2p_selftest.py", port_offset=17, what="p2p") -> bool:

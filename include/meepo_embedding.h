@@ -100,6 +100,12 @@ int mee_set_tuning(mee_table* t, const char* name, int value);
 /* ---- lookup-table operators (README.md:2 "lookuptable-style"; SPEC.md §3) ------------------------------ */
 /* out[i,:] = row of keys[i] or default_value; found nullable. */
 int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
+/* Several lookup requests of ONE table in one launch (a server draining its request queue): request q is exactly
+ * mee_find(t, reqs[q].d_keys, reqs[q].n, reqs[q].d_out, reqs[q].d_found) (d_found nullable).  `reqs` is a HOST array of at most 16
+ * entries (read during the call; the buffers it names are device memory).  The per-launch latency floor is paid once: four
+ * 256K-key requests cost what one 1M-key lookup costs. */
+typedef struct mee_find_request { const int64_t* d_keys; size_t n; float* d_out; uint8_t* d_found; } mee_find_request;
+int mee_find_many(const mee_table* t, const mee_find_request* reqs, uint32_t count, void* stream);
 /* mee_find that also reports where each key lives: d_slots_out[i] = an opaque slot handle, -1 for absent / reserved keys.  The
  * handles feed mee_apply_*_located of the SAME training step (forward find -> backward apply) and stay valid only until the next
  * call that can move or free a row of this table (mee_remove, mee_clear, mee_reserve; inserting OTHER keys is fine). */

@@ -42,6 +42,10 @@ class Config(C.Structure):
     ]
 
 
+class FindRequest(C.Structure):
+    _fields_ = [("d_keys", C.c_void_p), ("n", C.c_size_t), ("d_out", C.c_void_p), ("d_found", C.c_void_p)]
+
+
 class TableInfo(C.Structure):
     _fields_ = [
         ("capacity", C.c_uint64), ("n_buckets", C.c_uint64), ("max_batch", C.c_uint64), ("dim", C.c_uint32),
@@ -91,6 +95,7 @@ PROTOTYPES = {
     "mee_size": (C.c_int, [_vp, C.POINTER(_sz), _vp]),
     "mee_status": (C.c_int, [_vp, C.POINTER(_u32), _vp]),
     "mee_clear_status": (C.c_int, [_vp, _vp]),
+    "mee_find_many": (C.c_int, [_vp, C.POINTER(FindRequest), _u32, _vp]),
     "mee_find_located": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "mee_apply_adagrad_located": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _vp]),
     "mee_apply_adam_located": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),

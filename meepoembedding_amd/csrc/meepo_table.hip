@@ -131,14 +131,13 @@ __global__ void fill_i64_kernel(int64_t* p, uint64_t n, int64_t v) {
 // DIM4 = dim/4 when it is a multiple of 16 (each lane moves DIM4/16 float4 per row), 0 = any dim at run time.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// the find of n positions by `n_waves` waves of which this is wave `wave` (each wave step takes 4R consecutive positions)
 template <int DIM4, int R, int NT>
-__global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values,
-                                                   uint64_t nb, const int64_t* __restrict__ keys, uint64_t n,
-                                                   f32x4* __restrict__ out, uint8_t* __restrict__ found, float defv,
-                                                   uint32_t dim4_rt, uint32_t* hits, int64_t* __restrict__ slots_out = nullptr) {
+__device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
+                                          const int64_t* __restrict__ keys, uint64_t n, f32x4* __restrict__ out,
+                                          uint8_t* __restrict__ found, float defv, uint32_t dim4_rt, uint32_t* hits,
+                                          int64_t* __restrict__ slots_out, uint64_t wave, uint64_t n_waves) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
     const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
     constexpr int KPW = 4 * R;
     const f32x4 def4 = {defv, defv, defv, defv};
@@ -262,6 +261,37 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
             }
         }
     }
+}
+
+template <int DIM4, int R, int NT>
+__global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values,
+                                                   uint64_t nb, const int64_t* __restrict__ keys, uint64_t n,
+                                                   f32x4* __restrict__ out, uint8_t* __restrict__ found, float defv,
+                                                   uint32_t dim4_rt, uint32_t* hits, int64_t* __restrict__ slots_out = nullptr) {
+    find_span<DIM4, R, NT>(tkeys, values, nb, keys, n, out, found, defv, dim4_rt, hits, slots_out,
+                           (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), (uint64_t)gridDim.x * (blockDim.x >> 6));
+}
+
+// Several lookup requests of one table in ONE launch (mee_find_many): the per-launch latency floor (~5 us: dispatch + the dependent
+// chain of the first and last waves) is paid once for all of them, so four queued 256K-key requests run at the rate of one 1M-key
+// launch.  The request descriptors travel in the kernel argument; a block finds its request by its index (<= kMaxFindRequests entries).
+constexpr int kMaxFindRequests = 16;
+struct FindMany {
+    const int64_t* keys[kMaxFindRequests];
+    f32x4* out[kMaxFindRequests];
+    uint8_t* found[kMaxFindRequests];
+    uint64_t n[kMaxFindRequests];
+    uint32_t first_block[kMaxFindRequests + 1];
+    uint32_t count;
+};
+template <int DIM4, int R, int NT>
+__global__ __launch_bounds__(256) void find_many_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
+                                                        FindMany m, float defv, uint32_t dim4_rt) {
+    uint32_t q = 0;
+    while (q + 1 < m.count && blockIdx.x >= m.first_block[q + 1]) ++q;   // block-uniform
+    find_span<DIM4, R, NT>(tkeys, values, nb, m.keys[q], m.n[q], m.out[q], m.found[q], defv, dim4_rt, nullptr, nullptr,
+                           (uint64_t)(blockIdx.x - m.first_block[q]) * (blockDim.x >> 6) + (threadIdx.x >> 6),
+                           (uint64_t)(m.first_block[q + 1] - m.first_block[q]) * (blockDim.x >> 6));
 }
 
 // ---- sparse second pass (SPEC.md §3 find_missing; last pass of find_or_insert): only positions whose found byte is 0 -----
@@ -1909,6 +1939,37 @@ int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, 
 int mee_find_located(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
     if (!t || (n && (!d_keys || !d_out || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_located: null argument");
     return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, false, false, false, d_slots_out);
+}
+
+int mee_find_many(const mee_table* t, const mee_find_request* reqs, uint32_t count, void* stream) {
+    if (!t || !reqs) return fail(MEE_ERR_INVALID_ARG, "mee_find_many: null argument");
+    if (count == 0) return MEE_OK;
+    if (count > (uint32_t)kMaxFindRequests) return fail(MEE_ERR_INVALID_ARG, "mee_find_many: %u requests (at most %d per call)", count, kMaxFindRequests);
+    FindMany m{};
+    const int R = t->dim4 == 16 ? 2 : 1;
+    uint64_t blocks = 0, out_bytes = 0;
+    uint32_t used = 0;
+    for (uint32_t q = 0; q < count; ++q) {
+        if (reqs[q].n == 0) continue;
+        if (!reqs[q].d_keys || !reqs[q].d_out) return fail(MEE_ERR_INVALID_ARG, "mee_find_many: request %u has a null buffer", q);
+        m.keys[used] = reqs[q].d_keys; m.out[used] = (f32x4*)reqs[q].d_out; m.found[used] = reqs[q].d_found; m.n[used] = reqs[q].n;
+        m.first_block[used] = (uint32_t)blocks;
+        blocks += (reqs[q].n + 16ull * R - 1) / (16ull * R);
+        out_bytes += (uint64_t)reqs[q].n * t->dim * 4;
+        ++used;
+    }
+    if (used == 0) return MEE_OK;
+    if (blocks > (1ull << 31)) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_find_many: %llu blocks", (unsigned long long)blocks);
+    m.first_block[used] = (uint32_t)blocks; m.count = used;
+    DeviceGuard g(t->device);
+    hipStream_t st = as_stream(stream);
+    const bool cached_out = out_bytes <= (128ull << 20);   // same policy as mee_find, on the total output of the launch
+#define FM(D4, RR) do { if (cached_out) find_many_kernel<D4, RR, 4><<<(unsigned)blocks, 256, 0, st>>>(t->keys, (const f32x4*)t->values, t->nb, m, t->default_value, t->dim4); \
+                        else find_many_kernel<D4, RR, 0><<<(unsigned)blocks, 256, 0, st>>>(t->keys, (const f32x4*)t->values, t->nb, m, t->default_value, t->dim4); } while (0)
+    if (t->dim4 == 16) FM(16, 2); else if (t->dim4 == 32) FM(32, 1); else FM(0, 1);
+#undef FM
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
 }
 
 int mee_find_missing(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {

@@ -96,6 +96,23 @@ class LookupTable:
                                   self._s()))
         return out, found
 
+    def find_many(self, requests):
+        """Several lookups of this table in ONE launch (mee_find_many): `requests` = up to 16 key tensors, or (keys, out, found) tuples with
+        preallocated outputs.  Returns [(out, found), …] — each exactly what find() returns for that request."""
+        reqs, res = (_lib.FindRequest * len(requests))(), []
+        for q, r in enumerate(requests):
+            keys, out, found = (r if isinstance(r, tuple) else (r, None, None))
+            k = self._keys(keys)
+            n = k.numel()
+            if out is None:
+                out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+            if found is None:
+                found = torch.empty(n, dtype=torch.uint8, device=self.device)
+            reqs[q] = _lib.FindRequest(k.data_ptr(), n, out.data_ptr(), found.data_ptr())
+            res.append((out, found, k))   # k: keeps a contiguous copy alive until the launch is enqueued
+        check(_lib.lib().mee_find_many(self._h, reqs, len(requests), self._s()))
+        return [(o, f) for o, f, _ in res]
+
     def find_pooled(self, keys: torch.Tensor, bag_offsets: torch.Tensor, mode: str = "sum", out: torch.Tensor | None = None,
                     found: torch.Tensor | None = None):
         """Embedding-bag lookup: bag b = keys[bag_offsets[b]:bag_offsets[b+1]] (int64 offsets on the device) -> ([n_bags, dim]

@@ -70,6 +70,35 @@ def test_insert_find_assign_export(dev, dim, n, load):
     assert t.size() == 0 and not t.find(T(q[:100], dev))[1].any()
 
 
+@pytest.mark.parametrize("dim", [64, 128, 24])
+def test_find_many_equals_separate_finds(dev, dim):
+    """mee_find_many: several requests of one table in one launch == mee_find per request (ragged sizes, an empty request, absent and
+    reserved keys, a request that is not a multiple of the wave step)."""
+    n_keys = 30000
+    keys = synth.keys_np(17, 0, n_keys); rows = synth.rows_np(keys, dim, 2)
+    t = LookupTable(65536, dim, device=dev, max_batch=n_keys, default_value=0.25)
+    t.insert(T(keys, dev), T(rows, dev))
+    rng = np.random.default_rng(4)
+    reqs = []
+    for n in (4096, 1, 0, 777, 20000, 33):
+        q = keys[rng.integers(0, n_keys, n)]
+        if n > 10:
+            q[::7] = synth.keys_np(99, 0, q[::7].size)           # absent
+            q[3] = oracle.EMPTY_KEY
+        reqs.append(T(q, dev))
+    got = t.find_many(reqs)
+    for q, (o, f) in zip(reqs, got):
+        eo, ef = t.find(q)
+        assert torch.equal(o, eo) and torch.equal(f, ef)
+    # preallocated outputs, 16 requests (the maximum), and one more than that is refused
+    many = [(reqs[0][i * 100:(i + 1) * 100], torch.empty(100, dim, device=dev), torch.empty(100, dtype=torch.uint8, device=dev)) for i in range(16)]
+    got = t.find_many(many)
+    eo, ef = t.find(reqs[0][:1600])
+    assert torch.equal(torch.cat([o for o, _ in got]), eo) and torch.equal(torch.cat([f for _, f in got]), ef)
+    with pytest.raises(MeepoError):
+        t.find_many([reqs[1]] * 17)
+
+
 def test_find_edge_cases(dev):
     t = LookupTable(1000, 64, device=dev, max_batch=4096)
     out, found = t.find(torch.empty(0, dtype=torch.int64, device=dev))   # empty batch
