@@ -1902,7 +1902,10 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
     const int nt = t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
 #define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
     if (d_slots_out) {   // located find: the plain kernel + one 8-byte store per key
-#define FINDL(D4, RR) do { if (nt & 4) find_kernel<D4, RR, 68><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out); \
+        // cache policy of `out`: this is the forward of a TRAINING step — the apply that follows sweeps the Infinity Cache before the next
+        // forward, so keeping the dense output cached buys nothing and streaming stores win (136.9 -> 132.5 us per find + Adagrad step)
+        const bool cached_out = t->find_nt >= 0 && (t->find_nt & 4);
+#define FINDL(D4, RR) do { if (cached_out) find_kernel<D4, RR, 68><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out); \
                            else find_kernel<D4, RR, 64><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out); } while (0)
         if (t->dim4 == 16) { if (R >= 2) FINDL(16, 2); else FINDL(16, 1); }
         else if (t->dim4 == 32) { if (R >= 2) FINDL(32, 2); else FINDL(32, 1); }

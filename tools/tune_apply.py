@@ -56,6 +56,10 @@ def located_apply(i):
     if kind == OPT_ADAGRAD: t.apply_adagrad(batches[i % NB], grads[i % 4], lr=0.01, eps=1e-10, slots=slots)
     else: t.apply_adam(batches[i % NB], grads[i % 4], lr=0.001, step=i + 1, slots=slots)
 
+for nt_ in (-1, 0, 1, 4, 5):   # cache policy of the forward find INSIDE the training step (the apply's traffic sweeps the Infinity Cache between finds)
+    t.set_tuning('find_nt', nt_)
+    print(f"find_nt={nt_}: find_located + located apply step {timeit(located_step):.1f} us, plain find + apply step {timeit(lambda i: (t.find(batches[i % NB], out=out, found=found), apply(i))):.1f} us")
+t.set_tuning('find_nt', -1)
 for ov in (0, 1):
     ta = timeit(apply)
     t.find_located(batches[0], out=out, found=found, slots=slots)
