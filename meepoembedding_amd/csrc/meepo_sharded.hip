@@ -53,10 +53,14 @@ struct RcclApi {
     char error[256] = {0};
 };
 
-static RcclApi* rccl_api() {
+static RcclApi& rccl_state() {
     static RcclApi api;
+    return api;
+}
+static RcclApi* rccl_api() {
+    RcclApi& api = rccl_state();
     static std::once_flag once;
-    std::call_once(once, [] {
+    std::call_once(once, [&api] {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
             api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -74,7 +78,10 @@ static RcclApi* rccl_api() {
     });
     return api.handle ? &api : nullptr;
 }
-static const char* rccl_load_error() { static RcclApi* unused = rccl_api(); (void)unused; return "RCCL could not be loaded (librccl.so.1 not found or incomplete)"; }
+static const char* rccl_load_error() {
+    (void)rccl_api();
+    return rccl_state().error[0] ? rccl_state().error : "RCCL could not be loaded (librccl.so.1 not found or incomplete)";
+}
 
 #define MEE_NCCL(api, expr)                                                                                        \
     do {                                                                                                           \
@@ -226,16 +233,19 @@ static int exchange(mee_sharded* c, const Leg* legs, int n_legs, bool reverse, h
     }
     if (c->G == 1) return MEE_OK;
     MEE_NCCL(api, api->GroupStart());
-    for (uint32_t p = 0; p < c->G; ++p) {
+    ncclResult_t first_err = ncclSuccess;   // an open group must be closed whatever happens inside it
+    for (uint32_t p = 0; p < c->G && first_err == ncclSuccess; ++p) {
         if (p == c->rank) continue;
-        for (int l = 0; l < n_legs; ++l) {
+        for (int l = 0; l < n_legs && first_err == ncclSuccess; ++l) {
             const size_t row = legs[l].elems * legs[l].elem_bytes;
             // zero-length messages are skipped on both sides (the two ends agree on every count)
-            if (sc[p]) MEE_NCCL(api, api->Send((const char*)legs[l].send + sd[p] * row, sc[p] * legs[l].elems, legs[l].dt, (int)p, c->comm, st));
-            if (rc[p]) MEE_NCCL(api, api->Recv((char*)legs[l].recv + rd[p] * row, rc[p] * legs[l].elems, legs[l].dt, (int)p, c->comm, st));
+            if (sc[p]) first_err = api->Send((const char*)legs[l].send + sd[p] * row, sc[p] * legs[l].elems, legs[l].dt, (int)p, c->comm, st);
+            if (rc[p] && first_err == ncclSuccess) first_err = api->Recv((char*)legs[l].recv + rd[p] * row, rc[p] * legs[l].elems, legs[l].dt, (int)p, c->comm, st);
         }
     }
-    MEE_NCCL(api, api->GroupEnd());
+    const ncclResult_t end_err = api->GroupEnd();
+    if (first_err != ncclSuccess) return fail(MEE_ERR_RCCL, "ncclSend/ncclRecv failed: %s", api->GetErrorString(first_err));
+    if (end_err != ncclSuccess) return fail(MEE_ERR_RCCL, "ncclGroupEnd failed: %s", api->GetErrorString(end_err));
     return MEE_OK;
 }
 
@@ -257,12 +267,15 @@ static int route(mee_sharded* c, const int64_t* d_keys, size_t n, hipStream_t st
     MEE_HIP(hipMemcpyAsync(c->d_recv_counts + c->rank, c->counts + c->rank, 8, hipMemcpyDeviceToDevice, st));
     if (c->G > 1) {
         MEE_NCCL(api, api->GroupStart());
-        for (uint32_t p = 0; p < c->G; ++p) {
+        ncclResult_t first_err = ncclSuccess;
+        for (uint32_t p = 0; p < c->G && first_err == ncclSuccess; ++p) {
             if (p == c->rank) continue;
-            MEE_NCCL(api, api->Send(c->counts + p, 1, ncclUint64, (int)p, c->comm, st));
-            MEE_NCCL(api, api->Recv(c->d_recv_counts + p, 1, ncclUint64, (int)p, c->comm, st));
+            first_err = api->Send(c->counts + p, 1, ncclUint64, (int)p, c->comm, st);
+            if (first_err == ncclSuccess) first_err = api->Recv(c->d_recv_counts + p, 1, ncclUint64, (int)p, c->comm, st);
         }
-        MEE_NCCL(api, api->GroupEnd());
+        const ncclResult_t end_err = api->GroupEnd();
+        if (first_err != ncclSuccess || end_err != ncclSuccess)
+            return fail(MEE_ERR_RCCL, "counts exchange failed: %s", api->GetErrorString(first_err != ncclSuccess ? first_err : end_err));
     }
     // … and both count vectors reach the host: the ONE synchronisation of an exact-layout operator
     MEE_HIP(hipMemcpyAsync(c->h_counts, c->counts, c->G * 8, hipMemcpyDeviceToHost, st));
