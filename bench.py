@@ -146,6 +146,29 @@ def stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, uniform
     table.set_tuning("find_nt", -1)
     rows["uniform_with_streaming_load_hint"] = {"us_per_launch_median": med, "us_per_launch_min": mn, "lookups_per_s": batch / med * 1e6,
                                                 "algorithmic_GBps": batch * bpl / med / 1e3, "frac_of_hbm_roofline": batch * bpl / med / 1e3 / HBM_PEAK_GBS}
+    # the same uniform stream through mee_find_unordered: launches not ordered behind each other (hipExtAnyOrderLaunch), two alternating
+    # output buffers — independent requests queued on ONE stream overlap their launch latency
+    o2 = [out, torch.empty_like(out)]
+    f2 = [found, torch.empty_like(found)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for name, unordered in (("uniform_two_output_buffers_in_order", False), ("uniform_two_output_buffers_unordered_launches", True)):
+        per = []
+        for r in range(6):
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for i in range(200):
+                table.find(uniform_batches[(r * 200 + i) % len(uniform_batches)], out=o2[i & 1], found=f2[i & 1], unordered=unordered)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            if r:
+                per.append(e0.elapsed_time(e1) * 1e3 / 200)
+        last = uniform_batches[(5 * 200 + 199) % len(uniform_batches)]
+        assert bool(f2[1].all()) and torch.equal(o2[1][:4096], synth.rows_t(last[:4096], dim, 2)), "lookup returned wrong rows"
+        per.sort()
+        med = per[len(per) // 2]
+        rows[name] = {"us_per_launch_median": med, "us_per_launch_min": per[0], "lookups_per_s": batch / med * 1e6,
+                      "algorithmic_GBps": batch * bpl / med / 1e3, "frac_of_hbm_roofline": batch * bpl / med / 1e3 / HBM_PEAK_GBS}
+    del o2, f2
     # launch-size sweep on the uniform stream: time = floor + slope * lookups (least squares) separates the per-launch latency floor
     # from the streaming rate the layout reaches
     allk = torch.cat(uniform_batches[:16])

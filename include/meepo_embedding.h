@@ -100,6 +100,12 @@ int mee_set_tuning(mee_table* t, const char* name, int value);
 /* ---- lookup-table operators (README.md:2 "lookuptable-style"; SPEC.md §3) ------------------------------ */
 /* out[i,:] = row of keys[i] or default_value; found nullable. */
 int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
+/* mee_find whose launch is NOT ordered behind earlier work of `stream` (hipExtAnyOrderLaunch): it may begin while previous kernels of
+ * the stream are still running, so consecutive lookups on one stream overlap their launch latency (measured on MI355X: 32.3 -> 30.8 us
+ * per 256K-key lookup).  The caller guarantees that d_keys is complete before the call is issued to the device and that nothing
+ * earlier in the stream still reads or writes d_out / d_found (independent requests with buffers of their own).  Work submitted to the
+ * stream AFTER it is ordered behind it as usual.  Same results as mee_find. */
+int mee_find_unordered(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
 /* Several lookup requests of ONE table in one launch (a server draining its request queue): request q is exactly
  * mee_find(t, reqs[q].d_keys, reqs[q].n, reqs[q].d_out, reqs[q].d_found) (d_found nullable).  `reqs` is a HOST array of at most 16
  * entries (read during the call; the buffers it names are device memory).  The per-launch latency floor is paid once: four

@@ -95,6 +95,7 @@ PROTOTYPES = {
     "mee_size": (C.c_int, [_vp, C.POINTER(_sz), _vp]),
     "mee_status": (C.c_int, [_vp, C.POINTER(_u32), _vp]),
     "mee_clear_status": (C.c_int, [_vp, _vp]),
+    "mee_find_unordered": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_find_many": (C.c_int, [_vp, C.POINTER(FindRequest), _u32, _vp]),
     "mee_find_located": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "mee_apply_adagrad_located": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _vp]),

@@ -11,6 +11,7 @@
 // (stays in L2 / Infinity Cache), used to give every distinct key one owner tile: duplicate-key reduction
 // for the optimizers, last-wins for insert/assign, single insertion for find_or_insert.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdlib>
@@ -1889,7 +1890,7 @@ static const float* plane_of(const mee_table* t, uint32_t plane) {
 
 static int find_plane(const mee_table* t, const float* plane, float miss_value, const int64_t* d_keys, size_t n, float* d_out,
                       uint8_t* d_found, void* stream, bool missing_only = false, bool counted = false, bool rows_only = false,
-                      int64_t* d_slots_out = nullptr) {
+                      int64_t* d_slots_out = nullptr, bool unordered = false) {
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -1898,7 +1899,9 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
     if (t->dim4 != 16 && t->dim4 != 32 && R > 2) R = 2;
     R = R >= 8 ? 8 : R >= 4 ? 4 : R >= 2 ? 2 : 1;
     const unsigned grid = grid_for(n, 4u * 4u * (unsigned)R, t->find_grid_cap > 0 ? (unsigned)t->find_grid_cap : (1u << 22));
-#define FIND1(D4, RR, NT) find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr)
+#define FIND1(D4, RR, NT) do { if (unordered) hipExtLaunchKernelGGL((find_kernel<D4, RR, NT>), dim3(grid), dim3(256), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, \
+                                        (const int64_t*)t->keys, (const f32x4*)plane, t->nb, d_keys, (uint64_t)n, (f32x4*)d_out, d_found, miss_value, t->dim4, (uint32_t*)nullptr, (int64_t*)nullptr); \
+                               else find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr); } while (0)
     const int nt = t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
 #define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
     if (d_slots_out) {   // located find: the plain kernel + one 8-byte store per key
@@ -1973,6 +1976,11 @@ int mee_find_many(const mee_table* t, const mee_find_request* reqs, uint32_t cou
 #undef FM
     MEE_HIP(hipGetLastError());
     return MEE_OK;
+}
+
+int mee_find_unordered(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
+    if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_unordered: null argument");
+    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, false, false, false, nullptr, /*unordered=*/true);
 }
 
 int mee_find_missing(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {

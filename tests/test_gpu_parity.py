@@ -99,6 +99,30 @@ def test_find_many_equals_separate_finds(dev, dim):
         t.find_many([reqs[1]] * 17)
 
 
+def test_find_unordered_same_results(dev):
+    """mee_find_unordered (hipExtAnyOrderLaunch): many lookups queued back to back on one stream, each with buffers of its own, may overlap
+    each other; every one of them returns what mee_find returns, and later in-order work on the stream sees the results."""
+    dim, n_keys, nb = 64, 200_000, 12
+    keys = synth.keys_t(23, 0, n_keys, dev)
+    t = LookupTable(int(n_keys / 0.75), dim, device=dev, max_batch=n_keys)
+    t.insert(keys, synth.rows_t(keys, dim, 2))
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    batches = [keys[torch.randint(0, n_keys, (50_000,), device=dev, generator=g)] for _ in range(nb)]
+    for b in batches:
+        b[::9] = synth.keys_t(99, 0, b[::9].numel(), dev)    # absent
+    outs = [torch.full((50_000, dim), 7.0, device=dev) for _ in range(nb)]
+    founds = [torch.full((50_000,), 9, dtype=torch.uint8, device=dev) for _ in range(nb)]
+    torch.cuda.synchronize(dev)                               # inputs complete, nothing earlier touches the outputs
+    for _ in range(3):
+        for b, o, f in zip(batches, outs, founds):
+            t.find(b, out=o, found=f, unordered=True)
+    sums = [o.sum() for o in outs]                            # in-order work behind the unordered launches
+    torch.cuda.synchronize(dev)
+    for b, o, f, s_ in zip(batches, outs, founds, sums):
+        eo, ef = t.find(b)
+        assert torch.equal(o, eo) and torch.equal(f, ef) and torch.equal(s_, eo.sum())
+
+
 def test_find_edge_cases(dev):
     t = LookupTable(1000, 64, device=dev, max_batch=4096)
     out, found = t.find(torch.empty(0, dtype=torch.int64, device=dev))   # empty batch
