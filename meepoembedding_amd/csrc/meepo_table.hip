@@ -43,25 +43,27 @@ struct OpCounters {          // device-resident, zeroed at the start of each op 
     uint32_t pad;
 };
 struct GroupTable {            // S entries, indexed by h
-    unsigned long long* skeys; // key ^ kBias, 0 = empty
-    // sv[2h] ("lo"): COUNT: occurrences added by blocks other than the claimer's (atomicAdd) | LAST: 1 + highest position seen by them (atomicMax)
-    // sv[2h+1] ("hi"): the same quantity of the block whose CAS claimed the entry — a plain store, no atomic.
-    // The pair is one aligned 8-byte word: readers take both halves with ONE load and a release is ONE store, so a reader
-    // racing with a release sees either the complete pair or zeros, never a mixture.
-    uint32_t* sv;
-    uint32_t* soffs;           // start of the group's slice of the occurrence list
+    // One 16-byte entry per h: ent[2h] = key ^ kBias (0 = empty), ent[2h+1] = the count word below.  Key and count share a 64-byte sector,
+    // so the claim and the count store of group_kernel, the count load of the apply's main pass and the release (ONE 16-byte store) touch
+    // one line per key instead of two.
+    unsigned long long* ent;
+    // count word, low half ("lo"):  COUNT: occurrences added by blocks other than the claimer's (atomicAdd) | LAST: 1 + highest position seen by them (atomicMax)
+    // count word, high half ("hi"): the same quantity of the block whose CAS claimed the entry — a plain store, no atomic.
+    // The pair is one aligned 8-byte word: readers take both halves with ONE load (sv_load), so a reader racing with a release sees
+    // either the complete pair or zeros, never a mixture.
+    uint32_t* soffs;           // start of the group's slice of the occurrence list (hot keys of an apply; dedup)
     uint32_t* sbig;            // first fp64 partial-sum row of a group with more than kChunk occurrences
     uint32_t* sgrp;            // index of the group in the unique list (standalone dedup)
-    long long* sres;           // find_or_insert: slot | present<<62, -1 = not stored
+    long long* sres;           // apply: epoch-tagged head of a key's spliced position list; lent out as a per-position slot list by insert / remove
     uint64_t smask;
 };
+__device__ __forceinline__ uint32_t* sv_half(const GroupTable& g, uint32_t h) { return reinterpret_cast<uint32_t*>(g.ent + 2 * (uint64_t)h + 1); }   // [0] = lo, [1] = hi
 __device__ __forceinline__ void sv_load(const GroupTable& g, uint32_t h, uint32_t& lo, uint32_t& hi) {
-    const unsigned long long w = reinterpret_cast<const unsigned long long*>(g.sv)[h];
+    const unsigned long long w = g.ent[2 * (uint64_t)h + 1];
     lo = (uint32_t)w; hi = (uint32_t)(w >> 32);
 }
 __device__ __forceinline__ void group_release_entry(const GroupTable& g, uint32_t h) {
-    g.skeys[h] = 0;
-    reinterpret_cast<unsigned long long*>(g.sv)[h] = 0ull;
+    reinterpret_cast<ulonglong2*>(g.ent)[h] = make_ulonglong2(0ull, 0ull);
 }
 struct BatchScratch {          // max_batch entries, indexed by batch position unless noted
     uint32_t *hidx, *rank, *pcnt, *occ, *uniq_h, *work;
@@ -520,7 +522,7 @@ __device__ __forceinline__ uint32_t group_claim(const GroupTable& g, int64_t key
     const unsigned long long bk = (unsigned long long)key ^ kBias;  // != 0 because key != kEmpty
     uint32_t h = (uint32_t)(mix64b((uint64_t)key) & g.smask);
     while (true) {  // one CAS per probe step: callers are already one lane per (block, key), so no pre-read is needed
-        const unsigned long long cur = atomicCAS(&g.skeys[h], 0ull, bk);
+        const unsigned long long cur = atomicCAS(&g.ent[2 * (uint64_t)h], 0ull, bk);
         claimed = cur == 0;
         if (cur == 0 || cur == bk) return h;
         h = (h + 1) & (uint32_t)g.smask;
@@ -589,8 +591,8 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
         lh[slot] = h;
         if constexpr (MODE == kGroupCount || MODE == kGroupApply) {
             const uint32_t total = lval[slot];
-            if (claimed) { g.sv[2 * h + 1] = total; lbase[slot] = 0; }
-            else lbase[slot] = atomicAdd(&g.sv[2 * h], total) | kRankRemote;
+            if (claimed) { sv_half(g, h)[1] = total; lbase[slot] = 0; }
+            else lbase[slot] = atomicAdd(&sv_half(g, h)[0], total) | kRankRemote;
             if constexpr (MODE == kGroupApply) {
                 // (the claimer's chain starts at the rank-0 occurrence: nothing to store.)  Another block splices its chain onto the key's
                 // second list — unless the others' count it has just seen already makes the key a hot one (> kChunk occurrences): hot keys are
@@ -605,8 +607,8 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
         } else {
             // the block whose CAS created the entry parks its candidate in the hi half with a plain store; only later arrivals
             // pay an atomic.  Readers take max(lo, hi).  (Unique keys: one atomic per key instead of two.)
-            if (claimed) g.sv[2 * h + 1] = lval[slot];
-            else atomicMax(&g.sv[2 * h], lval[slot]);
+            if (claimed) sv_half(g, h)[1] = lval[slot];
+            else atomicMax(&sv_half(g, h)[0], lval[slot]);
         }
     }
     __syncthreads();
@@ -845,9 +847,9 @@ __global__ __launch_bounds__(256) void insert_join_kernel(const int64_t* __restr
         const unsigned long long bk = (unsigned long long)key ^ kBias;
         uint32_t h = (uint32_t)(mix64b((uint64_t)key) & g.smask);
         for (uint64_t step = 0; step <= g.smask; ++step) {
-            const unsigned long long cur = g.skeys[h];
+            const unsigned long long cur = g.ent[2 * (uint64_t)h];
             if (cur == 0) break;        // nobody else holds this key
-            if (cur == bk) { atomicMax(&g.sv[2 * h], i + 1); hidx[i] = h; break; }
+            if (cur == bk) { atomicMax(&sv_half(g, h)[0], i + 1); hidx[i] = h; break; }
             h = (h + 1) & (uint32_t)g.smask;
         }
     }
@@ -1351,7 +1353,7 @@ __global__ __launch_bounds__(256) void apply_big_kernel(const int64_t* __restric
         sv_load(g, h, cnt_lo, cnt_hi);
         const uint32_t cnt = cnt_lo + cnt_hi;
         const uint32_t n_rows = (cnt + kChunk - 1) / kChunk, row0 = g.sbig[h];
-        const int64_t key = (int64_t)(g.skeys[h] ^ kBias);
+        const int64_t key = (int64_t)(g.ent[2 * (uint64_t)h] ^ kBias);
         RowPlanes pl{values, s1, s2};   // GROUPED: every thread decodes the same (member, slot); else tile 0 probes
         const int64_t slot = resolve_row<GROUPED>(tkeys, nb, desc, key, GROUPED || threadIdx.x < 16, tile, tl, pl);
         if (threadIdx.x == 0) lslot = slot;
@@ -1403,7 +1405,7 @@ __global__ __launch_bounds__(256) void dedup_keys_emit_kernel(uint32_t n, GroupT
     for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
         if (u < nu) {
             const uint32_t h = bs.uniq_h[u];
-            uniq_out[u] = (int64_t)(g.skeys[h] ^ kBias);
+            uniq_out[u] = (int64_t)(g.ent[2 * (uint64_t)h] ^ kBias);
             group_release(g, h);
         } else {
             uniq_out[u] = kEmpty;
@@ -1434,7 +1436,7 @@ __global__ __launch_bounds__(256) void dedup_emit_kernel(uint32_t dim4, const fl
             }
         }
         if (tl == 0) {
-            if (uniq_out) uniq_out[u] = (int64_t)(g.skeys[h] ^ kBias);
+            if (uniq_out) uniq_out[u] = (int64_t)(g.ent[2 * (uint64_t)h] ^ kBias);
             if (counts_out) counts_out[u] = cnt;
             group_release(g, h);
         }
@@ -1673,7 +1675,7 @@ int mee_table_destroy(mee_table* t) {
     float* planes[] = {t->values, t->s1, t->s2};
     for (float* p : planes)
         if (p) { if (t->value_memory == MEE_MEM_HOST_PINNED) (void)hipHostFree(p); else (void)hipFree(p); }
-    void* dev[] = {t->keys, t->hits, t->sketch, t->g.skeys, t->g.sv, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
+    void* dev[] = {t->keys, t->hits, t->sketch, t->g.ent, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
                    t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.work, t->bs.fmask, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (t->h_ctr) (void)hipHostFree(t->h_ctr);
@@ -1762,7 +1764,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     if (t->optimizer != MEE_OPT_NONE) ALLOC_PLANE(t->s1);
     if (t->optimizer == MEE_OPT_ADAM) ALLOC_PLANE(t->s2);
 #undef ALLOC_PLANE
-    ALLOC(t->g.skeys, S * 8); ALLOC(t->g.sv, S * 8); ALLOC(t->g.soffs, S * 4); ALLOC(t->g.sgrp, S * 4);
+    ALLOC(t->g.ent, S * 16); ALLOC(t->g.soffs, S * 4); ALLOC(t->g.sgrp, S * 4);
     ALLOC(t->g.sbig, S * 4); ALLOC(t->g.sres, S * 8);
     ALLOC(t->bs.hidx, mb * 4); ALLOC(t->bs.rank, mb * 4); ALLOC(t->bs.pcnt, mb * 4); ALLOC(t->bs.occ, mb * 4); ALLOC(t->bs.uniq_h, mb * 4);
     ALLOC(t->bs.work, mb * 4); ALLOC(t->bs.fmask, mb);
@@ -1786,8 +1788,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess && t->hits) e = hipMemsetAsync(t->hits, 0, t->capacity * sizeof(uint32_t), 0);
         if (e == hipSuccess && t->sketch) e = hipMemsetAsync(t->sketch, 0, 3ull * sizeof(uint32_t) << t->sketch_log2w, 0);
-        if (e == hipSuccess) e = hipMemsetAsync(t->g.skeys, 0, S * 8, 0);
-        if (e == hipSuccess) e = hipMemsetAsync(t->g.sv, 0, S * 8, 0);
+        if (e == hipSuccess) e = hipMemsetAsync(t->g.ent, 0, S * 16, 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.sres, 0, S * 8, 0);   // list heads carry an epoch tag; epoch 0 is never used
         if (e == hipSuccess) e = hipMemsetAsync(t->bs.pcnt, 0, mb * 4, 0);  // so do the hot-key marks
         if (e == hipSuccess && t->bs.gacc) e = hipMemsetAsync(t->bs.gacc, 0, t->max_part * (uint64_t)t->dim * sizeof(double), 0);
