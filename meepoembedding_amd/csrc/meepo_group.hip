@@ -24,9 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // One tile per key, R keys in flight per tile (same shape as find_kernel).  DIM4 = dim/4 when it is 16 or 32, 0 = any.
 // LOCATE: no rows move; gslot[i] = member << 48 | slot of the key (kEmpty when absent / reserved / outside the segments) —
 // the first pass of a grouped apply.
-// MISSING: only positions whose found byte is 0 are looked at; rows are written where the key is now stored, found is
-// left alone (the last pass of a grouped find_or_insert: found keeps meaning "present before the call").
-template <int DIM4, int R, bool STREAM_OUT, bool LOCATE = false, bool MISSING = false>
+template <int DIM4, int R, bool STREAM_OUT, bool LOCATE = false>
 __global__ __launch_bounds__(256) void find_grouped_kernel(const GroupDesc* __restrict__ desc, uint32_t n_tables,
                                                            const uint64_t* __restrict__ offsets, const int64_t* __restrict__ keys,
                                                            uint64_t n, float4* __restrict__ out, uint8_t* __restrict__ found,
@@ -60,7 +58,6 @@ __global__ __launch_bounds__(256) void find_grouped_kernel(const GroupDesc* __re
             d[r] = desc[inb[r] ? lo : 0];   // 32 B, L1/L2 resident (staging the descriptors in LDS as well measured 3 % slower)
             key[r] = inb[r] ? keys[i] : kEmpty;
             act[r] = inb[r] && !reserved_key(key[r]);
-            if constexpr (MISSING) act[r] = act[r] && found[i] == 0;
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -105,7 +102,7 @@ __global__ __launch_bounds__(256) void find_grouped_kernel(const GroupDesc* __re
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint64_t i = base + r * 4 + tile;
-                if (MISSING ? slot[r] >= 0 : inb[r])
+                if (inb[r])
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         if constexpr (STREAM_OUT) {   // a dense output beyond the Infinity Cache: streaming stores (find_kernel's policy)
@@ -120,13 +117,13 @@ __global__ __launch_bounds__(256) void find_grouped_kernel(const GroupDesc* __re
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint64_t i = base + r * 4 + tile;
-                if (MISSING ? slot[r] >= 0 : inb[r])
+                if (inb[r])
                     for (uint32_t c = tl; c < dim4; c += 16)
                         out[i * dim4 + c] = slot[r] >= 0 ? d[r].values[(uint64_t)slot[r] * dim4 + c]
                                                          : make_float4(d[r].defv, d[r].defv, d[r].defv, d[r].defv);
             }
         }
-        if (found && !MISSING) {
+        if (found) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint64_t i = base + r * 4 + tile;
@@ -136,13 +133,14 @@ __global__ __launch_bounds__(256) void find_grouped_kernel(const GroupDesc* __re
     }
 }
 
-// Middle pass of a grouped find_or_insert: every position the find pass left missing claims (or finds, when a duplicate
+// Second pass of a grouped find_or_insert: every position the find pass left missing claims (or finds, when a duplicate
 // got there first) its key's slot in its member table; the tile whose CAS created the key writes the initial row, the
-// initial optimizer state and a zero hit counter.  One tile per position.
+// initial optimizer state and a zero hit counter, and every such tile writes that same initial row — a function of the
+// key and its table's initializer alone — into `out`, so nothing has to read the created rows back.  One tile per position.
 __global__ __launch_bounds__(256) void ensure_grouped_kernel(const GroupDesc* __restrict__ desc, const GroupInit* __restrict__ init,
                                                              uint32_t n_tables, const uint64_t* __restrict__ offsets,
                                                              const int64_t* __restrict__ keys, uint64_t n,
-                                                             const uint8_t* __restrict__ found, uint32_t dim4) {
+                                                             const uint8_t* __restrict__ found, uint32_t dim4, float4* __restrict__ out) {
     __shared__ uint64_t loff[kMaxGroupTables + 1];
     for (uint32_t j = threadIdx.x; j <= n_tables; j += blockDim.x) loff[j] = offsets[j];
     __syncthreads();
@@ -167,16 +165,20 @@ __global__ __launch_bounds__(256) void ensure_grouped_kernel(const GroupDesc* __
         const int64_t slot = tile_locate<true, true>(const_cast<int64_t*>(d.tkeys), d.nb, key, act, tile, tl, is_new, full);
         if (act) {
             const GroupInit in = init[lo];
-            if (slot >= 0 && is_new) {
+            if (slot >= 0) {
                 for (uint32_t c = tl; c < dim4; c += 16) {
-                    d.values[(uint64_t)slot * dim4 + c] = initial_row4(key, c * 4, in.initializer, in.init_scale, in.init_seed, d.defv);
-                    if (in.optimizer == MEE_OPT_ADAGRAD) d.s1[(uint64_t)slot * dim4 + c] = make_float4(in.init_acc, in.init_acc, in.init_acc, in.init_acc);
-                    if (in.optimizer == MEE_OPT_ADAM) {
-                        d.s1[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        d.s2[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 row = initial_row4(key, c * 4, in.initializer, in.init_scale, in.init_seed, d.defv);
+                    out[i * dim4 + c] = row;
+                    if (is_new) {
+                        d.values[(uint64_t)slot * dim4 + c] = row;
+                        if (in.optimizer == MEE_OPT_ADAGRAD) d.s1[(uint64_t)slot * dim4 + c] = make_float4(in.init_acc, in.init_acc, in.init_acc, in.init_acc);
+                        if (in.optimizer == MEE_OPT_ADAM) {
+                            d.s1[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            d.s2[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
                     }
                 }
-                if (in.hits && tl == 0) in.hits[slot] = 0;
+                if (is_new && in.hits && tl == 0) in.hits[slot] = 0;
             }
             if (full && tl == 0) atomicOr(in.status, (uint32_t)MEE_STATUS_TABLE_FULL);
         }
@@ -277,7 +279,6 @@ int mee_group_destroy(mee_group* g) {
 
 }  // extern "C"
 
-template <bool MISSING>
 static int launch_find_grouped(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found,
                                hipStream_t st) {
     const bool stream_out = (uint64_t)n * g->dim * 4 > (128ull << 20);   // find_kernel's store policy
@@ -286,8 +287,8 @@ static int launch_find_grouped(mee_group* g, const int64_t* d_keys, const uint64
     const unsigned grid_cap = 8192;
 #define GROUPED(D4, RR, PER)                                                                                                          \
     do {                                                                                                                              \
-        if (stream_out) find_grouped_kernel<D4, RR, true, false, MISSING><<<grid_for(n, PER, grid_cap), 256, 0, st>>>(g->d_desc, g->n_tables, d_offsets, d_keys, n, (float4*)d_out, d_found, g->dim4); \
-        else find_grouped_kernel<D4, RR, false, false, MISSING><<<grid_for(n, PER, grid_cap), 256, 0, st>>>(g->d_desc, g->n_tables, d_offsets, d_keys, n, (float4*)d_out, d_found, g->dim4);       \
+        if (stream_out) find_grouped_kernel<D4, RR, true><<<grid_for(n, PER, grid_cap), 256, 0, st>>>(g->d_desc, g->n_tables, d_offsets, d_keys, n, (float4*)d_out, d_found, g->dim4); \
+        else find_grouped_kernel<D4, RR, false><<<grid_for(n, PER, grid_cap), 256, 0, st>>>(g->d_desc, g->n_tables, d_offsets, d_keys, n, (float4*)d_out, d_found, g->dim4);       \
     } while (0)
     if (g->dim4 == 16) GROUPED(16, 2, 32);
     else if (g->dim4 == 32) GROUPED(32, 1, 16);
@@ -305,7 +306,7 @@ int mee_find_grouped(mee_group* g, const int64_t* d_keys, const uint64_t* d_offs
     if (n == 0) return MEE_OK;
     if (int rc = group_refresh(g, stream)) return rc;
     DeviceGuard guard(g->device);
-    return launch_find_grouped<false>(g, d_keys, d_offsets, n, d_out, d_found, (hipStream_t)stream);
+    return launch_find_grouped(g, d_keys, d_offsets, n, d_out, d_found, (hipStream_t)stream);
 }
 
 int mee_group_find_or_insert(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found,
@@ -321,11 +322,11 @@ int mee_group_find_or_insert(mee_group* g, const int64_t* d_keys, const uint64_t
     DeviceGuard guard(g->device);
     hipStream_t st = (hipStream_t)stream;
     // 1) the ordinary grouped find serves every stored key and yields the present-before mask
-    if (int rc = launch_find_grouped<false>(g, d_keys, d_offsets, n, d_out, d_found, st)) return rc;
-    // 2) missing positions create their key (one creator per distinct key: the CAS decides), 3) and then read its row
-    ensure_grouped_kernel<<<grid_for(n, 16, 8192), 256, 0, st>>>(g->d_desc, g->d_init, g->n_tables, d_offsets, d_keys, n, d_found, g->dim4);
+    if (int rc = launch_find_grouped(g, d_keys, d_offsets, n, d_out, d_found, st)) return rc;
+    // 2) missing positions create their key (one creator per distinct key: the CAS decides) and return its initial row
+    ensure_grouped_kernel<<<grid_for(n, 16, 8192), 256, 0, st>>>(g->d_desc, g->d_init, g->n_tables, d_offsets, d_keys, n, d_found, g->dim4, (float4*)d_out);
     MEE_HIP(hipGetLastError());
-    return launch_find_grouped<true>(g, d_keys, d_offsets, n, d_out, d_found, st);
+    return MEE_OK;
 }
 
 }  // extern "C"

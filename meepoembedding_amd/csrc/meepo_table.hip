@@ -949,7 +949,7 @@ __global__ __launch_bounds__(256) void ensure_direct_kernel(int64_t* tkeys, floa
                                                             uint32_t dim4, const int64_t* __restrict__ keys, uint32_t n,
                                                             const uint8_t* __restrict__ found, uint32_t optimizer, float init_acc,
                                                             uint32_t initializer, float init_scale, uint64_t init_seed,
-                                                            float default_value, Counters* ctr, uint32_t* hits) {
+                                                            float default_value, Counters* ctr, uint32_t* hits, float4* __restrict__ out) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
@@ -969,16 +969,23 @@ __global__ __launch_bounds__(256) void ensure_direct_kernel(int64_t* tkeys, floa
             const int64_t key = __shfl(k, p >= 0 ? p : 0);
             bool is_new, full;
             const int64_t slot = tile_locate<true, true>(tkeys, nb, key, p >= 0, tile, tl, is_new, full);
-            if (p >= 0 && slot >= 0 && is_new) {
+            if (p >= 0 && slot >= 0) {
+                // A position that was missing and whose key is stored now — created by this tile or by another occurrence in this batch —
+                // returns the key's initial row, which is a function of the key alone: every such tile writes it straight into `out`
+                // (bit-identical to what the creator stores), so no third pass has to read the created rows back.
                 for (uint32_t c = tl; c < dim4; c += 16) {
-                    values[(uint64_t)slot * dim4 + c] = initial_row4(key, c * 4, initializer, init_scale, init_seed, default_value);
-                    if (optimizer == MEE_OPT_ADAGRAD) s1[(uint64_t)slot * dim4 + c] = make_float4(init_acc, init_acc, init_acc, init_acc);
-                    if (optimizer == MEE_OPT_ADAM) {
-                        s1[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        s2[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 row = initial_row4(key, c * 4, initializer, init_scale, init_seed, default_value);
+                    if (out) out[(uint64_t)(base + p) * dim4 + c] = row;
+                    if (is_new) {
+                        values[(uint64_t)slot * dim4 + c] = row;
+                        if (optimizer == MEE_OPT_ADAGRAD) s1[(uint64_t)slot * dim4 + c] = make_float4(init_acc, init_acc, init_acc, init_acc);
+                        if (optimizer == MEE_OPT_ADAM) {
+                            s1[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            s2[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
                     }
                 }
-                if (hits && tl == 0) hits[slot] = 0;
+                if (is_new && hits && tl == 0) hits[slot] = 0;
             }
             const uint64_t fm = __ballot(full);
             if (lane == 0 && fm) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_TABLE_FULL);
@@ -2112,12 +2119,13 @@ static int find_or_insert_common(mee_table* t, const int64_t* d_keys, size_t n, 
     uint8_t* fmask = d_found ? d_found : t->bs.fmask;
     if (own_find_pass)
         if (int rc = find_plane(t, t->values, t->default_value, d_keys, n, d_out, fmask, stream)) return rc;
+    // pass 2: every position the mask leaves missing claims its key (or meets the occurrence that did) and writes the key's initial row
+    // into the table (creator) and into d_out (everybody): nothing is left for a third pass
     ensure_direct_kernel<<<grid_for(n, 256, 8192), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
                                                                 d_keys, nn, fmask, t->optimizer, t->init_acc, t->initializer, t->init_scale,
-                                                                t->init_seed, t->default_value, t->ctr, t->hits);
+                                                                t->init_seed, t->default_value, t->ctr, t->hits, (float4*)d_out);
     MEE_HIP(hipGetLastError());
-    // pass 3: the positions that were missing read their (created or already racing-created) row; the mask is left alone
-    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, fmask, stream, /*missing_only=*/true, /*counted=*/false, /*rows_only=*/true);
+    return MEE_OK;
 }
 
 int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
@@ -2138,10 +2146,9 @@ int mee_find_or_insert_admit(mee_table* t, const int64_t* d_keys, size_t n, floa
     sketch_decide_kernel<<<gl, 256, 0, st>>>(d_keys, fmask, n, t->sketch, t->sketch_log2w, min_count, skip);
     ensure_direct_kernel<<<grid_for(n, 256, 8192), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
                                                                 d_keys, (uint32_t)n, skip, t->optimizer, t->init_acc, t->initializer, t->init_scale,
-                                                                t->init_seed, t->default_value, t->ctr, t->hits);
+                                                                t->init_seed, t->default_value, t->ctr, t->hits, (float4*)d_out);   // admitted positions get their initial row here
     MEE_HIP(hipGetLastError());
-    // the admitted positions read their (created) row; everything else keeps what the first pass wrote
-    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, skip, stream, /*missing_only=*/true, /*counted=*/false, /*rows_only=*/true);
+    return MEE_OK;
 }
 int mee_admission_decay(mee_table* t, uint32_t shift, void* stream) {
     if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_admission_decay: null table");
