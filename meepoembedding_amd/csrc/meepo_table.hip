@@ -41,6 +41,7 @@ struct OpCounters {          // device-resident, zeroed at the start of each op 
     unsigned long long n_export;  // pairs exported / keys counted
     uint32_t n_part;         // fp64 partial-sum rows reserved by big groups
     uint32_t pad;
+    unsigned long long occ_work;  // plan-free apply: occurrence-list entries reserved (low half) | work items listed (high half)
 };
 struct GroupTable {            // S entries, indexed by h
     // One 16-byte entry per h: ent[2h] = key ^ kBias (0 = empty), ent[2h+1] = the count word below.  Key and count share a 64-byte sector,
@@ -54,7 +55,9 @@ struct GroupTable {            // S entries, indexed by h
     uint32_t* soffs;           // start of the group's slice of the occurrence list (hot keys of an apply; dedup)
     uint32_t* sbig;            // first fp64 partial-sum row of a group with more than kChunk occurrences
     uint32_t* sgrp;            // index of the group in the unique list (standalone dedup)
-    long long* sres;           // apply: epoch-tagged head of a key's spliced position list; lent out as a per-position slot list by insert / remove
+    long long* sres;           // lent out as a per-position slot list by insert / remove
+    uint32_t* inl;             // apply: 16 batch positions per entry (one 64-byte line): [0..7] the claiming block's occurrences of ranks 1..8,
+                               // [8..15] the first 8 occurrences other blocks added — a group that fits is finished by its leader from this one line
     uint64_t smask;
 };
 __device__ __forceinline__ uint32_t* sv_half(const GroupTable& g, uint32_t h) { return reinterpret_cast<uint32_t*>(g.ent + 2 * (uint64_t)h + 1); }   // [0] = lo, [1] = hi
@@ -67,6 +70,7 @@ __device__ __forceinline__ void group_release_entry(const GroupTable& g, uint32_
 }
 struct BatchScratch {          // max_batch entries, indexed by batch position unless noted
     uint32_t *hidx, *rank, *pcnt, *occ, *uniq_h, *work;
+    uint32_t *lead_bits, *filed_bits;   // apply: one bit per batch position (leader of an inline group | occurrence of a filed group); all-zero between applies
     uint8_t* fmask;            // found mask of find_or_insert's first pass when the caller passes none
     uint32_t* bigh;            // [max_big] group-table index of each big group
     double* gacc;              // [max_part][dim] fp64 partial-sum rows: one per chunk of a big group, a group's rows contiguous
@@ -101,7 +105,7 @@ struct mee_table {
     // a prepared (grouped + planned) apply waiting for its grads: mee_apply_prepare .. mee_apply_*
     uint64_t prepared_n;
     const int64_t* prepared_keys;
-    uint32_t epoch;             // batch number of the apply path's group_kernel launches (tags the list heads in sres; never 0)
+    uint32_t epoch;             // batch number of insert / apply launches (tags insert's election flag; never 0)
     // performance knobs (never change results): see mee_set_tuning()
     int find_rounds;            // keys in flight per tile in the find kernel: 1, 2, 4 or 8
     int find_grid_cap;          // max blocks of the find grid (0 = one pass, no grid-stride loop)
@@ -533,21 +537,24 @@ constexpr int kGroupLast = 0;   // max(lo, hi) = 1 + highest batch position of t
 constexpr int kGroupCount = 1;  // lo + hi = occurrence count, rank[i] = arrival order (finalised by the plan pass)
 constexpr int kGroupApply = 2;  // kGroupCount + every key's occurrences chained into lists (the apply path; see group_kernel)
 constexpr uint32_t kRankRemote = 0x80000000u;  // rank was handed out by an atomic on lo: add hi to finalise
-constexpr uint32_t kChunk = 32;                // occurrences summed by one tile; a key with more in one batch is a "hot" key
-constexpr uint32_t kHotMark = 0x80000000u;     // epoch tags: pcnt[i] = kHotMark | epoch marks position i as a hot key's occurrence of batch `epoch`
+#ifndef MEE_KCHUNK
+#define MEE_KCHUNK 32
+#endif
+constexpr uint32_t kChunk = MEE_KCHUNK;        // occurrences summed by one tile; a key with more in one batch is a "hot" key
+constexpr uint32_t kInl = 8;                    // positions per half of an entry's inline list (see GroupTable::inl)
+constexpr uint32_t kEpochWrap = (1u << 31) - 16;   // batch numbers (mee_table::epoch) start over here
 constexpr int kLds = 512;       // block-local aggregation table (256 threads -> at most 256 distinct keys)
 
 // One lane per batch position.  Occurrences of the same key inside a 256-thread block are first combined in an
 // LDS hash table keyed by the key itself; ONE lane per (block, key) then talks to the global group table.  A hot key
 // that is 8 % of the batch costs ~n/256 global accesses instead of 0.08 n serialised on one L2 line, and the block
 // whose CAS claimed the entry needs no counting atomic at all.
-// kGroupApply additionally chains the positions of every key, forward: inside a block every arrival is appended behind the previous
-// one through LDS (next pointer of position i in bs.uniq_h[i]), so a block's chain starts at its first arrival.  The chain of the
-// block that claimed the entry starts at the key's rank-0 occurrence — the group's leader, which therefore needs no head pointer;
-// every other block splices its chain in front of a second list whose head lives in sres[h] (atomicExch; tagged with the batch
-// `epoch`, so a stale head of an earlier batch reads as empty).  The claimer's chain has `hi` entries and the spliced list `lo` (the
-// two halves of the count word): neither needs a terminator.  A key that occurs once costs no atomic beyond its claim and no store
-// beyond its count.
+// kGroupApply additionally leaves every duplicate occurrence where the key's leader (the rank-0 occurrence: local rank 0 in the block
+// whose CAS claimed the entry) finds it with ONE 64-byte load: the claiming block's occurrences of local rank 1..kInl store their
+// position in inl[h][rank - 1], occurrences of other blocks with arrival number q < kInl (the atomicAdd on `lo` hands those out) in
+// inl[h][kInl + q].  A group with hi <= kInl + 1 and lo <= kInl therefore sits complete in its entry's line (no pointer chasing, no
+// terminators, stale words of earlier batches lie beyond the counts and are never read); larger groups are finished through their
+// ranks by the filing kernels.  A key that occurs once costs no atomic beyond its claim and no store beyond its count.
 template <int MODE>
 __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ keys, uint32_t n, GroupTable g, BatchScratch bs,
                                                     Counters* ctr, const uint8_t* __restrict__ skip, OpCounters* op_to_zero = nullptr,
@@ -557,8 +564,7 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
     if (op_to_zero && blockIdx.x == 0 && threadIdx.x < sizeof(OpCounters) / 4) reinterpret_cast<uint32_t*>(op_to_zero)[threadIdx.x] = 0u;
     __shared__ unsigned long long lkey[kLds];
     __shared__ uint32_t lval[kLds], lh[kLds], lbase[kLds];
-    __shared__ uint32_t lhead[MODE == kGroupApply ? kLds : 1], ltail[MODE == kGroupApply ? kLds : 1], lhr[MODE == kGroupApply ? kLds : 1];
-    for (int j = threadIdx.x; j < kLds; j += 256) { lkey[j] = 0; lval[j] = 0; if (MODE == kGroupApply) ltail[j] = 0; }
+    for (int j = threadIdx.x; j < kLds; j += 256) { lkey[j] = 0; lval[j] = 0; }
     __syncthreads();
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool inb = i < n;
@@ -578,11 +584,6 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
         }
         if (MODE == kGroupCount || MODE == kGroupApply) r_local = atomicAdd(&lval[slot], 1u);
         else atomicMax(&lval[slot], i + 1);
-        if constexpr (MODE == kGroupApply) {
-            const uint32_t lprev = atomicExch(&ltail[slot], i + 1);   // append behind the block's latest arrival
-            if (lprev != 0) bs.uniq_h[lprev - 1] = i + 1;             // its next pointer
-            else { lhead[slot] = i + 1; lhr[slot] = r_local; }        // the block's first arrival heads the chain (and will take local rank 0)
-        }
     }
     __syncthreads();
     if (inserter) {
@@ -593,17 +594,6 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
             const uint32_t total = lval[slot];
             if (claimed) { sv_half(g, h)[1] = total; lbase[slot] = 0; }
             else lbase[slot] = atomicAdd(&sv_half(g, h)[0], total) | kRankRemote;
-            if constexpr (MODE == kGroupApply) {
-                // (the claimer's chain starts at the rank-0 occurrence: nothing to store.)  Another block splices its chain onto the key's
-                // second list — unless the others' count it has just seen already makes the key a hot one (> kChunk occurrences): hot keys are
-                // finished through ranks, not lists, and skipping the splice spares their entry one same-address atomic per block.  A key that
-                // ends with <= kChunk occurrences had every block pass this test (the count only grows), so its list is complete.
-                if (!claimed && (lbase[slot] & ~kRankRemote) + total <= kChunk) {
-                    // the tag is epoch | kHotMark: sres is also lent out as a per-position slot list (insert, remove), whose values never carry it
-                    const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long*>(&g.sres[h]), ((unsigned long long)(epoch | kHotMark) << 32) | lhead[slot]);
-                    bs.uniq_h[ltail[slot] - 1] = (uint32_t)(old >> 32) == (epoch | kHotMark) ? (uint32_t)old : 0u;   // this block's last arrival -> the list so far
-                }
-            }
         } else {
             // the block whose CAS created the entry parks its candidate in the hi half with a plain store; only later arrivals
             // pay an atomic.  Readers take max(lo, hi).  (Unique keys: one atomic per key instead of two.)
@@ -614,11 +604,14 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
     __syncthreads();
     if (inb) {
         bs.hidx[i] = valid ? lh[slot] : kNoGroup;
-        if constexpr (MODE == kGroupApply) {
-            // the chain's head takes local rank 0 (the two atomics above order the block's arrivals independently): swap with whoever drew it
-            if (valid) r_local = i + 1 == lhead[slot] ? 0u : (r_local == 0 ? lhr[slot] : r_local);
-        }
         if ((MODE == kGroupCount || MODE == kGroupApply) && valid) bs.rank[i] = lbase[slot] + r_local;
+        if constexpr (MODE == kGroupApply) {
+            if (valid) {
+                const uint32_t lb = lbase[slot];
+                const uint32_t q = (lb & kRankRemote) ? kInl + (lb & ~kRankRemote) + r_local : r_local - 1;   // rank 0 of the claimer: 0xFFFFFFFF, no store
+                if (q < ((lb & kRankRemote) ? 2 * kInl : kInl)) g.inl[(uint64_t)lh[slot] * (2 * kInl) + q] = i;
+            }
+        }
         if (!valid && !skipped && key == kReclaimed) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);  // EMPTY = padding, silent
     }
 }
@@ -1111,12 +1104,14 @@ __global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __rest
 __device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, const uint32_t* __restrict__ occ, uint32_t first,
                                           uint32_t count, uint32_t dim4, uint32_t c, double& sx, double& sy, double& sz,
                                           double& sw, const uint32_t* __restrict__ gidx = nullptr, uint32_t grad_rows = 0) {
-    uint32_t o = 0;
-    for (; o + 8 <= count; o += 8) {
+    // eight rows in flight per step.  The last (or only) step has no one-row-at-a-time tail: it reads the chunk's last row again in
+    // the lanes past the end (a valid address, so the loads stay unconditional and leave together) and adds +0.0 for them — a group
+    // of three occurrences costs one round trip for its grad rows, not three.  (The sums start at +0.0: adding +0.0 changes nothing.)
+    for (uint32_t o = 0; o < count; o += 8) {
         uint32_t idx[8];
         float4 gq[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) idx[q] = occ[first + o + q];
+        for (int q = 0; q < 8; ++q) idx[q] = occ[first + min(o + q, count - 1)];
         if (gidx) {  // indexed apply: position -> row of the grad array (e.g. the bag of a pooled lookup)
 #pragma unroll
             for (int q = 0; q < 8; ++q) idx[q] = min(gidx[idx[q]], grad_rows - 1);
@@ -1124,12 +1119,10 @@ __device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, cons
 #pragma unroll
         for (int q = 0; q < 8; ++q) gq[q] = grads[(uint64_t)idx[q] * dim4 + c];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { sx += (double)gq[q].x; sy += (double)gq[q].y; sz += (double)gq[q].z; sw += (double)gq[q].w; }
-    }
-    for (; o < count; ++o) {
-        const uint32_t p = occ[first + o];
-        const float4 gg = grads[(uint64_t)(gidx ? min(gidx[p], grad_rows - 1) : p) * dim4 + c];
-        sx += (double)gg.x; sy += (double)gg.y; sz += (double)gg.z; sw += (double)gg.w;
+        for (int q = 0; q < 8; ++q) {
+            const bool live = o + q < count;
+            sx += live ? (double)gq[q].x : 0.0; sy += live ? (double)gq[q].y : 0.0; sz += live ? (double)gq[q].z : 0.0; sw += live ? (double)gq[q].w : 0.0;
+        }
     }
 }
 
@@ -1137,12 +1130,13 @@ __device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, cons
 // Runs right behind group_kernel<kGroupApply> and needs nothing but what that kernel left: a position reads its key's occurrence
 // count from its entry (one 8-byte load) and then
 //   count == 1            (the bulk):  the tile updates the row from the position's own grad row and releases the entry;
-//   2 <= count <= kChunk  (duplicates of ordinary keys): the occurrence that heads the claiming block's chain is the group's leader:
-//                         its tile walks the key's two position lists (complete: they were built by the previous kernel), sums the
-//                         grad rows in fp64, updates once, releases.  The other occurrences do nothing.
-//   count > kChunk        (hot keys): every occurrence finalises its rank; the leader reserves the group's slice of the occurrence
-//                         list and its fp64 partial-sum rows — three small kernels finish these groups afterwards.
-// No plan pass, no per-batch prefix sums, no atomics on the bulk path; a batch without hot keys is finished when this kernel ends.
+//   a group that fits its entry's inline list (hi <= kInl + 1, lo <= kInl: up to 17 occurrences): the rank-0 occurrence is the
+//                         group's leader and is only marked (a bit); the other occurrences do nothing.  apply_dups_kernel finishes
+//                         the group — a tile that led a group here would keep the three single-key tiles of its wave waiting through
+//                         four more dependent round trips, and its fp64 sums would cost every wave of this pass a quarter of its registers.
+//   larger groups         every occurrence finalises its rank and marks itself; the leader reserves the group's slice of the occurrence
+//                         list, one work item per kChunk occurrences and, beyond kChunk occurrences, fp64 partial-sum rows.
+// No plan pass, no per-batch prefix sums, no atomics on the bulk path; three small kernels finish the duplicates afterwards.
 // R positions in flight per tile; the grad rows of single keys are requested before the probe.  LOCATED: `slots` holds each
 // position's slot (or -1) as mee_find_located of the same step saw it — no probe, no bucket line.
 template <int KIND, int DIM4, int R, bool LOCATED>
@@ -1150,10 +1144,8 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
                                                          uint64_t nb, uint32_t dim4_rt, const int64_t* __restrict__ keys,
                                                          const int64_t* __restrict__ slots, const float4* __restrict__ grads,
                                                          uint32_t n, GroupTable g, BatchScratch bs, OpCounters* op, OptArgs a,
-                                                         const uint32_t* __restrict__ gidx, uint64_t capacity, uint32_t epoch) {
-    __shared__ uint32_t lpos[16][kChunk];   // the list a tile has walked (one row per tile of the block)
+                                                         const uint32_t* __restrict__ gidx, uint64_t capacity) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const int bt = (threadIdx.x >> 6) * 4 + tile;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
@@ -1161,8 +1153,8 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
     a.kind = KIND;  // lets the compiler drop the other optimizer's code
     for (uint32_t base = wave * 4 * R; base < n; base += n_waves * 4 * R) {
         int64_t key[R], slot[R];
-        uint32_t h[R], cnt[R], grow[R];
-        bool single[R], last[R];
+        uint32_t h[R], cnt[R], chi[R], grow[R];
+        bool single[R], fits[R];
         float4 gr[R][C];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -1178,6 +1170,8 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
             uint32_t lo = 0, hi = 0;
             if (h[r] != kNoGroup) sv_load(g, h[r], lo, hi);
             cnt[r] = lo + hi;
+            chi[r] = hi;
+            fits[r] = hi <= kInl + 1 && lo <= kInl;   // the whole group sits in the entry's inline list
             single[r] = cnt[r] == 1;
             if (gidx && single[r]) grow[r] = min(gidx[base + r * 4 + tile], a.grad_rows - 1);
         }
@@ -1191,41 +1185,53 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
                         gr[r][c] = make_float4(gv.x, gv.y, gv.z, gv.w);
                     }
         }
-        // duplicates (one lane per tile decides): leader of a small group -> this tile finishes it below; hot keys -> rank + reservation
+        // duplicates (one lane per tile acts): the leader of an inline group is marked; larger groups -> rank, mark, reservation.
+        // The marks are bits (one per batch position, two maps): a wave's four positions share a word, so ONE atomicOr per wave and map
+        // sets them — the 32 KB of a 256K-key batch's maps are all apply_dups_kernel reads to find its work (and it clears them as it goes).
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t i = base + r * 4 + tile;
-            uint32_t lf = 0;
-            if (tl == 0 && i < n) {
-                if (cnt[r] > 1) {
-                    const uint32_t rk = bs.rank[i];
-                    const bool leader = rk == 0;   // first arrival in the claiming block (ranks of other blocks carry kRankRemote): one per group
-                    if (cnt[r] <= kChunk) lf = leader;
-                    else {
-                        uint32_t lo, hi;
-                        sv_load(g, h[r], lo, hi);
-                        bs.rank[i] = (rk & ~kRankRemote) + ((rk & kRankRemote) ? hi : 0);   // arrival order over the whole batch
-                        bs.pcnt[i] = kHotMark | epoch;   // marks the position for apply_file_kernel (stale marks carry other epochs; counts
-                                                         // other paths leave in pcnt never have the top bit: max_batch <= 2^30)
-                        if (leader) {   // at most n / (kChunk + 1) such groups per batch
-                            const uint32_t rows = (cnt[r] + kChunk - 1) / kChunk;
-                            g.soffs[h[r]] = atomicAdd(&op->n_occ, cnt[r]);
-                            uint32_t p0 = atomicAdd(&op->n_part, rows);   // sum of ceil(cnt / kChunk) <= n / kChunk + n / (kChunk + 1) = max_part: fits
-                            if (p0 + rows > bs.max_part) p0 = 0;          // (only keeps a violated invariant from writing out of bounds)
+            bool lead = false, filed = false;
+            if (tl == 0 && i < n && cnt[r] > 1) {
+                const uint32_t rk = bs.rank[i];
+                const bool leader = rk == 0;   // local rank 0 in the claiming block (ranks of other blocks carry kRankRemote): one per group
+                if (fits[r]) lead = leader;
+                else {
+                    filed = true;
+                    bs.rank[i] = (rk & ~kRankRemote) + ((rk & kRankRemote) ? chi[r] : 0);   // arrival order over the whole batch
+                    if (leader) {   // at most n / (kInl + 1) such groups per batch
+                        const uint32_t rows = (cnt[r] + kChunk - 1) / kChunk;
+                        // ONE atomic reserves the slice of the occurrence list (low half) and the work items (high half): the counters of
+                        // a batch with thousands of such groups are one hot line, and every atomic on it is served in turn
+                        const unsigned long long ow = atomicAdd(&op->occ_work, ((unsigned long long)rows << 32) | cnt[r]);
+                        g.soffs[h[r]] = (uint32_t)ow;
+                        uint32_t w0 = (uint32_t)(ow >> 32);           // rows <= cnt: the work items of a batch add up to at most n
+                        if (w0 + rows > n) w0 = 0;                    // (only keeps a violated invariant from writing out of bounds)
+                        g.sgrp[h[r]] = w0;
+                        for (uint32_t c = 0; c < rows; ++c) bs.work[w0 + c] = h[r];   // work item -> its group
+                        if (cnt[r] > kChunk) {   // more than one chunk: fp64 partial-sum rows + a place in apply_big_kernel's list
+                            uint32_t p0 = atomicAdd(&op->n_part, rows);   // sum of ceil(cnt / kChunk) over such groups <= n / kChunk + n / (kChunk + 1) = max_part: fits
+                            if (p0 + rows > bs.max_part) p0 = 0;
                             g.sbig[h[r]] = p0;
                             bs.bigh[atomicAdd(&op->n_big, 1u)] = h[r];
-                            for (uint32_t c = 0; c < rows; ++c) bs.work[p0 + c] = h[r];   // partial row -> its group
                         }
                     }
                 }
             }
-            last[r] = __shfl(lf, tile * kW) != 0;
+            const uint64_t lm = __ballot(lead), fm = __ballot(filed);   // bits 0, 16, 32, 48: the wave's four tiles
+            if ((lm | fm) && lane == 0) {
+                const uint32_t p0 = base + r * 4, sh = p0 & 31;   // p0 is a multiple of 4: the four bits stay inside one word
+                const uint32_t lbits = (uint32_t)(lm & 1) | (uint32_t)((lm >> 16) & 1) << 1 | (uint32_t)((lm >> 32) & 1) << 2 | (uint32_t)((lm >> 48) & 1) << 3;
+                const uint32_t fbits = (uint32_t)(fm & 1) | (uint32_t)((fm >> 16) & 1) << 1 | (uint32_t)((fm >> 32) & 1) << 2 | (uint32_t)((fm >> 48) & 1) << 3;
+                if (lbits) atomicOr(&bs.lead_bits[p0 >> 5], lbits << sh);
+                if (fbits) atomicOr(&bs.filed_bits[p0 >> 5], fbits << sh);
+            }
         }
         if constexpr (!LOCATED) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 bool is_new, full;
-                slot[r] = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key[r], single[r] || last[r], tile, tl, is_new, full);
+                slot[r] = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key[r], single[r], tile, tl, is_new, full);
             }
         }
 #pragma unroll
@@ -1241,36 +1247,90 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
                     }
                 }
                 if (tl == 0) group_release(g, h[r]);  // this tile is the only user of the entry
-            } else if (last[r]) {   // this tile leads a small group: walk the claiming block's chain (hi entries), then the other blocks' list (lo)
-                uint32_t lo, hi, k = 0;
-                sv_load(g, h[r], lo, hi);
-                const unsigned long long others = (unsigned long long)g.sres[h[r]];
-                uint32_t p = base + r * 4 + tile + 1;   // this position heads the claiming block's chain
-                for (uint32_t e = 0; e < hi && p && k < kChunk; ++e) { if (tl == 0) lpos[bt][k] = p - 1; ++k; p = bs.uniq_h[p - 1]; }
-                p = (lo && (uint32_t)(others >> 32) == (epoch | kHotMark)) ? (uint32_t)others : 0u;
-                for (uint32_t e = 0; e < lo && p && k < kChunk; ++e) { if (tl == 0) lpos[bt][k] = p - 1; ++k; p = bs.uniq_h[p - 1]; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // lane 0's LDS writes before the tile's reads (same wave: in order)
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                if (ok)
-                    for (uint32_t c = tl; c < dim4; c += 16) {
-                        double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-                        chunk_sum(grads, lpos[bt], 0, k, dim4, c, sx, sy, sz, sw, gidx, a.grad_rows);
-                        update_row(a, values, s1, s2, (uint64_t)slot[r] * dim4 + c, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
-                    }
-                if (tl == 0) group_release(g, h[r]);
             }
         }
     }
 }
 
-// hot keys (count > kChunk), after the main pass: every occurrence files its position at its rank in its group's list slice
-__global__ __launch_bounds__(256) void apply_file_kernel(uint32_t n, GroupTable g, BatchScratch bs, const OpCounters* op, uint32_t epoch) {
-    if (op->n_big == 0) return;   // no hot key in this batch
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        if (bs.pcnt[i] == (kHotMark | epoch)) {
-            const uint32_t at = g.soffs[bs.hidx[i]] + bs.rank[i];
+// Duplicates, first kernel after the main pass; one lane per batch position reads the position's two mark bits (and the wave clears
+// the words it has read: the maps are all-zero again when this kernel ends).
+//   filed: an occurrence of a filed group stores its position at its rank in the group's slice of the occurrence list;
+//   lead:  the leader of a group that sits in its entry's inline list: a tile (the wave's four tiles take the wave's
+//                      leaders four at a time) reads the other positions with ONE 64-byte load, sums the grad rows in fp64, locates the
+//                      row (or takes the forward's slot), updates once and releases the entry.
+__global__ __launch_bounds__(256) void apply_dups_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1, float4* s2, uint64_t nb,
+                                                         uint32_t dim4, const int64_t* __restrict__ keys, const int64_t* __restrict__ slots,
+                                                         const float4* __restrict__ grads, uint32_t n, GroupTable g, BatchScratch bs,
+                                                         const OpCounters* op, OptArgs a, const uint32_t* __restrict__ gidx, uint64_t capacity) {
+    __shared__ uint32_t lpos[16][2 * kInl + 2];   // the positions of the group a tile finishes (one row per tile of the block)
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
+    const int bt = (threadIdx.x >> 6) * 4 + tile;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t base = wave * 64; base < n; base += n_waves * 64) {   // wave-uniform
+        const uint32_t i = base + lane, word = (base >> 5) + (lane >> 5);   // base is a multiple of 64: two words of each map per wave
+        const bool in_map = (uint64_t)word * 32 < n;
+        const uint32_t fw = in_map ? bs.filed_bits[word] : 0u, lw = in_map ? bs.lead_bits[word] : 0u;
+        if ((lane & 31) == 0) {
+            if (fw) bs.filed_bits[word] = 0u;
+            if (lw) bs.lead_bits[word] = 0u;
+        }
+        const bool is_filed = (fw >> (lane & 31)) & 1u, is_lead = (lw >> (lane & 31)) & 1u;
+        // everything a marked position needs that does not depend on its entry, requested now, one coalesced load per array
+        const uint32_t my_h = (is_filed || is_lead) ? bs.hidx[i] : 0u;
+        const uint32_t my_rank = is_filed ? bs.rank[i] : 0u;
+        const int64_t my_key = is_lead ? (slots ? slots[i] : keys[i]) : kEmpty;   // the forward's slot when the caller passed them
+        if (is_filed) {
+            const uint32_t at = g.soffs[my_h] + my_rank;
             if (at < n) bs.occ[at] = i;   // always true (the slices add up to at most n); a violated invariant must not write out of bounds
         }
+        uint64_t leads = __ballot(is_lead);
+        while (leads) {   // wave-uniform: tile t takes the t-th leader still waiting
+            uint64_t m = leads;
+            int src = -1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = m ? __builtin_ctzll(m) : -1;
+                if (q == tile) src = b;
+                if (m) m &= m - 1;
+            }
+            leads = m;
+            const bool act = src >= 0;
+            const uint32_t p = base + (uint32_t)(act ? src : 0);
+            const uint32_t h = __shfl(my_h, act ? src : 0);
+            const int64_t ks = (int64_t)(((unsigned long long)(uint32_t)__shfl((int)((unsigned long long)my_key >> 32), act ? src : 0) << 32) |
+                                         (uint32_t)__shfl((int)(uint32_t)my_key, act ? src : 0));
+            uint32_t lo = 0, hi = 0;
+            if (act) sv_load(g, h, lo, hi);
+            const uint32_t other = act ? g.inl[(uint64_t)h * (2 * kInl) + tl] : 0u;   // one 64-byte line for the tile
+            int64_t slot;
+            if (slots) slot = (act && (uint64_t)ks < capacity) ? ks : -1;   // a handle is the caller's data: never index past the planes
+            else {
+                bool is_new, full;
+                slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, act ? ks : kEmpty, act, tile, tl, is_new, full);
+            }
+            if (act) {
+                if (tl == 0) lpos[bt][0] = p;   // the leader's own position, then the claiming block's others, then the other blocks'
+                if (tl < (int)kInl ? (uint32_t)tl + 1 < hi : (uint32_t)tl - kInl < lo) lpos[bt][tl < (int)kInl ? 1 + tl : hi + (tl - kInl)] = other;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the tile's LDS writes before its reads (same wave: in order)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (act) {
+                if (slot >= 0)
+                    for (uint32_t c = tl; c < dim4; c += 16) {
+                        const uint64_t o = (uint64_t)slot * dim4 + c;   // the row is requested before the grad rows, not after their sum
+                        float4 w = values[o], x1 = s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (a.kind == MEE_OPT_ADAM) x2 = s2[o];
+                        double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+                        chunk_sum(grads, lpos[bt], 0, lo + hi, dim4, c, sx, sy, sz, sw, gidx, a.grad_rows);
+                        opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
+                        values[o] = w; s1[o] = x1;
+                        if (a.kind == MEE_OPT_ADAM) s2[o] = x2;
+                    }
+                if (tl == 0) group_release(g, h);
+            }
+        }
+    }
 }
 
 // Pass 2 over the work list (chunk leaders: the occurrences with rank 0, kChunk, 2*kChunk, ... of each multi-key).
@@ -1317,28 +1377,42 @@ __global__ __launch_bounds__(256) void apply_chunk_kernel(const int64_t* __restr
     }
 }
 
-// hot keys, second kernel: one tile per fp64 partial-sum row p (= one chunk of kChunk occurrences of one hot key): work[p] names the
-// group, the chunk index is p - sbig[group]; plain stores of the chunk's sums (f64 atomics on a hot key's row would serialise).
-__global__ __launch_bounds__(256) void apply_bigchunk_kernel(uint32_t dim4, const float4* __restrict__ grads, GroupTable g, BatchScratch bs,
-                                                             const OpCounters* op, const uint32_t* __restrict__ gidx, uint32_t grad_rows) {
+// filed groups, second kernel: one tile per work item w (= one chunk of kChunk occurrences of one group): work[w] names the group, the
+// chunk index is w - sgrp[group].  A group of one chunk is finished here (locate the key's row, one update, entry released); a chunk
+// of a larger group stores its fp64 sums as one row of the group's partial-sum block (plain stores: f64 atomics on a hot key's row
+// would serialise) and apply_big_kernel finishes the group.
+__global__ __launch_bounds__(256) void apply_filed_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1, float4* s2, uint64_t nb,
+                                                          uint32_t dim4, const float4* __restrict__ grads, uint32_t n, GroupTable g, BatchScratch bs,
+                                                          const OpCounters* op, OptArgs a, const uint32_t* __restrict__ gidx) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t n_part = min(op->n_part, bs.max_part);
-    for (uint32_t base = wave * 4; base < n_part; base += n_waves * 4) {
-        const uint32_t p = base + tile;
-        if (p >= n_part) continue;
-        const uint32_t h = bs.work[p];
-        uint32_t lo, hi;
-        sv_load(g, h, lo, hi);
-        const uint32_t cnt = lo + hi, c_idx = p - g.sbig[h];
+    const uint32_t n_work = min((uint32_t)(op->occ_work >> 32), n);
+    for (uint32_t base = wave * 4; base < n_work; base += n_waves * 4) {   // wave-uniform trip count
+        const uint32_t w = base + tile;
+        const bool inb = w < n_work;
+        const uint32_t h = inb ? bs.work[w] : 0;
+        uint32_t lo = 0, hi = 0;
+        if (inb) sv_load(g, h, lo, hi);
+        const uint32_t cnt = lo + hi;
+        const bool whole = inb && cnt <= kChunk;   // the group's only chunk
+        const int64_t key = whole ? (int64_t)(g.ent[2 * (uint64_t)h] ^ kBias) : kEmpty;
+        bool is_new, full;
+        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, whole, tile, tl, is_new, full);
+        if (!inb) continue;
+        const uint32_t c_idx = w - g.sgrp[h];
         const uint32_t first = g.soffs[h] + c_idx * kChunk, count = min(kChunk, cnt - c_idx * kChunk);
         for (uint32_t c = tl; c < dim4; c += 16) {
             double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-            chunk_sum(grads, bs.occ, first, count, dim4, c, sx, sy, sz, sw, gidx, grad_rows);
-            double* dst = bs.gacc + ((uint64_t)p * dim4 + c) * 4;
-            dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = sw;
+            chunk_sum(grads, bs.occ, first, count, dim4, c, sx, sy, sz, sw, gidx, a.grad_rows);
+            if (whole) {
+                if (slot >= 0) update_row(a, values, s1, s2, (uint64_t)slot * dim4 + c, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
+            } else {
+                double* dst = bs.gacc + ((uint64_t)(g.sbig[h] + c_idx) * dim4 + c) * 4;
+                dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = sw;
+            }
         }
+        if (whole && tl == 0) group_release(g, h);
     }
 }
 
@@ -1658,6 +1732,10 @@ static uint64_t next_prime(uint64_t n) {
 }
 
 // `needs_group_table`: the op would overwrite the group table, which a pending mee_apply_prepare still owns
+// the next batch number (insert's election flag carries it: a flag left by an earlier batch reads as "not raised")
+static void next_epoch(mee_table* t, hipStream_t) {
+    if (++t->epoch >= kEpochWrap) t->epoch = 1;
+}
 static int check_batch(const mee_table* t, size_t n, const char* op, bool needs_group_table = true) {
     if (t->prepared_n && needs_group_table)
         return fail(MEE_ERR_INVALID_ARG, "%s: a prepared apply is pending on this table (finish it with mee_apply_* or mee_apply_discard)", op);
@@ -1682,8 +1760,8 @@ int mee_table_destroy(mee_table* t) {
     float* planes[] = {t->values, t->s1, t->s2};
     for (float* p : planes)
         if (p) { if (t->value_memory == MEE_MEM_HOST_PINNED) (void)hipHostFree(p); else (void)hipFree(p); }
-    void* dev[] = {t->keys, t->hits, t->sketch, t->g.ent, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
-                   t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.work, t->bs.fmask, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
+    void* dev[] = {t->keys, t->hits, t->sketch, t->g.ent, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres, t->g.inl,
+                   t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.lead_bits, t->bs.filed_bits, t->bs.work, t->bs.fmask, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (t->h_ctr) (void)hipHostFree(t->h_ctr);
     if (t->h_op) (void)hipHostFree(t->h_op);
@@ -1772,8 +1850,9 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     if (t->optimizer == MEE_OPT_ADAM) ALLOC_PLANE(t->s2);
 #undef ALLOC_PLANE
     ALLOC(t->g.ent, S * 16); ALLOC(t->g.soffs, S * 4); ALLOC(t->g.sgrp, S * 4);
-    ALLOC(t->g.sbig, S * 4); ALLOC(t->g.sres, S * 8);
+    ALLOC(t->g.sbig, S * 4); ALLOC(t->g.sres, S * 8); ALLOC(t->g.inl, S * 2 * kInl * 4);
     ALLOC(t->bs.hidx, mb * 4); ALLOC(t->bs.rank, mb * 4); ALLOC(t->bs.pcnt, mb * 4); ALLOC(t->bs.occ, mb * 4); ALLOC(t->bs.uniq_h, mb * 4);
+    ALLOC(t->bs.lead_bits, (mb / 32 + 2) * 4); ALLOC(t->bs.filed_bits, (mb / 32 + 2) * 4);
     ALLOC(t->bs.work, mb * 4); ALLOC(t->bs.fmask, mb);
     t->max_big = mb / kChunk + 1;  // a batch of n keys has at most n / (kChunk + 1) groups larger than kChunk
     // ... and those groups need ceil(cnt / kChunk) partial-sum rows each: at most n / kChunk + n / (kChunk + 1) rows in all
@@ -1783,7 +1862,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     if (t->optimizer != MEE_OPT_NONE) ALLOC(t->bs.gacc, t->max_part * (uint64_t)t->dim * sizeof(double));
     ALLOC(t->ctr, sizeof(Counters)); ALLOC(t->op, sizeof(OpCounters));
 #undef ALLOC
-    t->workspace_bytes = S * 36 + mb * 25 + t->max_big * 4 + (t->bs.gacc ? t->max_part * (uint64_t)t->dim * sizeof(double) : 0) +
+    t->workspace_bytes = S * (36 + 2 * kInl * 4) + mb * 25 + t->max_big * 4 + (t->bs.gacc ? t->max_part * (uint64_t)t->dim * sizeof(double) : 0) +
                          sizeof(Counters) + sizeof(OpCounters);
     if (hipHostMalloc((void**)&t->h_ctr, sizeof(Counters)) != hipSuccess || hipHostMalloc((void**)&t->h_op, sizeof(OpCounters)) != hipSuccess) {
         rc = fail(MEE_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
@@ -1796,8 +1875,9 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
         if (e == hipSuccess && t->hits) e = hipMemsetAsync(t->hits, 0, t->capacity * sizeof(uint32_t), 0);
         if (e == hipSuccess && t->sketch) e = hipMemsetAsync(t->sketch, 0, 3ull * sizeof(uint32_t) << t->sketch_log2w, 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.ent, 0, S * 16, 0);
-        if (e == hipSuccess) e = hipMemsetAsync(t->g.sres, 0, S * 8, 0);   // list heads carry an epoch tag; epoch 0 is never used
-        if (e == hipSuccess) e = hipMemsetAsync(t->bs.pcnt, 0, mb * 4, 0);  // so do the hot-key marks
+        if (e == hipSuccess) e = hipMemsetAsync(t->g.sres, 0, S * 8, 0);
+        if (e == hipSuccess) e = hipMemsetAsync(t->bs.lead_bits, 0, (mb / 32 + 2) * 4, 0);
+        if (e == hipSuccess) e = hipMemsetAsync(t->bs.filed_bits, 0, (mb / 32 + 2) * 4, 0);
         if (e == hipSuccess && t->bs.gacc) e = hipMemsetAsync(t->bs.gacc, 0, t->max_part * (uint64_t)t->dim * sizeof(double), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->ctr, 0, sizeof(Counters), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->op, 0, sizeof(OpCounters), 0);
@@ -2052,7 +2132,7 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
     if (claim) {   // insert: creators write at once, an election only among positions that found their key present (see insert_direct_kernel)
-        if (++t->epoch >= kHotMark - 16) t->epoch = 1;
+        next_epoch(t, st);
         long long* slotof = t->g.sres;   // S >= 2 * max_batch entries: lent as the per-position slot list (as mee_remove does)
         const unsigned gd = grid_for(n, 32, 1u << 16);
 #define DIRECT(D4) insert_direct_kernel<D4><<<gd, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys, (const float4*)d_values, \
@@ -2093,7 +2173,7 @@ int mee_assign_plane(mee_table* t, uint32_t plane, const int64_t* d_keys, const 
 
 int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream) {
     if (!t || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_remove: null argument");
-    if (int rc = check_batch(t, n, "mee_remove")) return rc;   // lends sres as its slot list: a pending mee_apply_prepare keeps list heads there
+    if (int rc = check_batch(t, n, "mee_remove")) return rc;   // borrows group-table scratch: not while a prepared apply is pending
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -2279,14 +2359,14 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
             return fail(MEE_ERR_INVALID_ARG, "%s: keys/n differ from the pending mee_apply_prepare", name);
         t->prepared_n = 0; t->prepared_keys = nullptr;
     } else {
-        if (++t->epoch >= kHotMark - 16) t->epoch = 1;
+        next_epoch(t, st);
         group_kernel<kGroupApply><<<grid_for(nn, 256, 1u << 22), 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
     }
     {
         const int R = t->apply_rounds > 0 ? t->apply_rounds : 1;   // one position per tile: more waves per SIMD beat more loads per wave here
         const unsigned gs = grid_for(n, 16u * (R >= 2 ? 2u : 1u), 1u << 16);
 #define MAIN(K, D4, RR, LOC) apply_main_kernel<K, D4, RR, LOC><<<gs, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, \
-                                                                                  d_keys, d_slots, (const float4*)d_grads, nn, t->g, t->bs, t->op, a, d_gidx, t->capacity, t->epoch)
+                                                                                  d_keys, d_slots, (const float4*)d_grads, nn, t->g, t->bs, t->op, a, d_gidx, t->capacity)
 #define MAIN_R(K, D4) do { if (d_slots) { if (R >= 2) MAIN(K, D4, 2, true); else MAIN(K, D4, 1, true); } \
                            else { if (R >= 2) MAIN(K, D4, 2, false); else MAIN(K, D4, 1, false); } } while (0)
 #define MAIN_D(K) do { if (t->dim4 == 16) MAIN_R(K, 16); else if (t->dim4 == 32) MAIN_R(K, 32); else MAIN_R(K, 0); } while (0)
@@ -2300,8 +2380,10 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     // Zipf(1.05) batch); the main pass requesting grad rows / bucket lines before a position's count is known (no faster: the pass is
     // bound by bytes, the extra registers cost occupancy); the grouping folded into the forward find (its claim atomics do not overlap
     // with the row traffic: same total).
-    apply_file_kernel<<<grid_for(nn, 256, 256), 256, 0, st>>>(nn, t->g, t->bs, t->op, t->epoch);
-    apply_bigchunk_kernel<<<grid_for(n / kChunk + 1, 16, 512), 256, 0, st>>>(t->dim4, (const float4*)d_grads, t->g, t->bs, t->op, d_gidx, a.grad_rows);
+    apply_dups_kernel<<<grid_for(nn, 256, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys, d_slots,
+                                                             (const float4*)d_grads, nn, t->g, t->bs, t->op, a, d_gidx, t->capacity);
+    apply_filed_kernel<<<grid_for(n / (kInl + 1) + 1, 16, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
+                                                                              (const float4*)d_grads, nn, t->g, t->bs, t->op, a, d_gidx);
     apply_big_kernel<false><<<grid_for(n / kChunk + 1, 1, 256), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,
                                                                       t->dim4, t->g, t->bs, t->op, a);
     MEE_HIP(hipGetLastError());
@@ -2412,7 +2494,7 @@ int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* strea
     if (n > t->max_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_apply_prepare: n=%zu exceeds config.max_batch=%llu", n, (unsigned long long)t->max_batch);
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
-    if (++t->epoch >= kHotMark - 16) t->epoch = 1;
+    next_epoch(t, as_stream(stream));
     group_kernel<kGroupApply><<<grid_for(n, 256, 1u << 22), 256, 0, as_stream(stream)>>>(d_keys, (uint32_t)n, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
     MEE_HIP(hipGetLastError());
     t->prepared_n = n; t->prepared_keys = d_keys;
