@@ -537,13 +537,16 @@ constexpr int kGroupLast = 0;   // max(lo, hi) = 1 + highest batch position of t
 constexpr int kGroupCount = 1;  // lo + hi = occurrence count, rank[i] = arrival order (finalised by the plan pass)
 constexpr int kGroupApply = 2;  // kGroupCount + every key's occurrences chained into lists (the apply path; see group_kernel)
 constexpr uint32_t kRankRemote = 0x80000000u;  // rank was handed out by an atomic on lo: add hi to finalise
+constexpr uint32_t kRankFiled = 0x40000000u;   // apply: the occurrence's own block already saw its group outgrow the inline list (ranks stay below 2^30)
 #ifndef MEE_KCHUNK
 #define MEE_KCHUNK 32
 #endif
 constexpr uint32_t kChunk = MEE_KCHUNK;        // occurrences summed by one tile; a key with more in one batch is a "hot" key
 constexpr uint32_t kInl = 8;                    // positions per half of an entry's inline list (see GroupTable::inl)
+constexpr int kApplyGroupBlock = 1024;         // threads per block of the apply's group_kernel: a hot key costs its entry one atomic per block, so on a skewed
+                                               // batch big blocks win (Zipf(1.05), 256K keys: 33 -> 25 us, and more occurrences learn in their own block that their group is filed);
+                                               // on a batch of distinct keys the size makes no difference (20.9 vs 21.5 us)
 constexpr uint32_t kEpochWrap = (1u << 31) - 16;   // batch numbers (mee_table::epoch) start over here
-constexpr int kLds = 512;       // block-local aggregation table (256 threads -> at most 256 distinct keys)
 
 // One lane per batch position.  Occurrences of the same key inside a 256-thread block are first combined in an
 // LDS hash table keyed by the key itself; ONE lane per (block, key) then talks to the global group table.  A hot key
@@ -555,18 +558,21 @@ constexpr int kLds = 512;       // block-local aggregation table (256 threads ->
 // inl[h][kInl + q].  A group with hi <= kInl + 1 and lo <= kInl therefore sits complete in its entry's line (no pointer chasing, no
 // terminators, stale words of earlier batches lie beyond the counts and are never read); larger groups are finished through their
 // ranks by the filing kernels.  A key that occurs once costs no atomic beyond its claim and no store beyond its count.
-template <int MODE>
-__global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ keys, uint32_t n, GroupTable g, BatchScratch bs,
+template <int MODE, int BLOCK = 256>
+__global__ __launch_bounds__(BLOCK) void group_kernel(const int64_t* __restrict__ keys, uint32_t n, GroupTable g, BatchScratch bs,
                                                     Counters* ctr, const uint8_t* __restrict__ skip, OpCounters* op_to_zero = nullptr,
                                                     uint32_t epoch = 0, const uint32_t* __restrict__ gate = nullptr) {
     if (gate && *gate != epoch) return;   // insert: no position of this batch found its key present -> no election (grid-uniform)
     // the per-op counters are first touched by the kernel AFTER this one (plan pass): zeroing them here saves a launch
     if (op_to_zero && blockIdx.x == 0 && threadIdx.x < sizeof(OpCounters) / 4) reinterpret_cast<uint32_t*>(op_to_zero)[threadIdx.x] = 0u;
+    constexpr int kLds = 2 * BLOCK;   // block-local aggregation table (BLOCK threads -> at most BLOCK distinct keys: half full at worst)
+    constexpr int kLdsShift = BLOCK == 256 ? 55 : BLOCK == 512 ? 54 : 53;
+    static_assert(BLOCK == 256 || BLOCK == 512 || BLOCK == 1024, "group_kernel: block size");
     __shared__ unsigned long long lkey[kLds];
     __shared__ uint32_t lval[kLds], lh[kLds], lbase[kLds];
-    for (int j = threadIdx.x; j < kLds; j += 256) { lkey[j] = 0; lval[j] = 0; }
+    for (int j = threadIdx.x; j < kLds; j += BLOCK) { lkey[j] = 0; lval[j] = 0; }
     __syncthreads();
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const bool inb = i < n;
     const int64_t key = inb ? keys[i] : 0;
     const bool skipped = inb && skip && skip[i];  // position already served by an earlier pass (find_or_insert)
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
     bool inserter = false;
     if (valid) {
         const unsigned long long bk = (unsigned long long)key ^ kBias;
-        slot = (uint32_t)(mix64((uint64_t)key) >> 55);  // 9 bits
+        slot = (uint32_t)(mix64((uint64_t)key) >> kLdsShift);  // log2(kLds) bits
         while (true) {
             const unsigned long long old = atomicCAS(&lkey[slot], 0ull, bk);
             if (old == 0) { inserter = true; break; }
@@ -604,12 +610,22 @@ __global__ __launch_bounds__(256) void group_kernel(const int64_t* __restrict__ 
     __syncthreads();
     if (inb) {
         bs.hidx[i] = valid ? lh[slot] : kNoGroup;
-        if ((MODE == kGroupCount || MODE == kGroupApply) && valid) bs.rank[i] = lbase[slot] + r_local;
+        if (MODE == kGroupCount && valid) bs.rank[i] = lbase[slot] + r_local;
         if constexpr (MODE == kGroupApply) {
+            bool sure = false;
             if (valid) {
-                const uint32_t lb = lbase[slot];
+                const uint32_t lb = lbase[slot], total = lval[slot];
                 const uint32_t q = (lb & kRankRemote) ? kInl + (lb & ~kRankRemote) + r_local : r_local - 1;   // rank 0 of the claimer: 0xFFFFFFFF, no store
                 if (q < ((lb & kRankRemote) ? 2 * kInl : kInl)) g.inl[(uint64_t)lh[slot] * (2 * kInl) + q] = i;
+                // this block alone shows that the group outgrows the inline list (the counts only grow): every occurrence here but the
+                // group's leader is marked as filed now, and the main pass will not even read the entry for it
+                sure = ((lb & kRankRemote) ? (lb & ~kRankRemote) + total > kInl : total > kInl + 1) && lb + r_local != 0;
+                bs.rank[i] = (lb + r_local) | (sure ? kRankFiled : 0u);
+            }
+            const uint64_t fm = __ballot(sure);   // the wave's 64 positions are two words of the map, and nobody else writes them in this kernel
+            if ((threadIdx.x & 31) == 0) {
+                const uint32_t bits = (uint32_t)(fm >> (threadIdx.x & 32));
+                if (bits) bs.filed_bits[i >> 5] = bits;
             }
         }
         if (!valid && !skipped && key == kReclaimed) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);  // EMPTY = padding, silent
@@ -1153,7 +1169,7 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
     a.kind = KIND;  // lets the compiler drop the other optimizer's code
     for (uint32_t base = wave * 4 * R; base < n; base += n_waves * 4 * R) {
         int64_t key[R], slot[R];
-        uint32_t h[R], cnt[R], chi[R], grow[R];
+        uint32_t h[R], rk[R], cnt[R], chi[R], grow[R];
         bool single[R], fits[R];
         float4 gr[R][C];
 #pragma unroll
@@ -1161,6 +1177,7 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
             const uint32_t i = base + r * 4 + tile;
             const bool inb = i < n;
             h[r] = inb ? bs.hidx[i] : kNoGroup;
+            rk[r] = inb ? bs.rank[i] : 0u;
             key[r] = (!LOCATED && inb) ? keys[i] : kEmpty;
             slot[r] = (LOCATED && inb) ? slots[i] : -1;
             grow[r] = i;
@@ -1168,6 +1185,7 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             uint32_t lo = 0, hi = 0;
+            if (rk[r] & kRankFiled) h[r] = kNoGroup;   // group_kernel has marked this occurrence as filed already: nothing to do here, not even the entry
             if (h[r] != kNoGroup) sv_load(g, h[r], lo, hi);
             cnt[r] = lo + hi;
             chi[r] = hi;
@@ -1193,12 +1211,10 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
             const uint32_t i = base + r * 4 + tile;
             bool lead = false, filed = false;
             if (tl == 0 && i < n && cnt[r] > 1) {
-                const uint32_t rk = bs.rank[i];
-                const bool leader = rk == 0;   // local rank 0 in the claiming block (ranks of other blocks carry kRankRemote): one per group
+                const bool leader = rk[r] == 0;   // local rank 0 in the claiming block (ranks of other blocks carry kRankRemote): one per group
                 if (fits[r]) lead = leader;
                 else {
-                    filed = true;
-                    bs.rank[i] = (rk & ~kRankRemote) + ((rk & kRankRemote) ? chi[r] : 0);   // arrival order over the whole batch
+                    filed = true;   // (apply_dups_kernel turns the rank into the arrival order over the whole batch)
                     if (leader) {   // at most n / (kInl + 1) such groups per batch
                         const uint32_t rows = (cnt[r] + kChunk - 1) / kChunk;
                         // ONE atomic reserves the slice of the occurrence list (low half) and the work items (high half): the counters of
@@ -1275,13 +1291,16 @@ __global__ __launch_bounds__(256) void apply_dups_kernel(const int64_t* __restri
             if (fw) bs.filed_bits[word] = 0u;
             if (lw) bs.lead_bits[word] = 0u;
         }
+        // everything a marked position needs that does not depend on its entry is requested together with the marks, one coalesced load
+        // per array for the whole wave (4 MB more traffic per 256K positions, one dependent round trip less)
+        const uint32_t my_h = i < n ? bs.hidx[i] : 0u;
+        const uint32_t my_rank = i < n ? bs.rank[i] : 0u;
+        const int64_t my_key = i < n ? (slots ? slots[i] : keys[i]) : kEmpty;   // the forward's slot when the caller passed them
         const bool is_filed = (fw >> (lane & 31)) & 1u, is_lead = (lw >> (lane & 31)) & 1u;
-        // everything a marked position needs that does not depend on its entry, requested now, one coalesced load per array
-        const uint32_t my_h = (is_filed || is_lead) ? bs.hidx[i] : 0u;
-        const uint32_t my_rank = is_filed ? bs.rank[i] : 0u;
-        const int64_t my_key = is_lead ? (slots ? slots[i] : keys[i]) : kEmpty;   // the forward's slot when the caller passed them
-        if (is_filed) {
-            const uint32_t at = g.soffs[my_h] + my_rank;
+        if (is_filed) {   // arrival order over the whole batch: the claiming block's occurrences first, then the others in the order of their atomics
+            uint32_t lo, hi;
+            sv_load(g, my_h, lo, hi);
+            const uint32_t at = g.soffs[my_h] + (my_rank & ~(kRankRemote | kRankFiled)) + ((my_rank & kRankRemote) ? hi : 0u);
             if (at < n) bs.occ[at] = i;   // always true (the slices add up to at most n); a violated invariant must not write out of bounds
         }
         uint64_t leads = __ballot(is_lead);
@@ -1402,11 +1421,41 @@ __global__ __launch_bounds__(256) void apply_filed_kernel(const int64_t* __restr
         if (!inb) continue;
         const uint32_t c_idx = w - g.sgrp[h];
         const uint32_t first = g.soffs[h] + c_idx * kChunk, count = min(kChunk, cnt - c_idx * kChunk);
-        for (uint32_t c = tl; c < dim4; c += 16) {
+        // the chunk's (at most 32) positions: two coalesced loads for the whole tile, handed round by shuffle below — not a dependent
+        // index load in front of every eight grad rows
+        static_assert(kChunk == 32, "apply_filed_kernel: two positions per lane");
+        uint32_t pa = bs.occ[first + min((uint32_t)tl, count - 1)], pb = bs.occ[first + min(16u + (uint32_t)tl, count - 1)];
+        if (gidx) { pa = min(gidx[pa], a.grad_rows - 1); pb = min(gidx[pb], a.grad_rows - 1); }   // indexed apply: position -> row of the grad array
+        for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {   // same trip count in every lane: the shuffles need their source lanes
+            const uint32_t c = c0 + tl;
+            const bool live = c < dim4;
+            const uint64_t o_row = whole && slot >= 0 && live ? (uint64_t)slot * dim4 + c : 0;
+            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f), x1 = wv, x2 = wv;
+            if (whole && slot >= 0 && live) {   // the row is requested before the grad rows, not after their sum
+                wv = values[o_row]; x1 = s1[o_row];
+                if (a.kind == MEE_OPT_ADAM) x2 = s2[o_row];
+            }
             double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-            chunk_sum(grads, bs.occ, first, count, dim4, c, sx, sy, sz, sw, gidx, a.grad_rows);
+            for (uint32_t o = 0; o < count; o += 8) {
+                float4 gq[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t row = __shfl(o < 16 ? pa : pb, tile * 16 + (int)((o + q) & 15));   // past the end: the chunk's last row again
+                    gq[q] = grads[(uint64_t)row * dim4 + (live ? c : 0)];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool on = o + q < count;
+                    sx += on ? (double)gq[q].x : 0.0; sy += on ? (double)gq[q].y : 0.0; sz += on ? (double)gq[q].z : 0.0; sw += on ? (double)gq[q].w : 0.0;
+                }
+            }
+            if (!live) continue;
             if (whole) {
-                if (slot >= 0) update_row(a, values, s1, s2, (uint64_t)slot * dim4 + c, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
+                if (slot >= 0) {
+                    opt_update4(a, wv, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
+                    values[o_row] = wv; s1[o_row] = x1;
+                    if (a.kind == MEE_OPT_ADAM) s2[o_row] = x2;
+                }
             } else {
                 double* dst = bs.gacc + ((uint64_t)(g.sbig[h] + c_idx) * dim4 + c) * 4;
                 dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = sw;
@@ -1852,7 +1901,7 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     ALLOC(t->g.ent, S * 16); ALLOC(t->g.soffs, S * 4); ALLOC(t->g.sgrp, S * 4);
     ALLOC(t->g.sbig, S * 4); ALLOC(t->g.sres, S * 8); ALLOC(t->g.inl, S * 2 * kInl * 4);
     ALLOC(t->bs.hidx, mb * 4); ALLOC(t->bs.rank, mb * 4); ALLOC(t->bs.pcnt, mb * 4); ALLOC(t->bs.occ, mb * 4); ALLOC(t->bs.uniq_h, mb * 4);
-    ALLOC(t->bs.lead_bits, (mb / 32 + 2) * 4); ALLOC(t->bs.filed_bits, (mb / 32 + 2) * 4);
+    ALLOC(t->bs.lead_bits, (mb / 32 + 16) * 4); ALLOC(t->bs.filed_bits, (mb / 32 + 16) * 4);
     ALLOC(t->bs.work, mb * 4); ALLOC(t->bs.fmask, mb);
     t->max_big = mb / kChunk + 1;  // a batch of n keys has at most n / (kChunk + 1) groups larger than kChunk
     // ... and those groups need ceil(cnt / kChunk) partial-sum rows each: at most n / kChunk + n / (kChunk + 1) rows in all
@@ -1876,8 +1925,8 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
         if (e == hipSuccess && t->sketch) e = hipMemsetAsync(t->sketch, 0, 3ull * sizeof(uint32_t) << t->sketch_log2w, 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.ent, 0, S * 16, 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.sres, 0, S * 8, 0);
-        if (e == hipSuccess) e = hipMemsetAsync(t->bs.lead_bits, 0, (mb / 32 + 2) * 4, 0);
-        if (e == hipSuccess) e = hipMemsetAsync(t->bs.filed_bits, 0, (mb / 32 + 2) * 4, 0);
+        if (e == hipSuccess) e = hipMemsetAsync(t->bs.lead_bits, 0, (mb / 32 + 16) * 4, 0);
+        if (e == hipSuccess) e = hipMemsetAsync(t->bs.filed_bits, 0, (mb / 32 + 16) * 4, 0);
         if (e == hipSuccess && t->bs.gacc) e = hipMemsetAsync(t->bs.gacc, 0, t->max_part * (uint64_t)t->dim * sizeof(double), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->ctr, 0, sizeof(Counters), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->op, 0, sizeof(OpCounters), 0);
@@ -2360,7 +2409,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
         t->prepared_n = 0; t->prepared_keys = nullptr;
     } else {
         next_epoch(t, st);
-        group_kernel<kGroupApply><<<grid_for(nn, 256, 1u << 22), 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
+        group_kernel<kGroupApply, kApplyGroupBlock><<<grid_for(nn, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
     }
     {
         const int R = t->apply_rounds > 0 ? t->apply_rounds : 1;   // one position per tile: more waves per SIMD beat more loads per wave here
@@ -2495,7 +2544,7 @@ int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* strea
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     next_epoch(t, as_stream(stream));
-    group_kernel<kGroupApply><<<grid_for(n, 256, 1u << 22), 256, 0, as_stream(stream)>>>(d_keys, (uint32_t)n, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
+    group_kernel<kGroupApply, kApplyGroupBlock><<<grid_for(n, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, as_stream(stream)>>>(d_keys, (uint32_t)n, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
     MEE_HIP(hipGetLastError());
     t->prepared_n = n; t->prepared_keys = d_keys;
     return MEE_OK;
@@ -2508,6 +2557,7 @@ int mee_apply_discard(mee_table* t, void* stream) {
     const uint32_t nn = (uint32_t)t->prepared_n;
     group_reset_kernel<<<grid_for(nn, 256, 1u << 22), 256, 0, as_stream(stream)>>>(t->bs.hidx, nn, t->g);
     MEE_HIP(hipGetLastError());
+    MEE_HIP(hipMemsetAsync(t->bs.filed_bits, 0, ((size_t)nn / 32 + 16) * 4, as_stream(stream)));   // the prepare pass may have marked filed occurrences
     t->prepared_n = 0; t->prepared_keys = nullptr;
     return MEE_OK;
 }
