@@ -369,6 +369,81 @@ def test_optimizer_full_batch_of_medium_groups(dev, opt):
     assert bool(found.all()) and np.array_equal(got.cpu().numpy(), rows)
 
 
+@pytest.mark.parametrize("opt,dim,layout", [("adagrad", 64, "clustered"), ("adagrad", 64, "spread"), ("adam", 128, "mixed"),
+                                            ("adagrad", 16, "mixed"), ("adam", 24, "spread")])
+def test_optimizer_every_group_size(dev, opt, dim, layout):
+    """One batch holds a key of EVERY multiplicity 1..44 plus 64, 65, 100, 333 and 2100, so that each way a duplicate group can be
+    finished is taken and its edges are crossed: the inline list of a group-table entry (the claiming block's occurrences 1..8, eight
+    of other blocks), the filed groups of one chunk (up to 32), the groups with fp64 partial-sum rows (33 and more).  'clustered'
+    keeps a key's occurrences adjacent (one block of the grouping kernel sees them all), 'spread' puts them 1031 positions apart
+    (every occurrence in another block), 'mixed' does both at random.  Plain, located and indexed applies must all match the oracle."""
+    rng = np.random.default_rng(7 + dim)
+    sizes = list(range(1, 45)) + [64, 65, 100, 333, 2100]
+    n_keys = len(sizes) * 3
+    keys = synth.keys_np(123, 0, n_keys + 500); rows = synth.rows_np(keys, dim, 2)
+    reps = np.array(sizes * 3)
+    bk = np.repeat(keys[:n_keys], reps)
+    filler = keys[n_keys:n_keys + 400]                       # single keys between the groups
+    n = 1031 * ((bk.size + filler.size) // 1031 + 1)
+    batch = np.full(n, oracle.EMPTY_KEY, dtype=np.int64)    # padding where nothing lands
+    if layout == "clustered":
+        order = np.arange(bk.size)
+    elif layout == "spread":
+        k = np.arange(bk.size)
+        order = (k % (n // 1031)) * 1031 + k // (n // 1031)  # neighbours in bk land 1031 positions apart
+        assert np.unique(order).size == bk.size
+    else:
+        order = rng.permutation(n)[:bk.size]
+        half = rng.random(bk.size) < 0.5                     # half of the occurrences stay next to their neighbours
+        order[half] = np.sort(order[half])
+    batch[order] = bk
+    free = np.flatnonzero(batch == oracle.EMPTY_KEY)
+    batch[free[:filler.size]] = filler
+    kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
+    mk = lambda: LookupTable(4096, dim, device=dev, optimizer=kind, max_batch=n, initial_accumulator=0.1)
+    ta, tb, tc = mk(), mk(), mk()
+    o = oracle.OracleTable(4096, dim, optimizer=okind, initial_accumulator=0.1)
+    for t in (ta, tb, tc):
+        t.insert(T(keys[:n_keys + 400], dev), T(rows[:n_keys + 400], dev))
+    o.insert(keys[:n_keys + 400], rows[:n_keys + 400])
+    bkt = T(batch, dev)
+    for s in range(2):
+        pool = (rng.standard_normal((n // 3 + 1, dim)) * 0.02).astype(np.float32)     # indexed apply: three positions share a grad row
+        gi = rng.integers(0, pool.shape[0], n).astype(np.int64)
+        g = pool[gi]
+        _, _, slots = tb.find_located(bkt)
+        if opt == "adagrad":
+            ta.apply_adagrad(bkt, T(g, dev), lr=0.05)
+            tb.apply_adagrad(bkt, T(g, dev), lr=0.05, slots=slots)
+            tc.apply_adagrad(bkt, T(pool, dev), lr=0.05, grad_index=T(gi, dev))
+            o.apply_adagrad(batch, g, 0.05, 1e-10)
+        else:
+            ta.apply_adam(bkt, T(g, dev), lr=0.01, step=s + 1)
+            tb.apply_adam(bkt, T(g, dev), lr=0.01, step=s + 1, slots=slots)
+            tc.apply_adam(bkt, T(pool, dev), lr=0.01, step=s + 1, grad_index=T(gi, dev))
+            o.apply_adam(batch, g, 0.01, 0.9, 0.999, 1e-8, s + 1)
+    eo = o.export(with_state=True)
+    io = np.argsort(eo[0])
+    for t in (ta, tb, tc):
+        assert t.status() == 0
+        e = [x.cpu().numpy() if x is not None else None for x in t.export(with_state=True)]
+        it = np.argsort(e[0])
+        assert np.array_equal(e[0][it], eo[0][io])
+        for x, z in zip(e[1:], eo[1:]):
+            if z is not None:
+                np.testing.assert_allclose(x[it], z[io], rtol=RTOL, atol=ATOL)
+    # the scratch is left clean: a batch of distinct keys right behind it
+    g1 = (rng.standard_normal((400, dim)) * 0.02).astype(np.float32)
+    if opt == "adagrad":
+        ta.apply_adagrad(T(filler, dev), T(g1, dev), lr=0.05); o.apply_adagrad(filler, g1, 0.05, 1e-10)
+    else:
+        ta.apply_adam(T(filler, dev), T(g1, dev), lr=0.01, step=3); o.apply_adam(filler, g1, 0.01, 0.9, 0.999, 1e-8, 3)
+    got, found = ta.find(T(filler, dev))
+    exp, _ = o.find(filler)
+    assert bool(found.all())
+    np.testing.assert_allclose(got.cpu().numpy(), exp, rtol=RTOL, atol=ATOL)
+
+
 @pytest.mark.parametrize("opt,dim", [("adagrad", 64), ("adam", 128), ("adagrad", 24)])
 def test_located_apply_equals_plain_apply(dev, opt, dim):
     """find_located + apply_*(slots=…) — the forward's slot handles instead of a probe — must give the table the plain apply
