@@ -708,51 +708,94 @@ __global__ __launch_bounds__(256) void group_reset_kernel(const uint32_t* __rest
     if (h != kNoGroup) group_release_entry(g, h);
 }
 
-// ---- insert / assign (SPEC.md §3) --------------------------------------------------------------------------
-// Only the winner occurrence (highest batch position) of each distinct key writes.
-template <bool CLAIM>
-__global__ __launch_bounds__(256) void upsert_kernel(int64_t* tkeys, float4* values, float4* s1, float4* s2, uint64_t nb,
-                                                     uint32_t dim4, const int64_t* __restrict__ keys,
-                                                     const float4* __restrict__ vals, uint32_t n,
-                                                     const uint32_t* __restrict__ hidx, GroupTable g,
-                                                     uint8_t* found, uint32_t optimizer, float init_acc, Counters* ctr, uint32_t* hits) {
+// assign, after the election (group_kernel<kGroupLast>): the find kernel's shape with the row traffic turned round.  4R positions per
+// wave step: keys and group indices arrive with one coalesced load each, the R entries, the R first bucket lines and the winners' R
+// source rows are requested before anything is waited for; every occurrence probes (found[] is exact for all of them), only the
+// winner — the highest position of its key — overwrites the row and releases the group-table entry.
+template <int DIM4, int R>
+__global__ __launch_bounds__(256) void assign_kernel(const int64_t* __restrict__ tkeys, f32x4* __restrict__ plane, uint64_t nb, uint32_t dim4_rt,
+                                                     const int64_t* __restrict__ keys, const f32x4* __restrict__ vals, uint32_t n,
+                                                     const uint32_t* __restrict__ hidx, GroupTable g, uint8_t* __restrict__ found) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t base = wave * 4; base < n; base += n_waves * 4) {
-        const uint32_t i = base + tile;
-        const bool inb = i < n;
-        const int64_t key = inb ? keys[i] : kEmpty;
-        const uint32_t h = inb ? hidx[i] : kNoGroup;
-        const bool valid = h != kNoGroup;
-        uint32_t last_lo = 0, last_hi = 0;
-        if (valid) sv_load(g, h, last_lo, last_hi);   // one 8-byte load: the complete pair, or zeros once the winner released it
-        const bool winner = valid && max(last_lo, last_hi) == i + 1;
-        bool is_new, full;
-        // insert: only winners touch the table.  assign: every occurrence probes (keys do not change) so that
-        // found[] is exact for all of them; only the winner writes.
-        const int64_t slot = tile_locate<CLAIM, CLAIM>(tkeys, nb, key, CLAIM ? winner : valid, tile, tl, is_new, full);
-        if (CLAIM && hits && winner && slot >= 0 && is_new && tl == 0) hits[slot] = 0;
-        if (winner && slot >= 0) {
-            for (uint32_t c = tl; c < dim4; c += 16) {
-                values[(uint64_t)slot * dim4 + c] = vals[(uint64_t)i * dim4 + c];
-                if (CLAIM && is_new) {
-                    if (optimizer == MEE_OPT_ADAGRAD) s1[(uint64_t)slot * dim4 + c] = make_float4(init_acc, init_acc, init_acc, init_acc);
-                    if (optimizer == MEE_OPT_ADAM) {
-                        s1[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        s2[(uint64_t)slot * dim4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+    const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
+    constexpr int KPW = 4 * R, C = DIM4 ? DIM4 / 16 : 1;
+    for (uint32_t base = wave * KPW; base < n; base += n_waves * KPW) {
+        int64_t key[R], slot[R], kb[R];
+        uint32_t h[R];
+        uint64_t b[R];
+        bool valid[R], winner[R];
+        f32x4 row[R][C];
+        const bool mine = lane < KPW && base + lane < n;
+        const int64_t kmine = mine ? keys[base + lane] : kEmpty;
+        const uint32_t hmine = mine ? hidx[base + lane] : kNoGroup;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            key[r] = __shfl(kmine, r * 4 + tile);
+            h[r] = __shfl(hmine, r * 4 + tile);
+            valid[r] = h[r] != kNoGroup;   // reserved keys and positions past the end have no group
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint32_t lo = 0, hi = 0;
+            if (valid[r]) sv_load(g, h[r], lo, hi);   // one 8-byte load: the complete pair, or zeros once the winner released it
+            winner[r] = valid[r] && max(lo, hi) == base + r * 4 + tile + 1;
+            b[r] = bucket_of(key[r], nb);
+            kb[r] = valid[r] ? tkeys[b[r] * kW + tl] : kEmpty;
+        }
+        if constexpr (DIM4 != 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int c = 0; c < C; ++c)   // read once: past the caches.  (Losers read their own row too: a valid address, no branch around the load.)
+                    row[r][c] = __builtin_nontemporal_load(&vals[(uint64_t)min(base + r * 4 + tile, n - 1) * DIM4 + c * 16 + tl]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            slot[r] = -1;
+            bool pend = valid[r];
+            uint64_t bb = b[r], steps = 0;
+            int64_t k = kb[r];
+            while (true) {
+                const uint32_t tm = tile_bits(__ballot(pend && k == key[r]), tile);
+                const uint32_t te = tile_bits(__ballot(pend && k == kEmpty), tile);
+                if (pend) {
+                    if (tm) { slot[r] = (int64_t)(bb * kW) + (__ffs(tm) - 1); pend = false; }
+                    else if (te || ++steps >= nb) pend = false;
+                    else bb = next_bucket(bb, step_of(key[r], nb), nb);
                 }
+                if (!__any(pend)) break;
+                k = pend ? tkeys[bb * kW + tl] : kEmpty;
             }
         }
-        if (!CLAIM && found && inb && tl == 0) found[i] = slot >= 0;
-        if constexpr (CLAIM) {
-            const uint64_t fm = __ballot(full);
-            if (lane == 0 && fm) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_TABLE_FULL);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + r * 4 + tile;
+            if (winner[r] && slot[r] >= 0) {
+                if constexpr (DIM4 != 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) plane[(uint64_t)slot[r] * DIM4 + c * 16 + tl] = row[r][c];
+                } else {
+                    for (uint32_t c = tl; c < dim4; c += 16) plane[(uint64_t)slot[r] * dim4 + c] = vals[(uint64_t)i * dim4 + c];
+                }
+            }
+            // the winner is the last reader that needs the entry's value: an occurrence that looks later reads 0 != i + 1 (one
+            // 8-byte load: never a mixture) and is, correctly, not the winner.  The group table is clean when the kernel ends.
+            if (winner[r] && tl == 0) group_release_entry(g, h[r]);
         }
-        // the winner is the last reader that needs the entry's value: an occurrence that looks later reads 0 != i + 1 (one
-        // 8-byte load: never a mixture) and is, correctly, not the winner.  The group table is clean when the kernel ends.
-        if (winner && tl == 0) group_release_entry(g, h);
+        if (found) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t i0 = base + r * 4;
+                if (i0 + 4 <= n && (reinterpret_cast<uintptr_t>(found) & 3) == 0) {   // the four tiles' found bytes of this round leave as ONE aligned 4-byte store
+                    const uint64_t m = __ballot(slot[r] >= 0);
+                    const uint32_t w = (uint32_t)(m & 1) | ((uint32_t)((m >> 16) & 1) << 8) | ((uint32_t)((m >> 32) & 1) << 16) |
+                                       ((uint32_t)((m >> 48) & 1) << 24);
+                    if (lane == 0) *reinterpret_cast<uint32_t*>(found + i0) = w;
+                } else if (i0 + tile < n && tl == 0) found[i0 + tile] = slot[r] >= 0;
+            }
+        }
     }
 }
 
@@ -2179,7 +2222,7 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
-    const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
+    const unsigned gl = grid_for(n, 256, 1u << 22);
     if (claim) {   // insert: creators write at once, an election only among positions that found their key present (see insert_direct_kernel)
         next_epoch(t, st);
         long long* slotof = t->g.sres;   // S >= 2 * max_batch entries: lent as the per-position slot list (as mee_remove does)
@@ -2196,8 +2239,12 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
     }
     // assign: an election over all positions (last occurrence wins), then the winners probe and overwrite
     group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, skip);
-    upsert_kernel<false><<<gt, 256, 0, st>>>(t->keys, (float4*)plane, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys,
-                                                 (const float4*)d_values, nn, t->bs.hidx, t->g, d_found, t->optimizer, t->init_acc, t->ctr, t->hits);
+    {
+        const unsigned ga = grid_for(n, 32, 1u << 16);   // two positions per tile
+#define ASSIGN(D4) assign_kernel<D4, 2><<<ga, 256, 0, st>>>(t->keys, (f32x4*)plane, t->nb, t->dim4, d_keys, (const f32x4*)d_values, nn, t->bs.hidx, t->g, d_found)
+        if (t->dim4 == 16) ASSIGN(16); else if (t->dim4 == 32) ASSIGN(32); else ASSIGN(0);
+#undef ASSIGN
+    }
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
