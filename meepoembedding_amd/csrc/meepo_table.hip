@@ -2604,7 +2604,7 @@ int mee_apply_discard(mee_table* t, void* stream) {
     const uint32_t nn = (uint32_t)t->prepared_n;
     group_reset_kernel<<<grid_for(nn, 256, 1u << 22), 256, 0, as_stream(stream)>>>(t->bs.hidx, nn, t->g);
     MEE_HIP(hipGetLastError());
-    MEE_HIP(hipMemsetAsync(t->bs.filed_bits, 0, ((size_t)nn / 32 + 16) * 4, as_stream(stream)));   // the prepare pass may have marked filed occurrences
+    zero_words(t->bs.filed_bits, ((size_t)nn / 32 + 16) * 4, as_stream(stream));   // the prepare pass may have marked filed occurrences (a kernel, not a memset node: see zero_words)
     t->prepared_n = 0; t->prepared_keys = nullptr;
     return MEE_OK;
 }

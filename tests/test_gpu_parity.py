@@ -826,6 +826,14 @@ def test_apply_prepare_split(dev):
         assert np.array_equal(found.cpu().numpy(), ef) and np.array_equal(out.cpu().numpy(), eo)
     t.apply_prepare(T(keys[:5000], dev))
     t.apply_discard()
+    # a discarded batch WITH hot keys (the grouping pass has already marked their occurrences as filed): the marks must be gone, or the
+    # next apply would file positions of a batch that no longer exists
+    hot = np.concatenate([np.repeat(keys[:3], 400), keys[100:5000]]); rng.shuffle(hot)
+    t.apply_prepare(T(hot, dev))
+    t.apply_discard()
+    bk = keys[rng.integers(0, n_keys, 6000)]
+    g = (rng.standard_normal((6000, dim)) * 0.01).astype(np.float32)
+    t.apply_adagrad(T(bk, dev), T(g, dev), lr=0.01, eps=1e-10); o.apply_adagrad(bk, g, 0.01, 1e-10)
     t.insert(T(keys[:10], dev), T(rows[:10], dev)); o.insert(keys[:10], rows[:10])   # accepted again, scratch is clean
     u, _, c, _ = t.dedup_sum(T(np.concatenate([keys[:100], keys[:50]]), dev))
     assert u.numel() == 100 and int(c.sum()) == 150
