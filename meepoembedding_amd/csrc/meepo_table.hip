@@ -2437,10 +2437,10 @@ static int apply_prepare_launch(mee_table* t, const int64_t* d_keys, uint32_t nn
     return MEE_OK;
 }
 
-// One sparse-optimizer step: group_kernel (occurrence counts; skipped after mee_apply_prepare) -> apply_main_kernel (every key with
-// at most kChunk occurrences: all of them unless the batch has hot keys) -> three small kernels for the hot keys (file the
-// occurrences, fp64 chunk sums, tree + update).  `d_slots` (nullable): the slot of every position as mee_find_located of the same
-// step reported it.
+// One sparse-optimizer step: group_kernel (occurrence counts + inline position lists; skipped after mee_apply_prepare) ->
+// apply_main_kernel (every key that occurs once; duplicates are marked) -> three small kernels for the duplicates (groups that fit
+// their entry's inline list are finished by the first, which also files the occurrences of larger groups; fp64 chunk sums; tree +
+// update).  `d_slots` (nullable): the slot of every position as mee_find_located of the same step reported it.
 static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, const OptArgs& a, void* stream,
                         const char* name, const uint32_t* d_gidx = nullptr, const int64_t* d_slots = nullptr) {
     if (!t || (n && (!d_keys || !d_grads))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
@@ -2471,9 +2471,9 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
 #undef MAIN_R
 #undef MAIN
     }
-    // hot keys only (device-side lengths: fixed small grids that loop; all three leave at once on a batch without hot keys).
-    // Tried and dropped: the three as ONE launch with grid barriers between the steps (3.5 us less without hot keys, 33 us more on a
-    // Zipf(1.05) batch); the main pass requesting grad rows / bucket lines before a position's count is known (no faster: the pass is
+    // duplicates only (device-side lengths: fixed small grids that loop; on a batch of distinct keys the first reads 32 KB of marks
+    // per 256K positions and all three leave).  Tried and dropped: the three as ONE launch with grid barriers between the steps (3.5 us
+    // less without duplicates, 33 us more on a Zipf(1.05) batch); the main pass requesting grad rows / bucket lines before a position's count is known (no faster: the pass is
     // bound by bytes, the extra registers cost occupancy); the grouping folded into the forward find (its claim atomics do not overlap
     // with the row traffic: same total).
     apply_dups_kernel<<<grid_for(nn, 256, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys, d_slots,
