@@ -669,6 +669,18 @@ def main():
                     traffic = tj["bytes_per_launch"]   # measured in separate rocprofv3 --pmc passes (tools/pmc_traffic.py), not in this run
             except Exception:
                 traffic = None
+        step_traffic = step_traffic_src = None   # configs[2]: the step's kernels summed, from the PMC passes of tools/pmc_apply.sh
+        apath = os.path.join(ROOT, "profiles", "r02_apply_traffic.json")
+        if whole and not sharded and os.path.exists(apath) and args.dist == "uniform" and dim == 64 and keys_per_gpu == 100_000_000:
+            try:
+                aj = json.load(open(apath))
+                if aj.get("batch") == batch:
+                    ks = aj["kernels"]
+                    step_traffic = sum(ks[k]["bytes_per_launch"] for k in ("find_kernel<16, 2, 64>", "group_kernel<2", "apply_main_kernel<1, 16, 1, true>",
+                                                                          "apply_dups_kernel", "apply_filed_kernel", "apply_big_kernel"))
+                    step_traffic_src = "profiles/r02_apply_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_apply.sh; the step's six kernels summed)"
+            except Exception:
+                step_traffic = None
         res = {
             "metric": "key-lookups/sec" if not train else "train-step keys/sec (find + sparse Adagrad apply)", "value": value, "unit": "key-lookups/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -681,9 +693,9 @@ def main():
                        "key_distribution": args.dist, "table_gb": round(table.table_bytes / 1e9, 2), "launch": launch_mode,
                        "parallelism": (f"row-shard x{world}" + (f", {args.pipeline} steps in flight" if args.pipeline > 1 else "") + (", pre-exchange dedup" if args.dedup else "")) if sharded else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic if not whole else None, "kernel": "find_kernel" if not whole else "whole step (find_kernel + the apply's group / main / three hot-key kernels)",
-                         "traffic_source": ("profiles/find_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 per the gfx950 correction)"
-                                            if traffic is not None and not whole else None),
+                         "traffic": traffic if not whole else step_traffic, "kernel": "find_kernel" if not whole else "whole step (find_kernel + the apply's group / main / three duplicate kernels)",
+                         "traffic_source": (("profiles/find_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 per the gfx950 correction)"
+                                             if traffic is not None else None) if not whole else step_traffic_src),
                          "avg_launch_us": kern_s * 1e6, "min_launch_us": kern_min_s * 1e6,
                          "window": "median of 5 HIP-event windows of 200 back-to-back launches on the launch stream (independent of --steps)" if not whole else "the timed steps",
                          "algorithmic_bytes_per_lookup": bpl if not whole else step_bytes / batch,
