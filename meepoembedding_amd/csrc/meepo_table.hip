@@ -65,6 +65,11 @@ __device__ __forceinline__ void sv_load(const GroupTable& g, uint32_t h, uint32_
     const unsigned long long w = g.ent[2 * (uint64_t)h + 1];
     lo = (uint32_t)w; hi = (uint32_t)(w >> 32);
 }
+// kGroupApply entries (read while claimed): hi holds the claiming block's count - 1
+__device__ __forceinline__ void cnt_load(const GroupTable& g, uint32_t h, uint32_t& lo, uint32_t& hi) {
+    sv_load(g, h, lo, hi);
+    ++hi;
+}
 __device__ __forceinline__ void group_release_entry(const GroupTable& g, uint32_t h) {
     reinterpret_cast<ulonglong2*>(g.ent)[h] = make_ulonglong2(0ull, 0ull);
 }
@@ -598,7 +603,9 @@ __global__ __launch_bounds__(BLOCK) void group_kernel(const int64_t* __restrict_
         lh[slot] = h;
         if constexpr (MODE == kGroupCount || MODE == kGroupApply) {
             const uint32_t total = lval[slot];
-            if (claimed) { sv_half(g, h)[1] = total; lbase[slot] = 0; }
+            // kGroupApply keeps the claiming block's count as hi = count - 1: a key that occurs once in its block — nearly every key of
+            // a batch of distinct keys — leaves the zero the entry already holds, and its claim is the only access the entry costs here
+            if (claimed) { if (MODE != kGroupApply) sv_half(g, h)[1] = total; else if (total > 1) sv_half(g, h)[1] = total - 1; lbase[slot] = 0; }
             else lbase[slot] = atomicAdd(&sv_half(g, h)[0], total) | kRankRemote;
         } else {
             // the block whose CAS created the entry parks its candidate in the hi half with a plain store; only later arrivals
@@ -1229,7 +1236,7 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
         for (int r = 0; r < R; ++r) {
             uint32_t lo = 0, hi = 0;
             if (rk[r] & kRankFiled) h[r] = kNoGroup;   // group_kernel has marked this occurrence as filed already: nothing to do here, not even the entry
-            if (h[r] != kNoGroup) sv_load(g, h[r], lo, hi);
+            if (h[r] != kNoGroup) cnt_load(g, h[r], lo, hi);
             cnt[r] = lo + hi;
             chi[r] = hi;
             fits[r] = hi <= kInl + 1 && lo <= kInl;   // the whole group sits in the entry's inline list
@@ -1342,7 +1349,7 @@ __global__ __launch_bounds__(256) void apply_dups_kernel(const int64_t* __restri
         const bool is_filed = (fw >> (lane & 31)) & 1u, is_lead = (lw >> (lane & 31)) & 1u;
         if (is_filed) {   // arrival order over the whole batch: the claiming block's occurrences first, then the others in the order of their atomics
             uint32_t lo, hi;
-            sv_load(g, my_h, lo, hi);
+            cnt_load(g, my_h, lo, hi);
             const uint32_t at = g.soffs[my_h] + (my_rank & ~(kRankRemote | kRankFiled)) + ((my_rank & kRankRemote) ? hi : 0u);
             if (at < n) bs.occ[at] = i;   // always true (the slices add up to at most n); a violated invariant must not write out of bounds
         }
@@ -1363,7 +1370,7 @@ __global__ __launch_bounds__(256) void apply_dups_kernel(const int64_t* __restri
             const int64_t ks = (int64_t)(((unsigned long long)(uint32_t)__shfl((int)((unsigned long long)my_key >> 32), act ? src : 0) << 32) |
                                          (uint32_t)__shfl((int)(uint32_t)my_key, act ? src : 0));
             uint32_t lo = 0, hi = 0;
-            if (act) sv_load(g, h, lo, hi);
+            if (act) cnt_load(g, h, lo, hi);
             const uint32_t other = act ? g.inl[(uint64_t)h * (2 * kInl) + tl] : 0u;   // one 64-byte line for the tile
             int64_t slot;
             if (slots) slot = (act && (uint64_t)ks < capacity) ? ks : -1;   // a handle is the caller's data: never index past the planes
@@ -1455,7 +1462,7 @@ __global__ __launch_bounds__(256) void apply_filed_kernel(const int64_t* __restr
         const bool inb = w < n_work;
         const uint32_t h = inb ? bs.work[w] : 0;
         uint32_t lo = 0, hi = 0;
-        if (inb) sv_load(g, h, lo, hi);
+        if (inb) cnt_load(g, h, lo, hi);
         const uint32_t cnt = lo + hi;
         const bool whole = inb && cnt <= kChunk;   // the group's only chunk
         const int64_t key = whole ? (int64_t)(g.ent[2 * (uint64_t)h] ^ kBias) : kEmpty;
@@ -1523,7 +1530,7 @@ __global__ __launch_bounds__(256) void apply_big_kernel(const int64_t* __restric
     for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {  // block-uniform
         const uint32_t h = bs.bigh[b];
         uint32_t cnt_lo, cnt_hi;
-        sv_load(g, h, cnt_lo, cnt_hi);
+        if (GROUPED) sv_load(g, h, cnt_lo, cnt_hi); else cnt_load(g, h, cnt_lo, cnt_hi);   // the plan-free flow's entries (kGroupApply) hold hi - 1
         const uint32_t cnt = cnt_lo + cnt_hi;
         const uint32_t n_rows = (cnt + kChunk - 1) / kChunk, row0 = g.sbig[h];
         const int64_t key = (int64_t)(g.ent[2 * (uint64_t)h] ^ kBias);
