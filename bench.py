@@ -297,6 +297,45 @@ def p2p_selftest(ctrl, log, timeout=120, script="p2p_selftest.py", port_offset=1
     return bool(int(ok.item()))
 
 
+def train_streams(table, synth, n_keys, batch, dim, dev, out, found, bpl, steps=60, regions=3):
+    """the find + sparse-Adagrad step on a uniform and a Zipf(1.05) key stream, bytes by the 264*B + 1032*U rule
+    with U measured; median of `regions` HIP-event windows of `steps` steps each (after the timed region: not part of `value`)."""
+    res = {}
+    slots = torch.empty(batch, dtype=torch.int64, device=dev)
+    grads = [torch.randn(batch, dim, device=dev) * 0.01 for _ in range(4)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for name, dist_name in (("uniform", "uniform"), ("zipf_1.05", "zipf")):
+        bs_ = lookup_batches(synth, n_keys, batch, 8, dist_name, dev, seed=11)
+        uniq = sum(int(torch.unique(b_).numel()) for b_ in bs_) / len(bs_)
+
+        def step(i):
+            table.find_located(bs_[i % 8], out=out, found=found, slots=slots)
+            table.apply_adagrad(bs_[i % 8], grads[i % 4], lr=0.01, eps=1e-10, slots=slots)
+
+        def apply_only(i):
+            table.apply_adagrad(bs_[i % 8], grads[i % 4], lr=0.01, eps=1e-10)
+
+        row = {"unique_keys_per_batch": uniq}
+        for label, fn, nbytes in (("step", step, (bpl + 8 + 4 * dim) * batch + (8 + 16 * dim) * uniq),
+                                  ("apply_alone", apply_only, (8 + 4 * dim) * batch + (8 + 16 * dim) * uniq)):
+            ts = []
+            for _ in range(regions):
+                for i in range(5):
+                    fn(i)
+                torch.cuda.synchronize(dev)
+                e0.record()
+                for i in range(steps):
+                    fn(i)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                ts.append(e0.elapsed_time(e1) * 1e3 / steps)
+            us = sorted(ts)[len(ts) // 2]
+            row[label] = {"us": us, "keys_per_s": batch / us * 1e6, "algorithmic_bytes_per_key": nbytes / batch,
+                          "frac_of_hbm_roofline": nbytes / us / 1e3 / HBM_PEAK_GBS}
+        res[name] = row
+    return res
+
+
 def train_step_extra(find_table, synth, n_keys, dim, dev, chunk, batches, out, found, bpl, steps=100):
     """configs[2] on the same box, reported beside the headline: find + sparse-Adagrad apply per step."""
     from meepoembedding_amd import OPT_ADAGRAD, LookupTable
@@ -705,6 +744,11 @@ def main():
         if not sharded and not train and not args.no_streams:
             try:
                 res["streams"] = stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, batches, (kern_s * 1e6, kern_min_s * 1e6))
+            except Exception as e:  # noqa: BLE001
+                res["streams"] = {"error": repr(e)}
+        if whole and not args.no_streams:
+            try:
+                res["streams"] = train_streams(table, synth, n_keys, batch, dim, dev, out, found, bpl)
             except Exception as e:  # noqa: BLE001
                 res["streams"] = {"error": repr(e)}
         if not sharded and not args.no_cpu_baseline:
