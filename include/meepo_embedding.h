@@ -151,6 +151,10 @@ int mee_assign_plane(mee_table* t, uint32_t plane, const int64_t* d_keys, const 
 int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream);
 /* find, inserting absent keys with their initial row first; d_found (nullable) = present before the call. */
 int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
+/* mee_find_or_insert that also reports where every key lives now: d_slots_out[i] = the slot of keys[i] after the call (-1 only for
+ * reserved keys and for keys that could not be created: table full) — the handles mee_apply_*_located of the same training step
+ * takes instead of probing again.  Same validity as mee_find_located's handles: until the table's layout changes. */
+int mee_find_or_insert_located(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream);
 /* Admission policy: mee_find_or_insert that creates an absent key only once it has been asked for often enough.  Every absent
  * position adds 1 to its key's sketch counters; a key whose estimate — after ALL additions of this batch — is >= min_count is
  * created (initial row, initial optimizer state) and all its occurrences return that row; other absent keys return the default

@@ -72,6 +72,8 @@ public:
     void assign(const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_assign(t_, d_keys, d_values, n, d_found, stream)); }
     void remove(const int64_t* d_keys, size_t n, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_remove(t_, d_keys, n, d_found, stream)); }
     void find_or_insert(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_find_or_insert(t_, d_keys, n, d_out, d_found, stream)); }
+    // the forward of a training step over a growing vocabulary: rows + the slot of every key, for apply_*_located of the same step
+    void find_or_insert_located(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream = nullptr) { check(mee_find_or_insert_located(t_, d_keys, n, d_out, d_found, d_slots_out, stream)); }
     void find_plane(uint32_t plane, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found = nullptr, void* stream = nullptr) const { check(mee_find_plane(t_, plane, d_keys, n, d_out, d_found, stream)); }
     void assign_plane(uint32_t plane, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_assign_plane(t_, plane, d_keys, d_values, n, d_found, stream)); }
     void apply_adagrad(const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps = 1e-10f, void* stream = nullptr) { check(mee_apply_adagrad(t_, d_keys, d_grads, n, lr, eps, stream)); }

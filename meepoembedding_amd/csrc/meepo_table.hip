@@ -1008,7 +1008,8 @@ __global__ __launch_bounds__(256) void ensure_direct_kernel(int64_t* tkeys, floa
                                                             uint32_t dim4, const int64_t* __restrict__ keys, uint32_t n,
                                                             const uint8_t* __restrict__ found, uint32_t optimizer, float init_acc,
                                                             uint32_t initializer, float init_scale, uint64_t init_seed,
-                                                            float default_value, Counters* ctr, uint32_t* hits, float4* __restrict__ out) {
+                                                            float default_value, Counters* ctr, uint32_t* hits, float4* __restrict__ out,
+                                                            long long* __restrict__ slots_out = nullptr) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
@@ -1045,6 +1046,7 @@ __global__ __launch_bounds__(256) void ensure_direct_kernel(int64_t* tkeys, floa
                     }
                 }
                 if (is_new && hits && tl == 0) hits[slot] = 0;
+                if (slots_out && tl == 0) slots_out[base + p] = slot;   // the located variant: the find pass left -1 here
             }
             const uint64_t fm = __ballot(full);
             if (lane == 0 && fm) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_TABLE_FULL);
@@ -2290,7 +2292,7 @@ int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, 
 
 // shared by mee_find_or_insert (own find pass) and mee_find_or_insert_missing (mask supplied by the caller)
 static int find_or_insert_common(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream,
-                                 bool own_find_pass, const char* name) {
+                                 bool own_find_pass, const char* name, int64_t* d_slots_out = nullptr) {
     if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
     if (int rc = check_batch(t, n, name)) return rc;
     if (n == 0) return MEE_OK;
@@ -2301,16 +2303,20 @@ static int find_or_insert_common(mee_table* t, const int64_t* d_keys, size_t n, 
     // yields the "present before the call" mask; pass 2 runs the insert machinery over the missing positions only.
     uint8_t* fmask = d_found ? d_found : t->bs.fmask;
     if (own_find_pass)
-        if (int rc = find_plane(t, t->values, t->default_value, d_keys, n, d_out, fmask, stream)) return rc;
+        if (int rc = find_plane(t, t->values, t->default_value, d_keys, n, d_out, fmask, stream, false, false, false, d_slots_out)) return rc;
     // pass 2: every position the mask leaves missing claims its key (or meets the occurrence that did) and writes the key's initial row
     // into the table (creator) and into d_out (everybody): nothing is left for a third pass
     ensure_direct_kernel<<<grid_for(n, 256, 8192), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
                                                                 d_keys, nn, fmask, t->optimizer, t->init_acc, t->initializer, t->init_scale,
-                                                                t->init_seed, t->default_value, t->ctr, t->hits, (float4*)d_out);
+                                                                t->init_seed, t->default_value, t->ctr, t->hits, (float4*)d_out, (long long*)d_slots_out);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
 
+int mee_find_or_insert_located(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
+    if (n && !d_slots_out) return fail(MEE_ERR_INVALID_ARG, "mee_find_or_insert_located: null argument");
+    return find_or_insert_common(t, d_keys, n, d_out, d_found, stream, true, "mee_find_or_insert_located", d_slots_out);
+}
 int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
     return find_or_insert_common(t, d_keys, n, d_out, d_found, stream, true, "mee_find_or_insert");
 }

@@ -6,6 +6,9 @@
     meepo::apply_grad(keys, grad_rows, table_id)                      backward = the table's own sparse optimizer
                                                                                  (apply_adagrad / apply_adam), fed with
                                                                                  the dense grad of the output
+    meepo::lookup_located / meepo::apply_grad_located                 the same pair over ONE HBM table: the forward
+                                                                                 (find[_or_insert]_located) hands every key's slot
+                                                                                 to the backward, whose apply then does not probe
 
 The update happens INSIDE backward, so the layer has no torch parameters and needs no torch optimizer.  Both ops have
 fake (meta) kernels, so a model containing the layer traces and exports; they are opaque to the tracer (the table is
@@ -73,6 +76,58 @@ def _backward(ctx, grad_out):
 
 
 lookup.register_autograd(_backward, setup_context=_setup)
+
+
+# ---- the same pair for a plain HBM table: the forward hands its slot handles to the backward, whose apply then does not probe ------
+@torch.library.custom_op("meepo::lookup_located", mutates_args=())
+def lookup_located(keys: torch.Tensor, anchor: torch.Tensor, table_id: int, insert_missing: bool) -> tuple[torch.Tensor, torch.Tensor]:
+    """-> (rows [..., dim], slot handle of every key (-1 = absent) for the backward of this step)"""
+    layer = _layer(table_id)
+    flat = keys.reshape(-1)
+    rows, _, slots = layer.table.find_or_insert_located(flat) if insert_missing else layer.table.find_located(flat)
+    return rows.reshape(*keys.shape, layer.table.dim), slots   # fresh tensors: nothing aliases the table
+
+
+@lookup_located.register_fake
+def _(keys, anchor, table_id, insert_missing):
+    return keys.new_empty((*keys.shape, _layer(table_id).table.dim), dtype=torch.float32), keys.new_empty(keys.numel())
+
+
+@torch.library.custom_op("meepo::apply_grad_located", mutates_args=())
+def apply_grad_located(keys: torch.Tensor, grad_rows: torch.Tensor, located: torch.Tensor, table_id: int) -> None:
+    layer = _layer(table_id)
+    g = grad_rows.reshape(-1, layer.table.dim).contiguous()
+    slots = located if located.numel() == keys.numel() else None
+    layer.step += 1
+    if layer.optimizer == "adagrad":
+        layer.table.apply_adagrad(keys.reshape(-1), g, lr=layer.lr, eps=layer.eps, slots=slots)
+    else:
+        layer.table.apply_adam(keys.reshape(-1), g, lr=layer.lr, beta1=layer.betas[0], beta2=layer.betas[1], eps=layer.eps, step=layer.step,
+                               slots=slots)
+
+
+@apply_grad_located.register_fake
+def _(keys, grad_rows, located, table_id):
+    return None
+
+
+def _setup_located(ctx, inputs, output):
+    keys, _, table_id, _ = inputs
+    ctx.save_for_backward(keys, output[1])
+    ctx.table_id = table_id
+    ctx.layout_epoch = getattr(_layer(table_id).table, "layout_epoch", None)   # handles are slot numbers: stale once rows move
+    ctx.mark_non_differentiable(output[1])
+
+
+def _backward_located(ctx, grad_out, _grad_located):
+    keys, located = ctx.saved_tensors
+    if getattr(_layer(ctx.table_id).table, "layout_epoch", None) != ctx.layout_epoch:
+        located = located.new_empty(0)   # the table changed between forward and backward: the apply probes for itself
+    apply_grad_located(keys, grad_out.contiguous(), located, ctx.table_id)
+    return None, None, None, None
+
+
+lookup_located.register_autograd(_backward_located, setup_context=_setup_located)
 
 
 # ---- pooled: sum / mean per bag fused into the lookup, the bag's grad row indexed in the update ---------------------------
@@ -253,4 +308,6 @@ class DynamicEmbedding(torch.nn.Module):
         self._anchor = torch.nn.Parameter(torch.zeros(()), requires_grad=True)
 
     def forward(self, keys: torch.Tensor) -> torch.Tensor:
-        return lookup(keys, self._anchor, self.table_id, self.training)
+        if hasattr(self.table, "find_or_insert_located"):   # one HBM table: the backward updates the rows at the slots this lookup found
+            return lookup_located(keys, self._anchor, self.table_id, self.training)[0]
+        return lookup(keys, self._anchor, self.table_id, self.training)   # sharded / tiered tables: their apply routes by key

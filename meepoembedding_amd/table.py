@@ -218,6 +218,21 @@ class LookupTable:
             check(_lib.lib().mee_find_or_insert(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), self._s()))
         return out, found
 
+    def find_or_insert_located(self, keys: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None,
+                               slots: torch.Tensor | None = None):
+        """find_or_insert() that also returns where every key lives now (-1: reserved key / table full): the handles for
+        apply_*(…, slots=…) of the same training step — the forward of a step over a growing vocabulary."""
+        k = self._keys(keys)
+        n = k.numel()
+        if out is None:
+            out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        if found is None:
+            found = torch.empty(n, dtype=torch.uint8, device=self.device)
+        if slots is None:
+            slots = torch.empty(n, dtype=torch.int64, device=self.device)
+        check(_lib.lib().mee_find_or_insert_located(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), slots.data_ptr(), self._s()))
+        return out, found, slots
+
     def admission_decay(self, shift: int = 1) -> None:
         """Every counter of the admission sketch >>= shift (>= 32: reset): starts a new observation window."""
         check(_lib.lib().mee_admission_decay(self._h, int(shift), self._s()))

@@ -444,6 +444,41 @@ def test_optimizer_every_group_size(dev, opt, dim, layout):
     np.testing.assert_allclose(got.cpu().numpy(), exp, rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("dim", [64, 24])
+def test_find_or_insert_located(dev, dim):
+    """find_or_insert_located == find_or_insert (rows, found, table contents) and its handles are the slots mee_locate reports
+    afterwards — for present keys, new keys, duplicates of new keys, padding and a full table (-1)."""
+    n_keys = 3000
+    keys = synth.keys_np(91, 0, n_keys); rows = synth.rows_np(keys, dim, 2)
+    mk = lambda cap: LookupTable(cap, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=8192, initializer=INIT_UNIFORM, init_scale=0.05, init_seed=5)
+    ta, tb = mk(8192), mk(8192)
+    for t in (ta, tb):
+        t.insert(T(keys[:2000], dev), T(rows[:2000], dev))
+    rng = np.random.default_rng(4)
+    batch = np.concatenate([keys[rng.integers(0, n_keys, 5000)], keys[2500:2600], keys[2500:2600]])   # present, new, new twice
+    batch[rng.integers(0, batch.size, 5)] = oracle.EMPTY_KEY
+    rng.shuffle(batch)
+    oa, fa = ta.find_or_insert(T(batch, dev))
+    ob, fb, slots = tb.find_or_insert_located(T(batch, dev))
+    assert torch.equal(oa, ob) and torch.equal(fa, fb)
+    loc, lf = tb.locate(T(batch, dev))
+    assert torch.equal(slots, torch.where(lf.bool(), loc, torch.full_like(loc, -1)))
+    assert bool(((slots >= 0) == T(batch != oracle.EMPTY_KEY, dev)).all())
+    ea, eb = ta.export(with_state=True), tb.export(with_state=True)
+    ia, ib = torch.argsort(ea[0]), torch.argsort(eb[0])
+    assert torch.equal(ea[0][ia], eb[0][ib]) and torch.equal(ea[1][ia], eb[1][ib]) and torch.equal(ea[2][ia], eb[2][ib])
+    # the handles drive the apply of the same step
+    g = (rng.standard_normal((batch.size, dim)) * 0.01).astype(np.float32)
+    ta.apply_adagrad(T(batch, dev), T(g, dev), lr=0.01); tb.apply_adagrad(T(batch, dev), T(g, dev), lr=0.01, slots=slots)
+    ea, eb = ta.export(with_state=True), tb.export(with_state=True)
+    ia, ib = torch.argsort(ea[0]), torch.argsort(eb[0])
+    np.testing.assert_allclose(ea[1][ia].cpu().numpy(), eb[1][ib].cpu().numpy(), rtol=RTOL, atol=ATOL)
+    # a full table: keys that cannot be created report -1 and the default row
+    small = LookupTable(64, dim, device=dev, max_batch=8192)
+    o, f, s_ = small.find_or_insert_located(T(keys[:1000], dev))
+    assert small.status() & STATUS_TABLE_FULL and int((s_ >= 0).sum()) == small.size() and int((s_ < 0).sum()) == 1000 - small.size()
+
+
 @pytest.mark.parametrize("opt,dim", [("adagrad", 64), ("adam", 128), ("adagrad", 24)])
 def test_located_apply_equals_plain_apply(dev, opt, dim):
     """find_located + apply_*(slots=…) — the forward's slot handles instead of a probe — must give the table the plain apply

@@ -6,7 +6,7 @@ import torch
 
 import oracle
 from meepoembedding_amd import synth
-from meepoembedding_amd.nn import DynamicEmbedding, lookup
+from meepoembedding_amd.nn import DynamicEmbedding, lookup, lookup_located
 
 
 def test_custom_ops_on_cpu_adapter(built):
@@ -75,6 +75,13 @@ def test_dynamic_embedding_trains_like_torch_sparse_adagrad(dev):
     new = torch.tensor([[123456789, 987654321]], device=dev)
     layer.eval(); layer(new); assert table.size() == vocab
     layer.train(); layer(new); assert table.size() == vocab + 2
+    # the layer over ONE HBM table goes through meepo::lookup_located (the backward applies on the forward's slot handles)
+    k = keys[:12].view(3, 4).to(dev)
+    torch.library.opcheck(lookup_located, (k, layer._anchor, layer.table_id, False),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    rows, slots = lookup_located(k, layer._anchor, layer.table_id, True)
+    assert rows.shape == (3, 4, dim) and slots.shape == (12,) and bool((slots >= 0).all())
+    assert torch.equal(slots, table.locate(k.view(-1))[0])
 
 
 @pytest.mark.gpu
