@@ -1004,6 +1004,8 @@ __global__ __launch_bounds__(256) void remove_mark_kernel(int64_t* tkeys, const 
 // it, when another occurrence of the key got there first: the CAS decides the one creator); the creating tile writes the
 // hashed initial row, the initial optimizer state and a zero hit counter.  A wave with nothing missing leaves at once —
 // the steady state of a trained vocabulary costs one pass over keys + found.  The rows are read by a last find pass.
+template <int P>   // positions per wave step (64; 32 and 16 measured no faster on batches of new keys — the pass is bound by its claims — and
+                   // 3-7 % slower when nearly every key is present: tools/foi_bench.py)
 __global__ __launch_bounds__(256) void ensure_direct_kernel(int64_t* tkeys, float4* values, float4* s1, float4* s2, uint64_t nb,
                                                             uint32_t dim4, const int64_t* __restrict__ keys, uint32_t n,
                                                             const uint8_t* __restrict__ found, uint32_t optimizer, float init_acc,
@@ -1013,11 +1015,12 @@ __global__ __launch_bounds__(256) void ensure_direct_kernel(int64_t* tkeys, floa
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t base = wave * 64; base < n; base += n_waves * 64) {
-        // 64 positions per wave step: one coalesced load of keys and found bytes, then the missing ones four at a time
+    for (uint32_t base = wave * P; base < n; base += n_waves * P) {
+        // P positions per wave step: one coalesced load of keys and found bytes, then the missing ones four at a time
         const uint32_t i = base + lane;
-        const int64_t k = i < n ? keys[i] : kEmpty;
-        const bool miss = i < n && found[i] == 0;
+        const bool mine = lane < P && i < n;
+        const int64_t k = mine ? keys[i] : kEmpty;
+        const bool miss = mine && found[i] == 0;
         if (miss && k == kReclaimed) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);  // EMPTY = padding, silent
         uint64_t rest = __ballot(miss && !reserved_key(k));
         while (rest) {  // wave-uniform
@@ -2306,7 +2309,7 @@ static int find_or_insert_common(mee_table* t, const int64_t* d_keys, size_t n, 
         if (int rc = find_plane(t, t->values, t->default_value, d_keys, n, d_out, fmask, stream, false, false, false, d_slots_out)) return rc;
     // pass 2: every position the mask leaves missing claims its key (or meets the occurrence that did) and writes the key's initial row
     // into the table (creator) and into d_out (everybody): nothing is left for a third pass
-    ensure_direct_kernel<<<grid_for(n, 256, 8192), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
+    ensure_direct_kernel<64><<<grid_for(n, 256, 8192), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
                                                                 d_keys, nn, fmask, t->optimizer, t->init_acc, t->initializer, t->init_scale,
                                                                 t->init_seed, t->default_value, t->ctr, t->hits, (float4*)d_out, (long long*)d_slots_out);
     MEE_HIP(hipGetLastError());
@@ -2333,7 +2336,7 @@ int mee_find_or_insert_admit(mee_table* t, const int64_t* d_keys, size_t n, floa
     const unsigned gl = grid_for(n, 256, 4096);
     sketch_add_kernel<<<gl, 256, 0, st>>>(d_keys, fmask, n, t->sketch, t->sketch_log2w);
     sketch_decide_kernel<<<gl, 256, 0, st>>>(d_keys, fmask, n, t->sketch, t->sketch_log2w, min_count, skip);
-    ensure_direct_kernel<<<grid_for(n, 256, 8192), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
+    ensure_direct_kernel<64><<<grid_for(n, 256, 8192), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
                                                                 d_keys, (uint32_t)n, skip, t->optimizer, t->init_acc, t->initializer, t->init_scale,
                                                                 t->init_seed, t->default_value, t->ctr, t->hits, (float4*)d_out);   // admitted positions get their initial row here
     MEE_HIP(hipGetLastError());
