@@ -1332,7 +1332,7 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
 __global__ __launch_bounds__(256) void apply_dups_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1, float4* s2, uint64_t nb,
                                                          uint32_t dim4, const int64_t* __restrict__ keys, const int64_t* __restrict__ slots,
                                                          const float4* __restrict__ grads, uint32_t n, GroupTable g, BatchScratch bs,
-                                                         const OpCounters* op, OptArgs a, const uint32_t* __restrict__ gidx, uint64_t capacity) {
+                                                         OptArgs a, const uint32_t* __restrict__ gidx, uint64_t capacity) {
     __shared__ uint32_t lpos[16][2 * kInl + 2];   // the positions of the group a tile finishes (one row per tile of the block)
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const int bt = (threadIdx.x >> 6) * 4 + tile;
@@ -2493,7 +2493,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     // bound by bytes, the extra registers cost occupancy); the grouping folded into the forward find (its claim atomics do not overlap
     // with the row traffic: same total).
     apply_dups_kernel<<<grid_for(nn, 256, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys, d_slots,
-                                                             (const float4*)d_grads, nn, t->g, t->bs, t->op, a, d_gidx, t->capacity);
+                                                             (const float4*)d_grads, nn, t->g, t->bs, a, d_gidx, t->capacity);
     apply_filed_kernel<<<grid_for(n / (kInl + 1) + 1, 16, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
                                                                               (const float4*)d_grads, nn, t->g, t->bs, t->op, a, d_gidx);
     apply_big_kernel<false><<<grid_for(n / kChunk + 1, 1, 256), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,
