@@ -26,6 +26,16 @@ def test_header_symbols_exported(built):
     assert _lib.lib().mee_abi_version() == 1
 
 
+def test_header_is_plain_c():
+    """The boundary is a C ABI: the header must compile as C99 on its own (a cgo / JNI / ctypes binding includes nothing else), and
+    the header-only C++ layer as C++17."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-x", "c", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", os.path.join(inc, "meepo_embedding.h")])
+    subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wno-pragma-once-outside-header", "-I", inc,
+                           os.path.join(inc, "meepo_embedding.hpp")])
+
+
 def test_config_struct_layout(built):
     from meepoembedding_amd import _lib
     assert C.sizeof(_lib.Config) == 64 and C.sizeof(_lib.TableInfo) == 48
