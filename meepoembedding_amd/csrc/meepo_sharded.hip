@@ -25,6 +25,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -61,7 +62,13 @@ static RcclApi* rccl_api() {
     RcclApi& api = rccl_state();
     static std::once_flag once;
     std::call_once(once, [&api] {
+        // MEE_RCCL_LIB names the library to bind instead (a particular RCCL build; the multi-rank-on-one-GPU transport of the test
+        // suite, tests/cabi/fake_rccl.cpp): when set it is the only candidate, so a typo fails loudly instead of binding the default
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        if (const char* forced = getenv("MEE_RCCL_LIB")) {
+            api.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!api.handle) { snprintf(api.error, sizeof api.error, "dlopen(MEE_RCCL_LIB=%s): %s", forced, dlerror()); return; }
+        } else
         for (const char* n : names) {
             api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (api.handle) break;

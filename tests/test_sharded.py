@@ -72,7 +72,9 @@ def _run_rank_body(rank, world, port, backend, q, tiered=False, DIM=DIM):
             mk_local = lambda: TieredLookupTable(CpuTable(2048, DIM, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1), mk_flat(), hot_key_limit=1200)
         local = mk_local()
         router = CpuRouter(world)
-    elif backend == "gloo-gpu":
+    elif backend in ("gloo-gpu", "fake-rccl"):
+        if backend == "fake-rccl":   # the exchange behind the C-ABI binds the shared-memory stand-in (tests/cabi/fake_rccl.cpp) instead of RCCL
+            os.environ["MEE_RCCL_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "libfake_rccl.so")
         # several ranks share ONE GPU; the exchange is staged through host memory over gloo — every HIP kernel of the
         # multi-rank path (partition with G > 1, find on received keys, un-permute) runs for real
         from meepoembedding_amd import OPT_ADAGRAD, LookupTable, Router
@@ -165,7 +167,7 @@ def _run_rank_body(rank, world, port, backend, q, tiered=False, DIM=DIM):
             with pytest.raises(ValueError):
                 PeerShardedFind(local, Router(world, 1 << 16, device=dev), max_batch=1 << 16, payload=True)
             pt.close()
-        if backend == "nccl":
+        if backend in ("nccl", "fake-rccl"):
             _native_rccl_checks(rank, world, dev, DIM, keys, rows, grads, probe, dup, router)
         if not tiered:
             o2, f2 = sh.find(dup, dedup=True)
@@ -304,6 +306,16 @@ def test_sharded_multi_rank_on_one_gpu(dev, world, dim):
 def test_sharded_tiered_multi_rank_on_one_gpu(dev, dim):
     """configs[4] shape on the HIP backend: two ranks, every shard an HBM table backed by a pinned-host table."""
     _check(_launch(2, "gloo-gpu", tiered=True, dim=dim), 2, dim)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,dim", [(2, 64), (3, 16), (4, 128)])
+def test_native_exchange_multi_rank_on_one_gpu(dev, world, dim):
+    """The exchange behind the C-ABI (mee_sharded_*: partition, counts exchange, grouped send/recv of keys and rows, the way back,
+    un-permute; exact AND padded segment layouts) with 2-4 ranks.  RCCL refuses several ranks on one device, so the library binds a
+    shared-memory stand-in for librccl (MEE_RCCL_LIB; tests/cabi/fake_rccl.cpp) — the library's own bookkeeping for G > 1 is what
+    runs, and it must agree with the torch.distributed path and, through it, with ONE global oracle table."""
+    _check(_launch(world, "fake-rccl", dim=dim), world, dim)
 
 
 @pytest.mark.gpu
