@@ -346,7 +346,8 @@ int mee_p2p_status(mee_p2p* c, uint32_t* bits_out, void* stream); /* [syncs]; bi
  * Results are those of ONE table holding all shards (SPEC.md §5).  d_* pointers are device memory on the communicator's device.
  *
  * `nccl_comm` is an ncclComm_t passed as void*: the caller's own (borrowed, must outlive the context), or one made with the
- * three helpers below by callers that do not link RCCL themselves (the library binds librccl.so.1 at first use).
+ * three helpers below by callers that do not link RCCL themselves (the library binds librccl.so.1 at first use; the environment
+ * variable MEE_RCCL_LIB names another library to bind instead — a particular RCCL build, or the test suite's stand-in).
  *
  * Segment layout, fixed at creation:
  *   pad_slack = 0   exact: message sizes come from a counts exchange and ONE host synchronisation per operator [syncs].
