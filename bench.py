@@ -489,7 +489,8 @@ def main():
         native = None        # the RcclShardedTable that carries `step`, if any
         native_tables = []   # every native context created by the probe: closed (communicators destroyed) before the process group goes
         # ---- the exchange behind the C-ABI (mee_sharded_*: grouped ncclSend/ncclRecv inside the library), both layouts ----
-        native_ok = args.transport in ("auto", "native") and depth == 1 and args.backend == "nccl" and not args.dedup
+        # (the gloo rehearsal on one GPU can take this path too when MEE_RCCL_LIB names the test suite's shared-memory stand-in for RCCL)
+        native_ok = args.transport in ("auto", "native") and depth == 1 and (args.backend == "nccl" or os.environ.get("MEE_RCCL_LIB")) and not args.dedup
         if native_ok and not args.no_selftest:
             native_ok = p2p_selftest(ctrl, log, script="rccl_selftest.py", port_offset=23, what="native rccl")
         if native_ok:

@@ -53,3 +53,20 @@ def test_bench_two_rank_rehearsal(dev):
                           "--steps", "5", "--warmup", "2"])
     assert REQUIRED <= set(res) and res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
     assert "transport" in res["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_native_transport(dev):
+    """The N=2 flow through the exchange behind the C-ABI (self-test children, both segment layouts probed against the
+    torch.distributed path, the timed steps): two ranks share this box's GPU, so the library binds the shared-memory stand-in for
+    RCCL (tests/cabi/fake_rccl.cpp).  Timings mean nothing here; the flow and the result checks are what is rehearsed."""
+    env = dict(os.environ, MEE_RCCL_LIB=os.path.join(ROOT, "build", "libfake_rccl.so"), MEE_FAKE_RCCL_SLOT_MB="32")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--backend", "gloo", "--transport", "native", "--keys", "2000000",
+                        "--batch", "65536", "--steps", "5", "--warmup", "2", "--verbose"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert REQUIRED <= set(res) and res["n_gpus"] == 2 and res["value"] > 0
+    assert "behind the C-ABI" in res["config"]["workload"], (res["config"]["workload"], r.stderr[-2000:])
