@@ -1205,8 +1205,10 @@ __device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, cons
 //                         group's leader and is only marked (a bit); the other occurrences do nothing.  apply_dups_kernel finishes
 //                         the group — a tile that led a group here would keep the three single-key tiles of its wave waiting through
 //                         four more dependent round trips, and its fp64 sums would cost every wave of this pass a quarter of its registers.
-//   larger groups         every occurrence finalises its rank and marks itself; the leader reserves the group's slice of the occurrence
-//                         list, one work item per kChunk occurrences and, beyond kChunk occurrences, fp64 partial-sum rows.
+//   larger groups         every occurrence is marked as filed (a bit; occurrences whose own block saw the group outgrow the line were
+//                         marked by group_kernel already and are skipped here without a look at the entry); the leader reserves the
+//                         group's slice of the occurrence list, one work item per kChunk occurrences and, beyond kChunk occurrences,
+//                         fp64 partial-sum rows.
 // No plan pass, no per-batch prefix sums, no atomics on the bulk path; three small kernels finish the duplicates afterwards.
 // R positions in flight per tile; the grad rows of single keys are requested before the probe.  LOCATED: `slots` holds each
 // position's slot (or -1) as mee_find_located of the same step saw it — no probe, no bucket line.
