@@ -975,23 +975,57 @@ __global__ void sketch_decay_kernel(uint32_t* sketch, uint64_t n, uint32_t shift
 // ---- remove (SPEC.md §3) -----------------------------------------------------------------------------------
 // Two kernels so that every occurrence of a duplicate key reports the state before the call: locate (read-only,
 // found + slot per position), then tombstone (idempotent stores of RECLAIMED).
+// probe only (remove's first half, mee_locate): the find kernel's shape without the rows — 4R positions per wave step, keys by one
+// coalesced load, the R first bucket lines requested together, the slots stored by one coalesced store per wave step
+template <int R>
 __global__ __launch_bounds__(256) void remove_locate_kernel(const int64_t* __restrict__ tkeys, uint64_t nb,
                                                             const int64_t* __restrict__ keys, uint32_t n, long long* slot_out,
                                                             uint8_t* found, Counters* ctr) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t base = wave * 4; base < n; base += n_waves * 4) {
-        const uint32_t i = base + tile;
-        const bool inb = i < n;
-        const int64_t key = inb ? keys[i] : kEmpty;
-        const bool valid = inb && !reserved_key(key);
-        bool is_new, full;
-        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, valid, tile, tl, is_new, full);
-        if (inb && tl == 0) {
-            slot_out[i] = slot;
-            if (found) found[i] = slot >= 0;
-            if (!valid && key == kReclaimed) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);
+    constexpr int KPW = 4 * R;
+    for (uint32_t base = wave * KPW; base < n; base += n_waves * KPW) {
+        int64_t key[R], slot[R], kb[R];
+        uint64_t b[R];
+        bool valid[R];
+        const bool mine = lane < KPW && base + lane < n;
+        const int64_t kmine = mine ? keys[base + lane] : kEmpty;
+        if (mine && kmine == kReclaimed) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);   // EMPTY = padding, silent
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            key[r] = __shfl(kmine, r * 4 + tile);
+            valid[r] = base + r * 4 + tile < n && !reserved_key(key[r]);
+            b[r] = bucket_of(key[r], nb);
+            kb[r] = valid[r] ? tkeys[b[r] * kW + tl] : kEmpty;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            slot[r] = -1;
+            bool pend = valid[r];
+            uint64_t bb = b[r], steps = 0;
+            int64_t k = kb[r];
+            while (true) {
+                const uint32_t tm = tile_bits(__ballot(pend && k == key[r]), tile);
+                const uint32_t te = tile_bits(__ballot(pend && k == kEmpty), tile);
+                if (pend) {
+                    if (tm) { slot[r] = (int64_t)(bb * kW) + (__ffs(tm) - 1); pend = false; }
+                    else if (te || ++steps >= nb) pend = false;
+                    else bb = next_bucket(bb, step_of(key[r], nb), nb);
+                }
+                if (!__any(pend)) break;
+                k = pend ? tkeys[bb * kW + tl] : kEmpty;
+            }
+        }
+        long long my_slot = -1;   // lane j < 4R collects the slot of position base + j (round j / 4, tile j % 4)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long long v = __shfl((long long)slot[r], (lane & 3) * kW);
+            if ((lane >> 2) == r) my_slot = v;
+        }
+        if (mine) {
+            slot_out[base + lane] = my_slot;
+            if (found) found[base + lane] = my_slot >= 0;
         }
     }
 }
@@ -2289,7 +2323,7 @@ int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, 
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     long long* slots = t->g.sres;  // S >= 2 * max_batch entries: reused as the per-position slot list
-    remove_locate_kernel<<<grid_for(n, 16, 1u << 16), 256, 0, st>>>(t->keys, t->nb, d_keys, nn, slots, d_found, t->ctr);
+    remove_locate_kernel<2><<<grid_for(n, 32, 1u << 16), 256, 0, st>>>(t->keys, t->nb, d_keys, nn, slots, d_found, t->ctr);
     remove_mark_kernel<<<grid_for(n, 256, 1u << 22), 256, 0, st>>>(t->keys, slots, nn);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
@@ -2405,7 +2439,7 @@ int mee_locate(const mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_s
     if (n > 0xFFFFFFFFull) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_locate: n=%zu exceeds 2^32 - 1", n);
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
-    remove_locate_kernel<<<grid_for(n, 16, 1u << 16), 256, 0, as_stream(stream)>>>(t->keys, t->nb, d_keys, (uint32_t)n, (long long*)d_slots_out, d_found, t->ctr);
+    remove_locate_kernel<2><<<grid_for(n, 32, 1u << 16), 256, 0, as_stream(stream)>>>(t->keys, t->nb, d_keys, (uint32_t)n, (long long*)d_slots_out, d_found, t->ctr);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
