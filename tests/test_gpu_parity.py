@@ -1316,6 +1316,49 @@ def test_group_and_pooled_ops_are_graph_capturable(dev):
         np.testing.assert_allclose(ex[2][ix].cpu().numpy(), ey[2][iy].cpu().numpy(), rtol=RTOL, atol=ATOL)
 
 
+def test_train_step_is_graph_capturable(dev):
+    """One table's training step — find_or_insert_located + the located apply, on a batch with duplicate groups of every kind
+    (inline, filed, big) — captured in a hipGraph and replayed: the apply's scratch (mark maps, group table, counters) must be left
+    clean by every replay, whatever batch number the capture froze into the kernel arguments.  Compared with an eager twin."""
+    rng = np.random.default_rng(5)
+    dim, n_keys = 64, 3000
+    keys = synth.keys_np(150, 0, n_keys)
+    mk = lambda: LookupTable(8192, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=16384, initial_accumulator=0.1,
+                             initializer=INIT_UNIFORM, init_scale=0.05, init_seed=3)
+    a, b = mk(), mk()
+    rows = rng.standard_normal((2000, dim)).astype(np.float32)
+    for t in (a, b):
+        t.insert(T(keys[:2000], dev), T(rows, dev))
+    reps = np.concatenate([np.ones(1500, int), np.full(200, 3), np.full(40, 20), np.full(6, 100), [900]])
+    batch = np.repeat(keys[:reps.size], reps); rng.shuffle(batch)
+    batch = np.concatenate([batch, keys[2000:2300]])          # unseen ids: created by the forward
+    kb = T(batch, dev)
+    n = batch.size
+    g = T((rng.standard_normal((n, dim)) * 0.02).astype(np.float32), dev)
+    bufs = lambda: (torch.empty((n, dim), device=dev), torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.int64, device=dev))
+    oa, fa, sa = bufs(); ob, fb, sb = bufs()
+
+    def step(t, o, f, s_):
+        t.find_or_insert_located(kb, out=o, found=f, slots=s_)
+        t.apply_adagrad(kb, g, lr=0.05, slots=s_)
+
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step(a, oa, fa, sa)
+    for it in range(3):
+        step(b, ob, fb, sb)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ob) and torch.equal(fa, fb)
+    a.apply_adagrad(kb[:500], g[:500], lr=0.05); b.apply_adagrad(kb[:500], g[:500], lr=0.05)   # eager calls after the replays
+    ea, eb = a.export(with_state=True), b.export(with_state=True)
+    ia, ib = torch.argsort(ea[0]), torch.argsort(eb[0])
+    assert torch.equal(ea[0][ia], eb[0][ib]) and a.status() == 0
+    np.testing.assert_allclose(ea[1][ia].cpu().numpy(), eb[1][ib].cpu().numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(ea[2][ia].cpu().numpy(), eb[2][ib].cpu().numpy(), rtol=RTOL, atol=ATOL)
+
+
 _GSEQ = list(range(4)) + list(range(4, 4 + int(os.environ.get("MEE_SOAK_GROUPS", "0"))))
 
 
