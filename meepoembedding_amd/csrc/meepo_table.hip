@@ -2484,7 +2484,7 @@ int mee_clear_status(mee_table* t, void* stream) {
 
 // group the batch's keys and plan the duplicate reduction (everything that does not need the grads)
 static int apply_prepare_launch(mee_table* t, const int64_t* d_keys, uint32_t nn, hipStream_t st) {
-    group_kernel<kGroupCount><<<grid_for(nn, 256, 1u << 22), 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op);
+    group_kernel<kGroupCount, kApplyGroupBlock><<<grid_for(nn, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op);
     group_plan_kernel<false><<<grid_for(nn, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
@@ -2726,7 +2726,7 @@ int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, siz
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
-    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op);
+    group_kernel<kGroupCount, kApplyGroupBlock><<<grid_for(nn, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op);
     group_plan_kernel<true><<<grid_for(n, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
     dedup_fill_kernel<<<gl, 256, 0, st>>>(nn, t->g, t->bs, d_inverse_out);
     dedup_emit_kernel<<<gt, 256, 0, st>>>(t->dim4, (const float4*)d_grads, t->g, t->bs, t->op, d_uniq_out, (float4*)d_gsum_out, d_counts_out);
@@ -2748,7 +2748,7 @@ int mee_dedup_keys(mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_uni
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     const unsigned gl = grid_for(n, 256, 1u << 22);
-    group_kernel<kGroupCount><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op);
+    group_kernel<kGroupCount, kApplyGroupBlock><<<grid_for(nn, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op);
     group_plan_kernel<true><<<grid_for(n, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
     dedup_fill_kernel<<<gl, 256, 0, st>>>(nn, t->g, t->bs, d_inverse_out, miss_index);
     dedup_keys_emit_kernel<<<grid_for(n, 256, 4096), 256, 0, st>>>(nn, t->g, t->bs, t->op, d_uniq_out);
