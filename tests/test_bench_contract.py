@@ -70,3 +70,13 @@ def test_bench_two_rank_rehearsal_native_transport(dev):
     res = json.loads(lines[0])
     assert REQUIRED <= set(res) and res["n_gpus"] == 2 and res["value"] > 0
     assert "behind the C-ABI" in res["config"]["workload"], (res["config"]["workload"], r.stderr[-2000:])
+    # the same run with the transport's post-run check forced to fail: every rank falls back to the torch.distributed path, the timed
+    # region is run again, and the line says so — an automated N-GPU sweep must get its line either way
+    env["MEE_BENCH_FAIL_TRANSPORT_CHECK"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--backend", "gloo", "--transport", "native", "--no-selftest",
+                        "--mode", "train", "--keys", "2000000", "--batch", "65536", "--steps", "5", "--warmup", "2"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and "fallback" in res["config"]["workload"], res["config"]["workload"]
