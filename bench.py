@@ -2,15 +2,18 @@
 """bench.py — key-lookups/sec of the HIP find path (BASELINE.json metric), one process per GPU.
 
     python bench.py --gpus 1 --steps K --warmup W        configs[1]: 100M keys, dim 64, forward find, 256K-key batches
-    python -m torch.distributed.run --nproc-per-node N … bench.py --gpus N …
-                                                          row-sharded: 125M keys per GPU (N=8: the 1B-key table), dim 64,
-                                                          1M lookups per rank per step, RCCL all-to-all of keys / rows
+    python bench.py --gpus N --steps K --warmup W        row-sharded: 125M keys per GPU (N=8: the 1B-key table), dim 64, 1M lookups per
+                                                          rank per step, RCCL exchange of keys / rows.  Without a launcher around it the
+                                                          command starts its own N ranks (one per GPU) before touching the GPU and relays
+                                                          rank 0's line; under `python -m torch.distributed.run --nproc-per-node N … bench.py
+                                                          --gpus N …` it is one of the ranks.
 
 A step = one pass of the hot path over one batch of synthetic keys already resident in HBM.  N=1: one mee_find
-launch.  N>1: one sharded find (partition, all-to-all counts+keys, local find, all-to-all rows back, un-permute).
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (find_kernel) from HIP events around the
-timed launches; `cpu_baseline` is the in-repo CPU oracle ("port"; the reference snapshot has no implementation)
-on a bounded sample, rank 0, N=1 only.
+launch, results rotating over 6 output buffers (384 MB: more than the Infinity Cache absorbs).  N>1: one sharded find
+(partition, keys to their owners, local find, rows back, un-permute).  Rank 0 prints ONE JSON line.  `roofline` is for the
+dominant kernel (find_kernel) from HIP events around back-to-back launches; N=1 also carries the SURVEY 8d stream table,
+the configs[2] (find + sparse Adagrad) rows and `cpu_baseline` (the in-repo CPU oracle, "port": the reference snapshot has
+no implementation) on the configuration the GPU number is quoted on; N>1 carries `xgmi` (bytes on the busiest link).
 """
 from __future__ import annotations
 
@@ -70,50 +73,96 @@ def lookup_batches(synth, n_keys, batch, n_batches, dist_name, dev, seed):
     return out
 
 
-def cpu_baseline(synth, dim, batch, budget_s=12.0):
-    """In-repo CPU oracle find on a bounded sample: 8M-key table (2 GB of rows, DRAM-resident), 256K-key batches."""
+def _physical_cores(allowed) -> int:
+    """distinct (package, core) pairs among the CPUs this process may run on (sysfs topology); 0 if unreadable"""
+    seen = set()
+    try:
+        for c in allowed:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+    except OSError:
+        return 0
+    return len(seen)
+
+
+def cpu_baseline(synth, dim, batch, n_keys_config, load, budget_s=16.0):
+    """In-repo CPU oracle find (persistent worker pool) on the configuration the GPU number is quoted on: configs[1]'s table (100M keys,
+    dim 64, load 0.75: 35 GB of host DRAM) when the box has >= 64 GB available, else the largest table that fits (stated in `sample`);
+    uniform 256K-key batches; 1 thread, one thread per physical core, every hardware thread.  `value` = the best of them."""
     import oracle
-    n_keys = 8_000_000
-    # every hardware thread this process may run on (SURVEY §8d: std::thread::hardware_concurrency, here the affinity mask)
-    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
-    t = oracle.OracleTable(int(n_keys / 0.75), dim)
-    for s in range(0, n_keys, 1_000_000):
-        k = synth.keys_np(1, s, 1_000_000)
-        t.insert(k, synth.rows_np(k, dim, 2))
+    allowed = sorted(os.sched_getaffinity(0))
+    cores = max(1, min(os.cpu_count() or 1, len(allowed)))   # SURVEY 8d: std::thread::hardware_concurrency, here the affinity mask
+    phys = _physical_cores(allowed) or max(1, cores // 2)
+    avail = 0
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    per_key = (dim * 4 + 8) / load
+    n_keys = n_keys_config
+    if avail < (64 << 30):   # short box: the largest table that leaves half of the available memory alone (at least 1M keys)
+        n_keys = max(1_000_000, min(n_keys_config, int(avail * 0.5 / per_key) // 1_000_000 * 1_000_000))
+    t = oracle.OracleTable(int(n_keys / load), dim)
+    t0 = time.perf_counter()
+    placed, fill_budget_s = 0, 60.0
+    while placed < n_keys:   # the same key stream and key-derived rows as the GPU table, in slices so that a slow host cannot stall the run
+        c = min(10_000_000, n_keys - placed)
+        got = t.populate_synth(1, placed, c, 2, threads=cores)
+        assert got == c, (got, c)
+        placed += c
+        if time.perf_counter() - t0 > fill_budget_s and placed >= 8_000_000:
+            break
+    fill_s = time.perf_counter() - t0
+    n_keys = placed          # (smaller than planned only if the fill ran out of its time budget: stated in `sample`)
+    assert n_keys == t.size(), (n_keys, t.size())
     rng = np.random.default_rng(3)
-    batches = [synth.keys_np(1, 0, n_keys)[rng.integers(0, n_keys, batch)] for _ in range(8)]
+    with np.errstate(over="ignore"):
+        batches = [synth.mix64_np((rng.integers(0, n_keys, batch).astype(np.uint64) + np.uint64(1)) * np.uint64(synth._GOLDEN) + np.uint64(1)).view(np.int64)
+                   for _ in range(8)]
+    out, fnd = np.empty((batch, dim), np.float32), np.empty(batch, np.uint8)   # reused: a timing loop must not measure page faults
+    t.find(batches[0][:4096], out=out[:4096], found=fnd[:4096])
+    assert bool(fnd[:4096].all()) and np.array_equal(out[:4096], synth.rows_np(batches[0][:4096], dim, 2)), "CPU baseline returned wrong rows"
     res = {}
-    counts = sorted({1, min(16, cores), cores})   # 1 thread, a 1-GPU box's usual CPU share, every hardware thread
+    counts = sorted({1, min(16, cores), phys, cores})   # 1 thread, a 1-GPU box's usual CPU share, one per physical core, every hardware thread
     for threads in counts:
-        t.find(batches[0], threads=threads)  # warm-up
+        t.find(batches[0], threads=threads, out=out, found=fnd)  # warm-up (creates the pool's threads)
         done, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < budget_s / len(counts):
-            t.find(batches[done % len(batches)], threads=threads)
+            t.find(batches[done % len(batches)], threads=threads, out=out, found=fnd)
             done += 1
         res[threads] = done * batch / (time.perf_counter() - t0)
     t.close()
-    return {"value": res[cores], "unit": "key-lookups/s", "cores": cores, "kind": "port",
-            "single_thread_value": res[1], "hardware_concurrency": os.cpu_count(),
-            "by_threads": {str(k): v for k, v in res.items()},
-            "sample": f"in-repo CPU oracle (reference snapshot has no implementation): find on an {n_keys // 1_000_000}M-key dim-{dim} "
-                      f"table (load 0.75), uniform {batch}-key batches, ~{budget_s / len(counts):.0f}s per thread count ({', '.join(map(str, counts))} threads; `value` = all hardware threads)"}
+    best = max(res, key=res.get)
+    return {"value": res[best], "unit": "key-lookups/s", "cores": best, "kind": "port",
+            "single_thread_value": res[1], "hardware_threads": cores, "physical_cores": phys, "hardware_concurrency": os.cpu_count(),
+            "by_threads": {str(k): v for k, v in res.items()}, "table_keys": n_keys, "table_fill_seconds": fill_s,
+            "host_mem_available_gb": round(avail / 2 ** 30, 1),
+            "sample": f"in-repo CPU oracle (reference snapshot has no implementation), persistent worker pool: find on a {n_keys // 1_000_000}M-key dim-{dim} "
+                      f"table (load {load}; {'configs[1] size' if n_keys == n_keys_config else 'the largest that fits this host / its fill-time budget'}), uniform {batch}-key batches, "
+                      f"~{budget_s / len(counts):.0f}s per thread count ({', '.join(map(str, counts))} threads; `value` = the best of them, `cores` = its thread count)"}
 
 
 def kernel_window(table, batches, out, found, dev, launches=200, regions=5, warm=20):
     """The dominant kernel alone: `regions` windows of `launches` back-to-back mee_find launches on the launch stream, HIP events
     around each window, no host sync inside -> (median, min) microseconds per launch.  Independent of --steps, so that the
-    roofline object of a short driver run (--steps 20) agrees with a rocprofv3 average over hundreds of launches."""
+    roofline object of a short driver run (--steps 20) agrees with a rocprofv3 average over hundreds of launches.
+    `out` / `found`: one buffer (every launch writes the same 64 MB, which the 256 MiB Infinity Cache then absorbs) or a LIST of buffers
+    the launches rotate over (independent requests with results of their own: the writes have to reach HBM)."""
     import statistics
-    nb = len(batches)
+    outs, founds = (out, found) if isinstance(out, (list, tuple)) else ([out], [found])
+    nb, no = len(batches), len(outs)
     for i in range(warm):
-        table.find(batches[i % nb], out=out, found=found)
+        table.find(batches[i % nb], out=outs[i % no], found=founds[i % no])
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     per = []
     for r in range(regions):
         torch.cuda.synchronize(dev)
         e0.record()
         for i in range(launches):
-            table.find(batches[(r * launches + i) % nb], out=out, found=found)
+            j = r * launches + i
+            table.find(batches[j % nb], out=outs[j % no], found=founds[j % no])
         e1.record()
         torch.cuda.synchronize(dev)
         per.append(e0.elapsed_time(e1) * 1e3 / launches)
@@ -185,6 +234,19 @@ def stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, uniform
     rows["launch_size_sweep"] = {"lookups_per_launch": [p[0] for p in pts], "us_per_launch": [p[1] for p in pts],
                                  "fit_floor_us": float(floor), "fit_us_per_262144_lookups": float(slope * 262144),
                                  "asymptotic_frac_of_hbm_roofline": float(bpl / slope / 1e3 / HBM_PEAK_GBS)}
+    # north_star's batch size: 1M lookups per launch (256 MB of results per launch, two result buffers in rotation: nothing fits the Infinity
+    # Cache), under the library's default cache policy and with the caller's streaming-load hint
+    m1 = 1 << 20
+    b1 = [allk[o:o + m1] for o in range(0, allk.numel() - m1 + 1, m1)][:4]
+    o1, f1 = [obig[:m1], obig[m1:2 * m1]], [fbig[:m1], fbig[m1:2 * m1]]
+    row = {"lookups_per_launch": m1, "output_buffers": 2}
+    for label, nt in (("default_policy", -1), ("streaming_load_hint", 3)):
+        table.set_tuning("find_nt", nt)
+        med, mn = kernel_window(table, b1, o1, f1, dev, launches=50, regions=5, warm=5)
+        row[label] = {"us_per_launch_median": med, "us_per_launch_min": mn, "lookups_per_s": m1 / med * 1e6,
+                      "algorithmic_GBps": m1 * bpl / med / 1e3, "frac_of_hbm_roofline": m1 * bpl / med / 1e3 / HBM_PEAK_GBS}
+    table.set_tuning("find_nt", -1)
+    rows["north_star_batch_1M"] = row
     del obig, fbig, allk
     return rows
 
@@ -336,42 +398,82 @@ def train_streams(table, synth, n_keys, batch, dim, dev, out, found, bpl, steps=
     return res
 
 
-def train_step_extra(find_table, synth, n_keys, dim, dev, chunk, batches, out, found, bpl, steps=100):
-    """configs[2] on the same box, reported beside the headline: find + sparse-Adagrad apply per step."""
+def configs2_rows(find_table, synth, n_keys, dim, dev, chunk, batch, bpl):
+    """configs[2] on the same box, carried by the DEFAULT line: the find table is replaced by one with an Adagrad plane (69 GB at 100M keys),
+    then SURVEY 8d config 3's table is measured — find_located + sparse-Adagrad apply on the located slots per step, and the apply alone,
+    on a uniform and a Zipf(1.05) key stream, bytes by 528*B + 264*B + 1032*U with U measured."""
     from meepoembedding_amd import OPT_ADAGRAD, LookupTable
-    find_table.close()  # free 35 GB before the 69 GB table with optimizer state
-    batch = batches[0].numel()
-    t = LookupTable(find_table.capacity, dim, device=dev, max_batch=max(chunk, 2 * batch), optimizer=OPT_ADAGRAD)
+    cap = find_table.capacity
+    find_table.close()   # 35 GB back before the 69 GB table is made
+    torch.cuda.empty_cache()
+    t = LookupTable(cap, dim, device=dev, max_batch=max(chunk, 2 * batch), optimizer=OPT_ADAGRAD)
     populate(t, synth, n_keys, dim, dev, chunk)
-    grads = [torch.randn(batch, dim, device=dev) * 0.01 for _ in range(4)]
-    slots = torch.empty(batch, dtype=torch.int64, device=dev)
-
-    def step(i):
-        t.find_located(batches[i % len(batches)], out=out, found=found, slots=slots)
-        t.apply_adagrad(batches[i % len(batches)], grads[i % 4], lr=0.01, eps=1e-10, slots=slots)
-
-    for i in range(10):
-        step(i)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(i)
-    torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / steps
-    uniq = sum(int(torch.unique(b).numel()) for b in batches[:4]) / 4
-    step_bytes = (bpl + 8 + 4 * dim) * batch + (8 + 16 * dim) * uniq
+    out = torch.empty((batch, dim), dtype=torch.float32, device=dev)
+    found = torch.empty(batch, dtype=torch.uint8, device=dev)
+    rows = train_streams(t, synth, n_keys, batch, dim, dev, out, found, bpl)
+    rows["workload"] = (f"configs[2]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim}, forward gather (mee_find_located) + sparse-Adagrad backward scatter-update on the "
+                        f"located slots, {batch}-key batches, N(0, 1e-2) grads, lr 0.01; {t.table_bytes / 1e9:.1f} GB table; median of 3 HIP-event windows of 60 steps")
     t.close()
-    return {"workload": f"configs[2]: find_located + sparse-Adagrad apply on the located slots, {batch}-key uniform batches, {n_keys // 1_000_000}M keys, dim {dim}",
-            "train_step_keys_per_s": batch / dt, "us_per_step": dt * 1e6, "steps": steps,
-            "algorithmic_bytes_per_key": step_bytes / batch, "frac_of_hbm_roofline": step_bytes / dt / 1e9 / HBM_PEAK_GBS}
+    return rows
+
+
+def self_launch(n_ranks: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves (one per GPU, torch.distributed.run on
+    127.0.0.1), relay rank 0's single JSON line to our stdout and return the launcher's exit code (non-zero if any rank failed).
+    Runs BEFORE this process has made any HIP call: the ranks are fresh children, nothing is re-executed over a GPU context."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL and the peer-mapped transport need it on this driver
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)   # stderr passes through
+    line = None
+    for ln in p.stdout.decode(errors="replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    elif p.returncode == 0:
+        print("[bench] the ranks exited 0 but printed no result line", file=sys.stderr)
+        return 1
+    return p.returncode
+
+
+def link_traffic(router, batches, carrier, cap_padded, dim, world, ctrl, payload_dim=0):
+    """Bytes each ordered GPU pair (a -> b) carries per step, from the owner counts of a representative batch (all-gathered):
+    keys of a's lookups that b owns travel a -> b, the rows b serves for them travel b -> a.  SURVEY 8e: the fully connected xGMI mesh
+    gives every pair its own link, so the busiest link-direction bounds the step."""
+    _, counts, _ = router.partition(batches[0])
+    mine = counts.to(torch.int64).to(ctrl)
+    allc = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allc, mine)
+    c = torch.stack(allc).cpu().numpy().astype(np.float64)   # c[a][b]: keys rank a sends to owner b
+    back = 4 * dim + 1                                        # a row and its found byte
+    if carrier == "native" and cap_padded:
+        out_b = np.full_like(c, 8.0 * cap_padded)             # constant-size padded segments
+        back_b = np.full_like(c, float(back) * cap_padded)
+    elif carrier == "p2p":
+        out_b, back_b = c * 16.0, c * back                    # key + destination index pushed, rows stored straight into the requester
+    else:
+        out_b, back_b = c * 8.0 + 8.0, c * back               # counts word + keys out, rows + found back
+    out_b = out_b + c * 4.0 * payload_dim                     # train mode: the gradient rows follow the keys
+    per_link = out_b + back_b.T                               # a -> b carries a's keys to b and the rows a serves for b
+    np.fill_diagonal(per_link, 0.0)
+    return float(per_link.max()), float(per_link.sum())
+
+
+XGMI_LINK_GBS_PER_DIR = 76.8   # SURVEY 8e: 153.6 GB/s per link bidirectional (nominal; re-measure with a peer-copy microbenchmark)
 
 
 def main():
-    # stdout must carry exactly ONE JSON line: native libraries (RCCL prints a version banner to stdout when the process
-    # group is created) are pointed at stderr for the whole run, and the result is written to the saved descriptor.
-    sys.stdout.flush()
-    result_fd = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
@@ -383,8 +485,7 @@ def main():
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", action="store_true",
-                    help="append an `also` object: the same find launches on two caller streams, and a configs[2] (find + Adagrad) step. "
-                         "Off by default so that a rocprofv3 profile of the default command contains only the headline launches")
+                    help="append an `also` object: the same find launches on two caller streams and four requests per launch")
     ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)  # accepted for older command lines
     ap.add_argument("--mode", choices=["find", "train"], default="find",
                     help="find = configs[1] (the driver's metric); train = configs[2]: find + sparse-Adagrad apply per step (sharded: gradients travel to the owners too)")
@@ -401,7 +502,11 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="run the row-sharded path even at N=1 (rehearsal of the N>1 code)")
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph",
                     help="N=1 find mode: how the K timed steps are issued — one hipGraph replay of K chained kernel nodes (default) or K host launch calls")
-    ap.add_argument("--no-streams", action="store_true", help="skip the SURVEY 8d key-stream table (uniform / Zipf / 90-10 hit-miss) in the JSON line")
+    ap.add_argument("--no-streams", action="store_true", help="skip the SURVEY 8d key-stream table (uniform / Zipf / 90-10 hit-miss) and the configs[2] rows in the JSON line")
+    ap.add_argument("--out-buffers", type=int, default=6,
+                    help="N=1 find mode: the timed lookups rotate over this many dense output buffers (6 x 64 MB > the 256 MiB Infinity Cache: every "
+                         "result has to reach HBM, as the results of independent requests do); 1 = every step overwrites one buffer")
+    ap.add_argument("--no-configs2", action="store_true", help="N=1 find mode: skip the configs[2] (find + sparse Adagrad) rows that the default line carries")
     ap.add_argument("--tier-1b", action="store_true",
                     help="N=1 only: after the headline, also measure the LITERAL 1B-key dim-64 table on this one GPU through the hot/cold tier "
                          "(800M keys in HBM + 200M keys with rows in pinned host DRAM; needs ~270 GB of HBM and ~55 GB of pinned host memory); result under `also`")
@@ -411,8 +516,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1 and "LOCAL_RANK" not in os.environ:
+        # no launcher around us: become the launcher.  Nothing in this process has touched the GPU yet (device_count() only counts).
+        have = torch.cuda.device_count()
+        if args.backend == "nccl" and have < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} over RCCL needs {args.gpus} GPUs, {have} visible "
+                             f"(--backend gloo rehearses the N>1 flow with ranks sharing the GPUs there are)")
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    # stdout must carry exactly ONE JSON line: native libraries (RCCL prints a version banner to stdout when the process
+    # group is created) are pointed at stderr for the whole run, and the result is written to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
 
@@ -457,6 +574,11 @@ def main():
     batches = lookup_batches(synth, n_keys, batch, n_batches, args.dist, dev, seed=3 + rank)
     out = torch.empty((batch, dim), dtype=torch.float32, device=dev)
     found = torch.empty(batch, dtype=torch.uint8, device=dev)
+    # N=1 find mode: the timed steps rotate over several output buffers (results of independent requests; more bytes than the Infinity Cache holds)
+    n_out = max(1, args.out_buffers) if (not sharded and not train) else 1
+    outs = [out] + [torch.empty_like(out) for _ in range(n_out - 1)]
+    founds = [found] + [torch.empty_like(found) for _ in range(n_out - 1)]
+    store_hint = None   # the caller's cache-policy hint for the rotating case, chosen by a short probe below
 
     if sharded:
         # each in-flight step owns a stream and a Router (partition workspace); the local find is workspace-free, so
@@ -617,8 +739,19 @@ def main():
             table.apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10, slots=slots)
             return o_, f_
     else:
+        if n_out > 1:
+            # a caller whose result buffers rotate knows that nothing re-reads them from cache: mee_set_tuning "find_nt" = 0 (cached loads,
+            # streaming stores) is its hint; the library's own rule only sees one call's size (64 MB: cached stores).  Keep whichever is faster here.
+            t_auto = kernel_window(table, batches, outs, founds, dev, launches=100, regions=3, warm=10)[0]
+            table.set_tuning("find_nt", 0)
+            t_hint = kernel_window(table, batches, outs, founds, dev, launches=100, regions=3, warm=10)[0]
+            store_hint = {"auto_us": t_auto, "streaming_stores_us": t_hint, "used": "streaming stores (find_nt = 0)" if t_hint < t_auto else "library default"}
+            if not t_hint < t_auto:
+                table.set_tuning("find_nt", -1)
+            log(f"rotating output buffers: default policy {t_auto:.2f} us, streaming-store hint {t_hint:.2f} us per launch")
+
         def step(i):
-            return table.find(batches[i % n_batches], out=out, found=found)
+            return table.find(batches[i % n_batches], out=outs[i % n_out], found=founds[i % n_out])
 
     for i in range(args.warmup):
         r = step(i)
@@ -707,16 +840,56 @@ def main():
         torch.cuda.synchronize(dev)
         elapsed, ev_ms = timed_region()
 
+    launch_cmp = None
+    if not sharded and not train and args.steps > 0:
+        # the timed steps really ran: the LAST step's result buffer holds the rows of the last step's batch (a graph replay that skipped
+        # nodes, or wrote elsewhere, fails here)
+        last = args.steps - 1
+        lk = batches[last % n_batches]
+        assert bool(founds[last % n_out].all()) and torch.equal(outs[last % n_out][-4096:], synth.rows_t(lk[-4096:], dim, 2)), \
+            "the timed steps did not leave the last batch's rows in its output buffer"
+        if graph is not None:   # the same K steps issued eagerly (one host launch call per step), HIP events: reported beside the graph number
+            torch.cuda.synchronize(dev)
+            ev0.record()
+            for i_ in range(args.steps):
+                step(i_)
+            ev1.record()
+            torch.cuda.synchronize(dev)
+            launch_cmp = {"graph_us_per_step": ev_ms * 1e3 / args.steps, "eager_us_per_step": ev0.elapsed_time(ev1) * 1e3 / args.steps,
+                          "graph_wall_us_per_step": elapsed / args.steps * 1e6}
+
     # dominant kernel (find_kernel) alone in its own fixed window (5 x 200 launches, HIP events on the launch stream): the
     # roofline object does not depend on --steps
-    eager_us = None
+    roof_n = batch          # lookups per launch of the kernel the roofline object prices
+    xgmi = None
     if train and not sharded:
         kern_s = ev_ms / 1e3 / args.steps
         kern_min_s = kern_s
+    elif sharded and world > 1:
+        # the local find_kernel as the sharded step runs it: over keys THIS shard owns (what arrives from the G sources), about `batch` of them
+        mine_ = torch.cat([b_[hash_batch(b_, 1, world)[2] == rank] for b_ in batches])
+        kb = [mine_[s_:s_ + batch] for s_ in range(0, mine_.numel() - batch + 1, batch)] or [mine_]
+        roof_n = kb[0].numel()
+        med_us, min_us = kernel_window(table, kb, out[:roof_n], found[:roof_n], dev, launches=50, regions=3, warm=5)
+        kern_s, kern_min_s = med_us / 1e6, min_us / 1e6
+        busiest, total_b = link_traffic(shs[0].router, batches, carrier, native.segment_capacity if (carrier == "native" and native is not None) else 0,
+                                        dim, world, ctrl, payload_dim=dim if train else 0)
+        t_step = elapsed / args.steps
+        xgmi = {"bytes_on_busiest_link": busiest, "link_peak_GBps_per_direction": XGMI_LINK_GBS_PER_DIR,
+                "frac": busiest / t_step / 1e9 / XGMI_LINK_GBS_PER_DIR, "total_bytes_per_step": total_b, "aggregate_GBps": total_b / t_step / 1e9,
+                "links_are_xgmi": args.backend == "nccl",
+                "note": "algorithmic bytes per step on the busiest ordered GPU pair (keys out + rows and found bytes back; padded segments at their "
+                        "constant size), from the owner counts of a representative batch; fraction of the nominal 76.8 GB/s per link direction (SURVEY 8e)"}
     else:
-        med_us, min_us = kernel_window(table, batches, out, found, dev)
+        med_us, min_us = kernel_window(table, batches, outs, founds, dev)   # as the timed steps run: rotating output buffers
         kern_s, kern_min_s = med_us / 1e6, min_us / 1e6
     bpl = algorithmic_bytes_per_lookup(dim)
+    reused_us = None
+    if not sharded and not train and n_out > 1:   # the same launches into ONE reused 64 MB buffer under the library's default policy (what round 2 reported)
+        table.set_tuning("find_nt", -1)
+        reused_us = kernel_window(table, batches, out, found, dev)
+        if store_hint is not None and store_hint["used"].startswith("streaming"):
+            table.set_tuning("find_nt", 0)
     whole = train and not sharded   # sharded runs always price the local find_kernel alone
     if whole:
         # fwd 528 B/lookup + bwd 264 B/lookup + 1032 B per unique key (Adagrad); here the whole step is priced
@@ -724,7 +897,7 @@ def main():
         step_bytes = (bpl + 8 + 4 * dim) * batch + (8 + 16 * dim) * uniq
         achieved = step_bytes / kern_s / 1e9
     else:
-        achieved = batch * bpl / kern_s / 1e9
+        achieved = roof_n * bpl / kern_s / 1e9
 
     if rank == 0:
         value = world * batch * args.steps / elapsed
@@ -756,23 +929,37 @@ def main():
             "config": {"workload": (f"row-sharded {'train step (find + gradient exchange + sparse Adagrad)' if train else 'find'}: {n_keys // 1_000_000}M keys over {world} GPUs ({keys_per_gpu // 1_000_000}M/GPU), dim {dim}, "
                                     f"{batch} lookups per rank per step, transport: {transport}" if sharded else
                                     f"configs[2]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim}, forward find + sparse-Adagrad scatter-update, {batch}-key batches" if train else
-                                    f"configs[1]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim} fp32, forward find only, {batch}-key batches"),
+                                    f"configs[1]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim} fp32, forward find only, {batch}-key batches"
+                                    + (f", results rotating over {n_out} output buffers ({n_out * batch * dim * 4 >> 20} MB > Infinity Cache)" if n_out > 1 else ", one reused output buffer")),
                        "keys_per_gpu": keys_per_gpu, "local_size": local_size, "dim": dim, "batch_per_rank": batch, "load_factor": args.load,
                        "key_distribution": args.dist, "table_gb": round(table.table_bytes / 1e9, 2), "launch": launch_mode,
+                       "launch_comparison": launch_cmp, "output_buffers": (f"{n_out} x {batch * dim * 4 >> 20} MB dense result buffers in rotation" if n_out > 1 else "one reused result buffer"),
                        "parallelism": (f"row-shard x{world}" + (f", {args.pipeline} steps in flight" if args.pipeline > 1 else "") + (", pre-exchange dedup" if args.dedup else "")) if sharded else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic if not whole else step_traffic, "kernel": "find_kernel" if not whole else "whole step (find_kernel + the apply's group / main / three duplicate kernels)",
                          "traffic_source": (("profiles/find_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 per the gfx950 correction)"
                                              if traffic is not None else None) if not whole else step_traffic_src),
                          "avg_launch_us": kern_s * 1e6, "min_launch_us": kern_min_s * 1e6,
+                         # N=1 find: `frac` prices the launches as the timed steps run them — rotating over n_out result buffers (more than the
+                         # Infinity Cache holds); the same launches into ONE reused buffer are reported beside it
+                         "frac_out_rotating": (achieved / HBM_PEAK_GBS) if reused_us is not None else None,
+                         "frac_out_reused": (batch * bpl / reused_us[0] / 1e3 / HBM_PEAK_GBS) if reused_us is not None else None,
+                         "out_reused_avg_launch_us": reused_us[0] if reused_us is not None else None,
+                         "out_buffers": n_out, "out_store_policy": store_hint,
                          "window": "median of 5 HIP-event windows of 200 back-to-back launches on the launch stream (independent of --steps)" if not whole else "the timed steps",
                          "algorithmic_bytes_per_lookup": bpl if not whole else step_bytes / batch,
-                         "read_only_GBps": batch * (16 + 4 * dim) / kern_s / 1e9 if not whole else None,
-                         "lookups_per_launch": batch},
+                         "read_only_GBps": roof_n * (16 + 4 * dim) / kern_s / 1e9 if not whole else None,
+                         "lookups_per_launch": roof_n},
         }
+        if xgmi is not None:
+            res["xgmi"] = xgmi
+            res["roofline"]["window"] = ("median of 3 HIP-event windows of 50 back-to-back launches of the LOCAL find_kernel over keys this shard owns "
+                                         "(what arrives from the G sources per step), on rank 0")
         if not sharded and not train and not args.no_streams:
             try:
-                res["streams"] = stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, batches, (kern_s * 1e6, kern_min_s * 1e6))
+                table.set_tuning("find_nt", -1)   # the stream table is measured under the library's default cache policy, into one reused result buffer
+                res["streams"] = stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, batches, reused_us if reused_us is not None else (kern_s * 1e6, kern_min_s * 1e6))
+                res["streams"]["note"] = "every row but north_star_batch_1M and the two_output_buffers rows: launches into ONE reused result buffer, default cache policy"
             except Exception as e:  # noqa: BLE001
                 res["streams"] = {"error": repr(e)}
         if whole and not args.no_streams:
@@ -781,17 +968,22 @@ def main():
             except Exception as e:  # noqa: BLE001
                 res["streams"] = {"error": repr(e)}
         if not sharded and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(synth, dim, batch)
+            res["cpu_baseline"] = cpu_baseline(synth, dim, batch, keys_per_gpu, args.load)
         if not sharded and not train and args.extras:
             try:  # never allowed to break the headline line
                 res["also"] = {"two_caller_streams": two_stream_extra(table, batches, dim, dev, bpl)}
-                res["also"]["configs2_train_step"] = train_step_extra(table, synth, n_keys, dim, dev, chunk, batches, out, found, bpl)
             except Exception as e:  # noqa: BLE001
                 res.setdefault("also", {})["error"] = repr(e)
+        if not sharded and not train and not args.no_streams and not args.no_configs2:
+            try:  # configs[2] beside the headline, in the line the driver records (never allowed to break it)
+                del outs, founds
+                res["configs2"] = configs2_rows(table, synth, n_keys, dim, dev, chunk, batch, bpl)
+            except Exception as e:  # noqa: BLE001
+                res["configs2"] = {"error": repr(e)}
         if not sharded and args.tier_1b:
             try:
                 table.close()
-                del out, found, batches
+                del batches
                 torch.cuda.empty_cache()
                 res.setdefault("also", {})["tier_1b_keys_one_gpu"] = tier_1b_point(synth, dim, dev, batch, log)
             except Exception as e:  # noqa: BLE001

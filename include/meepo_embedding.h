@@ -45,7 +45,9 @@ enum { MEE_OK = 0, MEE_ERR_INVALID_ARG = -1, MEE_ERR_OUT_OF_MEMORY = -2, MEE_ERR
 
 enum { MEE_OPT_NONE = 0, MEE_OPT_ADAGRAD = 1, MEE_OPT_ADAM = 2 };
 enum { MEE_INIT_CONSTANT = 0, MEE_INIT_UNIFORM = 1 };
-enum { MEE_STATUS_TABLE_FULL = 1u, MEE_STATUS_RESERVED_KEY = 2u };
+/* MEE_STATUS_STALE_HANDLE: mee_apply_*_located met a slot handle made before the table's latest mee_remove / mee_clear / mee_reserve; such
+ * positions receive no update (the slot may hold another key by now). */
+enum { MEE_STATUS_TABLE_FULL = 1u, MEE_STATUS_RESERVED_KEY = 2u, MEE_STATUS_STALE_HANDLE = 4u };
 /* MEE_MEM_HOST_PINNED: rows in pinned, device-mapped host DRAM, read and written by the same kernels over PCIe — the
  * cold tier of a hot/cold pair (BASELINE configs[4]); see meepoembedding_amd/tiered.py. */
 enum { MEE_MEM_HBM = 0, MEE_MEM_HOST_PINNED = 1 };
@@ -92,9 +94,11 @@ int mee_table_create(const mee_config* cfg, mee_table** out);
 int mee_table_destroy(mee_table* t);
 int mee_table_info_get(const mee_table* t, mee_table_info* out);
 int mee_clear(mee_table* t, void* stream);
-/* performance knobs; never change results.  "find_rounds" (keys in flight per 16-lane tile: 1/2/4/8),
- * "find_grid_cap" (max blocks of the find grid, 0 = unbounded), "apply_rounds" (1/2), "apply_overlap" (1 = the duplicate path of
- * an apply runs on the table's side stream beside the main pass, 0 = everything on the caller's stream). */
+/* performance knobs; never change results.  "find_rounds" (keys in flight per 16-lane tile: 1/2/4/8), "find_grid_cap" (max blocks of
+ * the find grid, 0 = unbounded), "find_nt" (cache policy of a find: bit 0 streaming row loads, bit 1 streaming bucket loads, bit 2 cached
+ * stores of the dense output; -1 = the library's rule: cached loads, cached stores while one call's output is <= 128 MB.  A caller whose
+ * result buffers rotate — nothing re-reads them from cache — sets 0: cached loads, streaming stores), "apply_rounds" (1/2),
+ * "apply_path" (0 = group-table apply, 1 = bucketed apply, -1 = the library's choice).  "apply_overlap" is retired (accepted, ignored). */
 int mee_set_tuning(mee_table* t, const char* name, int value);
 
 /* ---- lookup-table operators (README.md:2 "lookuptable-style"; SPEC.md §3) ------------------------------ */
@@ -114,7 +118,9 @@ typedef struct mee_find_request { const int64_t* d_keys; size_t n; float* d_out;
 int mee_find_many(const mee_table* t, const mee_find_request* reqs, uint32_t count, void* stream);
 /* mee_find that also reports where each key lives: d_slots_out[i] = an opaque slot handle, -1 for absent / reserved keys.  The
  * handles feed mee_apply_*_located of the SAME training step (forward find -> backward apply) and stay valid only until the next
- * call that can move or free a row of this table (mee_remove, mee_clear, mee_reserve; inserting OTHER keys is fine). */
+ * call that can move or free a row of this table (mee_remove, mee_clear, mee_reserve; inserting OTHER keys is fine).  A handle carries
+ * the table's layout epoch (bits 40..61; bits 0..39 = the slot mee_locate reports): mee_apply_*_located skips handles of an earlier
+ * epoch and raises MEE_STATUS_STALE_HANDLE, so a kept-too-long handle can never update another key's row. */
 int mee_find_located(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream);
 /* second-tier pass after a mee_find on another table (same keys/out/found buffers): positions with d_found[i] == 0
  * that THIS table holds get their row and d_found[i] = 1; every other position is left untouched.  No host sync, no

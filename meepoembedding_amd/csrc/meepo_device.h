@@ -17,6 +17,18 @@ constexpr int64_t kReclaimed = INT64_MIN + 1;
 constexpr int kW = 16;                                   // bucket width == tile width
 constexpr unsigned long long kBias = 0x8000000000000000ull;  // scratch stores key^kBias so that 0 == empty
 constexpr uint32_t kNoGroup = 0xFFFFFFFFu;
+// Slot handles of mee_find_located / mee_find_or_insert_located: bits [0, 40) = the slot, bits [40, 62) = the table's layout epoch when the
+// handle was made (bumped by remove / clear / reserve: whatever can move or free a row).  mee_apply_*_located ignores a handle of another
+// epoch and raises MEE_STATUS_STALE_HANDLE instead of updating whatever lives in that slot now.  -1 = absent.
+constexpr int kHandleSlotBits = 40;
+constexpr int64_t kHandleSlotMask = (1ll << kHandleSlotBits) - 1;
+constexpr uint32_t kHandleEpochMask = (1u << 22) - 1;
+// decode: the slot a handle names, or -1 (absent, out of range, or made under another layout epoch: `stale`)
+__device__ __forceinline__ int64_t handle_slot(int64_t h, int64_t tag, uint64_t capacity, bool& stale) {
+    stale = h >= 0 && (h & ~kHandleSlotMask) != tag;
+    const int64_t s = h & kHandleSlotMask;
+    return (h >= 0 && !stale && (uint64_t)s < capacity) ? s : -1;   // a handle is the caller's data: never index past the planes
+}
 
 // SPEC.md §1
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {

@@ -107,6 +107,7 @@ struct mee_table {
     mee::OpCounters* h_op;
     uint64_t table_bytes, workspace_bytes;
     uint64_t generation;        // bumped whenever the planes move (mee_reserve): cached descriptors (mee_group) re-read them
+    uint32_t handle_epoch;      // bumped by every call that can move or free a row (remove / clear / reserve): tags the slot handles of mee_find_located
     // a prepared (grouped + planned) apply waiting for its grads: mee_apply_prepare .. mee_apply_*
     uint64_t prepared_n;
     const int64_t* prepared_keys;
@@ -148,7 +149,7 @@ template <int DIM4, int R, int NT>
 __device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
                                           const int64_t* __restrict__ keys, uint64_t n, f32x4* __restrict__ out,
                                           uint8_t* __restrict__ found, float defv, uint32_t dim4_rt, uint32_t* hits,
-                                          int64_t* __restrict__ slots_out, uint64_t wave, uint64_t n_waves) {
+                                          int64_t* __restrict__ slots_out, uint64_t wave, uint64_t n_waves, int64_t handle_tag = 0) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
     constexpr int KPW = 4 * R;
@@ -171,6 +172,9 @@ __device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, con
             act[r] = inb[r] && !reserved_key(key[r]);
             if constexpr ((NT & 8) != 0) {  // second-tier pass: only positions an earlier find left as missing
                 inb[r] = act[r] = act[r] && found[i] == 0;
+            }
+            if constexpr ((NT & 128) != 0) {  // owner side of a padded sharded exchange: EMPTY positions are padding nobody reads — no row, no found byte
+                inb[r] = act[r];
             }
         }
 #pragma unroll
@@ -254,13 +258,13 @@ __device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, con
                 const int64_t v = __shfl(slot[r], (lane & 3) * kW);
                 if ((lane >> 2) == r) mine = v;
             }
-            if (lane < KPW && base + lane < n) slots_out[base + lane] = mine;
+            if (lane < KPW && base + lane < n) slots_out[base + lane] = mine >= 0 ? (mine | handle_tag) : mine;   // tag: the table's layout epoch (see handle_tag_of)
         }
         if (found && !(NT & 32)) {  // NT&32: rows only (last pass of find_or_insert: found keeps meaning "present before")
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint64_t i0 = base + r * 4;
-                if ((NT & 8) == 0 && i0 + 4 <= n && (reinterpret_cast<uintptr_t>(found) & 3) == 0) {
+                if ((NT & (8 | 128)) == 0 && i0 + 4 <= n && (reinterpret_cast<uintptr_t>(found) & 3) == 0) {
                     // the four tiles' found bytes of this round leave as ONE aligned 4-byte store
                     const uint64_t m = __ballot(slot[r] >= 0);
                     const uint32_t w = (uint32_t)(m & 1) | ((uint32_t)((m >> 16) & 1) << 8) | ((uint32_t)((m >> 32) & 1) << 16) |
@@ -268,7 +272,7 @@ __device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, con
                     if (lane == 0) *reinterpret_cast<uint32_t*>(found + i0) = w;
                 } else {
                     const uint64_t i = i0 + tile;
-                    if (inb[r] && tl == 0 && (!(NT & 8) || slot[r] >= 0)) found[i] = slot[r] >= 0;
+                    if (inb[r] && tl == 0 && (!(NT & 8) || slot[r] >= 0)) found[i] = slot[r] >= 0;   // (NT & 128: inb excludes padding)
                 }
             }
         }
@@ -279,9 +283,9 @@ template <int DIM4, int R, int NT>
 __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values,
                                                    uint64_t nb, const int64_t* __restrict__ keys, uint64_t n,
                                                    f32x4* __restrict__ out, uint8_t* __restrict__ found, float defv,
-                                                   uint32_t dim4_rt, uint32_t* hits, int64_t* __restrict__ slots_out = nullptr) {
+                                                   uint32_t dim4_rt, uint32_t* hits, int64_t* __restrict__ slots_out = nullptr, int64_t handle_tag = 0) {
     find_span<DIM4, R, NT>(tkeys, values, nb, keys, n, out, found, defv, dim4_rt, hits, slots_out,
-                           (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), (uint64_t)gridDim.x * (blockDim.x >> 6));
+                           (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), (uint64_t)gridDim.x * (blockDim.x >> 6), handle_tag);
 }
 
 // Several lookup requests of one table in ONE launch (mee_find_many): the per-launch latency floor (~5 us: dispatch + the dependent
@@ -1046,7 +1050,7 @@ __global__ __launch_bounds__(256) void ensure_direct_kernel(int64_t* tkeys, floa
                                                             const uint8_t* __restrict__ found, uint32_t optimizer, float init_acc,
                                                             uint32_t initializer, float init_scale, uint64_t init_seed,
                                                             float default_value, Counters* ctr, uint32_t* hits, float4* __restrict__ out,
-                                                            long long* __restrict__ slots_out = nullptr) {
+                                                            long long* __restrict__ slots_out = nullptr, long long handle_tag = 0) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
@@ -1084,7 +1088,7 @@ __global__ __launch_bounds__(256) void ensure_direct_kernel(int64_t* tkeys, floa
                     }
                 }
                 if (is_new && hits && tl == 0) hits[slot] = 0;
-                if (slots_out && tl == 0) slots_out[base + p] = slot;   // the located variant: the find pass left -1 here
+                if (slots_out && tl == 0) slots_out[base + p] = slot | handle_tag;   // the located variant: the find pass left -1 here
             }
             const uint64_t fm = __ballot(full);
             if (lane == 0 && fm) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_TABLE_FULL);
@@ -1252,7 +1256,7 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
                                                          uint64_t nb, uint32_t dim4_rt, const int64_t* __restrict__ keys,
                                                          const int64_t* __restrict__ slots, const float4* __restrict__ grads,
                                                          uint32_t n, GroupTable g, BatchScratch bs, OpCounters* op, OptArgs a,
-                                                         const uint32_t* __restrict__ gidx, uint64_t capacity) {
+                                                         const uint32_t* __restrict__ gidx, uint64_t capacity, int64_t handle_tag, uint32_t* status) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
@@ -1271,7 +1275,12 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
             h[r] = inb ? bs.hidx[i] : kNoGroup;
             rk[r] = inb ? bs.rank[i] : 0u;
             key[r] = (!LOCATED && inb) ? keys[i] : kEmpty;
-            slot[r] = (LOCATED && inb) ? slots[i] : -1;
+            slot[r] = -1;
+            if constexpr (LOCATED) {
+                bool stale = false;
+                if (inb) slot[r] = handle_slot(slots[i], handle_tag, capacity, stale);
+                if (stale && tl == 0) atomicOr(status, (uint32_t)MEE_STATUS_STALE_HANDLE);   // rare: the caller kept handles across a remove / clear / reserve
+            }
             grow[r] = i;
         }
 #pragma unroll
@@ -1344,7 +1353,7 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const bool ok = slot[r] >= 0 && (!LOCATED || (uint64_t)slot[r] < capacity);   // a handle is the caller's data: never index past the planes
+            const bool ok = slot[r] >= 0;
             if (single[r]) {
                 if (ok) {
                     if constexpr (DIM4 != 0) {
@@ -1369,7 +1378,7 @@ __global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restri
 __global__ __launch_bounds__(256) void apply_dups_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1, float4* s2, uint64_t nb,
                                                          uint32_t dim4, const int64_t* __restrict__ keys, const int64_t* __restrict__ slots,
                                                          const float4* __restrict__ grads, uint32_t n, GroupTable g, BatchScratch bs,
-                                                         OptArgs a, const uint32_t* __restrict__ gidx, uint64_t capacity) {
+                                                         OptArgs a, const uint32_t* __restrict__ gidx, uint64_t capacity, int64_t handle_tag) {
     __shared__ uint32_t lpos[16][2 * kInl + 2];   // the positions of the group a tile finishes (one row per tile of the block)
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const int bt = (threadIdx.x >> 6) * 4 + tile;
@@ -1415,7 +1424,7 @@ __global__ __launch_bounds__(256) void apply_dups_kernel(const int64_t* __restri
             if (act) cnt_load(g, h, lo, hi);
             const uint32_t other = act ? g.inl[(uint64_t)h * (2 * kInl) + tl] : 0u;   // one 64-byte line for the tile
             int64_t slot;
-            if (slots) slot = (act && (uint64_t)ks < capacity) ? ks : -1;   // a handle is the caller's data: never index past the planes
+            if (slots) { bool stale; slot = act ? handle_slot(ks, handle_tag, capacity, stale) : -1; }   // (a stale handle was reported by the main pass)
             else {
                 bool is_new, full;
                 slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, act ? ks : kEmpty, act, tile, tl, is_new, full);
@@ -1854,6 +1863,7 @@ __global__ __launch_bounds__(256) void export_kernel(const int64_t* __restrict__
 // host side
 // =========================================================================================================
 static hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+static int64_t handle_tag_of(const mee_table* t) { return (int64_t)(t->handle_epoch & kHandleEpochMask) << kHandleSlotBits; }
 
 TableView table_view(const mee_table* t) {
     return TableView{t->device, t->keys, t->values, t->nb, t->dim, t->dim4, t->default_value, t->generation, t->s1, t->s2, t->optimizer,
@@ -2046,7 +2056,7 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     else if (!strcmp(name, "find_grid_cap")) t->find_grid_cap = value;
     else if (!strcmp(name, "find_nt")) t->find_nt = value;
     else if (!strcmp(name, "apply_rounds")) t->apply_rounds = value;
-    else if (!strcmp(name, "apply_overlap")) (void)value;   // retired knob (a side stream for the duplicate path lost to its fork/join gaps): accepted, ignored
+    else if (!strcmp(name, "apply_overlap")) (void)value;   // retired in round 2 (a side stream for the duplicate path lost to its fork/join gaps): accepted, ignored
     else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);
     return MEE_OK;
 }
@@ -2054,6 +2064,7 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
 int mee_clear(mee_table* t, void* stream) {
     if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_clear: null table");
     DeviceGuard g(t->device);
+    ++t->handle_epoch;
     fill_i64_kernel<<<2048, 256, 0, as_stream(stream)>>>(t->keys, t->capacity, kEmpty);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
@@ -2110,6 +2121,7 @@ int mee_reserve(mee_table* t, uint64_t new_capacity, void* stream) {
     t->nb = nnb; t->capacity = ncap;
     t->table_bytes = ncap * sizeof(int64_t) + (nhits ? ncap * sizeof(uint32_t) : 0) + plane * (1 + (n1 != nullptr) + (n2 != nullptr));
     ++t->generation;
+    ++t->handle_epoch;
     return MEE_OK;
 }
 
@@ -2129,7 +2141,7 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
     R = R >= 8 ? 8 : R >= 4 ? 4 : R >= 2 ? 2 : 1;
     const unsigned grid = grid_for(n, 4u * 4u * (unsigned)R, t->find_grid_cap > 0 ? (unsigned)t->find_grid_cap : (1u << 22));
 #define FIND1(D4, RR, NT) do { if (unordered) hipExtLaunchKernelGGL((find_kernel<D4, RR, NT>), dim3(grid), dim3(256), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, \
-                                        (const int64_t*)t->keys, (const f32x4*)plane, t->nb, d_keys, (uint64_t)n, (f32x4*)d_out, d_found, miss_value, t->dim4, (uint32_t*)nullptr, (int64_t*)nullptr); \
+                                        (const int64_t*)t->keys, (const f32x4*)plane, t->nb, d_keys, (uint64_t)n, (f32x4*)d_out, d_found, miss_value, t->dim4, (uint32_t*)nullptr, (int64_t*)nullptr, (int64_t)0); \
                                else find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr); } while (0)
     const int nt = t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
 #define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
@@ -2137,8 +2149,8 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
         // cache policy of `out`: this is the forward of a TRAINING step — the apply that follows sweeps the Infinity Cache before the next
         // forward, so keeping the dense output cached buys nothing and streaming stores win (136.9 -> 132.5 us per find + Adagrad step)
         const bool cached_out = t->find_nt >= 0 && (t->find_nt & 4);
-#define FINDL(D4, RR) do { if (cached_out) find_kernel<D4, RR, 68><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out); \
-                           else find_kernel<D4, RR, 64><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out); } while (0)
+#define FINDL(D4, RR) do { if (cached_out) find_kernel<D4, RR, 68><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out, handle_tag_of(t)); \
+                           else find_kernel<D4, RR, 64><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out, handle_tag_of(t)); } while (0)
         if (t->dim4 == 16) { if (R >= 2) FINDL(16, 2); else FINDL(16, 1); }
         else if (t->dim4 == 32) { if (R >= 2) FINDL(32, 2); else FINDL(32, 1); }
         else { if (R >= 2) FINDL(0, 2); else FINDL(0, 1); }
@@ -2324,6 +2336,7 @@ int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, 
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
     long long* slots = t->g.sres;  // S >= 2 * max_batch entries: reused as the per-position slot list
+    ++t->handle_epoch;   // rows are freed: slot handles handed out before this call are stale
     remove_locate_kernel<4><<<grid_for(n, 64, 1u << 16), 256, 0, st>>>(t->keys, t->nb, d_keys, nn, slots, d_found, t->ctr);
     remove_mark_kernel<<<grid_for(n, 256, 1u << 22), 256, 0, st>>>(t->keys, slots, nn);
     MEE_HIP(hipGetLastError());
@@ -2348,7 +2361,7 @@ static int find_or_insert_common(mee_table* t, const int64_t* d_keys, size_t n, 
     // into the table (creator) and into d_out (everybody): nothing is left for a third pass
     ensure_direct_kernel<64><<<grid_for(n, 256, 8192), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
                                                                 d_keys, nn, fmask, t->optimizer, t->init_acc, t->initializer, t->init_scale,
-                                                                t->init_seed, t->default_value, t->ctr, t->hits, (float4*)d_out, (long long*)d_slots_out);
+                                                                t->init_seed, t->default_value, t->ctr, t->hits, (float4*)d_out, (long long*)d_slots_out, (long long)handle_tag_of(t));
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
@@ -2515,7 +2528,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
         const int R = t->apply_rounds > 0 ? t->apply_rounds : 1;   // one position per tile: more waves per SIMD beat more loads per wave here
         const unsigned gs = grid_for(n, 16u * (R >= 2 ? 2u : 1u), 1u << 16);
 #define MAIN(K, D4, RR, LOC) apply_main_kernel<K, D4, RR, LOC><<<gs, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, \
-                                                                                  d_keys, d_slots, (const float4*)d_grads, nn, t->g, t->bs, t->op, a, d_gidx, t->capacity)
+                                                                                  d_keys, d_slots, (const float4*)d_grads, nn, t->g, t->bs, t->op, a, d_gidx, t->capacity, handle_tag_of(t), &t->ctr->status)
 #define MAIN_R(K, D4) do { if (d_slots) { if (R >= 2) MAIN(K, D4, 2, true); else MAIN(K, D4, 1, true); } \
                            else { if (R >= 2) MAIN(K, D4, 2, false); else MAIN(K, D4, 1, false); } } while (0)
 #define MAIN_D(K) do { if (t->dim4 == 16) MAIN_R(K, 16); else if (t->dim4 == 32) MAIN_R(K, 32); else MAIN_R(K, 0); } while (0)
@@ -2530,7 +2543,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     // bound by bytes, the extra registers cost occupancy); the grouping folded into the forward find (its claim atomics do not overlap
     // with the row traffic: same total).
     apply_dups_kernel<<<grid_for(nn, 256, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys, d_slots,
-                                                             (const float4*)d_grads, nn, t->g, t->bs, a, d_gidx, t->capacity);
+                                                             (const float4*)d_grads, nn, t->g, t->bs, a, d_gidx, t->capacity, handle_tag_of(t));
     apply_filed_kernel<<<grid_for(n / (kInl + 1) + 1, 16, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
                                                                               (const float4*)d_grads, nn, t->g, t->bs, t->op, a, d_gidx);
     apply_big_kernel<false><<<grid_for(n / kChunk + 1, 1, 256), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,

@@ -57,6 +57,7 @@ def lib() -> C.CDLL:
         L.meo_initial_row.restype = None; L.meo_initial_row.argtypes = [vp, C.c_int64, vp]
         L.meo_find.restype = None; L.meo_find.argtypes = [vp, vp, sz, vp, vp]
         L.meo_find_mt.restype = None; L.meo_find_mt.argtypes = [vp, vp, sz, vp, vp, C.c_int]
+        L.meo_populate_synth_mt.restype = u64; L.meo_populate_synth_mt.argtypes = [vp, u64, u64, u64, u64, C.c_int]
         L.meo_insert.restype = None; L.meo_insert.argtypes = [vp, vp, vp, sz]
         L.meo_assign.restype = None; L.meo_assign.argtypes = [vp, vp, vp, sz, vp]
         L.meo_find_plane.restype = None; L.meo_find_plane.argtypes = [vp, u32, vp, sz, vp, vp]
@@ -153,9 +154,15 @@ class OracleTable:
         lib().meo_initial_row(self._h, key, _p(r))
         return r
 
-    def find(self, keys, threads: int = 1):
+    def find(self, keys, threads: int = 1, out=None, found=None):
+        """threads > 1: the persistent worker pool of meo_find_mt.  out / found: caller-owned result buffers to reuse (a timing loop
+        that allocated 64 MB per call would measure page faults)."""
         k = _keys(keys)
-        out = np.empty((k.size, self.dim), np.float32); found = np.empty(k.size, np.uint8)
+        if out is None:
+            out = np.empty((k.size, self.dim), np.float32)
+        if found is None:
+            found = np.empty(k.size, np.uint8)
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == k.size * self.dim and found.size == k.size
         if threads > 1:
             lib().meo_find_mt(self._h, _p(k), k.size, _p(out), _p(found), threads)
         else:
@@ -165,6 +172,11 @@ class OracleTable:
     def insert(self, keys, values):
         k = _keys(keys); v = _rows(values, k.size, self.dim)
         lib().meo_insert(self._h, _p(k), _p(v), k.size)
+
+    def populate_synth(self, key_seed: int, start: int, count: int, row_seed: int, threads: int = 1) -> int:
+        """Bulk load synth.keys_np(key_seed, start, count) with synth.rows_np(keys, dim, row_seed), generated inside the library by
+        `threads` threads (the timed CPU baseline builds its 100M-key table this way); returns the number of keys placed."""
+        return int(lib().meo_populate_synth_mt(self._h, key_seed & ((1 << 64) - 1), start, count, row_seed & ((1 << 64) - 1), threads))
 
     def assign(self, keys, values):
         k = _keys(keys); v = _rows(values, k.size, self.dim)

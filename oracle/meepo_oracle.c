@@ -164,22 +164,132 @@ static void find_range(const meo_table* t, const int64_t* keys, size_t lo, size_
 void meo_find(const meo_table* t, const int64_t* keys, size_t n, float* out, uint8_t* found) {
     find_range(t, keys, 0, n, out, found);
 }
-struct find_job { const meo_table* t; const int64_t* keys; size_t lo, hi; float* out; uint8_t* found; };
-static void* find_thread(void* p) {
-    struct find_job* j = (struct find_job*)p;
-    find_range(j->t, j->keys, j->lo, j->hi, j->out, j->found);
+/* Multi-threaded find (the timed CPU baseline): a PERSISTENT worker pool.  Threads are created once (the pool only grows), wait on a
+ * condition variable between batches, and take chunks of kFindChunk keys from a shared counter — so a batch costs one wake-up and no
+ * pthread_create/join, and a slow thread (oversubscribed box, NUMA) does not hold the batch up with a fixed 1/N share.  The caller
+ * works too.  One batch at a time (the pool has one job slot): calls are serialised by pool.lock. */
+enum { kFindChunk = 512 };
+struct find_pool {
+    pthread_mutex_t lock;      /* one batch at a time */
+    pthread_mutex_t m;
+    pthread_cond_t wake, done;
+    int n_threads;             /* workers created so far */
+    int want;                  /* workers that take part in the current batch (ids < want) */
+    unsigned long generation;  /* bumped per batch */
+    int running;               /* workers still inside the current batch */
+    /* the job */
+    const meo_table* t; const int64_t* keys; size_t n; float* out; uint8_t* found;
+    size_t next;               /* next chunk start (atomic) */
+};
+static struct find_pool g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
+                                  0, 0, 0, 0, NULL, NULL, 0, NULL, NULL, 0};
+static void pool_work(struct find_pool* p) {
+    for (;;) {
+        const size_t lo = __atomic_fetch_add(&p->next, (size_t)kFindChunk, __ATOMIC_RELAXED);
+        if (lo >= p->n) break;
+        const size_t hi = lo + kFindChunk < p->n ? lo + kFindChunk : p->n;
+        find_range(p->t, p->keys, lo, hi, p->out, p->found);
+    }
+}
+static void* pool_thread(void* arg) {
+    struct find_pool* p = &g_pool;
+    const int id = (int)(intptr_t)arg;
+    unsigned long seen = 0;
+    pthread_mutex_lock(&p->m);
+    for (;;) {
+        while (p->generation == seen) pthread_cond_wait(&p->wake, &p->m);
+        seen = p->generation;
+        if (id >= p->want) continue;   /* this batch runs with fewer threads */
+        pthread_mutex_unlock(&p->m);
+        pool_work(p);
+        pthread_mutex_lock(&p->m);
+        if (--p->running == 0) pthread_cond_signal(&p->done);
+    }
     return NULL;
 }
 void meo_find_mt(const meo_table* t, const int64_t* keys, size_t n, float* out, uint8_t* found, int nthreads) {
-    if (nthreads <= 1) { find_range(t, keys, 0, n, out, found); return; }
-    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
-    struct find_job* jobs = (struct find_job*)malloc(sizeof(struct find_job) * nthreads);
-    for (int k = 0; k < nthreads; ++k) {
-        jobs[k] = (struct find_job){t, keys, n * k / nthreads, n * (k + 1) / nthreads, out, found};
-        pthread_create(&th[k], NULL, find_thread, &jobs[k]);
+    if (nthreads <= 1 || n <= (size_t)kFindChunk) { find_range(t, keys, 0, n, out, found); return; }
+    struct find_pool* p = &g_pool;
+    pthread_mutex_lock(&p->lock);
+    const int helpers = nthreads - 1;   /* the caller is one of the nthreads */
+    pthread_mutex_lock(&p->m);
+    while (p->n_threads < helpers) {
+        pthread_t th;
+        if (pthread_create(&th, NULL, pool_thread, (void*)(intptr_t)p->n_threads) != 0) break;   /* run with what there is */
+        pthread_detach(th);
+        p->n_threads++;
     }
-    for (int k = 0; k < nthreads; ++k) pthread_join(th[k], NULL);
+    p->t = t; p->keys = keys; p->n = n; p->out = out; p->found = found;
+    __atomic_store_n(&p->next, (size_t)0, __ATOMIC_RELAXED);
+    p->want = helpers < p->n_threads ? helpers : p->n_threads;
+    p->running = p->want;
+    p->generation++;
+    pthread_cond_broadcast(&p->wake);
+    pthread_mutex_unlock(&p->m);
+    pool_work(p);
+    pthread_mutex_lock(&p->m);
+    while (p->running > 0) pthread_cond_wait(&p->done, &p->m);
+    pthread_mutex_unlock(&p->m);
+    pthread_mutex_unlock(&p->lock);
+}
+
+/* Bulk load of the synthetic key stream for the timed CPU baseline (SURVEY.md 8d generators, bit-identical to meepoembedding_amd/synth.py):
+ *   key_i = mix64(key_seed + (start + i + 1) * GOLDEN),  row[j] = (float)(mix64(key ^ mix64(row_seed + j)) >> 40) * 2^-24 - 0.5.
+ * The keys of the stream are distinct, so threads insert disjoint key ranges concurrently and only race for SLOTS: a slot is claimed with a
+ * compare-and-swap on the key word (SPEC 2 probe sequence; tables that never saw a remove have no RECLAIMED slots to prefer).  Placement
+ * differs from a sequential insert, observables (find, size, sorted export) do not.  Not concurrent with any other call on the table. */
+#define MEO_GOLDEN 0x9E3779B97F4A7C15ull
+struct pop_job { meo_table* t; uint64_t key_seed, row_seed, lo, hi; uint64_t placed; };
+static void* pop_thread(void* arg) {
+    struct pop_job* j = (struct pop_job*)arg;
+    meo_table* t = j->t;
+    const uint32_t d = t->dim;
+    uint64_t cj[1024];
+    for (uint32_t c = 0; c < d; ++c) cj[c] = meo_mix64(j->row_seed + c);
+    for (uint64_t i = j->lo; i < j->hi; ++i) {
+        const int64_t key = (int64_t)meo_mix64(j->key_seed + (i + 1) * MEO_GOLDEN);
+        if (reserved(key)) continue;
+        uint64_t b = meo_bucket(key, t->n_buckets);
+        const uint64_t stride = meo_step(key, t->n_buckets);
+        int64_t slot = -1;
+        for (uint64_t step = 0; step < t->n_buckets && slot < 0; ++step) {
+            int64_t* kb = t->keys + b * MEO_BUCKET_W;
+            for (int q = 0; q < MEO_BUCKET_W && slot < 0; ++q) {
+                int64_t cur = __atomic_load_n(&kb[q], __ATOMIC_RELAXED);
+                if (cur == key) slot = (int64_t)(b * MEO_BUCKET_W + q);   /* cannot happen for a distinct stream; kept for safety */
+                else if (cur == MEO_EMPTY_KEY) {
+                    int64_t expect = MEO_EMPTY_KEY;
+                    if (__atomic_compare_exchange_n(&kb[q], &expect, key, 0, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED)) { slot = (int64_t)(b * MEO_BUCKET_W + q); j->placed++; }
+                    else if (expect == key) slot = (int64_t)(b * MEO_BUCKET_W + q);
+                    else --q;   /* another key took it: look at the same slot again (it is occupied now) */
+                }
+            }
+            b += stride; if (b >= t->n_buckets) b -= t->n_buckets;
+        }
+        if (slot < 0) continue;   /* table full: reported through the return value */
+        float* row = t->values + (uint64_t)slot * d;
+        for (uint32_t c = 0; c < d; ++c) row[c] = (float)(meo_mix64((uint64_t)key ^ cj[c]) >> 40) * 0x1p-24f - 0.5f;
+        init_state(t, slot);
+    }
+    return NULL;
+}
+uint64_t meo_populate_synth_mt(meo_table* t, uint64_t key_seed, uint64_t start, uint64_t count, uint64_t row_seed, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    struct pop_job* jobs = (struct pop_job*)malloc(sizeof(struct pop_job) * (size_t)nthreads);
+    int made = 0;
+    for (int k = 0; k < nthreads; ++k) {
+        jobs[k] = (struct pop_job){t, key_seed, row_seed, start + count * (uint64_t)k / (uint64_t)nthreads, start + count * (uint64_t)(k + 1) / (uint64_t)nthreads, 0};
+        if (k + 1 < nthreads && pthread_create(&th[made], NULL, pop_thread, &jobs[k]) == 0) ++made;
+        else { pop_thread(&jobs[k]); }   /* the last share (or one whose thread could not be made) runs here */
+    }
+    /* threads were made for the first `made` jobs that succeeded in order; jobs run inline have finished already */
+    for (int k = 0; k < made; ++k) pthread_join(th[k], NULL);
+    uint64_t placed = 0;
+    for (int k = 0; k < nthreads; ++k) placed += jobs[k].placed;
+    t->size += placed;
     free(th); free(jobs);
+    return placed;
 }
 
 static int has_reserved(meo_table* t, int64_t k) {

@@ -61,7 +61,9 @@ void     meo_initial_row(const meo_table* t, int64_t key, float* row);
 
 void meo_find(const meo_table* t, const int64_t* keys, size_t n, float* out, uint8_t* found);
 /* same, split over nthreads pthreads (read-only, embarrassingly parallel) — CPU baseline timing */
-void meo_find_mt(const meo_table* t, const int64_t* keys, size_t n, float* out, uint8_t* found, int nthreads);
+void meo_find_mt(const meo_table* t, const int64_t* keys, size_t n, float* out, uint8_t* found, int nthreads);   /* persistent worker pool */
+/* bulk load of the synthetic key stream (timed CPU baseline only): distinct keys inserted by nthreads threads; returns keys placed */
+uint64_t meo_populate_synth_mt(meo_table* t, uint64_t key_seed, uint64_t start, uint64_t count, uint64_t row_seed, int nthreads);
 void meo_insert(meo_table* t, const int64_t* keys, const float* values, size_t n);
 void meo_assign(meo_table* t, const int64_t* keys, const float* values, size_t n, uint8_t* found);
 void meo_find_plane(const meo_table* t, uint32_t plane, const int64_t* keys, size_t n, float* out, uint8_t* found);

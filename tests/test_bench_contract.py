@@ -44,6 +44,16 @@ def test_bench_single_gpu_contract(dev):
         assert st[name]["lookups_per_s"] > 0 and st[name]["mean_probe_length_buckets"] >= 0.9 and st[name]["read_only_GBps"] > 0
     assert st["hit90_miss10"]["mean_probe_length_buckets"] > st["zipf_1.05"]["mean_probe_length_buckets"] - 1e-9
     assert len(st["launch_size_sweep"]["us_per_launch"]) == 6 and st["launch_size_sweep"]["fit_us_per_262144_lookups"] > 0
+    assert st["north_star_batch_1M"]["lookups_per_launch"] == 1 << 20 and st["north_star_batch_1M"]["default_policy"]["frac_of_hbm_roofline"] > 0
+    # the headline rotates its results over more output bytes than the Infinity Cache holds and says so; the reused-buffer figure is beside it
+    assert rf["out_buffers"] >= 5 and rf["frac_out_rotating"] == rf["frac"] and rf["frac_out_reused"] > 0
+    assert "rotating" in res["config"]["workload"] and res["config"]["launch_comparison"]["eager_us_per_step"] > 0
+    # configs[2] travels in the default line: find + sparse Adagrad step and the apply alone, uniform and Zipf(1.05)
+    c2 = res["configs2"]
+    for name in ("uniform", "zipf_1.05"):
+        assert c2[name]["step"]["us"] > c2[name]["apply_alone"]["us"] > 0 and 0 < c2[name]["step"]["frac_of_hbm_roofline"] < 1
+    assert c2["zipf_1.05"]["unique_keys_per_batch"] < c2["uniform"]["unique_keys_per_batch"]
+    assert cb["table_keys"] == 2_000_000 and str(cb["cores"]) in cb["by_threads"] and cb["value"] == max(cb["by_threads"].values())
 
 
 @pytest.mark.gpu
@@ -53,6 +63,27 @@ def test_bench_two_rank_rehearsal(dev):
                           "--steps", "5", "--warmup", "2"])
     assert REQUIRED <= set(res) and res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
     assert "transport" in res["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_its_ranks(dev):
+    """`python bench.py --gpus 2` with NO launcher around it: the command starts its own two ranks (before it touches the GPU), relays rank 0's
+    line and exits with the ranks' code — the form a driver uses for every N.  gloo backend: both ranks share this box's one GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--keys", "2000000", "--batch", "65536", "--steps", "5", "--warmup", "2"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:500]
+    res = json.loads(lines[0])
+    assert REQUIRED <= set(res) and res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
+    rf, xg = res["roofline"], res["xgmi"]
+    assert rf["kernel"] == "find_kernel" and 0 < rf["frac"] < 1 and rf["lookups_per_launch"] > 0
+    # two ranks, uniform keys: about half of a rank's 65536 keys go to the peer (8 B each), their rows (256 B + found byte) come back
+    assert 0.8 < xg["bytes_on_busiest_link"] / (32768 * (8 + 257) * 1.0) < 1.6 and xg["frac"] > 0 and xg["link_peak_GBps_per_direction"] == 76.8
+    # a rank count that the launcher cannot honour fails loudly, before anything is started
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "64", "--steps", "1", "--warmup", "0"], cwd=ROOT, capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "GPUs" in (r.stderr + r.stdout)
 
 
 @pytest.mark.gpu

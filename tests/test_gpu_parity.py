@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import oracle
+from meepoembedding_amd import _lib
 from meepoembedding_amd import (INIT_UNIFORM, OPT_ADAGRAD, OPT_ADAM, STATUS_RESERVED_KEY, STATUS_TABLE_FULL, LookupTable,
                                 MeepoError, Router, hash_batch, synth)
 
@@ -462,7 +463,8 @@ def test_find_or_insert_located(dev, dim):
     ob, fb, slots = tb.find_or_insert_located(T(batch, dev))
     assert torch.equal(oa, ob) and torch.equal(fa, fb)
     loc, lf = tb.locate(T(batch, dev))
-    assert torch.equal(slots, torch.where(lf.bool(), loc, torch.full_like(loc, -1)))
+    # a handle = the slot mee_locate reports (bits 0..39) + the table's layout epoch (bits 40..61)
+    assert torch.equal(torch.where(slots >= 0, slots & _lib.HANDLE_SLOT_MASK, slots), torch.where(lf.bool(), loc, torch.full_like(loc, -1)))
     assert bool(((slots >= 0) == T(batch != oracle.EMPTY_KEY, dev)).all())
     ea, eb = ta.export(with_state=True), tb.export(with_state=True)
     ia, ib = torch.argsort(ea[0]), torch.argsort(eb[0])
@@ -527,7 +529,31 @@ def test_located_apply_equals_plain_apply(dev, opt, dim):
         tb.apply_adam(kk, torch.ones(8, dim, device=dev), lr=0.1, step=9, slots=bad)
     e2 = tb.export(with_state=True)
     i2 = torch.argsort(e2[0])
-    assert torch.equal(e2[1][i2], eb[1][ib]) and tb.status() == 0
+    assert torch.equal(e2[1][i2], eb[1][ib]) and tb.status() == _lib.STATUS_STALE_HANDLE   # a handle of no epoch of this table: flagged, not followed
+    tb.clear_status()
+    # handles kept across a remove are STALE: the freed slot may hold another key by now, so the located apply must not touch it
+    kq = T(keys[:64], dev)
+    _, _, h_old = tb.find_located(kq)
+    tb.remove(T(keys[:8], dev))                                   # frees 8 slots; every handle made before is of an earlier layout epoch
+    tb.insert(T(synth.keys_np(97, 0, 4000), dev), torch.zeros(4000, dim, device=dev))   # some of the freed slots are taken by other keys
+    before = tb.export(with_state=True)
+    g1 = torch.ones(64, dim, device=dev)
+    if opt == "adagrad":
+        tb.apply_adagrad(kq, g1, lr=0.1, slots=h_old)
+    else:
+        tb.apply_adam(kq, g1, lr=0.1, step=11, slots=h_old)
+    after = tb.export(with_state=True)
+    ib_, ia_ = torch.argsort(before[0]), torch.argsort(after[0])
+    assert torch.equal(before[1][ib_], after[1][ia_]) and torch.equal(before[2][ib_], after[2][ia_]), "a stale handle updated a row"
+    assert tb.status() & _lib.STATUS_STALE_HANDLE
+    tb.clear_status()
+    _, _, h_new = tb.find_located(kq)                             # fresh handles work again (keys[:8] are absent: -1)
+    assert bool((h_new[:8] == -1).all()) and bool((h_new[8:] >= 0).all())
+    if opt == "adagrad":
+        tb.apply_adagrad(kq, g1, lr=0.1, slots=h_new)
+    else:
+        tb.apply_adam(kq, g1, lr=0.1, step=12, slots=h_new)
+    assert tb.status() == 0 and not torch.equal(tb.find(kq[8:])[0], ta.find(kq[8:])[0])
 
 
 def test_optimizer_unique_keys_bit_exact(dev):

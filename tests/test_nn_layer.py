@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import oracle
-from meepoembedding_amd import synth
+from meepoembedding_amd import _lib, synth
 from meepoembedding_amd.nn import DynamicEmbedding, lookup, lookup_located
 
 
@@ -81,7 +81,7 @@ def test_dynamic_embedding_trains_like_torch_sparse_adagrad(dev):
                           test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
     rows, slots = lookup_located(k, layer._anchor, layer.table_id, True)
     assert rows.shape == (3, 4, dim) and slots.shape == (12,) and bool((slots >= 0).all())
-    assert torch.equal(slots, table.locate(k.view(-1))[0])
+    assert torch.equal(slots & _lib.HANDLE_SLOT_MASK, table.locate(k.view(-1))[0])   # handle = slot + layout epoch (bits 40..61)
 
 
 @pytest.mark.gpu
