@@ -85,14 +85,47 @@ def _physical_cores(allowed) -> int:
     return len(seen)
 
 
+def _cpu_quota():
+    """CPUs' worth of run time the cgroup grants this process (cgroup v2 cpu.max — the container's own file or, from /proc/self/cgroup, any
+    ancestor's — or the v1 cfs quota), or None when unlimited / unreadable"""
+    def v2(path):
+        try:
+            q, p = open(path).read().split()[:2]
+            return None if q == "max" else float(q) / float(p)
+        except (OSError, ValueError):
+            return None
+    best = v2("/sys/fs/cgroup/cpu.max")
+    try:
+        for ln in open("/proc/self/cgroup"):
+            parts = ln.strip().split(":", 2)
+            if len(parts) == 3 and parts[0] == "0":
+                d = parts[2].rstrip("/")
+                while d:
+                    q = v2("/sys/fs/cgroup" + d + "/cpu.max")
+                    best = q if (q is not None and (best is None or q < best)) else best
+                    d = d.rsplit("/", 1)[0]
+    except OSError:
+        pass
+    if best is not None:
+        return best
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(synth, dim, batch, n_keys_config, load, budget_s=16.0):
     """In-repo CPU oracle find (persistent worker pool) on the configuration the GPU number is quoted on: configs[1]'s table (100M keys,
     dim 64, load 0.75: 35 GB of host DRAM) when the box has >= 64 GB available, else the largest table that fits (stated in `sample`);
     uniform 256K-key batches; 1 thread, one thread per physical core, every hardware thread.  `value` = the best of them."""
     import oracle
     allowed = sorted(os.sched_getaffinity(0))
-    cores = max(1, min(os.cpu_count() or 1, len(allowed)))   # SURVEY 8d: std::thread::hardware_concurrency, here the affinity mask
-    phys = _physical_cores(allowed) or max(1, cores // 2)
+    hw_threads = max(1, min(os.cpu_count() or 1, len(allowed)))   # SURVEY 8d: std::thread::hardware_concurrency, here the affinity mask
+    quota = _cpu_quota()   # a container's CPU bandwidth limit (cgroup): threads beyond it only take turns on the same CPU time
+    cores = max(1, min(hw_threads, int(quota + 0.999))) if quota else hw_threads
+    phys = min(cores, _physical_cores(allowed) or max(1, cores // 2))
     avail = 0
     try:
         for ln in open("/proc/meminfo"):
@@ -125,7 +158,9 @@ def cpu_baseline(synth, dim, batch, n_keys_config, load, budget_s=16.0):
     t.find(batches[0][:4096], out=out[:4096], found=fnd[:4096])
     assert bool(fnd[:4096].all()) and np.array_equal(out[:4096], synth.rows_np(batches[0][:4096], dim, 2)), "CPU baseline returned wrong rows"
     res = {}
-    counts = sorted({1, min(16, cores), phys, cores})   # 1 thread, a 1-GPU box's usual CPU share, one per physical core, every hardware thread
+    # 1 thread, one per physical core, every hardware thread the process can actually run at once (affinity mask, capped by the cgroup's CPU
+    # quota); under a quota also twice that, to show that threads beyond the quota only take turns
+    counts = sorted({1, phys, cores} | ({min(hw_threads, 2 * cores)} if quota else {min(16, cores)}))
     for threads in counts:
         t.find(batches[0], threads=threads, out=out, found=fnd)  # warm-up (creates the pool's threads)
         done, t0 = 0, time.perf_counter()
@@ -136,7 +171,8 @@ def cpu_baseline(synth, dim, batch, n_keys_config, load, budget_s=16.0):
     t.close()
     best = max(res, key=res.get)
     return {"value": res[best], "unit": "key-lookups/s", "cores": best, "kind": "port",
-            "single_thread_value": res[1], "hardware_threads": cores, "physical_cores": phys, "hardware_concurrency": os.cpu_count(),
+            "single_thread_value": res[1], "usable_hardware_threads": cores, "physical_cores": phys, "hardware_concurrency": os.cpu_count(),
+            "affinity_mask_cpus": hw_threads, "cgroup_cpu_quota": quota,
             "by_threads": {str(k): v for k, v in res.items()}, "table_keys": n_keys, "table_fill_seconds": fill_s,
             "host_mem_available_gb": round(avail / 2 ** 30, 1),
             "sample": f"in-repo CPU oracle (reference snapshot has no implementation), persistent worker pool: find on a {n_keys // 1_000_000}M-key dim-{dim} "

@@ -1,0 +1,669 @@
+// meepo_apply.hip — the bucketed sparse-optimizer apply (SPEC.md §4): duplicate-key reduction without a global group table.
+//
+// Reference anchor: /root/reference/README.md:2 (no code upstream); BASELINE.json north_star: "the sparse-optimizer (Adagrad/Adam)
+// scatter-update … wavefront ballot/prefix-sum for duplicate-key reduction".
+//
+// The group-table apply (meepo_table.hip) pays, per key of a batch, one scattered atomic to claim an entry of a global table, one scattered
+// read of that entry in the main pass and one scattered store to release it — ~30 us of a 256K-key batch that has (almost) no duplicates —
+// plus three dependent launches for the duplicates.  Here the batch is first PARTITIONED by the top bits of mix64(key) into buckets of
+// 128..256 positions (two small kernels, LDS histograms, no global atomics), and then ONE kernel gives every bucket to one 512-thread
+// block: all occurrences of a key are in the same bucket, so the block finds the batch's duplicates in an LDS hash table, sorts the
+// bucket's positions by key with LDS prefix sums, and its 32 tiles update each distinct key once — a key that occurs once straight from
+// its gradient row (bit-exact), a key that occurs c times from the fp64 sum of its c rows (runs of more than 32 are cut into chunks
+// whose fp64 partial rows the block combines itself).  Three launches per apply whatever the key distribution, no per-key global atomic,
+// nothing to clean up afterwards.
+//
+// A bucket that a hot key makes larger than one block's LDS (512 positions) is SPLIT: its slabs of 512 positions go to blocks of their
+// own (listed first, so they start first), each slab emits one pending record per distinct key (key + fp64 partial sum), and the slab
+// that finishes last — an agent-scope release / ticket / acquire hand-off, no block ever waits for another — merges the bucket's records
+// with the same LDS machinery and applies the updates.  A key with 21 000 occurrences in a 256K-key batch (Zipf 1.05) is summed by 41
+// blocks on 41 CUs, not by one.
+//
+// Bucket = top bits of mix64(key) = the bits that pick the key's table bucket (mulhi64): a block's keys live in one contiguous 1/n_buckets
+// slice of the table.
+#include <hip/hip_runtime.h>
+
+#include "meepo_table_int.h"
+
+namespace mee {
+
+constexpr int kPartBlocks = 64;           // blocks of the two partition kernels
+constexpr int kPartThreads = 1024;
+constexpr uint32_t kSlab = 512;           // positions one apply block takes (= its thread count): what its LDS hash table holds at load 0.5
+constexpr int kApplyThreads = 512;
+constexpr int kApplyWaves = kApplyThreads / 64;
+constexpr uint32_t kLdsSlots = 2 * kSlab;
+constexpr uint32_t kBucketTarget = 256;   // positions per bucket aimed at (128..256 once the bucket count is a power of two)
+constexpr uint32_t kMaxBuckets = 8192;    // the partition kernels keep one LDS counter per bucket
+constexpr uint32_t kRun = 32;             // occurrences one tile sums in one go; longer runs are cut into chunks of this many
+
+uint32_t bucket_count_for(uint64_t n) {
+    uint32_t nbk = 1;
+    while ((uint64_t)nbk * kBucketTarget < n && nbk < kMaxBuckets) nbk <<= 1;
+    return nbk;
+}
+static uint32_t log2_of(uint32_t pow2) { uint32_t l = 0; while ((1u << l) < pow2) ++l; return l; }
+static uint32_t max_units_for(uint64_t n) { return bucket_count_for(n) + (uint32_t)(n / kSlab) + 2; }
+
+__device__ __forceinline__ uint32_t apply_bucket_of(int64_t key, uint32_t lb) { return lb ? (uint32_t)(mix64((uint64_t)key) >> (64 - lb)) : 0u; }
+
+// exclusive prefix sum of a packed 64-bit value over a block of NW waves; every field of the packed value must stay below its width
+template <int NW>
+__device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v, unsigned long long* wsum /*[NW]*/, unsigned long long& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    __syncthreads();   // wsum may still be read from an earlier call
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    unsigned long long pre = 0, tot = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) { const unsigned long long x = wsum[ww]; if (ww < w) pre += x; tot += x; }
+    total = tot;
+    return pre + incl - v;
+}
+
+// ---- partition, kernel 1: every partition block sorts ITS share of the batch by bucket, inside its own contiguous slice of pos / pkey ------
+// (LDS histogram -> in-block prefix sum -> LDS cursors).  A block's writes stay inside its slice (16 KB + 32 KB at 4096 keys), i.e. in one
+// XCD's L2, where the 4- and 8-byte stores combine into whole lines.  (The first version scattered every key straight to its bucket's global
+// position: 256K keys = 512K partial-line stores from 64 CUs on 8 XCDs into the same lines — 19 us; and it needed a count kernel in front.)
+// Per (block, bucket) it leaves the run's length and its start inside the slice: the apply kernel pulls a bucket's entries out of the
+// <= 64 slices (short contiguous reads), the units kernel needs only the lengths.
+__global__ __launch_bounds__(kPartThreads) void bkt_sort_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk, uint32_t lb,
+                                                                uint32_t per_block, BucketScratch bk, uint32_t* status) {
+    extern __shared__ uint32_t cursor[];
+    __shared__ unsigned long long wsum[kPartThreads / 64];
+    constexpr uint32_t kMaxPerThread = kMaxBuckets / kPartThreads;
+    for (uint32_t j = threadIdx.x; j < nbk; j += kPartThreads) cursor[j] = 0u;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
+    bool bad = false;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += kPartThreads) {
+        const int64_t k = keys[i];
+        if (!reserved_key(k)) atomicAdd(&cursor[apply_bucket_of(k, lb)], 1u);
+        else bad = bad || k == kReclaimed;   // EMPTY = padding, silent (SPEC.md §2)
+    }
+    if (bad) atomicOr(status, (uint32_t)MEE_STATUS_RESERVED_KEY);
+    __syncthreads();
+    const uint32_t per_t = (nbk + kPartThreads - 1) / kPartThreads;   // buckets [t * per_t, (t + 1) * per_t) belong to thread t
+    uint32_t c[kMaxPerThread];
+    unsigned long long sum = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kMaxPerThread; ++q) {
+        const uint32_t b = threadIdx.x * per_t + q;
+        c[q] = (q < per_t && b < nbk) ? cursor[b] : 0u;
+        sum += c[q];
+    }
+    unsigned long long total;
+    uint32_t start = (uint32_t)block_scan_u64<kPartThreads / 64>(sum, wsum, total);
+#pragma unroll
+    for (uint32_t q = 0; q < kMaxPerThread; ++q) {
+        const uint32_t b = threadIdx.x * per_t + q;
+        if (q < per_t && b < nbk) {
+            bk.cnt_mat[(uint64_t)blockIdx.x * nbk + b] = c[q];
+            bk.off_mat[(uint64_t)blockIdx.x * nbk + b] = start;
+            cursor[b] = start;
+            start += c[q];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += kPartThreads) {
+        const int64_t k = keys[i];
+        if (reserved_key(k)) continue;
+        const uint32_t r = lo + atomicAdd(&cursor[apply_bucket_of(k, lb)], 1u);
+        bk.pos[r] = i;
+        bk.pkey[r] = k;
+    }
+}
+
+// ---- partition, kernel 2 (one block): bucket sizes -> bucket offsets (the base of a split bucket's pending records) and the work-unit list --
+__global__ __launch_bounds__(kPartThreads) void bkt_units_kernel(uint32_t nbk, uint32_t n_blocks, BucketScratch bk, OpCounters* op) {
+    __shared__ unsigned long long wsum[kPartThreads / 64];
+    constexpr uint32_t kMaxPerThread = kMaxBuckets / kPartThreads;
+    const uint32_t per_t = (nbk + kPartThreads - 1) / kPartThreads;
+    uint32_t tot[kMaxPerThread];
+    unsigned long long packed = 0;   // bits 0..31 positions | 32..47 units of split buckets | 48..63 units of whole buckets
+#pragma unroll
+    for (uint32_t q = 0; q < kMaxPerThread; ++q) {
+        tot[q] = 0u;
+        const uint32_t b = threadIdx.x * per_t + q;
+        if (q < per_t && b < nbk) {
+#pragma unroll 8   // independent loads, eight in flight (one at a time this loop alone took 20 us)
+            for (uint32_t k = 0; k < n_blocks; ++k) tot[q] += bk.cnt_mat[(uint64_t)k * nbk + b];
+            const uint32_t ns = tot[q] > kSlab ? (tot[q] + kSlab - 1) / kSlab : (tot[q] ? 1u : 0u);
+            packed += (unsigned long long)tot[q] | (ns > 1 ? (unsigned long long)ns << 32 : (unsigned long long)ns << 48);
+        }
+    }
+    unsigned long long total;
+    const unsigned long long ex = block_scan_u64<kPartThreads / 64>(packed, wsum, total);
+    uint32_t pos0 = (uint32_t)ex, su0 = (uint32_t)(ex >> 32) & 0xFFFFu, nu0 = (uint32_t)(ex >> 48);
+    const uint32_t split_units = (uint32_t)(total >> 32) & 0xFFFFu, whole_units = (uint32_t)(total >> 48);
+#pragma unroll
+    for (uint32_t q = 0; q < kMaxPerThread; ++q) {
+        const uint32_t b = threadIdx.x * per_t + q;
+        if (q < per_t && b < nbk) {
+            bk.off[b] = pos0; bk.pend_cnt[b] = 0u; bk.ticket[b] = 0u;
+            const uint32_t ns = tot[q] > kSlab ? (tot[q] + kSlab - 1) / kSlab : (tot[q] ? 1u : 0u);
+            if (ns > 1) { for (uint32_t s = 0; s < ns; ++s) bk.units[su0 + s] = make_uint2(b, s); su0 += ns; }   // split buckets first: they take longest
+            else if (ns == 1) { bk.units[split_units + nu0] = make_uint2(b, 0u); ++nu0; }
+            pos0 += tot[q];
+        }
+    }
+    if (threadIdx.x == 0) {
+        bk.off[nbk] = (uint32_t)total;
+        *bk.n_units = split_units + whole_units;
+        op->n_part = 0u;   // fp64 partial rows of long runs are handed out from BatchScratch::gacc by the apply kernel
+    }
+}
+
+// ---- the apply kernel -------------------------------------------------------------------------------------------------------------
+struct ApplyLds {
+    unsigned long long key[kLdsSlots];   // key ^ kBias, 0 = empty
+    long long slot[kLdsSlots];           // per run: the table slot its handle names (LOCATED kernels)
+    uint32_t cnt[kLdsSlots];             // occurrences of the run's key in this slab
+    uint32_t off[kLdsSlots];             // where the run starts in src
+    uint32_t run[kLdsSlots];             // slabs of split buckets: the run's pending-record number inside the slab
+    uint32_t src[kSlab];                 // the slab's sources sorted by run: gradient-row index (positions) | pending-record index (merge)
+    uint32_t items[kSlab + 32];          // work items: run slot | chunk << 10 | partial row << 15
+    uint32_t big[32];                    // runs longer than kRun: run slot | first partial row << 10 | chunks << 20
+    unsigned long long wsum[kApplyWaves];
+    unsigned long long stk_val[72];      // merge: hash prefixes still to do
+    uint32_t stk_bits[72];
+    unsigned long long kmin, kmax;       // merge: smallest / largest biased key among a pass's candidates (equal: the pass holds ONE key)
+    uint32_t seg_first[kPartBlocks + 1]; // where partition block k's entries of this bucket begin within the bucket (prefix of the run lengths)
+    uint32_t seg_at[kPartBlocks];        // ... and where that run lies in pos / pkey
+    uint32_t n_items, n_big, n_runs, part_base, rec_base, is_last, n_cand, stk_n;
+};
+
+struct ApplyArgs {
+    const int64_t* tkeys; float4 *values, *s1, *s2; uint64_t nb; uint32_t dim4;
+    const float4* grads; const uint32_t* gidx; const int64_t* slots;
+    uint64_t capacity; int64_t handle_tag; uint32_t* status;
+    double* part; uint32_t max_part;     // fp64 partial rows of long runs (BatchScratch::gacc)
+    uint32_t nbk, part_blocks, per_block;   // the partition: buckets, partition blocks, batch positions per partition block
+    OpCounters* op;
+    OptArgs a;
+};
+
+// One slab: m <= kSlab sources -> one update (or one pending record) per distinct key.
+//   src_rec = false: the sources are entries [first, first + m) of bucket b (batch positions + keys, pulled out of the partition blocks' slices
+//                    of bk.pos / bk.pkey); a source's row is a row of grads.
+//   src_rec = true : (merge of a split bucket) the sources are the pending records whose bucket-relative numbers lie in L.src[0 .. m); a
+//                    source's row is the record's fp64 partial sum.
+//   emit: results become pending records of bucket `b` instead of table updates (slab of a split bucket).
+// ONE inlined instance per kernel (the kernel loops over it: slab first, merge passes after): as two instances the merge copy pushed the
+// kernel from 64 to 113 VGPRs, i.e. the hot path of every block from 4 to 2 resident blocks per CU (-10 us per 256K-key batch).
+template <int KIND, int DIM4, bool LOCATED>
+__device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, uint32_t first, uint32_t m, bool emit, bool src_rec,
+                                             uint32_t b) {
+    // The kernel calls this from a loop (slab, then merge passes).  The thread index is re-read through an empty asm in every call so that
+    // nothing derived from it looks loop-invariant: hoisted out of that loop, the per-thread address arithmetic of every array touched in
+    // here stayed live across the whole kernel (110 VGPRs instead of 64: half the resident blocks per CU for every block's hot path).
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6;
+    const uint32_t dim4 = DIM4 ? DIM4 : A.dim4;
+    const uint32_t rec_bucket0 = bk.off[b];   // the bucket's first pending record (records never outnumber the bucket's positions)
+    OptArgs a = A.a;
+    a.kind = KIND;
+    // ---- 1. the slab's keys into the LDS hash table: run = LDS slot, r = arrival number inside the run ----
+    uint32_t my_src = 0;
+    if (src_rec) my_src = t < m ? L.src[t] : 0u;   // read before the table is cleared / src is rewritten
+    else if (t < 64) {
+        // the bucket's entries lie in <= kPartBlocks runs, one per partition block: lane k of wave 0 fetches run k's length and place, a wave
+        // scan turns the lengths into the run's first index within the bucket
+        const uint32_t k = t, len = k < A.part_blocks ? bk.cnt_mat[(uint64_t)k * A.nbk + b] : 0u;
+        uint32_t incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d);
+            if ((int)t >= d) incl += v;
+        }
+        L.seg_first[k] = incl - len;
+        if (k == 63) L.seg_first[64] = incl;
+        L.seg_at[k] = k < A.part_blocks ? k * A.per_block + bk.off_mat[(uint64_t)k * A.nbk + b] : 0u;
+    }
+    __syncthreads();
+    for (uint32_t j = t; j < kLdsSlots; j += kApplyThreads) { L.key[j] = 0ull; L.cnt[j] = 0u; }
+    if (t == 0) { L.n_big = 0u; }
+    __syncthreads();
+    uint32_t my_slot = 0, my_r = 0;
+    if (t < m) {
+        int64_t key;
+        int64_t tslot = -1;   // LOCATED: the table slot of the key (decoded handle | carried by the record)
+        if (src_rec) {
+            key = bk.pend_key[rec_bucket0 + my_src];
+            if constexpr (LOCATED) tslot = bk.pend_slot[rec_bucket0 + my_src];
+        } else {
+            const uint32_t gi = first + t;   // index within the bucket -> its run (binary search over the 64 run starts) -> its place in pos / pkey
+            uint32_t k = 0;
+#pragma unroll
+            for (uint32_t stp = kPartBlocks / 2; stp; stp >>= 1) if (L.seg_first[k + stp] <= gi) k += stp;
+            const uint32_t at = L.seg_at[k] + (gi - L.seg_first[k]);
+            const uint32_t p = bk.pos[at];
+            key = bk.pkey[at];
+            my_src = A.gidx ? min(A.gidx[p], a.grad_rows - 1) : p;   // the row of the grad array that belongs to the position
+            if constexpr (LOCATED) {
+                bool stale;
+                tslot = handle_slot(A.slots[p], A.handle_tag, A.capacity, stale);
+                if (stale) atomicOr(A.status, (uint32_t)MEE_STATUS_STALE_HANDLE);   // rare: the caller kept handles across a remove / clear / reserve
+            }
+        }
+        const unsigned long long bkey = (unsigned long long)key ^ kBias;
+        my_slot = (uint32_t)(mix64b((uint64_t)key) & (kLdsSlots - 1));   // mix64's top bits chose the bucket: take another mixer here
+        bool first_of_run = false;
+        while (true) {
+            const unsigned long long old = atomicCAS(&L.key[my_slot], 0ull, bkey);
+            if (old == 0ull) { first_of_run = true; break; }
+            if (old == bkey) break;
+            my_slot = (my_slot + 1) & (kLdsSlots - 1);
+        }
+        my_r = atomicAdd(&L.cnt[my_slot], 1u);
+        if constexpr (LOCATED) {
+            if (first_of_run) L.slot[my_slot] = tslot;   // every occurrence of a key names the same slot: the run keeps one
+        }
+    }
+    __syncthreads();
+    // ---- 2. prefix sums over the runs: where each run starts in src, its work items, its number, its fp64 partial rows ----
+    {
+        const uint32_t s0 = 2 * t, c0 = L.cnt[s0], c1 = L.cnt[s0 + 1];
+        const uint32_t i0 = (c0 + kRun - 1) / kRun, i1 = (c1 + kRun - 1) / kRun;
+        const uint32_t p0 = c0 > kRun ? i0 : 0u, p1 = c1 > kRun ? i1 : 0u;
+        // bits 0..15 sources | 16..31 items | 32..47 runs | 48..63 partial rows — each at most kSlab + kSlab / kRun
+        const unsigned long long packed = (unsigned long long)(c0 + c1) | (unsigned long long)(i0 + i1) << 16 |
+                                          (unsigned long long)((c0 != 0) + (c1 != 0)) << 32 | (unsigned long long)(p0 + p1) << 48;
+        unsigned long long total;
+        const unsigned long long ex = block_scan_u64<kApplyWaves>(packed, L.wsum, total);
+        uint32_t so = (uint32_t)ex & 0xFFFFu, io = (uint32_t)(ex >> 16) & 0xFFFFu, ro = (uint32_t)(ex >> 32) & 0xFFFFu, po = (uint32_t)(ex >> 48);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t s = s0 + h, c = h ? c1 : c0, ni = h ? i1 : i0;
+            L.off[s] = so;
+            if (c) {
+                L.run[s] = ro;
+#pragma unroll 1   // (unrolled 16-fold this loop alone held 40 VGPRs of precomputed item words)
+                for (uint32_t j = 0; j < ni; ++j) L.items[io + j] = s | j << 10 | (c > kRun ? (po + j) << 15 : 0u);
+                if (c > kRun) { L.big[atomicAdd(&L.n_big, 1u)] = s | po << 10 | ni << 20; po += ni; }
+                so += c; io += ni; ++ro;
+            }
+        }
+        if (t == 0) {
+            L.n_items = (uint32_t)(total >> 16) & 0xFFFFu;
+            L.n_runs = (uint32_t)(total >> 32) & 0xFFFFu;
+            const uint32_t np = (uint32_t)(total >> 48);
+            uint32_t pb = np ? atomicAdd(&A.op->n_part, np) : 0u;
+            if (pb + np > A.max_part) pb = 0u;   // cannot happen (sum of ceil(c / kRun) over runs longer than kRun <= n / 32 + n / 33); never write out of bounds
+            L.part_base = pb;
+            if (emit) L.rec_base = atomicAdd(&bk.pend_cnt[b], L.n_runs);
+        }
+    }
+    __syncthreads();
+    if (t < m) L.src[L.off[my_slot] + my_r] = my_src;
+    __syncthreads();
+    const uint32_t n_items = L.n_items, n_big = L.n_big;
+    const uint32_t rec_out0 = rec_bucket0 + (emit ? L.rec_base : 0u);   // emit: where this slab's records go
+    // ---- 3. work items: one tile each ----
+    for (uint32_t it0 = (uint32_t)wv * 4; it0 < n_items; it0 += kApplyWaves * 4) {   // block-uniform bound: the ballots inside tile_locate need whole waves
+        const uint32_t item = it0 + tile;
+        const bool valid = item < n_items;
+        const uint32_t e = valid ? L.items[item] : 0u;
+        const uint32_t s = e & 1023u, chunk = (e >> 10) & 31u, prow = e >> 15;
+        const uint32_t c = valid ? L.cnt[s] : 0u;
+        const uint32_t run0 = L.off[s] + kRun * chunk;
+        const uint32_t nh = valid ? min(kRun, c - kRun * chunk) : 0u;
+        const bool whole = valid && c <= kRun;   // the run is this one item
+        const bool fin = whole && !emit;         // finished here: locate the row, update it once
+        const bool single = !src_rec && fin && c == 1;
+        const int64_t key = (int64_t)(L.key[s] ^ kBias);
+        const uint32_t src0 = valid ? L.src[run0] : 0u;
+        f32x4 gpre = {0.f, 0.f, 0.f, 0.f};
+        // a key that occurs once (the bulk): its gradient row is read exactly once — stream it, and request it before anything else
+        if (single && (uint32_t)tl < dim4) gpre = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A.grads) + (uint64_t)src0 * dim4 + tl);
+        int64_t slot = -1;
+        if constexpr (LOCATED) slot = valid ? (int64_t)L.slot[s] : -1;
+        else {
+            bool is_new, full;
+            slot = tile_locate<false, false>(const_cast<int64_t*>(A.tkeys), A.nb, key, fin, tile, tl, is_new, full);
+        }
+        if (!valid) continue;
+        const bool upd = fin && slot >= 0;
+        for (uint32_t col = tl; col < dim4; col += 16) {
+            const uint64_t o = upd ? (uint64_t)slot * dim4 + col : 0;
+            if (single) {   // gradient row (already requested) + the key's row -> update -> store; nothing else is live here
+                if (upd) {
+                    float4 w = A.values[o], x1 = A.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (KIND == MEE_OPT_ADAM) x2 = A.s2[o];
+                    const float4 g = col == (uint32_t)tl ? make_float4(gpre.x, gpre.y, gpre.z, gpre.w) : A.grads[(uint64_t)src0 * dim4 + col];
+                    opt_update4(a, w, x1, x2, g);
+                    A.values[o] = w; A.s1[o] = x1;
+                    if (KIND == MEE_OPT_ADAM) A.s2[o] = x2;
+                }
+                continue;
+            }
+            double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+            if (src_rec) {
+                for (uint32_t q0 = 0; q0 < nh; q0 += 2) {   // two fp64 rows in flight; a lane past the end reads the last row again and adds +0.0
+                    double2 lo[2], hi[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const double2* r = reinterpret_cast<const double2*>(bk.pend_row + ((uint64_t)(rec_bucket0 + L.src[run0 + min(q0 + q, nh - 1)]) * dim4 + col) * 4);
+                        lo[q] = r[0]; hi[q] = r[1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const bool on = q0 + q < nh;
+                        sx += on ? lo[q].x : 0.0; sy += on ? lo[q].y : 0.0; sz += on ? hi[q].x : 0.0; sw += on ? hi[q].y : 0.0;
+                    }
+                }
+            } else {
+                for (uint32_t q0 = 0; q0 < nh; q0 += 4) {   // four rows in flight, no one-row-at-a-time tail (see chunk_sum in meepo_table.hip)
+                    float4 gq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gq[q] = A.grads[(uint64_t)L.src[run0 + min(q0 + q, nh - 1)] * dim4 + col];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool on = q0 + q < nh;
+                        sx += on ? (double)gq[q].x : 0.0; sy += on ? (double)gq[q].y : 0.0; sz += on ? (double)gq[q].z : 0.0; sw += on ? (double)gq[q].w : 0.0;
+                    }
+                }
+            }
+            if (fin) {
+                if (upd) {
+                    float4 w = A.values[o], x1 = A.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (KIND == MEE_OPT_ADAM) x2 = A.s2[o];
+                    opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
+                    A.values[o] = w; A.s1[o] = x1;
+                    if (KIND == MEE_OPT_ADAM) A.s2[o] = x2;
+                }
+            } else {   // a chunk of a long run -> one fp64 partial row of this block | a whole run of a split bucket's slab -> its pending record
+                double2* dst = whole ? reinterpret_cast<double2*>(bk.pend_row + ((uint64_t)(rec_out0 + L.run[s]) * dim4 + col) * 4)
+                                     : reinterpret_cast<double2*>(A.part + ((uint64_t)(L.part_base + prow) * dim4 + col) * 4);
+                dst[0] = make_double2(sx, sy); dst[1] = make_double2(sz, sw);
+            }
+        }
+        if (!fin && whole && tl == 0) {
+            bk.pend_key[rec_out0 + L.run[s]] = key;
+            if constexpr (LOCATED) bk.pend_slot[rec_out0 + L.run[s]] = slot;
+        }
+    }
+    if (n_big == 0) return;   // block-uniform
+    // ---- 4. runs longer than kRun: one tile adds the run's chunk sums (written by this block: visible after the barrier) and finishes the run ----
+    __syncthreads();
+    for (uint32_t k0 = (uint32_t)wv * 4; k0 < n_big; k0 += kApplyWaves * 4) {
+        const uint32_t k = k0 + tile;
+        const bool valid = k < n_big;
+        const uint32_t e = valid ? L.big[k] : 0u;
+        const uint32_t s = e & 1023u, p0 = (e >> 10) & 1023u, np = e >> 20;
+        const bool fin = valid && !emit;
+        const int64_t key = (int64_t)(L.key[s] ^ kBias);
+        int64_t slot = -1;
+        if constexpr (LOCATED) slot = valid ? (int64_t)L.slot[s] : -1;
+        else {
+            bool is_new, full;
+            slot = tile_locate<false, false>(const_cast<int64_t*>(A.tkeys), A.nb, key, fin, tile, tl, is_new, full);
+        }
+        if (!valid) continue;
+        const bool upd = fin && slot >= 0;
+        for (uint32_t col = tl; col < dim4; col += 16) {
+            const uint64_t o = upd ? (uint64_t)slot * dim4 + col : 0;
+            double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+            for (uint32_t q0 = 0; q0 < np; q0 += 2) {
+                double2 lo[2], hi[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const double2* r = reinterpret_cast<const double2*>(A.part + ((uint64_t)(L.part_base + p0 + min(q0 + q, np - 1)) * dim4 + col) * 4);
+                    lo[q] = r[0]; hi[q] = r[1];
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bool on = q0 + q < np;
+                    sx += on ? lo[q].x : 0.0; sy += on ? lo[q].y : 0.0; sz += on ? hi[q].x : 0.0; sw += on ? hi[q].y : 0.0;
+                }
+            }
+            if (fin) {
+                if (upd) {
+                    float4 w = A.values[o], x1 = A.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (KIND == MEE_OPT_ADAM) x2 = A.s2[o];
+                    opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
+                    A.values[o] = w; A.s1[o] = x1;
+                    if (KIND == MEE_OPT_ADAM) A.s2[o] = x2;
+                }
+            } else {
+                double2* dst = reinterpret_cast<double2*>(bk.pend_row + ((uint64_t)(rec_out0 + L.run[s]) * dim4 + col) * 4);
+                dst[0] = make_double2(sx, sy); dst[1] = make_double2(sz, sw);
+            }
+        }
+        if (!fin && tl == 0) {
+            bk.pend_key[rec_out0 + L.run[s]] = key;
+            if constexpr (LOCATED) bk.pend_slot[rec_out0 + L.run[s]] = slot;
+        }
+    }
+}
+
+// Merge, one key with more records than a pass holds (a key that is a large share of a large batch: more than kSlab slabs each hold it): every
+// tile adds the records j = its number, +32, +64, … of bucket records [beg, beg + R) that carry `key` into one fp64 partial row, the rows are
+// combined after a barrier, the key is updated once.
+template <int KIND, int DIM4, bool LOCATED>
+__device__ __forceinline__ void mono_pass(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, uint32_t beg, uint32_t R, int64_t key, uint32_t any_rec) {
+    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15, wv = threadIdx.x >> 6;
+    const uint32_t dim4 = DIM4 ? DIM4 : A.dim4, q = (uint32_t)wv * 4 + tile;
+    constexpr uint32_t kTiles = kApplyWaves * 4;
+    OptArgs a = A.a;
+    a.kind = KIND;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t pb = atomicAdd(&A.op->n_part, kTiles);
+        if (pb + kTiles > A.max_part) pb = 0u;   // (see process_slab)
+        L.part_base = pb;
+    }
+    __syncthreads();
+    for (uint32_t col = tl; col < dim4; col += 16) {
+        double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+        for (uint32_t j0 = q; j0 < R; j0 += 2 * kTiles) {   // two records in flight; rows are read unconditionally (valid addresses), added only on a match
+            double2 lo[2], hi[2];
+            bool on[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t j = min(j0 + (uint32_t)u * kTiles, R - 1);
+                on[u] = j0 + (uint32_t)u * kTiles < R && bk.pend_key[beg + j] == key;
+                const double2* r = reinterpret_cast<const double2*>(bk.pend_row + ((uint64_t)(beg + j) * dim4 + col) * 4);
+                lo[u] = r[0]; hi[u] = r[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { sx += on[u] ? lo[u].x : 0.0; sy += on[u] ? lo[u].y : 0.0; sz += on[u] ? hi[u].x : 0.0; sw += on[u] ? hi[u].y : 0.0; }
+        }
+        double2* dst = reinterpret_cast<double2*>(A.part + ((uint64_t)(L.part_base + q) * dim4 + col) * 4);
+        dst[0] = make_double2(sx, sy); dst[1] = make_double2(sz, sw);
+    }
+    __syncthreads();   // the partial rows were written by this block: visible to its tile 0 after the barrier
+    int64_t slot;
+    if constexpr (LOCATED) slot = bk.pend_slot[beg + any_rec];   // every record of the key carries its slot
+    else {
+        bool is_new, full;
+        slot = tile_locate<false, false>(const_cast<int64_t*>(A.tkeys), A.nb, key, q == 0, tile, tl, is_new, full);
+    }
+    if (q == 0 && slot >= 0)
+        for (uint32_t col = tl; col < dim4; col += 16) {
+            double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+#pragma unroll 2   // (fully unrolled, the 32 rows' loads held 128 VGPRs: this rare path must not set the kernel's register count)
+            for (uint32_t u = 0; u < kTiles; ++u) {
+                const double2* r = reinterpret_cast<const double2*>(A.part + ((uint64_t)(L.part_base + u) * dim4 + col) * 4);
+                sx += r[0].x; sy += r[0].y; sz += r[1].x; sw += r[1].y;
+            }
+            const uint64_t o = (uint64_t)slot * dim4 + col;
+            float4 w = A.values[o], x1 = A.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KIND == MEE_OPT_ADAM) x2 = A.s2[o];
+            opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
+            A.values[o] = w; A.s1[o] = x1;
+            if (KIND == MEE_OPT_ADAM) A.s2[o] = x2;
+        }
+    __syncthreads();
+}
+
+// MEE_APPLY_WAVES (build-time experiment knob): waves per SIMD the register allocator must leave room for (0 = its own choice)
+#ifndef MEE_APPLY_WAVES
+#define MEE_APPLY_WAVES 0
+#endif
+#if MEE_APPLY_WAVES
+#define MEE_APPLY_BOUNDS __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES)
+#else
+#define MEE_APPLY_BOUNDS __launch_bounds__(kApplyThreads)
+#endif
+template <int KIND, int DIM4, bool LOCATED>
+__global__ MEE_APPLY_BOUNDS void bkt_apply_kernel(ApplyArgs A, BucketScratch bk) {
+    __shared__ ApplyLds L;
+    const uint32_t u = blockIdx.x;
+    if (u >= *bk.n_units) return;
+    const uint2 unit = bk.units[u];
+    const uint32_t b = unit.x, sub = unit.y;
+    const uint32_t beg = bk.off[b], size = bk.off[b + 1] - beg;
+    const bool split = size > kSlab;
+    // the slab first; in a split bucket's LAST slab the same loop then runs the merge passes (src_rec)
+    bool merging = false;
+    uint32_t first = sub * kSlab, m = min(kSlab, size - sub * kSlab), R = 0, bits0 = 0;
+    uint64_t v0 = 0;
+    for (;;) {
+        process_slab<KIND, DIM4, LOCATED>(L, A, bk, first, m, split && !merging, merging, b);
+        if (!merging) {
+            if (!split) return;
+            // ---- slab of a split bucket: publish this slab's pending records, take a ticket; the slab that draws the last ticket merges the
+            // bucket.  (The in-launch hand-off of cdna_hip_programming.md Guideline 16 in its counter form: plain stores, every wave drains
+            // them, one lane releases at agent scope, THEN the ticket; the last arriver acquires at agent scope before any of its waves reads
+            // a record.  No block ever waits for another.)
+            const uint32_t nsub = (size + kSlab - 1) / kSlab;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const uint32_t tk = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                L.is_last = tk == nsub - 1;
+                if (tk == nsub - 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            __syncthreads();
+            if (!L.is_last) return;   // block-uniform
+            // Merge: records of one key must meet in one pass and a pass holds kSlab records, so the records are taken by the low bits of
+            // mix64b(key): `bits0` bits give passes of ~256 records; a pass that still finds more than kSlab splits on one more bit, and a
+            // pass whose records all carry ONE key goes to mono_pass (mix64b is a bijection: the splitting ends).
+            merging = true;
+            R = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&bk.pend_cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // every slab added its runs before its ticket
+            while (((uint64_t)kSlab / 2 << bits0) < R && bits0 < 40) ++bits0;
+            v0 = 0;
+            if (threadIdx.x == 0) L.stk_n = 0u;
+            first = 0;
+        }
+        // ---- the next merge pass: pop a hash prefix, collect its records; too many -> split the prefix (or one key: mono_pass) ----
+        m = 0;
+        while (m == 0) {   // block-uniform
+            __syncthreads();
+            if (L.stk_n == 0) {
+                if (v0 >> bits0) return;   // every prefix done
+                __syncthreads();
+                if (threadIdx.x == 0) { L.stk_n = 1u; L.stk_bits[0] = bits0; L.stk_val[0] = v0; }
+                ++v0;
+                __syncthreads();
+            }
+            const uint32_t top = __builtin_amdgcn_readfirstlane(L.stk_n - 1), bits = __builtin_amdgcn_readfirstlane(L.stk_bits[top]);
+            const unsigned long long val_v = L.stk_val[top];
+            const uint64_t val = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)val_v) |
+                                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(val_v >> 32)) << 32;
+            const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
+            __syncthreads();
+            if (threadIdx.x == 0) { L.stk_n = top; L.n_cand = 0u; L.kmin = ~0ull; L.kmax = 0ull; }
+            __syncthreads();
+            for (uint32_t j = threadIdx.x; j < R; j += kApplyThreads) {
+                const int64_t kj = bk.pend_key[beg + j];
+                if ((mix64b((uint64_t)kj) & mask) != val) continue;
+                const uint32_t q = atomicAdd(&L.n_cand, 1u);
+                if (q < kSlab) L.src[q] = j;
+                atomicMin(&L.kmin, (unsigned long long)kj ^ kBias);
+                atomicMax(&L.kmax, (unsigned long long)kj ^ kBias);
+            }
+            __syncthreads();
+            const uint32_t nc = __builtin_amdgcn_readfirstlane(L.n_cand);
+            if (nc > kSlab) {
+                if (L.kmin == L.kmax) {   // more records of ONE key than a pass holds
+                    mono_pass<KIND, DIM4, LOCATED>(L, A, bk, beg, R, (int64_t)(L.kmin ^ kBias), L.src[0]);
+                } else if (threadIdx.x == 0 && bits < 64 && L.stk_n + 2 <= 72) {
+                    L.stk_bits[L.stk_n] = bits + 1; L.stk_val[L.stk_n] = val; ++L.stk_n;
+                    L.stk_bits[L.stk_n] = bits + 1; L.stk_val[L.stk_n] = val | 1ull << bits; ++L.stk_n;
+                }
+            } else m = nc;
+        }
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------------------
+int bucket_scratch_alloc(mee_table* t) {
+    BucketScratch& bk = t->bk;
+    bk.fast_max = t->max_batch < (uint64_t)kMaxBuckets * kBucketTarget ? t->max_batch : (uint64_t)kMaxBuckets * kBucketTarget;
+    bk.n_buckets_max = bucket_count_for(bk.fast_max);
+    bk.max_units = max_units_for(bk.fast_max);
+    bk.pos = t->bs.occ;   // max_batch entries; the group-table apply and this one never run at the same time on one table
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, uint64_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes); if (e == hipSuccess) t->workspace_bytes += bytes; } };
+    alloc((void**)&bk.pkey, bk.fast_max * 8);
+    alloc((void**)&bk.cnt_mat, (uint64_t)kPartBlocks * bk.n_buckets_max * 4);
+    alloc((void**)&bk.off_mat, (uint64_t)kPartBlocks * bk.n_buckets_max * 4);
+    alloc((void**)&bk.off, ((uint64_t)bk.n_buckets_max + 1) * 4);
+    alloc((void**)&bk.units, (uint64_t)bk.max_units * sizeof(uint2));
+    alloc((void**)&bk.n_units, 4);
+    alloc((void**)&bk.pend_cnt, (uint64_t)bk.n_buckets_max * 4);
+    alloc((void**)&bk.ticket, (uint64_t)bk.n_buckets_max * 4);
+    alloc((void**)&bk.pend_key, bk.fast_max * 8);
+    alloc((void**)&bk.pend_slot, bk.fast_max * 8);
+    alloc((void**)&bk.pend_row, bk.fast_max * (uint64_t)t->dim * sizeof(double));
+    if (e != hipSuccess) return fail(MEE_ERR_OUT_OF_MEMORY, "hipMalloc for the apply scratch: %s", hipGetErrorString(e));
+    return MEE_OK;
+}
+void bucket_scratch_free(mee_table* t) {
+    BucketScratch& bk = t->bk;
+    void* dev[] = {bk.pkey, bk.cnt_mat, bk.off_mat, bk.off, bk.units, bk.n_units, bk.pend_cnt, bk.ticket, bk.pend_key, bk.pend_slot, bk.pend_row};
+    for (void* p : dev) if (p) (void)hipFree(p);
+}
+
+static void part_geometry(uint32_t n, uint32_t& blocks, uint32_t& per_block) {
+    blocks = (n + 4095) / 4096;   // at least 4 keys per thread
+    if (blocks > (uint32_t)kPartBlocks) blocks = kPartBlocks;
+    if (blocks < 1) blocks = 1;
+    per_block = (n + blocks - 1) / blocks;
+}
+
+int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st) {
+    const uint32_t nbk = bucket_count_for(n), lb = log2_of(nbk);
+    uint32_t blocks, per_block;
+    part_geometry(n, blocks, per_block);
+    bkt_sort_kernel<<<blocks, kPartThreads, nbk * 4, st>>>(d_keys, n, nbk, lb, per_block, t->bk, &t->ctr->status);
+    bkt_units_kernel<<<1, kPartThreads, 0, st>>>(nbk, blocks, t->bk, t->op);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const OptArgs& a, const uint32_t* d_gidx, const int64_t* d_slots, hipStream_t st) {
+    ApplyArgs A{};
+    A.tkeys = t->keys; A.values = (float4*)t->values; A.s1 = (float4*)t->s1; A.s2 = (float4*)t->s2; A.nb = t->nb; A.dim4 = t->dim4;
+    A.grads = (const float4*)d_grads; A.gidx = d_gidx; A.slots = d_slots;
+    A.capacity = t->capacity; A.handle_tag = (int64_t)(t->handle_epoch & kHandleEpochMask) << kHandleSlotBits; A.status = &t->ctr->status;
+    A.part = t->bs.gacc; A.max_part = t->bs.max_part; A.op = t->op; A.a = a;
+    A.nbk = bucket_count_for(n);
+    part_geometry(n, A.part_blocks, A.per_block);
+    const unsigned grid = max_units_for(n);
+#define BKT(K, D4, LOC) bkt_apply_kernel<K, D4, LOC><<<grid, kApplyThreads, 0, st>>>(A, t->bk)
+#define BKT_L(K, D4) do { if (d_slots) BKT(K, D4, true); else BKT(K, D4, false); } while (0)
+#define BKT_D(K) do { if (t->dim4 == 16) BKT_L(K, 16); else if (t->dim4 == 32) BKT_L(K, 32); else BKT_L(K, 0); } while (0)
+    if (a.kind == MEE_OPT_ADAGRAD) BKT_D(MEE_OPT_ADAGRAD); else BKT_D(MEE_OPT_ADAM);
+#undef BKT_D
+#undef BKT_L
+#undef BKT
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+}  // namespace mee

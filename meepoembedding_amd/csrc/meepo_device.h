@@ -12,6 +12,8 @@
 
 namespace mee {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // what __builtin_nontemporal_load / _store move as one dwordx4
+
 constexpr int64_t kEmpty = INT64_MIN;
 constexpr int64_t kReclaimed = INT64_MIN + 1;
 constexpr int kW = 16;                                   // bucket width == tile width

@@ -18,8 +18,7 @@
 #include <cstring>
 #include <new>
 
-#include "meepo_device.h"
-#include "meepo_host.h"
+#include "meepo_table_int.h"
 
 namespace mee {
 
@@ -28,98 +27,7 @@ char* last_error_buf() {
     return buf;
 }
 
-struct Counters {            // device-resident, persistent
-    uint32_t status;         // sticky MEE_STATUS_* bits
-    uint32_t election;       // = the epoch of the latest insert whose batch had a position that found its key present (gates its election kernels)
-    uint32_t pad[2];
-};
-struct OpCounters {          // device-resident, zeroed at the start of each op that uses them
-    uint32_t n_uniq;         // distinct keys appended to the unique list
-    uint32_t n_occ;          // occurrence-list entries reserved
-    uint32_t n_big;          // groups with more than kChunk occurrences
-    uint32_t n_work;         // chunk leaders listed for apply_chunk_kernel
-    unsigned long long n_export;  // pairs exported / keys counted
-    uint32_t n_part;         // fp64 partial-sum rows reserved by big groups
-    uint32_t pad;
-    unsigned long long occ_work;  // plan-free apply: occurrence-list entries reserved (low half) | work items listed (high half)
-};
-struct GroupTable {            // S entries, indexed by h
-    // One 16-byte entry per h: ent[2h] = key ^ kBias (0 = empty), ent[2h+1] = the count word below.  Key and count share a 64-byte sector,
-    // so the claim and the count store of group_kernel, the count load of the apply's main pass and the release (ONE 16-byte store) touch
-    // one line per key instead of two.
-    unsigned long long* ent;
-    // count word, low half ("lo"):  COUNT: occurrences added by blocks other than the claimer's (atomicAdd) | LAST: 1 + highest position seen by them (atomicMax)
-    // count word, high half ("hi"): the same quantity of the block whose CAS claimed the entry — a plain store, no atomic.
-    // The pair is one aligned 8-byte word: readers take both halves with ONE load (sv_load), so a reader racing with a release sees
-    // either the complete pair or zeros, never a mixture.
-    uint32_t* soffs;           // start of the group's slice of the occurrence list (hot keys of an apply; dedup)
-    uint32_t* sbig;            // first fp64 partial-sum row of a group with more than kChunk occurrences
-    uint32_t* sgrp;            // index of the group in the unique list (standalone dedup)
-    long long* sres;           // lent out as a per-position slot list by insert / remove
-    uint32_t* inl;             // apply: 16 batch positions per entry (one 64-byte line): [0..7] the claiming block's occurrences of ranks 1..8,
-                               // [8..15] the first 8 occurrences other blocks added — a group that fits is finished by its leader from this one line
-    uint64_t smask;
-};
-__device__ __forceinline__ uint32_t* sv_half(const GroupTable& g, uint32_t h) { return reinterpret_cast<uint32_t*>(g.ent + 2 * (uint64_t)h + 1); }   // [0] = lo, [1] = hi
-__device__ __forceinline__ void sv_load(const GroupTable& g, uint32_t h, uint32_t& lo, uint32_t& hi) {
-    const unsigned long long w = g.ent[2 * (uint64_t)h + 1];
-    lo = (uint32_t)w; hi = (uint32_t)(w >> 32);
-}
-// kGroupApply entries (read while claimed): hi holds the claiming block's count - 1
-__device__ __forceinline__ void cnt_load(const GroupTable& g, uint32_t h, uint32_t& lo, uint32_t& hi) {
-    sv_load(g, h, lo, hi);
-    ++hi;
-}
-__device__ __forceinline__ void group_release_entry(const GroupTable& g, uint32_t h) {
-    reinterpret_cast<ulonglong2*>(g.ent)[h] = make_ulonglong2(0ull, 0ull);
-}
-struct BatchScratch {          // max_batch entries, indexed by batch position unless noted
-    uint32_t *hidx, *rank, *pcnt, *occ, *uniq_h, *work;
-    uint32_t *lead_bits, *filed_bits;   // apply: one bit per batch position (leader of an inline group | occurrence of a filed group); all-zero between applies
-    uint8_t* fmask;            // found mask of find_or_insert's first pass when the caller passes none
-    uint32_t* bigh;            // [max_big] group-table index of each big group
-    double* gacc;              // [max_part][dim] fp64 partial-sum rows: one per chunk of a big group, a group's rows contiguous
-    uint32_t max_part;         // rows of gacc (group_plan_kernel never hands out more)
-};
-
-
 }  // namespace mee
-
-struct mee_table {
-    int device;
-    uint64_t capacity, nb, max_batch;
-    uint32_t dim, dim4, optimizer, initializer, value_memory;
-    float default_value, init_acc, init_scale;
-    uint64_t init_seed;
-    // table planes
-    int64_t* keys;
-    float *values, *s1, *s2;
-    uint32_t* hits;             // per-slot access counter (config.flags & MEE_FLAG_TRACK_HITS), else null
-    uint32_t* sketch;           // admission policy (config.flags & MEE_FLAG_ADMISSION): count-min sketch, 3 rows of 2^sketch_log2w counters
-    uint32_t sketch_log2w;
-    // per-batch scratch: group table (S entries) and per-position arrays (max_batch entries)
-    uint64_t S, max_big, max_part;   // max_big: groups larger than kChunk; max_part: their fp64 partial-sum rows (one per chunk)
-    mee::GroupTable g;
-    mee::BatchScratch bs;
-    mee::Counters* ctr;
-    mee::OpCounters* op;
-    mee::Counters* h_ctr;       // pinned staging for read-backs
-    mee::OpCounters* h_op;
-    uint64_t table_bytes, workspace_bytes;
-    uint64_t generation;        // bumped whenever the planes move (mee_reserve): cached descriptors (mee_group) re-read them
-    uint32_t handle_epoch;      // bumped by every call that can move or free a row (remove / clear / reserve): tags the slot handles of mee_find_located
-    // a prepared (grouped + planned) apply waiting for its grads: mee_apply_prepare .. mee_apply_*
-    uint64_t prepared_n;
-    const int64_t* prepared_keys;
-    uint32_t epoch;             // batch number of insert / apply launches (tags insert's election flag; never 0)
-    // performance knobs (never change results): see mee_set_tuning()
-    int find_rounds;            // keys in flight per tile in the find kernel: 1, 2, 4 or 8
-    int find_grid_cap;          // max blocks of the find grid (0 = one pass, no grid-stride loop)
-    int apply_rounds;           // batch positions in flight per tile in the apply's main pass: 1 or 2 (0 = auto)
-    int find_nt;                // bit0: non-temporal row loads, bit1: non-temporal bucket loads, bit2: plain (cached) out stores;
-                                // -1 = auto: cached loads (hot rows of skewed streams stay in L2), cached stores while the
-                                // dense output fits the Infinity Cache (<= 128 MB), streaming stores beyond
-};
 
 namespace mee {
 
@@ -142,7 +50,6 @@ __global__ void fill_i64_kernel(int64_t* p, uint64_t n, int64_t v) {
 // ---- find (SPEC.md §3) — the headline kernel --------------------------------------------------------------
 // One tile per key, R keys in flight per tile: the R bucket lines are requested back to back, then the R rows.
 // DIM4 = dim/4 when it is a multiple of 16 (each lane moves DIM4/16 float4 per row), 0 = any dim at run time.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // the find of n positions by `n_waves` waves of which this is wave `wave` (each wave step takes 4R consecutive positions)
 template <int DIM4, int R, int NT>
@@ -1099,32 +1006,6 @@ __global__ __launch_bounds__(256) void ensure_direct_kernel(int64_t* tkeys, floa
 }
 
 // ---- sparse optimizers (SPEC.md §4) ------------------------------------------------------------------------
-struct OptArgs {
-    uint32_t kind;       // MEE_OPT_*
-    float lr, eps;       // adagrad: lr; adam: lr unused (step_size)
-    float step_size, omb1, omb2;
-    uint32_t grad_rows;  // indexed apply: rows of the grad array (indices are clamped to it: caller data never reads out of bounds)
-};
-
-__device__ __forceinline__ void opt_update4(const OptArgs& a, float4& w, float4& x1, float4& x2, const float4 g) {
-    if (a.kind == MEE_OPT_ADAGRAD) {
-        adagrad1(w.x, x1.x, g.x, a.lr, a.eps); adagrad1(w.y, x1.y, g.y, a.lr, a.eps);
-        adagrad1(w.z, x1.z, g.z, a.lr, a.eps); adagrad1(w.w, x1.w, g.w, a.lr, a.eps);
-    } else {
-        adam1(w.x, x1.x, x2.x, g.x, a.step_size, a.omb1, a.omb2, a.eps);
-        adam1(w.y, x1.y, x2.y, g.y, a.step_size, a.omb1, a.omb2, a.eps);
-        adam1(w.z, x1.z, x2.z, g.z, a.step_size, a.omb1, a.omb2, a.eps);
-        adam1(w.w, x1.w, x2.w, g.w, a.step_size, a.omb1, a.omb2, a.eps);
-    }
-}
-
-__device__ __forceinline__ void update_row(const OptArgs& a, float4* values, float4* s1, float4* s2, uint64_t o, const float4 g) {
-    float4 w = values[o], x1 = s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.kind == MEE_OPT_ADAM) x2 = s2[o];
-    opt_update4(a, w, x1, x2, g);
-    values[o] = w; s1[o] = x1;
-    if (a.kind == MEE_OPT_ADAM) s2[o] = x2;
-}
 // Where the row of an apply position lives.  Plain tables: probe for the key.  GROUPED (mee_group_apply_*): the batch
 // "keys" are located rows already, member << 48 | slot (meepo_group.hip), and the planes come from the member's descriptor.
 struct RowPlanes { float4 *values, *s1, *s2; };
@@ -1914,6 +1795,7 @@ int mee_table_destroy(mee_table* t) {
     void* dev[] = {t->keys, t->hits, t->sketch, t->g.ent, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres, t->g.inl,
                    t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.lead_bits, t->bs.filed_bits, t->bs.work, t->bs.fmask, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
     for (void* p : dev) if (p) (void)hipFree(p);
+    bucket_scratch_free(t);
     if (t->h_ctr) (void)hipHostFree(t->h_ctr);
     if (t->h_op) (void)hipHostFree(t->h_op);
     delete t;
@@ -2015,6 +1897,9 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
 #undef ALLOC
     t->workspace_bytes = S * (36 + 2 * kInl * 4) + mb * 25 + t->max_big * 4 + (t->bs.gacc ? t->max_part * (uint64_t)t->dim * sizeof(double) : 0) +
                          sizeof(Counters) + sizeof(OpCounters);
+    t->apply_path = -1;
+    if (t->optimizer != MEE_OPT_NONE)   // the bucketed apply's scratch (adds to workspace_bytes)
+        if ((rc = bucket_scratch_alloc(t)) != MEE_OK) goto bad;
     if (hipHostMalloc((void**)&t->h_ctr, sizeof(Counters)) != hipSuccess || hipHostMalloc((void**)&t->h_op, sizeof(OpCounters)) != hipSuccess) {
         rc = fail(MEE_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
         goto bad;
@@ -2056,6 +1941,7 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     else if (!strcmp(name, "find_grid_cap")) t->find_grid_cap = value;
     else if (!strcmp(name, "find_nt")) t->find_nt = value;
     else if (!strcmp(name, "apply_rounds")) t->apply_rounds = value;
+    else if (!strcmp(name, "apply_path")) t->apply_path = value;
     else if (!strcmp(name, "apply_overlap")) (void)value;   // retired in round 2 (a side stream for the duplicate path lost to its fork/join gaps): accepted, ignored
     else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);
     return MEE_OK;
@@ -2503,7 +2389,14 @@ static int apply_prepare_launch(mee_table* t, const int64_t* d_keys, uint32_t nn
     return MEE_OK;
 }
 
-// One sparse-optimizer step: group_kernel (occurrence counts + inline position lists; skipped after mee_apply_prepare) ->
+// Which apply a batch of n keys takes: the bucketed one (meepo_apply.hip: partition by hash bucket, one block-local dedup + update kernel)
+// unless the caller's knob says otherwise or the batch is beyond what its partition handles well (then: the group-table apply below).
+static bool use_bucketed_apply(const mee_table* t, size_t n) {
+    if (!t->bk.pkey || n > t->bk.fast_max) return false;
+    return t->apply_path != 0;
+}
+
+// One sparse-optimizer step (group-table path): group_kernel (occurrence counts + inline position lists; skipped after mee_apply_prepare) ->
 // apply_main_kernel (every key that occurs once; duplicates are marked) -> three small kernels for the duplicates (groups that fit
 // their entry's inline list are finished by the first, which also files the occurrences of larger groups; fp64 chunk sums; tree +
 // update).  `d_slots` (nullable): the slot of every position as mee_find_located of the same step reported it.
@@ -2516,14 +2409,19 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
-    if (t->prepared_n) {  // grouping was done ahead of time (mee_apply_prepare), possibly on another stream
+    bool bucketed = use_bucketed_apply(t, n);
+    if (t->prepared_n) {  // the grad-independent half was done ahead of time (mee_apply_prepare), possibly on another stream
         if (t->prepared_n != n || t->prepared_keys != d_keys)
             return fail(MEE_ERR_INVALID_ARG, "%s: keys/n differ from the pending mee_apply_prepare", name);
-        t->prepared_n = 0; t->prepared_keys = nullptr;
+        bucketed = t->prepared_path == 1;
+        t->prepared_n = 0; t->prepared_keys = nullptr; t->prepared_path = 0;
+    } else if (bucketed) {
+        if (int rc = bucket_apply_prepare(t, d_keys, nn, st)) return rc;
     } else {
         next_epoch(t, st);
         group_kernel<kGroupApply, kApplyGroupBlock><<<grid_for(nn, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
     }
+    if (bucketed) return bucket_apply_launch(t, d_grads, nn, a, d_gidx, d_slots, st);
     {
         const int R = t->apply_rounds > 0 ? t->apply_rounds : 1;   // one position per tile: more waves per SIMD beat more loads per wave here
         const unsigned gs = grid_for(n, 16u * (R >= 2 ? 2u : 1u), 1u << 16);
@@ -2656,9 +2554,15 @@ int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* strea
     if (n > t->max_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_apply_prepare: n=%zu exceeds config.max_batch=%llu", n, (unsigned long long)t->max_batch);
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
-    next_epoch(t, as_stream(stream));
-    group_kernel<kGroupApply, kApplyGroupBlock><<<grid_for(n, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, as_stream(stream)>>>(d_keys, (uint32_t)n, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
-    MEE_HIP(hipGetLastError());
+    if (use_bucketed_apply(t, n)) {   // the partition half of the bucketed apply: positions and keys in bucket order, the work-unit list
+        if (int rc = bucket_apply_prepare(t, d_keys, (uint32_t)n, as_stream(stream))) return rc;
+        t->prepared_path = 1;
+    } else {
+        next_epoch(t, as_stream(stream));
+        group_kernel<kGroupApply, kApplyGroupBlock><<<grid_for(n, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, as_stream(stream)>>>(d_keys, (uint32_t)n, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
+        MEE_HIP(hipGetLastError());
+        t->prepared_path = 2;
+    }
     t->prepared_n = n; t->prepared_keys = d_keys;
     return MEE_OK;
 }
@@ -2668,10 +2572,12 @@ int mee_apply_discard(mee_table* t, void* stream) {
     if (!t->prepared_n) return MEE_OK;
     DeviceGuard g(t->device);
     const uint32_t nn = (uint32_t)t->prepared_n;
-    group_reset_kernel<<<grid_for(nn, 256, 1u << 22), 256, 0, as_stream(stream)>>>(t->bs.hidx, nn, t->g);
-    MEE_HIP(hipGetLastError());
-    zero_words(t->bs.filed_bits, ((size_t)nn / 32 + 16) * 4, as_stream(stream));   // the prepare pass may have marked filed occurrences (a kernel, not a memset node: see zero_words)
-    t->prepared_n = 0; t->prepared_keys = nullptr;
+    if (t->prepared_path == 2) {   // a group table to give back (the bucketed partition leaves nothing behind)
+        group_reset_kernel<<<grid_for(nn, 256, 1u << 22), 256, 0, as_stream(stream)>>>(t->bs.hidx, nn, t->g);
+        MEE_HIP(hipGetLastError());
+        zero_words(t->bs.filed_bits, ((size_t)nn / 32 + 16) * 4, as_stream(stream));   // the prepare pass may have marked filed occurrences (a kernel, not a memset node: see zero_words)
+    }
+    t->prepared_n = 0; t->prepared_keys = nullptr; t->prepared_path = 0;
     return MEE_OK;
 }
 

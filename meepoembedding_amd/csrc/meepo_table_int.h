@@ -1,0 +1,160 @@
+// meepo_table_int.h — what the translation units of the table share: the device-side scratch structures, struct mee_table and the
+// optimizer update (SPEC.md §4).  Internal: nothing here is part of the C-ABI (include/meepo_embedding.h).
+#pragma once
+#include "meepo_device.h"
+#include "meepo_host.h"
+
+namespace mee {
+
+struct Counters {            // device-resident, persistent
+    uint32_t status;         // sticky MEE_STATUS_* bits
+    uint32_t election;       // = the epoch of the latest insert whose batch had a position that found its key present (gates its election kernels)
+    uint32_t pad[2];
+};
+struct OpCounters {          // device-resident, zeroed at the start of each op that uses them
+    uint32_t n_uniq;         // distinct keys appended to the unique list
+    uint32_t n_occ;          // occurrence-list entries reserved
+    uint32_t n_big;          // groups with more than kChunk occurrences
+    uint32_t n_work;         // chunk leaders listed for apply_chunk_kernel
+    unsigned long long n_export;  // pairs exported / keys counted
+    uint32_t n_part;         // fp64 partial-sum rows reserved by big groups
+    uint32_t pad;
+    unsigned long long occ_work;  // plan-free apply: occurrence-list entries reserved (low half) | work items listed (high half)
+};
+struct GroupTable {            // S entries, indexed by h
+    // One 16-byte entry per h: ent[2h] = key ^ kBias (0 = empty), ent[2h+1] = the count word below.  Key and count share a 64-byte sector,
+    // so the claim and the count store of group_kernel, the count load of the apply's main pass and the release (ONE 16-byte store) touch
+    // one line per key instead of two.
+    unsigned long long* ent;
+    // count word, low half ("lo"):  COUNT: occurrences added by blocks other than the claimer's (atomicAdd) | LAST: 1 + highest position seen by them (atomicMax)
+    // count word, high half ("hi"): the same quantity of the block whose CAS claimed the entry — a plain store, no atomic.
+    // The pair is one aligned 8-byte word: readers take both halves with ONE load (sv_load), so a reader racing with a release sees
+    // either the complete pair or zeros, never a mixture.
+    uint32_t* soffs;           // start of the group's slice of the occurrence list (hot keys of an apply; dedup)
+    uint32_t* sbig;            // first fp64 partial-sum row of a group with more than kChunk occurrences
+    uint32_t* sgrp;            // index of the group in the unique list (standalone dedup)
+    long long* sres;           // lent out as a per-position slot list by insert / remove
+    uint32_t* inl;             // apply: 16 batch positions per entry (one 64-byte line): [0..7] the claiming block's occurrences of ranks 1..8,
+                               // [8..15] the first 8 occurrences other blocks added — a group that fits is finished by its leader from this one line
+    uint64_t smask;
+};
+__device__ __forceinline__ uint32_t* sv_half(const GroupTable& g, uint32_t h) { return reinterpret_cast<uint32_t*>(g.ent + 2 * (uint64_t)h + 1); }   // [0] = lo, [1] = hi
+__device__ __forceinline__ void sv_load(const GroupTable& g, uint32_t h, uint32_t& lo, uint32_t& hi) {
+    const unsigned long long w = g.ent[2 * (uint64_t)h + 1];
+    lo = (uint32_t)w; hi = (uint32_t)(w >> 32);
+}
+// kGroupApply entries (read while claimed): hi holds the claiming block's count - 1
+__device__ __forceinline__ void cnt_load(const GroupTable& g, uint32_t h, uint32_t& lo, uint32_t& hi) {
+    sv_load(g, h, lo, hi);
+    ++hi;
+}
+__device__ __forceinline__ void group_release_entry(const GroupTable& g, uint32_t h) {
+    reinterpret_cast<ulonglong2*>(g.ent)[h] = make_ulonglong2(0ull, 0ull);
+}
+struct BatchScratch {          // max_batch entries, indexed by batch position unless noted
+    uint32_t *hidx, *rank, *pcnt, *occ, *uniq_h, *work;
+    uint32_t *lead_bits, *filed_bits;   // apply: one bit per batch position (leader of an inline group | occurrence of a filed group); all-zero between applies
+    uint8_t* fmask;            // found mask of find_or_insert's first pass when the caller passes none
+    uint32_t* bigh;            // [max_big] group-table index of each big group
+    double* gacc;              // [max_part][dim] fp64 partial-sum rows: one per chunk of a big group, a group's rows contiguous
+    uint32_t max_part;         // rows of gacc (group_plan_kernel never hands out more)
+};
+
+
+
+// ---- the bucketed apply (meepo_apply.hip): per-call scratch, all device resident ----------------------------------------------------
+struct BucketScratch {
+    uint32_t* pos;        // [fast_max] batch positions: partition block k's share of the batch, sorted by hash bucket, in slice k (aliases BatchScratch::occ)
+    int64_t* pkey;        // [fast_max] their keys, in the same order
+    uint32_t* cnt_mat;    // [kPartBlocks][n_buckets_max] keys of each bucket held by each partition block …
+    uint32_t* off_mat;    // … and where that run starts inside the block's slice of pos / pkey
+    uint32_t* off;        // [n_buckets_max + 1] start of each bucket in pos / pkey
+    uint2* units;         // [max_units] work unit -> (bucket, slab of the bucket): split buckets first
+    uint32_t* n_units;    // [1]
+    uint32_t* pend_cnt;   // [n_buckets_max] split buckets: pending records appended so far
+    uint32_t* ticket;     // [n_buckets_max] split buckets: slabs finished
+    int64_t* pend_key;    // [fast_max] pending records of split buckets: key …
+    int64_t* pend_slot;   // [fast_max] … the table slot its handle named (located applies: the merge needs no probe) …
+    double* pend_row;     // [fast_max][dim] … and the fp64 partial sum of its gradient rows within one slab
+    uint32_t n_buckets_max, max_units;
+    uint64_t fast_max;    // largest n the bucketed path takes
+};
+
+}  // namespace mee
+
+struct mee_table {
+    int device;
+    uint64_t capacity, nb, max_batch;
+    uint32_t dim, dim4, optimizer, initializer, value_memory;
+    float default_value, init_acc, init_scale;
+    uint64_t init_seed;
+    // table planes
+    int64_t* keys;
+    float *values, *s1, *s2;
+    uint32_t* hits;             // per-slot access counter (config.flags & MEE_FLAG_TRACK_HITS), else null
+    uint32_t* sketch;           // admission policy (config.flags & MEE_FLAG_ADMISSION): count-min sketch, 3 rows of 2^sketch_log2w counters
+    uint32_t sketch_log2w;
+    // per-batch scratch: group table (S entries) and per-position arrays (max_batch entries)
+    uint64_t S, max_big, max_part;   // max_big: groups larger than kChunk; max_part: their fp64 partial-sum rows (one per chunk)
+    mee::GroupTable g;
+    mee::BatchScratch bs;
+    mee::Counters* ctr;
+    mee::OpCounters* op;
+    mee::Counters* h_ctr;       // pinned staging for read-backs
+    mee::OpCounters* h_op;
+    uint64_t table_bytes, workspace_bytes;
+    uint64_t generation;        // bumped whenever the planes move (mee_reserve): cached descriptors (mee_group) re-read them
+    uint32_t handle_epoch;      // bumped by every call that can move or free a row (remove / clear / reserve): tags the slot handles of mee_find_located
+    // a prepared (grouped + planned) apply waiting for its grads: mee_apply_prepare .. mee_apply_*
+    uint64_t prepared_n;
+    const int64_t* prepared_keys;
+    uint32_t epoch;             // batch number of insert / apply launches (tags insert's election flag; never 0)
+    // performance knobs (never change results): see mee_set_tuning()
+    int find_rounds;            // keys in flight per tile in the find kernel: 1, 2, 4 or 8
+    int find_grid_cap;          // max blocks of the find grid (0 = one pass, no grid-stride loop)
+    int apply_rounds;           // batch positions in flight per tile in the apply's main pass: 1 or 2 (0 = auto)
+    int find_nt;                // bit0: non-temporal row loads, bit1: non-temporal bucket loads, bit2: plain (cached) out stores;
+                                // -1 = auto: cached loads (hot rows of skewed streams stay in L2), cached stores while the
+                                // dense output fits the Infinity Cache (<= 128 MB), streaming stores beyond
+    mee::BucketScratch bk;      // bucketed apply (null pointers when the table has no optimizer)
+    int apply_path;             // -1 = the library's choice, 0 = group-table apply, 1 = bucketed apply
+    uint32_t prepared_path;     // which path a pending mee_apply_prepare took
+};
+
+namespace mee {
+
+// ---- sparse optimizers (SPEC.md §4) ------------------------------------------------------------------------
+struct OptArgs {
+    uint32_t kind;       // MEE_OPT_*
+    float lr, eps;       // adagrad: lr; adam: lr unused (step_size)
+    float step_size, omb1, omb2;
+    uint32_t grad_rows;  // indexed apply: rows of the grad array (indices are clamped to it: caller data never reads out of bounds)
+};
+
+__device__ __forceinline__ void opt_update4(const OptArgs& a, float4& w, float4& x1, float4& x2, const float4 g) {
+    if (a.kind == MEE_OPT_ADAGRAD) {
+        adagrad1(w.x, x1.x, g.x, a.lr, a.eps); adagrad1(w.y, x1.y, g.y, a.lr, a.eps);
+        adagrad1(w.z, x1.z, g.z, a.lr, a.eps); adagrad1(w.w, x1.w, g.w, a.lr, a.eps);
+    } else {
+        adam1(w.x, x1.x, x2.x, g.x, a.step_size, a.omb1, a.omb2, a.eps);
+        adam1(w.y, x1.y, x2.y, g.y, a.step_size, a.omb1, a.omb2, a.eps);
+        adam1(w.z, x1.z, x2.z, g.z, a.step_size, a.omb1, a.omb2, a.eps);
+        adam1(w.w, x1.w, x2.w, g.w, a.step_size, a.omb1, a.omb2, a.eps);
+    }
+}
+
+__device__ __forceinline__ void update_row(const OptArgs& a, float4* values, float4* s1, float4* s2, uint64_t o, const float4 g) {
+    float4 w = values[o], x1 = s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.kind == MEE_OPT_ADAM) x2 = s2[o];
+    opt_update4(a, w, x1, x2, g);
+    values[o] = w; s1[o] = x1;
+    if (a.kind == MEE_OPT_ADAM) s2[o] = x2;
+}
+// the bucketed apply path (meepo_apply.hip)
+int bucket_scratch_alloc(mee_table* t);
+void bucket_scratch_free(mee_table* t);
+int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st);
+int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const OptArgs& a, const uint32_t* d_gidx, const int64_t* d_slots, hipStream_t st);
+uint32_t bucket_count_for(uint64_t n);
+
+}  // namespace mee
