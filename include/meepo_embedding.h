@@ -361,13 +361,39 @@ int mee_p2p_status(mee_p2p* c, uint32_t* bits_out, void* stream); /* [syncs]; bi
  *                   with MEE_EMPTY_KEY; message sizes are constants and nothing returns to the host.  A batch that sends one
  *                   owner more than that loses the surplus keys and sets bit 0 of mee_sharded_status (check it when convenient;
  *                   skewed batches: mee_dedup_keys first, or the exact layout).  Mutators then hand the local table G x segment
- *                   positions per call: create it with max_batch >= that. */
+ *                   positions per call: create it with max_batch >= that.
+ *
+ * Errors inside a collective operator: everything a rank needs for an operator is allocated when its context is created (owner-side buffers
+ * for G x max_batch arrivals; every rank must pass the same max_batch and pad_slack — checked collectively at creation), so no rank can
+ * drop out for memory between two exchange steps.  If an RCCL call itself fails, the context aborts its communicator (ncclCommAbort: peers
+ * blocked in the same collective return with an error instead of waiting forever) and every later call on it returns MEE_ERR_RCCL. */
 #define MEE_COMM_ID_BYTES 128
 int mee_comm_unique_id(void* id_out /* MEE_COMM_ID_BYTES */);                    /* ncclGetUniqueId: one rank calls, all ranks share the bytes */
 int mee_comm_create(const void* id, uint32_t n_ranks, uint32_t rank, int32_t device, void** comm_out); /* ncclCommInitRank (collective) */
 int mee_comm_destroy(void* comm);
-int mee_sharded_create(mee_table* local, void* nccl_comm, uint64_t max_batch /* largest n of this rank per call */, double pad_slack,
-                       mee_sharded** out);
+int mee_sharded_create(mee_table* local, void* nccl_comm, uint64_t max_batch /* largest n of a rank per call: the same on every rank */,
+                       double pad_slack, mee_sharded** out);
+/* The same with options (BASELINE configs[4]; SURVEY.md §7 lever (a)):
+ *   cold   the shard is a hot/cold PAIR: `local` holds its hot keys in HBM, `cold` (a table created with MEE_MEM_HOST_PINNED, same dim and
+ *          optimizer, same device) the rest.  A key lives in exactly one of the two.  On the owner side a lookup is mee_find on the hot
+ *          table + mee_find_missing on the cold one over the same buffers; assign / remove / apply_* go to both (each ignores keys it does
+ *          not hold, found masks are OR-ed); new keys are created in the hot table while it holds fewer than hot_key_limit keys (0 = 3/4 of
+ *          its capacity; an upper bound is kept on the host and refreshed with one mee_size — a synchronisation — only when it is hit),
+ *          else in the cold one.  Which keys are hot is the caller's policy (mee_find_plane / mee_assign_plane move a key with its state).
+ *   MEE_SHARDED_DEDUP   lookups (find, find_or_insert) exchange only the batch's DISTINCT keys: mee_dedup_keys on a scratch table of the
+ *          context's own -> the padded unique list is partitioned (padding belongs to no shard) -> keys out, rows back -> every occurrence
+ *          takes its key's row.  On skewed key streams the bytes on xGMI scale with the distinct keys while the result counts lookups.
+ *          Costs ~0.2 ms of local work per 1M keys: it pays where the saved link time exceeds that. */
+enum { MEE_SHARDED_DEDUP = 1u };
+typedef struct mee_sharded_options {
+    uint32_t struct_size;     /* = sizeof(mee_sharded_options); ABI guard */
+    uint32_t flags;           /* MEE_SHARDED_* bits */
+    uint64_t max_batch;       /* largest n of a rank per call: the same on every rank */
+    double   pad_slack;       /* 0 = exact segments, >= 1 = padded segments (see above) */
+    mee_table* cold;          /* nullable: the cold tier behind `local` */
+    uint64_t hot_key_limit;   /* with `cold`: keys the hot table may hold before new keys go cold (0 = 3/4 of its capacity) */
+} mee_sharded_options;
+int mee_sharded_create_ex(mee_table* local, void* nccl_comm, const mee_sharded_options* options, mee_sharded** out);
 int mee_sharded_destroy(mee_sharded* s);
 int mee_sharded_info(const mee_sharded* s, uint32_t* n_shards, uint32_t* rank, uint64_t* segment_capacity /* 0 = exact layout */);
 int mee_sharded_find(mee_sharded* s, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found /* nullable */, void* stream);
@@ -375,13 +401,19 @@ int mee_sharded_find_or_insert(mee_sharded* s, const int64_t* d_keys, size_t n, 
 int mee_sharded_insert(mee_sharded* s, const int64_t* d_keys, const float* d_values, size_t n, void* stream);
 int mee_sharded_assign(mee_sharded* s, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found, void* stream);
 int mee_sharded_remove(mee_sharded* s, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream);
-/* one update per distinct key over everything that reaches a shard: its table needs max_batch >= the pairs arriving per call
- * (<= G x the ranks' n), else MEE_ERR_BATCH_TOO_LARGE on that rank after the exchange has completed everywhere. */
+/* one update per distinct key over everything that reaches a shard.  Exact layout: when more pairs arrive than the local table's max_batch
+ * (a skewed step, or G ranks x max_batch against a table made for one rank's batch) the arrivals are split by key range — every key's pairs
+ * in one chunk, one apply per chunk (one more host synchronisation; MEE_ERR_BATCH_TOO_LARGE only if a single chunk still exceeds max_batch,
+ * i.e. one key dominates).  Padded layout: the local table receives G x segment positions per call, a constant known to every rank: a
+ * table with a smaller max_batch is refused on every rank alike, before anything is exchanged. */
 int mee_sharded_apply_adagrad(mee_sharded* s, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps, void* stream);
 int mee_sharded_apply_adam(mee_sharded* s, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float beta1, float beta2,
                            float eps, uint64_t step, void* stream);
 int mee_sharded_size(mee_sharded* s, size_t* n_out, void* stream);       /* [syncs] keys stored over all shards (ncclAllReduce) */
-int mee_sharded_status(mee_sharded* s, uint32_t* bits_out, void* stream); /* [syncs]; bit 0: a padded segment overflowed */
+/* [syncs]; bit 0: a padded segment overflowed (the lookups it could not send returned the default row and found = 0; mutators lost the
+ * surplus pairs).  Sticky until mee_sharded_clear_status. */
+int mee_sharded_status(mee_sharded* s, uint32_t* bits_out, void* stream);
+int mee_sharded_clear_status(mee_sharded* s, void* stream);
 
 #ifdef __cplusplus
 }

@@ -226,6 +226,12 @@ class ShardedTable {
 public:
     // pad_slack = 0: exact message sizes (one host sync per call); >= 1: fixed EMPTY-padded segments, no host sync
     ShardedTable(Table& local, void* nccl_comm, uint64_t max_batch, double pad_slack = 0.0) { check(mee_sharded_create(local.handle(), nccl_comm, max_batch, pad_slack, &s_)); }
+    // with options: a cold table behind `local` (every shard a hot/cold pair), pre-exchange dedup of lookups (MEE_SHARDED_DEDUP)
+    ShardedTable(Table& local, void* nccl_comm, uint64_t max_batch, double pad_slack, Table* cold, uint32_t flags = 0, uint64_t hot_key_limit = 0) {
+        mee_sharded_options o{};
+        o.struct_size = sizeof o; o.flags = flags; o.max_batch = max_batch; o.pad_slack = pad_slack; o.cold = cold ? cold->handle() : nullptr; o.hot_key_limit = hot_key_limit;
+        check(mee_sharded_create_ex(local.handle(), nccl_comm, &o, &s_));
+    }
     ~ShardedTable() { if (s_) mee_sharded_destroy(s_); }
     ShardedTable(const ShardedTable&) = delete;
     ShardedTable& operator=(const ShardedTable&) = delete;
@@ -238,6 +244,7 @@ public:
     void apply_adam(const int64_t* d_keys, const float* d_grads, size_t n, float lr, float b1, float b2, float eps, uint64_t step, void* stream = nullptr) { check(mee_sharded_apply_adam(s_, d_keys, d_grads, n, lr, b1, b2, eps, step, stream)); }
     size_t size(void* stream = nullptr) { size_t n = 0; check(mee_sharded_size(s_, &n, stream)); return n; }
     uint32_t status(void* stream = nullptr) { uint32_t b = 0; check(mee_sharded_status(s_, &b, stream)); return b; }
+    void clear_status(void* stream = nullptr) { check(mee_sharded_clear_status(s_, stream)); }
 private:
     mee_sharded* s_ = nullptr;
 };

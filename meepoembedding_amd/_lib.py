@@ -47,6 +47,14 @@ class FindRequest(C.Structure):
     _fields_ = [("d_keys", C.c_void_p), ("n", C.c_size_t), ("d_out", C.c_void_p), ("d_found", C.c_void_p)]
 
 
+class ShardedOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("max_batch", C.c_uint64), ("pad_slack", C.c_double),
+                ("cold", C.c_void_p), ("hot_key_limit", C.c_uint64)]
+
+
+SHARDED_DEDUP = 1
+
+
 class TableInfo(C.Structure):
     _fields_ = [
         ("capacity", C.c_uint64), ("n_buckets", C.c_uint64), ("max_batch", C.c_uint64), ("dim", C.c_uint32),
@@ -135,6 +143,8 @@ PROTOTYPES = {
     "mee_comm_create": (C.c_int, [_vp, _u32, _u32, _i32, C.POINTER(_vp)]),
     "mee_comm_destroy": (C.c_int, [_vp]),
     "mee_sharded_create": (C.c_int, [_vp, _vp, _u64, C.c_double, C.POINTER(_vp)]),
+    "mee_sharded_create_ex": (C.c_int, [_vp, _vp, C.POINTER(ShardedOptions), C.POINTER(_vp)]),
+    "mee_sharded_clear_status": (C.c_int, [_vp, _vp]),
     "mee_sharded_destroy": (C.c_int, [_vp]),
     "mee_sharded_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u64)]),
     "mee_sharded_find": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),

@@ -504,9 +504,11 @@ __device__ __forceinline__ void mono_pass(ApplyLds& L, const ApplyArgs& A, const
     __syncthreads();
 }
 
-// MEE_APPLY_WAVES (build-time experiment knob): waves per SIMD the register allocator must leave room for (0 = its own choice)
+// MEE_APPLY_WAVES: waves per SIMD the register allocator must leave room for (0 = its own choice: ~100 VGPRs, 4 waves = 2 blocks per CU).
+// 6 = 80 VGPRs, 3 resident blocks per CU at the price of 16-40 bytes of scratch in the merge path: measured -3 us on a uniform, -5 us on
+// a Zipf(1.05) batch of 256K keys; 8 (64 VGPRs, 100-140 bytes of scratch) loses what it gains.
 #ifndef MEE_APPLY_WAVES
-#define MEE_APPLY_WAVES 0
+#define MEE_APPLY_WAVES 6
 #endif
 #if MEE_APPLY_WAVES
 #define MEE_APPLY_BOUNDS __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES)

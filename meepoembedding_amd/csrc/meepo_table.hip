@@ -2017,7 +2017,7 @@ static const float* plane_of(const mee_table* t, uint32_t plane) {
 
 static int find_plane(const mee_table* t, const float* plane, float miss_value, const int64_t* d_keys, size_t n, float* d_out,
                       uint8_t* d_found, void* stream, bool missing_only = false, bool counted = false, bool rows_only = false,
-                      int64_t* d_slots_out = nullptr, bool unordered = false) {
+                      int64_t* d_slots_out = nullptr, bool unordered = false, bool skip_padding = false) {
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -2031,6 +2031,15 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
                                else find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr); } while (0)
     const int nt = t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
 #define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
+    if (skip_padding) {   // owner pass of a padded sharded exchange: EMPTY positions get neither a row nor a found byte (nobody reads them)
+        const bool cached = nt & 4;
+#define FINDP(D4, RR) do { if (cached) find_kernel<D4, RR, 132><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr); \
+                           else find_kernel<D4, RR, 128><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr); } while (0)
+        if (t->dim4 == 16) { if (R >= 2) FINDP(16, 2); else FINDP(16, 1); }
+        else if (t->dim4 == 32) { if (R >= 2) FINDP(32, 2); else FINDP(32, 1); }
+        else { if (R >= 2) FINDP(0, 2); else FINDP(0, 1); }
+#undef FINDP
+    } else
     if (d_slots_out) {   // located find: the plain kernel + one 8-byte store per key
         // cache policy of `out`: this is the forward of a TRAINING step — the apply that follows sweeps the Infinity Cache before the next
         // forward, so keeping the dense output cached buys nothing and streaming stores win (136.9 -> 132.5 us per find + Adagrad step)
@@ -2068,6 +2077,17 @@ int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, 
     if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find: null argument");
     return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream);
 }
+
+}  // extern "C"
+namespace mee {
+// mee_find for the owner side of a padded sharded exchange (meepo_sharded.hip): MEE_EMPTY_KEY positions are padding that nobody reads —
+// they get neither a default row nor a found byte
+int find_skip_padding(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
+    if (!t || (n && (!d_keys || !d_out || !d_found))) return fail(MEE_ERR_INVALID_ARG, "find_skip_padding: null argument");
+    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, false, false, false, nullptr, false, /*skip_padding=*/true);
+}
+}  // namespace mee
+extern "C" {
 
 int mee_find_located(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
     if (!t || (n && (!d_keys || !d_out || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_located: null argument");

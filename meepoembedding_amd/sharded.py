@@ -162,9 +162,11 @@ class RcclShardedTable:
     hand rank 0's ncclUniqueId to the other ranks; per step there is no Python-side collective at all.
 
     pad_slack = 0: exact message sizes (one host synchronisation per operator, for the split sizes).
-    pad_slack >= 1: fixed-capacity EMPTY-padded segments, no host synchronisation (see include/meepo_embedding.h)."""
+    pad_slack >= 1: fixed-capacity EMPTY-padded segments, no host synchronisation (see include/meepo_embedding.h).
+    cold: the cold table of a hot/cold pair (`local` = the hot one): BASELINE configs[4] behind the C-ABI (mee_sharded_create_ex).
+    dedup: lookups exchange only the batch's distinct keys (MEE_SHARDED_DEDUP)."""
 
-    def __init__(self, local, max_batch: int, group=None, pad_slack: float = 0.0):
+    def __init__(self, local, max_batch: int, group=None, pad_slack: float = 0.0, cold=None, dedup: bool = False, hot_key_limit: int = 0):
         import ctypes as C
 
         from . import _lib
@@ -185,7 +187,10 @@ class RcclShardedTable:
         check(L.mee_comm_create(box[0], self.world, self.rank, self.device.index, C.byref(comm)))
         self._comm = comm
         h = C.c_void_p()
-        check(L.mee_sharded_create(local._h, self._comm, self.max_batch, float(pad_slack), C.byref(h)))
+        self.cold = cold
+        opt = _lib.ShardedOptions(struct_size=C.sizeof(_lib.ShardedOptions), flags=_lib.SHARDED_DEDUP if dedup else 0, max_batch=self.max_batch,
+                                  pad_slack=float(pad_slack), cold=cold._h if cold is not None else None, hot_key_limit=int(hot_key_limit))
+        check(L.mee_sharded_create_ex(local._h, self._comm, C.byref(opt), C.byref(h)))
         self._h = h
         cap = C.c_uint64()
         check(L.mee_sharded_info(self._h, None, None, C.byref(cap)))
@@ -274,5 +279,12 @@ class RcclShardedTable:
         self._check(self._lib.lib().mee_sharded_status(self._h, self._C.byref(b), self._s()))
         return b.value
 
+    def clear_status(self) -> None:
+        self._check(self._lib.lib().mee_sharded_clear_status(self._h, self._s()))
+
     def export_local(self, with_state: bool = False):
-        return self.local.export(with_state=with_state)
+        a = self.local.export(with_state=with_state)
+        if getattr(self, "cold", None) is None:
+            return a
+        b = self.cold.export(with_state=with_state)
+        return tuple(None if x is None else torch.cat([x, y]) for x, y in zip(a, b))

@@ -160,6 +160,35 @@ int main() try {
           for (size_t i = 0; i < n; ++i) CHECK(f[i] == 1);
           CHECK(st.size() == n - 1 && st.status() == 0 && shard2.status() == 0);
       } }
+    // ---- the same over a hot/cold pair with pre-exchange dedup (mee_sharded_create_ex: BASELINE configs[4] behind the C-ABI), one rank -------
+    { char id[MEE_COMM_ID_BYTES];
+      meepo::Communicator::unique_id(id);
+      meepo::Communicator comm(id, 1, 0, 0);
+      meepo::TableOptions ho2 = o; ho2.optimizer = MEE_OPT_ADAGRAD; ho2.max_batch = n; ho2.capacity = (uint64_t)(n / 2);
+      meepo::TableOptions co2 = ho2; co2.capacity = (uint64_t)(n / 0.75); co2.value_memory = MEE_MEM_HOST_PINNED;
+      meepo::Table hot2(ho2), cold2(co2);
+      meepo::ShardedTable st(hot2, comm.handle(), n, 0.0, &cold2, MEE_SHARDED_DEDUP, /*hot_key_limit=*/n / 4);
+      st.insert(d_keys.p, d_rows.p, n / 4);                         // fits the hot tier
+      st.insert(d_keys.p + n / 4, d_rows.p + (n / 4) * dim, n - n / 4);   // does not: goes cold
+      CHECK(st.size() == n && hot2.size() == n / 4 && cold2.size() == n - n / 4);
+      st.find(d_q.p, n, d_out.p, d_found.p);
+      HIPCK(hipDeviceSynchronize());
+      auto out = d_out.down(n * dim); auto f = d_found.down(n);
+      for (size_t i = 0; i < n; ++i) {
+          if (i == 5) { CHECK(f[i] == 0 && out[i * dim] == -2.0f); continue; }
+          CHECK(f[i] == 1);
+          CHECK(memcmp(&out[i * dim], &rows[((i * 7919) % n) * dim], dim * 4) == 0);
+      }
+      // a batch of ONE repeated key: de-duplicated before the exchange, every occurrence gets the row
+      std::vector<int64_t> rep(n, keys[17]);
+      DevBuf<int64_t> d_rep(n); d_rep.up(rep);
+      st.find(d_rep.p, n, d_out.p, d_found.p);
+      HIPCK(hipDeviceSynchronize());
+      out = d_out.down(n * dim); f = d_found.down(n);
+      for (size_t i = 0; i < n; i += 97) CHECK(f[i] == 1 && memcmp(&out[i * dim], &rows[17 * dim], dim * 4) == 0);
+      st.remove(d_q.p, 1, nullptr);
+      CHECK(st.size() == n - 1 && st.status() == 0 && hot2.status() == 0 && cold2.status() == 0);
+    }
     printf("host_cpp_test ok: Table, TieredTable (HBM + pinned host), the peer-mapped sharded pipeline and the RCCL-backed ShardedTable through meepo_embedding.hpp\n");
     return 0;
 } catch (const std::exception& e) {

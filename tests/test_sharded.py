@@ -193,21 +193,29 @@ def _run_rank_body(rank, world, port, backend, q, tiered=False, DIM=DIM):
 
 
 def _native_rccl_checks(rank, world, dev, dim, keys, rows, grads, probe, dup, router):
-    """The exchange behind the C-ABI (mee_sharded_*: grouped ncclSend/ncclRecv inside the library), exact and padded segment
-    layouts, against the torch.distributed path on tables of their own: same op sequence -> same exports, same lookups."""
-    from meepoembedding_amd import OPT_ADAGRAD, LookupTable
+    """The exchange behind the C-ABI (mee_sharded_*: grouped ncclSend/ncclRecv inside the library), exact and padded segment layouts, with
+    pre-exchange dedup, over a hot/cold pair (BASELINE configs[4]) and over a local table too small for one apply of what arrives (chunked
+    by key range) — all against the torch.distributed path on tables of their own: same op sequence -> same exports, same lookups."""
+    from meepoembedding_amd import OPT_ADAGRAD, LookupTable, MeepoError, _lib
     from meepoembedding_amd.sharded import RcclShardedTable
     cap_pad = int(np.ceil(BATCH / world * 1.5)) + 1024
-    mk = lambda: LookupTable(16384, dim, device=dev, optimizer=OPT_ADAGRAD, initial_accumulator=0.1, max_batch=max(world * BATCH, world * cap_pad))
-    l_ref, l_exact, l_pad = mk(), mk(), mk()
+    big = max(world * BATCH, world * cap_pad)
+    mk = lambda mb=big, cap=16384, **kw: LookupTable(cap, dim, device=dev, optimizer=OPT_ADAGRAD, initial_accumulator=0.1, max_batch=mb, **kw)
+    l_ref, l_exact, l_pad, l_dd, l_ddp, l_small = mk(), mk(), mk(), mk(), mk(), mk(mb=BATCH // 2)
+    l_hot, l_cold = mk(cap=8192), mk(value_memory=_lib.MEM_HOST_PINNED)
     ref = ShardedLookupTable(l_ref, router)
     exact = RcclShardedTable(l_exact, BATCH, pad_slack=0.0)
     padded = RcclShardedTable(l_pad, BATCH, pad_slack=1.5)
+    dd_exact = RcclShardedTable(l_dd, BATCH, pad_slack=0.0, dedup=True)
+    dd_pad = RcclShardedTable(l_ddp, BATCH, pad_slack=1.5, dedup=True)
+    small = RcclShardedTable(l_small, BATCH, pad_slack=0.0)                    # ~BATCH pairs arrive at a table made for BATCH / 2: the apply is chunked by key range
+    tiered = RcclShardedTable(l_hot, BATCH, pad_slack=0.0, cold=l_cold, hot_key_limit=3000, dedup=True)   # the first (large) insert goes cold, later new keys hot
     assert exact.segment_capacity == 0 and padded.segment_capacity == cap_pad
     fresh_keys = torch.from_numpy(synth.keys_np(78, rank * 300, 300)).to(dev)
     mix = torch.cat([fresh_keys, probe[:200], fresh_keys[:50]])
     res = []
-    for t in (ref, exact, padded):
+    tables = (ref, exact, padded, dd_exact, dd_pad, small, tiered)
+    for t in tables:
         t.insert(keys, rows)
         t.apply_adagrad(keys, grads, lr=0.05, eps=1e-10)
         fa = t.assign(keys[:300], rows[300:600])
@@ -220,7 +228,7 @@ def _native_rccl_checks(rank, world, dev, dim, keys, rows, grads, probe, dup, ro
         res.append((fa, fr, o_p, f_p, o_d, f_d, o_m, f_m, t.size()))
         assert o_e.shape == (0, dim) and f_e.numel() == 0
     dist.barrier()
-    assert padded.status() == 0, "a padded segment overflowed"
+    assert padded.status() == 0 and dd_pad.status() == 0, "a padded segment overflowed"
     for other in res[1:]:
         for a, b in zip(res[0][:-1], other[:-1]):
             if a.dtype == torch.uint8:
@@ -230,17 +238,41 @@ def _native_rccl_checks(rank, world, dev, dim, keys, rows, grads, probe, dup, ro
         assert other[-1] == res[0][-1]
     e_ref = l_ref.export(with_state=True)
     i_ref = torch.argsort(e_ref[0])
-    for l in (l_exact, l_pad):
-        e = l.export(with_state=True)
+    for t in tables[1:]:
+        e = t.export_local(with_state=True)
         i = torch.argsort(e[0])
-        assert torch.equal(e[0][i], e_ref[0][i_ref]) and l.status() == 0
+        assert torch.equal(e[0][i], e_ref[0][i_ref]) and t.local.status() == 0
         for xa, xb in zip(e[1:3], e_ref[1:3]):
             torch.testing.assert_close(xa[i], xb[i_ref], rtol=1e-6, atol=1e-9)
-    # padded layout, overflow is detected: every copy of one key goes to one owner, whose segment holds cap_pad positions
+    # the pair really is two tiers, each key in exactly one of them
+    n_hot, n_cold = l_hot.size(), l_cold.size()
+    assert 0 < n_hot <= 3000 and n_cold > 0, (n_hot, n_cold)
+    hk, ck = l_hot.export()[0], l_cold.export()[0]
+    assert np.intersect1d(hk.cpu().numpy(), ck.cpu().numpy()).size == 0
+    # padded layout, overflow: every copy of one key goes to one owner, whose segment holds cap_pad positions.  It is detected, the lookups
+    # that could not be sent return the default row and found = 0 (never uninitialised memory), and the bit can be cleared again
     if BATCH > cap_pad:
-        padded.find(probe[:1].repeat(BATCH))
+        hot = probe[:1].repeat(BATCH)
+        o_h = torch.full((BATCH, dim), 7.5, device=dev); f_h = torch.full((BATCH,), 9, dtype=torch.uint8, device=dev)
+        padded.find(hot, out=o_h, found=f_h)
         assert padded.status() & 1
-    exact.close(); padded.close()
+        o_1, f_1 = ref.find(probe[:1])
+        served = f_h == f_1[0]
+        assert int(served.sum()) >= cap_pad and bool(((f_h == f_1[0]) | (f_h == 0)).all())
+        assert torch.equal(o_h[served], o_1.expand(int(served.sum()), dim))
+        dropped = ~served if int(f_1[0]) else torch.zeros_like(served)
+        if int(dropped.sum()):
+            assert bool((o_h[dropped] == l_pad.default_value).all()) and bool((f_h[dropped] == 0).all())
+        padded.clear_status()
+        assert padded.status() == 0
+        o_d2, f_d2 = dd_pad.find(hot)          # the same batch de-duplicated: ONE key travels, nothing overflows
+        assert dd_pad.status() == 0 and torch.equal(o_d2, o_1.expand(BATCH, dim)) and bool((f_d2 == f_1[0]).all())
+    # all ranks must agree on max_batch: a context made with another value is refused on EVERY rank, at creation
+    if world > 1:
+        with pytest.raises(MeepoError):
+            RcclShardedTable(l_exact, BATCH + (64 if rank == 0 else 0), pad_slack=0.0)
+    for t in tables[1:]:
+        t.close()
 
 
 def _check(results, world, dim=DIM):
