@@ -406,16 +406,23 @@ def train_streams(table, synth, n_keys, batch, dim, dev, out, found, bpl, steps=
         bs_ = lookup_batches(synth, n_keys, batch, 8, dist_name, dev, seed=11)
         uniq = sum(int(torch.unique(b_).numel()) for b_ in bs_) / len(bs_)
 
-        def step(i):
-            table.find_located(bs_[i % 8], out=out, found=found, slots=slots)
+        def step(i):   # the training forward (its launch also partitions the batch for the backward), then the backward on the located slots
+            table.find_located(bs_[i % 8], out=out, found=found, slots=slots, prepare_apply=fused_forward[0])
             table.apply_adagrad(bs_[i % 8], grads[i % 4], lr=0.01, eps=1e-10, slots=slots)
 
         def apply_only(i):
             table.apply_adagrad(bs_[i % 8], grads[i % 4], lr=0.01, eps=1e-10)
 
         row = {"unique_keys_per_batch": uniq}
+        fused_forward = [True]
         for label, fn, nbytes in (("step", step, (bpl + 8 + 4 * dim) * batch + (8 + 16 * dim) * uniq),
-                                  ("apply_alone", apply_only, (8 + 4 * dim) * batch + (8 + 16 * dim) * uniq)):
+                                  ("step_separate_forward", step, (bpl + 8 + 4 * dim) * batch + (8 + 16 * dim) * uniq),
+                                  ("apply_alone", apply_only, (8 + 4 * dim) * batch + (8 + 16 * dim) * uniq),
+                                  ("step_group_table_apply", step, (bpl + 8 + 4 * dim) * batch + (8 + 16 * dim) * uniq),
+                                  ("apply_alone_group_table_apply", apply_only, (8 + 4 * dim) * batch + (8 + 16 * dim) * uniq)):
+            # the last two rows: the same work through round 2's group-table apply (mee_set_tuning "apply_path" = 0), for comparison
+            table.set_tuning("apply_path", 0 if label.endswith("group_table_apply") else -1)
+            fused_forward[0] = label == "step"   # "step": mee_find_located_prepare + mee_apply_adagrad_located; the other step rows: mee_find_located + the apply
             ts = []
             for _ in range(regions):
                 for i in range(5):
@@ -430,6 +437,7 @@ def train_streams(table, synth, n_keys, batch, dim, dev, out, found, bpl, steps=
             us = sorted(ts)[len(ts) // 2]
             row[label] = {"us": us, "keys_per_s": batch / us * 1e6, "algorithmic_bytes_per_key": nbytes / batch,
                           "frac_of_hbm_roofline": nbytes / us / 1e3 / HBM_PEAK_GBS}
+        table.set_tuning("apply_path", -1)
         res[name] = row
     return res
 
@@ -770,8 +778,8 @@ def main():
 
         slots = torch.empty(batch, dtype=torch.int64, device=dev)
 
-        def step(i):   # forward gather, then the backward scatter-update on the slots the forward located (no second probe)
-            o_, f_, _ = table.find_located(batches[i % n_batches], out=out, found=found, slots=slots)
+        def step(i):   # forward gather (its launch also partitions the batch for the backward), then the backward scatter-update on the located slots
+            o_, f_, _ = table.find_located(batches[i % n_batches], out=out, found=found, slots=slots, prepare_apply=True)
             table.apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10, slots=slots)
             return o_, f_
     else:

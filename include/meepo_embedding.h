@@ -122,6 +122,12 @@ int mee_find_many(const mee_table* t, const mee_find_request* reqs, uint32_t cou
  * the table's layout epoch (bits 40..61; bits 0..39 = the slot mee_locate reports): mee_apply_*_located skips handles of an earlier
  * epoch and raises MEE_STATUS_STALE_HANDLE, so a kept-too-long handle can never update another key's row. */
 int mee_find_located(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream);
+/* The training forward: mee_find_located + mee_apply_prepare for the same keys in ONE launch.  The grad-independent half of the step's
+ * backward (the partition of the batch by hash bucket: latency-bound, 15-18 us per 256K keys) is run by the launch's first blocks beside the
+ * row gather (bound by bytes, twice as long), so the following mee_apply_*_located(d_keys, d_slots_out, …) with the SAME d_keys / n starts
+ * with its update kernel.  Same rules as mee_apply_prepare while the prepared apply is pending (mee_apply_discard drops it); tables without
+ * an optimizer: plain mee_find_located. */
+int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream);
 /* second-tier pass after a mee_find on another table (same keys/out/found buffers): positions with d_found[i] == 0
  * that THIS table holds get their row and d_found[i] = 1; every other position is left untouched.  No host sync, no
  * compaction: this is how a hot (HBM) table is backed by a cold (pinned host) one inside one stream. */

@@ -23,141 +23,26 @@
 // slice of the table.
 #include <hip/hip_runtime.h>
 
-#include "meepo_table_int.h"
+#include "meepo_apply_part.h"
 
 namespace mee {
 
-constexpr int kPartBlocks = 64;           // blocks of the two partition kernels
 constexpr int kPartThreads = 1024;
-constexpr uint32_t kSlab = 512;           // positions one apply block takes (= its thread count): what its LDS hash table holds at load 0.5
 constexpr int kApplyThreads = 512;
 constexpr int kApplyWaves = kApplyThreads / 64;
 constexpr uint32_t kLdsSlots = 2 * kSlab;
-constexpr uint32_t kBucketTarget = 256;   // positions per bucket aimed at (128..256 once the bucket count is a power of two)
-constexpr uint32_t kMaxBuckets = 8192;    // the partition kernels keep one LDS counter per bucket
 constexpr uint32_t kRun = 32;             // occurrences one tile sums in one go; longer runs are cut into chunks of this many
 
-uint32_t bucket_count_for(uint64_t n) {
-    uint32_t nbk = 1;
-    while ((uint64_t)nbk * kBucketTarget < n && nbk < kMaxBuckets) nbk <<= 1;
-    return nbk;
-}
-static uint32_t log2_of(uint32_t pow2) { uint32_t l = 0; while ((1u << l) < pow2) ++l; return l; }
+uint32_t bucket_count_for(uint64_t n) { return bucket_count_for_host(n); }
 static uint32_t max_units_for(uint64_t n) { return bucket_count_for(n) + (uint32_t)(n / kSlab) + 2; }
 
-__device__ __forceinline__ uint32_t apply_bucket_of(int64_t key, uint32_t lb) { return lb ? (uint32_t)(mix64((uint64_t)key) >> (64 - lb)) : 0u; }
-
-// exclusive prefix sum of a packed 64-bit value over a block of NW waves; every field of the packed value must stay below its width
-template <int NW>
-__device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v, unsigned long long* wsum /*[NW]*/, unsigned long long& total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned long long incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
-    __syncthreads();   // wsum may still be read from an earlier call
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    unsigned long long pre = 0, tot = 0;
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) { const unsigned long long x = wsum[ww]; if (ww < w) pre += x; tot += x; }
-    total = tot;
-    return pre + incl - v;
-}
-
-// ---- partition, kernel 1: every partition block sorts ITS share of the batch by bucket, inside its own contiguous slice of pos / pkey ------
-// (LDS histogram -> in-block prefix sum -> LDS cursors).  A block's writes stay inside its slice (16 KB + 32 KB at 4096 keys), i.e. in one
-// XCD's L2, where the 4- and 8-byte stores combine into whole lines.  (The first version scattered every key straight to its bucket's global
-// position: 256K keys = 512K partial-line stores from 64 CUs on 8 XCDs into the same lines — 19 us; and it needed a count kernel in front.)
-// Per (block, bucket) it leaves the run's length and its start inside the slice: the apply kernel pulls a bucket's entries out of the
-// <= 64 slices (short contiguous reads), the units kernel needs only the lengths.
+// ---- the partition kernel of an apply (the role itself: meepo_apply_part.h) ----------------------------------------------------------------
 __global__ __launch_bounds__(kPartThreads) void bkt_sort_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk, uint32_t lb,
-                                                                uint32_t per_block, BucketScratch bk, uint32_t* status) {
+                                                                uint32_t per_block, BucketScratch bk, uint32_t* status, OpCounters* op) {
     extern __shared__ uint32_t cursor[];
     __shared__ unsigned long long wsum[kPartThreads / 64];
-    constexpr uint32_t kMaxPerThread = kMaxBuckets / kPartThreads;
-    for (uint32_t j = threadIdx.x; j < nbk; j += kPartThreads) cursor[j] = 0u;
-    __syncthreads();
-    const uint32_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
-    bool bad = false;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += kPartThreads) {
-        const int64_t k = keys[i];
-        if (!reserved_key(k)) atomicAdd(&cursor[apply_bucket_of(k, lb)], 1u);
-        else bad = bad || k == kReclaimed;   // EMPTY = padding, silent (SPEC.md §2)
-    }
-    if (bad) atomicOr(status, (uint32_t)MEE_STATUS_RESERVED_KEY);
-    __syncthreads();
-    const uint32_t per_t = (nbk + kPartThreads - 1) / kPartThreads;   // buckets [t * per_t, (t + 1) * per_t) belong to thread t
-    uint32_t c[kMaxPerThread];
-    unsigned long long sum = 0;
-#pragma unroll
-    for (uint32_t q = 0; q < kMaxPerThread; ++q) {
-        const uint32_t b = threadIdx.x * per_t + q;
-        c[q] = (q < per_t && b < nbk) ? cursor[b] : 0u;
-        sum += c[q];
-    }
-    unsigned long long total;
-    uint32_t start = (uint32_t)block_scan_u64<kPartThreads / 64>(sum, wsum, total);
-#pragma unroll
-    for (uint32_t q = 0; q < kMaxPerThread; ++q) {
-        const uint32_t b = threadIdx.x * per_t + q;
-        if (q < per_t && b < nbk) {
-            bk.cnt_mat[(uint64_t)blockIdx.x * nbk + b] = c[q];
-            bk.off_mat[(uint64_t)blockIdx.x * nbk + b] = start;
-            cursor[b] = start;
-            start += c[q];
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += kPartThreads) {
-        const int64_t k = keys[i];
-        if (reserved_key(k)) continue;
-        const uint32_t r = lo + atomicAdd(&cursor[apply_bucket_of(k, lb)], 1u);
-        bk.pos[r] = i;
-        bk.pkey[r] = k;
-    }
-}
-
-// ---- partition, kernel 2 (one block): bucket sizes -> bucket offsets (the base of a split bucket's pending records) and the work-unit list --
-__global__ __launch_bounds__(kPartThreads) void bkt_units_kernel(uint32_t nbk, uint32_t n_blocks, BucketScratch bk, OpCounters* op) {
-    __shared__ unsigned long long wsum[kPartThreads / 64];
-    constexpr uint32_t kMaxPerThread = kMaxBuckets / kPartThreads;
-    const uint32_t per_t = (nbk + kPartThreads - 1) / kPartThreads;
-    uint32_t tot[kMaxPerThread];
-    unsigned long long packed = 0;   // bits 0..31 positions | 32..47 units of split buckets | 48..63 units of whole buckets
-#pragma unroll
-    for (uint32_t q = 0; q < kMaxPerThread; ++q) {
-        tot[q] = 0u;
-        const uint32_t b = threadIdx.x * per_t + q;
-        if (q < per_t && b < nbk) {
-#pragma unroll 8   // independent loads, eight in flight (one at a time this loop alone took 20 us)
-            for (uint32_t k = 0; k < n_blocks; ++k) tot[q] += bk.cnt_mat[(uint64_t)k * nbk + b];
-            const uint32_t ns = tot[q] > kSlab ? (tot[q] + kSlab - 1) / kSlab : (tot[q] ? 1u : 0u);
-            packed += (unsigned long long)tot[q] | (ns > 1 ? (unsigned long long)ns << 32 : (unsigned long long)ns << 48);
-        }
-    }
-    unsigned long long total;
-    const unsigned long long ex = block_scan_u64<kPartThreads / 64>(packed, wsum, total);
-    uint32_t pos0 = (uint32_t)ex, su0 = (uint32_t)(ex >> 32) & 0xFFFFu, nu0 = (uint32_t)(ex >> 48);
-    const uint32_t split_units = (uint32_t)(total >> 32) & 0xFFFFu, whole_units = (uint32_t)(total >> 48);
-#pragma unroll
-    for (uint32_t q = 0; q < kMaxPerThread; ++q) {
-        const uint32_t b = threadIdx.x * per_t + q;
-        if (q < per_t && b < nbk) {
-            bk.off[b] = pos0; bk.pend_cnt[b] = 0u; bk.ticket[b] = 0u;
-            const uint32_t ns = tot[q] > kSlab ? (tot[q] + kSlab - 1) / kSlab : (tot[q] ? 1u : 0u);
-            if (ns > 1) { for (uint32_t s = 0; s < ns; ++s) bk.units[su0 + s] = make_uint2(b, s); su0 += ns; }   // split buckets first: they take longest
-            else if (ns == 1) { bk.units[split_units + nu0] = make_uint2(b, 0u); ++nu0; }
-            pos0 += tot[q];
-        }
-    }
-    if (threadIdx.x == 0) {
-        bk.off[nbk] = (uint32_t)total;
-        *bk.n_units = split_units + whole_units;
-        op->n_part = 0u;   // fp64 partial rows of long runs are handed out from BatchScratch::gacc by the apply kernel
-    }
+    __shared__ uint32_t is_last;
+    sort_role<kPartThreads>(keys, n, nbk, lb, per_block, blockIdx.x, gridDim.x, bk, status, op, cursor, wsum, &is_last);
 }
 
 // ---- the apply kernel -------------------------------------------------------------------------------------------------------------
@@ -232,9 +117,11 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
     if (t == 0) { L.n_big = 0u; }
     __syncthreads();
     uint32_t my_slot = 0, my_r = 0;
+    bool my_first = false;
+    int64_t my_tslot = -1;
     if (t < m) {
         int64_t key;
-        int64_t tslot = -1;   // LOCATED: the table slot of the key (decoded handle | carried by the record)
+        int64_t tslot = -1;   // LOCATED: the key's slot handle (positions) | the table slot its record carries (merge)
         if (src_rec) {
             key = bk.pend_key[rec_bucket0 + my_src];
             if constexpr (LOCATED) tslot = bk.pend_slot[rec_bucket0 + my_src];
@@ -247,11 +134,7 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
             const uint32_t p = bk.pos[at];
             key = bk.pkey[at];
             my_src = A.gidx ? min(A.gidx[p], a.grad_rows - 1) : p;   // the row of the grad array that belongs to the position
-            if constexpr (LOCATED) {
-                bool stale;
-                tslot = handle_slot(A.slots[p], A.handle_tag, A.capacity, stale);
-                if (stale) atomicOr(A.status, (uint32_t)MEE_STATUS_STALE_HANDLE);   // rare: the caller kept handles across a remove / clear / reserve
-            }
+            if constexpr (LOCATED) tslot = A.slots[p];   // the raw handle: decoded where it is first needed, so that the load travels beside the LDS work
         }
         const unsigned long long bkey = (unsigned long long)key ^ kBias;
         my_slot = (uint32_t)(mix64b((uint64_t)key) & (kLdsSlots - 1));   // mix64's top bits chose the bucket: take another mixer here
@@ -263,9 +146,8 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
             my_slot = (my_slot + 1) & (kLdsSlots - 1);
         }
         my_r = atomicAdd(&L.cnt[my_slot], 1u);
-        if constexpr (LOCATED) {
-            if (first_of_run) L.slot[my_slot] = tslot;   // every occurrence of a key names the same slot: the run keeps one
-        }
+        my_first = first_of_run;
+        my_tslot = tslot;
     }
     __syncthreads();
     // ---- 2. prefix sums over the runs: where each run starts in src, its work items, its number, its fp64 partial rows ----
@@ -302,7 +184,19 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
         }
     }
     __syncthreads();
-    if (t < m) L.src[L.off[my_slot] + my_r] = my_src;
+    if (t < m) {
+        L.src[L.off[my_slot] + my_r] = my_src;
+        if constexpr (LOCATED) {
+            if (my_first) {   // every occurrence of a key names the same slot: the run keeps one
+                if (src_rec) L.slot[my_slot] = my_tslot;
+                else {
+                    bool stale;
+                    L.slot[my_slot] = handle_slot(my_tslot, A.handle_tag, A.capacity, stale);
+                    if (stale) atomicOr(A.status, (uint32_t)MEE_STATUS_STALE_HANDLE);   // rare: the caller kept handles across a remove / clear / reserve
+                }
+            }
+        }
+    }
     __syncthreads();
     const uint32_t n_items = L.n_items, n_big = L.n_big;
     const uint32_t rec_out0 = rec_bucket0 + (emit ? L.rec_base : 0u);   // emit: where this slab's records go
@@ -617,6 +511,8 @@ int bucket_scratch_alloc(mee_table* t) {
     alloc((void**)&bk.off, ((uint64_t)bk.n_buckets_max + 1) * 4);
     alloc((void**)&bk.units, (uint64_t)bk.max_units * sizeof(uint2));
     alloc((void**)&bk.n_units, 4);
+    alloc((void**)&bk.sort_ticket, 4);
+    if (e == hipSuccess) e = hipMemset(bk.sort_ticket, 0, 4);   // (the last block of every partition launch puts it back to 0)
     alloc((void**)&bk.pend_cnt, (uint64_t)bk.n_buckets_max * 4);
     alloc((void**)&bk.ticket, (uint64_t)bk.n_buckets_max * 4);
     alloc((void**)&bk.pend_key, bk.fast_max * 8);
@@ -627,23 +523,16 @@ int bucket_scratch_alloc(mee_table* t) {
 }
 void bucket_scratch_free(mee_table* t) {
     BucketScratch& bk = t->bk;
-    void* dev[] = {bk.pkey, bk.cnt_mat, bk.off_mat, bk.off, bk.units, bk.n_units, bk.pend_cnt, bk.ticket, bk.pend_key, bk.pend_slot, bk.pend_row};
+    void* dev[] = {bk.pkey, bk.cnt_mat, bk.off_mat, bk.off, bk.units, bk.n_units, bk.sort_ticket, bk.pend_cnt, bk.ticket, bk.pend_key, bk.pend_slot, bk.pend_row};
     for (void* p : dev) if (p) (void)hipFree(p);
-}
-
-static void part_geometry(uint32_t n, uint32_t& blocks, uint32_t& per_block) {
-    blocks = (n + 4095) / 4096;   // at least 4 keys per thread
-    if (blocks > (uint32_t)kPartBlocks) blocks = kPartBlocks;
-    if (blocks < 1) blocks = 1;
-    per_block = (n + blocks - 1) / blocks;
 }
 
 int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st) {
     const uint32_t nbk = bucket_count_for(n), lb = log2_of(nbk);
     uint32_t blocks, per_block;
-    part_geometry(n, blocks, per_block);
-    bkt_sort_kernel<<<blocks, kPartThreads, nbk * 4, st>>>(d_keys, n, nbk, lb, per_block, t->bk, &t->ctr->status);
-    bkt_units_kernel<<<1, kPartThreads, 0, st>>>(nbk, blocks, t->bk, t->op);
+    part_geometry(n, kPartThreads, blocks, per_block);
+    t->part_blocks = blocks; t->part_per_block = per_block;
+    bkt_sort_kernel<<<blocks, kPartThreads, nbk * 4, st>>>(d_keys, n, nbk, lb, per_block, t->bk, &t->ctr->status, t->op);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
@@ -655,7 +544,7 @@ int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const Op
     A.capacity = t->capacity; A.handle_tag = (int64_t)(t->handle_epoch & kHandleEpochMask) << kHandleSlotBits; A.status = &t->ctr->status;
     A.part = t->bs.gacc; A.max_part = t->bs.max_part; A.op = t->op; A.a = a;
     A.nbk = bucket_count_for(n);
-    part_geometry(n, A.part_blocks, A.per_block);
+    A.part_blocks = t->part_blocks; A.per_block = t->part_per_block;   // as whoever partitioned this batch left them
     const unsigned grid = max_units_for(n);
 #define BKT(K, D4, LOC) bkt_apply_kernel<K, D4, LOC><<<grid, kApplyThreads, 0, st>>>(A, t->bk)
 #define BKT_L(K, D4) do { if (d_slots) BKT(K, D4, true); else BKT(K, D4, false); } while (0)

@@ -1,0 +1,191 @@
+// meepo_apply_part.h — the partition half of the bucketed sparse-optimizer apply (see meepo_apply.hip), as device code two kernels share:
+// the partition kernel of an apply (meepo_apply.hip) and the training forward mee_find_located_prepare (meepo_table.hip), whose launch gives
+// its first blocks this role so that the partition of the step's backward runs beside — hidden behind — the forward's row gather.
+#pragma once
+#include "meepo_table_int.h"
+
+namespace mee {
+
+constexpr int kPartBlocks = 64;           // blocks that share the partition of one batch
+constexpr uint32_t kSlab = 512;           // positions one apply block takes (= its thread count): what its LDS hash table holds at load 0.5
+constexpr uint32_t kBucketTarget = 256;   // positions per bucket aimed at (128..256 once the bucket count is a power of two)
+constexpr uint32_t kMaxBuckets = 8192;    // the partition keeps one LDS counter per bucket
+constexpr int kKeyGroup = 8;              // keys a thread loads back to back before it touches LDS (one at a time, every load waited for the one before)
+
+inline uint32_t bucket_count_for_host(uint64_t n) {
+    uint32_t nbk = 1;
+    while ((uint64_t)nbk * kBucketTarget < n && nbk < kMaxBuckets) nbk <<= 1;
+    return nbk;
+}
+inline uint32_t log2_of(uint32_t pow2) { uint32_t l = 0; while ((1u << l) < pow2) ++l; return l; }
+inline void part_geometry(uint32_t n, uint32_t threads, uint32_t& blocks, uint32_t& per_block) {
+    blocks = (n + 4 * threads - 1) / (4 * threads);   // at least 4 keys per thread
+    if (blocks > (uint32_t)kPartBlocks) blocks = kPartBlocks;
+    if (blocks < 1) blocks = 1;
+    per_block = (n + blocks - 1) / blocks;
+}
+
+__device__ __forceinline__ uint32_t apply_bucket_of(int64_t key, uint32_t lb) { return lb ? (uint32_t)(mix64((uint64_t)key) >> (64 - lb)) : 0u; }
+
+// exclusive prefix sum of a packed 64-bit value over a block of NW waves; every field of the packed value must stay below its width
+template <int NW>
+__device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v, unsigned long long* wsum /*[NW]*/, unsigned long long& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    __syncthreads();   // wsum may still be read from an earlier call
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    unsigned long long pre = 0, tot = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) { const unsigned long long x = wsum[ww]; if (ww < w) pre += x; tot += x; }
+    total = tot;
+    return pre + incl - v;
+}
+
+// The block that finishes the partition LAST adds the run lengths up: bucket sizes -> bucket offsets (the base of a split bucket's pending
+// records) and the work-unit list (split buckets first: they take longest).  `tot_lds` = nbk words of LDS (the partition's cursors, free by now).
+template <int THREADS>
+__device__ __forceinline__ void build_units(uint32_t nbk, uint32_t n_blocks, const BucketScratch& bk, OpCounters* op, uint32_t* tot_lds, unsigned long long* wsum) {
+    const uint32_t per_t = (nbk + THREADS - 1) / THREADS;   // buckets [t * per_t, (t + 1) * per_t) belong to thread t
+    unsigned long long packed = 0;   // bits 0..31 positions | 32..47 units of split buckets | 48..63 units of whole buckets
+    for (uint32_t q = 0; q < per_t; ++q) {
+        const uint32_t b = threadIdx.x * per_t + q;
+        if (b >= nbk) break;
+        uint32_t tot = 0;
+        {   // all of the bucket's (at most kPartBlocks) run lengths in flight at once: under the forward's row traffic every dependent round trip
+            // of this role costs microseconds (sixteen at a time: four round trips; one at a time this step took 6 us even on an idle chip)
+            uint32_t cs[kPartBlocks];
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)kPartBlocks; ++k) cs[k] = k < n_blocks ? bk.cnt_mat[(uint64_t)k * nbk + b] : 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)kPartBlocks; ++k) tot += cs[k];
+        }
+        tot_lds[b] = tot;
+        const uint32_t ns = tot > kSlab ? (tot + kSlab - 1) / kSlab : (tot ? 1u : 0u);
+        packed += (unsigned long long)tot | (ns > 1 ? (unsigned long long)ns << 32 : (unsigned long long)ns << 48);
+    }
+    unsigned long long total;
+    const unsigned long long ex = block_scan_u64<THREADS / 64>(packed, wsum, total);
+    uint32_t pos0 = (uint32_t)ex, su0 = (uint32_t)(ex >> 32) & 0xFFFFu, nu0 = (uint32_t)(ex >> 48);
+    const uint32_t split_units = (uint32_t)(total >> 32) & 0xFFFFu, whole_units = (uint32_t)(total >> 48);
+    for (uint32_t q = 0; q < per_t; ++q) {
+        const uint32_t b = threadIdx.x * per_t + q;
+        if (b >= nbk) break;
+        const uint32_t tot = tot_lds[b];   // (this thread's own store)
+        bk.off[b] = pos0; bk.pend_cnt[b] = 0u; bk.ticket[b] = 0u;
+        const uint32_t ns = tot > kSlab ? (tot + kSlab - 1) / kSlab : (tot ? 1u : 0u);
+        if (ns > 1) { for (uint32_t s = 0; s < ns; ++s) bk.units[su0 + s] = make_uint2(b, s); su0 += ns; }
+        else if (ns == 1) { bk.units[split_units + nu0] = make_uint2(b, 0u); ++nu0; }
+        pos0 += tot;
+    }
+    if (threadIdx.x == 0) {
+        bk.off[nbk] = (uint32_t)total;
+        *bk.n_units = split_units + whole_units;
+        op->n_part = 0u;      // fp64 partial rows of long runs are handed out from BatchScratch::gacc by the apply kernel
+        *bk.sort_ticket = 0u; // for the next partition (visible to it by the kernel boundary)
+    }
+}
+
+// One partition block (block `blk` of `n_blocks`, THREADS threads): sorts ITS share of the batch by bucket, inside its own contiguous slice of
+// pos / pkey (LDS histogram -> in-block prefix sum -> LDS cursors).  A block's writes stay inside its slice (16 KB + 32 KB at 4096 keys),
+// i.e. in one XCD's L2, where the 4- and 8-byte stores combine into whole lines.  (The first version scattered every key straight to its
+// bucket's global position: 256K keys = 512K partial-line stores from 64 CUs on 8 XCDs into the same lines — 19 us; and it needed a count
+// kernel in front.)  Per (block, bucket) it leaves the run's length and its start inside the slice: the apply kernel pulls a bucket's
+// entries out of the <= 64 slices (short contiguous reads).  The block that finishes LAST (agent-scope release -> ticket -> acquire:
+// cdna_hip_programming.md Guideline 16, counter form; nobody waits) builds the unit list: as a kernel of its own that step cost a dependent
+// launch.  `cursor` = nbk words of LDS.
+template <int THREADS>
+__device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk, uint32_t lb, uint32_t per_block, uint32_t blk,
+                                          uint32_t n_blocks, const BucketScratch& bk, uint32_t* status, OpCounters* op, uint32_t* cursor,
+                                          unsigned long long* wsum /*[THREADS / 64]*/, uint32_t* is_last /* LDS */) {
+    for (uint32_t j = threadIdx.x; j < nbk; j += THREADS) cursor[j] = 0u;
+    __syncthreads();
+    const uint32_t lo = blk * per_block, hi = min(n, lo + per_block);
+    const bool in_regs = per_block <= (uint32_t)kKeyGroup * THREADS;   // block-uniform: each thread's keys fit its registers -> ONE pass over the key array
+    int64_t kr[kKeyGroup];
+    bool bad = false;
+    if (in_regs) {
+#pragma unroll
+        for (int q = 0; q < kKeyGroup; ++q) kr[q] = lo + threadIdx.x + q * THREADS < hi ? keys[lo + threadIdx.x + q * THREADS] : kEmpty;
+#pragma unroll
+        for (int q = 0; q < kKeyGroup; ++q) {
+            if (!reserved_key(kr[q])) atomicAdd(&cursor[apply_bucket_of(kr[q], lb)], 1u);
+            else bad = bad || kr[q] == kReclaimed;   // EMPTY = padding, silent (SPEC.md §2)
+        }
+    } else {
+        for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += kKeyGroup * THREADS) {
+            int64_t k[kKeyGroup];
+#pragma unroll
+            for (int q = 0; q < kKeyGroup; ++q) k[q] = i0 + q * THREADS < hi ? keys[i0 + q * THREADS] : kEmpty;
+#pragma unroll
+            for (int q = 0; q < kKeyGroup; ++q) {
+                if (!reserved_key(k[q])) atomicAdd(&cursor[apply_bucket_of(k[q], lb)], 1u);
+                else bad = bad || k[q] == kReclaimed;
+            }
+        }
+    }
+    if (bad) atomicOr(status, (uint32_t)MEE_STATUS_RESERVED_KEY);
+    __syncthreads();
+    const uint32_t per_t = (nbk + THREADS - 1) / THREADS;   // buckets [t * per_t, (t + 1) * per_t) belong to thread t
+    unsigned long long sum = 0;
+    for (uint32_t q = 0; q < per_t; ++q) {
+        const uint32_t b = threadIdx.x * per_t + q;
+        if (b < nbk) sum += cursor[b];
+    }
+    unsigned long long total;
+    uint32_t start = (uint32_t)block_scan_u64<THREADS / 64>(sum, wsum, total);
+    for (uint32_t q = 0; q < per_t; ++q) {
+        const uint32_t b = threadIdx.x * per_t + q;
+        if (b >= nbk) break;
+        const uint32_t c = cursor[b];
+        bk.cnt_mat[(uint64_t)blk * nbk + b] = c;
+        bk.off_mat[(uint64_t)blk * nbk + b] = start;
+        cursor[b] = start;
+        start += c;
+    }
+    __syncthreads();
+    if (in_regs) {
+#pragma unroll
+        for (int q = 0; q < kKeyGroup; ++q) {
+            if (reserved_key(kr[q])) continue;
+            const uint32_t r = lo + atomicAdd(&cursor[apply_bucket_of(kr[q], lb)], 1u);
+            bk.pos[r] = lo + threadIdx.x + q * THREADS;
+            bk.pkey[r] = kr[q];
+        }
+    } else {
+        for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += kKeyGroup * THREADS) {
+            int64_t k[kKeyGroup];
+#pragma unroll
+            for (int q = 0; q < kKeyGroup; ++q) k[q] = i0 + q * THREADS < hi ? keys[i0 + q * THREADS] : kEmpty;
+#pragma unroll
+            for (int q = 0; q < kKeyGroup; ++q) {
+                if (reserved_key(k[q])) continue;
+                const uint32_t r = lo + atomicAdd(&cursor[apply_bucket_of(k[q], lb)], 1u);
+                bk.pos[r] = i0 + q * THREADS;
+                bk.pkey[r] = k[q];
+            }
+        }
+    }
+    // ---- publish this block's rows of the count matrix, take a ticket; the last block builds the unit list ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t tk = __hip_atomic_fetch_add(bk.sort_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *is_last = tk == n_blocks - 1;
+        if (tk == n_blocks - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (*is_last) build_units<THREADS>(nbk, n_blocks, bk, op, cursor, wsum);   // block-uniform
+}
+
+}  // namespace mee

@@ -18,7 +18,7 @@
 #include <cstring>
 #include <new>
 
-#include "meepo_table_int.h"
+#include "meepo_apply_part.h"
 
 namespace mee {
 
@@ -193,6 +193,30 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
                                                    uint32_t dim4_rt, uint32_t* hits, int64_t* __restrict__ slots_out = nullptr, int64_t handle_tag = 0) {
     find_span<DIM4, R, NT>(tkeys, values, nb, keys, n, out, found, defv, dim4_rt, hits, slots_out,
                            (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), (uint64_t)gridDim.x * (blockDim.x >> 6), handle_tag);
+}
+
+// The training forward (mee_find_located_prepare): the located find whose launch gives its first `part_blocks` blocks the partition role of
+// the bucketed apply (meepo_apply_part.h).  The partition of the step's backward — a latency-bound 15-18 us of LDS histograms for a 256K-key
+// batch — runs beside the forward's row gather, which is bound by bytes and takes twice as long: the backward starts with its update kernel.
+// (1024-thread blocks: the partition role wants many threads per block — 64 blocks x 1024 threads for 256K keys; with 256-thread blocks the
+// role took as long as the find and the launch gained nothing — and the find, bound by bytes, does not care about its block size.)
+constexpr int kFindPrepareThreads = 1024;
+template <int DIM4, int R, int NT>
+__global__ __launch_bounds__(kFindPrepareThreads) void find_prepare_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
+                                                           const int64_t* __restrict__ keys, uint64_t n, f32x4* __restrict__ out,
+                                                           uint8_t* __restrict__ found, float defv, uint32_t dim4_rt, int64_t* __restrict__ slots_out,
+                                                           int64_t handle_tag, uint32_t part_blocks, uint32_t nbk, uint32_t lb, uint32_t per_block,
+                                                           BucketScratch bk, uint32_t* status, OpCounters* op) {
+    extern __shared__ uint32_t part_cursor[];
+    __shared__ unsigned long long part_wsum[kFindPrepareThreads / 64];
+    __shared__ uint32_t part_is_last;
+    if (blockIdx.x < part_blocks) {   // block-uniform
+        sort_role<kFindPrepareThreads>(keys, (uint32_t)n, nbk, lb, per_block, blockIdx.x, part_blocks, bk, status, op, part_cursor, part_wsum, &part_is_last);
+        return;
+    }
+    find_span<DIM4, R, NT>(tkeys, values, nb, keys, n, out, found, defv, dim4_rt, nullptr, slots_out,
+                           (uint64_t)(blockIdx.x - part_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6), (uint64_t)(gridDim.x - part_blocks) * (blockDim.x >> 6),
+                           handle_tag);
 }
 
 // Several lookup requests of one table in ONE launch (mee_find_many): the per-launch latency floor (~5 us: dispatch + the dependent
@@ -2584,6 +2608,39 @@ int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* strea
         t->prepared_path = 2;
     }
     t->prepared_n = n; t->prepared_keys = d_keys;
+    return MEE_OK;
+}
+
+// The training forward: mee_find_located whose launch also carries mee_apply_prepare for the SAME keys (the partition half of the bucketed
+// apply, run by the launch's first blocks beside the row gather).  Falls back to the two separate launches when the batch is not one the
+// bucketed apply takes (table without optimizer: plain mee_find_located).
+int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
+    if (!t || (n && (!d_keys || !d_out || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_located_prepare: null argument");
+    if (t->prepared_n) return fail(MEE_ERR_INVALID_ARG, "mee_find_located_prepare: a prepared apply is already pending");
+    if (n == 0) return MEE_OK;
+    if (t->optimizer == MEE_OPT_NONE) return mee_find_located(t, d_keys, n, d_out, d_found, d_slots_out, stream);
+    if (n > t->max_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_find_located_prepare: n=%zu exceeds config.max_batch=%llu", n, (unsigned long long)t->max_batch);
+    if (!use_bucketed_apply(t, n)) {
+        if (int rc = mee_find_located(t, d_keys, n, d_out, d_found, d_slots_out, stream)) return rc;
+        return mee_apply_prepare(t, d_keys, n, stream);
+    }
+    DeviceGuard g(t->device);
+    hipStream_t st = as_stream(stream);
+    const uint32_t nbk = bucket_count_for(n), lb = log2_of(nbk);
+    uint32_t part_blocks, per_block;
+    part_geometry((uint32_t)n, kFindPrepareThreads, part_blocks, per_block);
+    const int R = t->dim4 == 16 || t->dim4 == 32 ? 2 : 1;
+    const unsigned find_blocks = grid_for(n, (kFindPrepareThreads / 64) * 4u * (unsigned)R, 1u << 22);
+    const bool cached_out = t->find_nt >= 0 && (t->find_nt & 4);
+#define FINDLP1(D4, RR, NT) find_prepare_kernel<D4, RR, NT><<<part_blocks + find_blocks, kFindPrepareThreads, nbk * 4, st>>>(t->keys, (const f32x4*)t->values, t->nb, d_keys, n, (f32x4*)d_out, d_found, \
+        t->default_value, t->dim4, d_slots_out, handle_tag_of(t), part_blocks, nbk, lb, per_block, t->bk, &t->ctr->status, t->op)
+#define FINDLP(D4, RR) do { if (cached_out) FINDLP1(D4, RR, 68); else FINDLP1(D4, RR, 64); } while (0)
+    if (t->dim4 == 16) FINDLP(16, 2); else if (t->dim4 == 32) FINDLP(32, 2); else FINDLP(0, 1);
+#undef FINDLP
+#undef FINDLP1
+    MEE_HIP(hipGetLastError());
+    t->part_blocks = part_blocks; t->part_per_block = per_block;
+    t->prepared_n = n; t->prepared_keys = d_keys; t->prepared_path = 1;
     return MEE_OK;
 }
 

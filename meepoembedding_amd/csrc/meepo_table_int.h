@@ -71,6 +71,7 @@ struct BucketScratch {
     uint32_t* off;        // [n_buckets_max + 1] start of each bucket in pos / pkey
     uint2* units;         // [max_units] work unit -> (bucket, slab of the bucket): split buckets first
     uint32_t* n_units;    // [1]
+    uint32_t* sort_ticket;// [1] partition blocks finished (the last one builds the unit list and puts it back to 0)
     uint32_t* pend_cnt;   // [n_buckets_max] split buckets: pending records appended so far
     uint32_t* ticket;     // [n_buckets_max] split buckets: slabs finished
     int64_t* pend_key;    // [fast_max] pending records of split buckets: key …
@@ -119,6 +120,7 @@ struct mee_table {
     mee::BucketScratch bk;      // bucketed apply (null pointers when the table has no optimizer)
     int apply_path;             // -1 = the library's choice, 0 = group-table apply, 1 = bucketed apply
     uint32_t prepared_path;     // which path a pending mee_apply_prepare took
+    uint32_t part_blocks, part_per_block;   // bucketed apply: how the latest partition split the batch (blocks, batch positions per block)
 };
 
 namespace mee {

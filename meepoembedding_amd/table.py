@@ -395,8 +395,10 @@ class LookupTable:
         return slots.contiguous()
 
     def find_located(self, keys: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None,
-                     slots: torch.Tensor | None = None):
-        """find() that also returns each key's slot handle (-1 = absent) for apply_*(…, slots=…) of the same training step."""
+                     slots: torch.Tensor | None = None, prepare_apply: bool = False):
+        """find() that also returns each key's slot handle (-1 = absent) for apply_*(…, slots=…) of the same training step.
+        prepare_apply: the training forward (mee_find_located_prepare) — the launch also partitions the batch for the apply of the SAME
+        `keys` tensor that must follow (its grad-independent half runs beside the row gather)."""
         k = self._keys(keys)
         n = k.numel()
         if out is None:
@@ -405,7 +407,8 @@ class LookupTable:
             found = torch.empty(n, dtype=torch.uint8, device=self.device)
         if slots is None:
             slots = torch.empty(n, dtype=torch.int64, device=self.device)
-        check(_lib.lib().mee_find_located(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), slots.data_ptr(), self._s()))
+        fn = _lib.lib().mee_find_located_prepare if prepare_apply else _lib.lib().mee_find_located
+        check(fn(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), slots.data_ptr(), self._s()))
         return out, found, slots
 
     def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10,

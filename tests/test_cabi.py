@@ -17,3 +17,21 @@ def test_cpp_host_programs(dev, name):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert f"{name} ok" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_sharded_ranks_from_plain_cpp(dev, ranks):
+    """tests/cabi/sharded_mp_test.cpp: the program forks `ranks` processes BEFORE any HIP call and drives insert -> size -> find -> sparse Adagrad
+    -> find -> remove through mee_sharded_* (exact segments, then padded segments + pre-exchange dedup), checking key-derived rows and the
+    update computed on the host.  With fewer GPUs than ranks the library binds the shared-memory stand-in for librccl (several ranks on one
+    device); with enough GPUs it binds RCCL itself and the ranks exchange over xGMI."""
+    import torch
+    exe = os.path.join(ROOT, "build", "sharded_mp_test")
+    assert os.path.exists(exe), "build/sharded_mp_test missing: run __graft_entry__.build()"
+    env = dict(os.environ)
+    if torch.cuda.device_count() < ranks:
+        env["MEE_RCCL_LIB"] = os.path.join(ROOT, "build", "libfake_rccl.so")
+    r = subprocess.run([exe, str(ranks)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "sharded_mp_test ok" in r.stdout

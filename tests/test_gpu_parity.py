@@ -556,6 +556,45 @@ def test_located_apply_equals_plain_apply(dev, opt, dim):
     assert tb.status() == 0 and not torch.equal(tb.find(kq[8:])[0], ta.find(kq[8:])[0])
 
 
+@pytest.mark.parametrize("opt", ["adagrad", "adam"])
+@pytest.mark.parametrize("dim,n_keys,batch", [(64, 200000, 131072), (128, 3000, 2000), (24, 50000, 40000)])
+def test_training_forward_prepares_the_apply(dev, opt, dim, n_keys, batch):
+    """find_located(prepare_apply=True) — ONE launch: the located find + the partition of the step's apply, run by the launch's first blocks —
+    followed by apply_*(slots=…) must leave the table exactly as find_located + apply_* does, and return the same rows; uniform and skewed
+    batches (hot keys: split buckets), absent keys, padding; a prepared apply can also be discarded."""
+    keys = synth.keys_np(61, 0, n_keys); rows = synth.rows_np(keys, dim, 2)
+    kind = OPT_ADAGRAD if opt == "adagrad" else OPT_ADAM
+    mk = lambda: LookupTable(int(n_keys * 1.5), dim, device=dev, optimizer=kind, max_batch=batch, initial_accumulator=0.1)
+    ta, tb = mk(), mk()
+    for t in (ta, tb):
+        for s_ in range(0, n_keys, batch):
+            t.insert(T(keys[s_:s_ + batch], dev), T(rows[s_:s_ + batch], dev))
+    rng = np.random.default_rng(9)
+    for step in range(4):
+        idx = np.minimum(rng.zipf(1.2, size=batch) - 1, n_keys - 1) if step % 2 else rng.integers(0, n_keys, batch)
+        bk_ = keys[idx]
+        bk_[rng.integers(0, batch, 30)] = synth.keys_np(62, step * 30, 30)     # absent
+        bk_[rng.integers(0, batch, 3)] = oracle.EMPTY_KEY                       # padding
+        kt = T(bk_, dev)
+        g = torch.randn(batch, dim, device=dev) * 0.01
+        oa, fa, sa = ta.find_located(kt)
+        ob, fb, sb = tb.find_located(kt, prepare_apply=True)
+        assert torch.equal(oa, ob) and torch.equal(fa, fb) and torch.equal(sa >= 0, sb >= 0)   # (two tables: their slots differ)
+        if step == 2:   # a prepared apply may be dropped (and made again)
+            tb.apply_discard()
+            tb.find_located(kt, out=ob, found=fb, slots=sb, prepare_apply=True)
+        if opt == "adagrad":
+            ta.apply_adagrad(kt, g, lr=0.01, slots=sa); tb.apply_adagrad(kt, g, lr=0.01, slots=sb)
+        else:
+            ta.apply_adam(kt, g, lr=0.001, step=step + 1, slots=sa); tb.apply_adam(kt, g, lr=0.001, step=step + 1, slots=sb)
+    ea, eb = ta.export(with_state=True), tb.export(with_state=True)
+    ia, ib = torch.argsort(ea[0]), torch.argsort(eb[0])
+    assert torch.equal(ea[0][ia], eb[0][ib]) and ta.status() == tb.status() == 0
+    for xa, xb in zip(ea[1:], eb[1:]):
+        if xa is not None:
+            torch.testing.assert_close(xa[ia], xb[ib], rtol=RTOL, atol=ATOL)
+
+
 def test_optimizer_unique_keys_bit_exact(dev):
     """No duplicates -> no reduction-order freedom: the HIP update must equal the oracle bit for bit."""
     dim, n = 64, 10000

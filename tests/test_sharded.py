@@ -169,6 +169,8 @@ def _run_rank_body(rank, world, port, backend, q, tiered=False, DIM=DIM):
             pt.close()
         if backend in ("nccl", "fake-rccl"):
             _native_rccl_checks(rank, world, dev, DIM, keys, rows, grads, probe, dup, router)
+        if backend in ("nccl", "fake-rccl", "gloo-gpu") and not tiered:
+            _pipelined_lookup_checks(rank, world, dev, DIM, sh, local, probe, dup, backend)
         if not tiered:
             o2, f2 = sh.find(dup, dedup=True)
             assert torch.equal(o1, o2) and torch.equal(f1, f2)
@@ -273,6 +275,48 @@ def _native_rccl_checks(rank, world, dev, dim, keys, rows, grads, probe, dup, ro
             RcclShardedTable(l_exact, BATCH + (64 if rank == 0 else 0), pad_slack=0.0)
     for t in tables[1:]:
         t.close()
+
+
+def _pipelined_lookup_checks(rank, world, dev, dim, sh, local, probe, dup, backend):
+    """SURVEY 8f-2 "batch pipelining": TWO sharded lookups kept in flight — each on a context (buffers, router workspace) and a HIP stream of
+    its own, both over the same shard — must return bit for bit what the same lookups return one after the other.  Three carriers: the
+    torch.distributed exchange, the exchange behind the C-ABI (exact and padded segments), the peer-mapped transport."""
+    from meepoembedding_amd import Router
+    qa, qb = probe, torch.cat([dup[:1500], probe[100:900]])
+    serial = [sh.find(qa), sh.find(qb)]
+    torch.cuda.synchronize(dev)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream(dev))
+
+    def in_flight(ctxs):
+        got = []
+        for rep in range(3):   # several rounds back to back: a context's buffers are reused while the other context's lookup is still running
+            for j, (c, q) in enumerate(zip(ctxs, (qa, qb))):
+                with torch.cuda.stream(streams[j]):
+                    got.append(c.find(q))
+        for st in streams:
+            st.synchronize()
+        for j, (o, f) in enumerate(got):
+            assert torch.equal(o, serial[j % 2][0]) and torch.equal(f, serial[j % 2][1]), f"lookup {j} in flight differs from the serial result"
+
+    in_flight([ShardedLookupTable(local, Router(world, BATCH, device=dev)) for _ in range(2)])
+    if backend in ("nccl", "fake-rccl"):
+        from meepoembedding_amd.sharded import RcclShardedTable
+        for slack, dd in ((0.0, False), (1.5, False), (1.5, True)):
+            ctxs = [RcclShardedTable(local, BATCH, pad_slack=slack, dedup=dd) for _ in range(2)]
+            in_flight(ctxs)
+            assert all(c.status() == 0 for c in ctxs)
+            for c in ctxs:
+                c.close()
+    if backend in ("nccl", "gloo-gpu"):
+        from meepoembedding_amd.p2p import PeerShardedFind
+        ctxs = [PeerShardedFind(local, Router(world, 8192, device=dev), max_batch=8192) for _ in range(2)]
+        in_flight(ctxs)
+        for c in ctxs:
+            c.check()
+            c.close()
+    dist.barrier()
 
 
 def _check(results, world, dim=DIM):

@@ -28,10 +28,10 @@ def apply(k, **kw):
 
 for path in paths:
     t.set_tuning("apply_path", path)
-    for label, located in (("apply alone (probing)", False), ("find_located + apply (located)", True)):
+    for label, located in (("apply alone (probing)", False), ("find_located + apply (located)", True), ("find_located_prepare + apply (located)", 2)):
         def step(i):
             if located:
-                t.find_located(batches[i % 8], out=out, found=found, slots=slots)
+                t.find_located(batches[i % 8], out=out, found=found, slots=slots, prepare_apply=located == 2)
                 apply(batches[i % 8], slots=slots)
             else:
                 apply(batches[i % 8])
