@@ -34,15 +34,14 @@ constexpr uint32_t kLdsSlots = 2 * kSlab;
 constexpr uint32_t kRun = 32;             // occurrences one tile sums in one go; longer runs are cut into chunks of this many
 
 uint32_t bucket_count_for(uint64_t n) { return bucket_count_for_host(n); }
-static uint32_t max_units_for(uint64_t n) { return bucket_count_for(n) + (uint32_t)(n / kSlab) + 2; }
+static uint32_t max_extra_slabs(uint64_t n) { return 2 * (uint32_t)(n / kSlab) + 2; }   // slabs of split buckets: sum of ceil(size / kSlab) over buckets larger than kSlab
 
 // ---- the partition kernel of an apply (the role itself: meepo_apply_part.h) ----------------------------------------------------------------
 __global__ __launch_bounds__(kPartThreads) void bkt_sort_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk, uint32_t lb,
                                                                 uint32_t per_block, BucketScratch bk, uint32_t* status, OpCounters* op) {
     extern __shared__ uint32_t cursor[];
     __shared__ unsigned long long wsum[kPartThreads / 64];
-    __shared__ uint32_t is_last;
-    sort_role<kPartThreads>(keys, n, nbk, lb, per_block, blockIdx.x, gridDim.x, bk, status, op, cursor, wsum, &is_last);
+    sort_role<kPartThreads>(keys, n, nbk, lb, per_block, blockIdx.x, gridDim.x, bk, status, op, cursor, wsum);
 }
 
 // ---- the apply kernel -------------------------------------------------------------------------------------------------------------
@@ -70,6 +69,7 @@ struct ApplyArgs {
     uint64_t capacity; int64_t handle_tag; uint32_t* status;
     double* part; uint32_t max_part;     // fp64 partial rows of long runs (BatchScratch::gacc)
     uint32_t nbk, part_blocks, per_block;   // the partition: buckets, partition blocks, batch positions per partition block
+    uint32_t n_extra;                       // spare blocks at the head of the grid
     OpCounters* op;
     OptArgs a;
 };
@@ -84,7 +84,7 @@ struct ApplyArgs {
 // kernel from 64 to 113 VGPRs, i.e. the hot path of every block from 4 to 2 resident blocks per CU (-10 us per 256K-key batch).
 template <int KIND, int DIM4, bool LOCATED>
 __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, uint32_t first, uint32_t m, bool emit, bool src_rec,
-                                             uint32_t b) {
+                                             uint32_t b, uint32_t rec_bucket0 /* split buckets: the bucket's first pending record */) {
     // The kernel calls this from a loop (slab, then merge passes).  The thread index is re-read through an empty asm in every call so that
     // nothing derived from it looks loop-invariant: hoisted out of that loop, the per-thread address arithmetic of every array touched in
     // here stayed live across the whole kernel (110 VGPRs instead of 64: half the resident blocks per CU for every block's hot path).
@@ -92,7 +92,6 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
     asm volatile("" : "+v"(t));
     const int lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6;
     const uint32_t dim4 = DIM4 ? DIM4 : A.dim4;
-    const uint32_t rec_bucket0 = bk.off[b];   // the bucket's first pending record (records never outnumber the bucket's positions)
     OptArgs a = A.a;
     a.kind = KIND;
     // ---- 1. the slab's keys into the LDS hash table: run = LDS slot, r = arrival number inside the run ----
@@ -412,18 +411,58 @@ __device__ __forceinline__ void mono_pass(ApplyLds& L, const ApplyArgs& A, const
 template <int KIND, int DIM4, bool LOCATED>
 __global__ MEE_APPLY_BOUNDS void bkt_apply_kernel(ApplyArgs A, BucketScratch bk) {
     __shared__ ApplyLds L;
-    const uint32_t u = blockIdx.x;
-    if (u >= *bk.n_units) return;
-    const uint2 unit = bk.units[u];
-    const uint32_t b = unit.x, sub = unit.y;
-    const uint32_t beg = bk.off[b], size = bk.off[b + 1] - beg;
+    // Who am I?  Blocks [n_extra, n_extra + nbk): block n_extra + b takes bucket b if it fits one slab.  Blocks [0, n_extra) are SPARE: they take
+    // the slabs of the buckets that hold more than one (a hot key), found by a prefix sum over the bucket totals — and leave at once when the
+    // partition saw no such bucket.  Spare blocks lead the grid, so ALL slabs of a hot bucket start first (its merge cannot start before the
+    // last of them ends).
+    const uint32_t parity = bk.seq[1];   // which copy of the totals this batch's partition filled (meepo_apply_part.h)
+    if (blockIdx.x == A.n_extra && threadIdx.x == 0) atomicAdd(&bk.seq[0], 1u);   // this partition is consumed: the next one fills the other copy
+    const uint32_t tot_base = parity * bk.n_buckets_max;
+    uint32_t b, sub = 0;
+    if (blockIdx.x >= A.n_extra) b = blockIdx.x - A.n_extra;
+    else {
+        if (!bk.has_split[parity]) return;
+        const uint32_t e = blockIdx.x, per_t = (A.nbk + kApplyThreads - 1) / kApplyThreads;
+        unsigned long long mine = 0;
+        for (uint32_t q = 0; q < per_t; ++q) {
+            const uint32_t bb = threadIdx.x * per_t + q;
+            const uint32_t tt = bb < A.nbk ? bk.tot[tot_base + bb] : 0u;
+            mine += tt > kSlab ? (tt + kSlab - 1) / kSlab : 0u;
+        }
+        unsigned long long total;
+        const uint32_t ex = (uint32_t)block_scan_u64<kApplyWaves>(mine, L.wsum, total);
+        if (e >= (uint32_t)total) return;   // block-uniform
+        if (e >= ex && e < ex + (uint32_t)mine) {   // exactly one thread
+            uint32_t acc = ex;
+            for (uint32_t q = 0; q < per_t; ++q) {
+                const uint32_t bb = threadIdx.x * per_t + q;
+                const uint32_t tt = bb < A.nbk ? bk.tot[tot_base + bb] : 0u;
+                const uint32_t x = tt > kSlab ? (tt + kSlab - 1) / kSlab : 0u;
+                if (e < acc + x) { L.rec_base = bb; L.n_cand = e - acc; break; }
+                acc += x;
+            }
+        }
+        __syncthreads();
+        b = L.rec_base; sub = L.n_cand;
+        __syncthreads();
+    }
+    const uint32_t size = bk.tot[tot_base + b];
     const bool split = size > kSlab;
+    if (size == 0 || (split && blockIdx.x >= A.n_extra)) return;   // an empty bucket | a split bucket: the spare blocks have it
+    uint32_t beg = 0;   // split buckets: the bucket's first pending record = the keys in the buckets before it (records never outnumber positions)
+    if (split) {
+        unsigned long long mine = 0, total;
+        for (uint32_t bb = threadIdx.x; bb < b; bb += kApplyThreads) mine += bk.tot[tot_base + bb];
+        (void)block_scan_u64<kApplyWaves>(mine, L.wsum, total);
+        beg = (uint32_t)total;
+        __syncthreads();
+    }
     // the slab first; in a split bucket's LAST slab the same loop then runs the merge passes (src_rec)
     bool merging = false;
     uint32_t first = sub * kSlab, m = min(kSlab, size - sub * kSlab), R = 0, bits0 = 0;
     uint64_t v0 = 0;
     for (;;) {
-        process_slab<KIND, DIM4, LOCATED>(L, A, bk, first, m, split && !merging, merging, b);
+        process_slab<KIND, DIM4, LOCATED>(L, A, bk, first, m, split && !merging, merging, b, beg);
         if (!merging) {
             if (!split) return;
             // ---- slab of a split bucket: publish this slab's pending records, take a ticket; the slab that draws the last ticket merges the
@@ -501,18 +540,18 @@ int bucket_scratch_alloc(mee_table* t) {
     BucketScratch& bk = t->bk;
     bk.fast_max = t->max_batch < (uint64_t)kMaxBuckets * kBucketTarget ? t->max_batch : (uint64_t)kMaxBuckets * kBucketTarget;
     bk.n_buckets_max = bucket_count_for(bk.fast_max);
-    bk.max_units = max_units_for(bk.fast_max);
     bk.pos = t->bs.occ;   // max_batch entries; the group-table apply and this one never run at the same time on one table
     hipError_t e = hipSuccess;
     auto alloc = [&](void** p, uint64_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes); if (e == hipSuccess) t->workspace_bytes += bytes; } };
     alloc((void**)&bk.pkey, bk.fast_max * 8);
     alloc((void**)&bk.cnt_mat, (uint64_t)kPartBlocks * bk.n_buckets_max * 4);
     alloc((void**)&bk.off_mat, (uint64_t)kPartBlocks * bk.n_buckets_max * 4);
-    alloc((void**)&bk.off, ((uint64_t)bk.n_buckets_max + 1) * 4);
-    alloc((void**)&bk.units, (uint64_t)bk.max_units * sizeof(uint2));
-    alloc((void**)&bk.n_units, 4);
-    alloc((void**)&bk.sort_ticket, 4);
-    if (e == hipSuccess) e = hipMemset(bk.sort_ticket, 0, 4);   // (the last block of every partition launch puts it back to 0)
+    alloc((void**)&bk.tot, 2ull * bk.n_buckets_max * 4);
+    alloc((void**)&bk.has_split, 2 * 4);
+    alloc((void**)&bk.seq, 2 * 4);
+    if (e == hipSuccess) e = hipMemset(bk.seq, 0, 2 * 4);
+    if (e == hipSuccess) e = hipMemset(bk.tot, 0, 2ull * bk.n_buckets_max * 4);   // (every partition launch zeroes the copy the next one adds to)
+    if (e == hipSuccess) e = hipMemset(bk.has_split, 0, 2 * 4);
     alloc((void**)&bk.pend_cnt, (uint64_t)bk.n_buckets_max * 4);
     alloc((void**)&bk.ticket, (uint64_t)bk.n_buckets_max * 4);
     alloc((void**)&bk.pend_key, bk.fast_max * 8);
@@ -523,7 +562,7 @@ int bucket_scratch_alloc(mee_table* t) {
 }
 void bucket_scratch_free(mee_table* t) {
     BucketScratch& bk = t->bk;
-    void* dev[] = {bk.pkey, bk.cnt_mat, bk.off_mat, bk.off, bk.units, bk.n_units, bk.sort_ticket, bk.pend_cnt, bk.ticket, bk.pend_key, bk.pend_slot, bk.pend_row};
+    void* dev[] = {bk.pkey, bk.cnt_mat, bk.off_mat, bk.tot, bk.has_split, bk.seq, bk.pend_cnt, bk.ticket, bk.pend_key, bk.pend_slot, bk.pend_row};
     for (void* p : dev) if (p) (void)hipFree(p);
 }
 
@@ -537,6 +576,14 @@ int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStr
     return MEE_OK;
 }
 
+// a prepared partition that no apply will consume (mee_apply_discard): count it as consumed, so that the next partition fills the other copy
+__global__ void bkt_skip_kernel(BucketScratch bk) { if (threadIdx.x == 0) bk.seq[0] += 1u; }
+int bucket_apply_discard(mee_table* t, hipStream_t st) {
+    bkt_skip_kernel<<<1, 64, 0, st>>>(t->bk);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
 int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const OptArgs& a, const uint32_t* d_gidx, const int64_t* d_slots, hipStream_t st) {
     ApplyArgs A{};
     A.tkeys = t->keys; A.values = (float4*)t->values; A.s1 = (float4*)t->s1; A.s2 = (float4*)t->s2; A.nb = t->nb; A.dim4 = t->dim4;
@@ -545,7 +592,8 @@ int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const Op
     A.part = t->bs.gacc; A.max_part = t->bs.max_part; A.op = t->op; A.a = a;
     A.nbk = bucket_count_for(n);
     A.part_blocks = t->part_blocks; A.per_block = t->part_per_block;   // as whoever partitioned this batch left them
-    const unsigned grid = max_units_for(n);
+    A.n_extra = max_extra_slabs(n);
+    const unsigned grid = A.n_extra + A.nbk;
 #define BKT(K, D4, LOC) bkt_apply_kernel<K, D4, LOC><<<grid, kApplyThreads, 0, st>>>(A, t->bk)
 #define BKT_L(K, D4) do { if (d_slots) BKT(K, D4, true); else BKT(K, D4, false); } while (0)
 #define BKT_D(K) do { if (t->dim4 == 16) BKT_L(K, 16); else if (t->dim4 == 32) BKT_L(K, 32); else BKT_L(K, 0); } while (0)

@@ -47,63 +47,35 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
     return pre + incl - v;
 }
 
-// The block that finishes the partition LAST adds the run lengths up: bucket sizes -> bucket offsets (the base of a split bucket's pending
-// records) and the work-unit list (split buckets first: they take longest).  `tot_lds` = nbk words of LDS (the partition's cursors, free by now).
-template <int THREADS>
-__device__ __forceinline__ void build_units(uint32_t nbk, uint32_t n_blocks, const BucketScratch& bk, OpCounters* op, uint32_t* tot_lds, unsigned long long* wsum) {
-    const uint32_t per_t = (nbk + THREADS - 1) / THREADS;   // buckets [t * per_t, (t + 1) * per_t) belong to thread t
-    unsigned long long packed = 0;   // bits 0..31 positions | 32..47 units of split buckets | 48..63 units of whole buckets
-    for (uint32_t q = 0; q < per_t; ++q) {
-        const uint32_t b = threadIdx.x * per_t + q;
-        if (b >= nbk) break;
-        uint32_t tot = 0;
-        {   // all of the bucket's (at most kPartBlocks) run lengths in flight at once: under the forward's row traffic every dependent round trip
-            // of this role costs microseconds (sixteen at a time: four round trips; one at a time this step took 6 us even on an idle chip)
-            uint32_t cs[kPartBlocks];
-#pragma unroll
-            for (uint32_t k = 0; k < (uint32_t)kPartBlocks; ++k) cs[k] = k < n_blocks ? bk.cnt_mat[(uint64_t)k * nbk + b] : 0u;
-#pragma unroll
-            for (uint32_t k = 0; k < (uint32_t)kPartBlocks; ++k) tot += cs[k];
-        }
-        tot_lds[b] = tot;
-        const uint32_t ns = tot > kSlab ? (tot + kSlab - 1) / kSlab : (tot ? 1u : 0u);
-        packed += (unsigned long long)tot | (ns > 1 ? (unsigned long long)ns << 32 : (unsigned long long)ns << 48);
-    }
-    unsigned long long total;
-    const unsigned long long ex = block_scan_u64<THREADS / 64>(packed, wsum, total);
-    uint32_t pos0 = (uint32_t)ex, su0 = (uint32_t)(ex >> 32) & 0xFFFFu, nu0 = (uint32_t)(ex >> 48);
-    const uint32_t split_units = (uint32_t)(total >> 32) & 0xFFFFu, whole_units = (uint32_t)(total >> 48);
-    for (uint32_t q = 0; q < per_t; ++q) {
-        const uint32_t b = threadIdx.x * per_t + q;
-        if (b >= nbk) break;
-        const uint32_t tot = tot_lds[b];   // (this thread's own store)
-        bk.off[b] = pos0; bk.pend_cnt[b] = 0u; bk.ticket[b] = 0u;
-        const uint32_t ns = tot > kSlab ? (tot + kSlab - 1) / kSlab : (tot ? 1u : 0u);
-        if (ns > 1) { for (uint32_t s = 0; s < ns; ++s) bk.units[su0 + s] = make_uint2(b, s); su0 += ns; }
-        else if (ns == 1) { bk.units[split_units + nu0] = make_uint2(b, 0u); ++nu0; }
-        pos0 += tot;
-    }
-    if (threadIdx.x == 0) {
-        bk.off[nbk] = (uint32_t)total;
-        *bk.n_units = split_units + whole_units;
-        op->n_part = 0u;      // fp64 partial rows of long runs are handed out from BatchScratch::gacc by the apply kernel
-        *bk.sort_ticket = 0u; // for the next partition (visible to it by the kernel boundary)
-    }
-}
-
 // One partition block (block `blk` of `n_blocks`, THREADS threads): sorts ITS share of the batch by bucket, inside its own contiguous slice of
 // pos / pkey (LDS histogram -> in-block prefix sum -> LDS cursors).  A block's writes stay inside its slice (16 KB + 32 KB at 4096 keys),
 // i.e. in one XCD's L2, where the 4- and 8-byte stores combine into whole lines.  (The first version scattered every key straight to its
 // bucket's global position: 256K keys = 512K partial-line stores from 64 CUs on 8 XCDs into the same lines — 19 us; and it needed a count
 // kernel in front.)  Per (block, bucket) it leaves the run's length and its start inside the slice: the apply kernel pulls a bucket's
-// entries out of the <= 64 slices (short contiguous reads).  The block that finishes LAST (agent-scope release -> ticket -> acquire:
-// cdna_hip_programming.md Guideline 16, counter form; nobody waits) builds the unit list: as a kernel of its own that step cost a dependent
-// launch.  `cursor` = nbk words of LDS.
+// entries out of the <= 64 slices (short contiguous reads).  It also adds its run lengths to the buckets' totals (one atomic per non-empty
+// (block, bucket) pair, spread over nbk words); the add that takes a total beyond one slab raises `has_split`, which is all the apply kernel's
+// spare blocks look at when no bucket needs them.  Nothing is handed from block to block in here: the kernel boundary publishes everything.
+// (Two earlier forms: a units kernel of its own behind this one — a dependent launch, 6.5 us for one block's worth of work; the block that
+// finished last building the unit list — release fence, ticket, acquire, then the list: the same 6 us at the end of this kernel, and under
+// the training forward's row traffic every one of those dependent steps cost microseconds.)
+// Scratch that the apply kernel of THIS batch reads is reset here for the next but one use: totals and has_split alternate between two
+// copies, this launch zeroes the copy the next launch will add to.  Which copy is in use lives on the DEVICE (a captured graph replays the
+// same launches, so a host-side toggle would stand still): bk.seq[0] counts partitions that were consumed — the partition reads it, takes
+// its low bit as the copy, and leaves that bit in bk.seq[1] for the apply kernel, which reads only seq[1] and bumps only seq[0] (each word
+// is written by one kind of kernel and read by the other: the kernel boundary orders them).  `cursor` = nbk words of LDS.
 template <int THREADS>
 __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk, uint32_t lb, uint32_t per_block, uint32_t blk,
                                           uint32_t n_blocks, const BucketScratch& bk, uint32_t* status, OpCounters* op, uint32_t* cursor,
-                                          unsigned long long* wsum /*[THREADS / 64]*/, uint32_t* is_last /* LDS */) {
+                                          unsigned long long* wsum /*[THREADS / 64]*/) {
+    const uint32_t parity = bk.seq[0] & 1u;
     for (uint32_t j = threadIdx.x; j < nbk; j += THREADS) cursor[j] = 0u;
+    // housekeeping for the apply kernel of this batch (pending-record counters, slab tickets of every bucket, the partial-row allocator) and
+    // for the NEXT partition (the other copy of the totals): shared out over the blocks
+    for (uint32_t j = blk * THREADS + threadIdx.x; j < bk.n_buckets_max; j += n_blocks * THREADS) {
+        if (j < nbk) { bk.pend_cnt[j] = 0u; bk.ticket[j] = 0u; }
+        bk.tot[(parity ^ 1u) * bk.n_buckets_max + j] = 0u;
+    }
+    if (blk == 0 && threadIdx.x == 0) { op->n_part = 0u; bk.has_split[parity ^ 1u] = 0u; bk.seq[1] = parity; }
     __syncthreads();
     const uint32_t lo = blk * per_block, hi = min(n, lo + per_block);
     const bool in_regs = per_block <= (uint32_t)kKeyGroup * THREADS;   // block-uniform: each thread's keys fit its registers -> ONE pass over the key array
@@ -147,6 +119,10 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
         bk.off_mat[(uint64_t)blk * nbk + b] = start;
         cursor[b] = start;
         start += c;
+        if (c) {
+            const uint32_t before = atomicAdd(&bk.tot[parity * bk.n_buckets_max + b], c);
+            if (before <= kSlab && before + c > kSlab) bk.has_split[parity] = 1u;   // exactly one add per bucket crosses the line
+        }
     }
     __syncthreads();
     if (in_regs) {
@@ -171,21 +147,6 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
             }
         }
     }
-    // ---- publish this block's rows of the count matrix, take a ticket; the last block builds the unit list ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t tk = __hip_atomic_fetch_add(bk.sort_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *is_last = tk == n_blocks - 1;
-        if (tk == n_blocks - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
-    __syncthreads();
-    if (*is_last) build_units<THREADS>(nbk, n_blocks, bk, op, cursor, wsum);   // block-uniform
 }
 
 }  // namespace mee

@@ -209,9 +209,8 @@ __global__ __launch_bounds__(kFindPrepareThreads) void find_prepare_kernel(const
                                                            BucketScratch bk, uint32_t* status, OpCounters* op) {
     extern __shared__ uint32_t part_cursor[];
     __shared__ unsigned long long part_wsum[kFindPrepareThreads / 64];
-    __shared__ uint32_t part_is_last;
     if (blockIdx.x < part_blocks) {   // block-uniform
-        sort_role<kFindPrepareThreads>(keys, (uint32_t)n, nbk, lb, per_block, blockIdx.x, part_blocks, bk, status, op, part_cursor, part_wsum, &part_is_last);
+        sort_role<kFindPrepareThreads>(keys, (uint32_t)n, nbk, lb, per_block, blockIdx.x, part_blocks, bk, status, op, part_cursor, part_wsum);
         return;
     }
     find_span<DIM4, R, NT>(tkeys, values, nb, keys, n, out, found, defv, dim4_rt, nullptr, slots_out,
@@ -2653,6 +2652,8 @@ int mee_apply_discard(mee_table* t, void* stream) {
         group_reset_kernel<<<grid_for(nn, 256, 1u << 22), 256, 0, as_stream(stream)>>>(t->bs.hidx, nn, t->g);
         MEE_HIP(hipGetLastError());
         zero_words(t->bs.filed_bits, ((size_t)nn / 32 + 16) * 4, as_stream(stream));   // the prepare pass may have marked filed occurrences (a kernel, not a memset node: see zero_words)
+    } else if (t->prepared_path == 1) {
+        if (int rc = bucket_apply_discard(t, as_stream(stream))) return rc;
     }
     t->prepared_n = 0; t->prepared_keys = nullptr; t->prepared_path = 0;
     return MEE_OK;

@@ -68,16 +68,15 @@ struct BucketScratch {
     int64_t* pkey;        // [fast_max] their keys, in the same order
     uint32_t* cnt_mat;    // [kPartBlocks][n_buckets_max] keys of each bucket held by each partition block …
     uint32_t* off_mat;    // … and where that run starts inside the block's slice of pos / pkey
-    uint32_t* off;        // [n_buckets_max + 1] start of each bucket in pos / pkey
-    uint2* units;         // [max_units] work unit -> (bucket, slab of the bucket): split buckets first
-    uint32_t* n_units;    // [1]
-    uint32_t* sort_ticket;// [1] partition blocks finished (the last one builds the unit list and puts it back to 0)
+    uint32_t* tot;        // [2][n_buckets_max] keys per bucket (added up by the partition blocks); two copies, used alternately
+    uint32_t* has_split;  // [2] some bucket holds more than one slab (the apply kernel's spare blocks have work)
+    uint32_t* seq;        // [2] [0] partitions consumed so far (its low bit picks the copy the next partition fills), [1] the copy the latest partition filled
     uint32_t* pend_cnt;   // [n_buckets_max] split buckets: pending records appended so far
     uint32_t* ticket;     // [n_buckets_max] split buckets: slabs finished
     int64_t* pend_key;    // [fast_max] pending records of split buckets: key …
     int64_t* pend_slot;   // [fast_max] … the table slot its handle named (located applies: the merge needs no probe) …
     double* pend_row;     // [fast_max][dim] … and the fp64 partial sum of its gradient rows within one slab
-    uint32_t n_buckets_max, max_units;
+    uint32_t n_buckets_max;
     uint64_t fast_max;    // largest n the bucketed path takes
 };
 
@@ -156,6 +155,7 @@ __device__ __forceinline__ void update_row(const OptArgs& a, float4* values, flo
 int bucket_scratch_alloc(mee_table* t);
 void bucket_scratch_free(mee_table* t);
 int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st);
+int bucket_apply_discard(mee_table* t, hipStream_t st);
 int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const OptArgs& a, const uint32_t* d_gidx, const int64_t* d_slots, hipStream_t st);
 uint32_t bucket_count_for(uint64_t n);
 
