@@ -658,7 +658,7 @@ def main():
         native_tables = []   # every native context created by the probe: closed (communicators destroyed) before the process group goes
         # ---- the exchange behind the C-ABI (mee_sharded_*: grouped ncclSend/ncclRecv inside the library), both layouts ----
         # (the gloo rehearsal on one GPU can take this path too when MEE_RCCL_LIB names the test suite's shared-memory stand-in for RCCL)
-        native_ok = args.transport in ("auto", "native") and depth == 1 and (args.backend == "nccl" or os.environ.get("MEE_RCCL_LIB")) and not args.dedup
+        native_ok = args.transport in ("auto", "native") and depth == 1 and (args.backend == "nccl" or os.environ.get("MEE_RCCL_LIB"))
         if native_ok and not args.no_selftest:
             native_ok = p2p_selftest(ctrl, log, script="rccl_selftest.py", port_offset=23, what="native rccl")
         if native_ok:
@@ -667,7 +667,7 @@ def main():
             log(f"transport probe: torch.distributed all-to-all {t_best * 1e3:.3f} ms/step")
             for label, slack in (("exact segments, one host sync per lookup", 0.0), ("padded segments, no host sync", 1.04)):
                 try:
-                    nt = RcclShardedTable(table, batch, pad_slack=slack)   # collective (ncclCommInitRank): proven by the self-test
+                    nt = RcclShardedTable(table, batch, pad_slack=slack, dedup=args.dedup)   # collective (ncclCommInitRank): proven by the self-test
                 except Exception as e:  # noqa: BLE001
                     log(f"native rccl ({label}) unavailable: {e}")
                     break
@@ -954,16 +954,15 @@ def main():
                     traffic = tj["bytes_per_launch"]   # measured in separate rocprofv3 --pmc passes (tools/pmc_traffic.py), not in this run
             except Exception:
                 traffic = None
-        step_traffic = step_traffic_src = None   # configs[2]: the step's kernels summed, from the PMC passes of tools/pmc_apply.sh
-        apath = os.path.join(ROOT, "profiles", "r02_apply_traffic.json")
+        step_traffic = step_traffic_src = None   # configs[2]: the step's kernels summed, from the PMC passes of tools/final_r3.sh
+        apath = os.path.join(ROOT, "profiles", "r03_step_traffic.json")
         if whole and not sharded and os.path.exists(apath) and args.dist == "uniform" and dim == 64 and keys_per_gpu == 100_000_000:
             try:
                 aj = json.load(open(apath))
                 if aj.get("batch") == batch:
-                    ks = aj["kernels"]
-                    step_traffic = sum(ks[k]["bytes_per_launch"] for k in ("find_kernel<16, 2, 64>", "group_kernel<2", "apply_main_kernel<1, 16, 1, true>",
-                                                                          "apply_dups_kernel", "apply_filed_kernel", "apply_big_kernel"))
-                    step_traffic_src = "profiles/r02_apply_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_apply.sh; the step's six kernels summed)"
+                    step_traffic = sum(k_["bytes_per_launch"] for k_ in aj["kernels"].values())
+                    step_traffic_src = ("profiles/r03_step_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/final_r3.sh; "
+                                        "the step's kernels summed: " + ", ".join(aj["kernels"]) + ")")
             except Exception:
                 step_traffic = None
         res = {
@@ -980,7 +979,7 @@ def main():
                        "launch_comparison": launch_cmp, "output_buffers": (f"{n_out} x {batch * dim * 4 >> 20} MB dense result buffers in rotation" if n_out > 1 else "one reused result buffer"),
                        "parallelism": (f"row-shard x{world}" + (f", {args.pipeline} steps in flight" if args.pipeline > 1 else "") + (", pre-exchange dedup" if args.dedup else "")) if sharded else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic if not whole else step_traffic, "kernel": "find_kernel" if not whole else "whole step (find_kernel + the apply's group / main / three duplicate kernels)",
+                         "traffic": traffic if not whole else step_traffic, "kernel": "find_kernel" if not whole else "whole step (find_prepare_kernel: the located find + the apply's partition; bkt_apply_kernel: dedup + update)",
                          "traffic_source": (("profiles/find_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 per the gfx950 correction)"
                                              if traffic is not None else None) if not whole else step_traffic_src),
                          "avg_launch_us": kern_s * 1e6, "min_launch_us": kern_min_s * 1e6,
