@@ -33,15 +33,15 @@ constexpr int kApplyWaves = kApplyThreads / 64;
 constexpr uint32_t kLdsSlots = 2 * kSlab;
 constexpr uint32_t kRun = 32;             // occurrences one tile sums in one go; longer runs are cut into chunks of this many
 
-uint32_t bucket_count_for(uint64_t n) { return bucket_count_for_host(n); }
+uint32_t bucket_count_for(const mee_table* t, uint64_t n) { return bucket_count_for_host(n, t->bk.slots, t->bk.bucket_max ? t->bk.bucket_max : kBucketMax); }
 static uint32_t max_extra_slabs(uint64_t n) { return 2 * (uint32_t)(n / kSlab) + 2; }   // slabs of split buckets: sum of ceil(size / kSlab) over buckets larger than kSlab
 
 // ---- the partition kernel of an apply (the role itself: meepo_apply_part.h) ----------------------------------------------------------------
-__global__ __launch_bounds__(kPartThreads) void bkt_sort_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk, uint32_t lb,
+__global__ __launch_bounds__(kPartThreads) void bkt_sort_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk,
                                                                 uint32_t per_block, BucketScratch bk, uint32_t* status, OpCounters* op) {
     extern __shared__ uint32_t cursor[];
     __shared__ unsigned long long wsum[kPartThreads / 64];
-    sort_role<kPartThreads>(keys, n, nbk, lb, per_block, blockIdx.x, gridDim.x, bk, status, op, cursor, wsum);
+    sort_role<kPartThreads>(keys, n, nbk, per_block, blockIdx.x, gridDim.x, bk, status, op, cursor, wsum);
 }
 
 // ---- the apply kernel -------------------------------------------------------------------------------------------------------------
@@ -538,8 +538,12 @@ __global__ MEE_APPLY_BOUNDS void bkt_apply_kernel(ApplyArgs A, BucketScratch bk)
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
 int bucket_scratch_alloc(mee_table* t) {
     BucketScratch& bk = t->bk;
-    bk.fast_max = t->max_batch < (uint64_t)kMaxBuckets * kBucketTarget ? t->max_batch : (uint64_t)kMaxBuckets * kBucketTarget;
-    bk.n_buckets_max = bucket_count_for(bk.fast_max);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device);
+    bk.slots = (uint32_t)cus * kApplyBlocksPerCU;
+    const uint64_t most = (uint64_t)(kMaxBuckets / bk.slots ? kMaxBuckets / bk.slots * bk.slots : kMaxBuckets) * kBucketMax;   // beyond that buckets would outgrow their slabs
+    bk.fast_max = t->max_batch < most ? t->max_batch : most;
+    bk.n_buckets_max = kMaxBuckets;
     bk.pos = t->bs.occ;   // max_batch entries; the group-table apply and this one never run at the same time on one table
     hipError_t e = hipSuccess;
     auto alloc = [&](void** p, uint64_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes); if (e == hipSuccess) t->workspace_bytes += bytes; } };
@@ -567,11 +571,11 @@ void bucket_scratch_free(mee_table* t) {
 }
 
 int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st) {
-    const uint32_t nbk = bucket_count_for(n), lb = log2_of(nbk);
+    const uint32_t nbk = bucket_count_for(t, n);
     uint32_t blocks, per_block;
     part_geometry(n, kPartThreads, blocks, per_block);
     t->part_blocks = blocks; t->part_per_block = per_block;
-    bkt_sort_kernel<<<blocks, kPartThreads, nbk * 4, st>>>(d_keys, n, nbk, lb, per_block, t->bk, &t->ctr->status, t->op);
+    bkt_sort_kernel<<<blocks, kPartThreads, nbk * 4, st>>>(d_keys, n, nbk, per_block, t->bk, &t->ctr->status, t->op);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
@@ -590,7 +594,7 @@ int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const Op
     A.grads = (const float4*)d_grads; A.gidx = d_gidx; A.slots = d_slots;
     A.capacity = t->capacity; A.handle_tag = (int64_t)(t->handle_epoch & kHandleEpochMask) << kHandleSlotBits; A.status = &t->ctr->status;
     A.part = t->bs.gacc; A.max_part = t->bs.max_part; A.op = t->op; A.a = a;
-    A.nbk = bucket_count_for(n);
+    A.nbk = bucket_count_for(t, n);
     A.part_blocks = t->part_blocks; A.per_block = t->part_per_block;   // as whoever partitioned this batch left them
     A.n_extra = max_extra_slabs(n);
     const unsigned grid = A.n_extra + A.nbk;

@@ -8,16 +8,23 @@ namespace mee {
 
 constexpr int kPartBlocks = 64;           // blocks that share the partition of one batch
 constexpr uint32_t kSlab = 512;           // positions one apply block takes (= its thread count): what its LDS hash table holds at load 0.5
-constexpr uint32_t kBucketTarget = 256;   // positions per bucket aimed at (128..256 once the bucket count is a power of two)
+constexpr uint32_t kBucketMax = 352;      // positions per bucket aimed at, at most (a slab holds 512: Poisson(352) stays below that by 8 sigma)
 constexpr uint32_t kMaxBuckets = 8192;    // the partition keeps one LDS counter per bucket
+constexpr uint32_t kApplyBlocksPerCU = 3; // resident blocks of the apply kernel per CU (512 threads, 80 VGPRs: meepo_apply.hip)
 constexpr int kKeyGroup = 8;              // keys a thread loads back to back before it touches LDS (one at a time, every load waited for the one before)
 
-inline uint32_t bucket_count_for_host(uint64_t n) {
-    uint32_t nbk = 1;
-    while ((uint64_t)nbk * kBucketTarget < n && nbk < kMaxBuckets) nbk <<= 1;
+// How many buckets a batch of n keys is cut into.  One apply block per bucket, all buckets the same size (a hash), all blocks equally long:
+// with B blocks on S resident slots the kernel takes ceil(B / S) rounds, so B is made a MULTIPLE of S = CUs x kApplyBlocksPerCU — 1024
+// buckets on 768 slots (the first version: powers of two) ran one full round and then a second with a third of the chip.  Small batches:
+// fewer buckets than slots, at least 128 positions each.
+inline uint32_t bucket_count_for_host(uint64_t n, uint32_t slots, uint32_t bucket_max = kBucketMax) {
+    if (slots == 0) slots = 768;
+    if (n <= (uint64_t)slots * 128) return (uint32_t)((n + 127) / 128 ? (n + 127) / 128 : 1);
+    uint32_t rounds = (uint32_t)((n + (uint64_t)slots * bucket_max - 1) / ((uint64_t)slots * bucket_max));
+    uint32_t nbk = rounds * slots;
+    if (nbk > kMaxBuckets) nbk = kMaxBuckets / slots * slots ? kMaxBuckets / slots * slots : kMaxBuckets;
     return nbk;
 }
-inline uint32_t log2_of(uint32_t pow2) { uint32_t l = 0; while ((1u << l) < pow2) ++l; return l; }
 inline void part_geometry(uint32_t n, uint32_t threads, uint32_t& blocks, uint32_t& per_block) {
     blocks = (n + 4 * threads - 1) / (4 * threads);   // at least 4 keys per thread
     if (blocks > (uint32_t)kPartBlocks) blocks = kPartBlocks;
@@ -25,7 +32,8 @@ inline void part_geometry(uint32_t n, uint32_t threads, uint32_t& blocks, uint32
     per_block = (n + blocks - 1) / blocks;
 }
 
-__device__ __forceinline__ uint32_t apply_bucket_of(int64_t key, uint32_t lb) { return lb ? (uint32_t)(mix64((uint64_t)key) >> (64 - lb)) : 0u; }
+// the same bits, scaled the same way, as the key's table bucket (bucket_of): a block's keys live in one contiguous 1/nbk slice of the table
+__device__ __forceinline__ uint32_t apply_bucket_of(int64_t key, uint32_t nbk) { return (uint32_t)__umul64hi(mix64((uint64_t)key), (uint64_t)nbk); }
 
 // exclusive prefix sum of a packed 64-bit value over a block of NW waves; every field of the packed value must stay below its width
 template <int NW>
@@ -64,7 +72,7 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
 // its low bit as the copy, and leaves that bit in bk.seq[1] for the apply kernel, which reads only seq[1] and bumps only seq[0] (each word
 // is written by one kind of kernel and read by the other: the kernel boundary orders them).  `cursor` = nbk words of LDS.
 template <int THREADS>
-__device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk, uint32_t lb, uint32_t per_block, uint32_t blk,
+__device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk, uint32_t per_block, uint32_t blk,
                                           uint32_t n_blocks, const BucketScratch& bk, uint32_t* status, OpCounters* op, uint32_t* cursor,
                                           unsigned long long* wsum /*[THREADS / 64]*/) {
     const uint32_t parity = bk.seq[0] & 1u;
@@ -86,7 +94,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
         for (int q = 0; q < kKeyGroup; ++q) kr[q] = lo + threadIdx.x + q * THREADS < hi ? keys[lo + threadIdx.x + q * THREADS] : kEmpty;
 #pragma unroll
         for (int q = 0; q < kKeyGroup; ++q) {
-            if (!reserved_key(kr[q])) atomicAdd(&cursor[apply_bucket_of(kr[q], lb)], 1u);
+            if (!reserved_key(kr[q])) atomicAdd(&cursor[apply_bucket_of(kr[q], nbk)], 1u);
             else bad = bad || kr[q] == kReclaimed;   // EMPTY = padding, silent (SPEC.md §2)
         }
     } else {
@@ -96,7 +104,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
             for (int q = 0; q < kKeyGroup; ++q) k[q] = i0 + q * THREADS < hi ? keys[i0 + q * THREADS] : kEmpty;
 #pragma unroll
             for (int q = 0; q < kKeyGroup; ++q) {
-                if (!reserved_key(k[q])) atomicAdd(&cursor[apply_bucket_of(k[q], lb)], 1u);
+                if (!reserved_key(k[q])) atomicAdd(&cursor[apply_bucket_of(k[q], nbk)], 1u);
                 else bad = bad || k[q] == kReclaimed;
             }
         }
@@ -129,7 +137,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
 #pragma unroll
         for (int q = 0; q < kKeyGroup; ++q) {
             if (reserved_key(kr[q])) continue;
-            const uint32_t r = lo + atomicAdd(&cursor[apply_bucket_of(kr[q], lb)], 1u);
+            const uint32_t r = lo + atomicAdd(&cursor[apply_bucket_of(kr[q], nbk)], 1u);
             bk.pos[r] = lo + threadIdx.x + q * THREADS;
             bk.pkey[r] = kr[q];
         }
@@ -141,7 +149,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
 #pragma unroll
             for (int q = 0; q < kKeyGroup; ++q) {
                 if (reserved_key(k[q])) continue;
-                const uint32_t r = lo + atomicAdd(&cursor[apply_bucket_of(k[q], lb)], 1u);
+                const uint32_t r = lo + atomicAdd(&cursor[apply_bucket_of(k[q], nbk)], 1u);
                 bk.pos[r] = i0 + q * THREADS;
                 bk.pkey[r] = k[q];
             }

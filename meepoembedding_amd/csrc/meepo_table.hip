@@ -205,12 +205,12 @@ template <int DIM4, int R, int NT>
 __global__ __launch_bounds__(kFindPrepareThreads) void find_prepare_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
                                                            const int64_t* __restrict__ keys, uint64_t n, f32x4* __restrict__ out,
                                                            uint8_t* __restrict__ found, float defv, uint32_t dim4_rt, int64_t* __restrict__ slots_out,
-                                                           int64_t handle_tag, uint32_t part_blocks, uint32_t nbk, uint32_t lb, uint32_t per_block,
+                                                           int64_t handle_tag, uint32_t part_blocks, uint32_t nbk, uint32_t per_block,
                                                            BucketScratch bk, uint32_t* status, OpCounters* op) {
     extern __shared__ uint32_t part_cursor[];
     __shared__ unsigned long long part_wsum[kFindPrepareThreads / 64];
     if (blockIdx.x < part_blocks) {   // block-uniform
-        sort_role<kFindPrepareThreads>(keys, (uint32_t)n, nbk, lb, per_block, blockIdx.x, part_blocks, bk, status, op, part_cursor, part_wsum);
+        sort_role<kFindPrepareThreads>(keys, (uint32_t)n, nbk, per_block, blockIdx.x, part_blocks, bk, status, op, part_cursor, part_wsum);
         return;
     }
     find_span<DIM4, R, NT>(tkeys, values, nb, keys, n, out, found, defv, dim4_rt, nullptr, slots_out,
@@ -1965,6 +1965,7 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     else if (!strcmp(name, "find_nt")) t->find_nt = value;
     else if (!strcmp(name, "apply_rounds")) t->apply_rounds = value;
     else if (!strcmp(name, "apply_path")) t->apply_path = value;
+    else if (!strcmp(name, "apply_bucket_max")) t->bk.bucket_max = value > 0 && value <= 352 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_overlap")) (void)value;   // retired in round 2 (a side stream for the duplicate path lost to its fork/join gaps): accepted, ignored
     else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);
     return MEE_OK;
@@ -2625,14 +2626,14 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
     }
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
-    const uint32_t nbk = bucket_count_for(n), lb = log2_of(nbk);
+    const uint32_t nbk = bucket_count_for(t, n);
     uint32_t part_blocks, per_block;
     part_geometry((uint32_t)n, kFindPrepareThreads, part_blocks, per_block);
     const int R = t->dim4 == 16 || t->dim4 == 32 ? 2 : 1;
     const unsigned find_blocks = grid_for(n, (kFindPrepareThreads / 64) * 4u * (unsigned)R, 1u << 22);
     const bool cached_out = t->find_nt >= 0 && (t->find_nt & 4);
 #define FINDLP1(D4, RR, NT) find_prepare_kernel<D4, RR, NT><<<part_blocks + find_blocks, kFindPrepareThreads, nbk * 4, st>>>(t->keys, (const f32x4*)t->values, t->nb, d_keys, n, (f32x4*)d_out, d_found, \
-        t->default_value, t->dim4, d_slots_out, handle_tag_of(t), part_blocks, nbk, lb, per_block, t->bk, &t->ctr->status, t->op)
+        t->default_value, t->dim4, d_slots_out, handle_tag_of(t), part_blocks, nbk, per_block, t->bk, &t->ctr->status, t->op)
 #define FINDLP(D4, RR) do { if (cached_out) FINDLP1(D4, RR, 68); else FINDLP1(D4, RR, 64); } while (0)
     if (t->dim4 == 16) FINDLP(16, 2); else if (t->dim4 == 32) FINDLP(32, 2); else FINDLP(0, 1);
 #undef FINDLP

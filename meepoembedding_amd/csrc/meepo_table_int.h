@@ -76,7 +76,8 @@ struct BucketScratch {
     int64_t* pend_key;    // [fast_max] pending records of split buckets: key …
     int64_t* pend_slot;   // [fast_max] … the table slot its handle named (located applies: the merge needs no probe) …
     double* pend_row;     // [fast_max][dim] … and the fp64 partial sum of its gradient rows within one slab
-    uint32_t n_buckets_max;
+    uint32_t bucket_max;  // tuning ("apply_bucket_max"): positions per bucket aimed at, at most (0 = the default)
+    uint32_t n_buckets_max, slots;   // slots: apply blocks the device keeps resident at once (CUs x blocks per CU): bucket counts are multiples of it
     uint64_t fast_max;    // largest n the bucketed path takes
 };
 
@@ -157,6 +158,6 @@ void bucket_scratch_free(mee_table* t);
 int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st);
 int bucket_apply_discard(mee_table* t, hipStream_t st);
 int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const OptArgs& a, const uint32_t* d_gidx, const int64_t* d_slots, hipStream_t st);
-uint32_t bucket_count_for(uint64_t n);
+uint32_t bucket_count_for(const mee_table* t, uint64_t n);
 
 }  // namespace mee

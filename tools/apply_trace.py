@@ -10,6 +10,7 @@ keys_n, batch, dim = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000, 1 <
 dist_name = sys.argv[2] if len(sys.argv) > 2 else "uniform"
 paths = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "0,1").split(",")]
 adam = len(sys.argv) > 4 and sys.argv[4] == "adam"
+bmax = int(os.environ.get("MEE_BUCKET_MAX", "0"))
 t = LookupTable(int(keys_n / 0.75), dim, device=dev, max_batch=1 << 20, optimizer=OPT_ADAM if adam else OPT_ADAGRAD)
 bench.populate(t, synth, keys_n, dim, dev, 1 << 20)
 batches = bench.lookup_batches(synth, keys_n, batch, 8, dist_name, dev, seed=3)
@@ -28,6 +29,8 @@ def apply(k, **kw):
 
 for path in paths:
     t.set_tuning("apply_path", path)
+    if bmax:
+        t.set_tuning("apply_bucket_max", bmax)
     for label, located in (("apply alone (probing)", False), ("find_located + apply (located)", True), ("find_located_prepare + apply (located)", 2)):
         def step(i):
             if located:
