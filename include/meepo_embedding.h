@@ -98,7 +98,9 @@ int mee_clear(mee_table* t, void* stream);
  * the find grid, 0 = unbounded), "find_nt" (cache policy of a find: bit 0 streaming row loads, bit 1 streaming bucket loads, bit 2 cached
  * stores of the dense output; -1 = the library's rule: cached loads, cached stores while one call's output is <= 128 MB.  A caller whose
  * result buffers rotate — nothing re-reads them from cache — sets 0: cached loads, streaming stores), "apply_rounds" (1/2),
- * "apply_path" (0 = group-table apply, 1 = bucketed apply, -1 = the library's choice).  "apply_overlap" is retired (accepted, ignored). */
+ * "apply_path" (0 = group-table apply, 1 = bucketed apply, -1 = the library's choice), "apply_bucket_max" (target positions per
+ * bucket of the bucketed apply, 1..352; 0 = the library's rule: one bucket per resident block slot, as many rounds as the batch needs).
+ * "apply_overlap" is retired (accepted, ignored). */
 int mee_set_tuning(mee_table* t, const char* name, int value);
 
 /* ---- lookup-table operators (README.md:2 "lookuptable-style"; SPEC.md §3) ------------------------------ */
