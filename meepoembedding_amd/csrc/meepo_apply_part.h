@@ -6,12 +6,16 @@
 
 namespace mee {
 
-constexpr int kPartBlocks = 64;           // blocks that share the partition of one batch
+constexpr int kPartBlocks = 128;          // blocks that share the partition of one batch, at most (2 x 64: a wave of the apply kernel scans their run lengths, two per lane)
 constexpr uint32_t kSlab = 512;           // positions one apply block takes (= its thread count): what its LDS hash table holds at load 0.5
 constexpr uint32_t kBucketMax = 352;      // positions per bucket aimed at, at most (a slab holds 512: Poisson(352) stays below that by 8 sigma)
 constexpr uint32_t kMaxBuckets = 8192;    // the partition keeps one LDS counter per bucket
-constexpr uint32_t kApplyBlocksPerCU = 3; // resident blocks of the apply kernel per CU (512 threads, 80 VGPRs: meepo_apply.hip)
-constexpr int kKeyGroup = 8;              // keys a thread loads back to back before it touches LDS (one at a time, every load waited for the one before)
+// MEE_APPLY_WAVES: waves per SIMD the register allocator must leave room for in the bucket kernel (meepo_apply.hip): 8 = 64 VGPRs, four
+// 512-thread blocks per CU (6 = 80 VGPRs, three blocks)
+#ifndef MEE_APPLY_WAVES
+#define MEE_APPLY_WAVES 6
+#endif
+constexpr uint32_t kApplyBlocksPerCU = MEE_APPLY_WAVES / 2; // resident blocks of the bucket kernel per CU (512 threads = 2 waves per SIMD each)
 
 // How many buckets a batch of n keys is cut into.  One apply block per bucket, all buckets the same size (a hash), all blocks equally long:
 // with B blocks on S resident slots the kernel takes ceil(B / S) rounds, so B is made a MULTIPLE of S = CUs x kApplyBlocksPerCU — 1024
@@ -75,8 +79,19 @@ template <int THREADS>
 __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk, uint32_t per_block, uint32_t blk,
                                           uint32_t n_blocks, const BucketScratch& bk, uint32_t* status, OpCounters* op, uint32_t* cursor,
                                           unsigned long long* wsum /*[THREADS / 64]*/) {
-    const uint32_t parity = bk.seq[0] & 1u;
+    // Dependent round trips to memory are what this role costs (beside the training forward's row gather every one of them waits in the same
+    // queues as the gather's requests: microseconds each), so it makes two: the keys together with the copy selector, and — at the very end —
+    // the returns of the bucket-total atomics, which travel while the entries are scattered.
+    constexpr int kKeyGroup = 8;   // keys a thread loads back to back and keeps in registers (a block of THREADS threads takes up to 8 x THREADS keys in one pass)
     for (uint32_t j = threadIdx.x; j < nbk; j += THREADS) cursor[j] = 0u;
+    const uint32_t lo = blk * per_block, hi = min(n, lo + per_block);
+    const bool in_regs = per_block <= (uint32_t)kKeyGroup * THREADS;   // block-uniform: each thread's keys fit its registers -> ONE pass over the key array
+    int64_t kr[kKeyGroup];
+    if (in_regs) {
+#pragma unroll
+        for (int q = 0; q < kKeyGroup; ++q) kr[q] = lo + threadIdx.x + q * THREADS < hi ? keys[lo + threadIdx.x + q * THREADS] : kEmpty;
+    }
+    const uint32_t parity = bk.seq[0] & 1u;
     // housekeeping for the apply kernel of this batch (pending-record counters, slab tickets of every bucket, the partial-row allocator) and
     // for the NEXT partition (the other copy of the totals): shared out over the blocks
     for (uint32_t j = blk * THREADS + threadIdx.x; j < bk.n_buckets_max; j += n_blocks * THREADS) {
@@ -85,13 +100,8 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
     }
     if (blk == 0 && threadIdx.x == 0) { op->n_part = 0u; bk.has_split[parity ^ 1u] = 0u; bk.seq[1] = parity; }
     __syncthreads();
-    const uint32_t lo = blk * per_block, hi = min(n, lo + per_block);
-    const bool in_regs = per_block <= (uint32_t)kKeyGroup * THREADS;   // block-uniform: each thread's keys fit its registers -> ONE pass over the key array
-    int64_t kr[kKeyGroup];
     bool bad = false;
     if (in_regs) {
-#pragma unroll
-        for (int q = 0; q < kKeyGroup; ++q) kr[q] = lo + threadIdx.x + q * THREADS < hi ? keys[lo + threadIdx.x + q * THREADS] : kEmpty;
 #pragma unroll
         for (int q = 0; q < kKeyGroup; ++q) {
             if (!reserved_key(kr[q])) atomicAdd(&cursor[apply_bucket_of(kr[q], nbk)], 1u);
@@ -119,9 +129,13 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
     }
     unsigned long long total;
     uint32_t start = (uint32_t)block_scan_u64<THREADS / 64>(sum, wsum, total);
-    for (uint32_t q = 0; q < per_t; ++q) {
+    constexpr uint32_t kTotRegs = THREADS >= 512 ? 2 : 3;   // buckets per thread whose atomic's return is looked at only at the end (batches of up to 1024 buckets: all of them)
+    uint32_t tot_before[kTotRegs], tot_add[kTotRegs];
+#pragma unroll
+    for (uint32_t q = 0; q < kTotRegs; ++q) { tot_before[q] = 0u; tot_add[q] = 0u; }
+    auto place = [&](uint32_t q, bool deferred) {
         const uint32_t b = threadIdx.x * per_t + q;
-        if (b >= nbk) break;
+        if (b >= nbk) return;
         const uint32_t c = cursor[b];
         bk.cnt_mat[(uint64_t)blk * nbk + b] = c;
         bk.off_mat[(uint64_t)blk * nbk + b] = start;
@@ -129,9 +143,13 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
         start += c;
         if (c) {
             const uint32_t before = atomicAdd(&bk.tot[parity * bk.n_buckets_max + b], c);
-            if (before <= kSlab && before + c > kSlab) bk.has_split[parity] = 1u;   // exactly one add per bucket crosses the line
+            if (deferred) { tot_before[q < kTotRegs ? q : 0] = before; tot_add[q < kTotRegs ? q : 0] = c; }   // the return travels while the entries are scattered
+            else if (before <= kSlab && before + c > kSlab) bk.has_split[parity] = 1u;   // exactly one add per bucket takes its total beyond one slab
         }
-    }
+    };
+#pragma unroll
+    for (uint32_t q = 0; q < kTotRegs; ++q) if (q < per_t) place(q, true);
+    for (uint32_t q = kTotRegs; q < per_t; ++q) place(q, false);
     __syncthreads();
     if (in_regs) {
 #pragma unroll
@@ -155,6 +173,10 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
             }
         }
     }
+    bool crossed = false;
+#pragma unroll
+    for (uint32_t q = 0; q < kTotRegs; ++q) crossed = crossed || (tot_before[q] <= kSlab && tot_before[q] + tot_add[q] > kSlab);
+    if (crossed) bk.has_split[parity] = 1u;
 }
 
 }  // namespace mee

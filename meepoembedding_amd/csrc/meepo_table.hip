@@ -198,11 +198,17 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
 // The training forward (mee_find_located_prepare): the located find whose launch gives its first `part_blocks` blocks the partition role of
 // the bucketed apply (meepo_apply_part.h).  The partition of the step's backward — a latency-bound 15-18 us of LDS histograms for a 256K-key
 // batch — runs beside the forward's row gather, which is bound by bytes and takes twice as long: the backward starts with its update kernel.
-// (1024-thread blocks: the partition role wants many threads per block — 64 blocks x 1024 threads for 256K keys; with 256-thread blocks the
-// role took as long as the find and the launch gained nothing — and the find, bound by bytes, does not care about its block size.)
-constexpr int kFindPrepareThreads = 1024;
+// Block size = the find's own 256 threads.  The first version used 1024-thread blocks for the sake of the partition role (64 blocks x 1024
+// threads); measured with the role switched off, the FIND in 1024-thread blocks takes 47 us against 39 us in 256-thread blocks (a block's 16
+// waves each do one short pass, the block holds its 16 wave slots until the slowest of them is done; 512-thread blocks: 42 us) — the launch
+// took as long as its slow find and hid nothing.  With 256-thread blocks the role runs as 128 blocks x 256 threads x 8 keys, each making two
+// round trips to memory (meepo_apply_part.h): 42.5 us for the launch against 40 us with the role switched off.
+#ifndef MEE_FPT
+#define MEE_FPT 256
+#endif
+constexpr int kFindPrepareThreads = MEE_FPT;
 template <int DIM4, int R, int NT>
-__global__ __launch_bounds__(kFindPrepareThreads) void find_prepare_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
+__global__ __launch_bounds__(kFindPrepareThreads, kFindPrepareThreads <= 256 ? 8 : 4) void find_prepare_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
                                                            const int64_t* __restrict__ keys, uint64_t n, f32x4* __restrict__ out,
                                                            uint8_t* __restrict__ found, float defv, uint32_t dim4_rt, int64_t* __restrict__ slots_out,
                                                            int64_t handle_tag, uint32_t part_blocks, uint32_t nbk, uint32_t per_block,
@@ -1962,9 +1968,11 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     if (!t || !name) return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: null argument");
     if (!strcmp(name, "find_rounds")) t->find_rounds = value;
     else if (!strcmp(name, "find_grid_cap")) t->find_grid_cap = value;
+    else if (!strcmp(name, "prepare_debug")) t->prepare_debug = value;
     else if (!strcmp(name, "find_nt")) t->find_nt = value;
     else if (!strcmp(name, "apply_rounds")) t->apply_rounds = value;
     else if (!strcmp(name, "apply_path")) t->apply_path = value;
+    else if (!strcmp(name, "apply_spare_blocks")) t->bk.spare_blocks = value > 0 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_bucket_max")) t->bk.bucket_max = value > 0 && value <= 352 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_overlap")) (void)value;   // retired in round 2 (a side stream for the duplicate path lost to its fork/join gaps): accepted, ignored
     else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);
@@ -2630,7 +2638,10 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
     uint32_t part_blocks, per_block;
     part_geometry((uint32_t)n, kFindPrepareThreads, part_blocks, per_block);
     const int R = t->dim4 == 16 || t->dim4 == 32 ? 2 : 1;
-    const unsigned find_blocks = grid_for(n, (kFindPrepareThreads / 64) * 4u * (unsigned)R, 1u << 22);
+    const unsigned find_cap = t->prepare_debug >> 8;
+    const unsigned find_blocks = grid_for(n, (kFindPrepareThreads / 64) * 4u * (unsigned)R, find_cap ? find_cap : 1u << 22);
+    const bool separate = t->prepare_debug & 1;
+    if (separate) part_blocks = 0;
     const bool cached_out = t->find_nt >= 0 && (t->find_nt & 4);
 #define FINDLP1(D4, RR, NT) find_prepare_kernel<D4, RR, NT><<<part_blocks + find_blocks, kFindPrepareThreads, nbk * 4, st>>>(t->keys, (const f32x4*)t->values, t->nb, d_keys, n, (f32x4*)d_out, d_found, \
         t->default_value, t->dim4, d_slots_out, handle_tag_of(t), part_blocks, nbk, per_block, t->bk, &t->ctr->status, t->op)
@@ -2639,7 +2650,8 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
 #undef FINDLP
 #undef FINDLP1
     MEE_HIP(hipGetLastError());
-    t->part_blocks = part_blocks; t->part_per_block = per_block;
+    if (separate) { if (int rc = bucket_apply_prepare(t, d_keys, (uint32_t)n, st)) return rc; }
+    else { t->part_blocks = part_blocks; t->part_per_block = per_block; }
     t->prepared_n = n; t->prepared_keys = d_keys; t->prepared_path = 1;
     return MEE_OK;
 }

@@ -76,6 +76,7 @@ struct BucketScratch {
     int64_t* pend_key;    // [fast_max] pending records of split buckets: key …
     int64_t* pend_slot;   // [fast_max] … the table slot its handle named (located applies: the merge needs no probe) …
     double* pend_row;     // [fast_max][dim] … and the fp64 partial sum of its gradient rows within one slab
+    uint32_t spare_blocks; // tuning ("apply_spare_blocks"): blocks at the head of the apply grid that take the slabs of split buckets (0 = one per CU)
     uint32_t bucket_max;  // tuning ("apply_bucket_max"): positions per bucket aimed at, at most (0 = the default)
     uint32_t n_buckets_max, slots;   // slots: apply blocks the device keeps resident at once (CUs x blocks per CU): bucket counts are multiples of it
     uint64_t fast_max;    // largest n the bucketed path takes
@@ -113,6 +114,7 @@ struct mee_table {
     // performance knobs (never change results): see mee_set_tuning()
     int find_rounds;            // keys in flight per tile in the find kernel: 1, 2, 4 or 8
     int find_grid_cap;          // max blocks of the find grid (0 = one pass, no grid-stride loop)
+    int prepare_debug;          // experiments on the training forward: bit 0 = partition as a launch of its own behind it, bits 8.. = cap on its find blocks
     int apply_rounds;           // batch positions in flight per tile in the apply's main pass: 1 or 2 (0 = auto)
     int find_nt;                // bit0: non-temporal row loads, bit1: non-temporal bucket loads, bit2: plain (cached) out stores;
                                 // -1 = auto: cached loads (hot rows of skewed streams stay in L2), cached stores while the

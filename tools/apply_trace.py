@@ -11,6 +11,8 @@ dist_name = sys.argv[2] if len(sys.argv) > 2 else "uniform"
 paths = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "0,1").split(",")]
 adam = len(sys.argv) > 4 and sys.argv[4] == "adam"
 bmax = int(os.environ.get("MEE_BUCKET_MAX", "0"))
+spare = int(os.environ.get("MEE_SPARE", "0"))
+pdbg = int(os.environ.get("MEE_PREPARE_DEBUG", "0"))
 t = LookupTable(int(keys_n / 0.75), dim, device=dev, max_batch=1 << 20, optimizer=OPT_ADAM if adam else OPT_ADAGRAD)
 bench.populate(t, synth, keys_n, dim, dev, 1 << 20)
 batches = bench.lookup_batches(synth, keys_n, batch, 8, dist_name, dev, seed=3)
@@ -31,6 +33,10 @@ for path in paths:
     t.set_tuning("apply_path", path)
     if bmax:
         t.set_tuning("apply_bucket_max", bmax)
+    if spare:
+        t.set_tuning("apply_spare_blocks", spare)
+    if pdbg:
+        t.set_tuning("prepare_debug", pdbg)
     for label, located in (("apply alone (probing)", False), ("find_located + apply (located)", True), ("find_located_prepare + apply (located)", 2)):
         def step(i):
             if located:
