@@ -302,11 +302,13 @@ def test_dedup_sum(dev):
 
 @pytest.mark.parametrize("opt", ["adagrad", "adam"])
 @pytest.mark.parametrize("dim", [16, 64, 128])
-def test_optimizer_parity(dev, opt, dim):
+@pytest.mark.parametrize("apply_path", [-1, 0], ids=["bucketed", "group_table"])
+def test_optimizer_parity(dev, opt, dim, apply_path):
     n_keys, steps, batch = 20000, 4, 30000
     keys = synth.keys_np(31, 0, n_keys); rows = synth.rows_np(keys, dim, 2)
     kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
     t = LookupTable(32768, dim, device=dev, optimizer=kind, max_batch=batch, initial_accumulator=0.1)
+    t.set_tuning("apply_path", apply_path)
     o = oracle.OracleTable(32768, dim, optimizer=okind, initial_accumulator=0.1)
     t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
     rng = np.random.default_rng(41)
@@ -331,7 +333,8 @@ def test_optimizer_parity(dev, opt, dim):
 
 
 @pytest.mark.parametrize("opt", ["adagrad", "adam"])
-def test_optimizer_full_batch_of_medium_groups(dev, opt):
+@pytest.mark.parametrize("apply_path", [-1, 0], ids=["bucketed", "group_table"])
+def test_optimizer_full_batch_of_medium_groups(dev, opt, apply_path):
     """n == max_batch and EVERY key repeated 33..40 times: each group is 'big' (> 32 occurrences) and needs TWO fp64
     partial-sum rows, the worst case for the partial-sum block (about n/32 + n/33 rows; a block sized for n/32 + 1 rows
     was overrun by exactly this shape)."""
@@ -347,6 +350,7 @@ def test_optimizer_full_batch_of_medium_groups(dev, opt):
     assert bk.size == batch
     kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
     t = LookupTable(8192, dim, device=dev, optimizer=kind, max_batch=batch, initial_accumulator=0.1)
+    t.set_tuning("apply_path", apply_path)
     o = oracle.OracleTable(8192, dim, optimizer=okind, initial_accumulator=0.1)
     t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
     # a canary table allocated right behind the first one's scratch: an overrun of the partial-sum block would land in it
@@ -372,7 +376,8 @@ def test_optimizer_full_batch_of_medium_groups(dev, opt):
 
 @pytest.mark.parametrize("opt,dim,layout", [("adagrad", 64, "clustered"), ("adagrad", 64, "spread"), ("adam", 128, "mixed"),
                                             ("adagrad", 16, "mixed"), ("adam", 24, "spread")])
-def test_optimizer_every_group_size(dev, opt, dim, layout):
+@pytest.mark.parametrize("apply_path", [-1, 0], ids=["bucketed", "group_table"])
+def test_optimizer_every_group_size(dev, opt, dim, layout, apply_path):
     """One batch holds a key of EVERY multiplicity 1..44 plus 64, 65, 100, 333 and 2100, so that each way a duplicate group can be
     finished is taken and its edges are crossed: the inline list of a group-table entry (the claiming block's occurrences 1..8, eight
     of other blocks), the filed groups of one chunk (up to 32), the groups with fp64 partial-sum rows (33 and more).  'clustered'
@@ -403,6 +408,8 @@ def test_optimizer_every_group_size(dev, opt, dim, layout):
     kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
     mk = lambda: LookupTable(4096, dim, device=dev, optimizer=kind, max_batch=n, initial_accumulator=0.1)
     ta, tb, tc = mk(), mk(), mk()
+    for t in (ta, tb, tc):
+        t.set_tuning("apply_path", apply_path)
     o = oracle.OracleTable(4096, dim, optimizer=okind, initial_accumulator=0.1)
     for t in (ta, tb, tc):
         t.insert(T(keys[:n_keys + 400], dev), T(rows[:n_keys + 400], dev))
@@ -445,6 +452,82 @@ def test_optimizer_every_group_size(dev, opt, dim, layout):
     np.testing.assert_allclose(got.cpu().numpy(), exp, rtol=RTOL, atol=ATOL)
 
 
+def _keys_of_apply_bucket_zero(count, seed):
+    """Distinct keys whose mix64 has 13 leading zero bits: for ANY bucket count up to 8192 the bucketed apply puts them all into bucket 0
+    (and the table into the first 1/8192 of its buckets)."""
+    rng = np.random.default_rng(seed)
+    got = []
+    while sum(len(g) for g in got) < count:
+        cand = rng.integers(-(1 << 62), 1 << 62, size=1 << 22, dtype=np.int64)
+        mix, _, _ = oracle.hash_batch(cand, 1, 1)
+        got.append(cand[mix < (np.uint64(1) << np.uint64(51))])
+    return np.unique(np.concatenate(got))[:count]
+
+
+@pytest.mark.parametrize("opt", ["adagrad", "adam"])
+@pytest.mark.parametrize("case", ["one_key", "one_bucket_many_keys", "forty_hot_keys", "one_bucket_two_keys"])
+def test_bucketed_apply_extremes(dev, case, opt):
+    """The rare ways through the bucketed apply (meepo_apply.hip), each forced by construction, plain and located, against the oracle:
+    one_key — a single key fills 400K of a 410K-position batch: ~780 slabs of one bucket each emit a record of that key, more records of ONE key
+    than a merge pass holds (mono_pass);  one_bucket_many_keys — 3000 keys that all fall into apply bucket 0, 100+ occurrences each: every slab
+    emits hundreds of records, the merge has far more records than one pass holds and splits them by hash prefix (the DFS stack);
+    forty_hot_keys — 40 keys of ~6000 occurrences in a uniform batch: forty split buckets merge side by side, spare blocks loop over slabs;
+    one_bucket_two_keys — two keys of one bucket, 150K occurrences each: the prefix split must separate exactly two keys."""
+    dim, n_bg = 64, 20000
+    rng = np.random.default_rng(5)
+    bg = synth.keys_np(321, 0, n_bg)
+    if case == "one_key":
+        hot = synth.keys_np(322, 0, 1); reps = np.array([400_000]); n_fill = 10_000
+    elif case == "one_bucket_many_keys":
+        hot = _keys_of_apply_bucket_zero(3000, 7); reps = rng.integers(100, 140, size=3000); n_fill = 20_000
+    elif case == "forty_hot_keys":
+        hot = synth.keys_np(323, 0, 40); reps = rng.integers(5000, 7000, size=40); n_fill = 150_000
+    else:
+        hot = _keys_of_apply_bucket_zero(2, 9); reps = np.array([150_000, 150_001]); n_fill = 5_000
+    keys = np.unique(np.concatenate([bg, hot]))
+    rows = synth.rows_np(keys, dim, 2)
+    bk = np.concatenate([np.repeat(hot, reps), bg[rng.integers(0, n_bg, n_fill)], synth.keys_np(324, 0, 50)])   # + 50 absent keys
+    rng.shuffle(bk)
+    n = bk.size
+    kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
+    mk = lambda: LookupTable(1 << 17, dim, device=dev, optimizer=kind, max_batch=n, initial_accumulator=0.1)
+    ta, tb = mk(), mk()
+    o = oracle.OracleTable(1 << 17, dim, optimizer=okind, initial_accumulator=0.1)
+    for t in (ta, tb):
+        t.insert(T(keys, dev), T(rows, dev))
+    o.insert(keys, rows)
+    bkt = T(bk, dev)
+    for s in range(2):
+        g = (rng.standard_normal((n, dim)) * 0.01).astype(np.float32)
+        gt = T(g, dev)
+        _, _, slots = tb.find_located(bkt, prepare_apply=(s == 1))
+        if opt == "adagrad":
+            ta.apply_adagrad(bkt, gt, lr=0.05); tb.apply_adagrad(bkt, gt, lr=0.05, slots=slots); o.apply_adagrad(bk, g, 0.05, 1e-10)
+        else:
+            ta.apply_adam(bkt, gt, lr=0.01, step=s + 1); tb.apply_adam(bkt, gt, lr=0.01, step=s + 1, slots=slots)
+            o.apply_adam(bk, g, 0.01, 0.9, 0.999, 1e-8, s + 1)
+    eo = o.export(with_state=True)
+    io = np.argsort(eo[0])
+    for t in (ta, tb):
+        assert t.status() == 0
+        e = [x.cpu().numpy() if x is not None else None for x in t.export(with_state=True)]
+        it = np.argsort(e[0])
+        assert np.array_equal(e[0][it], eo[0][io])
+        for x, z in zip(e[1:], eo[1:]):
+            if z is not None:
+                np.testing.assert_allclose(x[it], z[io], rtol=RTOL, atol=ATOL)
+    # the scratch is left clean: a batch of distinct keys right behind it, bit-exact
+    g1 = (rng.standard_normal((n_bg, dim)) * 0.02).astype(np.float32)
+    if opt == "adagrad":
+        ta.apply_adagrad(T(bg, dev), T(g1, dev), lr=0.05); o.apply_adagrad(bg, g1, 0.05, 1e-10)
+    else:
+        ta.apply_adam(T(bg, dev), T(g1, dev), lr=0.01, step=3); o.apply_adam(bg, g1, 0.01, 0.9, 0.999, 1e-8, 3)
+    got, found = ta.find(T(bg, dev))
+    exp, _ = o.find(bg)
+    assert bool(found.all()) and ta.status() == 0
+    np.testing.assert_allclose(got.cpu().numpy(), exp, rtol=RTOL, atol=ATOL)
+
+
 @pytest.mark.parametrize("dim", [64, 24])
 def test_find_or_insert_located(dev, dim):
     """find_or_insert_located == find_or_insert (rows, found, table contents) and its handles are the slots mee_locate reports
@@ -482,7 +565,8 @@ def test_find_or_insert_located(dev, dim):
 
 
 @pytest.mark.parametrize("opt,dim", [("adagrad", 64), ("adam", 128), ("adagrad", 24)])
-def test_located_apply_equals_plain_apply(dev, opt, dim):
+@pytest.mark.parametrize("apply_path", [-1, 0], ids=["bucketed", "group_table"])
+def test_located_apply_equals_plain_apply(dev, opt, dim, apply_path):
     """find_located + apply_*(slots=…) — the forward's slot handles instead of a probe — must give the table the plain apply
     gives (and the oracle's), with duplicates, absent keys (handle -1), reserved keys and both settings of the side-stream knob."""
     n_keys, batch = 30000, 20000
@@ -490,6 +574,8 @@ def test_located_apply_equals_plain_apply(dev, opt, dim):
     kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
     mk = lambda: LookupTable(65536, dim, device=dev, optimizer=kind, max_batch=n_keys, initial_accumulator=0.1)
     ta, tb = mk(), mk()
+    for t in (ta, tb):
+        t.set_tuning("apply_path", apply_path)
     o = oracle.OracleTable(65536, dim, optimizer=okind, initial_accumulator=0.1)
     for t in (ta, tb):
         t.insert(T(keys, dev), T(rows, dev))
