@@ -276,7 +276,7 @@ def stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, uniform
     b1 = [allk[o:o + m1] for o in range(0, allk.numel() - m1 + 1, m1)][:4]
     o1, f1 = [obig[:m1], obig[m1:2 * m1]], [fbig[:m1], fbig[m1:2 * m1]]
     row = {"lookups_per_launch": m1, "output_buffers": 2}
-    for label, nt in (("default_policy", -1), ("streaming_load_hint", 3)):
+    for label, nt in (("default_policy", -1), ("streaming_row_load_hint", 1), ("streaming_load_hint", 3)):
         table.set_tuning("find_nt", nt)
         med, mn = kernel_window(table, b1, o1, f1, dev, launches=50, regions=5, warm=5)
         row[label] = {"us_per_launch_median": med, "us_per_launch_min": mn, "lookups_per_s": m1 / med * 1e6,
@@ -785,14 +785,20 @@ def main():
     else:
         if n_out > 1:
             # a caller whose result buffers rotate knows that nothing re-reads them from cache: mee_set_tuning "find_nt" = 0 (cached loads,
-            # streaming stores) is its hint; the library's own rule only sees one call's size (64 MB: cached stores).  Keep whichever is faster here.
-            t_auto = kernel_window(table, batches, outs, founds, dev, launches=100, regions=3, warm=10)[0]
-            table.set_tuning("find_nt", 0)
-            t_hint = kernel_window(table, batches, outs, founds, dev, launches=100, regions=3, warm=10)[0]
-            store_hint = {"auto_us": t_auto, "streaming_stores_us": t_hint, "used": "streaming stores (find_nt = 0)" if t_hint < t_auto else "library default"}
-            if not t_hint < t_auto:
-                table.set_tuning("find_nt", -1)
-            log(f"rotating output buffers: default policy {t_auto:.2f} us, streaming-store hint {t_hint:.2f} us per launch")
+            # streaming stores) is its hint — the library's own rule only sees one call's size (64 MB: cached stores) — and one whose keys are
+            # uniform over a table far larger than the caches adds streaming row loads (find_nt = 1; skewed streams re-read their hot rows and
+            # lose with it: 27 -> 30 us on Zipf(1.05)).  Keep whichever is fastest here.
+            probe = {}
+            for label, nt in (("auto", -1), ("streaming_stores", 0), ("streaming_stores_and_row_loads", 1)):
+                table.set_tuning("find_nt", nt)
+                probe[label] = kernel_window(table, batches, outs, founds, dev, launches=100, regions=3, warm=10)[0]
+            best = min(probe, key=probe.get)
+            hint_nt = {"auto": -1, "streaming_stores": 0, "streaming_stores_and_row_loads": 1}[best]
+            table.set_tuning("find_nt", hint_nt)
+            store_hint = {"auto_us": probe["auto"], "streaming_stores_us": probe["streaming_stores"],
+                          "streaming_stores_and_row_loads_us": probe["streaming_stores_and_row_loads"], "find_nt": hint_nt,
+                          "used": "library default" if best == "auto" else f"{best.replace('_', ' ')} (find_nt = {hint_nt})"}
+            log("rotating output buffers: " + ", ".join(f"{k} {v:.2f} us" for k, v in probe.items()) + " per launch")
 
         def step(i):
             return table.find(batches[i % n_batches], out=outs[i % n_out], found=founds[i % n_out])
@@ -932,8 +938,8 @@ def main():
     if not sharded and not train and n_out > 1:   # the same launches into ONE reused 64 MB buffer under the library's default policy (what round 2 reported)
         table.set_tuning("find_nt", -1)
         reused_us = kernel_window(table, batches, out, found, dev)
-        if store_hint is not None and store_hint["used"].startswith("streaming"):
-            table.set_tuning("find_nt", 0)
+        if store_hint is not None:
+            table.set_tuning("find_nt", store_hint["find_nt"])
     whole = train and not sharded   # sharded runs always price the local find_kernel alone
     if whole:
         # fwd 528 B/lookup + bwd 264 B/lookup + 1032 B per unique key (Adagrad); here the whole step is priced

@@ -389,28 +389,23 @@ __device__ __forceinline__ void mono_pass(ApplyLds& L, const ApplyArgs& A, const
 // fetches the lengths and places of runs 2l and 2l + 1 (seg_load: four independent loads), a wave scan turns the lengths into each run's first
 // index within the bucket (seg_scan -> L.seg_first / L.seg_at; the caller's next barrier publishes them).
 struct SegRuns { uint32_t len0, len1, at0, at1; };
-__device__ __forceinline__ SegRuns seg_load(const ApplyArgs& A, const BucketScratch& bk, uint32_t b) {
+__device__ __forceinline__ SegRuns seg_load(const ApplyArgs& A, const BucketScratch& bk, uint32_t b, uint32_t tid) {
     SegRuns r{0u, 0u, 0u, 0u};
-    if (threadIdx.x < 64) {
-        const uint32_t k0 = 2 * threadIdx.x, k1 = k0 + 1;
+    if (tid < 64) {
+        const uint32_t k0 = 2 * tid, k1 = k0 + 1;
         if (k0 < A.part_blocks) { r.len0 = bk.cnt_mat[(uint64_t)k0 * A.nbk + b]; r.at0 = k0 * A.per_block + bk.off_mat[(uint64_t)k0 * A.nbk + b]; }
         if (k1 < A.part_blocks) { r.len1 = bk.cnt_mat[(uint64_t)k1 * A.nbk + b]; r.at1 = k1 * A.per_block + bk.off_mat[(uint64_t)k1 * A.nbk + b]; }
     }
     return r;
 }
-__device__ __forceinline__ void seg_scan(ApplyLds& L, const SegRuns& r) {
-    if (threadIdx.x >= 64) return;
+__device__ __forceinline__ void seg_scan(ApplyLds& L, const SegRuns& r, uint32_t tid) {
+    if (tid >= 64) return;
     const uint32_t both = r.len0 + r.len1;
-    uint32_t incl = both;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t v = __shfl_up(incl, d);
-        if ((int)threadIdx.x >= d) incl += v;
-    }
-    const uint32_t k0 = 2 * threadIdx.x;
+    const uint32_t incl = wave_incl_scan_u32(both);
+    const uint32_t k0 = 2 * tid;
     L.seg_first[k0] = incl - both;
     L.seg_first[k0 + 1] = incl - r.len1;
-    if (threadIdx.x == 63) L.seg_first[kPartBlocks] = incl;
+    if (tid == 63) L.seg_first[kPartBlocks] = incl;
     L.seg_at[k0] = r.at0;
     L.seg_at[k0 + 1] = r.at1;
 }
@@ -429,13 +424,13 @@ __device__ __forceinline__ void bucket_role(ApplyLds& L, const ApplyArgs& A, con
     // filled (bk.seq[1], meepo_apply_part.h), the bucket's total in BOTH copies, and — lanes of wave 0 — the lengths and places of the bucket's
     // runs in the partition blocks' slices.  (As a chain seq -> total -> run lengths these were three dependent loads, 2-3 us of every block's
     // life before its first useful request.)
-    const SegRuns runs = seg_load(A, bk, b);
+    const SegRuns runs = seg_load(A, bk, b, threadIdx.x);
     const uint32_t tot0 = bk.tot[b], tot1 = bk.tot[bk.n_buckets_max + b];
     const uint32_t parity = bk.seq[1];
     if (b == 0 && threadIdx.x == 0) atomicAdd(&bk.seq[0], 1u);   // this partition is consumed: the next one fills the other copy
     const uint32_t size = __builtin_amdgcn_readfirstlane(parity ? tot1 : tot0);
     if (size == 0 || size > kSlab) return;   // an empty bucket | a split bucket: bkt_split_kernel has it
-    seg_scan(L, runs);
+    seg_scan(L, runs, threadIdx.x);
     process_slab<KIND, DIM4, LOCATED, false>(L, A, bk, 0, size, false, false, b, 0);
 }
 
@@ -448,12 +443,16 @@ __device__ __forceinline__ void split_role(ApplyLds& L, const ApplyArgs& A, cons
     if (!__builtin_amdgcn_readfirstlane(parity ? hs1 : hs0)) return;
     const uint32_t tot_base = parity * bk.n_buckets_max;
     for (uint32_t e = e0;; e += stride) {
+        // (the thread index is re-read through an empty asm in every turn, as in process_slab: hoisted out of this loop, the per-thread addresses
+        // of everything below stayed live across the whole role and were spilled to scratch — a memory round trip in front of every use)
+        uint32_t tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));
         uint32_t b, sub;
         {
             const uint32_t per_t = (A.nbk + kApplyThreads - 1) / kApplyThreads;
             unsigned long long mine = 0;
             for (uint32_t q = 0; q < per_t; ++q) {
-                const uint32_t bb = threadIdx.x * per_t + q;
+                const uint32_t bb = tx * per_t + q;
                 const uint32_t tt = bb < A.nbk ? bk.tot[tot_base + bb] : 0u;
                 mine += tt > kSlab ? (tt + kSlab - 1) / kSlab : 0u;
             }
@@ -463,7 +462,7 @@ __device__ __forceinline__ void split_role(ApplyLds& L, const ApplyArgs& A, cons
             if (e >= ex && e < ex + (uint32_t)mine) {   // exactly one thread
                 uint32_t acc = ex;
                 for (uint32_t q = 0; q < per_t; ++q) {
-                    const uint32_t bb = threadIdx.x * per_t + q;
+                    const uint32_t bb = tx * per_t + q;
                     const uint32_t tt = bb < A.nbk ? bk.tot[tot_base + bb] : 0u;
                     const uint32_t x = tt > kSlab ? (tt + kSlab - 1) / kSlab : 0u;
                     if (e < acc + x) { L.rec_base = bb; L.n_cand = e - acc; break; }
@@ -475,11 +474,11 @@ __device__ __forceinline__ void split_role(ApplyLds& L, const ApplyArgs& A, cons
             __syncthreads();
         }
         const uint32_t size = __builtin_amdgcn_readfirstlane(bk.tot[tot_base + b]);
-        seg_scan(L, seg_load(A, bk, b));   // the bucket's runs in the partition blocks' slices
+        seg_scan(L, seg_load(A, bk, b, tx), tx);   // the bucket's runs in the partition blocks' slices
         uint32_t beg;   // the bucket's first pending record = the keys in the buckets before it (records never outnumber positions)
         {
             unsigned long long mine = 0, total;
-            for (uint32_t bb = threadIdx.x; bb < b; bb += kApplyThreads) mine += bk.tot[tot_base + bb];
+            for (uint32_t bb = tx; bb < b; bb += kApplyThreads) mine += bk.tot[tot_base + bb];
             (void)block_scan_u64<kApplyWaves>(mine, L.wsum, total);
             beg = __builtin_amdgcn_readfirstlane((uint32_t)total);
             __syncthreads();

@@ -39,16 +39,37 @@ inline void part_geometry(uint32_t n, uint32_t threads, uint32_t& blocks, uint32
 // the same bits, scaled the same way, as the key's table bucket (bucket_of): a block's keys live in one contiguous 1/nbk slice of the table
 __device__ __forceinline__ uint32_t apply_bucket_of(int64_t key, uint32_t nbk) { return (uint32_t)__umul64hi(mix64((uint64_t)key), (uint64_t)nbk); }
 
+// Inclusive prefix sums over the 64 lanes of a wave on the DPP path (row_shr 1 / 2 / 4 / 8 inside each row of 16 lanes, then row_bcast:15 into rows
+// 1 and 3 and row_bcast:31 into rows 2 and 3; lanes without a source add the `old` operand, 0).  No LDS, no lane-address arithmetic: the
+// __shfl_up form computes six (lane - d) << 2 addresses for ds_bpermute, which the compiler hoisted out of the apply kernel's loops and then
+// spilled to scratch — a memory round trip in front of every scan of the split role.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+#define MEE_DPP_ADD64(CTRL, ROWS)                                                                                      \
+    do {                                                                                                               \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROWS, 0xf, false);      \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROWS, 0xf, false); \
+        v += (unsigned long long)hi_ << 32 | lo_;                                                                      \
+    } while (0)
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v) {
+    MEE_DPP_ADD64(0x111, 0xf); MEE_DPP_ADD64(0x112, 0xf); MEE_DPP_ADD64(0x114, 0xf); MEE_DPP_ADD64(0x118, 0xf);
+    MEE_DPP_ADD64(0x142, 0xa); MEE_DPP_ADD64(0x143, 0xc);
+    return v;
+}
+#undef MEE_DPP_ADD64
+
 // exclusive prefix sum of a packed 64-bit value over a block of NW waves; every field of the packed value must stay below its width
 template <int NW>
 __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v, unsigned long long* wsum /*[NW]*/, unsigned long long& total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned long long incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (wave-uniform: the comparisons below are scalar)
+    const unsigned long long incl = wave_incl_scan_u64(v);
     __syncthreads();   // wsum may still be read from an earlier call
     if (lane == 63) wsum[w] = incl;
     __syncthreads();

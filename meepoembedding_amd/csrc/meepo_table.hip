@@ -1968,6 +1968,7 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     if (!t || !name) return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: null argument");
     if (!strcmp(name, "find_rounds")) t->find_rounds = value;
     else if (!strcmp(name, "find_grid_cap")) t->find_grid_cap = value;
+    else if (!strcmp(name, "find_block")) t->find_block = value;
     else if (!strcmp(name, "prepare_debug")) t->prepare_debug = value;
     else if (!strcmp(name, "find_nt")) t->find_nt = value;
     else if (!strcmp(name, "apply_rounds")) t->apply_rounds = value;
@@ -2057,10 +2058,11 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
     if (t->dim4 != 16 && R > 4) R = 4;
     if (t->dim4 != 16 && t->dim4 != 32 && R > 2) R = 2;
     R = R >= 8 ? 8 : R >= 4 ? 4 : R >= 2 ? 2 : 1;
-    const unsigned grid = grid_for(n, 4u * 4u * (unsigned)R, t->find_grid_cap > 0 ? (unsigned)t->find_grid_cap : (1u << 22));
+    const unsigned fblock = t->find_block == 64 || t->find_block == 128 ? (unsigned)t->find_block : 256u;   // (launch bound of find_kernel: 256)
+    const unsigned grid = grid_for(n, (fblock / 64u) * 4u * (unsigned)R, t->find_grid_cap > 0 ? (unsigned)t->find_grid_cap : (1u << 22));
 #define FIND1(D4, RR, NT) do { if (unordered) hipExtLaunchKernelGGL((find_kernel<D4, RR, NT>), dim3(grid), dim3(256), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, \
                                         (const int64_t*)t->keys, (const f32x4*)plane, t->nb, d_keys, (uint64_t)n, (f32x4*)d_out, d_found, miss_value, t->dim4, (uint32_t*)nullptr, (int64_t*)nullptr, (int64_t)0); \
-                               else find_kernel<D4, RR, NT><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr); } while (0)
+                               else find_kernel<D4, RR, NT><<<grid, fblock, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr); } while (0)
     const int nt = t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
 #define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
     if (skip_padding) {   // owner pass of a padded sharded exchange: EMPTY positions get neither a row nor a found byte (nobody reads them)
@@ -2076,8 +2078,8 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
         // cache policy of `out`: this is the forward of a TRAINING step — the apply that follows sweeps the Infinity Cache before the next
         // forward, so keeping the dense output cached buys nothing and streaming stores win (136.9 -> 132.5 us per find + Adagrad step)
         const bool cached_out = t->find_nt >= 0 && (t->find_nt & 4);
-#define FINDL(D4, RR) do { if (cached_out) find_kernel<D4, RR, 68><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out, handle_tag_of(t)); \
-                           else find_kernel<D4, RR, 64><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out, handle_tag_of(t)); } while (0)
+#define FINDL(D4, RR) do { if (cached_out) find_kernel<D4, RR, 68><<<grid, fblock, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out, handle_tag_of(t)); \
+                           else find_kernel<D4, RR, 64><<<grid, fblock, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out, handle_tag_of(t)); } while (0)
         if (t->dim4 == 16) { if (R >= 2) FINDL(16, 2); else FINDL(16, 1); }
         else if (t->dim4 == 32) { if (R >= 2) FINDL(32, 2); else FINDL(32, 1); }
         else { if (R >= 2) FINDL(0, 2); else FINDL(0, 1); }

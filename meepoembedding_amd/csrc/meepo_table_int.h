@@ -114,6 +114,7 @@ struct mee_table {
     // performance knobs (never change results): see mee_set_tuning()
     int find_rounds;            // keys in flight per tile in the find kernel: 1, 2, 4 or 8
     int find_grid_cap;          // max blocks of the find grid (0 = one pass, no grid-stride loop)
+    int find_block;             // threads per block of the find launch (64 / 128; anything else: 256)
     int prepare_debug;          // experiments on the training forward: bit 0 = partition as a launch of its own behind it, bits 8.. = cap on its find blocks
     int apply_rounds;           // batch positions in flight per tile in the apply's main pass: 1 or 2 (0 = auto)
     int find_nt;                // bit0: non-temporal row loads, bit1: non-temporal bucket loads, bit2: plain (cached) out stores;

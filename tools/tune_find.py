@@ -16,6 +16,7 @@ ap.add_argument("--dist", default="uniform")
 ap.add_argument("--no-found", action="store_true")
 ap.add_argument("--miss", type=float, default=0.0, help="fraction of looked-up keys that are absent")
 ap.add_argument("--load", type=float, default=0.75)
+ap.add_argument("--out-buffers", type=int, default=1, help="result buffers used in turn (6 x 64 MB: nothing of a launch's output is still cached when its buffer comes round again)")
 ap.add_argument("variants", nargs="*", default=["find_rounds=1", "find_rounds=2", "find_rounds=4", "find_rounds=8"])
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -27,10 +28,10 @@ if a.miss > 0:
     for b in batches:
         m = torch.rand(a.batch, device=dev, generator=g_) < a.miss
         b[m] = synth.keys_t(99, 0, a.batch, dev)[m]   # keys of another stream: absent
-out = torch.empty((a.batch, a.dim), dtype=torch.float32, device=dev); found = None if a.no_found else torch.empty(a.batch, dtype=torch.uint8, device=dev)
+outs = [torch.empty((a.batch, a.dim), dtype=torch.float32, device=dev) for _ in range(a.out_buffers)]; found = None if a.no_found else torch.empty(a.batch, dtype=torch.uint8, device=dev)
 times = {v: [] for v in a.variants}
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-defaults = {"find_rounds": 2, "find_grid_cap": 0, "find_nt": -1}
+defaults = {"find_rounds": 2, "find_grid_cap": 0, "find_nt": -1, "find_block": 256}
 for r in range(a.rounds + 1):
     for v in a.variants:
         for k, d in defaults.items():
@@ -38,11 +39,11 @@ for r in range(a.rounds + 1):
         for kv in v.split(","):
             k, val = kv.split("="); t.set_tuning(k, int(val))
         for i in range(10):
-            t.find(batches[i % 64], out=out, found=found, want_found=not a.no_found)
+            t.find(batches[i % 64], out=outs[i % a.out_buffers], found=found, want_found=not a.no_found)
         torch.cuda.synchronize()
         e0.record()
         for i in range(a.launches):
-            t.find(batches[i % 64], out=out, found=found, want_found=not a.no_found)
+            t.find(batches[i % 64], out=outs[i % a.out_buffers], found=found, want_found=not a.no_found)
         e1.record(); torch.cuda.synchronize()
         if r:
             times[v].append(e0.elapsed_time(e1) * 1e3 / a.launches)
