@@ -130,6 +130,9 @@ int mee_find_located(const mee_table* t, const int64_t* d_keys, size_t n, float*
  * with its update kernel.  Same rules as mee_apply_prepare while the prepared apply is pending (mee_apply_discard drops it); tables without
  * an optimizer: plain mee_find_located. */
 int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream);
+/* The same for a growing vocabulary: mee_find_or_insert_located whose first launch also carries the partition (absent keys are then created by
+ * its second pass exactly as in mee_find_or_insert_located; d_found = present BEFORE the call, nullable). */
+int mee_find_or_insert_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream);
 /* second-tier pass after a mee_find on another table (same keys/out/found buffers): positions with d_found[i] == 0
  * that THIS table holds get their row and d_found[i] = 1; every other position is left untouched.  No host sync, no
  * compaction: this is how a hot (HBM) table is backed by a cold (pinned host) one inside one stream. */

@@ -74,6 +74,17 @@ public:
     void find_or_insert(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_find_or_insert(t_, d_keys, n, d_out, d_found, stream)); }
     // the forward of a training step over a growing vocabulary: rows + the slot of every key, for apply_*_located of the same step
     void find_or_insert_located(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream = nullptr) { check(mee_find_or_insert_located(t_, d_keys, n, d_out, d_found, d_slots_out, stream)); }
+    // forward + backward of one training step: the located lookup (prepare = true: its launch also partitions the batch for the apply of the
+    // SAME d_keys / n that must follow — mee_find_located_prepare / mee_find_or_insert_located_prepare), then the update at the slots it found
+    void find_located(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, bool prepare = false, void* stream = nullptr) {
+        check(prepare ? mee_find_located_prepare(t_, d_keys, n, d_out, d_found, d_slots_out, stream) : mee_find_located(t_, d_keys, n, d_out, d_found, d_slots_out, stream));
+    }
+    void find_or_insert_located_prepare(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream = nullptr) { check(mee_find_or_insert_located_prepare(t_, d_keys, n, d_out, d_found, d_slots_out, stream)); }
+    void apply_adagrad_located(const int64_t* d_keys, const int64_t* d_slots, const float* d_grads, size_t n, float lr, float eps = 1e-10f, void* stream = nullptr) { check(mee_apply_adagrad_located(t_, d_keys, d_slots, d_grads, n, lr, eps, stream)); }
+    void apply_adam_located(const int64_t* d_keys, const int64_t* d_slots, const float* d_grads, size_t n, float lr, uint64_t step, float beta1 = 0.9f, float beta2 = 0.999f, float eps = 1e-8f, void* stream = nullptr) {
+        check(mee_apply_adam_located(t_, d_keys, d_slots, d_grads, n, lr, beta1, beta2, eps, step, stream));
+    }
+    void apply_discard(void* stream = nullptr) { check(mee_apply_discard(t_, stream)); }
     void find_plane(uint32_t plane, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found = nullptr, void* stream = nullptr) const { check(mee_find_plane(t_, plane, d_keys, n, d_out, d_found, stream)); }
     void assign_plane(uint32_t plane, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found = nullptr, void* stream = nullptr) { check(mee_assign_plane(t_, plane, d_keys, d_values, n, d_found, stream)); }
     void apply_adagrad(const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps = 1e-10f, void* stream = nullptr) { check(mee_apply_adagrad(t_, d_keys, d_grads, n, lr, eps, stream)); }

@@ -109,6 +109,7 @@ PROTOTYPES = {
     "mee_find_located": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "mee_find_or_insert_located": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "mee_find_located_prepare": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "mee_find_or_insert_located_prepare": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "mee_apply_adagrad_located": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _vp]),
     "mee_apply_adam_located": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
     "mee_find_or_insert_admit": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _u32, _vp]),

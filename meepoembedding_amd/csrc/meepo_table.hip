@@ -2658,6 +2658,24 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
     return MEE_OK;
 }
 
+int mee_find_or_insert_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
+    if (!t || (n && (!d_keys || !d_out || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_or_insert_located_prepare: null argument");
+    if (t->optimizer == MEE_OPT_NONE) return mee_find_or_insert_located(t, d_keys, n, d_out, d_found, d_slots_out, stream);
+    if (int rc = check_batch(t, n, "mee_find_or_insert_located_prepare")) return rc;   // (refuses while another prepared apply is pending)
+    if (n == 0) return MEE_OK;
+    uint8_t* fmask = d_found ? d_found : t->bs.fmask;
+    // pass 1: the training forward's launch (located find of the stored keys + the partition of the backward); pass 2: the missing positions
+    // claim their keys and write the initial rows (table, d_out) and the slot handles, as in mee_find_or_insert_located — it touches none of the
+    // scratch the partition left for the apply, and the partition depends on the batch's keys alone
+    if (int rc = mee_find_located_prepare(t, d_keys, n, d_out, fmask, d_slots_out, stream)) return rc;
+    DeviceGuard g(t->device);
+    ensure_direct_kernel<64><<<grid_for(n, 256, 8192), 256, 0, as_stream(stream)>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
+                                                                d_keys, (uint32_t)n, fmask, t->optimizer, t->init_acc, t->initializer, t->init_scale,
+                                                                t->init_seed, t->default_value, t->ctr, t->hits, (float4*)d_out, (long long*)d_slots_out, (long long)handle_tag_of(t));
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
 int mee_apply_discard(mee_table* t, void* stream) {
     if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_apply_discard: null table");
     if (!t->prepared_n) return MEE_OK;

@@ -80,16 +80,26 @@ lookup.register_autograd(_backward, setup_context=_setup)
 
 # ---- the same pair for a plain HBM table: the forward hands its slot handles to the backward, whose apply then does not probe ------
 @torch.library.custom_op("meepo::lookup_located", mutates_args=())
-def lookup_located(keys: torch.Tensor, anchor: torch.Tensor, table_id: int, insert_missing: bool) -> tuple[torch.Tensor, torch.Tensor]:
-    """-> (rows [..., dim], slot handle of every key (-1 = absent) for the backward of this step)"""
+def lookup_located(keys: torch.Tensor, anchor: torch.Tensor, table_id: int, insert_missing: bool, prepare: bool = False) -> tuple[torch.Tensor, torch.Tensor]:
+    """-> (rows [..., dim], slot handle of every key (-1 = absent) for the backward of this step).
+    prepare: a backward for exactly these keys follows — the lookup's launch also partitions the batch for its apply (mee_find_located_prepare /
+    mee_find_or_insert_located_prepare).  A partition that no backward consumed (a forward without backward, a second layer over the same
+    table) is dropped here before the next one is made."""
     layer = _layer(table_id)
+    table = layer.table
     flat = keys.reshape(-1)
-    rows, _, slots = layer.table.find_or_insert_located(flat) if insert_missing else layer.table.find_located(flat)
-    return rows.reshape(*keys.shape, layer.table.dim), slots   # fresh tensors: nothing aliases the table
+    if getattr(table, "_nn_prepared", None) is not None:   # an earlier forward's partition that no backward used
+        table.apply_discard()
+        table._nn_prepared = None
+    prepare = prepare and flat.is_contiguous() and flat.numel() > 0 and flat.numel() <= table.max_batch
+    rows, _, slots = (table.find_or_insert_located(flat, prepare_apply=prepare) if insert_missing else table.find_located(flat, prepare_apply=prepare))
+    if prepare:
+        table._nn_prepared = (flat.data_ptr(), flat.numel())
+    return rows.reshape(*keys.shape, table.dim), slots   # fresh tensors: nothing aliases the table
 
 
 @lookup_located.register_fake
-def _(keys, anchor, table_id, insert_missing):
+def _(keys, anchor, table_id, insert_missing, prepare=False):
     return keys.new_empty((*keys.shape, _layer(table_id).table.dim), dtype=torch.float32), keys.new_empty(keys.numel())
 
 
@@ -99,6 +109,12 @@ def apply_grad_located(keys: torch.Tensor, grad_rows: torch.Tensor, located: tor
     g = grad_rows.reshape(-1, layer.table.dim).contiguous()
     slots = located if located.numel() == keys.numel() else None
     layer.step += 1
+    prepared = getattr(layer.table, "_nn_prepared", None)
+    if prepared is not None:   # the forward's partition is for exactly (this tensor, this length), or it is dropped
+        flat = keys.reshape(-1)
+        if prepared != (flat.data_ptr(), flat.numel()):
+            layer.table.apply_discard()
+        layer.table._nn_prepared = None
     if layer.optimizer == "adagrad":
         layer.table.apply_adagrad(keys.reshape(-1), g, lr=layer.lr, eps=layer.eps, slots=slots)
     else:
@@ -112,7 +128,7 @@ def _(keys, grad_rows, located, table_id):
 
 
 def _setup_located(ctx, inputs, output):
-    keys, _, table_id, _ = inputs
+    keys, _, table_id = inputs[:3]
     ctx.save_for_backward(keys, output[1])
     ctx.table_id = table_id
     ctx.layout_epoch = getattr(_layer(table_id).table, "layout_epoch", None)   # handles are slot numbers: stale once rows move
@@ -124,7 +140,7 @@ def _backward_located(ctx, grad_out, _grad_located):
     if getattr(_layer(ctx.table_id).table, "layout_epoch", None) != ctx.layout_epoch:
         located = located.new_empty(0)   # the table changed between forward and backward: the apply probes for itself
     apply_grad_located(keys, grad_out.contiguous(), located, ctx.table_id)
-    return None, None, None, None
+    return None, None, None, None, None
 
 
 lookup_located.register_autograd(_backward_located, setup_context=_setup_located)
@@ -302,6 +318,7 @@ class DynamicEmbedding(torch.nn.Module):
         self.table, self.optimizer, self.lr, self.betas = table, optimizer, lr, betas
         self.eps = eps if eps is not None else (1e-10 if optimizer == "adagrad" else 1e-8)
         self.step = 0
+        self.fuse_backward_partition = True   # see forward()
         self.table_id = next(_IDS)
         _LAYERS[self.table_id] = self
         # autograd only runs backward for ops with an input that requires grad
@@ -309,5 +326,7 @@ class DynamicEmbedding(torch.nn.Module):
 
     def forward(self, keys: torch.Tensor) -> torch.Tensor:
         if hasattr(self.table, "find_or_insert_located"):   # one HBM table: the backward updates the rows at the slots this lookup found
-            return lookup_located(keys, self._anchor, self.table_id, self.training)[0]
+            # training: the lookup's launch also partitions the batch for the backward's apply (nothing else may change the table in between:
+            # the C-ABI refuses mutators while that partition is pending — table.apply_discard() drops it)
+            return lookup_located(keys, self._anchor, self.table_id, self.training, self.training and torch.is_grad_enabled() and self.fuse_backward_partition)[0]
         return lookup(keys, self._anchor, self.table_id, self.training)   # sharded / tiered tables: their apply routes by key

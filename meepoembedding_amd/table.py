@@ -219,9 +219,10 @@ class LookupTable:
         return out, found
 
     def find_or_insert_located(self, keys: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None,
-                               slots: torch.Tensor | None = None):
+                               slots: torch.Tensor | None = None, prepare_apply: bool = False):
         """find_or_insert() that also returns where every key lives now (-1: reserved key / table full): the handles for
-        apply_*(…, slots=…) of the same training step — the forward of a step over a growing vocabulary."""
+        apply_*(…, slots=…) of the same training step — the forward of a step over a growing vocabulary.
+        prepare_apply: as in find_located — the launch also partitions the batch for the apply of the SAME `keys` tensor that must follow."""
         k = self._keys(keys)
         n = k.numel()
         if out is None:
@@ -230,7 +231,8 @@ class LookupTable:
             found = torch.empty(n, dtype=torch.uint8, device=self.device)
         if slots is None:
             slots = torch.empty(n, dtype=torch.int64, device=self.device)
-        check(_lib.lib().mee_find_or_insert_located(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), slots.data_ptr(), self._s()))
+        fn = _lib.lib().mee_find_or_insert_located_prepare if prepare_apply else _lib.lib().mee_find_or_insert_located
+        check(fn(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr(), slots.data_ptr(), self._s()))
         return out, found, slots
 
     def admission_decay(self, shift: int = 1) -> None:

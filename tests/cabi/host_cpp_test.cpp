@@ -3,6 +3,7 @@
 // (Router partition -> PeerExchange push -> find -> rows in batch order) with one rank.  Exit code 0 = pass.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -74,6 +75,36 @@ int main() try {
           CHECK(f[i] == (expect ? 1 : 0));
           if (expect) CHECK(memcmp(&out[i * dim], &rows[i * dim], dim * 4) == 0); else CHECK(out[i * dim] == -2.0f);
       } }
+
+    // ---- one training step from C++: the located forward (its launch also partitions the batch for the backward), then sparse Adagrad at
+    //      the slots it found — every key twice in the batch, grads = 1: w -= lr * 2 / sqrt(acc0 + 4) ---------------------------------
+    { const size_t m = 20000;
+      meepo::TableOptions to = o; to.optimizer = MEE_OPT_ADAGRAD; to.initial_accumulator = 0.5f; to.max_batch = 2 * m; to.capacity = 65536;
+      meepo::Table tr(to);
+      tr.insert(d_keys.p, d_rows.p, m);
+      std::vector<int64_t> b(2 * m);
+      for (size_t i = 0; i < m; ++i) { b[i] = keys[i]; b[m + i] = keys[(i * 31) % m]; }   // 31 is coprime to m: every key exactly twice
+      b[7] = (int64_t)mix64(424242);                                  // an absent key: handle -1, no update (and keys[7] occurs once)
+      DevBuf<int64_t> d_b(2 * m), d_slots(2 * m); DevBuf<float> d_o(2 * m * dim), d_g(2 * m * dim); DevBuf<uint8_t> d_f(2 * m);
+      d_b.up(b); d_g.up(std::vector<float>(2 * m * dim, 1.0f));
+      tr.find_located(d_b.p, 2 * m, d_o.p, d_f.p, d_slots.p, /*prepare=*/true);
+      threw = false;
+      try { tr.insert(d_keys.p, d_rows.p, 4); } catch (const meepo::Error& e) { threw = e.code() == MEE_ERR_INVALID_ARG; }   // a prepared apply is pending
+      CHECK(threw);
+      tr.apply_adagrad_located(d_b.p, d_slots.p, d_g.p, 2 * m, 0.1f);
+      CHECK(tr.status() == 0);
+      tr.find(d_keys.p, m, d_o.p, d_f.p);
+      HIPCK(hipDeviceSynchronize());
+      auto out = d_o.down(m * dim); auto sl = d_slots.down(2 * m);
+      CHECK(sl[7] == -1 && sl[8] >= 0);
+      for (size_t i = 0; i < m; ++i) {
+          const float gsum = i == 7 ? 1.0f : 2.0f, expect = rows[i * dim + 3] - 0.1f * gsum / sqrtf(0.5f + gsum * gsum);
+          CHECK(fabsf(out[i * dim + 3] - expect) <= 1e-6f * fabsf(expect) + 1e-7f);
+      }
+      tr.find_located(d_b.p, 2 * m, d_o.p, d_f.p, d_slots.p, true);   // a partition nobody uses ...
+      tr.apply_discard();                                              // ... is dropped
+      tr.insert(d_keys.p, d_rows.p, 4);
+      CHECK(tr.status() == 0); }
 
     // ---- hot/cold pair: first half of the keys in HBM, second half in the pinned-host tier ------------------------
     meepo::TableOptions ho = o; ho.capacity = (uint64_t)(n / 2 / 0.75);

@@ -558,6 +558,22 @@ def test_find_or_insert_located(dev, dim):
     ea, eb = ta.export(with_state=True), tb.export(with_state=True)
     ia, ib = torch.argsort(ea[0]), torch.argsort(eb[0])
     np.testing.assert_allclose(ea[1][ia].cpu().numpy(), eb[1][ib].cpu().numpy(), rtol=RTOL, atol=ATOL)
+    # the training forward of a growing vocabulary: the same call with the backward's partition in its first launch
+    batch2 = np.concatenate([keys[rng.integers(0, n_keys, 4000)], synth.keys_np(93, 0, 300), synth.keys_np(93, 0, 300)])   # present, new, new twice
+    rng.shuffle(batch2)
+    b2 = T(batch2, dev)
+    oa, fa = ta.find_or_insert(b2)
+    ob, fb, slots = tb.find_or_insert_located(b2, prepare_apply=True)
+    assert torch.equal(oa, ob) and torch.equal(fa, fb) and bool((slots >= 0).all())
+    with pytest.raises(MeepoError):
+        tb.insert(b2[:4], ob[:4])   # a prepared apply is pending
+    g = (rng.standard_normal((batch2.size, dim)) * 0.01).astype(np.float32)
+    ta.apply_adagrad(b2, T(g, dev), lr=0.01); tb.apply_adagrad(b2, T(g, dev), lr=0.01, slots=slots)
+    ea, eb = ta.export(with_state=True), tb.export(with_state=True)
+    ia, ib = torch.argsort(ea[0]), torch.argsort(eb[0])
+    assert torch.equal(ea[0][ia], eb[0][ib]) and ta.status() == tb.status() == 0
+    np.testing.assert_allclose(ea[1][ia].cpu().numpy(), eb[1][ib].cpu().numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(ea[2][ia].cpu().numpy(), eb[2][ib].cpu().numpy(), rtol=RTOL, atol=ATOL)
     # a full table: keys that cannot be created report -1 and the default row
     small = LookupTable(64, dim, device=dev, max_batch=8192)
     o, f, s_ = small.find_or_insert_located(T(keys[:1000], dev))

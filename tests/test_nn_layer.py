@@ -183,3 +183,49 @@ def test_embedding_bag_collection_layer(dev):
     before = [t.size() for t in a]
     grow.eval(); grow(new_ids, new_off); assert [t.size() for t in a] == before
     grow.train(); grow(new_ids, new_off); assert [t.size() for t in a] == [s + 4 for s in before]
+
+
+@pytest.mark.gpu
+def test_training_forward_carries_the_backward_partition(dev):
+    """DynamicEmbedding in training mode: the lookup's launch also partitions the batch for the backward's apply
+    (mee_find_or_insert_located_prepare).  Same table as with the knob off — growing vocabulary, duplicates, absent keys —; a forward
+    that no backward follows, two layers over one table and a caller who changes the table between forward and backward stay correct."""
+    from meepoembedding_amd import OPT_ADAGRAD, LookupTable, MeepoError
+    dim, steps, batch = 32, 5, 3000
+    rng = np.random.default_rng(4)
+    pool = synth.keys_np(71, 0, 5000)
+    tabs = [LookupTable(16384, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=4096, initial_accumulator=0.1, initializer=1, init_scale=0.05, init_seed=9)
+            for _ in range(2)]
+    layers = [DynamicEmbedding(t, optimizer="adagrad", lr=0.05).to(dev) for t in tabs]
+    layers[1].fuse_backward_partition = False
+    head = torch.randn(dim, 1, device=dev) * 0.1
+    for s in range(steps):
+        idx = np.minimum(rng.zipf(1.3, size=batch) - 1, pool.size - 1) if s % 2 else rng.integers(0, 1000 * (s + 1), batch)   # new ids every step
+        k = torch.from_numpy(pool[idx]).to(dev).view(batch // 4, 4)
+        for layer in layers:
+            ((layer(k).sum(1) @ head) ** 2).mean().backward()
+        assert getattr(tabs[0], "_nn_prepared", None) is None   # the backward consumed the forward's partition
+    ea, eb = tabs[0].export(with_state=True), tabs[1].export(with_state=True)
+    ia, ib = torch.argsort(ea[0]), torch.argsort(eb[0])
+    assert torch.equal(ea[0][ia], eb[0][ib]) and tabs[0].status() == tabs[1].status() == 0
+    for xa, xb in zip(ea[1:], eb[1:]):
+        if xa is not None:
+            torch.testing.assert_close(xa[ia], xb[ib], rtol=1e-6, atol=1e-9)
+    # a forward without a backward leaves a partition behind: mutators are refused until it is dropped — the next forward drops it itself
+    t, layer = tabs[0], layers[0]
+    k = torch.from_numpy(pool[:64]).to(dev)
+    out = layer(k)
+    assert t._nn_prepared is not None
+    with pytest.raises(MeepoError):
+        t.insert(k, torch.zeros(64, dim, device=dev))
+    out2 = layer(k)   # drops the stale partition, makes its own
+    (out2.sum()).backward()
+    assert t._nn_prepared is None
+    t.insert(k, torch.zeros(64, dim, device=dev))   # accepted again
+    # two layers over ONE table: the second forward drops the first one's partition; both backwards still apply (each on its own keys)
+    other = DynamicEmbedding(t, optimizer="adagrad", lr=0.05).to(dev)
+    before, _ = t.find(k)
+    la, lb = layer(k[:32]), other(k[32:])
+    (la.sum() + lb.sum()).backward()
+    after, _ = t.find(k)
+    assert bool(((after - before).abs().sum(1) > 0).all()) and t.status() == 0
