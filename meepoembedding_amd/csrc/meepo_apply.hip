@@ -28,7 +28,10 @@
 
 namespace mee {
 
-constexpr int kPartThreads = 1024;
+#ifndef MEE_PT
+#define MEE_PT 1024
+#endif
+constexpr int kPartThreads = MEE_PT;
 constexpr int kApplyThreads = 512;
 constexpr int kApplyWaves = kApplyThreads / 64;
 constexpr uint32_t kLdsSlots = 2 * kSlab;

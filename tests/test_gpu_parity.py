@@ -1483,10 +1483,12 @@ def test_group_and_pooled_ops_are_graph_capturable(dev):
         np.testing.assert_allclose(ex[2][ix].cpu().numpy(), ey[2][iy].cpu().numpy(), rtol=RTOL, atol=ATOL)
 
 
-def test_train_step_is_graph_capturable(dev):
-    """One table's training step — find_or_insert_located + the located apply, on a batch with duplicate groups of every kind
-    (inline, filed, big) — captured in a hipGraph and replayed: the apply's scratch (mark maps, group table, counters) must be left
-    clean by every replay, whatever batch number the capture froze into the kernel arguments.  Compared with an eager twin."""
+@pytest.mark.parametrize("fused", [False, True], ids=["separate", "forward_carries_partition"])
+def test_train_step_is_graph_capturable(dev, fused):
+    """One table's training step — find_or_insert_located (fused: its launch also carries the apply's partition) + the located apply, on a
+    batch with duplicate groups of every kind (runs of 3 / 20 / 100 / 900: chunks, partial rows, a split bucket) — captured in a hipGraph and
+    replayed: the apply's scratch (bucket totals and their two copies, tickets, pending counters) must be left clean by every replay, whatever
+    state the capture froze into the kernel arguments.  Compared with an eager twin."""
     rng = np.random.default_rng(5)
     dim, n_keys = 64, 3000
     keys = synth.keys_np(150, 0, n_keys)
@@ -1506,7 +1508,7 @@ def test_train_step_is_graph_capturable(dev):
     oa, fa, sa = bufs(); ob, fb, sb = bufs()
 
     def step(t, o, f, s_):
-        t.find_or_insert_located(kb, out=o, found=f, slots=s_)
+        t.find_or_insert_located(kb, out=o, found=f, slots=s_, prepare_apply=fused)
         t.apply_adagrad(kb, g, lr=0.05, slots=s_)
 
     torch.cuda.synchronize()
