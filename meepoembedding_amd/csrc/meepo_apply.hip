@@ -6,15 +6,15 @@
 // The group-table apply (meepo_table.hip) pays, per key of a batch, one scattered atomic to claim an entry of a global table, one scattered
 // read of that entry in the main pass and one scattered store to release it — ~30 us of a 256K-key batch that has (almost) no duplicates —
 // plus three dependent launches for the duplicates.  Here the batch is first PARTITIONED by the top bits of mix64(key) into buckets of
-// 128..256 positions (two small kernels, LDS histograms, no global atomics), and then ONE kernel gives every bucket to one 512-thread
+// 128..352 positions (one small kernel, LDS histograms, no per-key global atomic), and then ONE kernel gives every bucket to one 512-thread
 // block: all occurrences of a key are in the same bucket, so the block finds the batch's duplicates in an LDS hash table, sorts the
 // bucket's positions by key with LDS prefix sums, and its 32 tiles update each distinct key once — a key that occurs once straight from
 // its gradient row (bit-exact), a key that occurs c times from the fp64 sum of its c rows (runs of more than 32 are cut into chunks
-// whose fp64 partial rows the block combines itself).  Three launches per apply whatever the key distribution, no per-key global atomic,
-// nothing to clean up afterwards.
+// whose fp64 partial rows the block combines itself).  Two launches per apply whatever the key distribution (one behind the training
+// forward, whose launch carries the partition), no per-key global atomic, nothing to clean up afterwards.
 //
 // A bucket that a hot key makes larger than one block's LDS (512 positions) is SPLIT: its slabs of 512 positions go to blocks of their
-// own (listed first, so they start first), each slab emits one pending record per distinct key (key + fp64 partial sum), and the slab
+// own (the spare blocks at the head of the grid, so they start first), each slab emits one pending record per distinct key (key + fp64 partial sum), and the slab
 // that finishes last — an agent-scope release / ticket / acquire hand-off, no block ever waits for another — merges the bucket's records
 // with the same LDS machinery and applies the updates.  A key with 21 000 occurrences in a 256K-key batch (Zipf 1.05) is summed by 41
 // blocks on 41 CUs, not by one.
@@ -22,7 +22,6 @@
 // Bucket = top bits of mix64(key) = the bits that pick the key's table bucket (mulhi64): a block's keys live in one contiguous 1/n_buckets
 // slice of the table.
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 
 #include "meepo_apply_part.h"
 
@@ -413,14 +412,14 @@ __device__ __forceinline__ void seg_scan(ApplyLds& L, const SegRuns& r, uint32_t
     L.seg_at[k0 + 1] = r.at1;
 }
 
-// The two kernels of an apply.  bkt_apply_kernel: one block per bucket, for the buckets that fit one slab — all of them on a batch without
-// hot keys.  bkt_split_kernel: the slabs of the buckets that do not, and their merges.  They are launched back to back and run side by
-// side (the second launch is not ordered behind the first, see bucket_apply_launch): the split kernel's blocks — few, long chains: slab,
-// hand-off, merge — are dispatched first.  (As ONE kernel, spare blocks in front of the bucket blocks, the rare path set the register
-// budget of every block — 80 VGPRs with spills instead of 64 — and a thousand spare blocks that only looked at one word stood in front of
-// every uniform batch: 97 us instead of 113 us for an apply alone once they were cut to 128.)
-//
-// MEE_APPLY_WAVES (meepo_apply_part.h): waves per SIMD the register allocator must leave room for in the bucket kernel.
+// The two roles of the apply kernel.  bucket_role: one block per bucket, for the buckets that fit one slab — all of them on a batch without
+// hot keys.  split_role: the slabs of the buckets that do not, and their merges — few blocks with long chains (slab, hand-off, merge), so
+// they lead the grid.  They are separate code paths of ONE kernel, each with its own instance of process_slab: the bucket role's needs 64
+// VGPRs, the split role's 107 — one shared instance (emit / src_rec as run-time flags inside a loop) kept the rare path's state live in every
+// block's hot path.  The kernel is bounded to 80 VGPRs (MEE_APPLY_WAVES = 6, meepo_apply_part.h: three 512-thread blocks per CU); what does
+// not fit spills in the split role only (24-56 B per lane).  Tried instead: two kernels, the second launched with hipExtAnyOrderLaunch so
+// that they share the device — the flag is not supported on gfx9, the launches serialise (Zipf(1.05): 48 + 39 us against 79 us); the split
+// role as a __noinline__ function — a kernel's register allocation covers its callees (400-500 B of stack per lane).
 template <int KIND, int DIM4, bool LOCATED>
 __device__ __forceinline__ void bucket_role(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t b) {
     // ONE round trip brings everything the block must know before it can fetch its entries: which copy of the totals this batch's partition
