@@ -528,6 +528,40 @@ def test_bucketed_apply_extremes(dev, case, opt):
     np.testing.assert_allclose(got.cpu().numpy(), exp, rtol=RTOL, atol=ATOL)
 
 
+def test_apply_beyond_the_bucketed_limit(dev):
+    """A batch larger than the bucketed apply takes (8192 buckets x 352 positions = 2.7M keys) goes through the group-table apply, also behind
+    the training forward (mee_find_located_prepare then prepares THAT path); same results as the oracle, and the next small batch is back
+    on the bucketed path with clean scratch."""
+    dim, n_keys, n = 4, 400_000, 2_900_000
+    keys = synth.keys_np(171, 0, n_keys); rows = synth.rows_np(keys, dim, 2)
+    rng = np.random.default_rng(8)
+    bk = keys[rng.integers(0, n_keys, n)]           # ~7 occurrences per key
+    bk[:50_000] = keys[3]                            # and one hot key
+    bk[rng.integers(0, n, 100)] = synth.keys_np(172, 0, 100)   # absent
+    t = LookupTable(1 << 20, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=3_000_000, initial_accumulator=0.1)
+    o = oracle.OracleTable(1 << 20, dim, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
+    t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
+    bkt = T(bk, dev)
+    for s in range(2):
+        g = (rng.standard_normal((n, dim)) * 0.01).astype(np.float32)
+        if s == 0:
+            t.apply_adagrad(bkt, T(g, dev), lr=0.05)
+        else:
+            _, _, slots = t.find_located(bkt, prepare_apply=True)
+            t.apply_adagrad(bkt, T(g, dev), lr=0.05, slots=slots)
+        o.apply_adagrad(bk, g, 0.05, 1e-10)
+    g1 = (rng.standard_normal((5000, dim)) * 0.01).astype(np.float32)
+    t.apply_adagrad(T(keys[:5000], dev), T(g1, dev), lr=0.05); o.apply_adagrad(keys[:5000], g1, 0.05, 1e-10)
+    assert t.status() == 0
+    e = [x.cpu().numpy() if x is not None else None for x in t.export(with_state=True)]
+    eo = o.export(with_state=True)
+    it, io = np.argsort(e[0]), np.argsort(eo[0])
+    assert np.array_equal(e[0][it], eo[0][io])
+    for x, z in zip(e[1:], eo[1:]):
+        if z is not None:
+            np.testing.assert_allclose(x[it], z[io], rtol=RTOL, atol=ATOL)
+
+
 @pytest.mark.parametrize("dim", [64, 24])
 def test_find_or_insert_located(dev, dim):
     """find_or_insert_located == find_or_insert (rows, found, table contents) and its handles are the slots mee_locate reports
