@@ -224,6 +224,9 @@ int mee_probe_length(const mee_table* t, const int64_t* d_keys, size_t n, uint64
 typedef struct mee_group mee_group;
 int mee_group_create(mee_table* const* tables, uint32_t n_tables, uint64_t max_apply_batch, mee_group** out);
 int mee_group_destroy(mee_group* g);
+/* mee_set_tuning for the group's own apply ("apply_path", "apply_bucket_max", "apply_spare_blocks": as for a table; groups created with
+ * max_apply_batch = 0 have nothing to tune: MEE_ERR_UNSUPPORTED). */
+int mee_group_set_tuning(mee_group* g, const char* name, int value);
 int mee_find_grouped(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found,
                      void* stream);
 /* mee_find_or_insert over the jagged layout (three launches): absent keys are created in their member table with that

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "mee_group_apply_adagrad": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _vp]),
     "mee_group_apply_adam": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
     "mee_group_destroy": (C.c_int, [_vp]),
+    "mee_group_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mee_find_grouped": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_find_pooled": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _vp, _vp, C.c_int, _vp]),
     "mee_apply_adagrad_indexed": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _sz, _f32, _f32, _vp]),

@@ -74,8 +74,25 @@ struct ApplyArgs {
     uint32_t nbk, part_blocks, per_block;   // the partition: buckets, partition blocks, batch positions per partition block
     uint32_t n_extra;                       // spare blocks at the head of the grid
     OpCounters* op;
+    const GroupDesc* desc; uint32_t n_tables;   // GROUPED kernels (mee_group_apply_*): the members' planes; a "slot" is member << 48 | slot
     OptArgs a;
 };
+
+// Where a finished run's row lives.  Plain tables: the table's planes, `slot` as it is.  GROUPED (the apply of a table group: the batch "keys"
+// are located rows already, member << 48 | slot, and serve as slot handles too): the member's planes — its descriptor comes out of LDS when the
+// group is small enough to be staged there (gdesc != nullptr), else from device memory — and the low 48 bits.
+struct RowAt { float4 *values, *s1, *s2; uint64_t row; };
+template <bool GROUPED>
+__device__ __forceinline__ RowAt row_at(const ApplyArgs& A, const GroupDesc* gdesc, int64_t slot, bool upd) {
+    RowAt r{A.values, A.s1, A.s2, upd ? (uint64_t)slot : 0ull};
+    if constexpr (GROUPED) {
+        const uint64_t member = upd ? (uint64_t)slot >> kGroupSlotBits : 0ull;
+        const GroupDesc& d = gdesc ? gdesc[member] : A.desc[member];
+        r.values = d.values; r.s1 = d.s1; r.s2 = d.s2;
+        r.row = upd ? (uint64_t)slot & ((1ull << kGroupSlotBits) - 1) : 0ull;
+    }
+    return r;
+}
 
 // One slab: m <= kSlab sources -> one update (or one pending record) per distinct key.
 //   src_rec = false: the sources are entries [first, first + m) of bucket b (batch positions + keys, pulled out of the partition blocks' slices
@@ -85,9 +102,10 @@ struct ApplyArgs {
 //   emit: results become pending records of bucket `b` instead of table updates (slab of a split bucket).
 // ONE inlined instance per kernel (the kernel loops over it: slab first, merge passes after): as two instances the merge copy pushed the
 // kernel from 64 to 113 VGPRs, i.e. the hot path of every block from 4 to 2 resident blocks per CU (-10 us per 256K-key batch).
-template <int KIND, int DIM4, bool LOCATED, bool SPLIT /* false: emit and src_rec are known to be false (the kernel of the whole buckets) */>
+template <int KIND, int DIM4, bool LOCATED, bool SPLIT /* false: emit and src_rec are known to be false (the kernel of the whole buckets) */, bool GROUPED = false>
 __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, uint32_t first, uint32_t m, bool emit_rt, bool src_rec_rt,
-                                             uint32_t b, uint32_t rec_bucket0 /* split buckets: the bucket's first pending record */) {
+                                             uint32_t b, uint32_t rec_bucket0 /* split buckets: the bucket's first pending record */, const GroupDesc* gdesc = nullptr) {
+    static_assert(!GROUPED || LOCATED, "a group's batch names rows, not keys");
     const bool emit = SPLIT && emit_rt, src_rec = SPLIT && src_rec_rt;
     // The kernel calls this from a loop (slab, then merge passes).  The thread index is re-read through an empty asm in every call so that
     // nothing derived from it looks loop-invariant: hoisted out of that loop, the per-thread address arithmetic of every array touched in
@@ -178,6 +196,7 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
         if constexpr (LOCATED) {
             if (my_first) {   // every occurrence of a key names the same slot: the run keeps one
                 if (src_rec) L.slot[my_slot] = my_tslot;
+                else if constexpr (GROUPED) L.slot[my_slot] = my_tslot >= 0 && ((uint64_t)my_tslot >> kGroupSlotBits) < A.n_tables ? my_tslot : -1;
                 else {
                     bool stale;
                     L.slot[my_slot] = handle_slot(my_tslot, A.handle_tag, A.capacity, stale);
@@ -214,16 +233,17 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
         }
         if (!valid) continue;
         const bool upd = fin && slot >= 0;
+        const RowAt at = row_at<GROUPED>(A, gdesc, slot, upd);
         for (uint32_t col = tl; col < dim4; col += 16) {
-            const uint64_t o = upd ? (uint64_t)slot * dim4 + col : 0;
+            const uint64_t o = at.row * dim4 + col;
             if (single) {   // gradient row (already requested) + the key's row -> update -> store; nothing else is live here
                 if (upd) {
-                    float4 w = A.values[o], x1 = A.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (KIND == MEE_OPT_ADAM) x2 = A.s2[o];
+                    float4 w = at.values[o], x1 = at.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
                     const float4 g = col == (uint32_t)tl ? make_float4(gpre.x, gpre.y, gpre.z, gpre.w) : A.grads[(uint64_t)src0 * dim4 + col];
                     opt_update4(a, w, x1, x2, g);
-                    A.values[o] = w; A.s1[o] = x1;
-                    if (KIND == MEE_OPT_ADAM) A.s2[o] = x2;
+                    at.values[o] = w; at.s1[o] = x1;
+                    if (KIND == MEE_OPT_ADAM) at.s2[o] = x2;
                 }
                 continue;
             }
@@ -256,11 +276,11 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
             }
             if (fin) {
                 if (upd) {
-                    float4 w = A.values[o], x1 = A.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (KIND == MEE_OPT_ADAM) x2 = A.s2[o];
+                    float4 w = at.values[o], x1 = at.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
                     opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
-                    A.values[o] = w; A.s1[o] = x1;
-                    if (KIND == MEE_OPT_ADAM) A.s2[o] = x2;
+                    at.values[o] = w; at.s1[o] = x1;
+                    if (KIND == MEE_OPT_ADAM) at.s2[o] = x2;
                 }
             } else {   // a chunk of a long run -> one fp64 partial row of this block | a whole run of a split bucket's slab -> its pending record
                 double2* dst = whole ? reinterpret_cast<double2*>(bk.pend_row + ((uint64_t)(rec_out0 + L.run[s]) * dim4 + col) * 4)
@@ -291,8 +311,9 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
         }
         if (!valid) continue;
         const bool upd = fin && slot >= 0;
+        const RowAt at = row_at<GROUPED>(A, gdesc, slot, upd);
         for (uint32_t col = tl; col < dim4; col += 16) {
-            const uint64_t o = upd ? (uint64_t)slot * dim4 + col : 0;
+            const uint64_t o = at.row * dim4 + col;
             double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
             for (uint32_t q0 = 0; q0 < np; q0 += 2) {
                 double2 lo[2], hi[2];
@@ -309,11 +330,11 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
             }
             if (fin) {
                 if (upd) {
-                    float4 w = A.values[o], x1 = A.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (KIND == MEE_OPT_ADAM) x2 = A.s2[o];
+                    float4 w = at.values[o], x1 = at.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
                     opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
-                    A.values[o] = w; A.s1[o] = x1;
-                    if (KIND == MEE_OPT_ADAM) A.s2[o] = x2;
+                    at.values[o] = w; at.s1[o] = x1;
+                    if (KIND == MEE_OPT_ADAM) at.s2[o] = x2;
                 }
             } else {
                 double2* dst = reinterpret_cast<double2*>(bk.pend_row + ((uint64_t)(rec_out0 + L.run[s]) * dim4 + col) * 4);
@@ -330,8 +351,9 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
 // Merge, one key with more records than a pass holds (a key that is a large share of a large batch: more than kSlab slabs each hold it): every
 // tile adds the records j = its number, +32, +64, … of bucket records [beg, beg + R) that carry `key` into one fp64 partial row, the rows are
 // combined after a barrier, the key is updated once.
-template <int KIND, int DIM4, bool LOCATED>
-__device__ __forceinline__ void mono_pass(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, uint32_t beg, uint32_t R, int64_t key, uint32_t any_rec) {
+template <int KIND, int DIM4, bool LOCATED, bool GROUPED = false>
+__device__ __forceinline__ void mono_pass(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, uint32_t beg, uint32_t R, int64_t key, uint32_t any_rec,
+                                          const GroupDesc* gdesc = nullptr) {
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15, wv = threadIdx.x >> 6;
     const uint32_t dim4 = DIM4 ? DIM4 : A.dim4, q = (uint32_t)wv * 4 + tile;
     constexpr uint32_t kTiles = kApplyWaves * 4;
@@ -369,7 +391,8 @@ __device__ __forceinline__ void mono_pass(ApplyLds& L, const ApplyArgs& A, const
         bool is_new, full;
         slot = tile_locate<false, false>(const_cast<int64_t*>(A.tkeys), A.nb, key, q == 0, tile, tl, is_new, full);
     }
-    if (q == 0 && slot >= 0)
+    if (q == 0 && slot >= 0) {
+        const RowAt at = row_at<GROUPED>(A, gdesc, slot, true);
         for (uint32_t col = tl; col < dim4; col += 16) {
             double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
 #pragma unroll 2   // (fully unrolled, the 32 rows' loads held 128 VGPRs: this rare path must not set the kernel's register count)
@@ -377,13 +400,14 @@ __device__ __forceinline__ void mono_pass(ApplyLds& L, const ApplyArgs& A, const
                 const double2* r = reinterpret_cast<const double2*>(A.part + ((uint64_t)(L.part_base + u) * dim4 + col) * 4);
                 sx += r[0].x; sy += r[0].y; sz += r[1].x; sw += r[1].y;
             }
-            const uint64_t o = (uint64_t)slot * dim4 + col;
-            float4 w = A.values[o], x1 = A.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (KIND == MEE_OPT_ADAM) x2 = A.s2[o];
+            const uint64_t o = at.row * dim4 + col;
+            float4 w = at.values[o], x1 = at.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
             opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
-            A.values[o] = w; A.s1[o] = x1;
-            if (KIND == MEE_OPT_ADAM) A.s2[o] = x2;
+            at.values[o] = w; at.s1[o] = x1;
+            if (KIND == MEE_OPT_ADAM) at.s2[o] = x2;
         }
+    }
     __syncthreads();
 }
 
@@ -420,8 +444,8 @@ __device__ __forceinline__ void seg_scan(ApplyLds& L, const SegRuns& r, uint32_t
 // not fit spills in the split role only (24-56 B per lane).  Tried instead: two kernels, the second launched with hipExtAnyOrderLaunch so
 // that they share the device — the flag is not supported on gfx9, the launches serialise (Zipf(1.05): 48 + 39 us against 79 us); the split
 // role as a __noinline__ function — a kernel's register allocation covers its callees (400-500 B of stack per lane).
-template <int KIND, int DIM4, bool LOCATED>
-__device__ __forceinline__ void bucket_role(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t b) {
+template <int KIND, int DIM4, bool LOCATED, bool GROUPED>
+__device__ __forceinline__ void bucket_role(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t b, const GroupDesc* gdesc) {
     // ONE round trip brings everything the block must know before it can fetch its entries: which copy of the totals this batch's partition
     // filled (bk.seq[1], meepo_apply_part.h), the bucket's total in BOTH copies, and — lanes of wave 0 — the lengths and places of the bucket's
     // runs in the partition blocks' slices.  (As a chain seq -> total -> run lengths these were three dependent loads, 2-3 us of every block's
@@ -433,11 +457,11 @@ __device__ __forceinline__ void bucket_role(ApplyLds& L, const ApplyArgs& A, con
     const uint32_t size = __builtin_amdgcn_readfirstlane(parity ? tot1 : tot0);
     if (size == 0 || size > kSlab) return;   // an empty bucket | a split bucket: bkt_split_kernel has it
     seg_scan(L, runs, threadIdx.x);
-    process_slab<KIND, DIM4, LOCATED, false>(L, A, bk, 0, size, false, false, b, 0);
+    process_slab<KIND, DIM4, LOCATED, false, GROUPED>(L, A, bk, 0, size, false, false, b, 0, gdesc);
 }
 
-template <int KIND, int DIM4, bool LOCATED>
-__device__ __forceinline__ void split_role(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t e0, const uint32_t stride) {
+template <int KIND, int DIM4, bool LOCATED, bool GROUPED>
+__device__ __forceinline__ void split_role(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t e0, const uint32_t stride, const GroupDesc* gdesc) {
     // Block e takes slabs e, e + stride, … of the buckets that hold more than one slab (a hot key), found by a prefix sum over the bucket
     // totals — and leaves at once when the partition saw no such bucket.
     const uint32_t hs0 = bk.has_split[0], hs1 = bk.has_split[1];
@@ -491,7 +515,7 @@ __device__ __forceinline__ void split_role(ApplyLds& L, const ApplyArgs& A, cons
         uint64_t v0 = 0;
         bool done = false;
         while (!done) {
-            process_slab<KIND, DIM4, LOCATED, true>(L, A, bk, first, m, !merging, merging, b, beg);
+            process_slab<KIND, DIM4, LOCATED, true, GROUPED>(L, A, bk, first, m, !merging, merging, b, beg, gdesc);
             if (!merging) {
                 // ---- publish this slab's pending records, take a ticket; the slab that draws the last ticket merges the bucket.  (The in-launch
                 // hand-off of cdna_hip_programming.md Guideline 16 in its counter form: plain stores, every wave drains them, one lane releases at
@@ -553,7 +577,7 @@ __device__ __forceinline__ void split_role(ApplyLds& L, const ApplyArgs& A, cons
                 const uint32_t nc = __builtin_amdgcn_readfirstlane(L.n_cand);
                 if (nc > kSlab) {
                     if (L.kmin == L.kmax) {   // more records of ONE key than a pass holds
-                        mono_pass<KIND, DIM4, LOCATED>(L, A, bk, beg, R, (int64_t)(L.kmin ^ kBias), L.src[0]);
+                        mono_pass<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, beg, R, (int64_t)(L.kmin ^ kBias), L.src[0], gdesc);
                     } else if (threadIdx.x == 0 && bits < 64 && L.stk_n + 2 <= 72) {
                         L.stk_bits[L.stk_n] = bits + 1; L.stk_val[L.stk_n] = val; ++L.stk_n;
                         L.stk_bits[L.stk_n] = bits + 1; L.stk_val[L.stk_n] = val | 1ull << bits; ++L.stk_n;
@@ -564,11 +588,20 @@ __device__ __forceinline__ void split_role(ApplyLds& L, const ApplyArgs& A, cons
     }   // next slab of this block
 }
 
-template <int KIND, int DIM4, bool LOCATED>
+constexpr uint32_t kGroupDescLds = 64;   // members whose descriptors a GROUPED kernel stages in LDS (3 KB): larger groups read them from device memory
+template <int KIND, int DIM4, bool LOCATED, bool GROUPED = false>
 __global__ __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES) void bkt_apply_kernel(ApplyArgs A, BucketScratch bk) {
     __shared__ ApplyLds L;
-    if (blockIdx.x < A.n_extra) split_role<KIND, DIM4, LOCATED>(L, A, bk, blockIdx.x, A.n_extra);   // block-uniform
-    else bucket_role<KIND, DIM4, LOCATED>(L, A, bk, blockIdx.x - A.n_extra);
+    const GroupDesc* gdesc = nullptr;
+    if constexpr (GROUPED) {   // the members' planes: needed once per work item, so they come out of LDS (the first barrier inside the roles publishes them)
+        __shared__ GroupDesc gd[kGroupDescLds];
+        if (A.n_tables <= kGroupDescLds) {
+            for (uint32_t j = threadIdx.x; j < A.n_tables; j += kApplyThreads) gd[j] = A.desc[j];
+            gdesc = gd;
+        }
+    }
+    if (blockIdx.x < A.n_extra) split_role<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, blockIdx.x, A.n_extra, gdesc);   // block-uniform
+    else bucket_role<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, blockIdx.x - A.n_extra, gdesc);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
@@ -624,12 +657,14 @@ int bucket_apply_discard(mee_table* t, hipStream_t st) {
     return MEE_OK;
 }
 
-int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const OptArgs& a, const uint32_t* d_gidx, const int64_t* d_slots, hipStream_t st) {
+int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const OptArgs& a, const uint32_t* d_gidx, const int64_t* d_slots, hipStream_t st,
+                        const GroupDesc* d_desc, uint32_t n_tables) {
     ApplyArgs A{};
     A.tkeys = t->keys; A.values = (float4*)t->values; A.s1 = (float4*)t->s1; A.s2 = (float4*)t->s2; A.nb = t->nb; A.dim4 = t->dim4;
     A.grads = (const float4*)d_grads; A.gidx = d_gidx; A.slots = d_slots;
     A.capacity = t->capacity; A.handle_tag = (int64_t)(t->handle_epoch & kHandleEpochMask) << kHandleSlotBits; A.status = &t->ctr->status;
     A.part = t->bs.gacc; A.max_part = t->bs.max_part; A.op = t->op; A.a = a;
+    A.desc = d_desc; A.n_tables = n_tables;   // a table group's apply (d_slots = the batch's located rows = its keys; t = the group's scratch table)
     A.nbk = bucket_count_for(t, n);
     A.part_blocks = t->part_blocks; A.per_block = t->part_per_block;   // as whoever partitioned this batch left them
     // blocks [0, n_extra): the slabs of split buckets (few blocks, long chains: slab, hand-off, merge — so they lead the grid), one per CU unless
@@ -638,7 +673,7 @@ int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const Op
     const uint32_t spare = t->bk.spare_blocks ? t->bk.spare_blocks : t->bk.slots / kApplyBlocksPerCU;
     A.n_extra = max_extra_slabs(n) < spare ? max_extra_slabs(n) : spare;
 #define BKT(K, D4, LOC) bkt_apply_kernel<K, D4, LOC><<<A.n_extra + A.nbk, kApplyThreads, 0, st>>>(A, t->bk)
-#define BKT_L(K, D4) do { if (d_slots) BKT(K, D4, true); else BKT(K, D4, false); } while (0)
+#define BKT_L(K, D4) do { if (d_desc) bkt_apply_kernel<K, D4, true, true><<<A.n_extra + A.nbk, kApplyThreads, 0, st>>>(A, t->bk); else if (d_slots) BKT(K, D4, true); else BKT(K, D4, false); } while (0)
 #define BKT_D(K) do { if (t->dim4 == 16) BKT_L(K, 16); else if (t->dim4 == 32) BKT_L(K, 32); else BKT_L(K, 0); } while (0)
     if (a.kind == MEE_OPT_ADAGRAD) BKT_D(MEE_OPT_ADAGRAD); else BKT_D(MEE_OPT_ADAM);
 #undef BKT_D

@@ -264,6 +264,12 @@ int mee_group_create(mee_table* const* tables, uint32_t n_tables, uint64_t max_a
     return MEE_OK;
 }
 
+int mee_group_set_tuning(mee_group* g, const char* name, int value) {
+    if (!g || !name) return fail(MEE_ERR_INVALID_ARG, "mee_group_set_tuning: null argument");
+    if (!g->scratch) return fail(MEE_ERR_UNSUPPORTED, "mee_group_set_tuning: the group has no apply of its own (max_apply_batch = 0 or tables without optimizer)");
+    return mee_set_tuning(g->scratch, name, value);
+}
+
 int mee_group_destroy(mee_group* g) {
     if (!g) return MEE_OK;
     DeviceGuard guard(g->device);

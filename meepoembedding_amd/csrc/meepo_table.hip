@@ -2529,6 +2529,13 @@ static int group_apply_common(mee_group* g, const int64_t* d_keys, const uint64_
         if (int rc = group_locate(g, d_keys, d_offsets, off_stride, n, g->d_gslot, st)) return rc;
         gslot = g->d_gslot;
     }
+    // the located rows are perfect keys (member << 48 | slot; absent positions EMPTY): the bucketed apply takes them as the batch's keys AND as
+    // its slot handles — partition, then one dedup + update kernel whose work items fetch their member's planes from the descriptors (r1-r2: a
+    // plan pass over a group table + three kernels; 5 launches, 26 tables x 8192 keys 158 us)
+    if (use_bucketed_apply(t, n) && !t->prepared_n) {
+        if (int rc = bucket_apply_prepare(t, gslot, nn, st)) return rc;
+        return bucket_apply_launch(t, d_grads, nn, a, d_gidx, gslot, st, g->d_desc, g->n_tables);
+    }
     if (int rc = apply_prepare_launch(t, gslot, nn, st)) return rc;
     const unsigned gs = grid_for(n, 32, 1u << 16);
 #define GSINGLE(K, D4) apply_single_kernel<K, D4, 2, true><<<gs, 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, gslot, (const float4*)d_grads, nn, t->g, t->bs, a, g->d_desc, d_gidx)

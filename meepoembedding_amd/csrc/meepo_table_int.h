@@ -160,7 +160,8 @@ int bucket_scratch_alloc(mee_table* t);
 void bucket_scratch_free(mee_table* t);
 int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st);
 int bucket_apply_discard(mee_table* t, hipStream_t st);
-int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const OptArgs& a, const uint32_t* d_gidx, const int64_t* d_slots, hipStream_t st);
+int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const OptArgs& a, const uint32_t* d_gidx, const int64_t* d_slots, hipStream_t st,
+                        const GroupDesc* d_desc = nullptr, uint32_t n_tables = 0);
 uint32_t bucket_count_for(const mee_table* t, uint64_t n);
 
 }  // namespace mee

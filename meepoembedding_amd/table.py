@@ -517,6 +517,10 @@ class TableGroup:
         except Exception:
             pass
 
+    def set_tuning(self, name: str, value: int) -> None:
+        """Performance knobs of the group's own apply ("apply_path" 0 = group-table apply, -1 / 1 = bucketed apply, …); never change results."""
+        check(_lib.lib().mee_group_set_tuning(self._h, name.encode(), int(value)))
+
     def _check_offsets(self, offsets: torch.Tensor) -> None:
         if offsets.device != self.device or offsets.dtype not in (torch.int64, torch.uint64) or offsets.numel() != len(self.tables) + 1 \
                 or not offsets.is_contiguous():

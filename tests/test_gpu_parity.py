@@ -1178,8 +1178,9 @@ def test_grouped_find_equals_per_table_find(dev, dim):
     grp.close()
 
 
+@pytest.mark.parametrize("apply_path", [-1, 0], ids=["bucketed", "group_table"])
 @pytest.mark.parametrize("opt,dim", [("adagrad", 64), ("adam", 128), ("adagrad", 24)])
-def test_grouped_apply_equals_per_table_apply(dev, opt, dim):
+def test_grouped_apply_equals_per_table_apply(dev, opt, dim, apply_path):
     """mee_group_apply_*: one optimizer step over the jagged batch of a group == apply per table == the oracle, with
     duplicate-heavy segments (hot keys beyond the chunk and big-group thresholds), absent and reserved keys, the SAME key
     value stored in several tables, and empty segments."""
@@ -1200,6 +1201,7 @@ def test_grouped_apply_equals_per_table_apply(dev, opt, dim):
         a.insert(T(u, dev), T(rows, dev)); b.insert(T(u, dev), T(rows, dev)); o.insert(u, rows)
         grouped.append(a); solo.append(b); oracles.append(o); universes.append(u)
     grp = TableGroup(grouped, max_apply_batch=1 << 15)
+    grp.set_tuning("apply_path", apply_path)
     for step in range(1, 4):
         segs = []
         for j in range(n_tables):
@@ -1374,8 +1376,9 @@ def test_indexed_apply_is_apply_of_gathered_grads(dev, opt):
             np.testing.assert_allclose(x.cpu()[ia].numpy(), z[io], rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("apply_path", [-1, 0], ids=["bucketed", "group_table"])
 @pytest.mark.parametrize("dim,mode,opt", [(64, "sum", "adagrad"), (128, "mean", "adam"), (24, "sum", "adagrad")])
-def test_group_pooled_equals_per_table_pooled(dev, dim, mode, opt):
+def test_group_pooled_equals_per_table_pooled(dev, dim, mode, opt, apply_path):
     """The embedding-bag collection: mee_group_find_pooled == find_pooled per member (bit-exact), and its backward
     (mee_group_apply_*_pooled) == apply_*_indexed per member == the oracle."""
     from meepoembedding_amd import TableGroup
@@ -1394,6 +1397,7 @@ def test_group_pooled_equals_per_table_pooled(dev, dim, mode, opt):
         x.insert(T(u, dev), T(rows, dev)); y.insert(T(u, dev), T(rows, dev)); z.insert(u, rows)
         a.append(x); b.append(y); o.append(z); univ.append(u)
     grp = TableGroup(a, max_apply_batch=1 << 14)
+    grp.set_tuning("apply_path", apply_path)
     for step, long_bags in ((1, False), (2, True)):          # both launch shapes of the pooled kernel
         lens = rng.integers(8, 40, n_tables * bpt) if long_bags else rng.integers(0, 7, n_tables * bpt)
         lens[3] = 0; lens[bpt] = 25
@@ -1584,6 +1588,7 @@ def test_random_group_sequences(dev, seed):
         orcs.append(oracle.OracleTable(1 << 14, dim, optimizer=okind, **kw))
         univ.append(synth.keys_np(7000 + seed * 10 + j, 0, 400))
     grp = TableGroup(tabs, max_apply_batch=1 << 14)
+    grp.set_tuning("apply_path", 0 if seed % 4 == 3 else -1)   # every fourth seed: the group-table apply (the fallback for huge batches)
     step = 0
 
     def batch(pooled):
