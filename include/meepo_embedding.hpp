@@ -141,6 +141,7 @@ public:
     void find(const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found, void* stream = nullptr) {
         check(mee_find_grouped(g_, d_keys, d_offsets, n, d_out, d_found, stream));
     }
+    void set_tuning(const char* name, int value) { check(mee_group_set_tuning(g_, name, value)); }   // knobs of the group's own apply; never change results
     void apply_adagrad(const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr, float eps = 1e-10f, void* stream = nullptr) {
         check(mee_group_apply_adagrad(g_, d_keys, d_offsets, d_grads, n, lr, eps, stream));
     }
