@@ -455,7 +455,7 @@ __device__ __forceinline__ void bucket_role(ApplyLds& L, const ApplyArgs& A, con
     const uint32_t parity = bk.seq[1];
     if (b == 0 && threadIdx.x == 0) atomicAdd(&bk.seq[0], 1u);   // this partition is consumed: the next one fills the other copy
     const uint32_t size = __builtin_amdgcn_readfirstlane(parity ? tot1 : tot0);
-    if (size == 0 || size > kSlab) return;   // an empty bucket | a split bucket: bkt_split_kernel has it
+    if (size == 0 || size > kSlab) return;   // an empty bucket | a split bucket: the spare blocks (split_role) have it
     seg_scan(L, runs, threadIdx.x);
     process_slab<KIND, DIM4, LOCATED, false, GROUPED>(L, A, bk, 0, size, false, false, b, 0, gdesc);
 }
