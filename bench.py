@@ -665,7 +665,7 @@ def main():
             from meepoembedding_amd.sharded import RcclShardedTable
             t_best = timed(step_rccl)
             log(f"transport probe: torch.distributed all-to-all {t_best * 1e3:.3f} ms/step")
-            for label, slack in (("exact segments, one host sync per lookup", 0.0), ("padded segments, no host sync", 1.04)):
+            for label, slack in (("exact segments, one host sync per lookup", 0.0), ("padded segments, no host sync", 1.02)):   # +2 % + 1024 positions per segment: 10 sigma of a uniform batch at 131K..1M keys per rank
                 try:
                     nt = RcclShardedTable(table, batch, pad_slack=slack, dedup=args.dedup)   # collective (ncclCommInitRank): proven by the self-test
                 except Exception as e:  # noqa: BLE001
