@@ -66,6 +66,32 @@ struct ApplyLds {
     uint32_t n_items, n_big, n_runs, part_base, rec_base, is_last, n_cand, stk_n;
 };
 
+// MEE_APPLY_TIMELINE (diagnostic builds only: tools/apply_timeline.py): thread 0 of every block stamps the 100 MHz wall clock at the phase
+// boundaries of its bucket into a buffer the host reads back (mee_debug_timeline).
+#ifndef MEE_APPLY_TIMELINE
+#define MEE_APPLY_TIMELINE 0
+#endif
+#if MEE_APPLY_TIMELINE
+#define MEE_TL(A_, i) do { if (threadIdx.x == 0) (A_).dbg[(uint64_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define MEE_TL(A_, i) do { } while (0)
+#endif
+
+// MEE_APPLY_STORE_MODE (diagnostic builds): how an update's rows are stored — 0 plain, 1 nt, 2 sc1 (write-through, the line leaves the XCD's L2)
+#ifndef MEE_APPLY_STORE_MODE
+#define MEE_APPLY_STORE_MODE 0
+#endif
+__device__ __forceinline__ void store_row4(float4* p, const float4& v) {
+#if MEE_APPLY_STORE_MODE == 1
+    __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+#elif MEE_APPLY_STORE_MODE == 2
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
+#else
+    *p = v;
+#endif
+}
+
 struct ApplyArgs {
     const int64_t* tkeys; float4 *values, *s1, *s2; uint64_t nb; uint32_t dim4;
     const float4* grads; const uint32_t* gidx; const int64_t* slots;
@@ -74,6 +100,9 @@ struct ApplyArgs {
     uint32_t nbk, part_blocks, per_block;   // the partition: buckets, partition blocks, batch positions per partition block
     uint32_t n_extra;                       // spare blocks at the head of the grid
     OpCounters* op;
+#if MEE_APPLY_TIMELINE
+    unsigned long long* dbg;
+#endif
     const GroupDesc* desc; uint32_t n_tables;   // GROUPED kernels (mee_group_apply_*): the members' planes; a "slot" is member << 48 | slot
     OptArgs a;
 };
@@ -157,6 +186,7 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
         my_tslot = tslot;
     }
     __syncthreads();
+    if constexpr (!SPLIT) MEE_TL(A, 2);   // entries fetched, keys in the LDS table
     // ---- 2. prefix sums over the runs: where each run starts in src, its work items, its number, its fp64 partial rows ----
     {
         const uint32_t s0 = 2 * t, c0 = L.cnt[s0], c1 = L.cnt[s0 + 1];
@@ -206,6 +236,7 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
         }
     }
     __syncthreads();
+    if constexpr (!SPLIT) MEE_TL(A, 3);   // scans done, sources sorted (LOCATED: slot handles arrived)
     const uint32_t n_items = L.n_items, n_big = L.n_big;
     const uint32_t rec_out0 = rec_bucket0 + (emit ? L.rec_base : 0u);   // emit: where this slab's records go
     // ---- 3. work items: one tile each ----
@@ -242,8 +273,8 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
                     if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
                     const float4 g = col == (uint32_t)tl ? make_float4(gpre.x, gpre.y, gpre.z, gpre.w) : A.grads[(uint64_t)src0 * dim4 + col];
                     opt_update4(a, w, x1, x2, g);
-                    at.values[o] = w; at.s1[o] = x1;
-                    if (KIND == MEE_OPT_ADAM) at.s2[o] = x2;
+                    store_row4(&at.values[o], w); store_row4(&at.s1[o], x1);
+                    if (KIND == MEE_OPT_ADAM) store_row4(&at.s2[o], x2);
                 }
                 continue;
             }
@@ -279,8 +310,8 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
                     float4 w = at.values[o], x1 = at.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
                     opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
-                    at.values[o] = w; at.s1[o] = x1;
-                    if (KIND == MEE_OPT_ADAM) at.s2[o] = x2;
+                    store_row4(&at.values[o], w); store_row4(&at.s1[o], x1);
+                    if (KIND == MEE_OPT_ADAM) store_row4(&at.s2[o], x2);
                 }
             } else {   // a chunk of a long run -> one fp64 partial row of this block | a whole run of a split bucket's slab -> its pending record
                 double2* dst = whole ? reinterpret_cast<double2*>(bk.pend_row + ((uint64_t)(rec_out0 + L.run[s]) * dim4 + col) * 4)
@@ -293,6 +324,7 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
             if constexpr (LOCATED) bk.pend_slot[rec_out0 + L.run[s]] = slot;
         }
     }
+    if constexpr (!SPLIT) MEE_TL(A, 4);   // this thread's items done
     if (n_big == 0) return;   // block-uniform
     // ---- 4. runs longer than kRun: one tile adds the run's chunk sums (written by this block: visible after the barrier) and finishes the run ----
     __syncthreads();
@@ -333,8 +365,8 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
                     float4 w = at.values[o], x1 = at.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
                     opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
-                    at.values[o] = w; at.s1[o] = x1;
-                    if (KIND == MEE_OPT_ADAM) at.s2[o] = x2;
+                    store_row4(&at.values[o], w); store_row4(&at.s1[o], x1);
+                    if (KIND == MEE_OPT_ADAM) store_row4(&at.s2[o], x2);
                 }
             } else {
                 double2* dst = reinterpret_cast<double2*>(bk.pend_row + ((uint64_t)(rec_out0 + L.run[s]) * dim4 + col) * 4);
@@ -404,8 +436,8 @@ __device__ __forceinline__ void mono_pass(ApplyLds& L, const ApplyArgs& A, const
             float4 w = at.values[o], x1 = at.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
             opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
-            at.values[o] = w; at.s1[o] = x1;
-            if (KIND == MEE_OPT_ADAM) at.s2[o] = x2;
+            store_row4(&at.values[o], w); store_row4(&at.s1[o], x1);
+            if (KIND == MEE_OPT_ADAM) store_row4(&at.s2[o], x2);
         }
     }
     __syncthreads();
@@ -450,14 +482,20 @@ __device__ __forceinline__ void bucket_role(ApplyLds& L, const ApplyArgs& A, con
     // filled (bk.seq[1], meepo_apply_part.h), the bucket's total in BOTH copies, and — lanes of wave 0 — the lengths and places of the bucket's
     // runs in the partition blocks' slices.  (As a chain seq -> total -> run lengths these were three dependent loads, 2-3 us of every block's
     // life before its first useful request.)
+    MEE_TL(A, 0);
     const SegRuns runs = seg_load(A, bk, b, threadIdx.x);
     const uint32_t tot0 = bk.tot[b], tot1 = bk.tot[bk.n_buckets_max + b];
     const uint32_t parity = bk.seq[1];
     if (b == 0 && threadIdx.x == 0) atomicAdd(&bk.seq[0], 1u);   // this partition is consumed: the next one fills the other copy
     const uint32_t size = __builtin_amdgcn_readfirstlane(parity ? tot1 : tot0);
     if (size == 0 || size > kSlab) return;   // an empty bucket | a split bucket: the spare blocks (split_role) have it
+    MEE_TL(A, 1);   // first round trip done (size known)
+#if MEE_APPLY_TIMELINE
+    if (threadIdx.x == 0) { A.dbg[(uint64_t)blockIdx.x * 8 + 6] = size | (unsigned long long)b << 32; unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); A.dbg[(uint64_t)blockIdx.x * 8 + 7] = (unsigned long long)(xcc & 0xf) << 32 | hw; }
+#endif
     seg_scan(L, runs, threadIdx.x);
     process_slab<KIND, DIM4, LOCATED, false, GROUPED>(L, A, bk, 0, size, false, false, b, 0, gdesc);
+    MEE_TL(A, 5);
 }
 
 template <int KIND, int DIM4, bool LOCATED, bool GROUPED>
@@ -601,7 +639,11 @@ __global__ __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES) void bkt_apply_kern
         }
     }
     if (blockIdx.x < A.n_extra) split_role<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, blockIdx.x, A.n_extra, gdesc);   // block-uniform
+#if MEE_APPLY_TIMELINE == 2   // diagnostic: decouple a bucket's parity from its block's XCD (blocks are dealt round-robin over the 8 XCDs)
+    else { const uint32_t i = blockIdx.x - A.n_extra; bucket_role<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, (i ^ ((i >> 3) & 1u)) < A.nbk ? i ^ ((i >> 3) & 1u) : i, gdesc); }
+#else
     else bucket_role<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, blockIdx.x - A.n_extra, gdesc);
+#endif
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
@@ -639,6 +681,13 @@ void bucket_scratch_free(mee_table* t) {
     for (void* p : dev) if (p) (void)hipFree(p);
 }
 
+#if MEE_APPLY_TIMELINE
+static unsigned long long* g_dbg = nullptr;
+extern "C" int mee_debug_timeline(unsigned long long* host_out, uint64_t n_words) {
+    if (!g_dbg) return 1;
+    return hipMemcpy(host_out, g_dbg, n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+#endif
 int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st) {
     const uint32_t nbk = bucket_count_for(t, n);
     uint32_t blocks, per_block;
@@ -664,6 +713,10 @@ int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const Op
     A.grads = (const float4*)d_grads; A.gidx = d_gidx; A.slots = d_slots;
     A.capacity = t->capacity; A.handle_tag = (int64_t)(t->handle_epoch & kHandleEpochMask) << kHandleSlotBits; A.status = &t->ctr->status;
     A.part = t->bs.gacc; A.max_part = t->bs.max_part; A.op = t->op; A.a = a;
+#if MEE_APPLY_TIMELINE
+    if (!g_dbg) { (void)hipMalloc((void**)&g_dbg, 16384 * 8 * 8); (void)hipMemset(g_dbg, 0, 16384 * 8 * 8); }
+    A.dbg = g_dbg;
+#endif
     A.desc = d_desc; A.n_tables = n_tables;   // a table group's apply (d_slots = the batch's located rows = its keys; t = the group's scratch table)
     A.nbk = bucket_count_for(t, n);
     A.part_blocks = t->part_blocks; A.per_block = t->part_per_block;   // as whoever partitioned this batch left them

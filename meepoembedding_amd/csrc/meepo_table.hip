@@ -186,13 +186,31 @@ __device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, con
     }
 }
 
+#ifndef MEE_FIND_TIMELINE
+#define MEE_FIND_TIMELINE 0
+#endif
+#if MEE_FIND_TIMELINE
+__device__ unsigned long long* g_find_dbg = nullptr;
+#endif
 template <int DIM4, int R, int NT>
 __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values,
                                                    uint64_t nb, const int64_t* __restrict__ keys, uint64_t n,
                                                    f32x4* __restrict__ out, uint8_t* __restrict__ found, float defv,
                                                    uint32_t dim4_rt, uint32_t* hits, int64_t* __restrict__ slots_out = nullptr, int64_t handle_tag = 0) {
+#if MEE_FIND_TIMELINE   // diagnostic builds only (tools/find_timeline.py): wave 0 of every block stamps its start, its end and the XCD it ran on
+    unsigned long long t0_ = 0;
+    if (threadIdx.x == 0) t0_ = wall_clock64();
+#endif
     find_span<DIM4, R, NT>(tkeys, values, nb, keys, n, out, found, defv, dim4_rt, hits, slots_out,
                            (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), (uint64_t)gridDim.x * (blockDim.x >> 6), handle_tag);
+#if MEE_FIND_TIMELINE
+    if (threadIdx.x == 0 && g_find_dbg && blockIdx.x < 16384) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_find_dbg[blockIdx.x * 4 + 0] = t0_; g_find_dbg[blockIdx.x * 4 + 1] = wall_clock64(); g_find_dbg[blockIdx.x * 4 + 2] = xcc & 0xf;
+    }
+#endif
 }
 
 // The training forward (mee_find_located_prepare): the located find whose launch gives its first `part_blocks` blocks the partition role of
@@ -2683,6 +2701,18 @@ int mee_find_or_insert_located_prepare(mee_table* t, const int64_t* d_keys, size
     return MEE_OK;
 }
 
+#if MEE_FIND_TIMELINE
+int mee_debug_find_timeline(unsigned long long* host_out, uint64_t n_words) {   // first call arms the buffer, later calls read it
+    static unsigned long long* buf = nullptr;
+    if (!buf) {
+        if (hipMalloc((void**)&buf, 16384 * 4 * 8) != hipSuccess) return 1;
+        (void)hipMemset(buf, 0, 16384 * 4 * 8);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_find_dbg), &buf, sizeof buf);
+        return 0;
+    }
+    return hipMemcpy(host_out, buf, n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+#endif
 int mee_apply_discard(mee_table* t, void* stream) {
     if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_apply_discard: null table");
     if (!t->prepared_n) return MEE_OK;
