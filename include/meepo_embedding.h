@@ -46,8 +46,10 @@ enum { MEE_OK = 0, MEE_ERR_INVALID_ARG = -1, MEE_ERR_OUT_OF_MEMORY = -2, MEE_ERR
 enum { MEE_OPT_NONE = 0, MEE_OPT_ADAGRAD = 1, MEE_OPT_ADAM = 2 };
 enum { MEE_INIT_CONSTANT = 0, MEE_INIT_UNIFORM = 1 };
 /* MEE_STATUS_STALE_HANDLE: mee_apply_*_located met a slot handle made before the table's latest mee_remove / mee_clear / mee_reserve; such
- * positions receive no update (the slot may hold another key by now). */
-enum { MEE_STATUS_TABLE_FULL = 1u, MEE_STATUS_RESERVED_KEY = 2u, MEE_STATUS_STALE_HANDLE = 4u };
+ * positions receive no update (the slot may hold another key by now).
+ * MEE_STATUS_INTERNAL: a per-batch scratch area that is sized so that no batch can exhaust it was exhausted after all (a defect of the library:
+ * the batch's updates are not to be trusted); never observed, reported rather than hidden. */
+enum { MEE_STATUS_TABLE_FULL = 1u, MEE_STATUS_RESERVED_KEY = 2u, MEE_STATUS_STALE_HANDLE = 4u, MEE_STATUS_INTERNAL = 8u };
 /* MEE_MEM_HOST_PINNED: rows in pinned, device-mapped host DRAM, read and written by the same kernels over PCIe — the
  * cold tier of a hot/cold pair (BASELINE configs[4]); see meepoembedding_amd/tiered.py. */
 enum { MEE_MEM_HBM = 0, MEE_MEM_HOST_PINNED = 1 };

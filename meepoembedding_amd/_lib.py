@@ -19,7 +19,7 @@ OK = 0
 ERR_INVALID_ARG, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_NO_DEVICE, ERR_BATCH_TOO_LARGE, ERR_UNSUPPORTED, ERR_RCCL = -1, -2, -3, -4, -5, -6, -7
 OPT_NONE, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
 INIT_CONSTANT, INIT_UNIFORM = 0, 1
-STATUS_TABLE_FULL, STATUS_RESERVED_KEY, STATUS_STALE_HANDLE = 1, 2, 4
+STATUS_TABLE_FULL, STATUS_RESERVED_KEY, STATUS_STALE_HANDLE, STATUS_INTERNAL = 1, 2, 4, 8
 HANDLE_SLOT_MASK = (1 << 40) - 1   # a located-find handle: bits 0..39 the slot (as mee_locate reports it), bits 40..61 the table's layout epoch
 MEM_HBM, MEM_HOST_PINNED = 0, 1
 FLAG_TRACK_HITS, FLAG_ADMISSION = 1, 2

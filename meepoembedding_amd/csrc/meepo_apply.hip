@@ -33,11 +33,32 @@ namespace mee {
 constexpr int kPartThreads = MEE_PT;
 constexpr int kApplyThreads = 512;
 constexpr int kApplyWaves = kApplyThreads / 64;
-constexpr uint32_t kLdsSlots = 2 * kSlab;
-constexpr uint32_t kRun = 32;             // occurrences one tile sums in one go; longer runs are cut into chunks of this many
+constexpr uint32_t kLdsSlots = kBucketCap;   // the LDS hash table: as many slots as a block holds sources (a bucket of kBucketCap DISTINCT keys fills it to the
+                                             // last slot — linear probing then costs ~sqrt(n) probes per key, a few us for a bucket no hash produces by chance)
+constexpr uint32_t kChunk = 8;            // sources one tile sums in one go (four rows in flight: two dependent round trips); longer runs are cut into chunks
+constexpr uint32_t kMaxQuads = 192;       // wave items (quads of four chunks) of one slab: at most m / 32 + (runs longer than a chunk: m / 9) = 32 + 113 at m = 1024
+constexpr uint32_t kLdsPartRows = 16;     // fp64 partial rows a slab keeps in LDS (a slab that is ONE key of 512 occurrences: 16 quads)
 
-uint32_t bucket_count_for(const mee_table* t, uint64_t n) { return bucket_count_for_host(n, t->bk.slots, t->bk.bucket_max ? t->bk.bucket_max : kBucketMax); }
-static uint32_t max_extra_slabs(uint64_t n) { return 2 * (uint32_t)(n / kSlab) + 2; }   // slabs of split buckets: sum of ceil(size / kSlab) over buckets larger than kSlab
+// Buckets and apply blocks for a batch of n keys.  One block per bucket and one round of equal blocks (bucket_count_for_host) — unless the
+// latest batch was skewed: its S slabs were units of their own in front of the buckets, and S + buckets beyond the resident block slots ran as
+// a second round behind the first (25 us units: a Zipf(1.05) batch of 256K keys, 146 slabs + 768 buckets on 768 slots, ended at 75-80 us
+// instead of ~50).  Key streams keep their skew from batch to batch, so the next batch gets S (+ 1/16) fewer, larger buckets and as many
+// blocks as before: slabs and buckets together fill the slots once.  S comes back through a pinned host word the apply kernel writes — read
+// here without any synchronisation (a stale or zero value costs time, never results: the kernel works through whatever units there are).
+uint32_t bucket_count_for(const mee_table* t, uint64_t n, uint32_t* grid_out) {
+    const uint32_t full = bucket_count_for_host(n, t->bk.slots, t->bk.bucket_max ? t->bk.bucket_max : kBucketMax);
+    uint32_t nbk = full;
+    const uint32_t s_prev = t->bk.h_slabs && t->bk.skew_adapt ? *(volatile uint32_t*)t->bk.h_slabs : 0u;
+    if (s_prev && n > (uint64_t)t->bk.slots * 128) {
+        uint32_t adj = s_prev + s_prev / 16 + 1;
+        if (adj > t->bk.slots / 2) adj = t->bk.slots / 2;
+        if (adj > full / 2) adj = full / 2;
+        nbk = full - adj;
+        while ((uint64_t)nbk * 2 * kBucketMax < n && nbk < full) ++nbk;   // (never more than ~700 positions per bucket on average: kBucketCap stays 12 sigma away)
+    }
+    if (grid_out) *grid_out = full;
+    return nbk;
+}
 
 // ---- the partition kernel of an apply (the role itself: meepo_apply_part.h) ----------------------------------------------------------------
 __global__ __launch_bounds__(kPartThreads) void bkt_sort_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk,
@@ -53,17 +74,25 @@ struct ApplyLds {
     long long slot[kLdsSlots];           // per run: the table slot its handle names (LOCATED kernels)
     uint32_t cnt[kLdsSlots];             // occurrences of the run's key in this slab
     uint32_t off[kLdsSlots];             // where the run starts in src
-    uint32_t run[kLdsSlots];             // slabs of split buckets: the run's pending-record number inside the slab
-    uint32_t src[kSlab];                 // the slab's sources sorted by run: gradient-row index (positions) | pending-record index (merge)
-    uint32_t items[kSlab + 32];          // work items: run slot | chunk << 10 | partial row << 15
-    uint32_t big[32];                    // runs longer than kRun: run slot | first partial row << 10 | chunks << 20
+    uint16_t run[kLdsSlots];             // slabs of split buckets: the run's pending-record number inside the slab
+    uint32_t src[kBucketCap];            // the slab's sources sorted by run: gradient-row index (positions) | pending-record index (merge)
+    uint16_t items[kBucketCap];          // tile items: the slots of the runs of up to kChunk sources (one tile sums and finishes such a run)
+    uint32_t quad[kMaxQuads];            // wave items: run slot | quad of the run << 10 | fp64 partial row << 16 (a quad = 4 chunks of kChunk sources)
+    uint32_t big[32];                    // runs of more than one quad: run slot | first partial row << 10 | quads << 22
     unsigned long long wsum[kApplyWaves];
     unsigned long long stk_val[72];      // merge: hash prefixes still to do
     uint32_t stk_bits[72];
     unsigned long long kmin, kmax;       // merge: smallest / largest biased key among a pass's candidates (equal: the pass holds ONE key)
     uint32_t seg_first[kPartBlocks + 1]; // where partition block k's entries of this bucket begin within the bucket (prefix of the run lengths)
     uint32_t seg_at[kPartBlocks];        // ... and where that run lies in pos / pkey
-    uint32_t n_items, n_big, n_runs, part_base, rec_base, is_last, n_cand, stk_n;
+    uint32_t n_items, n_quads, n_big, n_runs, part_base, rec_base, is_last, n_cand, stk_n, next_turn;
+    uint32_t u_b, u_sub, u_size, u_beg;   // skewed batches: the slab the block works on
+    uint32_t pre_slabs[kApplyThreads + 1], pre_pos[kApplyThreads + 1], pre_a[kApplyThreads];   // (pre_a: the total of the thread's first bucket)
+    alignas(16) double prow[kLdsPartRows][64];   // fp64 partial rows of the slab's long runs when there are few and the rows are short (dim <= 64): no trip through memory
+    uint32_t part_lds;   // skewed batches: slabs / positions in front of each thread's buckets
+#if MEE_APPLY_TIMELINE
+    uint32_t tl_w;
+#endif
 };
 
 // MEE_APPLY_TIMELINE (diagnostic builds only: tools/apply_timeline.py): thread 0 of every block stamps the 100 MHz wall clock at the phase
@@ -73,8 +102,14 @@ struct ApplyLds {
 #endif
 #if MEE_APPLY_TIMELINE
 #define MEE_TL(A_, i) do { if (threadIdx.x == 0) (A_).dbg[(uint64_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+// blocks of a skewed batch (skew_units): 128 words per block behind that area — [0] entry, [1] units taken, [2] scan done, then 16 words per slab unit taken
+#define MEE_TLS(A_, e_, w_, v_) do { if (threadIdx.x == 0 && (w_) < 128) (A_).dbg[16384ull * 8 + (uint64_t)(e_) * 128 + (w_)] = (v_); } while (0)
+// ... of which process_slab stamps its own phases: words 8..11 of the slab pass, 12..15 of the latest merge pass (L.tl_w = the slab's first word)
+#define MEE_TLP(A_, L_, k_) do { if (SPLIT && threadIdx.x == 0) (A_).dbg[16384ull * 8 + (L_).tl_w + (src_rec ? 12 : 8) + (k_)] = wall_clock64(); } while (0)
 #else
 #define MEE_TL(A_, i) do { } while (0)
+#define MEE_TLS(A_, e_, w_, v_) do { } while (0)
+#define MEE_TLP(A_, L_, k_) do { } while (0)
 #endif
 
 // MEE_APPLY_STORE_MODE (diagnostic builds): how an update's rows are stored — 0 plain, 1 nt, 2 sc1 (write-through, the line leaves the XCD's L2)
@@ -98,7 +133,7 @@ struct ApplyArgs {
     uint64_t capacity; int64_t handle_tag; uint32_t* status;
     double* part; uint32_t max_part;     // fp64 partial rows of long runs (BatchScratch::gacc)
     uint32_t nbk, part_blocks, per_block;   // the partition: buckets, partition blocks, batch positions per partition block
-    uint32_t n_extra;                       // spare blocks at the head of the grid
+    uint32_t* h_slabs;                      // pinned host word: the slabs this batch's split buckets were cut into (0: none)
     OpCounters* op;
 #if MEE_APPLY_TIMELINE
     unsigned long long* dbg;
@@ -123,133 +158,276 @@ __device__ __forceinline__ RowAt row_at(const ApplyArgs& A, const GroupDesc* gde
     return r;
 }
 
-// One slab: m <= kSlab sources -> one update (or one pending record) per distinct key.
+// Pending records (key, slot, fp64 partial row) go from the slab that writes them to the block that merges the bucket — another CU, most
+// likely another XCD with its own L2.  They are written with agent-scope (sc1: write-through) stores and read with agent-scope loads; the
+// producer drains its stores (s_waitcnt vmcnt(0)) before it draws its ticket.  No release / acquire fence: an agent-scope release is a
+// write-back of the XCD's whole L2, full of the rows the batch has just updated — MI355X_MICROARCH.md "publish-large": 8.2 us against 3.0
+// for a 64 KB slab, and the hand-off of a slab measured 6-7 us with the fence pair (tools/apply_timeline.py).
+__device__ __forceinline__ void rec_store(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void rec_store(int64_t* p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double rec_load(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ int64_t rec_load(const int64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rec_store_row4(double* dst, double x, double y, double z, double w) { rec_store(dst, x); rec_store(dst + 1, y); rec_store(dst + 2, z); rec_store(dst + 3, w); }
+
+// sum over the wave's four tiles (lane l, l ^ 16, l ^ 32, l ^ 48 hold the same column of four different partial sums): every lane gets the total
+__device__ __forceinline__ double tiles_sum(double v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// nh rows of A.grads (fp32) | of the pending records (fp64), four in flight, added up in fp64; a lane past the end reads the last row again and
+// adds +0.0 (no one-row-at-a-time tail: every round trip carries four rows)
+template <bool REC>
+__device__ __forceinline__ void sum_sources(const ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, bool src_rec, uint32_t rec_bucket0, uint32_t run0, uint32_t nh,
+                                            uint32_t dim4, uint32_t col, double& sx, double& sy, double& sz, double& sw) {
+    if (REC && src_rec) {
+        for (uint32_t q0 = 0; q0 < nh; q0 += 4) {
+            double2 lo[4], hi[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double* r = bk.pend_row + ((uint64_t)(rec_bucket0 + L.src[run0 + min(q0 + q, nh - 1)]) * dim4 + col) * 4;
+                lo[q] = make_double2(rec_load(r), rec_load(r + 1)); hi[q] = make_double2(rec_load(r + 2), rec_load(r + 3));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool on = q0 + q < nh;
+                sx += on ? lo[q].x : 0.0; sy += on ? lo[q].y : 0.0; sz += on ? hi[q].x : 0.0; sw += on ? hi[q].y : 0.0;
+            }
+        }
+    } else {
+        for (uint32_t q0 = 0; q0 < nh; q0 += 4) {
+            float4 gq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gq[q] = A.grads[(uint64_t)L.src[run0 + min(q0 + q, nh - 1)] * dim4 + col];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool on = q0 + q < nh;
+                sx += on ? (double)gq[q].x : 0.0; sy += on ? (double)gq[q].y : 0.0; sz += on ? (double)gq[q].z : 0.0; sw += on ? (double)gq[q].w : 0.0;
+            }
+        }
+    }
+}
+
+// One slab: m sources -> one update (or one pending record) per distinct key.  m <= kBucketCap in the kernel of the whole buckets (SPLIT =
+// false: a thread takes sources t and t + 512), m <= kSlab in the split role.
 //   src_rec = false: the sources are entries [first, first + m) of bucket b (batch positions + keys, pulled out of the partition blocks' slices
 //                    of bk.pos / bk.pkey); a source's row is a row of grads.
 //   src_rec = true : (merge of a split bucket) the sources are the pending records whose bucket-relative numbers lie in L.src[0 .. m); a
 //                    source's row is the record's fp64 partial sum.
 //   emit: results become pending records of bucket `b` instead of table updates (slab of a split bucket).
-// ONE inlined instance per kernel (the kernel loops over it: slab first, merge passes after): as two instances the merge copy pushed the
-// kernel from 64 to 113 VGPRs, i.e. the hot path of every block from 4 to 2 resident blocks per CU (-10 us per 256K-key batch).
+// Work items.  kChunk = 8 sources is what one TILE sums in one go (four rows in flight: two dependent round trips).  A run of up to 8 sources
+// is a tile item: one tile sums it and finishes it.  A longer run is cut into chunks of 8 and handed out as QUADS of four chunks: the four
+// tiles of a wave sum one chunk each and add their sums up with two shuffles — a run of up to 32 sources is finished right there, a longer
+// one leaves one fp64 partial row per quad (in LDS when the slab has at most 16 of them and dim <= 64), and after a barrier a wave adds the
+// rows (tile u: rows u, u + 4, …) and finishes the run.  A slab that is ONE hot key (512 occurrences) is 16 quads on 8 waves, then 16 partial
+// rows on one wave: 2 x 2 + 1 dependent round trips.  (Round 3: chunks of 32 as tile items, one partial row per chunk, ONE tile adding them
+// two at a time: 8 + 8 round trips, the slab pass of a split bucket 30-45 us.  Chunks of ceil(m / 32) sources — "as many items as tiles" —:
+// a bucket of 800 positions around a key of 500 occurrences spent 7 round trips in each of that key's quads.)  Waves take turns from an LDS
+// counter, quads first (a quad is up to 32 rows, a key that occurs once is one).
 template <int KIND, int DIM4, bool LOCATED, bool SPLIT /* false: emit and src_rec are known to be false (the kernel of the whole buckets) */, bool GROUPED = false>
 __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, uint32_t first, uint32_t m, bool emit_rt, bool src_rec_rt,
                                              uint32_t b, uint32_t rec_bucket0 /* split buckets: the bucket's first pending record */, const GroupDesc* gdesc = nullptr) {
     static_assert(!GROUPED || LOCATED, "a group's batch names rows, not keys");
+    constexpr int PPT = SPLIT ? 1 : (int)(kBucketCap / kApplyThreads);   // sources per thread
     const bool emit = SPLIT && emit_rt, src_rec = SPLIT && src_rec_rt;
     // The kernel calls this from a loop (slab, then merge passes).  The thread index is re-read through an empty asm in every call so that
     // nothing derived from it looks loop-invariant: hoisted out of that loop, the per-thread address arithmetic of every array touched in
     // here stayed live across the whole kernel (110 VGPRs instead of 64: half the resident blocks per CU for every block's hot path).
     uint32_t t = threadIdx.x;
     asm volatile("" : "+v"(t));
-    const int lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6;
+    const int lane = t & 63, tile = lane >> 4, tl = lane & 15;
     const uint32_t dim4 = DIM4 ? DIM4 : A.dim4;
+    constexpr uint32_t lc = kChunk;
     OptArgs a = A.a;
     a.kind = KIND;
     // ---- 1. the slab's keys into the LDS hash table: run = LDS slot, r = arrival number inside the run ----
-    uint32_t my_src = 0;
-    if (src_rec) my_src = t < m ? L.src[t] : 0u;   // read before the table is cleared / src is rewritten
+    uint32_t my_src[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) my_src[u] = 0u;
+    if (src_rec) my_src[0] = t < m ? L.src[t] : 0u;   // read before the table is cleared / src is rewritten
     __syncthreads();   // (src_rec = false: the caller's wave 0 has just written L.seg_first / L.seg_at)
     for (uint32_t j = t; j < kLdsSlots; j += kApplyThreads) { L.key[j] = 0ull; L.cnt[j] = 0u; }
-    if (t == 0) { L.n_big = 0u; }
+    if (t == 0) { L.n_big = 0u; L.next_turn = 0u; }
     __syncthreads();
-    uint32_t my_slot = 0, my_r = 0;
-    bool my_first = false;
-    int64_t my_tslot = -1;
-    if (t < m) {
-        int64_t key;
-        int64_t tslot = -1;   // LOCATED: the key's slot handle (positions) | the table slot its record carries (merge)
-        if (src_rec) {
-            key = bk.pend_key[rec_bucket0 + my_src];
-            if constexpr (LOCATED) tslot = bk.pend_slot[rec_bucket0 + my_src];
-        } else {
-            const uint32_t gi = first + t;   // index within the bucket -> its run (binary search over the 64 run starts) -> its place in pos / pkey
-            uint32_t k = 0;
+    uint32_t my_slot[PPT], my_r[PPT];
+    bool my_first[PPT];
+    int64_t my_tslot[PPT], my_key[PPT];
+    // (the global loads of all of a thread's sources are requested before the first LDS insertion waits for any of them)
 #pragma unroll
-            for (uint32_t stp = kPartBlocks / 2; stp; stp >>= 1) if (L.seg_first[k + stp] <= gi) k += stp;
-            const uint32_t at = L.seg_at[k] + (gi - L.seg_first[k]);
-            const uint32_t p = bk.pos[at];
-            key = bk.pkey[at];
-            my_src = A.gidx ? min(A.gidx[p], a.grad_rows - 1) : p;   // the row of the grad array that belongs to the position
-            if constexpr (LOCATED) tslot = A.slots[p];   // the raw handle: decoded where it is first needed, so that the load travels beside the LDS work
+    for (int u = 0; u < PPT; ++u) {
+        const uint32_t ti = t + (uint32_t)u * kApplyThreads;
+        my_key[u] = kEmpty; my_tslot[u] = -1; my_slot[u] = 0u; my_r[u] = 0u; my_first[u] = false;
+        if (ti < m) {
+            if (src_rec) {
+                my_key[u] = rec_load(bk.pend_key + rec_bucket0 + my_src[u]);
+                if constexpr (LOCATED) my_tslot[u] = rec_load(bk.pend_slot + rec_bucket0 + my_src[u]);   // the table slot the record carries
+            } else {
+                const uint32_t gi = first + ti;   // index within the bucket -> its run (binary search over the run starts) -> its place in pos / pkey
+                uint32_t k = 0;
+#pragma unroll
+                for (uint32_t stp = kPartBlocks / 2; stp; stp >>= 1) if (L.seg_first[k + stp] <= gi) k += stp;
+                const uint32_t at = L.seg_at[k] + (gi - L.seg_first[k]);
+                const uint32_t p = bk.pos[at];
+                my_key[u] = bk.pkey[at];
+                my_src[u] = A.gidx ? min(A.gidx[p], a.grad_rows - 1) : p;   // the row of the grad array that belongs to the position
+                if constexpr (LOCATED) my_tslot[u] = A.slots[p];   // the raw handle: decoded where it is first needed, so that the load travels beside the LDS work
+            }
         }
-        const unsigned long long bkey = (unsigned long long)key ^ kBias;
-        my_slot = (uint32_t)(mix64b((uint64_t)key) & (kLdsSlots - 1));   // mix64's top bits chose the bucket: take another mixer here
-        bool first_of_run = false;
-        while (true) {
-            const unsigned long long old = atomicCAS(&L.key[my_slot], 0ull, bkey);
-            if (old == 0ull) { first_of_run = true; break; }
-            if (old == bkey) break;
-            my_slot = (my_slot + 1) & (kLdsSlots - 1);
+    }
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+        if (t + (uint32_t)u * kApplyThreads < m) {
+            const int64_t key = my_key[u];
+            const unsigned long long bkey = (unsigned long long)key ^ kBias;
+            uint32_t sl = (uint32_t)(mix64b((uint64_t)key) & (kLdsSlots - 1));   // mix64's top bits chose the bucket: take another mixer here
+            bool first_of_run = false;
+            while (true) {
+                const unsigned long long old = atomicCAS(&L.key[sl], 0ull, bkey);
+                if (old == 0ull) { first_of_run = true; break; }
+                if (old == bkey) break;
+                sl = (sl + 1) & (kLdsSlots - 1);
+            }
+            my_r[u] = atomicAdd(&L.cnt[sl], 1u);
+            my_slot[u] = sl;
+            my_first[u] = first_of_run;
         }
-        my_r = atomicAdd(&L.cnt[my_slot], 1u);
-        my_first = first_of_run;
-        my_tslot = tslot;
     }
     __syncthreads();
     if constexpr (!SPLIT) MEE_TL(A, 2);   // entries fetched, keys in the LDS table
+    MEE_TLP(A, L, 0);
     // ---- 2. prefix sums over the runs: where each run starts in src, its work items, its number, its fp64 partial rows ----
     {
         const uint32_t s0 = 2 * t, c0 = L.cnt[s0], c1 = L.cnt[s0 + 1];
-        const uint32_t i0 = (c0 + kRun - 1) / kRun, i1 = (c1 + kRun - 1) / kRun;
-        const uint32_t p0 = c0 > kRun ? i0 : 0u, p1 = c1 > kRun ? i1 : 0u;
-        // bits 0..15 sources | 16..31 items | 32..47 runs | 48..63 partial rows — each at most kSlab + kSlab / kRun
-        const unsigned long long packed = (unsigned long long)(c0 + c1) | (unsigned long long)(i0 + i1) << 16 |
-                                          (unsigned long long)((c0 != 0) + (c1 != 0)) << 32 | (unsigned long long)(p0 + p1) << 48;
+        const uint32_t t0 = c0 != 0 && c0 <= lc, t1 = c1 != 0 && c1 <= lc;                                        // tile items
+        const uint32_t q0 = c0 > lc ? ((c0 + lc - 1) / lc + 3) / 4 : 0u, q1 = c1 > lc ? ((c1 + lc - 1) / lc + 3) / 4 : 0u;   // quads
+        const uint32_t p0 = q0 > 1 ? q0 : 0u, p1 = q1 > 1 ? q1 : 0u;                                                // partial rows: one per quad of a run of several
+        // five fields of 12 bits: sources | tile items | runs | quads | partial rows — each at most kBucketCap in total
+        const unsigned long long packed = (unsigned long long)(c0 + c1) | (unsigned long long)(t0 + t1) << 12 | (unsigned long long)((c0 != 0) + (c1 != 0)) << 24 |
+                                          (unsigned long long)(q0 + q1) << 36 | (unsigned long long)(p0 + p1) << 48;
         unsigned long long total;
         const unsigned long long ex = block_scan_u64<kApplyWaves>(packed, L.wsum, total);
-        uint32_t so = (uint32_t)ex & 0xFFFFu, io = (uint32_t)(ex >> 16) & 0xFFFFu, ro = (uint32_t)(ex >> 32) & 0xFFFFu, po = (uint32_t)(ex >> 48);
+        uint32_t so = (uint32_t)ex & 0xFFFu, io = (uint32_t)(ex >> 12) & 0xFFFu, ro = (uint32_t)(ex >> 24) & 0xFFFu, qo = (uint32_t)(ex >> 36) & 0xFFFu, po = (uint32_t)(ex >> 48) & 0xFFFu;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const uint32_t s = s0 + h, c = h ? c1 : c0, ni = h ? i1 : i0;
+            const uint32_t s = s0 + h, c = h ? c1 : c0, nq = h ? q1 : q0;
             L.off[s] = so;
             if (c) {
                 L.run[s] = ro;
-#pragma unroll 1   // (unrolled 16-fold this loop alone held 40 VGPRs of precomputed item words)
-                for (uint32_t j = 0; j < ni; ++j) L.items[io + j] = s | j << 10 | (c > kRun ? (po + j) << 15 : 0u);
-                if (c > kRun) { L.big[atomicAdd(&L.n_big, 1u)] = s | po << 10 | ni << 20; po += ni; }
-                so += c; io += ni; ++ro;
+                if (c <= lc) L.items[io++] = s;
+#pragma unroll 1
+                for (uint32_t j = 0; j < nq; ++j) if (qo + j < kMaxQuads) L.quad[qo + j] = s | j << 10 | (nq > 1 ? po + j : 0u) << 16;
+                if (nq > 1) { L.big[atomicAdd(&L.n_big, 1u) & 31u] = s | po << 10 | nq << 22; po += nq; }   // fewer than 32 such runs: m / 33
+                so += c; qo += nq; ++ro;
             }
         }
         if (t == 0) {
-            L.n_items = (uint32_t)(total >> 16) & 0xFFFFu;
-            L.n_runs = (uint32_t)(total >> 32) & 0xFFFFu;
-            const uint32_t np = (uint32_t)(total >> 48);
-            uint32_t pb = np ? atomicAdd(&A.op->n_part, np) : 0u;
-            if (pb + np > A.max_part) pb = 0u;   // cannot happen (sum of ceil(c / kRun) over runs longer than kRun <= n / 32 + n / 33); never write out of bounds
+            L.n_items = (uint32_t)(total >> 12) & 0xFFFu;
+            L.n_runs = (uint32_t)(total >> 24) & 0xFFFu;
+            L.n_quads = min((uint32_t)(total >> 36) & 0xFFFu, kMaxQuads);
+            const uint32_t np = (uint32_t)(total >> 48) & 0xFFFu;
+            const bool in_lds = np <= kLdsPartRows && dim4 <= 16;
+            L.part_lds = in_lds;
+            uint32_t pb = np && !in_lds ? atomicAdd(&A.op->n_part, np) : 0u;
+            if (pb + np > A.max_part) { pb = 0u; atomicOr(A.status, (uint32_t)MEE_STATUS_INTERNAL); }   // cannot happen (max_part covers n / 8 rows: one per 32 sources of a run longer than 32); never write out of bounds
             L.part_base = pb;
             if (emit) L.rec_base = atomicAdd(&bk.pend_cnt[b], L.n_runs);
         }
     }
     __syncthreads();
-    if (t < m) {
-        L.src[L.off[my_slot] + my_r] = my_src;
-        if constexpr (LOCATED) {
-            if (my_first) {   // every occurrence of a key names the same slot: the run keeps one
-                if (src_rec) L.slot[my_slot] = my_tslot;
-                else if constexpr (GROUPED) L.slot[my_slot] = my_tslot >= 0 && ((uint64_t)my_tslot >> kGroupSlotBits) < A.n_tables ? my_tslot : -1;
-                else {
-                    bool stale;
-                    L.slot[my_slot] = handle_slot(my_tslot, A.handle_tag, A.capacity, stale);
-                    if (stale) atomicOr(A.status, (uint32_t)MEE_STATUS_STALE_HANDLE);   // rare: the caller kept handles across a remove / clear / reserve
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+        if (t + (uint32_t)u * kApplyThreads < m) {
+            L.src[L.off[my_slot[u]] + my_r[u]] = my_src[u];
+            if constexpr (LOCATED) {
+                if (my_first[u]) {   // every occurrence of a key names the same slot: the run keeps one
+                    if (src_rec) L.slot[my_slot[u]] = my_tslot[u];
+                    else if constexpr (GROUPED) L.slot[my_slot[u]] = my_tslot[u] >= 0 && ((uint64_t)my_tslot[u] >> kGroupSlotBits) < A.n_tables ? my_tslot[u] : -1;
+                    else {
+                        bool stale;
+                        L.slot[my_slot[u]] = handle_slot(my_tslot[u], A.handle_tag, A.capacity, stale);
+                        if (stale) atomicOr(A.status, (uint32_t)MEE_STATUS_STALE_HANDLE);   // rare: the caller kept handles across a remove / clear / reserve
+                    }
                 }
             }
         }
     }
     __syncthreads();
     if constexpr (!SPLIT) MEE_TL(A, 3);   // scans done, sources sorted (LOCATED: slot handles arrived)
-    const uint32_t n_items = L.n_items, n_big = L.n_big;
+    MEE_TLP(A, L, 1);
+    const uint32_t n_items = L.n_items, n_quads = L.n_quads, n_big = L.n_big;
+    const bool part_lds = L.part_lds != 0;
+    const uint32_t n_turns = n_quads + (n_items + 3) / 4;
     const uint32_t rec_out0 = rec_bucket0 + (emit ? L.rec_base : 0u);   // emit: where this slab's records go
-    // ---- 3. work items: one tile each ----
-    for (uint32_t it0 = (uint32_t)wv * 4; it0 < n_items; it0 += kApplyWaves * 4) {   // block-uniform bound: the ballots inside tile_locate need whole waves
-        const uint32_t item = it0 + tile;
+    // ---- 3. work items: a wave per turn — a quad (its four tiles sum one chunk each of ONE run) or four tile items ----
+    [[maybe_unused]] uint32_t tl_turn = 0;
+    while (true) {
+        uint32_t turn = 0;
+        if (lane == 0) turn = atomicAdd(&L.next_turn, 1u);
+        turn = __builtin_amdgcn_readfirstlane(turn);
+#if MEE_APPLY_TIMELINE
+        if (!SPLIT && threadIdx.x == 0 && tl_turn < 16) A.dbg[16384ull * 8 + (uint64_t)blockIdx.x * 128 + 68 + 2 * tl_turn] = wall_clock64() << 8 | (turn >= n_turns ? 3u : turn < n_quads ? 1u : 2u) | (turn < n_quads ? min(255u, L.cnt[L.quad[turn] & 1023u]) : 0u) << 2 & 0xfcu;
+        ++tl_turn;
+#endif
+        if (turn >= n_turns) break;   // wave-uniform: the ballots inside tile_locate and the shuffles of a quad need whole waves
+        if (turn < n_quads) {
+            const uint32_t e = L.quad[turn];
+            const uint32_t s = e & 1023u, qj = (e >> 10) & 63u, prow = e >> 16;
+            const uint32_t c = L.cnt[s], ni = (c + lc - 1) / lc;
+            const bool one = ni <= 4;                // the run is this one quad: finished here
+            const bool fin = one && !emit;
+            const uint32_t j = 4 * qj + (uint32_t)tile;
+            const uint32_t nh = j < ni ? min(lc, c - lc * j) : 0u;
+            const uint32_t run0 = L.off[s] + lc * j;
+            const int64_t key = (int64_t)(L.key[s] ^ kBias);
+            int64_t slot = -1;
+            if constexpr (LOCATED) slot = (int64_t)L.slot[s];
+            else {
+                bool is_new, full;
+                slot = tile_locate<false, false>(const_cast<int64_t*>(A.tkeys), A.nb, key, fin && tile == 0, tile, tl, is_new, full);
+            }
+            const bool upd = fin && slot >= 0 && tile == 0;
+            const RowAt at = row_at<GROUPED>(A, gdesc, slot, upd);
+            for (uint32_t col = tl; col < dim4; col += 16) {
+                const uint64_t o = at.row * dim4 + col;
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f), x1 = w, x2 = w;
+                if (upd) {   // the run's row is requested before its sources are summed: the update's round trip overlaps with the sum's
+                    w = at.values[o]; x1 = at.s1[o];
+                    if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
+                }
+                double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+                sum_sources<SPLIT>(L, A, bk, src_rec, rec_bucket0, run0, nh, dim4, col, sx, sy, sz, sw);
+                sx = tiles_sum(sx); sy = tiles_sum(sy); sz = tiles_sum(sz); sw = tiles_sum(sw);
+                if (tile != 0) continue;
+                if (upd) {
+                    opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
+                    store_row4(&at.values[o], w); store_row4(&at.s1[o], x1);
+                    if (KIND == MEE_OPT_ADAM) store_row4(&at.s2[o], x2);
+                } else if (!fin) {   // a quad of a longer run -> one fp64 partial row of this block | a whole run of a split bucket's slab -> its pending record
+                    if (one) rec_store_row4(bk.pend_row + ((uint64_t)(rec_out0 + L.run[s]) * dim4 + col) * 4, sx, sy, sz, sw);
+                    else {
+                        double2* dst = part_lds ? reinterpret_cast<double2*>(&L.prow[prow & (kLdsPartRows - 1)][(col & 15u) * 4])
+                                                : reinterpret_cast<double2*>(A.part + ((uint64_t)(L.part_base + prow) * dim4 + col) * 4);
+                        dst[0] = make_double2(sx, sy); dst[1] = make_double2(sz, sw);
+                    }
+                }
+            }
+            if (one && !fin && lane == 0) {
+                rec_store(bk.pend_key + rec_out0 + L.run[s], key);
+                if constexpr (LOCATED) rec_store(bk.pend_slot + rec_out0 + L.run[s], slot);
+            }
+            continue;
+        }
+        const uint32_t item = (turn - n_quads) * 4 + (uint32_t)tile;
         const bool valid = item < n_items;
-        const uint32_t e = valid ? L.items[item] : 0u;
-        const uint32_t s = e & 1023u, chunk = (e >> 10) & 31u, prow = e >> 15;
-        const uint32_t c = valid ? L.cnt[s] : 0u;
-        const uint32_t run0 = L.off[s] + kRun * chunk;
-        const uint32_t nh = valid ? min(kRun, c - kRun * chunk) : 0u;
-        const bool whole = valid && c <= kRun;   // the run is this one item
-        const bool fin = whole && !emit;         // finished here: locate the row, update it once
+        const uint32_t s = valid ? L.items[item] : 0u;
+        const uint32_t c = valid ? L.cnt[s] : 0u;   // <= lc: the run is this one item
+        const uint32_t run0 = L.off[s];
+        const bool fin = valid && !emit;            // finished here: locate the row, update it once
         const bool single = !src_rec && fin && c == 1;
         const int64_t key = (int64_t)(L.key[s] ^ kBias);
         const uint32_t src0 = valid ? L.src[run0] : 0u;
@@ -267,10 +445,13 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
         const RowAt at = row_at<GROUPED>(A, gdesc, slot, upd);
         for (uint32_t col = tl; col < dim4; col += 16) {
             const uint64_t o = at.row * dim4 + col;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f), x1 = w, x2 = w;
+            if (upd) {
+                w = at.values[o]; x1 = at.s1[o];
+                if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
+            }
             if (single) {   // gradient row (already requested) + the key's row -> update -> store; nothing else is live here
                 if (upd) {
-                    float4 w = at.values[o], x1 = at.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
                     const float4 g = col == (uint32_t)tl ? make_float4(gpre.x, gpre.y, gpre.z, gpre.w) : A.grads[(uint64_t)src0 * dim4 + col];
                     opt_update4(a, w, x1, x2, g);
                     store_row4(&at.values[o], w); store_row4(&at.s1[o], x1);
@@ -279,103 +460,69 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
                 continue;
             }
             double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-            if (src_rec) {
-                for (uint32_t q0 = 0; q0 < nh; q0 += 2) {   // two fp64 rows in flight; a lane past the end reads the last row again and adds +0.0
-                    double2 lo[2], hi[2];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const double2* r = reinterpret_cast<const double2*>(bk.pend_row + ((uint64_t)(rec_bucket0 + L.src[run0 + min(q0 + q, nh - 1)]) * dim4 + col) * 4);
-                        lo[q] = r[0]; hi[q] = r[1];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const bool on = q0 + q < nh;
-                        sx += on ? lo[q].x : 0.0; sy += on ? lo[q].y : 0.0; sz += on ? hi[q].x : 0.0; sw += on ? hi[q].y : 0.0;
-                    }
-                }
-            } else {
-                for (uint32_t q0 = 0; q0 < nh; q0 += 4) {   // four rows in flight, no one-row-at-a-time tail (see chunk_sum in meepo_table.hip)
-                    float4 gq[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) gq[q] = A.grads[(uint64_t)L.src[run0 + min(q0 + q, nh - 1)] * dim4 + col];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool on = q0 + q < nh;
-                        sx += on ? (double)gq[q].x : 0.0; sy += on ? (double)gq[q].y : 0.0; sz += on ? (double)gq[q].z : 0.0; sw += on ? (double)gq[q].w : 0.0;
-                    }
-                }
-            }
+            sum_sources<SPLIT>(L, A, bk, src_rec, rec_bucket0, run0, c, dim4, col, sx, sy, sz, sw);
             if (fin) {
                 if (upd) {
-                    float4 w = at.values[o], x1 = at.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
                     opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
                     store_row4(&at.values[o], w); store_row4(&at.s1[o], x1);
                     if (KIND == MEE_OPT_ADAM) store_row4(&at.s2[o], x2);
                 }
-            } else {   // a chunk of a long run -> one fp64 partial row of this block | a whole run of a split bucket's slab -> its pending record
-                double2* dst = whole ? reinterpret_cast<double2*>(bk.pend_row + ((uint64_t)(rec_out0 + L.run[s]) * dim4 + col) * 4)
-                                     : reinterpret_cast<double2*>(A.part + ((uint64_t)(L.part_base + prow) * dim4 + col) * 4);
-                dst[0] = make_double2(sx, sy); dst[1] = make_double2(sz, sw);
-            }
+            } else rec_store_row4(bk.pend_row + ((uint64_t)(rec_out0 + L.run[s]) * dim4 + col) * 4, sx, sy, sz, sw);   // a whole run of a split bucket's slab -> its pending record
         }
-        if (!fin && whole && tl == 0) {
-            bk.pend_key[rec_out0 + L.run[s]] = key;
-            if constexpr (LOCATED) bk.pend_slot[rec_out0 + L.run[s]] = slot;
+        if (!fin && tl == 0) {
+            rec_store(bk.pend_key + rec_out0 + L.run[s], key);
+            if constexpr (LOCATED) rec_store(bk.pend_slot + rec_out0 + L.run[s], slot);
         }
     }
     if constexpr (!SPLIT) MEE_TL(A, 4);   // this thread's items done
+    MEE_TLP(A, L, 2);
     if (n_big == 0) return;   // block-uniform
-    // ---- 4. runs longer than kRun: one tile adds the run's chunk sums (written by this block: visible after the barrier) and finishes the run ----
+    // ---- 4. runs of several quads: a wave adds the run's partial rows (written by this block: visible after the barrier), tile u rows u, u + 4, …,
+    //         and finishes the run ----
     __syncthreads();
-    for (uint32_t k0 = (uint32_t)wv * 4; k0 < n_big; k0 += kApplyWaves * 4) {
-        const uint32_t k = k0 + tile;
-        const bool valid = k < n_big;
-        const uint32_t e = valid ? L.big[k] : 0u;
-        const uint32_t s = e & 1023u, p0 = (e >> 10) & 1023u, np = e >> 20;
-        const bool fin = valid && !emit;
+    MEE_TLP(A, L, 3);
+    for (uint32_t k = t >> 6; k < n_big; k += kApplyWaves) {   // wave-uniform
+        const uint32_t e = L.big[k];
+        const uint32_t s = e & 1023u, p0 = (e >> 10) & 4095u, nq = e >> 22;
+        const bool fin = !emit;
         const int64_t key = (int64_t)(L.key[s] ^ kBias);
         int64_t slot = -1;
-        if constexpr (LOCATED) slot = valid ? (int64_t)L.slot[s] : -1;
+        if constexpr (LOCATED) slot = (int64_t)L.slot[s];
         else {
             bool is_new, full;
-            slot = tile_locate<false, false>(const_cast<int64_t*>(A.tkeys), A.nb, key, fin, tile, tl, is_new, full);
+            slot = tile_locate<false, false>(const_cast<int64_t*>(A.tkeys), A.nb, key, fin && tile == 0, tile, tl, is_new, full);
         }
-        if (!valid) continue;
-        const bool upd = fin && slot >= 0;
+        const bool upd = fin && slot >= 0 && tile == 0;
         const RowAt at = row_at<GROUPED>(A, gdesc, slot, upd);
         for (uint32_t col = tl; col < dim4; col += 16) {
             const uint64_t o = at.row * dim4 + col;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f), x1 = w, x2 = w;
+            if (upd) {
+                w = at.values[o]; x1 = at.s1[o];
+                if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
+            }
             double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-            for (uint32_t q0 = 0; q0 < np; q0 += 2) {
-                double2 lo[2], hi[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const double2* r = reinterpret_cast<const double2*>(A.part + ((uint64_t)(L.part_base + p0 + min(q0 + q, np - 1)) * dim4 + col) * 4);
-                    lo[q] = r[0]; hi[q] = r[1];
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const bool on = q0 + q < np;
-                    sx += on ? lo[q].x : 0.0; sy += on ? lo[q].y : 0.0; sz += on ? hi[q].x : 0.0; sw += on ? hi[q].y : 0.0;
-                }
+            for (uint32_t q0 = (uint32_t)tile; q0 < nq; q0 += 8) {   // two rows in flight per tile (nq <= 8: one round trip)
+                const uint32_t q1 = q0 + 4;
+                const double2* r0 = part_lds ? reinterpret_cast<const double2*>(&L.prow[(p0 + q0) & (kLdsPartRows - 1)][(col & 15u) * 4])
+                                             : reinterpret_cast<const double2*>(A.part + ((uint64_t)(L.part_base + p0 + q0) * dim4 + col) * 4);
+                const double2* r1 = part_lds ? reinterpret_cast<const double2*>(&L.prow[(p0 + min(q1, nq - 1)) & (kLdsPartRows - 1)][(col & 15u) * 4])
+                                             : reinterpret_cast<const double2*>(A.part + ((uint64_t)(L.part_base + p0 + min(q1, nq - 1)) * dim4 + col) * 4);
+                const double2 a0 = r0[0], b0 = r0[1], a1 = r1[0], b1 = r1[1];
+                const bool on = q1 < nq;
+                sx += a0.x + (on ? a1.x : 0.0); sy += a0.y + (on ? a1.y : 0.0); sz += b0.x + (on ? b1.x : 0.0); sw += b0.y + (on ? b1.y : 0.0);
             }
-            if (fin) {
-                if (upd) {
-                    float4 w = at.values[o], x1 = at.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
-                    opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
-                    store_row4(&at.values[o], w); store_row4(&at.s1[o], x1);
-                    if (KIND == MEE_OPT_ADAM) store_row4(&at.s2[o], x2);
-                }
-            } else {
-                double2* dst = reinterpret_cast<double2*>(bk.pend_row + ((uint64_t)(rec_out0 + L.run[s]) * dim4 + col) * 4);
-                dst[0] = make_double2(sx, sy); dst[1] = make_double2(sz, sw);
-            }
+            sx = tiles_sum(sx); sy = tiles_sum(sy); sz = tiles_sum(sz); sw = tiles_sum(sw);
+            if (tile != 0) continue;
+            if (upd) {
+                opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
+                store_row4(&at.values[o], w); store_row4(&at.s1[o], x1);
+                if (KIND == MEE_OPT_ADAM) store_row4(&at.s2[o], x2);
+            } else if (!fin) rec_store_row4(bk.pend_row + ((uint64_t)(rec_out0 + L.run[s]) * dim4 + col) * 4, sx, sy, sz, sw);
         }
-        if (!fin && tl == 0) {
-            bk.pend_key[rec_out0 + L.run[s]] = key;
-            if constexpr (LOCATED) bk.pend_slot[rec_out0 + L.run[s]] = slot;
+        if (!fin && lane == 0) {
+            rec_store(bk.pend_key + rec_out0 + L.run[s], key);
+            if constexpr (LOCATED) rec_store(bk.pend_slot + rec_out0 + L.run[s], slot);
         }
     }
 }
@@ -394,7 +541,7 @@ __device__ __forceinline__ void mono_pass(ApplyLds& L, const ApplyArgs& A, const
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t pb = atomicAdd(&A.op->n_part, kTiles);
-        if (pb + kTiles > A.max_part) pb = 0u;   // (see process_slab)
+        if (pb + kTiles > A.max_part) { pb = 0u; atomicOr(A.status, (uint32_t)MEE_STATUS_INTERNAL); }   // (see process_slab)
         L.part_base = pb;
     }
     __syncthreads();
@@ -406,9 +553,9 @@ __device__ __forceinline__ void mono_pass(ApplyLds& L, const ApplyArgs& A, const
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const uint32_t j = min(j0 + (uint32_t)u * kTiles, R - 1);
-                on[u] = j0 + (uint32_t)u * kTiles < R && bk.pend_key[beg + j] == key;
-                const double2* r = reinterpret_cast<const double2*>(bk.pend_row + ((uint64_t)(beg + j) * dim4 + col) * 4);
-                lo[u] = r[0]; hi[u] = r[1];
+                on[u] = j0 + (uint32_t)u * kTiles < R && rec_load(bk.pend_key + beg + j) == key;
+                const double* r = bk.pend_row + ((uint64_t)(beg + j) * dim4 + col) * 4;
+                lo[u] = make_double2(rec_load(r), rec_load(r + 1)); hi[u] = make_double2(rec_load(r + 2), rec_load(r + 3));
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) { sx += on[u] ? lo[u].x : 0.0; sy += on[u] ? lo[u].y : 0.0; sz += on[u] ? hi[u].x : 0.0; sw += on[u] ? hi[u].y : 0.0; }
@@ -418,7 +565,7 @@ __device__ __forceinline__ void mono_pass(ApplyLds& L, const ApplyArgs& A, const
     }
     __syncthreads();   // the partial rows were written by this block: visible to its tile 0 after the barrier
     int64_t slot;
-    if constexpr (LOCATED) slot = bk.pend_slot[beg + any_rec];   // every record of the key carries its slot
+    if constexpr (LOCATED) slot = rec_load(bk.pend_slot + beg + any_rec);   // every record of the key carries its slot
     else {
         bool is_new, full;
         slot = tile_locate<false, false>(const_cast<int64_t*>(A.tkeys), A.nb, key, q == 0, tile, tl, is_new, full);
@@ -468,182 +615,254 @@ __device__ __forceinline__ void seg_scan(ApplyLds& L, const SegRuns& r, uint32_t
     L.seg_at[k0 + 1] = r.at1;
 }
 
-// The two roles of the apply kernel.  bucket_role: one block per bucket, for the buckets that fit one slab — all of them on a batch without
-// hot keys.  split_role: the slabs of the buckets that do not, and their merges — few blocks with long chains (slab, hand-off, merge), so
-// they lead the grid.  They are separate code paths of ONE kernel, each with its own instance of process_slab: the bucket role's needs 64
-// VGPRs, the split role's 107 — one shared instance (emit / src_rec as run-time flags inside a loop) kept the rare path's state live in every
-// block's hot path.  The kernel is bounded to 80 VGPRs (MEE_APPLY_WAVES = 6, meepo_apply_part.h: three 512-thread blocks per CU); what does
-// not fit spills in the split role only (24-56 B per lane).  Tried instead: two kernels, the second launched with hipExtAnyOrderLaunch so
-// that they share the device — the flag is not supported on gfx9, the launches serialise (Zipf(1.05): 48 + 39 us against 79 us); the split
-// role as a __noinline__ function — a kernel's register allocation covers its callees (400-500 B of stack per lane).
-template <int KIND, int DIM4, bool LOCATED, bool GROUPED>
-__device__ __forceinline__ void bucket_role(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t b, const GroupDesc* gdesc) {
-    // ONE round trip brings everything the block must know before it can fetch its entries: which copy of the totals this batch's partition
-    // filled (bk.seq[1], meepo_apply_part.h), the bucket's total in BOTH copies, and — lanes of wave 0 — the lengths and places of the bucket's
-    // runs in the partition blocks' slices.  (As a chain seq -> total -> run lengths these were three dependent loads, 2-3 us of every block's
-    // life before its first useful request.)
-    MEE_TL(A, 0);
-    const SegRuns runs = seg_load(A, bk, b, threadIdx.x);
-    const uint32_t tot0 = bk.tot[b], tot1 = bk.tot[bk.n_buckets_max + b];
-    const uint32_t parity = bk.seq[1];
-    if (b == 0 && threadIdx.x == 0) atomicAdd(&bk.seq[0], 1u);   // this partition is consumed: the next one fills the other copy
-    const uint32_t size = __builtin_amdgcn_readfirstlane(parity ? tot1 : tot0);
-    if (size == 0 || size > kSlab) return;   // an empty bucket | a split bucket: the spare blocks (split_role) have it
-    MEE_TL(A, 1);   // first round trip done (size known)
-#if MEE_APPLY_TIMELINE
-    if (threadIdx.x == 0) { A.dbg[(uint64_t)blockIdx.x * 8 + 6] = size | (unsigned long long)b << 32; unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); A.dbg[(uint64_t)blockIdx.x * 8 + 7] = (unsigned long long)(xcc & 0xf) << 32 | hw; }
-#endif
-    seg_scan(L, runs, threadIdx.x);
-    process_slab<KIND, DIM4, LOCATED, false, GROUPED>(L, A, bk, 0, size, false, false, b, 0, gdesc);
-    MEE_TL(A, 5);
-}
-
-template <int KIND, int DIM4, bool LOCATED, bool GROUPED>
-__device__ __forceinline__ void split_role(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t e0, const uint32_t stride, const GroupDesc* gdesc) {
-    // Block e takes slabs e, e + stride, … of the buckets that hold more than one slab (a hot key), found by a prefix sum over the bucket
-    // totals — and leaves at once when the partition saw no such bucket.
-    const uint32_t hs0 = bk.has_split[0], hs1 = bk.has_split[1];
-    const uint32_t parity = __builtin_amdgcn_readfirstlane(bk.seq[1]);   // which copy of the totals this batch's partition filled
-    if (!__builtin_amdgcn_readfirstlane(parity ? hs1 : hs0)) return;
+// A batch WITHOUT a split bucket (every batch of a uniform key stream): block = bucket, and the kernel's first lines are all there is to it.
+// A SKEWED batch (some bucket holds more than kBucketCap positions: a key with >= ~700 occurrences) is a list of units — first the slabs of the
+// split buckets (kSlab positions each; long chains: slab, hand-off, merge — so they come first), then the buckets.  Block i starts with unit
+// i; a block that has finished its unit claims the next one beyond the grid from a counter (bk.claim), so that whatever the sizes of the units
+// every resident block slot has work until the list is exhausted.  (Before: 256 spare blocks at the head of the grid looped over the slabs with
+// a stride and re-scanned the bucket totals for every slab, while the buckets' blocks waited for their slots: on Zipf(1.05) the last quarter of
+// the bucket blocks started 30 us into the kernel, and the chains of the spare blocks ended at 70-79 us.)
+//
+// The slab machinery needs more registers (107-119) than the bucket path (77); the kernel is bounded to 80 (MEE_APPLY_WAVES = 6: three 512-thread
+// blocks per CU) and what does not fit spills in the skewed path only.  Tried instead: two kernels, the second launched with
+// hipExtAnyOrderLaunch so that they share the device — the flag is not supported on gfx9, the launches serialise; the slab path as a
+// __noinline__ function — a kernel's register allocation covers its callees (400-500 B of stack per lane).
+constexpr uint32_t kGroupDescLds = 64;   // members whose descriptors a GROUPED kernel stages in LDS (3 KB): larger groups read them from device memory
+// The units of one block.  SKEW = false (a batch without a split bucket): block = bucket, straight-line code, everything the block needs came
+// with the kernel's first round trip (runs0, size0).  SKEW = true: the unit list, slabs first; the two are separate instances so that the
+// registers the slab machinery needs (111-124; the kernel is bounded to 80: three blocks per CU) never spill in the path of a uniform batch (77).
+template <int KIND, int DIM4, bool LOCATED, bool GROUPED, bool SKEW>
+__device__ __forceinline__ void run_units(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t parity, SegRuns runs, const uint32_t size0, const uint32_t pre_a, const uint32_t pre_b,
+                                          const GroupDesc* gdesc) {
     const uint32_t tot_base = parity * bk.n_buckets_max;
-    for (uint32_t e = e0;; e += stride) {
+    constexpr bool skew = SKEW;
+    uint32_t S = 0;   // slabs of split buckets = the first units of a skewed batch
+    if constexpr (SKEW) {
+        // ONE scan over the bucket totals: the slabs and the positions in front of each thread's buckets (the positions = where a split bucket's
+        // pending records begin: records never outnumber positions), left in LDS for whoever resolves a unit later
+        const uint32_t per_t = (A.nbk + kApplyThreads - 1) / kApplyThreads;   // buckets [t * per_t, (t + 1) * per_t) belong to thread t
+        unsigned long long mine = 0;
+        for (uint32_t q = 0; q < per_t; ++q) {
+            const uint32_t bb = threadIdx.x * per_t + q;
+            // (up to two buckets per thread — batches of up to ~340K keys — came with the kernel's first round trip)
+            const uint32_t tt = per_t <= 2 ? (q ? pre_b : pre_a) : bb < A.nbk ? bk.tot[tot_base + bb] : 0u;
+            mine += (unsigned long long)(tt > kBucketCap ? (tt + kSlab - 1) / kSlab : 0u) | (unsigned long long)tt << 32;
+        }
+        unsigned long long total;
+        const unsigned long long ex = block_scan_u64<kApplyWaves>(mine, L.wsum, total);
+        L.pre_slabs[threadIdx.x] = (uint32_t)ex; L.pre_pos[threadIdx.x] = (uint32_t)(ex >> 32); L.pre_a[threadIdx.x] = pre_a;
+        if (threadIdx.x == 0) { L.pre_slabs[kApplyThreads] = (uint32_t)total; L.pre_pos[kApplyThreads] = (uint32_t)(total >> 32); }
+        S = (uint32_t)total;
+        MEE_TLS(A, blockIdx.x, 0, wall_clock64());
+    }
+    // Who takes what (G = the grid = the bucket count).  Round 0: block i takes slab i if there is one, else bucket i — the bucket whose totals
+    // and run matrix came with the kernel's first round trip.  The slabs beyond G (more slabs than blocks: a batch that is mostly one key) and
+    // the buckets the slabs displaced, [0, min(S, nbk)), follow in rounds of G, dealt from the LAST block downwards: the blocks that began with
+    // a bucket (short) take a second unit, the blocks that began with a slab (slab, hand-off, perhaps the bucket's merge) do not.  No counter:
+    // 768 blocks that claim their next unit from one word within a few microseconds of each other wait ~15 us for it (measured).
+    const uint32_t G = gridDim.x, S0 = min(S, G), n_late_slabs = S - S0, n_late = n_late_slabs + min(S, A.nbk);
+    if (SKEW && blockIdx.x == 0 && threadIdx.x == 0) *A.h_slabs = S;   // (pinned host word: the next partition sizes its bucket count and grid by it)
+    [[maybe_unused]] uint32_t tl_i = 0, tl_units = 0;
+    for (uint32_t round = 0;; ++round) {
         // (the thread index is re-read through an empty asm in every turn, as in process_slab: hoisted out of this loop, the per-thread addresses
-        // of everything below stayed live across the whole role and were spilled to scratch — a memory round trip in front of every use)
+        // of everything below stayed live across the whole loop and were spilled to scratch — a memory round trip in front of every use)
         uint32_t tx = threadIdx.x;
         asm volatile("" : "+v"(tx));
-        uint32_t b, sub;
-        {
-            const uint32_t per_t = (A.nbk + kApplyThreads - 1) / kApplyThreads;
-            unsigned long long mine = 0;
-            for (uint32_t q = 0; q < per_t; ++q) {
-                const uint32_t bb = tx * per_t + q;
-                const uint32_t tt = bb < A.nbk ? bk.tot[tot_base + bb] : 0u;
-                mine += tt > kSlab ? (tt + kSlab - 1) / kSlab : 0u;
+        bool is_slab = false;
+        uint32_t u = blockIdx.x;   // slab number | bucket number
+        if constexpr (SKEW) {
+            if (round == 0) {
+                is_slab = u < S;
+                if (!is_slab && u >= A.nbk) continue;   // (block-uniform) a block beyond the buckets that no slab needs either: straight to the later rounds
+            } else {
+                const uint32_t j = (round - 1) * G + (G - 1 - blockIdx.x);
+                if (j >= n_late) break;   // block-uniform
+                is_slab = j < n_late_slabs;
+                u = is_slab ? S0 + j : j - n_late_slabs;
             }
-            unsigned long long total;
-            const uint32_t ex = (uint32_t)block_scan_u64<kApplyWaves>(mine, L.wsum, total);
-            if (e >= (uint32_t)total) return;   // block-uniform
-            if (e >= ex && e < ex + (uint32_t)mine) {   // exactly one thread
-                uint32_t acc = ex;
-                for (uint32_t q = 0; q < per_t; ++q) {
-                    const uint32_t bb = tx * per_t + q;
-                    const uint32_t tt = bb < A.nbk ? bk.tot[tot_base + bb] : 0u;
-                    const uint32_t x = tt > kSlab ? (tt + kSlab - 1) / kSlab : 0u;
-                    if (e < acc + x) { L.rec_base = bb; L.n_cand = e - acc; break; }
-                    acc += x;
+        }
+        ++tl_units;
+        if (SKEW && is_slab) {   // ---- a slab of a split bucket (block-uniform) ----
+            __syncthreads();   // (the scan's LDS stores; L.u_* of the unit before)
+            {   // the thread whose buckets hold slab u publishes (bucket, slab of the bucket, size, first pending record)
+                const uint32_t lo = L.pre_slabs[tx], hi = L.pre_slabs[tx + 1];
+                if (u >= lo && u < hi) {   // exactly one thread
+                    const uint32_t per_t = (A.nbk + kApplyThreads - 1) / kApplyThreads;
+                    uint32_t acc = lo, pacc = L.pre_pos[tx];
+                    for (uint32_t q = 0; q < per_t; ++q) {
+                        const uint32_t bb = tx * per_t + q;
+                        // (two buckets per thread at most: the first one's total is in LDS, the second one's is the rest of the thread's positions)
+                        const uint32_t tt = per_t <= 2 ? (q ? L.pre_pos[tx + 1] - L.pre_pos[tx] - L.pre_a[tx] : L.pre_a[tx]) : bb < A.nbk ? bk.tot[tot_base + bb] : 0u;
+                        const uint32_t x = tt > kBucketCap ? (tt + kSlab - 1) / kSlab : 0u;
+                        if (u < acc + x) { L.u_b = bb; L.u_sub = u - acc; L.u_size = tt; L.u_beg = pacc; break; }
+                        acc += x; pacc += tt;
+                    }
                 }
             }
             __syncthreads();
-            b = __builtin_amdgcn_readfirstlane(L.rec_base); sub = __builtin_amdgcn_readfirstlane(L.n_cand);
-            __syncthreads();
-        }
-        const uint32_t size = __builtin_amdgcn_readfirstlane(bk.tot[tot_base + b]);
-        seg_scan(L, seg_load(A, bk, b, tx), tx);   // the bucket's runs in the partition blocks' slices
-        uint32_t beg;   // the bucket's first pending record = the keys in the buckets before it (records never outnumber positions)
-        {
-            unsigned long long mine = 0, total;
-            for (uint32_t bb = tx; bb < b; bb += kApplyThreads) mine += bk.tot[tot_base + bb];
-            (void)block_scan_u64<kApplyWaves>(mine, L.wsum, total);
-            beg = __builtin_amdgcn_readfirstlane((uint32_t)total);
-            __syncthreads();
-        }
-        // the slab first; in the bucket's LAST slab the same loop then runs the merge passes (src_rec)
-        bool merging = false;
-        uint32_t first = sub * kSlab, m = min(kSlab, size - sub * kSlab), R = 0, bits0 = 0;
-        uint64_t v0 = 0;
-        bool done = false;
-        while (!done) {
-            process_slab<KIND, DIM4, LOCATED, true, GROUPED>(L, A, bk, first, m, !merging, merging, b, beg, gdesc);
-            if (!merging) {
-                // ---- publish this slab's pending records, take a ticket; the slab that draws the last ticket merges the bucket.  (The in-launch
-                // hand-off of cdna_hip_programming.md Guideline 16 in its counter form: plain stores, every wave drains them, one lane releases at
-                // agent scope, THEN the ticket; the last arriver acquires at agent scope before any of its waves reads a record.  No block ever
-                // waits for another.)
-                const uint32_t nsub = (size + kSlab - 1) / kSlab;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const uint32_t b = __builtin_amdgcn_readfirstlane(L.u_b), sub = __builtin_amdgcn_readfirstlane(L.u_sub);
+            const uint32_t size = __builtin_amdgcn_readfirstlane(L.u_size), beg = __builtin_amdgcn_readfirstlane(L.u_beg);
+#if MEE_APPLY_TIMELINE
+            if (threadIdx.x == 0) L.tl_w = blockIdx.x * 128 + 4 + 16 * min(tl_i, 5u);
+#endif
+            MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 0, wall_clock64());
+            MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 5, (unsigned long long)b | (unsigned long long)sub << 16 | (unsigned long long)size << 32);
+            seg_scan(L, seg_load(A, bk, b, tx), tx);   // the bucket's runs in the partition blocks' slices
+            // the slab first; in the bucket's LAST slab the same loop then runs the merge passes (src_rec)
+            bool merging = false, one_pass = false;
+            uint32_t first = sub * kSlab, m = min(kSlab, size - sub * kSlab), R = 0, bits0 = 0;
+            uint64_t v0 = 0;
+            bool done = false;
+            while (!done) {
+                process_slab<KIND, DIM4, LOCATED, true, GROUPED>(L, A, bk, first, m, !merging, merging, b, beg, gdesc);
+                if (!merging) MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 1, wall_clock64());
+                else MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 4, wall_clock64());
+                if (merging && one_pass) break;
+                if (!merging) {
+                    // ---- publish this slab's pending records, take a ticket; the slab that draws the last ticket merges the bucket.  The records
+                    // were written through (rec_store), every wave drains its stores, THEN the ticket; the merger reads them with agent-scope
+                    // loads (rec_load).  No block ever waits for another.
+                    const uint32_t nsub = (size + kSlab - 1) / kSlab;
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const uint32_t tk = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    L.is_last = tk == nsub - 1;
-                    if (tk == nsub - 1) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (threadIdx.x == 0) {
+                        const uint32_t tk = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        L.is_last = tk == nsub - 1;
                     }
+                    __syncthreads();
+                    MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 2, wall_clock64());
+                    if (!L.is_last) break;   // block-uniform: on to this block's next unit
+                    merging = true;
+                    R = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&bk.pend_cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // every slab added its runs before its ticket
+                    MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 6, (unsigned long long)R);
+                    first = 0;
+                    if (R <= kSlab) {   // (the usual case) the bucket's records fit ONE pass: all of them, no selection
+                        if (tx < R) L.src[tx] = tx;
+                        m = R; one_pass = true;
+                        MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 3, wall_clock64());
+                        continue;   // (process_slab begins with a barrier)
+                    }
+                    // Merge in passes: records of one key must meet in one pass and a pass holds kSlab records, so the records are taken by the low bits
+                    // of mix64b(key): `bits0` bits give passes of ~256 records; a pass that still finds more than kSlab splits on one more bit, and a
+                    // pass whose records all carry ONE key goes to mono_pass (mix64b is a bijection: the splitting ends).
+                    while (((uint64_t)kSlab / 2 << bits0) < R && bits0 < 40) ++bits0;
+                    v0 = 0;
+                    if (threadIdx.x == 0) L.stk_n = 0u;
                 }
-                __syncthreads();
-                if (!L.is_last) break;   // block-uniform: on to this block's next slab
-                // Merge: records of one key must meet in one pass and a pass holds kSlab records, so the records are taken by the low bits of
-                // mix64b(key): `bits0` bits give passes of ~256 records; a pass that still finds more than kSlab splits on one more bit, and a
-                // pass whose records all carry ONE key goes to mono_pass (mix64b is a bijection: the splitting ends).
-                merging = true;
-                R = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&bk.pend_cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // every slab added its runs before its ticket
-                while (((uint64_t)kSlab / 2 << bits0) < R && bits0 < 40) ++bits0;
-                v0 = 0;
-                if (threadIdx.x == 0) L.stk_n = 0u;
-                first = 0;
+                // ---- the next merge pass: pop a hash prefix, collect its records; too many -> split the prefix (or one key: mono_pass) ----
+                m = 0;
+                while (m == 0 && !done) {   // block-uniform
+                    __syncthreads();
+                    if (L.stk_n == 0) {
+                        if (v0 >> bits0) { done = true; break; }   // every prefix done
+                        __syncthreads();
+                        if (threadIdx.x == 0) { L.stk_n = 1u; L.stk_bits[0] = bits0; L.stk_val[0] = v0; }
+                        ++v0;
+                        __syncthreads();
+                    }
+                    const uint32_t top = __builtin_amdgcn_readfirstlane(L.stk_n - 1), bits = __builtin_amdgcn_readfirstlane(L.stk_bits[top]);
+                    const unsigned long long val_v = L.stk_val[top];
+                    const uint64_t val = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)val_v) |
+                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(val_v >> 32)) << 32;
+                    const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
+                    __syncthreads();
+                    if (threadIdx.x == 0) { L.stk_n = top; L.n_cand = 0u; L.kmin = ~0ull; L.kmax = 0ull; }
+                    __syncthreads();
+                    for (uint32_t j = threadIdx.x; j < R; j += kApplyThreads) {
+                        const int64_t kj = rec_load(bk.pend_key + beg + j);
+                        if ((mix64b((uint64_t)kj) & mask) != val) continue;
+                        const uint32_t q = atomicAdd(&L.n_cand, 1u);
+                        if (q < kSlab) L.src[q] = j;
+                        atomicMin(&L.kmin, (unsigned long long)kj ^ kBias);
+                        atomicMax(&L.kmax, (unsigned long long)kj ^ kBias);
+                    }
+                    __syncthreads();
+                    const uint32_t nc = __builtin_amdgcn_readfirstlane(L.n_cand);
+                    if (nc > kSlab) {
+                        if (L.kmin == L.kmax) {   // more records of ONE key than a pass holds
+                            mono_pass<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, beg, R, (int64_t)(L.kmin ^ kBias), L.src[0], gdesc);
+                        } else if (threadIdx.x == 0 && bits < 64 && L.stk_n + 2 <= 72) {
+                            L.stk_bits[L.stk_n] = bits + 1; L.stk_val[L.stk_n] = val; ++L.stk_n;
+                            L.stk_bits[L.stk_n] = bits + 1; L.stk_val[L.stk_n] = val | 1ull << bits; ++L.stk_n;
+                        }
+                    } else m = nc;
+                }
+                if (m) MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 3, wall_clock64());   // the latest merge pass's records are collected
             }
-            // ---- the next merge pass: pop a hash prefix, collect its records; too many -> split the prefix (or one key: mono_pass) ----
-            m = 0;
-            while (m == 0 && !done) {   // block-uniform
-                __syncthreads();
-                if (L.stk_n == 0) {
-                    if (v0 >> bits0) { done = true; break; }   // every prefix done
-                    __syncthreads();
-                    if (threadIdx.x == 0) { L.stk_n = 1u; L.stk_bits[0] = bits0; L.stk_val[0] = v0; }
-                    ++v0;
-                    __syncthreads();
-                }
-                const uint32_t top = __builtin_amdgcn_readfirstlane(L.stk_n - 1), bits = __builtin_amdgcn_readfirstlane(L.stk_bits[top]);
-                const unsigned long long val_v = L.stk_val[top];
-                const uint64_t val = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)val_v) |
-                                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(val_v >> 32)) << 32;
-                const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
-                __syncthreads();
-                if (threadIdx.x == 0) { L.stk_n = top; L.n_cand = 0u; L.kmin = ~0ull; L.kmax = 0ull; }
-                __syncthreads();
-                for (uint32_t j = threadIdx.x; j < R; j += kApplyThreads) {
-                    const int64_t kj = bk.pend_key[beg + j];
-                    if ((mix64b((uint64_t)kj) & mask) != val) continue;
-                    const uint32_t q = atomicAdd(&L.n_cand, 1u);
-                    if (q < kSlab) L.src[q] = j;
-                    atomicMin(&L.kmin, (unsigned long long)kj ^ kBias);
-                    atomicMax(&L.kmax, (unsigned long long)kj ^ kBias);
-                }
-                __syncthreads();
-                const uint32_t nc = __builtin_amdgcn_readfirstlane(L.n_cand);
-                if (nc > kSlab) {
-                    if (L.kmin == L.kmax) {   // more records of ONE key than a pass holds
-                        mono_pass<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, beg, R, (int64_t)(L.kmin ^ kBias), L.src[0], gdesc);
-                    } else if (threadIdx.x == 0 && bits < 64 && L.stk_n + 2 <= 72) {
-                        L.stk_bits[L.stk_n] = bits + 1; L.stk_val[L.stk_n] = val; ++L.stk_n;
-                        L.stk_bits[L.stk_n] = bits + 1; L.stk_val[L.stk_n] = val | 1ull << bits; ++L.stk_n;
-                    }
-                } else m = nc;
+            MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 7, wall_clock64());
+            ++tl_i;
+        } else {   // ---- a bucket ----
+            const uint32_t b = u;
+            uint32_t size = size0;
+            if (SKEW && round != 0) {   // (round 0: the block's own bucket, everything came with the kernel's first round trip)
+                runs = seg_load(A, bk, b, tx);
+                size = __builtin_amdgcn_readfirstlane(bk.tot[tot_base + b]);
+            }
+            if (skew) MEE_TLS(A, blockIdx.x, 100 + 4 * min(tl_units - tl_i - 1, 6u), wall_clock64());
+            if (size != 0 && size <= kBucketCap) {   // (an empty bucket | a split bucket: its slabs' business)
+                MEE_TL(A, 1);   // first round trip done (size known)
+#if MEE_APPLY_TIMELINE
+                if (threadIdx.x == 0 && !skew) { A.dbg[(uint64_t)blockIdx.x * 8 + 6] = size | (unsigned long long)b << 32; unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); A.dbg[(uint64_t)blockIdx.x * 8 + 7] = (unsigned long long)(xcc & 0xf) << 32 | hw; }
+#endif
+                seg_scan(L, runs, tx);
+                process_slab<KIND, DIM4, LOCATED, false, GROUPED>(L, A, bk, 0, size, false, false, b, 0, gdesc);
+                MEE_TL(A, 5);
+            }
+            if (skew) {
+                MEE_TLS(A, blockIdx.x, 101 + 4 * min(tl_units - tl_i - 1, 6u), wall_clock64());
+                MEE_TLS(A, blockIdx.x, 102 + 4 * min(tl_units - tl_i - 1, 6u), (unsigned long long)b | (unsigned long long)size << 32);
             }
         }
-    }   // next slab of this block
+        if (!SKEW || n_late == 0) break;   // (block-uniform: every unit has its block — every batch without a split bucket)
+        __syncthreads();   // (the unit's last readers of the LDS tables | the next unit's first writers)
+    }
+    if (skew) {
+        MEE_TLS(A, blockIdx.x, 1, (unsigned long long)(tl_i) | (unsigned long long)(tl_units) << 32);
+        MEE_TLS(A, blockIdx.x, 3, wall_clock64());
+    }
 }
 
-constexpr uint32_t kGroupDescLds = 64;   // members whose descriptors a GROUPED kernel stages in LDS (3 KB): larger groups read them from device memory
 template <int KIND, int DIM4, bool LOCATED, bool GROUPED = false>
 __global__ __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES) void bkt_apply_kernel(ApplyArgs A, BucketScratch bk) {
     __shared__ ApplyLds L;
     const GroupDesc* gdesc = nullptr;
-    if constexpr (GROUPED) {   // the members' planes: needed once per work item, so they come out of LDS (the first barrier inside the roles publishes them)
+    if constexpr (GROUPED) {   // the members' planes: needed once per work item, so they come out of LDS (the first barrier inside process_slab publishes them)
         __shared__ GroupDesc gd[kGroupDescLds];
         if (A.n_tables <= kGroupDescLds) {
             for (uint32_t j = threadIdx.x; j < A.n_tables; j += kApplyThreads) gd[j] = A.desc[j];
             gdesc = gd;
         }
     }
-    if (blockIdx.x < A.n_extra) split_role<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, blockIdx.x, A.n_extra, gdesc);   // block-uniform
-#if MEE_APPLY_TIMELINE == 2   // diagnostic: decouple a bucket's parity from its block's XCD (blocks are dealt round-robin over the 8 XCDs)
-    else { const uint32_t i = blockIdx.x - A.n_extra; bucket_role<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, (i ^ ((i >> 3) & 1u)) < A.nbk ? i ^ ((i >> 3) & 1u) : i, gdesc); }
-#else
-    else bucket_role<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, blockIdx.x - A.n_extra, gdesc);
+    // ONE round trip brings everything the block must know before it can fetch its entries: which copy of the totals this batch's partition
+    // filled (bk.seq[1], meepo_apply_part.h), whether that partition met a split bucket, this block's bucket total in BOTH copies, and — lanes of
+    // wave 0 — the lengths and places of the bucket's runs in the partition blocks' slices.  (As a chain seq -> total -> run lengths these were
+    // three dependent loads, 2-3 us of every block's life before its first useful request.)
+    MEE_TL(A, 0);
+    // (the grid is the bucket count, plus — behind a skewed batch — as many blocks as that batch had slabs: they have no bucket of their own)
+    const bool own = blockIdx.x < A.nbk;
+    const SegRuns runs = seg_load(A, bk, own ? blockIdx.x : 0u, own ? threadIdx.x : 64u);
+    const uint32_t tot0 = own ? bk.tot[blockIdx.x] : 0u, tot1 = own ? bk.tot[bk.n_buckets_max + blockIdx.x] : 0u;
+    const uint32_t hs0 = bk.has_split[0], hs1 = bk.has_split[1];
+    // (what a skewed batch needs next — the totals of the <= 2 buckets this thread owns in the blocks' common scan, both copies — travels with
+    // it: 4 loads of L1-resident lines per thread, instead of a dependent round trip in front of every block of a skewed batch)
+    uint32_t pa0 = 0, pa1 = 0, pb0 = 0, pb1 = 0;
+    if (A.nbk <= 2 * kApplyThreads) {
+        const uint32_t per_t = (A.nbk + kApplyThreads - 1) / kApplyThreads, ba = threadIdx.x * per_t, bb = ba + 1;
+        if (ba < A.nbk) { pa0 = bk.tot[ba]; pa1 = bk.tot[bk.n_buckets_max + ba]; }
+        if (per_t == 2 && bb < A.nbk) { pb0 = bk.tot[bb]; pb1 = bk.tot[bk.n_buckets_max + bb]; }
+    }
+    const uint32_t parity = __builtin_amdgcn_readfirstlane(bk.seq[1]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&bk.seq[0], 1u);   // this partition is consumed: the next one fills the other copy
+#ifndef MEE_APPLY_ONLY_ROLE   // diagnostic (tools/resource_usage.sh file -DMEE_APPLY_ONLY_ROLE=1|2): the registers ONE path needs — 1 = batches without a split bucket, 2 = skewed batches
+#define MEE_APPLY_ONLY_ROLE 0
 #endif
+    const uint32_t size0 = __builtin_amdgcn_readfirstlane(parity ? tot1 : tot0);
+    if (__builtin_amdgcn_readfirstlane(parity ? hs1 : hs0) != 0) {   // block-uniform
+        if (MEE_APPLY_ONLY_ROLE != 1) run_units<KIND, DIM4, LOCATED, GROUPED, true>(L, A, bk, parity, runs, size0, parity ? pa1 : pa0, parity ? pb1 : pb0, gdesc);
+    } else if (MEE_APPLY_ONLY_ROLE != 2) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *A.h_slabs = 0u;
+        if (own) run_units<KIND, DIM4, LOCATED, GROUPED, false>(L, A, bk, parity, runs, size0, 0u, 0u, gdesc);
+    }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
@@ -672,6 +891,9 @@ int bucket_scratch_alloc(mee_table* t) {
     alloc((void**)&bk.pend_key, bk.fast_max * 8);
     alloc((void**)&bk.pend_slot, bk.fast_max * 8);
     alloc((void**)&bk.pend_row, bk.fast_max * (uint64_t)t->dim * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&bk.h_slabs, 64, hipHostMallocMapped | hipHostMallocPortable);
+    if (e == hipSuccess) { *bk.h_slabs = 0u; e = hipHostGetDevicePointer((void**)&bk.h_slabs_dev, bk.h_slabs, 0); }
+    bk.skew_adapt = 1;
     if (e != hipSuccess) return fail(MEE_ERR_OUT_OF_MEMORY, "hipMalloc for the apply scratch: %s", hipGetErrorString(e));
     return MEE_OK;
 }
@@ -679,6 +901,7 @@ void bucket_scratch_free(mee_table* t) {
     BucketScratch& bk = t->bk;
     void* dev[] = {bk.pkey, bk.cnt_mat, bk.off_mat, bk.tot, bk.has_split, bk.seq, bk.pend_cnt, bk.ticket, bk.pend_key, bk.pend_slot, bk.pend_row};
     for (void* p : dev) if (p) (void)hipFree(p);
+    if (bk.h_slabs) (void)hipHostFree(bk.h_slabs);
 }
 
 #if MEE_APPLY_TIMELINE
@@ -689,10 +912,11 @@ extern "C" int mee_debug_timeline(unsigned long long* host_out, uint64_t n_words
 }
 #endif
 int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st) {
-    const uint32_t nbk = bucket_count_for(t, n);
+    uint32_t grid;
+    const uint32_t nbk = bucket_count_for(t, n, &grid);
     uint32_t blocks, per_block;
     part_geometry(n, kPartThreads, blocks, per_block);
-    t->part_blocks = blocks; t->part_per_block = per_block;
+    t->part_blocks = blocks; t->part_per_block = per_block; t->part_nbk = nbk; t->part_grid = grid;
     bkt_sort_kernel<<<blocks, kPartThreads, nbk * 4, st>>>(d_keys, n, nbk, per_block, t->bk, &t->ctr->status, t->op);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
@@ -712,21 +936,20 @@ int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const Op
     A.tkeys = t->keys; A.values = (float4*)t->values; A.s1 = (float4*)t->s1; A.s2 = (float4*)t->s2; A.nb = t->nb; A.dim4 = t->dim4;
     A.grads = (const float4*)d_grads; A.gidx = d_gidx; A.slots = d_slots;
     A.capacity = t->capacity; A.handle_tag = (int64_t)(t->handle_epoch & kHandleEpochMask) << kHandleSlotBits; A.status = &t->ctr->status;
-    A.part = t->bs.gacc; A.max_part = t->bs.max_part; A.op = t->op; A.a = a;
+    A.part = t->bs.gacc; A.max_part = t->bs.max_part; A.op = t->op; A.a = a; A.h_slabs = t->bk.h_slabs_dev;
 #if MEE_APPLY_TIMELINE
-    if (!g_dbg) { (void)hipMalloc((void**)&g_dbg, 16384 * 8 * 8); (void)hipMemset(g_dbg, 0, 16384 * 8 * 8); }
+    if (!g_dbg) (void)hipMalloc((void**)&g_dbg, (16384 * 8 + 1024 * 128) * 8);
+    (void)hipMemsetAsync(g_dbg, 0, (16384 * 8 + 1024 * 128) * 8, st);
     A.dbg = g_dbg;
 #endif
     A.desc = d_desc; A.n_tables = n_tables;   // a table group's apply (d_slots = the batch's located rows = its keys; t = the group's scratch table)
-    A.nbk = bucket_count_for(t, n);
-    A.part_blocks = t->part_blocks; A.per_block = t->part_per_block;   // as whoever partitioned this batch left them
-    // blocks [0, n_extra): the slabs of split buckets (few blocks, long chains: slab, hand-off, merge — so they lead the grid), one per CU unless
-    // the batch cannot have that many slabs; block e takes slabs e, e + n_extra, …  (One block per POSSIBLE slab — 2n / 512 — put a thousand blocks
-    // that only look at one word in front of every uniform batch: an apply alone 113 us instead of 97 us.)
-    const uint32_t spare = t->bk.spare_blocks ? t->bk.spare_blocks : t->bk.slots / kApplyBlocksPerCU;
-    A.n_extra = max_extra_slabs(n) < spare ? max_extra_slabs(n) : spare;
-#define BKT(K, D4, LOC) bkt_apply_kernel<K, D4, LOC><<<A.n_extra + A.nbk, kApplyThreads, 0, st>>>(A, t->bk)
-#define BKT_L(K, D4) do { if (d_desc) bkt_apply_kernel<K, D4, true, true><<<A.n_extra + A.nbk, kApplyThreads, 0, st>>>(A, t->bk); else if (d_slots) BKT(K, D4, true); else BKT(K, D4, false); } while (0)
+    A.nbk = t->part_nbk; A.part_blocks = t->part_blocks; A.per_block = t->part_per_block;   // as whoever partitioned this batch left them (a tuning
+    // call between the partition and the apply — "apply_bucket_max" — must not change the stride the run matrices were written with)
+    // one block per bucket (+ the blocks a skewed stream's slabs need); on a skewed batch the blocks work through a list of units, the slabs of the
+    // split buckets first (run_units)
+    const uint32_t grid = t->part_grid > A.nbk ? t->part_grid : A.nbk;
+#define BKT(K, D4, LOC) bkt_apply_kernel<K, D4, LOC><<<grid, kApplyThreads, 0, st>>>(A, t->bk)
+#define BKT_L(K, D4) do { if (d_desc) bkt_apply_kernel<K, D4, true, true><<<grid, kApplyThreads, 0, st>>>(A, t->bk); else if (d_slots) BKT(K, D4, true); else BKT(K, D4, false); } while (0)
 #define BKT_D(K) do { if (t->dim4 == 16) BKT_L(K, 16); else if (t->dim4 == 32) BKT_L(K, 32); else BKT_L(K, 0); } while (0)
     if (a.kind == MEE_OPT_ADAGRAD) BKT_D(MEE_OPT_ADAGRAD); else BKT_D(MEE_OPT_ADAM);
 #undef BKT_D

@@ -7,8 +7,10 @@
 namespace mee {
 
 constexpr int kPartBlocks = 128;          // blocks that share the partition of one batch, at most (2 x 64: a wave of the apply kernel scans their run lengths, two per lane)
-constexpr uint32_t kSlab = 512;           // positions one apply block takes (= its thread count): what its LDS hash table holds at load 0.5
-constexpr uint32_t kBucketMax = 352;      // positions per bucket aimed at, at most (a slab holds 512: Poisson(352) stays below that by 8 sigma)
+constexpr uint32_t kSlab = 512;           // positions per slab of a SPLIT bucket (= an apply block's thread count)
+constexpr uint32_t kBucketCap = 1024;     // largest bucket ONE apply block takes whole (two positions per thread; its LDS table has this many slots): only
+                                          // larger buckets — a key with >= ~700 occurrences in the batch — are split into slabs with pending records and a merge
+constexpr uint32_t kBucketMax = 352;      // positions per bucket aimed at, at most (Poisson(352) stays below 512 by 8 sigma: a uniform batch never needs a thread's second position)
 constexpr uint32_t kMaxBuckets = 8192;    // the partition keeps one LDS counter per bucket
 // MEE_APPLY_WAVES: waves per SIMD the register allocator must leave room for in the bucket kernel (meepo_apply.hip): 8 = 64 VGPRs, four
 // 512-thread blocks per CU (6 = 80 VGPRs, three blocks)
@@ -86,7 +88,7 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
 // bucket's global position: 256K keys = 512K partial-line stores from 64 CUs on 8 XCDs into the same lines — 19 us; and it needed a count
 // kernel in front.)  Per (block, bucket) it leaves the run's length and its start inside the slice: the apply kernel pulls a bucket's
 // entries out of the <= 64 slices (short contiguous reads).  It also adds its run lengths to the buckets' totals (one atomic per non-empty
-// (block, bucket) pair, spread over nbk words); the add that takes a total beyond one slab raises `has_split`, which is all the apply kernel's
+// (block, bucket) pair, spread over nbk words); the add that takes a total beyond what one block holds (kBucketCap) raises `has_split`, which is all the apply kernel's
 // spare blocks look at when no bucket needs them.  Nothing is handed from block to block in here: the kernel boundary publishes everything.
 // (Two earlier forms: a units kernel of its own behind this one — a dependent launch, 6.5 us for one block's worth of work; the block that
 // finished last building the unit list — release fence, ticket, acquire, then the list: the same 6 us at the end of this kernel, and under
@@ -165,7 +167,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
         if (c) {
             const uint32_t before = atomicAdd(&bk.tot[parity * bk.n_buckets_max + b], c);
             if (deferred) { tot_before[q < kTotRegs ? q : 0] = before; tot_add[q < kTotRegs ? q : 0] = c; }   // the return travels while the entries are scattered
-            else if (before <= kSlab && before + c > kSlab) bk.has_split[parity] = 1u;   // exactly one add per bucket takes its total beyond one slab
+            else if (before <= kBucketCap && before + c > kBucketCap) bk.has_split[parity] = 1u;   // exactly one add per bucket takes its total beyond what one block holds
         }
     };
 #pragma unroll
@@ -196,7 +198,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
     }
     bool crossed = false;
 #pragma unroll
-    for (uint32_t q = 0; q < kTotRegs; ++q) crossed = crossed || (tot_before[q] <= kSlab && tot_before[q] + tot_add[q] > kSlab);
+    for (uint32_t q = 0; q < kTotRegs; ++q) crossed = crossed || (tot_before[q] <= kBucketCap && tot_before[q] + tot_add[q] > kBucketCap);
     if (crossed) bk.has_split[parity] = 1u;
 }
 

@@ -1937,6 +1937,9 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     t->max_big = mb / kChunk + 1;  // a batch of n keys has at most n / (kChunk + 1) groups larger than kChunk
     // ... and those groups need ceil(cnt / kChunk) partial-sum rows each: at most n / kChunk + n / (kChunk + 1) rows in all
     t->max_part = mb / kChunk + mb / (kChunk + 1) + 2;
+    // the bucketed apply (meepo_apply.hip) cuts runs into chunks of 8 .. 32 sources, following the slab: sum of ceil(c / lc) over runs longer than
+    // lc <= m / 8 + m / 9 per slab of m sources, slabs and merge passes of split buckets together (+ 32 rows per single-key merge pass)
+    if (t->optimizer != MEE_OPT_NONE && t->max_part < mb / 4 + mb / 32 + 4096) t->max_part = mb / 4 + mb / 32 + 4096;
     t->bs.max_part = (uint32_t)t->max_part;
     ALLOC(t->bs.bigh, t->max_big * 4);
     if (t->optimizer != MEE_OPT_NONE) ALLOC(t->bs.gacc, t->max_part * (uint64_t)t->dim * sizeof(double));
@@ -1993,6 +1996,7 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     else if (!strcmp(name, "apply_path")) t->apply_path = value;
     else if (!strcmp(name, "apply_spare_blocks")) t->bk.spare_blocks = value > 0 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_bucket_max")) t->bk.bucket_max = value > 0 && value <= 352 ? (uint32_t)value : 0u;
+    else if (!strcmp(name, "apply_skew_adapt")) t->bk.skew_adapt = value != 0;
     else if (!strcmp(name, "apply_overlap")) (void)value;   // retired in round 2 (a side stream for the duplicate path lost to its fork/join gaps): accepted, ignored
     else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);
     return MEE_OK;
@@ -2661,7 +2665,8 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
     }
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
-    const uint32_t nbk = bucket_count_for(t, n);
+    uint32_t apply_grid;
+    const uint32_t nbk = bucket_count_for(t, n, &apply_grid);
     uint32_t part_blocks, per_block;
     part_geometry((uint32_t)n, kFindPrepareThreads, part_blocks, per_block);
     const int R = t->dim4 == 16 || t->dim4 == 32 ? 2 : 1;
@@ -2678,7 +2683,7 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
 #undef FINDLP1
     MEE_HIP(hipGetLastError());
     if (separate) { if (int rc = bucket_apply_prepare(t, d_keys, (uint32_t)n, st)) return rc; }
-    else { t->part_blocks = part_blocks; t->part_per_block = per_block; }
+    else { t->part_blocks = part_blocks; t->part_per_block = per_block; t->part_nbk = nbk; t->part_grid = apply_grid; }
     t->prepared_n = n; t->prepared_keys = d_keys; t->prepared_path = 1;
     return MEE_OK;
 }

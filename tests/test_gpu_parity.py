@@ -465,14 +465,17 @@ def _keys_of_apply_bucket_zero(count, seed):
 
 
 @pytest.mark.parametrize("opt", ["adagrad", "adam"])
-@pytest.mark.parametrize("case", ["one_key", "one_bucket_many_keys", "forty_hot_keys", "one_bucket_two_keys"])
+@pytest.mark.parametrize("case", ["one_key", "one_bucket_many_keys", "forty_hot_keys", "one_bucket_two_keys", "bucket_of_900_distinct", "bucket_of_300_warm"])
 def test_bucketed_apply_extremes(dev, case, opt):
     """The rare ways through the bucketed apply (meepo_apply.hip), each forced by construction, plain and located, against the oracle:
     one_key — a single key fills 400K of a 410K-position batch: ~780 slabs of one bucket each emit a record of that key, more records of ONE key
     than a merge pass holds (mono_pass);  one_bucket_many_keys — 3000 keys that all fall into apply bucket 0, 100+ occurrences each: every slab
     emits hundreds of records, the merge has far more records than one pass holds and splits them by hash prefix (the DFS stack);
     forty_hot_keys — 40 keys of ~6000 occurrences in a uniform batch: forty split buckets merge side by side, spare blocks loop over slabs;
-    one_bucket_two_keys — two keys of one bucket, 150K occurrences each: the prefix split must separate exactly two keys."""
+    one_bucket_two_keys — two keys of one bucket, 150K occurrences each: the prefix split must separate exactly two keys;
+    bucket_of_900_distinct — 900 keys of apply bucket 0, once each, in a small batch: ONE block takes a bucket of ~1000 positions whole (two positions
+    per thread) with its LDS hash table filled almost to the last slot;  bucket_of_300_warm — 300 keys of bucket 0 with 1..6 occurrences each: the
+    same path with runs."""
     dim, n_bg = 64, 20000
     rng = np.random.default_rng(5)
     bg = synth.keys_np(321, 0, n_bg)
@@ -482,15 +485,19 @@ def test_bucketed_apply_extremes(dev, case, opt):
         hot = _keys_of_apply_bucket_zero(3000, 7); reps = rng.integers(100, 140, size=3000); n_fill = 20_000
     elif case == "forty_hot_keys":
         hot = synth.keys_np(323, 0, 40); reps = rng.integers(5000, 7000, size=40); n_fill = 150_000
-    else:
+    elif case == "one_bucket_two_keys":
         hot = _keys_of_apply_bucket_zero(2, 9); reps = np.array([150_000, 150_001]); n_fill = 5_000
+    elif case == "bucket_of_900_distinct":
+        hot = _keys_of_apply_bucket_zero(900, 11); reps = np.ones(900, dtype=np.int64); n_fill = 5_000
+    else:
+        hot = _keys_of_apply_bucket_zero(300, 12); reps = rng.integers(1, 7, size=300); n_fill = 3_000
     keys = np.unique(np.concatenate([bg, hot]))
     rows = synth.rows_np(keys, dim, 2)
     bk = np.concatenate([np.repeat(hot, reps), bg[rng.integers(0, n_bg, n_fill)], synth.keys_np(324, 0, 50)])   # + 50 absent keys
     rng.shuffle(bk)
     n = bk.size
     kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
-    mk = lambda: LookupTable(1 << 17, dim, device=dev, optimizer=kind, max_batch=n, initial_accumulator=0.1)
+    mk = lambda: LookupTable(1 << 17, dim, device=dev, optimizer=kind, max_batch=max(n, keys.size), initial_accumulator=0.1)
     ta, tb = mk(), mk()
     o = oracle.OracleTable(1 << 17, dim, optimizer=okind, initial_accumulator=0.1)
     for t in (ta, tb):
