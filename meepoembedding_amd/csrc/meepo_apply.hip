@@ -45,10 +45,15 @@ constexpr uint32_t kLdsPartRows = 16;     // fp64 partial rows a slab keeps in L
 // instead of ~50).  Key streams keep their skew from batch to batch, so the next batch gets S (+ 1/16) fewer, larger buckets and as many
 // blocks as before: slabs and buckets together fill the slots once.  S comes back through a pinned host word the apply kernel writes — read
 // here without any synchronisation (a stale or zero value costs time, never results: the kernel works through whatever units there are).
-uint32_t bucket_count_for(const mee_table* t, uint64_t n, uint32_t* grid_out) {
+uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out, uint32_t* nbk_total_out, bool* full_out) {
     const uint32_t full = bucket_count_for_host(n, t->bk.slots, t->bk.bucket_max ? t->bk.bucket_max : kBucketMax);
     uint32_t nbk = full;
     const uint32_t s_prev = t->bk.h_slabs && t->bk.skew_adapt ? *(volatile uint32_t*)t->bk.h_slabs : 0u;
+    // which kernel (bkt_apply_kernel): FULL behind a skewed batch — and for the 64 batches after the last one: a stream whose skew comes and
+    // goes must not fall into the LEAN kernel's slow path every other batch —, else LEAN
+    if (s_prev) t->bk.skew_sticky = 64;
+    else if (t->bk.skew_sticky) --t->bk.skew_sticky;
+    if (full_out) *full_out = t->bk.kernel_choice >= 0 ? t->bk.kernel_choice != 0 : (s_prev != 0 || t->bk.skew_sticky != 0);
     if (s_prev && n > (uint64_t)t->bk.slots * 128) {
         uint32_t adj = s_prev + s_prev / 16 + 1;
         if (adj > t->bk.slots / 2) adj = t->bk.slots / 2;
@@ -57,15 +62,20 @@ uint32_t bucket_count_for(const mee_table* t, uint64_t n, uint32_t* grid_out) {
         while ((uint64_t)nbk * 2 * kBucketMax < n && nbk < full) ++nbk;   // (never more than ~700 positions per bucket on average: kBucketCap stays 12 sigma away)
     }
     if (grid_out) *grid_out = full;
+    // behind a skewed batch the keys that batch reported as hot get buckets of their own, behind the hash buckets (meepo_apply_part.h) — the
+    // FULL kernel's business
+    const bool hot = s_prev && nbk + kHotCap <= kMaxBuckets && (!full_out || *full_out);
+    if (nbk_total_out) *nbk_total_out = hot ? nbk + kHotCap : nbk;
     return nbk;
 }
 
 // ---- the partition kernel of an apply (the role itself: meepo_apply_part.h) ----------------------------------------------------------------
-__global__ __launch_bounds__(kPartThreads) void bkt_sort_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk,
+__global__ __launch_bounds__(kPartThreads) void bkt_sort_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk_hash, uint32_t nbk,
                                                                 uint32_t per_block, BucketScratch bk, uint32_t* status, OpCounters* op) {
-    extern __shared__ uint32_t cursor[];
+    extern __shared__ unsigned long long part_lds[];   // PartHot, then one counter per bucket
     __shared__ unsigned long long wsum[kPartThreads / 64];
-    sort_role<kPartThreads>(keys, n, nbk, per_block, blockIdx.x, gridDim.x, bk, status, op, cursor, wsum);
+    PartHot* hot = reinterpret_cast<PartHot*>(part_lds);
+    sort_role<kPartThreads>(keys, n, nbk_hash, nbk, per_block, blockIdx.x, gridDim.x, bk, status, op, reinterpret_cast<uint32_t*>(hot + 1), wsum, hot);
 }
 
 // ---- the apply kernel -------------------------------------------------------------------------------------------------------------
@@ -132,7 +142,8 @@ struct ApplyArgs {
     const float4* grads; const uint32_t* gidx; const int64_t* slots;
     uint64_t capacity; int64_t handle_tag; uint32_t* status;
     double* part; uint32_t max_part;     // fp64 partial rows of long runs (BatchScratch::gacc)
-    uint32_t nbk, part_blocks, per_block;   // the partition: buckets, partition blocks, batch positions per partition block
+    uint32_t nbk, part_blocks, per_block;   // the partition: buckets (hash buckets, then one per hot key), partition blocks, batch positions per partition block
+    uint32_t nbk_hash;                      // ... the hash buckets among them
     uint32_t* h_slabs;                      // pinned host word: the slabs this batch's split buckets were cut into (0: none)
     OpCounters* op;
 #if MEE_APPLY_TIMELINE
@@ -183,9 +194,9 @@ __device__ __forceinline__ double tiles_sum(double v) {
 // nh rows of A.grads (fp32) | of the pending records (fp64), four in flight, added up in fp64; a lane past the end reads the last row again and
 // adds +0.0 (no one-row-at-a-time tail: every round trip carries four rows)
 template <bool REC>
-__device__ __forceinline__ void sum_sources(const ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, bool src_rec, uint32_t rec_bucket0, uint32_t run0, uint32_t nh,
+__device__ __forceinline__ void sum_sources(const ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, uint32_t rec_bucket0, uint32_t run0, uint32_t nh,
                                             uint32_t dim4, uint32_t col, double& sx, double& sy, double& sz, double& sw) {
-    if (REC && src_rec) {
+    if constexpr (REC) {
         for (uint32_t q0 = 0; q0 < nh; q0 += 4) {
             double2 lo[4], hi[4];
 #pragma unroll
@@ -229,12 +240,39 @@ __device__ __forceinline__ void sum_sources(const ApplyLds& L, const ApplyArgs& 
 // two at a time: 8 + 8 round trips, the slab pass of a split bucket 30-45 us.  Chunks of ceil(m / 32) sources — "as many items as tiles" —:
 // a bucket of 800 positions around a key of 500 occurrences spent 7 round trips in each of that key's quads.)  Waves take turns from an LDS
 // counter, quads first (a quad is up to 32 rows, a key that occurs once is one).
-template <int KIND, int DIM4, bool LOCATED, bool SPLIT /* false: emit and src_rec are known to be false (the kernel of the whole buckets) */, bool GROUPED = false>
-__device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, uint32_t first, uint32_t m, bool emit_rt, bool src_rec_rt,
-                                             uint32_t b, uint32_t rec_bucket0 /* split buckets: the bucket's first pending record */, const GroupDesc* gdesc = nullptr) {
+// a key with enough occurrences in this batch to fill a slab: into the hot-key set the next partition reads (copy `parity`, cleared by this
+// batch's partition).  A few hundred calls per skewed batch, none on a uniform one.
+__device__ __forceinline__ void report_hot_key(const BucketScratch& bk, uint32_t parity, int64_t key) {
+    const unsigned long long bkey = (unsigned long long)key ^ kBias;
+    uint32_t h = (uint32_t)(mix64b((uint64_t)key) >> 20) & (kHotSlots - 1);
+    unsigned long long* set = bk.hot_key + parity * kHotSlots;
+    for (uint32_t tries = 0; tries < kHotSlots; ++tries) {
+        const unsigned long long old = atomicCAS(&set[h], 0ull, bkey);
+        if (old == bkey) return;   // another slab of the key was first
+        if (old == 0ull) {
+            const uint32_t i = atomicAdd(&bk.hot_n[parity], 1u);
+            if (i < kHotCap) bk.hot_idx[parity * kHotSlots + h] = i;   // (read by the NEXT partition: a later kernel)
+            return;
+        }
+        h = (h + 1) & (kHotSlots - 1);
+    }
+}
+
+// MODE: kWhole — a whole bucket (sources: batch positions, results: table updates); kEmit — a slab of a split bucket (sources: batch positions,
+// results: pending records); kMerge — a merge pass (sources: pending records, results: table updates).  Compile-time: each instance carries only
+// what its mode needs (a slab never touches a table row, a merge never reads a gradient row), which is what keeps the skewed path's register
+// need near the whole buckets' 77 — every byte of scratch the kernel declares costs the UNIFORM batches time although they never touch it
+// (measured: 0 B: 62.5 us, 56 B (round 3): 63.1, 128-160 B: 67-68, 600 B: 94 us for the same bucket path).
+constexpr int kWhole = 0, kEmit = 1, kMerge = 2;
+template <int KIND, int DIM4, bool LOCATED, int MODE, bool GROUPED = false>
+__device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, uint32_t first, uint32_t m,
+                                             uint32_t b, uint32_t rec_bucket0 /* split buckets: the bucket's first pending record */, uint32_t parity_rt, const GroupDesc* gdesc = nullptr) {
+    constexpr bool SPLIT = MODE != kWhole, emit = MODE == kEmit, src_rec = MODE == kMerge;
     static_assert(!GROUPED || LOCATED, "a group's batch names rows, not keys");
-    constexpr int PPT = SPLIT ? 1 : (int)(kBucketCap / kApplyThreads);   // sources per thread
-    const bool emit = SPLIT && emit_rt, src_rec = SPLIT && src_rec_rt;
+#ifndef MEE_AB_PPT
+#define MEE_AB_PPT (int)(kBucketCap / kApplyThreads)
+#endif
+    constexpr int PPT = SPLIT ? 1 : MEE_AB_PPT;   // sources per thread
     // The kernel calls this from a loop (slab, then merge passes).  The thread index is re-read through an empty asm in every call so that
     // nothing derived from it looks loop-invariant: hoisted out of that loop, the per-thread address arithmetic of every array touched in
     // here stayed live across the whole kernel (110 VGPRs instead of 64: half the resident blocks per CU for every block's hot path).
@@ -254,14 +292,13 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
     for (uint32_t j = t; j < kLdsSlots; j += kApplyThreads) { L.key[j] = 0ull; L.cnt[j] = 0u; }
     if (t == 0) { L.n_big = 0u; L.next_turn = 0u; }
     __syncthreads();
-    uint32_t my_slot[PPT], my_r[PPT];
-    bool my_first[PPT];
+    uint32_t my_sr[PPT];   // the source's run (LDS slot, 10 bits) | its arrival number inside the run << 10 | first of its run << 31
     int64_t my_tslot[PPT], my_key[PPT];
     // (the global loads of all of a thread's sources are requested before the first LDS insertion waits for any of them)
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
         const uint32_t ti = t + (uint32_t)u * kApplyThreads;
-        my_key[u] = kEmpty; my_tslot[u] = -1; my_slot[u] = 0u; my_r[u] = 0u; my_first[u] = false;
+        my_key[u] = kEmpty; my_tslot[u] = -1; my_sr[u] = 0u;
         if (ti < m) {
             if (src_rec) {
                 my_key[u] = rec_load(bk.pend_key + rec_bucket0 + my_src[u]);
@@ -292,9 +329,7 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
                 if (old == bkey) break;
                 sl = (sl + 1) & (kLdsSlots - 1);
             }
-            my_r[u] = atomicAdd(&L.cnt[sl], 1u);
-            my_slot[u] = sl;
-            my_first[u] = first_of_run;
+            my_sr[u] = sl | atomicAdd(&L.cnt[sl], 1u) << 10 | (uint32_t)first_of_run << 31;
         }
     }
     __syncthreads();
@@ -318,6 +353,7 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
             L.off[s] = so;
             if (c) {
                 L.run[s] = ro;
+                if (!src_rec && c >= kHotCount) report_hot_key(bk, parity_rt, (int64_t)(L.key[s] ^ kBias));   // a key that fills half a slab: its own bucket next time
                 if (c <= lc) L.items[io++] = s;
 #pragma unroll 1
                 for (uint32_t j = 0; j < nq; ++j) if (qo + j < kMaxQuads) L.quad[qo + j] = s | j << 10 | (nq > 1 ? po + j : 0u) << 16;
@@ -342,14 +378,15 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
         if (t + (uint32_t)u * kApplyThreads < m) {
-            L.src[L.off[my_slot[u]] + my_r[u]] = my_src[u];
+            const uint32_t my_slot = my_sr[u] & 1023u;
+            L.src[L.off[my_slot] + ((my_sr[u] >> 10) & 0x1FFFFFu)] = my_src[u];
             if constexpr (LOCATED) {
-                if (my_first[u]) {   // every occurrence of a key names the same slot: the run keeps one
-                    if (src_rec) L.slot[my_slot[u]] = my_tslot[u];
-                    else if constexpr (GROUPED) L.slot[my_slot[u]] = my_tslot[u] >= 0 && ((uint64_t)my_tslot[u] >> kGroupSlotBits) < A.n_tables ? my_tslot[u] : -1;
+                if (my_sr[u] >> 31) {   // every occurrence of a key names the same slot: the run keeps one
+                    if (src_rec) L.slot[my_slot] = my_tslot[u];
+                    else if constexpr (GROUPED) L.slot[my_slot] = my_tslot[u] >= 0 && ((uint64_t)my_tslot[u] >> kGroupSlotBits) < A.n_tables ? my_tslot[u] : -1;
                     else {
                         bool stale;
-                        L.slot[my_slot[u]] = handle_slot(my_tslot[u], A.handle_tag, A.capacity, stale);
+                        L.slot[my_slot] = handle_slot(my_tslot[u], A.handle_tag, A.capacity, stale);
                         if (stale) atomicOr(A.status, (uint32_t)MEE_STATUS_STALE_HANDLE);   // rare: the caller kept handles across a remove / clear / reserve
                     }
                 }
@@ -365,10 +402,17 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
     const uint32_t rec_out0 = rec_bucket0 + (emit ? L.rec_base : 0u);   // emit: where this slab's records go
     // ---- 3. work items: a wave per turn — a quad (its four tiles sum one chunk each of ONE run) or four tile items ----
     [[maybe_unused]] uint32_t tl_turn = 0;
+    // (a wave asks for its NEXT turn before it works on the current one: the counter's answer travels while the rows do)
+#ifndef MEE_AB_STATIC_TURNS
+#define MEE_AB_STATIC_TURNS 0
+#endif
+    uint32_t turn_next = 0;
+    if (MEE_AB_STATIC_TURNS) turn_next = t >> 6;
+    else if (lane == 0) turn_next = atomicAdd(&L.next_turn, 1u);
     while (true) {
-        uint32_t turn = 0;
-        if (lane == 0) turn = atomicAdd(&L.next_turn, 1u);
-        turn = __builtin_amdgcn_readfirstlane(turn);
+        const uint32_t turn = __builtin_amdgcn_readfirstlane(turn_next);
+        if (MEE_AB_STATIC_TURNS) turn_next += kApplyWaves;
+        else if (turn < n_turns && lane == 0) turn_next = atomicAdd(&L.next_turn, 1u);
 #if MEE_APPLY_TIMELINE
         if (!SPLIT && threadIdx.x == 0 && tl_turn < 16) A.dbg[16384ull * 8 + (uint64_t)blockIdx.x * 128 + 68 + 2 * tl_turn] = wall_clock64() << 8 | (turn >= n_turns ? 3u : turn < n_quads ? 1u : 2u) | (turn < n_quads ? min(255u, L.cnt[L.quad[turn] & 1023u]) : 0u) << 2 & 0xfcu;
         ++tl_turn;
@@ -400,7 +444,7 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
                     if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
                 }
                 double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-                sum_sources<SPLIT>(L, A, bk, src_rec, rec_bucket0, run0, nh, dim4, col, sx, sy, sz, sw);
+                sum_sources<src_rec>(L, A, bk, rec_bucket0, run0, nh, dim4, col, sx, sy, sz, sw);
                 sx = tiles_sum(sx); sy = tiles_sum(sy); sz = tiles_sum(sz); sw = tiles_sum(sw);
                 if (tile != 0) continue;
                 if (upd) {
@@ -427,8 +471,8 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
         const uint32_t s = valid ? L.items[item] : 0u;
         const uint32_t c = valid ? L.cnt[s] : 0u;   // <= lc: the run is this one item
         const uint32_t run0 = L.off[s];
-        const bool fin = valid && !emit;            // finished here: locate the row, update it once
-        const bool single = !src_rec && fin && c == 1;
+        const bool fin = !emit && valid;            // finished here: locate the row, update it once
+        const bool single = MODE == kWhole && fin && c == 1;
         const int64_t key = (int64_t)(L.key[s] ^ kBias);
         const uint32_t src0 = valid ? L.src[run0] : 0u;
         f32x4 gpre = {0.f, 0.f, 0.f, 0.f};
@@ -460,7 +504,7 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
                 continue;
             }
             double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-            sum_sources<SPLIT>(L, A, bk, src_rec, rec_bucket0, run0, c, dim4, col, sx, sy, sz, sw);
+            sum_sources<src_rec>(L, A, bk, rec_bucket0, run0, c, dim4, col, sx, sy, sz, sw);
             if (fin) {
                 if (upd) {
                     opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
@@ -636,7 +680,7 @@ __device__ __forceinline__ void run_units(ApplyLds& L, const ApplyArgs& A, const
                                           const GroupDesc* gdesc) {
     const uint32_t tot_base = parity * bk.n_buckets_max;
     constexpr bool skew = SKEW;
-    uint32_t S = 0;   // slabs of split buckets = the first units of a skewed batch
+    uint32_t S = 0, H = 0;   // slabs of split buckets, hot keys' buckets that one block takes whole: the units of a skewed batch beyond its hash buckets
     if constexpr (SKEW) {
         // ONE scan over the bucket totals: the slabs and the positions in front of each thread's buckets (the positions = where a split bucket's
         // pending records begin: records never outnumber positions), left in LDS for whoever resolves a unit later
@@ -646,46 +690,62 @@ __device__ __forceinline__ void run_units(ApplyLds& L, const ApplyArgs& A, const
             const uint32_t bb = threadIdx.x * per_t + q;
             // (up to two buckets per thread — batches of up to ~340K keys — came with the kernel's first round trip)
             const uint32_t tt = per_t <= 2 ? (q ? pre_b : pre_a) : bb < A.nbk ? bk.tot[tot_base + bb] : 0u;
-            mine += (unsigned long long)(tt > kBucketCap ? (tt + kSlab - 1) / kSlab : 0u) | (unsigned long long)tt << 32;
+            // low word: slabs (20 bits) | hot keys' buckets that one block takes whole (12 bits); high word: positions
+            mine += (unsigned long long)(tt > kBucketCap ? (tt + kSlab - 1) / kSlab : 0u) | (unsigned long long)(bb >= A.nbk_hash && tt != 0 && tt <= kBucketCap) << 20 |
+                    (unsigned long long)tt << 32;
         }
         unsigned long long total;
         const unsigned long long ex = block_scan_u64<kApplyWaves>(mine, L.wsum, total);
-        L.pre_slabs[threadIdx.x] = (uint32_t)ex; L.pre_pos[threadIdx.x] = (uint32_t)(ex >> 32); L.pre_a[threadIdx.x] = pre_a;
+        L.pre_slabs[threadIdx.x] = (uint32_t)ex; L.pre_pos[threadIdx.x] = (uint32_t)(ex >> 32); L.pre_a[threadIdx.x] = pre_a;   // (pre_slabs: slabs | hot keys' whole buckets << 20)
         if (threadIdx.x == 0) { L.pre_slabs[kApplyThreads] = (uint32_t)total; L.pre_pos[kApplyThreads] = (uint32_t)(total >> 32); }
-        S = (uint32_t)total;
+        S = (uint32_t)total & 0xFFFFFu; H = ((uint32_t)total >> 20) & 0xFFFu;
+        // (pinned host word: the units this batch had beyond its hash buckets — the next partition sizes its bucket count by it)
+        if (blockIdx.x == 0 && threadIdx.x == 0) *A.h_slabs = S + H;
         MEE_TLS(A, blockIdx.x, 0, wall_clock64());
     }
-    // Who takes what (G = the grid = the bucket count).  Round 0: block i takes slab i if there is one, else bucket i — the bucket whose totals
-    // and run matrix came with the kernel's first round trip.  The slabs beyond G (more slabs than blocks: a batch that is mostly one key) and
-    // the buckets the slabs displaced, [0, min(S, nbk)), follow in rounds of G, dealt from the LAST block downwards: the blocks that began with
-    // a bucket (short) take a second unit, the blocks that began with a slab (slab, hand-off, perhaps the bucket's merge) do not.  No counter:
-    // 768 blocks that claim their next unit from one word within a few microseconds of each other wait ~15 us for it (measured).
-    const uint32_t G = gridDim.x, S0 = min(S, G), n_late_slabs = S - S0, n_late = n_late_slabs + min(S, A.nbk);
-    if (SKEW && blockIdx.x == 0 && threadIdx.x == 0) *A.h_slabs = S;   // (pinned host word: the next partition sizes its bucket count and grid by it)
+    // Who takes what.  nbk_hash hash buckets, then one bucket per hot key; G = the grid = one round of the resident block slots.  The blocks
+    // [0, nbk_hash) OWN a hash bucket each (its totals and run matrix came with the kernel's first round trip).  The blocks behind them are
+    // AGENTS: the partition of a skewed stream makes the hash buckets fewer by the units the latest batch had beyond them, and agent a takes
+    // unit a of the list [slabs of the split buckets ..., hot keys' buckets that one block takes whole ...] — the long chains (slab, hand-off,
+    // perhaps the bucket's merge) start with the kernel and no hash bucket waits for a slot.  What the agents cannot take — the first skewed
+    // batch of a stream has none — : slabs first go to the blocks [0, O) INSTEAD of their buckets, and everything left over (more slabs, hot
+    // keys' buckets, the displaced buckets [0, O)) follows in later rounds over the hash buckets' blocks, from the last one downwards.  A static
+    // schedule: 768 blocks that claim their next unit from one word within a few microseconds of each other wait ~15 us for it (measured).
+    const uint32_t G = gridDim.x, NH = min(A.nbk_hash, G), n_agents = G - NH;
+    const uint32_t s_agents = min(S, n_agents), O = min(S - s_agents, NH);        // slabs [0, s_agents): agents; [s_agents, s_agents + O): blocks [0, O)
+    const uint32_t h_agents = min(H, n_agents - s_agents);                        // hot keys' whole buckets [0, h_agents): agents
+    const uint32_t late_slabs = S - s_agents - O, late_hot = H - h_agents, n_late = late_slabs + late_hot + O + (A.nbk_hash > G ? A.nbk_hash - G : 0u);
     [[maybe_unused]] uint32_t tl_i = 0, tl_units = 0;
     for (uint32_t round = 0;; ++round) {
         // (the thread index is re-read through an empty asm in every turn, as in process_slab: hoisted out of this loop, the per-thread addresses
         // of everything below stayed live across the whole loop and were spilled to scratch — a memory round trip in front of every use)
         uint32_t tx = threadIdx.x;
         asm volatile("" : "+v"(tx));
-        bool is_slab = false;
-        uint32_t u = blockIdx.x;   // slab number | bucket number
+        bool is_slab = false, is_hot = false;
+        uint32_t u = blockIdx.x;   // slab number | hot keys' bucket number (among those one block takes whole) | bucket number
         if constexpr (SKEW) {
             if (round == 0) {
-                is_slab = u < S;
-                if (!is_slab && u >= A.nbk) continue;   // (block-uniform) a block beyond the buckets that no slab needs either: straight to the later rounds
+                if (u >= NH) {   // an agent
+                    const uint32_t a = u - NH;
+                    if (a < s_agents) { is_slab = true; u = a; }
+                    else if (a - s_agents < h_agents) { is_hot = true; u = a - s_agents; }
+                    else continue;   // (block-uniform) nothing in round 0
+                } else if (u < O) { is_slab = true; u = s_agents + u; }
             } else {
-                const uint32_t j = (round - 1) * G + (G - 1 - blockIdx.x);
-                if (j >= n_late) break;   // block-uniform
-                is_slab = j < n_late_slabs;
-                u = is_slab ? S0 + j : j - n_late_slabs;
+                if (NH == 0) break;
+                const uint32_t j = (round - 1) * NH + (NH - 1 - blockIdx.x);
+                if (blockIdx.x >= NH || j >= n_late) break;   // block-uniform
+                if (j < late_slabs) { is_slab = true; u = s_agents + O + j; }
+                else if (j - late_slabs < late_hot) { is_hot = true; u = h_agents + (j - late_slabs); }
+                else if (j - late_slabs - late_hot < O) u = j - late_slabs - late_hot;
+                else u = G + (j - late_slabs - late_hot - O);
             }
         }
         ++tl_units;
         if (SKEW && is_slab) {   // ---- a slab of a split bucket (block-uniform) ----
             __syncthreads();   // (the scan's LDS stores; L.u_* of the unit before)
             {   // the thread whose buckets hold slab u publishes (bucket, slab of the bucket, size, first pending record)
-                const uint32_t lo = L.pre_slabs[tx], hi = L.pre_slabs[tx + 1];
+                const uint32_t lo = L.pre_slabs[tx] & 0xFFFFFu, hi = L.pre_slabs[tx + 1] & 0xFFFFFu;
                 if (u >= lo && u < hi) {   // exactly one thread
                     const uint32_t per_t = (A.nbk + kApplyThreads - 1) / kApplyThreads;
                     uint32_t acc = lo, pacc = L.pre_pos[tx];
@@ -708,95 +768,114 @@ __device__ __forceinline__ void run_units(ApplyLds& L, const ApplyArgs& A, const
             MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 0, wall_clock64());
             MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 5, (unsigned long long)b | (unsigned long long)sub << 16 | (unsigned long long)size << 32);
             seg_scan(L, seg_load(A, bk, b, tx), tx);   // the bucket's runs in the partition blocks' slices
-            // the slab first; in the bucket's LAST slab the same loop then runs the merge passes (src_rec)
-            bool merging = false, one_pass = false;
-            uint32_t first = sub * kSlab, m = min(kSlab, size - sub * kSlab), R = 0, bits0 = 0;
-            uint64_t v0 = 0;
-            bool done = false;
-            while (!done) {
-                process_slab<KIND, DIM4, LOCATED, true, GROUPED>(L, A, bk, first, m, !merging, merging, b, beg, gdesc);
-                if (!merging) MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 1, wall_clock64());
-                else MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 4, wall_clock64());
-                if (merging && one_pass) break;
-                if (!merging) {
-                    // ---- publish this slab's pending records, take a ticket; the slab that draws the last ticket merges the bucket.  The records
-                    // were written through (rec_store), every wave drains its stores, THEN the ticket; the merger reads them with agent-scope
-                    // loads (rec_load).  No block ever waits for another.
-                    const uint32_t nsub = (size + kSlab - 1) / kSlab;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    if (threadIdx.x == 0) {
-                        const uint32_t tk = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        L.is_last = tk == nsub - 1;
+            // the slab; the slab that finishes the bucket LAST then runs the merge passes
+            process_slab<KIND, DIM4, LOCATED, kEmit, GROUPED>(L, A, bk, sub * kSlab, min(kSlab, size - sub * kSlab), b, beg, parity, gdesc);
+            MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 1, wall_clock64());
+            // ---- publish this slab's pending records, take a ticket; the slab that draws the last ticket merges the bucket.  The records were
+            // written through (rec_store), every wave drains its stores, THEN the ticket; the merger reads them with agent-scope loads
+            // (rec_load).  No block ever waits for another.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t tk = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                L.is_last = tk == (size + kSlab - 1) / kSlab - 1;
+            }
+            __syncthreads();
+            MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 2, wall_clock64());
+            if (L.is_last) {   // block-uniform
+                const uint32_t R = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&bk.pend_cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // every slab added its runs before its ticket
+                MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 6, (unsigned long long)R);
+                // Merge in passes: records of one key must meet in one pass and a pass holds kSlab records.  Usually the bucket's records fit ONE
+                // pass (a hot key's own bucket: one record per slab).  Otherwise the records are taken by the low bits of mix64b(key): `bits0`
+                // bits give passes of ~256 records; a pass that still finds more than kSlab splits on one more bit, and a pass whose records all
+                // carry ONE key goes to mono_pass (mix64b is a bijection: the splitting ends).
+                const bool one_pass = R <= kSlab;
+                uint32_t bits0 = 0;
+                while (!one_pass && ((uint64_t)kSlab / 2 << bits0) < R && bits0 < 40) ++bits0;
+                uint64_t v0 = 0;
+                if (threadIdx.x == 0) L.stk_n = 0u;
+                for (bool done = false; !done;) {
+                    uint32_t m = 0;
+                    if (one_pass) {
+                        if (tx < R) L.src[tx] = tx;   // (process_slab begins with a barrier)
+                        m = R; done = true;
                     }
-                    __syncthreads();
-                    MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 2, wall_clock64());
-                    if (!L.is_last) break;   // block-uniform: on to this block's next unit
-                    merging = true;
-                    R = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&bk.pend_cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // every slab added its runs before its ticket
-                    MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 6, (unsigned long long)R);
-                    first = 0;
-                    if (R <= kSlab) {   // (the usual case) the bucket's records fit ONE pass: all of them, no selection
-                        if (tx < R) L.src[tx] = tx;
-                        m = R; one_pass = true;
-                        MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 3, wall_clock64());
-                        continue;   // (process_slab begins with a barrier)
-                    }
-                    // Merge in passes: records of one key must meet in one pass and a pass holds kSlab records, so the records are taken by the low bits
-                    // of mix64b(key): `bits0` bits give passes of ~256 records; a pass that still finds more than kSlab splits on one more bit, and a
-                    // pass whose records all carry ONE key goes to mono_pass (mix64b is a bijection: the splitting ends).
-                    while (((uint64_t)kSlab / 2 << bits0) < R && bits0 < 40) ++bits0;
-                    v0 = 0;
-                    if (threadIdx.x == 0) L.stk_n = 0u;
-                }
-                // ---- the next merge pass: pop a hash prefix, collect its records; too many -> split the prefix (or one key: mono_pass) ----
-                m = 0;
-                while (m == 0 && !done) {   // block-uniform
-                    __syncthreads();
-                    if (L.stk_n == 0) {
-                        if (v0 >> bits0) { done = true; break; }   // every prefix done
+                    // ---- the next merge pass: pop a hash prefix, collect its records; too many -> split the prefix (or one key: mono_pass) ----
+                    while (m == 0 && !done) {   // block-uniform
                         __syncthreads();
-                        if (threadIdx.x == 0) { L.stk_n = 1u; L.stk_bits[0] = bits0; L.stk_val[0] = v0; }
-                        ++v0;
-                        __syncthreads();
-                    }
-                    const uint32_t top = __builtin_amdgcn_readfirstlane(L.stk_n - 1), bits = __builtin_amdgcn_readfirstlane(L.stk_bits[top]);
-                    const unsigned long long val_v = L.stk_val[top];
-                    const uint64_t val = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)val_v) |
-                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(val_v >> 32)) << 32;
-                    const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
-                    __syncthreads();
-                    if (threadIdx.x == 0) { L.stk_n = top; L.n_cand = 0u; L.kmin = ~0ull; L.kmax = 0ull; }
-                    __syncthreads();
-                    for (uint32_t j = threadIdx.x; j < R; j += kApplyThreads) {
-                        const int64_t kj = rec_load(bk.pend_key + beg + j);
-                        if ((mix64b((uint64_t)kj) & mask) != val) continue;
-                        const uint32_t q = atomicAdd(&L.n_cand, 1u);
-                        if (q < kSlab) L.src[q] = j;
-                        atomicMin(&L.kmin, (unsigned long long)kj ^ kBias);
-                        atomicMax(&L.kmax, (unsigned long long)kj ^ kBias);
-                    }
-                    __syncthreads();
-                    const uint32_t nc = __builtin_amdgcn_readfirstlane(L.n_cand);
-                    if (nc > kSlab) {
-                        if (L.kmin == L.kmax) {   // more records of ONE key than a pass holds
-                            mono_pass<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, beg, R, (int64_t)(L.kmin ^ kBias), L.src[0], gdesc);
-                        } else if (threadIdx.x == 0 && bits < 64 && L.stk_n + 2 <= 72) {
-                            L.stk_bits[L.stk_n] = bits + 1; L.stk_val[L.stk_n] = val; ++L.stk_n;
-                            L.stk_bits[L.stk_n] = bits + 1; L.stk_val[L.stk_n] = val | 1ull << bits; ++L.stk_n;
+                        if (L.stk_n == 0) {
+                            if (v0 >> bits0) { done = true; break; }   // every prefix done
+                            __syncthreads();
+                            if (threadIdx.x == 0) { L.stk_n = 1u; L.stk_bits[0] = bits0; L.stk_val[0] = v0; }
+                            ++v0;
+                            __syncthreads();
                         }
-                    } else m = nc;
+                        const uint32_t top = __builtin_amdgcn_readfirstlane(L.stk_n - 1), bits = __builtin_amdgcn_readfirstlane(L.stk_bits[top]);
+                        const unsigned long long val_v = L.stk_val[top];
+                        const uint64_t val = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)val_v) |
+                                             (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(val_v >> 32)) << 32;
+                        const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
+                        __syncthreads();
+                        if (threadIdx.x == 0) { L.stk_n = top; L.n_cand = 0u; L.kmin = ~0ull; L.kmax = 0ull; }
+                        __syncthreads();
+                        for (uint32_t j = threadIdx.x; j < R; j += kApplyThreads) {
+                            const int64_t kj = rec_load(bk.pend_key + beg + j);
+                            if ((mix64b((uint64_t)kj) & mask) != val) continue;
+                            const uint32_t q = atomicAdd(&L.n_cand, 1u);
+                            if (q < kSlab) L.src[q] = j;
+                            atomicMin(&L.kmin, (unsigned long long)kj ^ kBias);
+                            atomicMax(&L.kmax, (unsigned long long)kj ^ kBias);
+                        }
+                        __syncthreads();
+                        const uint32_t nc = __builtin_amdgcn_readfirstlane(L.n_cand);
+                        if (nc > kSlab) {
+                            if (L.kmin == L.kmax) {   // more records of ONE key than a pass holds
+                                mono_pass<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, beg, R, (int64_t)(L.kmin ^ kBias), L.src[0], gdesc);
+                            } else if (threadIdx.x == 0 && bits < 64 && L.stk_n + 2 <= 72) {
+                                L.stk_bits[L.stk_n] = bits + 1; L.stk_val[L.stk_n] = val; ++L.stk_n;
+                                L.stk_bits[L.stk_n] = bits + 1; L.stk_val[L.stk_n] = val | 1ull << bits; ++L.stk_n;
+                            }
+                        } else m = nc;
+                    }
+                    if (m == 0) break;
+                    MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 3, wall_clock64());   // the pass's records are collected
+                    process_slab<KIND, DIM4, LOCATED, kMerge, GROUPED>(L, A, bk, 0, m, b, beg, parity, gdesc);
+                    MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 4, wall_clock64());
                 }
-                if (m) MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 3, wall_clock64());   // the latest merge pass's records are collected
             }
             MEE_TLS(A, blockIdx.x, 4 + 16 * tl_i + 7, wall_clock64());
             ++tl_i;
         } else {   // ---- a bucket ----
-            const uint32_t b = u;
+            uint32_t b = u;
+            if (SKEW && is_hot) {   // the u-th of the hot keys' buckets that one block takes whole: the thread that owns it in the scan publishes its number
+                __syncthreads();
+                const uint32_t lo = L.pre_slabs[tx] >> 20, hi = L.pre_slabs[tx + 1] >> 20;
+                if (u >= lo && u < hi) {   // exactly one thread
+                    const uint32_t per_t = (A.nbk + kApplyThreads - 1) / kApplyThreads;
+                    uint32_t acc = lo;
+                    for (uint32_t q = 0; q < per_t; ++q) {
+                        const uint32_t bb = tx * per_t + q;
+                        const uint32_t tt = per_t <= 2 ? (q ? L.pre_pos[tx + 1] - L.pre_pos[tx] - L.pre_a[tx] : L.pre_a[tx]) : bb < A.nbk ? bk.tot[tot_base + bb] : 0u;
+                        const uint32_t x = bb >= A.nbk_hash && tt != 0 && tt <= kBucketCap;
+                        if (u < acc + x) { L.u_b = bb; break; }
+                        acc += x;
+                    }
+                }
+                __syncthreads();
+                b = __builtin_amdgcn_readfirstlane(L.u_b);
+            }
             uint32_t size = size0;
-            if (SKEW && round != 0) {   // (round 0: the block's own bucket, everything came with the kernel's first round trip)
-                runs = seg_load(A, bk, b, tx);
-                size = __builtin_amdgcn_readfirstlane(bk.tot[tot_base + b]);
+            if (SKEW && (round != 0 || is_hot)) {   // (else: the block's own bucket, everything came with the kernel's first round trip)
+                const uint32_t per_t = (A.nbk + kApplyThreads - 1) / kApplyThreads;
+                if (per_t <= 2) {   // the bucket totals are in LDS (the blocks' common scan): an empty bucket — most hot-key buckets — costs no load
+                    const uint32_t tb = b / per_t;
+                    size = b % per_t ? L.pre_pos[tb + 1] - L.pre_pos[tb] - L.pre_a[tb] : L.pre_a[tb];
+                    size = __builtin_amdgcn_readfirstlane(size);
+                    if (size != 0 && size <= kBucketCap) runs = seg_load(A, bk, b, tx);
+                } else {
+                    runs = seg_load(A, bk, b, tx);
+                    size = __builtin_amdgcn_readfirstlane(bk.tot[tot_base + b]);
+                }
             }
             if (skew) MEE_TLS(A, blockIdx.x, 100 + 4 * min(tl_units - tl_i - 1, 6u), wall_clock64());
             if (size != 0 && size <= kBucketCap) {   // (an empty bucket | a split bucket: its slabs' business)
@@ -805,7 +884,7 @@ __device__ __forceinline__ void run_units(ApplyLds& L, const ApplyArgs& A, const
                 if (threadIdx.x == 0 && !skew) { A.dbg[(uint64_t)blockIdx.x * 8 + 6] = size | (unsigned long long)b << 32; unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); A.dbg[(uint64_t)blockIdx.x * 8 + 7] = (unsigned long long)(xcc & 0xf) << 32 | hw; }
 #endif
                 seg_scan(L, runs, tx);
-                process_slab<KIND, DIM4, LOCATED, false, GROUPED>(L, A, bk, 0, size, false, false, b, 0, gdesc);
+                process_slab<KIND, DIM4, LOCATED, kWhole, GROUPED>(L, A, bk, 0, size, b, 0, parity, gdesc);
                 MEE_TL(A, 5);
             }
             if (skew) {
@@ -822,7 +901,125 @@ __device__ __forceinline__ void run_units(ApplyLds& L, const ApplyArgs& A, const
     }
 }
 
-template <int KIND, int DIM4, bool LOCATED, bool GROUPED = false>
+// index within the bucket -> its place in pos / pkey (binary search over the bucket's runs in the partition blocks' slices: seg_scan)
+__device__ __forceinline__ uint32_t bucket_entry_at(const ApplyLds& L, uint32_t gi) {
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t stp = kPartBlocks / 2; stp; stp >>= 1) if (L.seg_first[k + stp] <= gi) k += stp;
+    return L.seg_at[k] + (gi - L.seg_first[k]);
+}
+
+// A split bucket in the LEAN kernel (below): its own block takes it, one key at a time in increasing key order — pick the smallest key not yet
+// done (one scan of the bucket's keys), add up its gradient rows (a second scan finds them, 1024 entries at a time; 32 tiles sum, shuffles and
+// LDS combine), update its row once.  O(distinct keys x bucket size) key reads from L2: a bucket of 15 000 positions around one hot key
+// takes ~2 ms.  This is the price of the first skewed batch of a stream, paid once: the keys it reports as hot and the slab count it leaves in
+// the pinned host word switch the following batches to the FULL kernel.  No pending records, no merge, no scratch.
+template <int KIND, int DIM4, bool LOCATED, bool GROUPED>
+__device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t size, const uint32_t parity, const GroupDesc* gdesc) {
+    static_assert(!GROUPED || LOCATED, "a group's batch names rows, not keys");
+    const uint32_t t = threadIdx.x;
+    const int lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6;
+    const uint32_t dim4 = DIM4 ? DIM4 : A.dim4;
+    OptArgs a = A.a;
+    a.kind = KIND;
+    bool have_last = false;
+    unsigned long long last = 0;
+    for (;;) {
+        // ---- the next key: the smallest (biased) key beyond the last one
+        __syncthreads();
+        if (t == 0) L.kmin = ~0ull;
+        __syncthreads();
+        unsigned long long mn = ~0ull;
+        for (uint32_t e = t; e < size; e += kApplyThreads) {
+            const unsigned long long bkey = (unsigned long long)bk.pkey[bucket_entry_at(L, e)] ^ kBias;
+            if ((!have_last || bkey > last) && bkey < mn) mn = bkey;
+        }
+        if (mn != ~0ull) atomicMin(&L.kmin, mn);
+        __syncthreads();
+        const unsigned long long cur = L.kmin;
+        if (cur == ~0ull) break;   // block-uniform
+        const int64_t key = (int64_t)(cur ^ kBias);
+        // ---- its gradient rows, 1024 entries of the bucket at a time: matches into L.src, 32 tiles sum them, the running total stays in LDS — one
+        // group of 64 columns at a time (the LDS rows hold 64: the update is element-wise, column groups are independent)
+        uint32_t total = 0;
+        for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {
+            const uint32_t col = c0 + (uint32_t)tl;
+            const bool cok = col < dim4;
+            __syncthreads();
+            if (t < 16) { double* r = &L.prow[8][tl * 4]; r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; r[3] = 0.0; }
+            total = 0;
+            for (uint32_t e0 = 0; e0 < size; e0 += kBucketCap) {
+                __syncthreads();
+                if (t == 0) L.n_cand = 0u;
+                __syncthreads();
+                for (uint32_t e = e0 + t; e < min(size, e0 + kBucketCap); e += kApplyThreads) {
+                    const uint32_t at = bucket_entry_at(L, e);
+                    if (((unsigned long long)bk.pkey[at] ^ kBias) != cur) continue;
+                    const uint32_t p = bk.pos[at];
+                    const uint32_t q = atomicAdd(&L.n_cand, 1u);
+                    L.src[q] = A.gidx ? min(A.gidx[p], a.grad_rows - 1) : p;
+                    if constexpr (LOCATED) if (q == 0) L.slot[0] = A.slots[p];   // every occurrence of a key names the same slot
+                }
+                __syncthreads();
+                const uint32_t nc = L.n_cand;
+                total += nc;
+                if (nc == 0) continue;   // block-uniform
+                double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+                for (uint32_t q0 = (uint32_t)wv * 4 + tile; q0 < nc; q0 += 4 * 4 * kApplyWaves) {   // four rows in flight per tile
+                    float4 g[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] = cok ? A.grads[(uint64_t)L.src[min(q0 + (uint32_t)q * 4 * kApplyWaves, nc - 1)] * dim4 + col] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool on = q0 + (uint32_t)q * 4 * kApplyWaves < nc;
+                        sx += on ? (double)g[q].x : 0.0; sy += on ? (double)g[q].y : 0.0; sz += on ? (double)g[q].z : 0.0; sw += on ? (double)g[q].w : 0.0;
+                    }
+                }
+                sx = tiles_sum(sx); sy = tiles_sum(sy); sz = tiles_sum(sz); sw = tiles_sum(sw);
+                if (tile == 0) { double* d = &L.prow[wv][tl * 4]; d[0] = sx; d[1] = sy; d[2] = sz; d[3] = sw; }
+                __syncthreads();
+                if (t < 16) {
+                    double* r = &L.prow[8][tl * 4];
+                    for (int w = 0; w < kApplyWaves; ++w) { const double* d = &L.prow[w][tl * 4]; r[0] += d[0]; r[1] += d[1]; r[2] += d[2]; r[3] += d[3]; }
+                }
+            }
+            __syncthreads();
+            // ---- one update of these columns (wave 0; its tile 0 holds the row)
+            if (wv == 0) {
+                int64_t slot = -1;
+                if constexpr (GROUPED) { const int64_t h = L.slot[0]; slot = h >= 0 && ((uint64_t)h >> kGroupSlotBits) < A.n_tables ? h : -1; }
+                else if constexpr (LOCATED) {
+                    bool stale;
+                    slot = handle_slot(L.slot[0], A.handle_tag, A.capacity, stale);
+                    if (stale && lane == 0 && c0 == 0) atomicOr(A.status, (uint32_t)MEE_STATUS_STALE_HANDLE);
+                } else {
+                    bool is_new, full;
+                    slot = tile_locate<false, false>(const_cast<int64_t*>(A.tkeys), A.nb, key, tile == 0, tile, tl, is_new, full);
+                }
+                if (tile == 0 && slot >= 0 && cok) {
+                    const RowAt at = row_at<GROUPED>(A, gdesc, slot, true);
+                    const uint64_t o = at.row * dim4 + col;
+                    const double* r = &L.prow[8][tl * 4];
+                    float4 w = at.values[o], x1 = at.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
+                    opt_update4(a, w, x1, x2, make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]));
+                    store_row4(&at.values[o], w); store_row4(&at.s1[o], x1);
+                    if (KIND == MEE_OPT_ADAM) store_row4(&at.s2[o], x2);
+                }
+            }
+        }
+        if (t == 0 && total >= kHotCount) report_hot_key(bk, parity, key);   // its own bucket next time
+        last = cur; have_last = true;
+    }
+}
+
+// Two kernels.  LEAN: block = bucket, the bucket path alone (77 registers, NO scratch) — what every batch of a uniform key stream runs; a
+// split bucket, should one turn up, is taken by its own block the slow way (slow_bucket).  FULL: the unit list of the skewed batches (slabs,
+// pending records, merges, hot keys' buckets: 111-128 registers bounded to 80, 170-200 B of scratch per lane).  The host picks by what the
+// latest batches of the table were (bucket_apply_launch); both are correct for any batch.  One kernel for both was the first form: the
+// scratch it declares for the skewed path — never touched by a uniform batch — cost the uniform batches 4-5 us of their 63 (the same bucket
+// path: 0 B of scratch 62.5 us, 56 B 63.1, 128-160 B 67-68, 600 B 94: resident waves are limited by the scratch the queue has for them).
+template <int KIND, int DIM4, bool LOCATED, bool GROUPED, bool FULL>
 __global__ __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES) void bkt_apply_kernel(ApplyArgs A, BucketScratch bk) {
     __shared__ ApplyLds L;
     const GroupDesc* gdesc = nullptr;
@@ -838,30 +1035,41 @@ __global__ __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES) void bkt_apply_kern
     // wave 0 — the lengths and places of the bucket's runs in the partition blocks' slices.  (As a chain seq -> total -> run lengths these were
     // three dependent loads, 2-3 us of every block's life before its first useful request.)
     MEE_TL(A, 0);
-    // (the grid is the bucket count, plus — behind a skewed batch — as many blocks as that batch had slabs: they have no bucket of their own)
-    const bool own = blockIdx.x < A.nbk;
+    // (FULL: the grid is one round of the resident block slots; the blocks beyond the hash buckets have no bucket of their own)
+    const bool own = blockIdx.x < A.nbk_hash;
     const SegRuns runs = seg_load(A, bk, own ? blockIdx.x : 0u, own ? threadIdx.x : 64u);
     const uint32_t tot0 = own ? bk.tot[blockIdx.x] : 0u, tot1 = own ? bk.tot[bk.n_buckets_max + blockIdx.x] : 0u;
-    const uint32_t hs0 = bk.has_split[0], hs1 = bk.has_split[1];
-    // (what a skewed batch needs next — the totals of the <= 2 buckets this thread owns in the blocks' common scan, both copies — travels with
-    // it: 4 loads of L1-resident lines per thread, instead of a dependent round trip in front of every block of a skewed batch)
+    const uint4 hdr = *reinterpret_cast<const uint4*>(bk.seq);   // seq[0] (unused here), seq[1] = the copy, has_split[0], has_split[1]
+    // (FULL: what a skewed batch needs next — the totals of the <= 2 buckets this thread owns in the blocks' common scan, both copies — travels
+    // with it: 4 loads of L1-resident lines per thread, instead of a dependent round trip in front of every block of a skewed batch)
     uint32_t pa0 = 0, pa1 = 0, pb0 = 0, pb1 = 0;
-    if (A.nbk <= 2 * kApplyThreads) {
+    if (FULL && A.nbk <= 2 * kApplyThreads) {
         const uint32_t per_t = (A.nbk + kApplyThreads - 1) / kApplyThreads, ba = threadIdx.x * per_t, bb = ba + 1;
         if (ba < A.nbk) { pa0 = bk.tot[ba]; pa1 = bk.tot[bk.n_buckets_max + ba]; }
         if (per_t == 2 && bb < A.nbk) { pb0 = bk.tot[bb]; pb1 = bk.tot[bk.n_buckets_max + bb]; }
     }
-    const uint32_t parity = __builtin_amdgcn_readfirstlane(bk.seq[1]);
+    const uint32_t parity = __builtin_amdgcn_readfirstlane(hdr.y);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&bk.seq[0], 1u);   // this partition is consumed: the next one fills the other copy
-#ifndef MEE_APPLY_ONLY_ROLE   // diagnostic (tools/resource_usage.sh file -DMEE_APPLY_ONLY_ROLE=1|2): the registers ONE path needs — 1 = batches without a split bucket, 2 = skewed batches
-#define MEE_APPLY_ONLY_ROLE 0
-#endif
     const uint32_t size0 = __builtin_amdgcn_readfirstlane(parity ? tot1 : tot0);
-    if (__builtin_amdgcn_readfirstlane(parity ? hs1 : hs0) != 0) {   // block-uniform
-        if (MEE_APPLY_ONLY_ROLE != 1) run_units<KIND, DIM4, LOCATED, GROUPED, true>(L, A, bk, parity, runs, size0, parity ? pa1 : pa0, parity ? pb1 : pb0, gdesc);
-    } else if (MEE_APPLY_ONLY_ROLE != 2) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *A.h_slabs = 0u;
-        if (own) run_units<KIND, DIM4, LOCATED, GROUPED, false>(L, A, bk, parity, runs, size0, 0u, 0u, gdesc);
+    if constexpr (FULL) {
+        // (block-uniform) the unit list: a batch with a split bucket | a batch partitioned with buckets for hot keys (more buckets than blocks,
+        // most of them empty)
+        if (__builtin_amdgcn_readfirstlane(parity ? hdr.w : hdr.z) != 0 || A.nbk != A.nbk_hash) {
+            run_units<KIND, DIM4, LOCATED, GROUPED, true>(L, A, bk, parity, runs, size0, parity ? pa1 : pa0, parity ? pb1 : pb0, gdesc);
+        } else {
+            if (blockIdx.x == 0 && threadIdx.x == 0) *A.h_slabs = 0u;
+            if (own) run_units<KIND, DIM4, LOCATED, GROUPED, false>(L, A, bk, parity, runs, size0, 0u, 0u, gdesc);
+        }
+    } else {   // LEAN: the batch was partitioned into hash buckets only, block = bucket
+        if (size0 <= kBucketCap) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) *A.h_slabs = 0u;   // (a block with a split bucket overwrites it when it is done, much later)
+            run_units<KIND, DIM4, LOCATED, GROUPED, false>(L, A, bk, parity, runs, size0, 0u, 0u, gdesc);
+        } else {
+            seg_scan(L, runs, threadIdx.x);
+            slow_bucket<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, size0, parity, gdesc);
+            // the stream is skewed: the FULL kernel from now on, with as many agents as this batch had slabs (the block that finishes last leaves the sum)
+            if (threadIdx.x == 0) { const uint32_t mine = (size0 + kSlab - 1) / kSlab; *A.h_slabs = atomicAdd(&bk.seq[4], mine) + mine; }
+        }
     }
 }
 
@@ -881,11 +1089,14 @@ int bucket_scratch_alloc(mee_table* t) {
     alloc((void**)&bk.cnt_mat, (uint64_t)kPartBlocks * bk.n_buckets_max * 4);
     alloc((void**)&bk.off_mat, (uint64_t)kPartBlocks * bk.n_buckets_max * 4);
     alloc((void**)&bk.tot, 2ull * bk.n_buckets_max * 4);
-    alloc((void**)&bk.has_split, 2 * 4);
-    alloc((void**)&bk.seq, 2 * 4);
-    if (e == hipSuccess) e = hipMemset(bk.seq, 0, 2 * 4);
+    alloc((void**)&bk.seq, 8 * 4);   // seq[0], seq[1], has_split[0], has_split[1]: ONE line of one page, read by every apply block with ONE load; [4]: the LEAN kernel's slab count
+    bk.has_split = bk.seq ? bk.seq + 2 : nullptr;
+    alloc((void**)&bk.hot_key, 2ull * kHotSlots * 8); alloc((void**)&bk.hot_idx, 2ull * kHotSlots * 4); alloc((void**)&bk.hot_n, 2 * 4);
+    if (e == hipSuccess) e = hipMemset(bk.hot_key, 0, 2ull * kHotSlots * 8);
+    if (e == hipSuccess) e = hipMemset(bk.hot_idx, 0xFF, 2ull * kHotSlots * 4);
+    if (e == hipSuccess) e = hipMemset(bk.hot_n, 0, 2 * 4);
+    if (e == hipSuccess) e = hipMemset(bk.seq, 0, 8 * 4);
     if (e == hipSuccess) e = hipMemset(bk.tot, 0, 2ull * bk.n_buckets_max * 4);   // (every partition launch zeroes the copy the next one adds to)
-    if (e == hipSuccess) e = hipMemset(bk.has_split, 0, 2 * 4);
     alloc((void**)&bk.pend_cnt, (uint64_t)bk.n_buckets_max * 4);
     alloc((void**)&bk.ticket, (uint64_t)bk.n_buckets_max * 4);
     alloc((void**)&bk.pend_key, bk.fast_max * 8);
@@ -893,13 +1104,13 @@ int bucket_scratch_alloc(mee_table* t) {
     alloc((void**)&bk.pend_row, bk.fast_max * (uint64_t)t->dim * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc((void**)&bk.h_slabs, 64, hipHostMallocMapped | hipHostMallocPortable);
     if (e == hipSuccess) { *bk.h_slabs = 0u; e = hipHostGetDevicePointer((void**)&bk.h_slabs_dev, bk.h_slabs, 0); }
-    bk.skew_adapt = 1;
+    bk.skew_adapt = 1; bk.skew_sticky = 0; bk.kernel_choice = -1;
     if (e != hipSuccess) return fail(MEE_ERR_OUT_OF_MEMORY, "hipMalloc for the apply scratch: %s", hipGetErrorString(e));
     return MEE_OK;
 }
 void bucket_scratch_free(mee_table* t) {
     BucketScratch& bk = t->bk;
-    void* dev[] = {bk.pkey, bk.cnt_mat, bk.off_mat, bk.tot, bk.has_split, bk.seq, bk.pend_cnt, bk.ticket, bk.pend_key, bk.pend_slot, bk.pend_row};
+    void* dev[] = {bk.pkey, bk.cnt_mat, bk.off_mat, bk.tot, bk.seq, bk.hot_key, bk.hot_idx, bk.hot_n, bk.pend_cnt, bk.ticket, bk.pend_key, bk.pend_slot, bk.pend_row};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (bk.h_slabs) (void)hipHostFree(bk.h_slabs);
 }
@@ -912,12 +1123,14 @@ extern "C" int mee_debug_timeline(unsigned long long* host_out, uint64_t n_words
 }
 #endif
 int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st) {
-    uint32_t grid;
-    const uint32_t nbk = bucket_count_for(t, n, &grid);
+    uint32_t grid, nbk;
+    bool full;
+    const uint32_t nbk_hash = bucket_count_for(t, n, &grid, &nbk, &full);
+    t->part_full = full;
     uint32_t blocks, per_block;
     part_geometry(n, kPartThreads, blocks, per_block);
-    t->part_blocks = blocks; t->part_per_block = per_block; t->part_nbk = nbk; t->part_grid = grid;
-    bkt_sort_kernel<<<blocks, kPartThreads, nbk * 4, st>>>(d_keys, n, nbk, per_block, t->bk, &t->ctr->status, t->op);
+    t->part_blocks = blocks; t->part_per_block = per_block; t->part_nbk = nbk; t->part_nbk_hash = nbk_hash; t->part_grid = grid;
+    bkt_sort_kernel<<<blocks, kPartThreads, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
@@ -943,13 +1156,15 @@ int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const Op
     A.dbg = g_dbg;
 #endif
     A.desc = d_desc; A.n_tables = n_tables;   // a table group's apply (d_slots = the batch's located rows = its keys; t = the group's scratch table)
-    A.nbk = t->part_nbk; A.part_blocks = t->part_blocks; A.per_block = t->part_per_block;   // as whoever partitioned this batch left them (a tuning
+    A.nbk = t->part_nbk; A.nbk_hash = t->part_nbk_hash; A.part_blocks = t->part_blocks; A.per_block = t->part_per_block;   // as whoever partitioned this batch left them (a tuning
     // call between the partition and the apply — "apply_bucket_max" — must not change the stride the run matrices were written with)
     // one block per bucket (+ the blocks a skewed stream's slabs need); on a skewed batch the blocks work through a list of units, the slabs of the
     // split buckets first (run_units)
-    const uint32_t grid = t->part_grid > A.nbk ? t->part_grid : A.nbk;
-#define BKT(K, D4, LOC) bkt_apply_kernel<K, D4, LOC><<<grid, kApplyThreads, 0, st>>>(A, t->bk)
-#define BKT_L(K, D4) do { if (d_desc) bkt_apply_kernel<K, D4, true, true><<<grid, kApplyThreads, 0, st>>>(A, t->bk); else if (d_slots) BKT(K, D4, true); else BKT(K, D4, false); } while (0)
+    const bool full = t->part_full;   // as the partition decided: FULL = a skewed stream (hot keys' buckets may exist, the grid is one round of the block slots)
+    const uint32_t grid = full ? t->part_grid : A.nbk;   // LEAN: block = bucket
+#define BKT(K, D4, LOC) do { if (full) bkt_apply_kernel<K, D4, LOC, false, true><<<grid, kApplyThreads, 0, st>>>(A, t->bk); else bkt_apply_kernel<K, D4, LOC, false, false><<<grid, kApplyThreads, 0, st>>>(A, t->bk); } while (0)
+#define BKT_L(K, D4) do { if (d_desc) { if (full) bkt_apply_kernel<K, D4, true, true, true><<<grid, kApplyThreads, 0, st>>>(A, t->bk); else bkt_apply_kernel<K, D4, true, true, false><<<grid, kApplyThreads, 0, st>>>(A, t->bk); } \
+                          else if (d_slots) BKT(K, D4, true); else BKT(K, D4, false); } while (0)
 #define BKT_D(K) do { if (t->dim4 == 16) BKT_L(K, 16); else if (t->dim4 == 32) BKT_L(K, 32); else BKT_L(K, 0); } while (0)
     if (a.kind == MEE_OPT_ADAGRAD) BKT_D(MEE_OPT_ADAGRAD); else BKT_D(MEE_OPT_ADAM);
 #undef BKT_D

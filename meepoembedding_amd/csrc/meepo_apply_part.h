@@ -8,10 +8,22 @@ namespace mee {
 
 constexpr int kPartBlocks = 128;          // blocks that share the partition of one batch, at most (2 x 64: a wave of the apply kernel scans their run lengths, two per lane)
 constexpr uint32_t kSlab = 512;           // positions per slab of a SPLIT bucket (= an apply block's thread count)
-constexpr uint32_t kBucketCap = 1024;     // largest bucket ONE apply block takes whole (two positions per thread; its LDS table has this many slots): only
+#ifndef MEE_AB_BUCKET_CAP
+#define MEE_AB_BUCKET_CAP 1024
+#endif
+constexpr uint32_t kBucketCap = MEE_AB_BUCKET_CAP;     // largest bucket ONE apply block takes whole (two positions per thread; its LDS table has this many slots): only
                                           // larger buckets — a key with >= ~700 occurrences in the batch — are split into slabs with pending records and a merge
 constexpr uint32_t kBucketMax = 352;      // positions per bucket aimed at, at most (Poisson(352) stays below 512 by 8 sigma: a uniform batch never needs a thread's second position)
 constexpr uint32_t kMaxBuckets = 8192;    // the partition keeps one LDS counter per bucket
+// Hot keys (a key with >= kHotCount = 256 occurrences in a bucket or in one slab of the latest batch) get a bucket of their OWN in the
+// next batch: the apply kernel reports them into a small hash set (BucketScratch::hot_*), the next partition looks every key up in an LDS
+// copy of that set and sends a listed key to bucket nbk_hash + its number.  Popular keys stay popular from batch to batch; a wrong guess
+// costs time, never results (a listed key that turns out rare is a small bucket of one key).  What it buys: the hash buckets of a skewed
+// batch hold no hot key any more — they are not split, their cold keys need no pending records and no merge — and a hot key's own bucket is
+// split into slabs of ONE key whose merge adds up one record per slab.
+constexpr uint32_t kHotCount = 256;       // occurrences (in one bucket or one slab) that make a key hot: half a slab
+constexpr uint32_t kHotSlots = 256;       // slots of the hot-key set
+constexpr uint32_t kHotCap = 128;         // hot keys that get a bucket (the set's load stays <= 0.5); a Zipf(1.05) batch of 256K keys lists ~50, one of 1M keys ~120
 // MEE_APPLY_WAVES: waves per SIMD the register allocator must leave room for in the bucket kernel (meepo_apply.hip): 8 = 64 VGPRs, four
 // 512-thread blocks per CU (6 = 80 VGPRs, three blocks)
 #ifndef MEE_APPLY_WAVES
@@ -40,6 +52,22 @@ inline void part_geometry(uint32_t n, uint32_t threads, uint32_t& blocks, uint32
 
 // the same bits, scaled the same way, as the key's table bucket (bucket_of): a block's keys live in one contiguous 1/nbk slice of the table
 __device__ __forceinline__ uint32_t apply_bucket_of(int64_t key, uint32_t nbk) { return (uint32_t)__umul64hi(mix64((uint64_t)key), (uint64_t)nbk); }
+// LDS the partition role needs beside its bucket counters: the copy of the hot-key set
+struct PartHot { unsigned long long key[kHotSlots]; uint16_t idx[kHotSlots]; };
+// a key's bucket: its own if the key is listed as hot (nbk_total > nbk_hash: hot buckets exist), else by hash
+__device__ __forceinline__ uint32_t part_bucket_of(int64_t key, uint32_t nbk_hash, uint32_t nbk_total, const PartHot* hot) {
+    if (nbk_total != nbk_hash) {
+        const unsigned long long bkey = (unsigned long long)key ^ kBias;
+        uint32_t h = (uint32_t)(mix64b((uint64_t)key) >> 20) & (kHotSlots - 1);
+        while (true) {
+            const unsigned long long k = hot->key[h];
+            if (k == bkey) { const uint32_t i = hot->idx[h]; if (i < nbk_total - nbk_hash) return nbk_hash + i; break; }
+            if (k == 0ull) break;
+            h = (h + 1) & (kHotSlots - 1);
+        }
+    }
+    return apply_bucket_of(key, nbk_hash);
+}
 
 // Inclusive prefix sums over the 64 lanes of a wave on the DPP path (row_shr 1 / 2 / 4 / 8 inside each row of 16 lanes, then row_bcast:15 into rows
 // 1 and 3 and row_bcast:31 into rows 2 and 3; lanes without a source add the `old` operand, 0).  No LDS, no lane-address arithmetic: the
@@ -99,9 +127,9 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
 // its low bit as the copy, and leaves that bit in bk.seq[1] for the apply kernel, which reads only seq[1] and bumps only seq[0] (each word
 // is written by one kind of kernel and read by the other: the kernel boundary orders them).  `cursor` = nbk words of LDS.
 template <int THREADS>
-__device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk, uint32_t per_block, uint32_t blk,
-                                          uint32_t n_blocks, const BucketScratch& bk, uint32_t* status, OpCounters* op, uint32_t* cursor,
-                                          unsigned long long* wsum /*[THREADS / 64]*/) {
+__device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk_hash, uint32_t nbk /* hash buckets + hot buckets */, uint32_t per_block, uint32_t blk,
+                                          uint32_t n_blocks, const BucketScratch& bk, uint32_t* status, OpCounters* op, uint32_t* cursor /*[nbk]*/,
+                                          unsigned long long* wsum /*[THREADS / 64]*/, PartHot* hot) {
     // Dependent round trips to memory are what this role costs (beside the training forward's row gather every one of them waits in the same
     // queues as the gather's requests: microseconds each), so it makes two: the keys together with the copy selector, and — at the very end —
     // the returns of the bucket-total atomics, which travel while the entries are scattered.
@@ -115,20 +143,36 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
         for (int q = 0; q < kKeyGroup; ++q) kr[q] = lo + threadIdx.x + q * THREADS < hi ? keys[lo + threadIdx.x + q * THREADS] : kEmpty;
     }
     const uint32_t parity = bk.seq[0] & 1u;
+    // the hot-key set the LATEST apply kernel left (copy parity ^ 1) comes into LDS with the same round trip; the copy this batch's apply kernel
+    // will fill (parity) is cleared, shared out over the blocks
+    // (BOTH copies are requested, before the selector is known: one round trip instead of two)
+    if (nbk != nbk_hash) {
+        for (uint32_t j = threadIdx.x; j < kHotSlots; j += THREADS) {
+            const unsigned long long k0 = bk.hot_key[j], k1 = bk.hot_key[kHotSlots + j];
+            const uint32_t i0 = bk.hot_idx[j], i1 = bk.hot_idx[kHotSlots + j];
+            hot->key[j] = parity ? k0 : k1;
+            hot->idx[j] = (uint16_t)min(parity ? i0 : i1, 0xFFFFu);
+        }
+    }
+    for (uint32_t j = blk * THREADS + threadIdx.x; j < kHotSlots; j += n_blocks * THREADS) { bk.hot_key[parity * kHotSlots + j] = 0ull; bk.hot_idx[parity * kHotSlots + j] = 0xFFFFFFFFu; }
+    if (blk == 0 && threadIdx.x == 0) bk.hot_n[parity] = 0u;
     // housekeeping for the apply kernel of this batch (pending-record counters, slab tickets of every bucket, the partial-row allocator) and
     // for the NEXT partition (the other copy of the totals): shared out over the blocks
     for (uint32_t j = blk * THREADS + threadIdx.x; j < bk.n_buckets_max; j += n_blocks * THREADS) {
         if (j < nbk) { bk.pend_cnt[j] = 0u; bk.ticket[j] = 0u; }
         bk.tot[(parity ^ 1u) * bk.n_buckets_max + j] = 0u;
     }
-    if (blk == 0 && threadIdx.x == 0) { op->n_part = 0u; bk.has_split[parity ^ 1u] = 0u; bk.seq[1] = parity; }
+    if (blk == 0 && threadIdx.x == 0) { op->n_part = 0u; bk.has_split[parity ^ 1u] = 0u; bk.seq[1] = parity; bk.seq[4] = 0u; }
     __syncthreads();
     bool bad = false;
+    uint32_t bid[kKeyGroup / 2];   // in_regs: the keys' buckets, two per register (< 2^16: kMaxBuckets + kHotCap), for the second pass
     if (in_regs) {
 #pragma unroll
         for (int q = 0; q < kKeyGroup; ++q) {
-            if (!reserved_key(kr[q])) atomicAdd(&cursor[apply_bucket_of(kr[q], nbk)], 1u);
+            uint32_t bq = 0xFFFFu;
+            if (!reserved_key(kr[q])) { bq = part_bucket_of(kr[q], nbk_hash, nbk, hot); atomicAdd(&cursor[bq], 1u); }
             else bad = bad || kr[q] == kReclaimed;   // EMPTY = padding, silent (SPEC.md §2)
+            bid[q / 2] = q & 1 ? bid[q / 2] | bq << 16 : bq;
         }
     } else {
         for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += kKeyGroup * THREADS) {
@@ -137,7 +181,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
             for (int q = 0; q < kKeyGroup; ++q) k[q] = i0 + q * THREADS < hi ? keys[i0 + q * THREADS] : kEmpty;
 #pragma unroll
             for (int q = 0; q < kKeyGroup; ++q) {
-                if (!reserved_key(k[q])) atomicAdd(&cursor[apply_bucket_of(k[q], nbk)], 1u);
+                if (!reserved_key(k[q])) atomicAdd(&cursor[part_bucket_of(k[q], nbk_hash, nbk, hot)], 1u);
                 else bad = bad || k[q] == kReclaimed;
             }
         }
@@ -152,7 +196,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
     }
     unsigned long long total;
     uint32_t start = (uint32_t)block_scan_u64<THREADS / 64>(sum, wsum, total);
-    constexpr uint32_t kTotRegs = THREADS >= 512 ? 2 : 3;   // buckets per thread whose atomic's return is looked at only at the end (batches of up to 1024 buckets: all of them)
+    constexpr uint32_t kTotRegs = THREADS >= 512 ? 2 : 4;   // buckets per thread whose atomic's return is looked at only at the end (batches of up to 1024 buckets: all of them)
     uint32_t tot_before[kTotRegs], tot_add[kTotRegs];
 #pragma unroll
     for (uint32_t q = 0; q < kTotRegs; ++q) { tot_before[q] = 0u; tot_add[q] = 0u; }
@@ -178,7 +222,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
 #pragma unroll
         for (int q = 0; q < kKeyGroup; ++q) {
             if (reserved_key(kr[q])) continue;
-            const uint32_t r = lo + atomicAdd(&cursor[apply_bucket_of(kr[q], nbk)], 1u);
+            const uint32_t r = lo + atomicAdd(&cursor[(bid[q / 2] >> (q & 1 ? 16 : 0)) & 0xFFFFu], 1u);
             bk.pos[r] = lo + threadIdx.x + q * THREADS;
             bk.pkey[r] = kr[q];
         }
@@ -190,7 +234,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
 #pragma unroll
             for (int q = 0; q < kKeyGroup; ++q) {
                 if (reserved_key(k[q])) continue;
-                const uint32_t r = lo + atomicAdd(&cursor[apply_bucket_of(k[q], nbk)], 1u);
+                const uint32_t r = lo + atomicAdd(&cursor[part_bucket_of(k[q], nbk_hash, nbk, hot)], 1u);
                 bk.pos[r] = i0 + q * THREADS;
                 bk.pkey[r] = k[q];
             }

@@ -229,12 +229,13 @@ template <int DIM4, int R, int NT>
 __global__ __launch_bounds__(kFindPrepareThreads, kFindPrepareThreads <= 256 ? 8 : 4) void find_prepare_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
                                                            const int64_t* __restrict__ keys, uint64_t n, f32x4* __restrict__ out,
                                                            uint8_t* __restrict__ found, float defv, uint32_t dim4_rt, int64_t* __restrict__ slots_out,
-                                                           int64_t handle_tag, uint32_t part_blocks, uint32_t nbk, uint32_t per_block,
+                                                           int64_t handle_tag, uint32_t part_blocks, uint32_t nbk_hash, uint32_t nbk, uint32_t per_block,
                                                            BucketScratch bk, uint32_t* status, OpCounters* op) {
-    extern __shared__ uint32_t part_cursor[];
+    extern __shared__ unsigned long long part_lds[];   // PartHot, then one counter per bucket (meepo_apply_part.h)
     __shared__ unsigned long long part_wsum[kFindPrepareThreads / 64];
     if (blockIdx.x < part_blocks) {   // block-uniform
-        sort_role<kFindPrepareThreads>(keys, (uint32_t)n, nbk, per_block, blockIdx.x, part_blocks, bk, status, op, part_cursor, part_wsum);
+        PartHot* hot = reinterpret_cast<PartHot*>(part_lds);
+        sort_role<kFindPrepareThreads>(keys, (uint32_t)n, nbk_hash, nbk, per_block, blockIdx.x, part_blocks, bk, status, op, reinterpret_cast<uint32_t*>(hot + 1), part_wsum, hot);
         return;
     }
     find_span<DIM4, R, NT>(tkeys, values, nb, keys, n, out, found, defv, dim4_rt, nullptr, slots_out,
@@ -1997,6 +1998,7 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     else if (!strcmp(name, "apply_spare_blocks")) t->bk.spare_blocks = value > 0 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_bucket_max")) t->bk.bucket_max = value > 0 && value <= 352 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_skew_adapt")) t->bk.skew_adapt = value != 0;
+    else if (!strcmp(name, "apply_kernel")) t->bk.kernel_choice = value < 0 ? -1 : value != 0;
     else if (!strcmp(name, "apply_overlap")) (void)value;   // retired in round 2 (a side stream for the duplicate path lost to its fork/join gaps): accepted, ignored
     else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);
     return MEE_OK;
@@ -2665,8 +2667,9 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
     }
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
-    uint32_t apply_grid;
-    const uint32_t nbk = bucket_count_for(t, n, &apply_grid);
+    uint32_t apply_grid, nbk;
+    bool apply_full;
+    const uint32_t nbk_hash = bucket_count_for(t, n, &apply_grid, &nbk, &apply_full);
     uint32_t part_blocks, per_block;
     part_geometry((uint32_t)n, kFindPrepareThreads, part_blocks, per_block);
     const int R = t->dim4 == 16 || t->dim4 == 32 ? 2 : 1;
@@ -2675,15 +2678,15 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
     const bool separate = t->prepare_debug & 1;
     if (separate) part_blocks = 0;
     const bool cached_out = t->find_nt >= 0 && (t->find_nt & 4);
-#define FINDLP1(D4, RR, NT) find_prepare_kernel<D4, RR, NT><<<part_blocks + find_blocks, kFindPrepareThreads, nbk * 4, st>>>(t->keys, (const f32x4*)t->values, t->nb, d_keys, n, (f32x4*)d_out, d_found, \
-        t->default_value, t->dim4, d_slots_out, handle_tag_of(t), part_blocks, nbk, per_block, t->bk, &t->ctr->status, t->op)
+#define FINDLP1(D4, RR, NT) find_prepare_kernel<D4, RR, NT><<<part_blocks + find_blocks, kFindPrepareThreads, sizeof(PartHot) + nbk * 4, st>>>(t->keys, (const f32x4*)t->values, t->nb, d_keys, n, (f32x4*)d_out, d_found, \
+        t->default_value, t->dim4, d_slots_out, handle_tag_of(t), part_blocks, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op)
 #define FINDLP(D4, RR) do { if (cached_out) FINDLP1(D4, RR, 68); else FINDLP1(D4, RR, 64); } while (0)
     if (t->dim4 == 16) FINDLP(16, 2); else if (t->dim4 == 32) FINDLP(32, 2); else FINDLP(0, 1);
 #undef FINDLP
 #undef FINDLP1
     MEE_HIP(hipGetLastError());
     if (separate) { if (int rc = bucket_apply_prepare(t, d_keys, (uint32_t)n, st)) return rc; }
-    else { t->part_blocks = part_blocks; t->part_per_block = per_block; t->part_nbk = nbk; t->part_grid = apply_grid; }
+    else { t->part_blocks = part_blocks; t->part_per_block = per_block; t->part_nbk = nbk; t->part_nbk_hash = nbk_hash; t->part_grid = apply_grid; t->part_full = apply_full; }
     t->prepared_n = n; t->prepared_keys = d_keys; t->prepared_path = 1;
     return MEE_OK;
 }

@@ -76,8 +76,13 @@ struct BucketScratch {
     int64_t* pend_key;    // [fast_max] pending records of split buckets: key …
     int64_t* pend_slot;   // [fast_max] … the table slot its handle named (located applies: the merge needs no probe) …
     double* pend_row;     // [fast_max][dim] … and the fp64 partial sum of its gradient rows within one slab
+    unsigned long long* hot_key;   // [2][kHotSlots] the hot-key set (key ^ kBias, 0 = empty): keys that filled a slab, reported by the apply kernel; two copies like tot
+    uint32_t* hot_idx;    // [2][kHotSlots] the number the key was given (its bucket in the next batch: nbk_hash + number); 0xFFFFFFFF: none
+    uint32_t* hot_n;      // [2] numbers handed out
     uint32_t *h_slabs, *h_slabs_dev;   // pinned host word (and its device address): slabs of the latest batch's split buckets, written by the apply kernel
     uint32_t skew_adapt;  // tuning ("apply_skew_adapt", default 1): size the next batch's bucket count by h_slabs
+    uint32_t skew_sticky; // batches for which the FULL apply kernel stays chosen after the latest skewed batch
+    int kernel_choice;    // tuning ("apply_kernel"): -1 = by the stream (default), 0 = always the LEAN kernel, 1 = always the FULL kernel
     uint32_t spare_blocks; // tuning ("apply_spare_blocks"): accepted and ignored since round 4 (the apply kernel's blocks claim the slabs of split buckets themselves)
     uint32_t bucket_max;  // tuning ("apply_bucket_max"): positions per bucket aimed at, at most (0 = the default)
     uint32_t n_buckets_max, slots;   // slots: apply blocks the device keeps resident at once (CUs x blocks per CU): bucket counts are multiples of it
@@ -125,6 +130,8 @@ struct mee_table {
     mee::BucketScratch bk;      // bucketed apply (null pointers when the table has no optimizer)
     int apply_path;             // -1 = the library's choice, 0 = group-table apply, 1 = bucketed apply
     uint32_t prepared_path;     // which path a pending mee_apply_prepare took
+    uint32_t part_nbk_hash;   // ... of which the first part_nbk_hash are hash buckets (the rest: one per hot key)
+    bool part_full;           // ... and the apply kernel chosen for it (FULL | LEAN: meepo_apply.hip)
     uint32_t part_blocks, part_per_block, part_nbk, part_grid;   // bucketed apply: how the latest partition split the batch (blocks, batch positions per block, buckets) and the apply grid that goes with it
 };
 
@@ -164,6 +171,6 @@ int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStr
 int bucket_apply_discard(mee_table* t, hipStream_t st);
 int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const OptArgs& a, const uint32_t* d_gidx, const int64_t* d_slots, hipStream_t st,
                         const GroupDesc* d_desc = nullptr, uint32_t n_tables = 0);
-uint32_t bucket_count_for(const mee_table* t, uint64_t n, uint32_t* grid_out = nullptr);
+uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out = nullptr, uint32_t* nbk_total_out = nullptr, bool* full_out = nullptr);
 
 }  // namespace mee

@@ -465,8 +465,9 @@ def _keys_of_apply_bucket_zero(count, seed):
 
 
 @pytest.mark.parametrize("opt", ["adagrad", "adam"])
+@pytest.mark.parametrize("kernel", ["auto", "lean", "full"])
 @pytest.mark.parametrize("case", ["one_key", "one_bucket_many_keys", "forty_hot_keys", "one_bucket_two_keys", "bucket_of_900_distinct", "bucket_of_300_warm"])
-def test_bucketed_apply_extremes(dev, case, opt):
+def test_bucketed_apply_extremes(dev, case, opt, kernel):
     """The rare ways through the bucketed apply (meepo_apply.hip), each forced by construction, plain and located, against the oracle:
     one_key — a single key fills 400K of a 410K-position batch: ~780 slabs of one bucket each emit a record of that key, more records of ONE key
     than a merge pass holds (mono_pass);  one_bucket_many_keys — 3000 keys that all fall into apply bucket 0, 100+ occurrences each: every slab
@@ -475,7 +476,10 @@ def test_bucketed_apply_extremes(dev, case, opt):
     one_bucket_two_keys — two keys of one bucket, 150K occurrences each: the prefix split must separate exactly two keys;
     bucket_of_900_distinct — 900 keys of apply bucket 0, once each, in a small batch: ONE block takes a bucket of ~1000 positions whole (two positions
     per thread) with its LDS hash table filled almost to the last slot;  bucket_of_300_warm — 300 keys of bucket 0 with 1..6 occurrences each: the
-    same path with runs."""
+    same path with runs.
+    kernel: which apply kernel takes the batches — "lean" (block = bucket; a split bucket is taken by its own block one key at a time: what the
+    FIRST skewed batch of a stream gets), "full" (slabs, pending records, merges; from the second step on also the hot keys' own buckets, which the
+    first step's kernel reported), "auto" (the library's choice: lean for step 0, full for step 1)."""
     dim, n_bg = 64, 20000
     rng = np.random.default_rng(5)
     bg = synth.keys_np(321, 0, n_bg)
@@ -502,9 +506,11 @@ def test_bucketed_apply_extremes(dev, case, opt):
     o = oracle.OracleTable(1 << 17, dim, optimizer=okind, initial_accumulator=0.1)
     for t in (ta, tb):
         t.insert(T(keys, dev), T(rows, dev))
+        t.set_tuning("apply_kernel", {"auto": -1, "lean": 0, "full": 1}[kernel])
     o.insert(keys, rows)
     bkt = T(bk, dev)
-    for s in range(2):
+    for s in range(3 if kernel == "full" else 2):
+        torch.cuda.synchronize()   # (the host sizes step s + 1 by what step s reported: hot keys' buckets exist from the second full step on)
         g = (rng.standard_normal((n, dim)) * 0.01).astype(np.float32)
         gt = T(g, dev)
         _, _, slots = tb.find_located(bkt, prepare_apply=(s == 1))

@@ -21,6 +21,7 @@ for i in range(12):
         t.apply_adagrad(batches[i % 8], grads, lr=0.01, slots=slots)
     else:
         t.apply_adagrad(batches[i % 8], grads, lr=0.01)
+    torch.cuda.synchronize()   # (the library sizes a batch's bucket count by what the latest FINISHED apply reported: let the host see it, as a training loop's does)
 torch.cuda.synchronize()
 n_blocks = 768
 buf = np.zeros(16384 * 8 + 1024 * 128, dtype=np.uint64)
