@@ -165,14 +165,17 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
     if (blk == 0 && threadIdx.x == 0) { op->n_part = 0u; bk.has_split[parity ^ 1u] = 0u; bk.seq[1] = parity; bk.seq[4] = 0u; }
     __syncthreads();
     bool bad = false;
-    uint32_t bid[kKeyGroup / 2];   // in_regs: the keys' buckets, two per register (< 2^16: kMaxBuckets + kHotCap), for the second pass
+    // in_regs: the keys' buckets, two per register (< 2^16: kMaxBuckets + kHotCap), for the second pass — in the partition kernel of an apply only:
+    // inside the training forward's launch (256-thread blocks, 64 registers for the sake of the find) the second pass looks them up again
+    constexpr bool kKeepBuckets = THREADS >= 512;
+    uint32_t bid[kKeyGroup / 2];
     if (in_regs) {
 #pragma unroll
         for (int q = 0; q < kKeyGroup; ++q) {
             uint32_t bq = 0xFFFFu;
             if (!reserved_key(kr[q])) { bq = part_bucket_of(kr[q], nbk_hash, nbk, hot); atomicAdd(&cursor[bq], 1u); }
             else bad = bad || kr[q] == kReclaimed;   // EMPTY = padding, silent (SPEC.md §2)
-            bid[q / 2] = q & 1 ? bid[q / 2] | bq << 16 : bq;
+            if (kKeepBuckets) bid[q / 2] = q & 1 ? bid[q / 2] | bq << 16 : bq;
         }
     } else {
         for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += kKeyGroup * THREADS) {
@@ -222,7 +225,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
 #pragma unroll
         for (int q = 0; q < kKeyGroup; ++q) {
             if (reserved_key(kr[q])) continue;
-            const uint32_t r = lo + atomicAdd(&cursor[(bid[q / 2] >> (q & 1 ? 16 : 0)) & 0xFFFFu], 1u);
+            const uint32_t r = lo + atomicAdd(&cursor[kKeepBuckets ? (bid[q / 2] >> (q & 1 ? 16 : 0)) & 0xFFFFu : part_bucket_of(kr[q], nbk_hash, nbk, hot)], 1u);
             bk.pos[r] = lo + threadIdx.x + q * THREADS;
             bk.pkey[r] = kr[q];
         }
