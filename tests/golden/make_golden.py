@@ -4,7 +4,8 @@
                          here against oracle/meepo_oracle.c before writing: two independent implementations.
   optimizer_golden.npz   SPEC §4 cross-check against THIRD-PARTY math: torch.optim.Adagrad and
                          torch.optim.SparseAdam on nn.Embedding(sparse=True) (duplicate indices coalesced by
-                         sum), 5 steps, dim 16 and 64.  torch is an installed package, not reference code.
+                         sum), 5 steps, dim 16 and 64; round 4: five more cases (dim 128, non-default eps and betas,
+                         initial_accumulator_value 0 and 0.1).  torch is an installed package, not reference code.
 
 The reference snapshot (/root/reference) has no tests, fixtures or code to generate vectors from, so these are
 the only pins the oracle has ("parity unpinned" by upstream).
@@ -77,10 +78,42 @@ def optimizer_golden():
                 y.backward(grads[s])
                 opt.step()
             out[f"{name}_w_{dim}"] = emb.weight.detach().numpy().copy()
+    # round 4: more of the parameter space — dim 128 (configs[3]'s row width), non-default eps / betas, initial_accumulator_value 0 and 0.1.
+    # Each case is self-describing (cases_json) so that the tests iterate over whatever is here.
+    cases = [dict(tag="adagrad_d128", opt="adagrad", dim=128, lr=0.05, eps=1e-10, acc0=0.1),
+             dict(tag="adagrad_d64_eps1e-6_acc0", opt="adagrad", dim=64, lr=0.02, eps=1e-6, acc0=0.0),
+             dict(tag="adagrad_d128_eps1e-4_acc0", opt="adagrad", dim=128, lr=0.1, eps=1e-4, acc0=0.0),
+             dict(tag="adam_d128", opt="adam", dim=128, lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8),
+             dict(tag="adam_d64_eps1e-6_b0.8_0.99", opt="adam", dim=64, lr=0.003, beta1=0.8, beta2=0.99, eps=1e-6)]
+    for ci, c in enumerate(cases):
+        g = torch.Generator().manual_seed(4321 + ci)
+        rows, steps, batch, dim = 193, 6, 160, c["dim"]
+        w0 = torch.rand(rows, dim, generator=g) - 0.5
+        # every batch: 112 distinct rows, 48 of them twice — PAIRS only, never more: torch coalesces duplicates with an fp32 sum, which equals
+        # SPEC.md's "fp64 sum, rounded once" bit for bit for two terms; with three or more terms torch's own rounding error, amplified where the
+        # terms cancel (and again by eps when the accumulator starts at 0), exceeds the 1e-6 the comparison allows — longer runs are checked
+        # against the oracle, not against torch
+        idx = torch.stack([torch.cat([p[:112], p[:48]]) for p in (torch.randperm(rows, generator=g) for _ in range(steps))])
+        grads = torch.randn(steps, batch, dim, generator=g) * 0.1
+        emb = torch.nn.Embedding(rows, dim, sparse=True)
+        with torch.no_grad():
+            emb.weight.copy_(w0)
+        if c["opt"] == "adagrad":
+            opt = torch.optim.Adagrad(emb.parameters(), lr=c["lr"], eps=c["eps"], initial_accumulator_value=c["acc0"])
+        else:
+            opt = torch.optim.SparseAdam(emb.parameters(), lr=c["lr"], betas=(c["beta1"], c["beta2"]), eps=c["eps"])
+        for s in range(steps):
+            opt.zero_grad()
+            emb(idx[s]).backward(grads[s])
+            opt.step()
+        t = c["tag"]
+        out[f"c_{t}_w0"], out[f"c_{t}_idx"], out[f"c_{t}_grads"], out[f"c_{t}_w"] = w0.numpy(), idx.numpy(), grads.numpy(), emb.weight.detach().numpy().copy()
+    out["cases_json"] = np.array(json.dumps(cases))
     np.savez_compressed(os.path.join(HERE, "optimizer_golden.npz"), **out)
     print("optimizer_golden.npz written")
 
 
 if __name__ == "__main__":
-    hash_kat()
+    if "--optimizer-only" not in sys.argv:
+        hash_kat()
     optimizer_golden()

@@ -38,6 +38,25 @@ def test_hash_kat_on_device(dev):
             assert [int(x) for x in own.cpu().numpy()] == exp_o
 
 
+def test_published_known_answers_on_device(dev):
+    """The PUBLISHED outputs of splitmix64 and murmur3 fmix64 (tests/golden/published_kat.json) from the device's own mixers: mix64 in full through
+    mee_hash_batch's mix output, mix64b through the owner function at 2^31 shards (owner = the top 31 bits of mix64b)."""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "published_kat.json")) as f:
+        pub = json.load(f)
+    as_i64 = lambda x: x - (1 << 64) if x >= 1 << 63 else x
+    pairs, gamma = [], int(pub["splitmix64"]["gamma"], 0)   # output k of the stream seeded with s is mix64(s + (k + 1) * gamma)
+    for st_ in pub["splitmix64"]["streams"]:
+        x = int(st_["seed"], 0)
+        for o in st_["outputs"]:
+            x = (x + gamma) & ((1 << 64) - 1)
+            pairs.append((x, int(o, 0)))
+    mix, _, _ = hash_batch(T(np.array([as_i64(x) for x, _ in pairs], dtype=np.int64), dev), 1, 1)
+    assert [int(v) for v in mix.cpu().numpy().view(np.uint64)] == [w for _, w in pairs]
+    fm = pub["fmix64"]["pairs"]
+    _, _, own = hash_batch(T(np.array([as_i64(int(a, 0)) for a, _ in fm if int(a, 0) != (1 << 63)], dtype=np.int64), dev), 1, 1 << 31)
+    assert [int(v) for v in own.cpu().numpy()] == [int(b, 0) >> 33 for _, b in fm]
+
+
 @pytest.mark.parametrize("dim,n,load", [(16, 20000, 0.75), (64, 50000, 0.75), (128, 8192, 0.9), (4, 1000, 0.5), (40, 3000, 0.75),
                                         (256, 2000, 0.75)])
 def test_insert_find_assign_export(dev, dim, n, load):
@@ -777,6 +796,29 @@ def test_optimizer_vs_torch_golden_on_gpu(dev):
                     t.apply_adam(T(keys[idx[s]], dev), T(grads[s], dev), lr=0.01, step=s + 1)
             got, _ = t.find(T(keys, dev))
             np.testing.assert_allclose(got.cpu().numpy(), z[f"{name}_w_{dim}"], rtol=2e-6, atol=1e-7)
+
+
+def test_optimizer_vs_torch_golden_more_cases_on_gpu(dev):
+    """Round 4's golden cases (dim 128, non-default eps / betas, initial accumulator 0 and 0.1) on the device, plain and located applies."""
+    z = np.load(os.path.join(GOLDEN, "optimizer_golden.npz"))
+    cases = json.loads(str(z["cases_json"]))
+    for c in cases:
+        t_ = c["tag"]
+        w0, idx, grads = z[f"c_{t_}_w0"], z[f"c_{t_}_idx"], z[f"c_{t_}_grads"]
+        keys = synth.keys_np(22, 0, w0.shape[0])
+        adagrad = c["opt"] == "adagrad"
+        for located in (False, True):
+            t = LookupTable(1024, c["dim"], device=dev, optimizer=OPT_ADAGRAD if adagrad else OPT_ADAM, max_batch=1024, initial_accumulator=c.get("acc0", 0.0))
+            t.insert(T(keys, dev), T(w0, dev))
+            for s in range(idx.shape[0]):
+                kt = T(keys[idx[s]], dev)
+                slots = t.find_located(kt)[2] if located else None
+                if adagrad:
+                    t.apply_adagrad(kt, T(grads[s], dev), lr=c["lr"], eps=c["eps"], slots=slots)
+                else:
+                    t.apply_adam(kt, T(grads[s], dev), lr=c["lr"], beta1=c["beta1"], beta2=c["beta2"], eps=c["eps"], step=s + 1, slots=slots)
+            got, _ = t.find(T(keys, dev))
+            np.testing.assert_allclose(got.cpu().numpy(), z[f"c_{t_}_w"], rtol=2e-6, atol=1e-7, err_msg=f"{t_} located={located}")
 
 
 @pytest.mark.parametrize("g", [1, 2, 3, 8])

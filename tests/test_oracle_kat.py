@@ -45,6 +45,38 @@ def test_hash_kat_pyspec(kat):
             assert 1 <= int(exp[i]) < max(2, int(nb))
 
 
+def published_kat():
+    with open(os.path.join(GOLDEN, "published_kat.json")) as f:
+        return json.load(f)
+
+
+def splitmix_inputs_outputs(pub):
+    """(mix64 input, published output) pairs: output k of the stream seeded with s is mix64(s + (k + 1) * gamma)."""
+    gamma = int(pub["splitmix64"]["gamma"], 0)
+    pairs = []
+    for st_ in pub["splitmix64"]["streams"]:
+        x = int(st_["seed"], 0)
+        for o in st_["outputs"]:
+            x = (x + gamma) & ((1 << 64) - 1)
+            pairs.append((x, int(o, 0)))
+    return pairs
+
+
+def test_published_known_answers():
+    """Third-party anchors for the integer half of the oracle: the PUBLISHED outputs of splitmix64 (SPEC.md mix64) and of murmur3's fmix64
+    (SPEC.md mix64b), against the pure-Python restatement AND the C oracle."""
+    pub = published_kat()
+    L = oracle.lib()
+    as_i64 = lambda x: x - (1 << 64) if x >= 1 << 63 else x
+    for x, want in splitmix_inputs_outputs(pub):
+        assert pyspec.mix64(x) == want
+        mix, _, _ = oracle.hash_batch(np.array([as_i64(x)], dtype=np.int64), 1, 1)
+        assert int(mix[0]) == want
+    for a, b in pub["fmix64"]["pairs"]:
+        assert pyspec.mix64b(int(a, 0)) == int(b, 0)
+        assert int(L.meo_mix64b(int(a, 0))) == int(b, 0)
+
+
 def test_hash_ranges(kat):
     keys = np.array([int(k) for k in kat["keys"]], dtype=np.int64)
     _, bkt, own = oracle.hash_batch(keys, 625, 8)
@@ -231,6 +263,32 @@ def test_optimizers_vs_torch_golden(dim):
         got, found = t.find(keys)
         assert found.all()
         np.testing.assert_allclose(got, z[f"{name}_w_{dim}"], rtol=2e-6, atol=1e-7)
+
+
+def golden_cases():
+    z = np.load(os.path.join(GOLDEN, "optimizer_golden.npz"))
+    return z, json.loads(str(z["cases_json"]))
+
+
+def test_optimizers_vs_torch_golden_more_cases():
+    """Round 4's cases: dim 128, non-default eps / betas, initial accumulator 0 and 0.1 (tests/golden/make_golden.py)."""
+    z, cases = golden_cases()
+    assert len(cases) >= 5
+    for c in cases:
+        t_ = c["tag"]
+        w0, idx, grads = z[f"c_{t_}_w0"], z[f"c_{t_}_idx"], z[f"c_{t_}_grads"]
+        keys = synth.keys_np(22, 0, w0.shape[0])
+        adagrad = c["opt"] == "adagrad"
+        t = oracle.OracleTable(1024, c["dim"], optimizer=oracle.OPT_ADAGRAD if adagrad else oracle.OPT_ADAM, initial_accumulator=c.get("acc0", 0.0))
+        t.insert(keys, w0)
+        for s in range(idx.shape[0]):
+            if adagrad:
+                t.apply_adagrad(keys[idx[s]], grads[s], c["lr"], c["eps"])
+            else:
+                t.apply_adam(keys[idx[s]], grads[s], c["lr"], c["beta1"], c["beta2"], c["eps"], s + 1)
+        got, found = t.find(keys)
+        assert found.all()
+        np.testing.assert_allclose(got, z[f"c_{t_}_w"], rtol=2e-6, atol=1e-7, err_msg=t_)
 
 
 def test_pool_rows_known_answer():
