@@ -180,7 +180,7 @@ def cpu_baseline(synth, dim, batch, n_keys_config, load, budget_s=16.0):
                       f"~{budget_s / len(counts):.0f}s per thread count ({', '.join(map(str, counts))} threads; `value` = the best of them, `cores` = its thread count)"}
 
 
-def kernel_window(table, batches, out, found, dev, launches=200, regions=5, warm=20):
+def kernel_window(table, batches, out, found, dev, launches=200, regions=5, warm=20, flags=None):
     """The dominant kernel alone: `regions` windows of `launches` back-to-back mee_find launches on the launch stream, HIP events
     around each window, no host sync inside -> (median, min) microseconds per launch.  Independent of --steps, so that the
     roofline object of a short driver run (--steps 20) agrees with a rocprofv3 average over hundreds of launches.
@@ -189,8 +189,9 @@ def kernel_window(table, batches, out, found, dev, launches=200, regions=5, warm
     import statistics
     outs, founds = (out, found) if isinstance(out, (list, tuple)) else ([out], [found])
     nb, no = len(batches), len(outs)
+    # flags: this request queue's cache policy, passed with every call (mee_find_ex); None = the library's default rule (mee_find)
     for i in range(warm):
-        table.find(batches[i % nb], out=outs[i % no], found=founds[i % no])
+        table.find(batches[i % nb], out=outs[i % no], found=founds[i % no], flags=flags)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     per = []
     for r in range(regions):
@@ -198,7 +199,7 @@ def kernel_window(table, batches, out, found, dev, launches=200, regions=5, warm
         e0.record()
         for i in range(launches):
             j = r * launches + i
-            table.find(batches[j % nb], out=outs[j % no], found=founds[j % no])
+            table.find(batches[j % nb], out=outs[j % no], found=founds[j % no], flags=flags)
         e1.record()
         torch.cuda.synchronize(dev)
         per.append(e0.elapsed_time(e1) * 1e3 / launches)
@@ -224,11 +225,10 @@ def stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, uniform
                       "algorithmic_GBps": batch * bpl / med / 1e3, "frac_of_hbm_roofline": batch * bpl / med / 1e3 / HBM_PEAK_GBS,
                       "read_only_GBps": batch * (16 + 4 * dim) / med / 1e3,
                       "mean_probe_length_buckets": table.probe_length(bs[0])}
-    # the same uniform stream with the caller's cache-policy hint for a stream without reuse (mee_set_tuning "find_nt" = 7: streaming row and
-    # bucket loads; the default keeps them cached because skewed streams re-read their hot rows)
-    table.set_tuning("find_nt", 7)
-    med, mn = kernel_window(table, uniform_batches, out, found, dev)
-    table.set_tuning("find_nt", -1)
+    # the same uniform stream with the caller's per-call cache-policy hint for a stream without reuse (mee_find_ex: streaming row and bucket
+    # loads, cached stores; the default keeps the loads cached because skewed streams re-read their hot rows)
+    from meepoembedding_amd import _lib as _ml
+    med, mn = kernel_window(table, uniform_batches, out, found, dev, flags=_ml.FIND_STREAM_ROWS | _ml.FIND_STREAM_BUCKETS | _ml.FIND_CACHED_STORES)
     rows["uniform_with_streaming_load_hint"] = {"us_per_launch_median": med, "us_per_launch_min": mn, "lookups_per_s": batch / med * 1e6,
                                                 "algorithmic_GBps": batch * bpl / med / 1e3, "frac_of_hbm_roofline": batch * bpl / med / 1e3 / HBM_PEAK_GBS}
     # the same uniform stream through mee_find_unordered: launches not ordered behind each other (hipExtAnyOrderLaunch), two alternating
@@ -276,12 +276,11 @@ def stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, uniform
     b1 = [allk[o:o + m1] for o in range(0, allk.numel() - m1 + 1, m1)][:4]
     o1, f1 = [obig[:m1], obig[m1:2 * m1]], [fbig[:m1], fbig[m1:2 * m1]]
     row = {"lookups_per_launch": m1, "output_buffers": 2}
-    for label, nt in (("default_policy", -1), ("streaming_row_load_hint", 1), ("streaming_load_hint", 3)):
-        table.set_tuning("find_nt", nt)
-        med, mn = kernel_window(table, b1, o1, f1, dev, launches=50, regions=5, warm=5)
+    for label, fl in (("default_policy", None), ("streaming_row_load_hint", _ml.FIND_STREAM_STORES | _ml.FIND_STREAM_ROWS),
+                      ("streaming_load_hint", _ml.FIND_STREAM_STORES | _ml.FIND_STREAM_ROWS | _ml.FIND_STREAM_BUCKETS)):
+        med, mn = kernel_window(table, b1, o1, f1, dev, launches=50, regions=5, warm=5, flags=fl)
         row[label] = {"us_per_launch_median": med, "us_per_launch_min": mn, "lookups_per_s": m1 / med * 1e6,
                       "algorithmic_GBps": m1 * bpl / med / 1e3, "frac_of_hbm_roofline": m1 * bpl / med / 1e3 / HBM_PEAK_GBS}
-    table.set_tuning("find_nt", -1)
     rows["north_star_batch_1M"] = row
     del obig, fbig, allk
     return rows
@@ -395,7 +394,7 @@ def p2p_selftest(ctrl, log, timeout=120, script="p2p_selftest.py", port_offset=1
     return bool(int(ok.item()))
 
 
-def train_streams(table, synth, n_keys, batch, dim, dev, out, found, bpl, steps=60, regions=3):
+def train_streams(table, synth, n_keys, batch, dim, dev, out, found, bpl, steps=60, regions=3, opt="adagrad"):
     """the find + sparse-Adagrad step on a uniform and a Zipf(1.05) key stream, bytes by the 264*B + 1032*U rule
     with U measured; median of `regions` HIP-event windows of `steps` steps each (after the timed region: not part of `value`)."""
     res = {}
@@ -406,23 +405,30 @@ def train_streams(table, synth, n_keys, batch, dim, dev, out, found, bpl, steps=
         bs_ = lookup_batches(synth, n_keys, batch, 8, dist_name, dev, seed=11)
         uniq = sum(int(torch.unique(b_).numel()) for b_ in bs_) / len(bs_)
 
+        step_no = [0]
+
+        def apply(i, **kw):
+            if opt == "adagrad":
+                table.apply_adagrad(bs_[i % 8], grads[i % 4], lr=0.01, eps=1e-10, **kw)
+            else:
+                step_no[0] += 1
+                table.apply_adam(bs_[i % 8], grads[i % 4], lr=0.001, step=step_no[0], **kw)
+
         def step(i):   # the training forward (its launch also partitions the batch for the backward), then the backward on the located slots
             table.find_located(bs_[i % 8], out=out, found=found, slots=slots, prepare_apply=fused_forward[0])
-            table.apply_adagrad(bs_[i % 8], grads[i % 4], lr=0.01, eps=1e-10, slots=slots)
+            apply(i, slots=slots)
 
         def apply_only(i):
-            table.apply_adagrad(bs_[i % 8], grads[i % 4], lr=0.01, eps=1e-10)
+            apply(i)
 
         row = {"unique_keys_per_batch": uniq}
         fused_forward = [True]
-        for label, fn, nbytes in (("step", step, (bpl + 8 + 4 * dim) * batch + (8 + 16 * dim) * uniq),
-                                  ("step_separate_forward", step, (bpl + 8 + 4 * dim) * batch + (8 + 16 * dim) * uniq),
-                                  ("apply_alone", apply_only, (8 + 4 * dim) * batch + (8 + 16 * dim) * uniq),
-                                  ("step_group_table_apply", step, (bpl + 8 + 4 * dim) * batch + (8 + 16 * dim) * uniq),
-                                  ("apply_alone_group_table_apply", apply_only, (8 + 4 * dim) * batch + (8 + 16 * dim) * uniq)):
-            # the last two rows: the same work through round 2's group-table apply (mee_set_tuning "apply_path" = 0), for comparison
-            table.set_tuning("apply_path", 0 if label.endswith("group_table_apply") else -1)
-            fused_forward[0] = label == "step"   # "step": mee_find_located_prepare + mee_apply_adagrad_located; the other step rows: mee_find_located + the apply
+        per_u = 8 + (16 if opt == "adagrad" else 24) * dim   # table key + w, state read and written (1032 B Adagrad / 1544 B Adam at dim 64)
+        sfx = "" if opt == "adagrad" else "_adam"
+        for label, fn, nbytes in (("step" + sfx, step, (bpl + 8 + 4 * dim) * batch + per_u * uniq),
+                                  ("step_separate_forward" + sfx, step, (bpl + 8 + 4 * dim) * batch + per_u * uniq),
+                                  ("apply_alone" + sfx, apply_only, (8 + 4 * dim) * batch + per_u * uniq)):
+            fused_forward[0] = label.startswith("step") and "separate" not in label   # "step": mee_find_located_prepare + mee_apply_*_located; "step_separate_forward": mee_find_located + the apply
             ts = []
             for _ in range(regions):
                 for i in range(5):
@@ -437,7 +443,6 @@ def train_streams(table, synth, n_keys, batch, dim, dev, out, found, bpl, steps=
             us = sorted(ts)[len(ts) // 2]
             row[label] = {"us": us, "keys_per_s": batch / us * 1e6, "algorithmic_bytes_per_key": nbytes / batch,
                           "frac_of_hbm_roofline": nbytes / us / 1e3 / HBM_PEAK_GBS}
-        table.set_tuning("apply_path", -1)
         res[name] = row
     return res
 
@@ -456,9 +461,43 @@ def configs2_rows(find_table, synth, n_keys, dim, dev, chunk, batch, bpl):
     found = torch.empty(batch, dtype=torch.uint8, device=dev)
     rows = train_streams(t, synth, n_keys, batch, dim, dev, out, found, bpl)
     rows["workload"] = (f"configs[2]: 1xMI355X, {n_keys // 1_000_000}M keys, dim {dim}, forward gather (mee_find_located) + sparse-Adagrad backward scatter-update on the "
-                        f"located slots, {batch}-key batches, N(0, 1e-2) grads, lr 0.01; {t.table_bytes / 1e9:.1f} GB table; median of 3 HIP-event windows of 60 steps")
+                        f"located slots, {batch}-key batches, N(0, 1e-2) grads, lr 0.01; {t.table_bytes / 1e9:.1f} GB table; median of 3 HIP-event windows of 60 steps; "
+                        f"the *_adam rows: the same with sparse Adam (lazy: untouched rows' moments not decayed) on a table with two state planes")
     t.close()
+    torch.cuda.empty_cache()
+    try:   # north_star "Adagrad/Adam": the same rows with sparse Adam (103 GB table: rows + two moment planes)
+        from meepoembedding_amd import OPT_ADAM
+        ta = LookupTable(cap, dim, device=dev, max_batch=max(chunk, 2 * batch), optimizer=OPT_ADAM)
+        populate(ta, synth, n_keys, dim, dev, chunk)
+        adam = train_streams(ta, synth, n_keys, batch, dim, dev, out, found, bpl, opt="adam")
+        for name_, row_ in adam.items():
+            rows[name_].update({k_: v_ for k_, v_ in row_.items() if k_.endswith("_adam")})
+        rows["adam_table_gb"] = round(ta.table_bytes / 1e9, 1)
+        ta.close()
+    except Exception as e:  # noqa: BLE001
+        rows["adam_error"] = repr(e)
     return rows
+
+
+def visible_gpu_count() -> int:
+    """GPUs this process could use, WITHOUT touching the HIP runtime (the launcher forks its ranks right after: nothing that may open the
+    device belongs in front of that): KFD topology nodes with SIMDs, cut down by HIP_/ROCR_/CUDA_VISIBLE_DEVICES if they are set."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for ln in open(f):
+                if ln.startswith("simd_count") and int(ln.split()[1]) > 0:
+                    n += 1
+        except OSError:
+            pass
+    if n == 0:
+        n = len(glob.glob("/dev/dri/renderD*"))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def self_launch(n_ranks: int) -> int:
@@ -561,8 +600,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1 and "LOCAL_RANK" not in os.environ:
-        # no launcher around us: become the launcher.  Nothing in this process has touched the GPU yet (device_count() only counts).
-        have = torch.cuda.device_count()
+        # no launcher around us: become the launcher.  Nothing in this process has touched the GPU yet (the GPUs are counted from sysfs).
+        have = visible_gpu_count()
         if args.backend == "nccl" and have < args.gpus:
             raise SystemExit(f"--gpus {args.gpus} over RCCL needs {args.gpus} GPUs, {have} visible "
                              f"(--backend gloo rehearses the N>1 flow with ranks sharing the GPUs there are)")
@@ -596,9 +635,11 @@ def main():
     from meepoembedding_amd import LookupTable, Router, hash_batch, synth
     from meepoembedding_amd.sharded import ShardedLookupTable
 
-    def log(msg):
+    t_start = time.time()
+
+    def log(msg):   # --verbose: every phase with the wall time since the start of the process (populate, self-tests, probes, timed region ...)
         if args.verbose and rank == 0:
-            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+            print(f"[bench +{time.time() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
     sharded = world > 1 or args.force_sharded
     keys_per_gpu = args.keys or (125_000_000 if sharded else 100_000_000)
@@ -655,6 +696,8 @@ def main():
         peer_ctxs = []       # every peer-mapped context the timed steps use (several when lookups are kept in flight)
         t_best = None        # seconds per step of `step`, once something has been timed against it
         native = None        # the RcclShardedTable that carries `step`, if any
+        verified_native = [] # (label, context) of every native layout that matched the torch.distributed path bit for bit in the probe
+        p2p_verified = False # the peer-mapped context matched it too
         native_tables = []   # every native context created by the probe: closed (communicators destroyed) before the process group goes
         # ---- the exchange behind the C-ABI (mee_sharded_*: grouped ncclSend/ncclRecv inside the library), both layouts ----
         # (the gloo rehearsal on one GPU can take this path too when MEE_RCCL_LIB names the test suite's shared-memory stand-in for RCCL)
@@ -683,6 +726,7 @@ def main():
                 if int(okn.item()) != 1:
                     log(f"native rccl ({label}): differs from the torch.distributed path or a segment overflowed: not used")
                     continue
+                verified_native.append((label, nt))
                 t_n = timed(step_nat)
                 log(f"transport probe: native rccl ({label}) {t_n * 1e3:.3f} ms/step")
                 if t_n < t_best or (args.transport == "native" and native is None):
@@ -723,6 +767,7 @@ def main():
                     same = torch.tensor([int(torch.equal(o_a, o_b) and torch.equal(f_a, f_b))], device=ctrl)
                     dist.all_reduce(same, op=dist.ReduceOp.MIN)
                     log(f"transport probe: rccl {t_rccl * 1e3:.3f} ms/step, p2p {t_p2p * 1e3:.3f} ms/step, re-check {'ok' if int(same.item()) else 'MISMATCH'}")
+                    p2p_verified = int(same.item()) == 1
                     if int(same.item()) == 1 and (args.transport == "p2p" or t_p2p < t_best):
                         step, transport, native, carrier, peer_ctxs = step_p2p, "peer-mapped stores (no all-to-all)", None, "p2p", [peer]
                         pd = max(1, args.p2p_depth)
@@ -783,25 +828,24 @@ def main():
             table.apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10, slots=slots)
             return o_, f_
     else:
+        find_flags = None   # the cache policy this request queue passes with every call (mee_find_ex); None = the library's default rule
         if n_out > 1:
-            # a caller whose result buffers rotate knows that nothing re-reads them from cache: mee_set_tuning "find_nt" = 0 (cached loads,
-            # streaming stores) is its hint — the library's own rule only sees one call's size (64 MB: cached stores) — and one whose keys are
-            # uniform over a table far larger than the caches adds streaming row loads (find_nt = 1; skewed streams re-read their hot rows and
-            # lose with it: 27 -> 30 us on Zipf(1.05)).  Keep whichever is fastest here.
-            probe = {}
-            for label, nt in (("auto", -1), ("streaming_stores", 0), ("streaming_stores_and_row_loads", 1)):
-                table.set_tuning("find_nt", nt)
-                probe[label] = kernel_window(table, batches, outs, founds, dev, launches=100, regions=3, warm=10)[0]
+            # a caller whose result buffers rotate knows that nothing re-reads them from cache: MEE_FIND_STREAM_STORES with every call is its hint
+            # — the library's own rule only sees one call's size (64 MB: cached stores) — and one whose keys are uniform over a table far larger
+            # than the caches adds MEE_FIND_STREAM_ROWS (skewed streams re-read their hot rows and lose with it: 27 -> 30 us on Zipf(1.05)).
+            # The hints travel with the CALL (round 3 set them on the table, which other callers of the table share): keep whichever is fastest.
+            from meepoembedding_amd import _lib as _ml
+            choices = {"auto": None, "streaming_stores": _ml.FIND_STREAM_STORES, "streaming_stores_and_row_loads": _ml.FIND_STREAM_STORES | _ml.FIND_STREAM_ROWS}
+            probe = {label: kernel_window(table, batches, outs, founds, dev, launches=100, regions=3, warm=10, flags=fl)[0] for label, fl in choices.items()}
             best = min(probe, key=probe.get)
-            hint_nt = {"auto": -1, "streaming_stores": 0, "streaming_stores_and_row_loads": 1}[best]
-            table.set_tuning("find_nt", hint_nt)
+            find_flags = choices[best]
             store_hint = {"auto_us": probe["auto"], "streaming_stores_us": probe["streaming_stores"],
-                          "streaming_stores_and_row_loads_us": probe["streaming_stores_and_row_loads"], "find_nt": hint_nt,
-                          "used": "library default" if best == "auto" else f"{best.replace('_', ' ')} (find_nt = {hint_nt})"}
+                          "streaming_stores_and_row_loads_us": probe["streaming_stores_and_row_loads"], "mee_find_ex_flags": find_flags or 0,
+                          "used": "library default (mee_find)" if best == "auto" else f"{best.replace('_', ' ')} (mee_find_ex flags = {find_flags}, per call)"}
             log("rotating output buffers: " + ", ".join(f"{k} {v:.2f} us" for k, v in probe.items()) + " per launch")
 
         def step(i):
-            return table.find(batches[i % n_batches], out=outs[i % n_out], found=founds[i % n_out])
+            return table.find(batches[i % n_batches], out=outs[i % n_out], found=founds[i % n_out], flags=find_flags)
 
     for i in range(args.warmup):
         r = step(i)
@@ -890,6 +934,68 @@ def main():
         torch.cuda.synchronize(dev)
         elapsed, ev_ms = timed_region()
 
+    # ---- N > 1: SURVEY 8d config 4 (iii) in the SAME line: the uniform stream and Zipf(1.05) without and with pre-exchange dedup, each over every
+    # carrier that can run it (verified against the torch.distributed path in the probe), best one reported with its bytes on the busiest link.
+    # Every rank takes part (collectives inside); short windows (3 + 6 steps per candidate): well under a second per row.
+    dist_streams = None
+    if sharded and world > 1 and not train and not args.no_streams:
+        dist_streams = {}
+        if verified_native and not args.dedup:
+            # the exchange behind the C-ABI de-duplicates per CONTEXT (MEE_SHARDED_DEDUP): one more context for the dedup row, checked against the
+            # torch.distributed path's dedup lookup on a skewed batch before it may carry a number
+            try:
+                from meepoembedding_amd.sharded import RcclShardedTable
+                ntd = RcclShardedTable(table, batch, pad_slack=0.0, dedup=True)
+                native_tables.append(ntd)
+                zb = lookup_batches(synth, n_keys, batch, 1, "zipf", dev, seed=3 + rank)[0]
+                o_a, f_a = shs[0].find(zb, dedup=True)
+                o_b, f_b = ntd.find(zb)
+                okd = torch.tensor([int(torch.equal(o_a, o_b) and torch.equal(f_a, f_b) and ntd.status() == 0)], dtype=torch.int32, device=ctrl)
+                dist.all_reduce(okd, op=dist.ReduceOp.MIN)
+                if int(okd.item()) == 1:
+                    verified_native.append(("exact segments, pre-exchange dedup", ntd))
+            except Exception as e:  # noqa: BLE001
+                log(f"native rccl with dedup unavailable: {e}")
+        for sname, dname, dd in (("uniform", "uniform", False), ("zipf_1.05", "zipf", False), ("zipf_1.05_dedup", "zipf", True)):
+            bs_ = batches if dname == args.dist else lookup_batches(synth, n_keys, batch, 8, dname, dev, seed=3 + rank)
+            cands = [("rccl all-to-all (torch.distributed)", "rccl", 0, lambda i, bs_=bs_, dd=dd: shs[0].find(bs_[i % len(bs_)], dedup=dd), lambda: True)]
+            for label_, nt_ in verified_native:
+                if bool(getattr(nt_, "dedup", False)) == dd:
+                    cands.append((f"RCCL grouped send/recv behind the C-ABI ({label_})", "native", nt_.segment_capacity,
+                                  lambda i, bs_=bs_, nt_=nt_: nt_.find(bs_[i % len(bs_)]), lambda nt_=nt_: nt_.status() == 0))
+            if p2p_verified and peer is not None:
+                def p2p_ok_(peer=peer):
+                    try:
+                        peer.check()
+                        return True
+                    except Exception:  # noqa: BLE001  (an inbox overflowed: a skewed stream without dedup)
+                        return False
+                cands.append(("peer-mapped stores (no all-to-all)", "p2p", 0,
+                              lambda i, bs_=bs_, dd=dd: peer.find(bs_[i % len(bs_)], check_overflow=False, dedup=dd), p2p_ok_))
+            best = None
+            for label_, carrier_, cap_, fn_, ok_fn in cands:
+                t_c = timed(fn_)
+                okc = torch.tensor([int(bool(ok_fn()))], dtype=torch.int32, device=ctrl)   # no overflow / time-out on ANY rank, or the number does not count
+                dist.all_reduce(okc, op=dist.ReduceOp.MIN)
+                if carrier_ == "native" and int(okc.item()) == 0:
+                    for _, nt_ in verified_native:
+                        nt_.clear_status() if hasattr(nt_, "clear_status") else None
+                log(f"streams[{sname}]: {label_}: {t_c * 1e3:.3f} ms/step{'' if int(okc.item()) else ' (overflowed: not counted)'}")
+                if int(okc.item()) == 1 and (best is None or t_c < best[0]):
+                    best = (t_c, label_, carrier_, cap_)
+            t_c, label_, carrier_, cap_ = best
+            # bytes on the links: with dedup only a batch's DISTINCT keys (and their rows) travel
+            traffic_b = [torch.unique(b_) for b_ in bs_[:1]] if dd else bs_
+            busiest_, total_ = link_traffic(shs[0].router, traffic_b, carrier_, cap_, dim, world, ctrl)
+            uq = torch.tensor([float(torch.unique(bs_[0]).numel()) / bs_[0].numel()], dtype=torch.float64, device=ctrl)
+            dist.all_reduce(uq, op=dist.ReduceOp.SUM)
+            dist_streams[sname] = {"value": world * batch / t_c, "unit": "key-lookups/s", "ms_per_step": t_c * 1e3, "transport": label_, "pre_exchange_dedup": dd,
+                                   "unique_fraction_per_rank_batch": float(uq.item()) / world,
+                                   "xgmi": {"bytes_on_busiest_link": busiest_, "frac": busiest_ / t_c / 1e9 / XGMI_LINK_GBS_PER_DIR, "total_bytes_per_step": total_,
+                                            "aggregate_GBps": total_ / t_c / 1e9}}
+        dist_streams["note"] = ("each row: 3 warm-up + 6 timed steps (barrier + synchronize on both sides, max over ranks) of the sharded find on that key stream over every "
+                                "carrier verified against the torch.distributed path; the fastest one without a segment / inbox overflow is reported")
+
     launch_cmp = None
     if not sharded and not train and args.steps > 0:
         # the timed steps really ran: the LAST step's result buffer holds the rows of the last step's batch (a graph replay that skipped
@@ -931,15 +1037,12 @@ def main():
                 "note": "algorithmic bytes per step on the busiest ordered GPU pair (keys out + rows and found bytes back; padded segments at their "
                         "constant size), from the owner counts of a representative batch; fraction of the nominal 76.8 GB/s per link direction (SURVEY 8e)"}
     else:
-        med_us, min_us = kernel_window(table, batches, outs, founds, dev)   # as the timed steps run: rotating output buffers
+        med_us, min_us = kernel_window(table, batches, outs, founds, dev, flags=find_flags)   # as the timed steps run: rotating output buffers, the caller's per-call hints
         kern_s, kern_min_s = med_us / 1e6, min_us / 1e6
     bpl = algorithmic_bytes_per_lookup(dim)
     reused_us = None
     if not sharded and not train and n_out > 1:   # the same launches into ONE reused 64 MB buffer under the library's default policy (what round 2 reported)
-        table.set_tuning("find_nt", -1)
         reused_us = kernel_window(table, batches, out, found, dev)
-        if store_hint is not None:
-            table.set_tuning("find_nt", store_hint["find_nt"])
     whole = train and not sharded   # sharded runs always price the local find_kernel alone
     if whole:
         # fwd 528 B/lookup + bwd 264 B/lookup + 1032 B per unique key (Adagrad); here the whole step is priced
@@ -992,6 +1095,8 @@ def main():
                          # N=1 find: `frac` prices the launches as the timed steps run them — rotating over n_out result buffers (more than the
                          # Infinity Cache holds); the same launches into ONE reused buffer are reported beside it
                          "frac_out_rotating": (achieved / HBM_PEAK_GBS) if reused_us is not None else None,
+                         # ... and what a caller that passes NO hint gets into the same rotating buffers (the library's per-call rule: mee_find)
+                         "frac_library_default": (batch * bpl / store_hint["auto_us"] / 1e3 / HBM_PEAK_GBS) if store_hint is not None else None,
                          "frac_out_reused": (batch * bpl / reused_us[0] / 1e3 / HBM_PEAK_GBS) if reused_us is not None else None,
                          "out_reused_avg_launch_us": reused_us[0] if reused_us is not None else None,
                          "out_buffers": n_out, "out_store_policy": store_hint,
@@ -1000,13 +1105,14 @@ def main():
                          "read_only_GBps": roof_n * (16 + 4 * dim) / kern_s / 1e9 if not whole else None,
                          "lookups_per_launch": roof_n},
         }
+        if dist_streams is not None:
+            res["streams"] = dist_streams
         if xgmi is not None:
             res["xgmi"] = xgmi
             res["roofline"]["window"] = ("median of 3 HIP-event windows of 50 back-to-back launches of the LOCAL find_kernel over keys this shard owns "
                                          "(what arrives from the G sources per step), on rank 0")
         if not sharded and not train and not args.no_streams:
             try:
-                table.set_tuning("find_nt", -1)   # the stream table is measured under the library's default cache policy, into one reused result buffer
                 res["streams"] = stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, batches, reused_us if reused_us is not None else (kern_s * 1e6, kern_min_s * 1e6))
                 res["streams"]["note"] = "every row but north_star_batch_1M and the two_output_buffers rows: launches into ONE reused result buffer, default cache policy"
             except Exception as e:  # noqa: BLE001

@@ -108,6 +108,17 @@ int mee_set_tuning(mee_table* t, const char* name, int value);
 /* ---- lookup-table operators (README.md:2 "lookuptable-style"; SPEC.md §3) ------------------------------ */
 /* out[i,:] = row of keys[i] or default_value; found nullable. */
 int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);
+/* mee_find with the cache policy of THIS call in `flags` (never changes results).  Hints are per request, not per table: two request
+ * queues with different access patterns share one table without touching anything the other one's calls read (mee_set_tuning("find_nt")
+ * stays as the table's default for callers that pass MEE_FIND_DEFAULT and for mee_find).
+ *   MEE_FIND_STREAM_STORES  the dense output is not re-read from cache (result buffers that rotate, outputs beyond the Infinity Cache)
+ *   MEE_FIND_CACHED_STORES  the opposite: keep the output cached whatever its size (at most one of the two; neither = by size: cached
+ *                           while one call's output is <= 128 MB)
+ *   MEE_FIND_STREAM_ROWS    rows are not looked up again soon (uniform streams over a table far larger than the caches); a skewed stream
+ *                           wants its hot rows cached and must not set it
+ *   MEE_FIND_STREAM_BUCKETS the same for the 128-byte key lines */
+enum { MEE_FIND_DEFAULT = 0u, MEE_FIND_STREAM_STORES = 1u, MEE_FIND_CACHED_STORES = 2u, MEE_FIND_STREAM_ROWS = 4u, MEE_FIND_STREAM_BUCKETS = 8u };
+int mee_find_ex(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, uint32_t flags, void* stream);
 /* mee_find whose launch is NOT ordered behind earlier work of `stream` (hipExtAnyOrderLaunch): it may begin while previous kernels of
  * the stream are still running, so consecutive lookups on one stream overlap their launch latency (measured on MI355X: 32.3 -> 30.8 us
  * per 256K-key lookup).  The caller guarantees that d_keys is complete before the call is issued to the device and that nothing

@@ -62,6 +62,8 @@ public:
     mee_table_info info() const { mee_table_info i{}; check(mee_table_info_get(t_, &i)); return i; }
 
     void find(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream = nullptr) const { check(mee_find(t_, d_keys, n, d_out, d_found, stream)); }
+    // ... with this call's cache policy (MEE_FIND_* flags)
+    void find(const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, uint32_t flags, void* stream) const { check(mee_find_ex(t_, d_keys, n, d_out, d_found, flags, stream)); }
     // embedding bag: d_out[b,:] = sum (MEE_POOL_SUM) or mean (MEE_POOL_MEAN) of the rows of d_keys[d_bag_offsets[b] .. d_bag_offsets[b+1])
     void find_pooled(const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t n_bags, float* d_out, uint8_t* d_found = nullptr, int mode = MEE_POOL_SUM, void* stream = nullptr) const {
         check(mee_find_pooled(t_, d_keys, n, d_bag_offsets, n_bags, d_out, d_found, mode, stream));

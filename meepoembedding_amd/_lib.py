@@ -20,6 +20,7 @@ ERR_INVALID_ARG, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_NO_DEVICE, ERR_BATCH_TOO_LARGE,
 OPT_NONE, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
 INIT_CONSTANT, INIT_UNIFORM = 0, 1
 STATUS_TABLE_FULL, STATUS_RESERVED_KEY, STATUS_STALE_HANDLE, STATUS_INTERNAL = 1, 2, 4, 8
+FIND_DEFAULT, FIND_STREAM_STORES, FIND_CACHED_STORES, FIND_STREAM_ROWS, FIND_STREAM_BUCKETS = 0, 1, 2, 4, 8   # mee_find_ex flags
 HANDLE_SLOT_MASK = (1 << 40) - 1   # a located-find handle: bits 0..39 the slot (as mee_locate reports it), bits 40..61 the table's layout epoch
 MEM_HBM, MEM_HOST_PINNED = 0, 1
 FLAG_TRACK_HITS, FLAG_ADMISSION = 1, 2
@@ -74,6 +75,7 @@ PROTOTYPES = {
     "mee_clear": (C.c_int, [_vp, _vp]),
     "mee_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mee_find": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "mee_find_ex": (C.c_int, [_vp, _vp, _sz, _vp, _vp, C.c_uint32, _vp]),
     "mee_find_missing": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_find_counted": (C.c_int, [_vp, _vp, _sz, _vp, _vp, C.c_int, _vp]),
     "mee_hits_scan": (C.c_int, [_vp, _u32, _u32, C.c_int, _vp, _sz, C.POINTER(_sz), _vp]),

@@ -2074,7 +2074,7 @@ static const float* plane_of(const mee_table* t, uint32_t plane) {
 
 static int find_plane(const mee_table* t, const float* plane, float miss_value, const int64_t* d_keys, size_t n, float* d_out,
                       uint8_t* d_found, void* stream, bool missing_only = false, bool counted = false, bool rows_only = false,
-                      int64_t* d_slots_out = nullptr, bool unordered = false, bool skip_padding = false) {
+                      int64_t* d_slots_out = nullptr, bool unordered = false, bool skip_padding = false, int nt_call = -1 /* this call's cache policy (mee_find_ex); -1: the table's */) {
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -2087,7 +2087,7 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
 #define FIND1(D4, RR, NT) do { if (unordered) hipExtLaunchKernelGGL((find_kernel<D4, RR, NT>), dim3(grid), dim3(256), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, \
                                         (const int64_t*)t->keys, (const f32x4*)plane, t->nb, d_keys, (uint64_t)n, (f32x4*)d_out, d_found, miss_value, t->dim4, (uint32_t*)nullptr, (int64_t*)nullptr, (int64_t)0); \
                                else find_kernel<D4, RR, NT><<<grid, fblock, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr); } while (0)
-    const int nt = t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
+    const int nt = nt_call >= 0 ? nt_call : t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
 #define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
     if (skip_padding) {   // owner pass of a padded sharded exchange: EMPTY positions get neither a row nor a found byte (nobody reads them)
         const bool cached = nt & 4;
@@ -2134,6 +2134,19 @@ static int find_plane(const mee_table* t, const float* plane, float miss_value, 
 int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
     if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find: null argument");
     return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream);
+}
+
+int mee_find_ex(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, uint32_t flags, void* stream) {
+    if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_ex: null argument");
+    if (flags & ~(uint32_t)(MEE_FIND_STREAM_STORES | MEE_FIND_CACHED_STORES | MEE_FIND_STREAM_ROWS | MEE_FIND_STREAM_BUCKETS))
+        return fail(MEE_ERR_INVALID_ARG, "mee_find_ex: unknown flag bits 0x%x", flags);
+    if ((flags & MEE_FIND_STREAM_STORES) && (flags & MEE_FIND_CACHED_STORES))
+        return fail(MEE_ERR_INVALID_ARG, "mee_find_ex: MEE_FIND_STREAM_STORES and MEE_FIND_CACHED_STORES exclude each other");
+    if (flags == MEE_FIND_DEFAULT) return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream);
+    // the kernel's policy bits: 1 = streaming row loads, 2 = streaming bucket loads, 4 = cached stores of the dense output
+    const bool cached_out = (flags & MEE_FIND_CACHED_STORES) || (!(flags & MEE_FIND_STREAM_STORES) && (uint64_t)n * t->dim * 4 <= (128ull << 20));
+    const int nt = (flags & MEE_FIND_STREAM_ROWS ? 1 : 0) | (flags & MEE_FIND_STREAM_BUCKETS ? 2 : 0) | (cached_out ? 4 : 0);
+    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, false, false, false, nullptr, false, false, nt);
 }
 
 }  // extern "C"

@@ -173,6 +173,7 @@ class RcclShardedTable:
         from ._lib import check
         self._lib, self._check, self._C = _lib, check, C
         self.local, self.group = local, group
+        self.dedup = bool(dedup)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.device, self.dim, self.max_batch = local.device, local.dim, int(max_batch)
         L = _lib.lib()

@@ -85,15 +85,19 @@ class LookupTable:
 
     # -- operators (SPEC.md §3) ----------------------------------------------------------------------------
     def find(self, keys: torch.Tensor, out: torch.Tensor | None = None, found: torch.Tensor | None = None,
-             want_found: bool = True, unordered: bool = False):
+             want_found: bool = True, unordered: bool = False, flags: int | None = None):
         """unordered=True (mee_find_unordered): the launch is not ordered behind EARLIER work of the current stream — only for independent
-        requests whose keys are complete and whose output buffers nothing earlier in the stream still touches."""
+        requests whose keys are complete and whose output buffers nothing earlier in the stream still touches.
+        flags (mee_find_ex): this call's cache policy, an OR of _lib.FIND_* — e.g. FIND_STREAM_STORES for result buffers that rotate."""
         k = self._keys(keys)
         n = k.numel()
         if out is None:
             out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
         if found is None and want_found:
             found = torch.empty(n, dtype=torch.uint8, device=self.device)
+        if flags is not None:
+            check(_lib.lib().mee_find_ex(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr() if found is not None else None, int(flags), self._s()))
+            return out, found
         fn = _lib.lib().mee_find_unordered if unordered else _lib.lib().mee_find
         check(fn(self._h, k.data_ptr(), n, out.data_ptr(), found.data_ptr() if found is not None else None, self._s()))
         return out, found

@@ -47,11 +47,15 @@ def test_bench_single_gpu_contract(dev):
     assert st["north_star_batch_1M"]["lookups_per_launch"] == 1 << 20 and st["north_star_batch_1M"]["default_policy"]["frac_of_hbm_roofline"] > 0
     # the headline rotates its results over more output bytes than the Infinity Cache holds and says so; the reused-buffer figure is beside it
     assert rf["out_buffers"] >= 5 and rf["frac_out_rotating"] == rf["frac"] and rf["frac_out_reused"] > 0
+    # ... with the caller's hints passed per call (mee_find_ex), and the no-hint figure (the library's own rule into the same rotating buffers) beside it
+    assert 0 < rf["frac_library_default"] <= rf["frac"] + 1e-9 and "mee_find_ex_flags" in rf["out_store_policy"]
     assert "rotating" in res["config"]["workload"] and res["config"]["launch_comparison"]["eager_us_per_step"] > 0
     # configs[2] travels in the default line: find + sparse Adagrad step and the apply alone, uniform and Zipf(1.05)
     c2 = res["configs2"]
     for name in ("uniform", "zipf_1.05"):
         assert c2[name]["step"]["us"] > c2[name]["apply_alone"]["us"] > 0 and 0 < c2[name]["step"]["frac_of_hbm_roofline"] < 1
+        # north_star "Adagrad/Adam": the same rows with sparse Adam
+        assert c2[name]["step_adam"]["us"] > c2[name]["apply_alone_adam"]["us"] > 0 and 0 < c2[name]["step_adam"]["frac_of_hbm_roofline"] < 1
     assert c2["zipf_1.05"]["unique_keys_per_batch"] < c2["uniform"]["unique_keys_per_batch"]
     assert cb["table_keys"] == 2_000_000 and str(cb["cores"]) in cb["by_threads"] and cb["value"] == max(cb["by_threads"].values())
 
@@ -63,6 +67,15 @@ def test_bench_two_rank_rehearsal(dev):
                           "--steps", "5", "--warmup", "2"])
     assert REQUIRED <= set(res) and res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
     assert "transport" in res["config"]["workload"]
+    # SURVEY 8d config 4 (iii) in the one line: the uniform stream and Zipf(1.05) without and with pre-exchange dedup, each with its value, the
+    # transport that carried it and the bytes on the busiest link
+    st = res["streams"]
+    for name in ("uniform", "zipf_1.05", "zipf_1.05_dedup"):
+        row = st[name]
+        assert row["value"] > 0 and row["ms_per_step"] > 0 and row["transport"] and row["xgmi"]["bytes_on_busiest_link"] > 0 and row["xgmi"]["frac"] > 0
+    assert st["zipf_1.05_dedup"]["pre_exchange_dedup"] and not st["zipf_1.05"]["pre_exchange_dedup"]
+    assert st["zipf_1.05_dedup"]["xgmi"]["bytes_on_busiest_link"] < st["zipf_1.05"]["xgmi"]["bytes_on_busiest_link"]   # only the distinct keys travel
+    assert st["zipf_1.05"]["unique_fraction_per_rank_batch"] < st["uniform"]["unique_fraction_per_rank_batch"]
 
 
 @pytest.mark.gpu

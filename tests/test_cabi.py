@@ -8,10 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cabi_test", "host_cpp_test"])
+@pytest.mark.parametrize("name", ["cabi_test", "host_cpp_test", "threads_test"])
 def test_cpp_host_programs(dev, name):
     """cabi_test: raw C-ABI from C++.  host_cpp_test: the C++ host layer (include/meepo_embedding.hpp) — Table,
-    TieredTable with a pinned-host cold half, Router + PeerExchange sharded pipeline."""
+    TieredTable with a pinned-host cold half, Router + PeerExchange sharded pipeline.  threads_test: 4 host threads, each with its own stream,
+    200 mee_find_ex calls each with different per-call cache-policy flags on ONE table — results equal to a serial pass, mee_last_error()
+    thread-local (one thread provokes errors, the others' slots stay empty)."""
     exe = os.path.join(ROOT, "build", name)
     assert os.path.exists(exe), f"build/{name} missing: run __graft_entry__.build()"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
