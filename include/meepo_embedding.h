@@ -294,7 +294,9 @@ int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_g
  * that does not need the grads — so it can run early (e.g. on a side stream beside the forward lookup and the dense
  * model); the following mee_apply_adagrad / mee_apply_adam with the SAME d_keys / n then only streams the updates.
  * While a prepared apply is pending only mee_find*, mee_locate, mee_size/status/export and mee_apply_* are accepted;
- * mee_apply_discard drops it.  The caller orders the two streams (event / wait). */
+ * mee_apply_discard drops it.  The caller orders the two streams (event / wait).  (The partition a training forward leaves —
+ * mee_find_located_prepare / mee_find_or_insert_located_prepare — is softer: a mutator or mee_reserve that comes before the backward drops
+ * it itself, and the apply that follows partitions its batch again.) */
 int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* stream);
 int mee_apply_discard(mee_table* t, void* stream);
 /* [syncs] duplicate-key reduction on its own (SPEC.md §4): unique keys (unspecified order), their summed
@@ -393,11 +395,16 @@ int mee_p2p_status(mee_p2p* c, uint32_t* bits_out, void* stream); /* [syncs]; bi
  * Errors inside a collective operator: everything a rank needs for an operator is allocated when its context is created (owner-side buffers
  * for G x max_batch arrivals; every rank must pass the same max_batch and pad_slack — checked collectively at creation), so no rank can
  * drop out for memory between two exchange steps.  If an RCCL call itself fails, the context aborts its communicator (ncclCommAbort: peers
- * blocked in the same collective return with an error instead of waiting forever) and every later call on it returns MEE_ERR_RCCL. */
+ * blocked in the same collective return with an error instead of waiting forever) and every later call on it returns MEE_ERR_RCCL.
+ * OWNERSHIP after an abort: a context only borrows its communicator, and ncclCommAbort frees it.  The abort is recorded per communicator:
+ * every OTHER context that shares it fails at once with MEE_ERR_RCCL as well (none of them touches the freed communicator again),
+ * mee_comm_destroy() of an aborted communicator does nothing and returns MEE_OK, and a caller that passed in an ncclComm_t of its own asks
+ * mee_comm_aborted(comm) — 1: aborted and freed, do NOT call ncclCommDestroy on it — before it destroys it. */
 #define MEE_COMM_ID_BYTES 128
 int mee_comm_unique_id(void* id_out /* MEE_COMM_ID_BYTES */);                    /* ncclGetUniqueId: one rank calls, all ranks share the bytes */
 int mee_comm_create(const void* id, uint32_t n_ranks, uint32_t rank, int32_t device, void** comm_out); /* ncclCommInitRank (collective) */
 int mee_comm_destroy(void* comm);
+int mee_comm_aborted(void* comm);   /* 1: this library aborted (and thereby freed) the communicator after an RCCL error */
 int mee_sharded_create(mee_table* local, void* nccl_comm, uint64_t max_batch /* largest n of a rank per call: the same on every rank */,
                        double pad_slack, mee_sharded** out);
 /* The same with options (BASELINE configs[4]; SURVEY.md §7 lever (a)):

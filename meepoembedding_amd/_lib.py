@@ -147,6 +147,7 @@ PROTOTYPES = {
     "mee_comm_unique_id": (C.c_int, [_vp]),
     "mee_comm_create": (C.c_int, [_vp, _u32, _u32, _i32, C.POINTER(_vp)]),
     "mee_comm_destroy": (C.c_int, [_vp]),
+    "mee_comm_aborted": (C.c_int, [_vp]),
     "mee_sharded_create": (C.c_int, [_vp, _vp, _u64, C.c_double, C.POINTER(_vp)]),
     "mee_sharded_create_ex": (C.c_int, [_vp, _vp, C.POINTER(ShardedOptions), C.POINTER(_vp)]),
     "mee_sharded_clear_status": (C.c_int, [_vp, _vp]),

@@ -37,6 +37,8 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <mutex>
+#include <unordered_set>
 #include <vector>
 
 #include "meepo_device.h"
@@ -275,12 +277,29 @@ struct Leg {              // one buffer pair of a grouped exchange
     ncclDataType_t dt;
 };
 
+// Communicators this library has aborted.  A context only BORROWS its communicator (the caller's own ncclComm_t, or one made by
+// mee_comm_create and shared by several contexts), and ncclCommAbort FREES it: whoever owns it must not destroy it afterwards, and no other
+// context on it may issue another call.  So the abort is recorded per communicator, process-wide: every context on an aborted communicator
+// fails at once (check_call), mee_comm_destroy of an aborted communicator does nothing, and an owner that made the communicator itself asks
+// mee_comm_aborted() before it calls ncclCommDestroy.
+static std::mutex g_abort_mu;
+static std::unordered_set<void*> g_aborted;
+static bool comm_is_aborted(void* comm) { std::lock_guard<std::mutex> lk(g_abort_mu); return g_aborted.count(comm) != 0; }
+static void abort_comm(RcclApi* api, ncclComm_t comm) {
+    {
+        std::lock_guard<std::mutex> lk(g_abort_mu);
+        if (!g_aborted.insert((void*)comm).second) return;   // another context on it was first: ncclCommAbort runs once
+    }
+    if (api->CommAbort) (void)api->CommAbort(comm);
+}
+
 // an RCCL call failed inside a collective operator: peers may be waiting for this rank inside the same group.  Abort the communicator
-// (their calls then return with an error instead of hanging) and refuse every later call on this context.
+// (their calls then return with an error instead of hanging) and refuse every later call on this context and on every other context that
+// shares the communicator.
 static int rccl_failed(mee_sharded* c, RcclApi* api, ncclResult_t err, const char* what) {
     c->dead = true;
-    if (api->CommAbort) (void)api->CommAbort(c->comm);
-    return fail(MEE_ERR_RCCL, "%s failed: %s — the communicator was aborted, this sharded context is unusable", what, api->GetErrorString(err));
+    abort_comm(api, c->comm);
+    return fail(MEE_ERR_RCCL, "%s failed: %s — the communicator was aborted (and thereby freed: do not destroy it), every sharded context on it is unusable", what, api->GetErrorString(err));
 }
 
 // forward: requester segments (scount/sdisp) -> owner segments (rcount/rdisp); reverse: the other way round.
@@ -356,7 +375,7 @@ static int route(mee_sharded* c, const int64_t* d_keys, size_t n, hipStream_t st
     }
     if (r_acc > c->recv_slots) {   // cannot happen when every rank keeps to the max_batch all ranks agreed on: a peer sent more than it may
         c->dead = true;
-        if (api->CommAbort) (void)api->CommAbort(c->comm);
+        abort_comm(api, c->comm);
         return fail(MEE_ERR_BATCH_TOO_LARGE, "%llu keys arrive at this shard, more than G x max_batch = %llu: a rank exceeded the max_batch the ranks agreed on",
                     (unsigned long long)r_acc, (unsigned long long)c->recv_slots);
     }
@@ -390,7 +409,7 @@ static int give_back(mee_sharded* c, bool rows, float* d_out, uint8_t* d_found, 
 
 static int check_call(const mee_sharded* c, size_t n, const char* name) {
     if (!c) return fail(MEE_ERR_INVALID_ARG, "%s: null context", name);
-    if (c->dead) return fail(MEE_ERR_RCCL, "%s: an earlier RCCL error aborted this context's communicator", name);
+    if (c->dead || comm_is_aborted((void*)c->comm)) return fail(MEE_ERR_RCCL, "%s: an earlier RCCL error aborted this context's communicator", name);
     if (n > c->max_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "%s: n=%zu exceeds the context's max_batch=%llu", name, n, (unsigned long long)c->max_batch);
     return MEE_OK;
 }
@@ -560,17 +579,24 @@ int mee_comm_create(const void* id, uint32_t n_ranks, uint32_t rank, int32_t dev
     memcpy(&uid, id, sizeof uid);
     ncclComm_t comm = nullptr;
     MEE_NCCL(api, api->CommInitRank(&comm, (int)n_ranks, uid, (int)rank));
+    { std::lock_guard<std::mutex> lk(g_abort_mu); g_aborted.erase((void*)comm); }   // (an address that an aborted communicator once had)
     *comm_out = comm;
     return MEE_OK;
 }
 
 int mee_comm_destroy(void* comm) {
     if (!comm) return MEE_OK;
+    {   // ncclCommAbort has freed an aborted communicator already: forget it, there is nothing left to destroy
+        std::lock_guard<std::mutex> lk(g_abort_mu);
+        if (g_aborted.erase(comm)) return MEE_OK;
+    }
     RcclApi* api = rccl_api();
     if (!api) return fail(MEE_ERR_RCCL, "%s", rccl_load_error());
     MEE_NCCL(api, api->CommDestroy((ncclComm_t)comm));
     return MEE_OK;
 }
+
+int mee_comm_aborted(void* comm) { return comm && comm_is_aborted(comm) ? 1 : 0; }
 
 int mee_sharded_destroy(mee_sharded* c) {
     if (!c) return MEE_OK;
@@ -781,7 +807,7 @@ int mee_sharded_apply_adam(mee_sharded* c, const int64_t* d_keys, const float* d
 
 int mee_sharded_size(mee_sharded* c, size_t* n_out, void* stream) {
     if (!c || !n_out) return fail(MEE_ERR_INVALID_ARG, "mee_sharded_size: null argument");
-    if (c->dead) return fail(MEE_ERR_RCCL, "mee_sharded_size: an earlier RCCL error aborted this context's communicator");
+    if (c->dead || comm_is_aborted((void*)c->comm)) return fail(MEE_ERR_RCCL, "mee_sharded_size: an earlier RCCL error aborted this context's communicator");
     RcclApi* api = rccl_api();
     if (!api) return fail(MEE_ERR_RCCL, "%s", rccl_load_error());
     DeviceGuard g(c->device);

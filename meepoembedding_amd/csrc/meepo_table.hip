@@ -80,7 +80,10 @@ __device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, con
             if constexpr ((NT & 8) != 0) {  // second-tier pass: only positions an earlier find left as missing
                 inb[r] = act[r] = act[r] && found[i] == 0;
             }
-            if constexpr ((NT & 128) != 0) {  // owner side of a padded sharded exchange: EMPTY positions are padding nobody reads — no row, no found byte
+            if constexpr ((NT & 128) != 0) {  // owner side of a padded sharded exchange: EMPTY positions are padding nobody reads — no row; their
+                // found byte says "served" so that a second-tier pass over the same buffers (mee_find_missing / mee_find_or_insert_missing on the
+                // cold table of a tiered shard) leaves them alone instead of reading a byte nobody wrote
+                if (inb[r] && !act[r] && tl == 0 && found) found[i] = 1;
                 inb[r] = act[r];
             }
         }
@@ -1816,9 +1819,19 @@ static uint64_t next_prime(uint64_t n) {
 static void next_epoch(mee_table* t, hipStream_t) {
     if (++t->epoch >= kEpochWrap) t->epoch = 1;
 }
-static int check_batch(const mee_table* t, size_t n, const char* op, bool needs_group_table = true) {
-    if (t->prepared_n && needs_group_table)
-        return fail(MEE_ERR_INVALID_ARG, "%s: a prepared apply is pending on this table (finish it with mee_apply_* or mee_apply_discard)", op);
+}  // namespace mee
+extern "C" int mee_apply_discard(mee_table* t, void* stream);
+namespace mee {
+// A mutator (or mee_reserve) that needs the per-batch scratch while the partition a TRAINING FORWARD left (mee_find*_located_prepare) is still
+// pending — its backward has not come yet; an eviction, a growth step or a second lookup in between — drops that partition itself: the apply
+// that follows finds nothing prepared and partitions its batch again (same results, one partition launch more).  `stream`: where the mutator
+// runs.  A partition the caller asked for explicitly (mee_apply_prepare, perhaps on another stream) is the caller's to finish or discard.
+static int check_batch(mee_table* t, size_t n, const char* op, void* stream, bool needs_group_table = true, bool drop_pending = true) {
+    if (t->prepared_n && needs_group_table) {
+        if (!drop_pending || !t->prepared_by_forward)
+            return fail(MEE_ERR_INVALID_ARG, "%s: a prepared apply is pending on this table (finish it with mee_apply_* or mee_apply_discard)", op);
+        if (int rc = mee_apply_discard(t, stream)) return rc;
+    }
     if (n > t->max_batch)
         return fail(MEE_ERR_BATCH_TOO_LARGE, "%s: n=%zu exceeds config.max_batch=%llu", op, n, (unsigned long long)t->max_batch);
     return MEE_OK;
@@ -2024,7 +2037,10 @@ static void plane_free(uint32_t value_memory, float* p) {
 
 int mee_reserve(mee_table* t, uint64_t new_capacity, void* stream) {
     if (!t || new_capacity == 0) return fail(MEE_ERR_INVALID_ARG, "mee_reserve: null table or zero capacity");
-    if (t->prepared_n) return fail(MEE_ERR_INVALID_ARG, "mee_reserve: a prepared apply is pending on this table (finish it with mee_apply_* or mee_apply_discard)");
+    if (t->prepared_n) {
+        if (!t->prepared_by_forward) return fail(MEE_ERR_INVALID_ARG, "mee_reserve: a prepared apply is pending on this table (finish it with mee_apply_* or mee_apply_discard)");
+        if (int rc = mee_apply_discard(t, stream)) return rc;   // a training forward's partition: the apply that follows partitions its batch again
+    }
     size_t stored = 0;
     if (int rc = mee_size(t, &stored, stream)) return rc;
     const uint64_t nnb = next_prime((new_capacity + kW - 1) / kW), ncap = nnb * kW;
@@ -2255,7 +2271,7 @@ int mee_find_plane(const mee_table* t, uint32_t plane, const int64_t* d_keys, si
 static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found,
                          void* stream, bool claim, const char* name, const uint8_t* skip = nullptr) {
     if (!t || !plane || (n && (!d_keys || !d_values))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
-    if (int rc = check_batch(t, n, name)) return rc;
+    if (int rc = check_batch(t, n, name, stream)) return rc;
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -2307,7 +2323,7 @@ int mee_assign_plane(mee_table* t, uint32_t plane, const int64_t* d_keys, const 
 
 int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream) {
     if (!t || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_remove: null argument");
-    if (int rc = check_batch(t, n, "mee_remove")) return rc;   // borrows group-table scratch: not while a prepared apply is pending
+    if (int rc = check_batch(t, n, "mee_remove", stream)) return rc;   // borrows group-table scratch: a pending prepared apply is dropped
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -2324,7 +2340,7 @@ int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, 
 static int find_or_insert_common(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream,
                                  bool own_find_pass, const char* name, int64_t* d_slots_out = nullptr) {
     if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
-    if (int rc = check_batch(t, n, name)) return rc;
+    if (int rc = check_batch(t, n, name, stream)) return rc;
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -2353,7 +2369,7 @@ int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_o
 int mee_find_or_insert_admit(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, uint32_t min_count, void* stream) {
     if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_or_insert_admit: null argument");
     if (!t->sketch) return fail(MEE_ERR_UNSUPPORTED, "mee_find_or_insert_admit: table was created without MEE_FLAG_ADMISSION");
-    if (int rc = check_batch(t, n, "mee_find_or_insert_admit")) return rc;
+    if (int rc = check_batch(t, n, "mee_find_or_insert_admit", stream)) return rc;
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -2495,7 +2511,7 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
                         const char* name, const uint32_t* d_gidx = nullptr, const int64_t* d_slots = nullptr) {
     if (!t || (n && (!d_keys || !d_grads))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
     if (t->optimizer != a.kind) return fail(MEE_ERR_UNSUPPORTED, "%s: table was created with optimizer=%u", name, t->optimizer);
-    if (int rc = check_batch(t, n, name, false)) return rc;
+    if (int rc = check_batch(t, n, name, stream, false)) return rc;
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -2661,7 +2677,7 @@ int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* strea
         MEE_HIP(hipGetLastError());
         t->prepared_path = 2;
     }
-    t->prepared_n = n; t->prepared_keys = d_keys;
+    t->prepared_n = n; t->prepared_keys = d_keys; t->prepared_by_forward = false;
     return MEE_OK;
 }
 
@@ -2700,14 +2716,14 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
     MEE_HIP(hipGetLastError());
     if (separate) { if (int rc = bucket_apply_prepare(t, d_keys, (uint32_t)n, st)) return rc; }
     else { t->part_blocks = part_blocks; t->part_per_block = per_block; t->part_nbk = nbk; t->part_nbk_hash = nbk_hash; t->part_grid = apply_grid; t->part_full = apply_full; }
-    t->prepared_n = n; t->prepared_keys = d_keys; t->prepared_path = 1;
+    t->prepared_n = n; t->prepared_keys = d_keys; t->prepared_path = 1; t->prepared_by_forward = true;
     return MEE_OK;
 }
 
 int mee_find_or_insert_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
     if (!t || (n && (!d_keys || !d_out || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_or_insert_located_prepare: null argument");
     if (t->optimizer == MEE_OPT_NONE) return mee_find_or_insert_located(t, d_keys, n, d_out, d_found, d_slots_out, stream);
-    if (int rc = check_batch(t, n, "mee_find_or_insert_located_prepare")) return rc;   // (refuses while another prepared apply is pending)
+    if (int rc = check_batch(t, n, "mee_find_or_insert_located_prepare", stream, true, false)) return rc;   // (refuses while another prepared apply is pending)
     if (n == 0) return MEE_OK;
     uint8_t* fmask = d_found ? d_found : t->bs.fmask;
     // pass 1: the training forward's launch (located find of the stored keys + the partition of the backward); pass 2: the missing positions
@@ -2807,7 +2823,7 @@ int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_g
 int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, int64_t* d_uniq_out, float* d_gsum_out,
                   uint32_t* d_counts_out, int64_t* d_inverse_out, size_t* n_unique_out, void* stream) {
     if (!t || !n_unique_out || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_dedup_sum: null argument");
-    if (int rc = check_batch(t, n, "mee_dedup_sum")) return rc;
+    if (int rc = check_batch(t, n, "mee_dedup_sum", stream)) return rc;
     *n_unique_out = 0;
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
@@ -2830,7 +2846,7 @@ int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, siz
 int mee_dedup_keys(mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_uniq_out, int64_t* d_inverse_out, int64_t miss_index,
                    void* stream) {
     if (!t || (n && (!d_keys || !d_uniq_out || !d_inverse_out))) return fail(MEE_ERR_INVALID_ARG, "mee_dedup_keys: null argument");
-    if (int rc = check_batch(t, n, "mee_dedup_keys")) return rc;
+    if (int rc = check_batch(t, n, "mee_dedup_keys", stream)) return rc;
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);

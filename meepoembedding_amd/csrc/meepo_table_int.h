@@ -130,6 +130,7 @@ struct mee_table {
     mee::BucketScratch bk;      // bucketed apply (null pointers when the table has no optimizer)
     int apply_path;             // -1 = the library's choice, 0 = group-table apply, 1 = bucketed apply
     uint32_t prepared_path;     // which path a pending mee_apply_prepare took
+    bool prepared_by_forward;   // the pending partition came with a training forward (mee_find*_located_prepare): a mutator in between drops it
     uint32_t part_nbk_hash;   // ... of which the first part_nbk_hash are hash buckets (the rest: one per hot key)
     bool part_full;           // ... and the apply kernel chosen for it (FULL | LEAN: meepo_apply.hip)
     uint32_t part_blocks, part_per_block, part_nbk, part_grid;   // bucketed apply: how the latest partition split the batch (blocks, batch positions per block, buckets) and the apply grid that goes with it

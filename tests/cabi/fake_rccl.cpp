@@ -25,6 +25,10 @@
 #include <cstring>
 #include <vector>
 
+// communicators this stand-in has freed (ncclCommAbort / ncclCommDestroy below)
+static std::vector<void*> g_freed;
+static void forget_freed(void* c) { for (size_t i = 0; i < g_freed.size(); ++i) if (g_freed[i] == c) { g_freed.erase(g_freed.begin() + i); return; } }
+
 namespace {
 
 constexpr int kSlots = 4;
@@ -157,12 +161,34 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
     close(fd);
     if (c->base == MAP_FAILED) { delete c; return ncclSystemError; }
     *comm = reinterpret_cast<ncclComm_t>(c);
+    forget_freed(c);   // (the allocator may hand out an address a destroyed communicator had)
+    return ncclSuccess;
+}
+
+// communicators this stand-in has freed: destroying or aborting one of them again is the double free the real library would commit —
+// reported loudly (the test that drives the abort path fails on it)
+// (g_freed / forget_freed: defined in front of the anonymous namespace's users, above)
+static void note_free(void* c, const char* who) {
+    for (void* f : g_freed)
+        if (f == c) { fprintf(stderr, "fake_rccl: %s on a communicator that was already freed (double free)\n", who); abort(); }
+    g_freed.push_back(c);
+}
+
+// ncclCommAbort frees the communicator, like ncclCommDestroy
+ncclResult_t ncclCommAbort(ncclComm_t comm) {
+    FakeComm* c = reinterpret_cast<FakeComm*>(comm);
+    if (!c) return ncclSuccess;
+    note_free(c, "ncclCommAbort");
+    munmap(c->base, c->total);
+    shm_unlink(c->name);
+    c->base = nullptr;   // (the object itself stays allocated: a use after the abort is caught below instead of corrupting the heap)
     return ncclSuccess;
 }
 
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     FakeComm* c = reinterpret_cast<FakeComm*>(comm);
     if (!c) return ncclSuccess;
+    note_free(c, "ncclCommDestroy");
     munmap(c->base, c->total);
     shm_unlink(c->name);   // the first rank to get here removes the name; the others keep their mapping until they unmap
     delete c;
@@ -177,15 +203,21 @@ ncclResult_t ncclGroupStart() { ++g_depth; return ncclSuccess; }
 ncclResult_t ncclGroupEnd() {
     if (g_depth <= 0) return ncclInvalidUsage;
     if (--g_depth > 0) return ncclSuccess;
+    // test hook: the MEE_FAKE_RCCL_FAIL_GROUP-th outermost ncclGroupEnd of the process (1-based) fails — the library's abort path
+    static int n_groups = 0;
+    static const int fail_at = getenv("MEE_FAKE_RCCL_FAIL_GROUP") ? atoi(getenv("MEE_FAKE_RCCL_FAIL_GROUP")) : 0;
+    if (++n_groups == fail_at) { g_ops.clear(); return ncclSystemError; }
     std::vector<Op> ops;
     ops.swap(g_ops);
     return run(ops);
 }
 
 ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) {
+    if (!reinterpret_cast<FakeComm*>(comm)->base) { fprintf(stderr, "fake_rccl: ncclSend on an aborted communicator (use after free)\n"); abort(); }
     return post(Op{true, const_cast<void*>(sendbuff), count * dt_size(datatype), peer, reinterpret_cast<FakeComm*>(comm), stream});
 }
 ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) {
+    if (!reinterpret_cast<FakeComm*>(comm)->base) { fprintf(stderr, "fake_rccl: ncclRecv on an aborted communicator (use after free)\n"); abort(); }
     return post(Op{false, recvbuff, count * dt_size(datatype), peer, reinterpret_cast<FakeComm*>(comm), stream});
 }
 

@@ -88,9 +88,9 @@ int main() try {
       DevBuf<int64_t> d_b(2 * m), d_slots(2 * m); DevBuf<float> d_o(2 * m * dim), d_g(2 * m * dim); DevBuf<uint8_t> d_f(2 * m);
       d_b.up(b); d_g.up(std::vector<float>(2 * m * dim, 1.0f));
       tr.find_located(d_b.p, 2 * m, d_o.p, d_f.p, d_slots.p, /*prepare=*/true);
-      threw = false;
-      try { tr.insert(d_keys.p, d_rows.p, 4); } catch (const meepo::Error& e) { threw = e.code() == MEE_ERR_INVALID_ARG; }   // a prepared apply is pending
-      CHECK(threw);
+      // a mutator between the training forward and its backward drops the partition the forward left; the apply partitions the batch again
+      // (same result: the four rows are rewritten with what they hold)
+      tr.insert(d_keys.p, d_rows.p, 4);
       tr.apply_adagrad_located(d_b.p, d_slots.p, d_g.p, 2 * m, 0.1f);
       CHECK(tr.status() == 0);
       tr.find(d_keys.p, m, d_o.p, d_f.p);

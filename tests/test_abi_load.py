@@ -64,3 +64,15 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "meepo_oracle" not in txt, f
+
+
+def test_test_infrastructure_libraries_load():
+    """The shared-memory stand-in for librccl (tests/cabi/fake_rccl.cpp) that the one-GPU multi-rank tests bind must at least load: an
+    unresolved symbol in it would silently turn those tests' native-transport legs into fallbacks on the GPU box."""
+    import ctypes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "build", "libfake_rccl.so")
+    assert os.path.exists(so), "build/libfake_rccl.so missing: run __graft_entry__.build()"
+    L = ctypes.CDLL(so)
+    for sym in ("ncclCommInitRank", "ncclCommDestroy", "ncclCommAbort", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd", "ncclAllReduce"):
+        assert hasattr(L, sym), sym

@@ -631,8 +631,9 @@ def test_find_or_insert_located(dev, dim):
     oa, fa = ta.find_or_insert(b2)
     ob, fb, slots = tb.find_or_insert_located(b2, prepare_apply=True)
     assert torch.equal(oa, ob) and torch.equal(fa, fb) and bool((slots >= 0).all())
-    with pytest.raises(MeepoError):
-        tb.insert(b2[:4], ob[:4])   # a prepared apply is pending
+    # a mutator between the training forward and its backward (an eviction hook, a second lookup that creates keys, growth): it drops the
+    # partition the forward left and the apply partitions its batch again — same result (here: rows rewritten with what they hold already)
+    tb.insert(b2[:4], ob[:4])
     g = (rng.standard_normal((batch2.size, dim)) * 0.01).astype(np.float32)
     ta.apply_adagrad(b2, T(g, dev), lr=0.01); tb.apply_adagrad(b2, T(g, dev), lr=0.01, slots=slots)
     ea, eb = ta.export(with_state=True), tb.export(with_state=True)

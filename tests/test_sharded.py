@@ -400,6 +400,61 @@ def test_sharded_rccl_single_gpu(dev, dim):
     _check(_launch(1, "nccl", dim=dim), 1, dim)
 
 
+_ABORT_SCRIPT = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+from meepoembedding_amd import LookupTable, _lib, synth
+dev = torch.device("cuda", 0)
+L = _lib.lib()
+t = LookupTable(4096, 16, device=dev, max_batch=1024)
+keys = synth.keys_t(5, 0, 512, dev)
+t.insert(keys, synth.rows_t(keys, 16, 2))
+ident = (C.c_char * 128)()
+assert L.mee_comm_unique_id(ident) == 0
+comm = C.c_void_p()
+assert L.mee_comm_create(bytes(ident), 1, 0, 0, C.byref(comm)) == 0
+ctxs = []
+for _ in range(2):   # TWO contexts borrow ONE communicator
+    h = C.c_void_p()
+    opt = _lib.ShardedOptions(struct_size=C.sizeof(_lib.ShardedOptions), flags=0, max_batch=1024, pad_slack=0.0, cold=None, hot_key_limit=0)
+    assert L.mee_sharded_create_ex(t._h, comm, C.byref(opt), C.byref(h)) == 0
+    ctxs.append(h)
+out = torch.empty((512, 16), device=dev); found = torch.empty(512, dtype=torch.uint8, device=dev)
+st = torch.cuda.current_stream(dev).cuda_stream
+rcs = [L.mee_sharded_find(ctxs[0], keys.data_ptr(), 512, out.data_ptr(), found.data_ptr(), st) for _ in range(6)]
+assert rcs[0] == 0 and _lib.ERR_RCCL in rcs, rcs                      # the injected failure hit one of the calls ...
+k = rcs.index(_lib.ERR_RCCL)
+assert all(r == _lib.ERR_RCCL for r in rcs[k:]), rcs                  # ... and every later call on that context fails at once
+assert b"aborted" in L.mee_last_error()
+assert L.mee_comm_aborted(comm) == 1
+# the OTHER context on the same communicator must not touch it again (the stand-in aborts the process on a use after free)
+assert L.mee_sharded_find(ctxs[1], keys.data_ptr(), 512, out.data_ptr(), found.data_ptr(), st) == _lib.ERR_RCCL
+n = C.c_uint64()
+assert L.mee_sharded_size(ctxs[1], C.byref(n), st) == _lib.ERR_RCCL
+for h in ctxs:
+    assert L.mee_sharded_destroy(h) == 0
+assert L.mee_comm_destroy(comm) == 0                                   # ncclCommAbort freed it: nothing left to destroy (a double free aborts the process)
+assert L.mee_comm_aborted(comm) == 0
+print("abort path ok")
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_error_aborts_the_communicator_once(dev, tmp_path):
+    """An RCCL call that fails inside an operator: the context aborts the communicator it BORROWS (ncclCommAbort frees it) — every context on
+    that communicator then fails at once with MEE_ERR_RCCL, nobody issues another call on it, and mee_comm_destroy of it is a no-op.  Driven
+    through the shared-memory stand-in for librccl, which fails its 4th ncclGroupEnd on request and aborts the process on any use or second
+    free of an aborted communicator."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "abort_path.py"
+    script.write_text(_ABORT_SCRIPT)
+    env = dict(os.environ, MEE_RCCL_LIB=os.path.join(root, "build", "libfake_rccl.so"), MEE_FAKE_RCCL_FAIL_GROUP="4")
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "abort path ok" in r.stdout, r.stdout + r.stderr
+
+
 def _n_gpus():
     return torch.cuda.device_count() if torch.cuda.is_available() else 0
 
