@@ -225,6 +225,11 @@ ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int
 ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream) {
     FakeComm* c = reinterpret_cast<FakeComm*>(comm);
     if (datatype != ncclUint64 || op != ncclSum || count > 64) return ncclInvalidArgument;
+    // test hook: the MEE_FAKE_RCCL_FAIL_ALLREDUCE-th ncclAllReduce of the process (1-based) fails — the library's abort path at world 1
+    static int n_allreduce = 0;
+    static const int fail_ar = getenv("MEE_FAKE_RCCL_FAIL_ALLREDUCE") ? atoi(getenv("MEE_FAKE_RCCL_FAIL_ALLREDUCE")) : 0;
+    if (++n_allreduce == fail_ar) return ncclSystemError;
+    if (!c->base) { fprintf(stderr, "fake_rccl: ncclAllReduce on an aborted communicator (use after free)\n"); abort(); }
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
     uint64_t mine[64], sum[64];
     if (hipMemcpy(mine, sendbuff, count * 8, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;

@@ -401,29 +401,40 @@ def test_sharded_rccl_single_gpu(dev, dim):
 
 
 _ABORT_SCRIPT = r"""
-import ctypes as C, os, sys
-sys.path.insert(0, sys.argv[1])
+import ctypes as C, os, sys, time
+root, rank, idfile = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+sys.path.insert(0, root)
 import torch
 from meepoembedding_amd import LookupTable, _lib, synth
 dev = torch.device("cuda", 0)
 L = _lib.lib()
 t = LookupTable(4096, 16, device=dev, max_batch=1024)
 keys = synth.keys_t(5, 0, 512, dev)
-t.insert(keys, synth.rows_t(keys, 16, 2))
+own = keys[_lib_owner(keys) == rank] if False else keys
 ident = (C.c_char * 128)()
-assert L.mee_comm_unique_id(ident) == 0
+if rank == 0:
+    assert L.mee_comm_unique_id(ident) == 0
+    open(idfile + ".tmp", "wb").write(bytes(ident)); os.rename(idfile + ".tmp", idfile)
+else:
+    t0 = time.time()
+    while not os.path.exists(idfile):
+        assert time.time() - t0 < 60
+        time.sleep(0.01)
+    ident = (C.c_char * 128).from_buffer_copy(open(idfile, "rb").read())
 comm = C.c_void_p()
-assert L.mee_comm_create(bytes(ident), 1, 0, 0, C.byref(comm)) == 0
+assert L.mee_comm_create(bytes(ident), 2, rank, 0, C.byref(comm)) == 0
 ctxs = []
 for _ in range(2):   # TWO contexts borrow ONE communicator
     h = C.c_void_p()
     opt = _lib.ShardedOptions(struct_size=C.sizeof(_lib.ShardedOptions), flags=0, max_batch=1024, pad_slack=0.0, cold=None, hot_key_limit=0)
-    assert L.mee_sharded_create_ex(t._h, comm, C.byref(opt), C.byref(h)) == 0
+    assert L.mee_sharded_create_ex(t._h, comm, C.byref(opt), C.byref(h)) == 0, L.mee_last_error()
     ctxs.append(h)
 out = torch.empty((512, 16), device=dev); found = torch.empty(512, dtype=torch.uint8, device=dev)
 st = torch.cuda.current_stream(dev).cuda_stream
-rcs = [L.mee_sharded_find(ctxs[0], keys.data_ptr(), 512, out.data_ptr(), found.data_ptr(), st) for _ in range(6)]
-assert rcs[0] == 0 and _lib.ERR_RCCL in rcs, rcs                      # the injected failure hit one of the calls ...
+rows = synth.rows_t(keys, 16, 2)
+assert L.mee_sharded_insert(ctxs[0], keys.data_ptr(), rows.data_ptr(), 512, st) == 0, L.mee_last_error()
+rcs = [L.mee_sharded_find(ctxs[0], keys.data_ptr(), 512, out.data_ptr(), found.data_ptr(), st) for _ in range(8)]
+assert rcs[0] == 0 and _lib.ERR_RCCL in rcs, rcs                      # the injected failure hit one of the calls (on both ranks alike) ...
 k = rcs.index(_lib.ERR_RCCL)
 assert all(r == _lib.ERR_RCCL for r in rcs[k:]), rcs                  # ... and every later call on that context fails at once
 assert b"aborted" in L.mee_last_error()
@@ -443,16 +454,19 @@ print("abort path ok")
 @pytest.mark.gpu
 def test_rccl_error_aborts_the_communicator_once(dev, tmp_path):
     """An RCCL call that fails inside an operator: the context aborts the communicator it BORROWS (ncclCommAbort frees it) — every context on
-    that communicator then fails at once with MEE_ERR_RCCL, nobody issues another call on it, and mee_comm_destroy of it is a no-op.  Driven
-    through the shared-memory stand-in for librccl, which fails its 4th ncclGroupEnd on request and aborts the process on any use or second
-    free of an aborted communicator."""
+    that communicator then fails at once with MEE_ERR_RCCL, nobody issues another call on it, and mee_comm_destroy of it is a no-op.  Two ranks
+    on this box's GPU through the shared-memory stand-in for librccl, which fails its 9th outermost ncclGroupEnd on request (on both ranks alike)
+    and aborts the process on any use or second free of an aborted communicator."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "abort_path.py"
-    script.write_text(_ABORT_SCRIPT)
-    env = dict(os.environ, MEE_RCCL_LIB=os.path.join(root, "build", "libfake_rccl.so"), MEE_FAKE_RCCL_FAIL_GROUP="4")
-    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0 and "abort path ok" in r.stdout, r.stdout + r.stderr
+    script.write_text(_ABORT_SCRIPT.replace("own = keys[_lib_owner(keys) == rank] if False else keys\n", ""))
+    env = dict(os.environ, MEE_RCCL_LIB=os.path.join(root, "build", "libfake_rccl.so"), MEE_FAKE_RCCL_FAIL_GROUP="9", MEE_FAKE_RCCL_SLOT_MB="8")
+    procs = [subprocess.Popen([sys.executable, str(script), root, str(r), str(tmp_path / "comm_id")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and "abort path ok" in o, o + e
 
 
 def _n_gpus():
