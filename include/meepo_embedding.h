@@ -306,10 +306,12 @@ int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, siz
                   float* d_gsum_out, uint32_t* d_counts_out, int64_t* d_inverse_out, size_t* n_unique_out,
                   void* stream);
 
-/* The keys-only, sync-free form (what a sharded lookup of a skewed batch needs before the exchange): d_uniq_out[n] = the
- * distinct non-reserved keys in unspecified order followed by MEE_EMPTY_KEY padding, d_inverse_out[i] = index of d_keys[i]
- * in d_uniq_out, or miss_index for reserved keys.  The number of distinct keys never travels to the host: consumers take the
- * padded array at its fixed length n (padding is skipped by every operator and by mee_partition_padded). */
+/* The keys-only, sync-free form (what a sharded lookup of a skewed batch needs before the exchange): every distinct non-reserved
+ * key of the batch occurs exactly once in d_uniq_out[0 .. n), at an unspecified position; every other entry is MEE_EMPTY_KEY
+ * (padding — it may lie BETWEEN the keys: each hash bucket of the batch fills the front of a slice of its own, so that no block
+ * has to reserve its place from a shared counter); d_inverse_out[i] = index of d_keys[i] in d_uniq_out, or miss_index for
+ * reserved keys.  The number of distinct keys never travels to the host: consumers take the padded array at its fixed length n
+ * (padding is skipped by every operator and by mee_partition_padded). */
 int mee_dedup_keys(mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_uniq_out, int64_t* d_inverse_out, int64_t miss_index,
                    void* stream);
 

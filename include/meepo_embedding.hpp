@@ -113,7 +113,7 @@ public:
     size_t dedup_sum(const int64_t* d_keys, const float* d_grads, size_t n, int64_t* d_uniq_out, float* d_gsum_out, uint32_t* d_counts_out, int64_t* d_inverse_out, void* stream = nullptr) {
         size_t u = 0; check(mee_dedup_sum(t_, d_keys, d_grads, n, d_uniq_out, d_gsum_out, d_counts_out, d_inverse_out, &u, stream)); return u;
     }
-    // sync-free: d_uniq_out[n] = distinct keys then EMPTY padding, d_inverse_out[i] = index into it (miss_index for reserved keys)
+    // sync-free: d_uniq_out[n] = every distinct key once, EMPTY everywhere else (also between the keys), d_inverse_out[i] = index into it (miss_index for reserved keys)
     void dedup_keys(const int64_t* d_keys, size_t n, int64_t* d_uniq_out, int64_t* d_inverse_out, int64_t miss_index = -1, void* stream = nullptr) {
         check(mee_dedup_keys(t_, d_keys, n, d_uniq_out, d_inverse_out, miss_index, stream));
     }

@@ -71,11 +71,43 @@ uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out, uint32_t
 
 // ---- the partition kernel of an apply (the role itself: meepo_apply_part.h) ----------------------------------------------------------------
 __global__ __launch_bounds__(kPartThreads) void bkt_sort_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk_hash, uint32_t nbk,
-                                                                uint32_t per_block, BucketScratch bk, uint32_t* status, OpCounters* op) {
+                                                                uint32_t per_block, BucketScratch bk, uint32_t* status, OpCounters* op, uint32_t tot_atomics) {
     extern __shared__ unsigned long long part_lds[];   // PartHot, then one counter per bucket
     __shared__ unsigned long long wsum[kPartThreads / 64];
     PartHot* hot = reinterpret_cast<PartHot*>(part_lds);
-    sort_role<kPartThreads>(keys, n, nbk_hash, nbk, per_block, blockIdx.x, gridDim.x, bk, status, op, reinterpret_cast<uint32_t*>(hot + 1), wsum, hot);
+    sort_role<kPartThreads>(keys, n, nbk_hash, nbk, per_block, blockIdx.x, gridDim.x, bk, status, op, reinterpret_cast<uint32_t*>(hot + 1), wsum, hot, tot_atomics != 0);
+}
+
+// the bucket totals of a large batch: column sums of the run-length matrix (one thread per bucket, coalesced along the buckets), and the
+// "some bucket is split" flag — what the partition blocks' atomics do for batches of up to ~512K keys
+__global__ __launch_bounds__(256) void bkt_totals_kernel(BucketScratch bk, uint32_t nbk, uint32_t part_blocks) {
+    // 64 buckets per block; wave w adds up the rows w, w + 4, … of its 64 columns, eight loads in flight; LDS combines the four partial sums
+    __shared__ uint32_t part[4][64];
+    const uint32_t b = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    uint32_t sum = 0;
+    if (b < nbk) {
+        for (uint32_t k0 = w; k0 < part_blocks; k0 += 32) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) { const uint32_t k = k0 + 4 * q; v[q] = k < part_blocks ? bk.cnt_mat[(uint64_t)k * nbk + b] : 0u; }
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) sum += v[q];
+        }
+    }
+    part[w][threadIdx.x & 63] = sum;
+    __syncthreads();
+    if (w == 0 && b < nbk) {
+        const uint32_t parity = bk.seq[0] & 1u;   // (the partition in front of this kernel filled this copy; nothing has consumed it yet)
+        const uint32_t tot = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        bk.tot[parity * bk.n_buckets_max + b] = tot;
+        if (tot > kBucketCap) bk.has_split[parity] = 1u;
+    }
+}
+bool bucket_totals_by_atomics(uint32_t blocks, uint32_t nbk) { return (uint64_t)blocks * nbk <= 160000; }
+int bucket_totals_launch(mee_table* t, uint32_t nbk, uint32_t blocks, hipStream_t st) {
+    bkt_totals_kernel<<<(nbk + 63) / 64, 256, 0, st>>>(t->bk, nbk, blocks);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
 }
 
 // ---- the apply kernel -------------------------------------------------------------------------------------------------------------
@@ -144,6 +176,7 @@ struct ApplyArgs {
     double* part; uint32_t max_part;     // fp64 partial rows of long runs (BatchScratch::gacc)
     uint32_t nbk, part_blocks, per_block;   // the partition: buckets (hash buckets, then one per hot key), partition blocks, batch positions per partition block
     uint32_t nbk_hash;                      // ... the hash buckets among them
+    uint32_t hot_count;                     // occurrences in one bucket or slab that make a key hot (its own bucket in the next batch)
     uint32_t* h_slabs;                      // pinned host word: the slabs this batch's split buckets were cut into (0: none)
     OpCounters* op;
 #if MEE_APPLY_TIMELINE
@@ -240,23 +273,6 @@ __device__ __forceinline__ void sum_sources(const ApplyLds& L, const ApplyArgs& 
 // two at a time: 8 + 8 round trips, the slab pass of a split bucket 30-45 us.  Chunks of ceil(m / 32) sources — "as many items as tiles" —:
 // a bucket of 800 positions around a key of 500 occurrences spent 7 round trips in each of that key's quads.)  Waves take turns from an LDS
 // counter, quads first (a quad is up to 32 rows, a key that occurs once is one).
-// a key with enough occurrences in this batch to fill a slab: into the hot-key set the next partition reads (copy `parity`, cleared by this
-// batch's partition).  A few hundred calls per skewed batch, none on a uniform one.
-__device__ __forceinline__ void report_hot_key(const BucketScratch& bk, uint32_t parity, int64_t key) {
-    const unsigned long long bkey = (unsigned long long)key ^ kBias;
-    uint32_t h = (uint32_t)(mix64b((uint64_t)key) >> 20) & (kHotSlots - 1);
-    unsigned long long* set = bk.hot_key + parity * kHotSlots;
-    for (uint32_t tries = 0; tries < kHotSlots; ++tries) {
-        const unsigned long long old = atomicCAS(&set[h], 0ull, bkey);
-        if (old == bkey) return;   // another slab of the key was first
-        if (old == 0ull) {
-            const uint32_t i = atomicAdd(&bk.hot_n[parity], 1u);
-            if (i < kHotCap) bk.hot_idx[parity * kHotSlots + h] = i;   // (read by the NEXT partition: a later kernel)
-            return;
-        }
-        h = (h + 1) & (kHotSlots - 1);
-    }
-}
 
 // MODE: kWhole — a whole bucket (sources: batch positions, results: table updates); kEmit — a slab of a split bucket (sources: batch positions,
 // results: pending records); kMerge — a merge pass (sources: pending records, results: table updates).  Compile-time: each instance carries only
@@ -353,7 +369,7 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
             L.off[s] = so;
             if (c) {
                 L.run[s] = ro;
-                if (!src_rec && c >= kHotCount) report_hot_key(bk, parity_rt, (int64_t)(L.key[s] ^ kBias));   // a key that fills half a slab: its own bucket next time
+                if (!src_rec && c >= A.hot_count) report_hot_key(bk, parity_rt, (int64_t)(L.key[s] ^ kBias));   // a key that fills half a slab: its own bucket next time
                 if (c <= lc) L.items[io++] = s;
 #pragma unroll 1
                 for (uint32_t j = 0; j < nq; ++j) if (qo + j < kMaxQuads) L.quad[qo + j] = s | j << 10 | (nq > 1 ? po + j : 0u) << 16;
@@ -1008,7 +1024,7 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
                 }
             }
         }
-        if (t == 0 && total >= kHotCount) report_hot_key(bk, parity, key);   // its own bucket next time
+        if (t == 0 && total >= A.hot_count) report_hot_key(bk, parity, key);   // its own bucket next time
         last = cur; have_last = true;
     }
 }
@@ -1081,13 +1097,16 @@ int bucket_scratch_alloc(mee_table* t) {
     bk.slots = (uint32_t)cus * kApplyBlocksPerCU;
     const uint64_t most = (uint64_t)(kMaxBuckets / bk.slots ? kMaxBuckets / bk.slots * bk.slots : kMaxBuckets) * kBucketMax;   // beyond that buckets would outgrow their slabs
     bk.fast_max = t->max_batch < most ? t->max_batch : most;
-    bk.n_buckets_max = kMaxBuckets;
+    // buckets the largest batch can be cut into (+ the hot keys' own): the strides of the totals' two copies and of the run matrices
+    bk.n_buckets_max = bucket_count_for_host(bk.fast_max, bk.slots) + kHotCap;
+    if (bk.n_buckets_max > kMaxBuckets) bk.n_buckets_max = kMaxBuckets;
+    bk.n_buckets_max = (bk.n_buckets_max + 63u) & ~63u;
     bk.pos = t->bs.occ;   // max_batch entries; the group-table apply and this one never run at the same time on one table
     hipError_t e = hipSuccess;
     auto alloc = [&](void** p, uint64_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes); if (e == hipSuccess) t->workspace_bytes += bytes; } };
     alloc((void**)&bk.pkey, bk.fast_max * 8);
-    alloc((void**)&bk.cnt_mat, (uint64_t)kPartBlocks * bk.n_buckets_max * 4);
-    alloc((void**)&bk.off_mat, (uint64_t)kPartBlocks * bk.n_buckets_max * 4);
+    alloc((void**)&bk.cnt_mat, (uint64_t)kPartBlocksMax * bk.n_buckets_max * 4);
+    alloc((void**)&bk.off_mat, (uint64_t)kPartBlocksMax * bk.n_buckets_max * 4);
     alloc((void**)&bk.tot, 2ull * bk.n_buckets_max * 4);
     alloc((void**)&bk.seq, 8 * 4);   // seq[0], seq[1], has_split[0], has_split[1]: ONE line of one page, read by every apply block with ONE load; [4]: the LEAN kernel's slab count
     bk.has_split = bk.seq ? bk.seq + 2 : nullptr;
@@ -1099,9 +1118,11 @@ int bucket_scratch_alloc(mee_table* t) {
     if (e == hipSuccess) e = hipMemset(bk.tot, 0, 2ull * bk.n_buckets_max * 4);   // (every partition launch zeroes the copy the next one adds to)
     alloc((void**)&bk.pend_cnt, (uint64_t)bk.n_buckets_max * 4);
     alloc((void**)&bk.ticket, (uint64_t)bk.n_buckets_max * 4);
-    alloc((void**)&bk.pend_key, bk.fast_max * 8);
-    alloc((void**)&bk.pend_slot, bk.fast_max * 8);
-    alloc((void**)&bk.pend_row, bk.fast_max * (uint64_t)t->dim * sizeof(double));
+    if (t->optimizer != MEE_OPT_NONE) {   // pending records of split buckets: the sparse-optimizer apply alone (dedup and elections take a bucket of any size whole)
+        alloc((void**)&bk.pend_key, bk.fast_max * 8);
+        alloc((void**)&bk.pend_slot, bk.fast_max * 8);
+        alloc((void**)&bk.pend_row, bk.fast_max * (uint64_t)t->dim * sizeof(double));
+    }
     if (e == hipSuccess) e = hipHostMalloc((void**)&bk.h_slabs, 64, hipHostMallocMapped | hipHostMallocPortable);
     if (e == hipSuccess) { *bk.h_slabs = 0u; e = hipHostGetDevicePointer((void**)&bk.h_slabs_dev, bk.h_slabs, 0); }
     bk.skew_adapt = 1; bk.skew_sticky = 0; bk.kernel_choice = -1;
@@ -1130,9 +1151,18 @@ int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStr
     uint32_t blocks, per_block;
     part_geometry(n, kPartThreads, blocks, per_block);
     t->part_blocks = blocks; t->part_per_block = per_block; t->part_nbk = nbk; t->part_nbk_hash = nbk_hash; t->part_grid = grid;
-    bkt_sort_kernel<<<blocks, kPartThreads, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op);
+    const bool atom = bucket_totals_by_atomics(blocks, nbk);
+    bkt_sort_kernel<<<blocks, kPartThreads, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, atom);
     MEE_HIP(hipGetLastError());
-    return MEE_OK;
+    return atom ? MEE_OK : bucket_totals_launch(t, nbk, blocks, st);
+}
+
+// the same partition for another consumer (meepo_dedup.hip: last-wins elections), with the geometry the caller chose
+int bucket_apply_prepare_as(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st, uint32_t nbk_hash, uint32_t nbk, uint32_t blocks, uint32_t per_block) {
+    const bool atom = bucket_totals_by_atomics(blocks, nbk);
+    bkt_sort_kernel<<<blocks, kPartThreads, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, atom);
+    MEE_HIP(hipGetLastError());
+    return atom ? MEE_OK : bucket_totals_launch(t, nbk, blocks, st);
 }
 
 // a prepared partition that no apply will consume (mee_apply_discard): count it as consumed, so that the next partition fills the other copy
@@ -1156,6 +1186,7 @@ int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const Op
     A.dbg = g_dbg;
 #endif
     A.desc = d_desc; A.n_tables = n_tables;   // a table group's apply (d_slots = the batch's located rows = its keys; t = the group's scratch table)
+    A.hot_count = hot_count_for(n);
     A.nbk = t->part_nbk; A.nbk_hash = t->part_nbk_hash; A.part_blocks = t->part_blocks; A.per_block = t->part_per_block;   // as whoever partitioned this batch left them (a tuning
     // call between the partition and the apply — "apply_bucket_max" — must not change the stride the run matrices were written with)
     // one block per bucket (+ the blocks a skewed stream's slabs need); on a skewed batch the blocks work through a list of units, the slabs of the

@@ -7,6 +7,8 @@
 namespace mee {
 
 constexpr int kPartBlocks = 128;          // blocks that share the partition of one batch, at most (2 x 64: a wave of the apply kernel scans their run lengths, two per lane)
+constexpr int kPartBlocksMax = 256;       // ... of a dedup / an election (meepo_dedup.hip: four runs per lane; its kernels have the registers for it): a batch of 1M keys is
+                                          // partitioned by 256 blocks on 256 CUs instead of 128 (36 -> ~20 us)
 constexpr uint32_t kSlab = 512;           // positions per slab of a SPLIT bucket (= an apply block's thread count)
 #ifndef MEE_AB_BUCKET_CAP
 #define MEE_AB_BUCKET_CAP 1024
@@ -21,9 +23,12 @@ constexpr uint32_t kMaxBuckets = 8192;    // the partition keeps one LDS counter
 // costs time, never results (a listed key that turns out rare is a small bucket of one key).  What it buys: the hash buckets of a skewed
 // batch hold no hot key any more — they are not split, their cold keys need no pending records and no merge — and a hot key's own bucket is
 // split into slabs of ONE key whose merge adds up one record per slab.
-constexpr uint32_t kHotCount = 256;       // occurrences (in one bucket or one slab) that make a key hot: half a slab
-constexpr uint32_t kHotSlots = 256;       // slots of the hot-key set
-constexpr uint32_t kHotCap = 128;         // hot keys that get a bucket (the set's load stays <= 0.5); a Zipf(1.05) batch of 256K keys lists ~50, one of 1M keys ~120
+constexpr uint32_t kHotCount = 256;       // occurrences (in one bucket or one slab) that make a key hot: half a slab ...
+// ... or n / 1024 of a larger batch: the set numbers the first kHotCap comers, so the bar must leave fewer candidates than that (Zipf(1.05):
+// ~68 keys reach 256 occurrences in a batch of 256K, ~250 do in a batch of 1M — but only ~66 reach 1024)
+inline uint32_t hot_count_for(uint64_t n) { const uint64_t c = n / 1024; return c > kHotCount ? (uint32_t)c : kHotCount; }
+constexpr uint32_t kHotSlots = 512;       // slots of the hot-key set
+constexpr uint32_t kHotCap = 128;         // hot keys that get a bucket (the set takes no more keys once that many are numbered: its load stays ~0.25); a Zipf(1.05) batch of 256K keys lists ~50, one of 1M keys ~120
 // MEE_APPLY_WAVES: waves per SIMD the register allocator must leave room for in the bucket kernel (meepo_apply.hip): 8 = 64 VGPRs, four
 // 512-thread blocks per CU (6 = 80 VGPRs, three blocks)
 #ifndef MEE_APPLY_WAVES
@@ -43,9 +48,9 @@ inline uint32_t bucket_count_for_host(uint64_t n, uint32_t slots, uint32_t bucke
     if (nbk > kMaxBuckets) nbk = kMaxBuckets / slots * slots ? kMaxBuckets / slots * slots : kMaxBuckets;
     return nbk;
 }
-inline void part_geometry(uint32_t n, uint32_t threads, uint32_t& blocks, uint32_t& per_block) {
+inline void part_geometry(uint32_t n, uint32_t threads, uint32_t& blocks, uint32_t& per_block, uint32_t max_blocks = kPartBlocks) {
     blocks = (n + 4 * threads - 1) / (4 * threads);   // at least 4 keys per thread
-    if (blocks > (uint32_t)kPartBlocks) blocks = kPartBlocks;
+    if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     per_block = (n + blocks - 1) / blocks;
 }
@@ -59,7 +64,7 @@ __device__ __forceinline__ uint32_t part_bucket_of(int64_t key, uint32_t nbk_has
     if (nbk_total != nbk_hash) {
         const unsigned long long bkey = (unsigned long long)key ^ kBias;
         uint32_t h = (uint32_t)(mix64b((uint64_t)key) >> 20) & (kHotSlots - 1);
-        while (true) {
+        for (uint32_t tries = 0; tries < kHotSlots; ++tries) {   // (bounded: a set without an empty slot must not trap the probe)
             const unsigned long long k = hot->key[h];
             if (k == bkey) { const uint32_t i = hot->idx[h]; if (i < nbk_total - nbk_hash) return nbk_hash + i; break; }
             if (k == 0ull) break;
@@ -110,6 +115,26 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
     return pre + incl - v;
 }
 
+// a key with enough occurrences in this batch to fill half a slab: into the hot-key set the next partition reads (copy `parity`, cleared by this
+// batch's partition).  A few hundred calls per skewed batch, none on a uniform one.  The set stops taking keys once kHotCap are numbered (a
+// batch with more hot keys than that keeps the first comers): its load stays low and every probe of it ends at an empty slot.
+__device__ __forceinline__ void report_hot_key(const BucketScratch& bk, uint32_t parity, int64_t key) {
+    if (__hip_atomic_load(&bk.hot_n[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kHotCap) return;
+    const unsigned long long bkey = (unsigned long long)key ^ kBias;
+    uint32_t h = (uint32_t)(mix64b((uint64_t)key) >> 20) & (kHotSlots - 1);
+    unsigned long long* set = bk.hot_key + parity * kHotSlots;
+    for (uint32_t tries = 0; tries < kHotSlots / 2; ++tries) {
+        const unsigned long long old = atomicCAS(&set[h], 0ull, bkey);
+        if (old == bkey) return;   // another slab of the key was first
+        if (old == 0ull) {
+            const uint32_t i = atomicAdd(&bk.hot_n[parity], 1u);
+            if (i < kHotCap) bk.hot_idx[parity * kHotSlots + h] = i;   // (read by the NEXT partition: a later kernel)
+            return;
+        }
+        h = (h + 1) & (kHotSlots - 1);
+    }
+}
+
 // One partition block (block `blk` of `n_blocks`, THREADS threads): sorts ITS share of the batch by bucket, inside its own contiguous slice of
 // pos / pkey (LDS histogram -> in-block prefix sum -> LDS cursors).  A block's writes stay inside its slice (16 KB + 32 KB at 4096 keys),
 // i.e. in one XCD's L2, where the 4- and 8-byte stores combine into whole lines.  (The first version scattered every key straight to its
@@ -121,6 +146,8 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
 // (Two earlier forms: a units kernel of its own behind this one — a dependent launch, 6.5 us for one block's worth of work; the block that
 // finished last building the unit list — release fence, ticket, acquire, then the list: the same 6 us at the end of this kernel, and under
 // the training forward's row traffic every one of those dependent steps cost microseconds.)
+// (Large batches — partition blocks x buckets beyond ~160 000 cells: 410 000 atomics for 1M keys, 25 of the partition's 36 us — skip the atomics:
+// bkt_totals_kernel adds the run-length matrix's columns up behind this kernel, 2-3 us.)
 // Scratch that the apply kernel of THIS batch reads is reset here for the next but one use: totals and has_split alternate between two
 // copies, this launch zeroes the copy the next launch will add to.  Which copy is in use lives on the DEVICE (a captured graph replays the
 // same launches, so a host-side toggle would stand still): bk.seq[0] counts partitions that were consumed — the partition reads it, takes
@@ -129,7 +156,8 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
 template <int THREADS>
 __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk_hash, uint32_t nbk /* hash buckets + hot buckets */, uint32_t per_block, uint32_t blk,
                                           uint32_t n_blocks, const BucketScratch& bk, uint32_t* status, OpCounters* op, uint32_t* cursor /*[nbk]*/,
-                                          unsigned long long* wsum /*[THREADS / 64]*/, PartHot* hot) {
+                                          unsigned long long* wsum /*[THREADS / 64]*/, PartHot* hot,
+                                          bool tot_atomics = true /* false: the bucket totals are summed up by a small kernel behind this one (bkt_totals_kernel) */) {
     // Dependent round trips to memory are what this role costs (beside the training forward's row gather every one of them waits in the same
     // queues as the gather's requests: microseconds each), so it makes two: the keys together with the copy selector, and — at the very end —
     // the returns of the bucket-total atomics, which travel while the entries are scattered.
@@ -189,7 +217,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
             }
         }
     }
-    if (bad) atomicOr(status, (uint32_t)MEE_STATUS_RESERVED_KEY);
+    if (bad && status) atomicOr(status, (uint32_t)MEE_STATUS_RESERVED_KEY);
     __syncthreads();
     const uint32_t per_t = (nbk + THREADS - 1) / THREADS;   // buckets [t * per_t, (t + 1) * per_t) belong to thread t
     unsigned long long sum = 0;
@@ -211,7 +239,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
         bk.off_mat[(uint64_t)blk * nbk + b] = start;
         cursor[b] = start;
         start += c;
-        if (c) {
+        if (c && tot_atomics) {
             const uint32_t before = atomicAdd(&bk.tot[parity * bk.n_buckets_max + b], c);
             if (deferred) { tot_before[q < kTotRegs ? q : 0] = before; tot_add[q < kTotRegs ? q : 0] = c; }   // the return travels while the entries are scattered
             else if (before <= kBucketCap && before + c > kBucketCap) bk.has_split[parity] = 1u;   // exactly one add per bucket takes its total beyond what one block holds

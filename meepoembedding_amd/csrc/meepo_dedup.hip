@@ -1,0 +1,480 @@
+// meepo_dedup.hip — duplicate-key elimination and last-wins elections on the bucketed machinery (SPEC.md §3 "duplicates: last wins", §4
+// "duplicate keys"): the partition of meepo_apply_part.h, then ONE kernel whose blocks find a bucket's distinct keys in an LDS hash table.
+//
+// Reference anchor: /root/reference/README.md:2 (no code upstream); BASELINE.json north_star "LDS-staged key buckets and wavefront ballot /
+// prefix-sum for duplicate-key reduction".
+//
+// Rounds 2-3 did both through a GLOBAL group table: one scattered CAS per key to claim an entry (13-20 G scattered atomics/s chip-wide:
+// 23 us per 256K keys, 90 us per 1M), a plan pass, a fill pass and an emit pass — 0.23 ms per 1M keys for mee_dedup_keys, which sits on the
+// critical path of a sharded lookup with pre-exchange dedup, and 85 of assign's 227 us.  Here all occurrences of a key are in one bucket
+// (the partition sorts the batch by the top bits of mix64(key), LDS histograms, no per-key global atomic), a 256-thread block takes a bucket
+// of ANY size — there are no rows to sum, so no slabs and no pending records: a bucket larger than the LDS table is taken in passes by the
+// low bits of mix64b(key) —, and the only global atomic is one per (block, pass) that reserves the pass's slice of the unique list.
+//
+//   bkt_dedup_keys_kernel   mee_dedup_keys: the distinct keys into d_uniq (each bucket's into its own slice of the list: EMPTY between them),
+//                           each position's index into d_inverse; sync-free, no global atomic (the partition's launch pre-fills d_uniq with
+//                           EMPTY and gives reserved keys their miss_index).
+//   bkt_assign_kernel       mee_assign: per distinct key the LAST position wins (atomicMax in the LDS table), one probe per distinct key, the
+//                           winner's row overwrites the key's row; every occurrence gets the key's found byte.
+#include <hip/hip_runtime.h>
+
+#include "meepo_apply_part.h"
+
+namespace mee {
+
+constexpr int kDedupThreads = 256;
+constexpr int kDedupWaves = kDedupThreads / 64;
+constexpr uint32_t kDedupSlots = 1024;        // LDS hash table of one pass
+constexpr uint32_t kDedupFill = 896;          // distinct keys a pass may hold (load 0.875); beyond: the pass is split by one more hash bit
+
+struct DedupLds {
+    unsigned long long key[kDedupSlots];      // key ^ kBias, 0 = empty
+    uint32_t val[kDedupSlots];                // dedup: the key's index in this pass's slice of the unique list | assign: 1 + the key's last position, later its found flag
+    uint32_t cnt[kDedupSlots];                // occurrences (hot-key report)
+    uint32_t seg_first[kPartBlocksMax + 1], seg_at[kPartBlocksMax];
+    unsigned long long wsum[kDedupWaves];
+    uint32_t stk_bits[40], stk_val[40];       // passes still to do: (hash bits, value)
+    uint32_t stk_n, n_distinct, overflow, base;
+};
+
+__device__ __forceinline__ uint32_t dd_entry_at(const DedupLds& L, uint32_t gi) {   // index within the bucket -> its place in pos / pkey
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t stp = kPartBlocksMax / 2; stp; stp >>= 1) if (L.seg_first[k + stp] <= gi) k += stp;
+    return L.seg_at[k] + (gi - L.seg_first[k]);
+}
+
+// the bucket's runs in the partition blocks' slices (wave 0: two runs per lane), as in the apply kernel: the loads (dd_seg_load) travel with the
+// kernel's first round trip, the scan (dd_seg_scan) puts the runs' first indices into LDS
+struct DdRuns { uint32_t len[4], at[4]; };   // lane l of wave 0: runs 4l .. 4l + 3
+__device__ __forceinline__ DdRuns dd_seg_load(const BucketScratch& bk, uint32_t nbk, uint32_t part_blocks, uint32_t per_block, uint32_t b, uint32_t tid) {
+    DdRuns r{{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    if (tid < 64) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t k = 4 * tid + q;
+            if (k < part_blocks) { r.len[q] = bk.cnt_mat[(uint64_t)k * nbk + b]; r.at[q] = k * per_block + bk.off_mat[(uint64_t)k * nbk + b]; }
+        }
+    }
+    return r;
+}
+__device__ __forceinline__ void dd_seg_scan(DedupLds& L, const DdRuns& r, uint32_t tid) {
+    if (tid >= 64) return;
+    const uint32_t all = r.len[0] + r.len[1] + r.len[2] + r.len[3], incl = wave_incl_scan_u32(all);
+    uint32_t first = incl - all;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) { L.seg_first[4 * tid + q] = first; L.seg_at[4 * tid + q] = r.at[q]; first += r.len[q]; }
+    if (tid == 63) L.seg_first[kPartBlocksMax] = incl;
+}
+
+// slot of `bkey` in the pass's table (the key is there)
+__device__ __forceinline__ uint32_t dd_lookup(const DedupLds& L, unsigned long long bkey) {
+    uint32_t s = (uint32_t)(mix64b(bkey ^ kBias) >> 12) & (kDedupSlots - 1);
+    while (L.key[s] != bkey) s = (s + 1) & (kDedupSlots - 1);
+    return s;
+}
+
+// One pass over the bucket: every entry whose key has `val` in the low `bits` bits of mix64b goes into the LDS table.  LAST: the table keeps
+// 1 + the key's highest batch position.  A wave whose 64 entries all carry ONE key (a hot key's own bucket, 15 000 entries of one key) inserts
+// it once.  Returns false if the pass holds more distinct keys than the table takes (the caller splits it on one more bit).
+template <bool LAST>
+__device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, uint32_t size, uint32_t bits, uint32_t val) {
+    const uint32_t t = threadIdx.x;
+    for (uint32_t j = t; j < kDedupSlots; j += kDedupThreads) { L.key[j] = 0ull; L.val[j] = 0u; L.cnt[j] = 0u; }
+    if (t == 0) { L.n_distinct = 0u; L.overflow = 0u; }
+    __syncthreads();
+    const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u;
+    constexpr int kIn = 4;   // entries a thread has in flight per step (one dependent round trip per step: a bucket of 4 000 entries takes 4 steps, not 16)
+    for (uint32_t e0 = 0; e0 < size; e0 += kIn * kDedupThreads) {   // block-uniform trip count: the wave ballots below need whole waves
+        int64_t kq[kIn];
+        uint32_t pq[kIn];
+#pragma unroll
+        for (int q = 0; q < kIn; ++q) {
+            const uint32_t e = e0 + (uint32_t)q * kDedupThreads + t;
+            kq[q] = kEmpty; pq[q] = 0u;
+            if (e < size) {
+                const uint32_t at = dd_entry_at(L, e);
+                kq[q] = bk.pkey[at];
+                if (LAST) pq[q] = bk.pos[at];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kIn; ++q) {
+            const int64_t key = kq[q];
+            const uint32_t p = pq[q];
+            const unsigned long long bkey = (unsigned long long)key ^ kBias;
+            const bool mine = key != kEmpty && ((uint32_t)mix64b((uint64_t)key) & mask) == val;   // (EMPTY is in no bucket: it marks a lane past the end)
+            // all of the wave's entries in this pass carry one key: one lane speaks for the wave
+            const unsigned long long act = __ballot(mine);
+            if (act == 0ull) continue;
+            const int lead = __ffsll((long long)act) - 1;
+            const unsigned long long k0 = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(bkey >> 32), lead) << 32) | (uint32_t)__shfl((int)(uint32_t)bkey, lead);
+            const bool uniform = __ballot(mine && bkey == k0) == act;
+            uint32_t pmax = mine ? p : 0u;
+            if (LAST && uniform) {   // the wave's highest position of that key
+#pragma unroll
+                for (int d = 32; d; d >>= 1) pmax = max(pmax, (uint32_t)__shfl_xor((int)pmax, d));
+            }
+            if (mine && (!uniform || (int)(t & 63) == lead) && __hip_atomic_load(&L.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+                uint32_t s = (uint32_t)(mix64b(bkey ^ kBias) >> 12) & (kDedupSlots - 1);
+                bool placed = false;
+                for (uint32_t probes = 0; probes < kDedupSlots; ++probes) {   // (bounded: a table that other threads fill up meanwhile must not trap this one)
+                    const unsigned long long old = atomicCAS(&L.key[s], 0ull, bkey);
+                    if (old == 0ull) { if (atomicAdd(&L.n_distinct, 1u) >= kDedupFill) __hip_atomic_store(&L.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); placed = true; break; }
+                    if (old == bkey) { placed = true; break; }
+                    s = (s + 1) & (kDedupSlots - 1);
+                }
+                if (placed) {
+                    atomicAdd(&L.cnt[s], uniform ? (uint32_t)__popcll(act) : 1u);
+                    if (LAST) atomicMax(&L.val[s], 1u + pmax);
+                } else __hip_atomic_store(&L.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+    return L.overflow == 0u;
+}
+
+// the pass driver: DFS over hash prefixes, every pass that fits is handed to `emit(bits, val)`
+template <bool LAST, class Emit>
+__device__ __forceinline__ void dd_passes(DedupLds& L, const BucketScratch& bk, uint32_t size, uint32_t parity, uint32_t hot_count, Emit emit) {
+    if (threadIdx.x == 0) { L.stk_n = 1u; L.stk_bits[0] = 0u; L.stk_val[0] = 0u; }
+    __syncthreads();
+    while (true) {
+        const uint32_t n = __builtin_amdgcn_readfirstlane(L.stk_n);
+        if (n == 0) break;
+        const uint32_t bits = __builtin_amdgcn_readfirstlane(L.stk_bits[n - 1]), val = __builtin_amdgcn_readfirstlane(L.stk_val[n - 1]);
+        __syncthreads();
+        if (threadIdx.x == 0) L.stk_n = n - 1;
+        if (dd_build<LAST>(L, bk, size, bits, val)) {
+            // keys with enough occurrences to fill half a slab get a bucket of their own in the next batch (meepo_apply_part.h)
+            for (uint32_t s = threadIdx.x; s < kDedupSlots; s += kDedupThreads)
+                if (L.cnt[s] >= hot_count) report_hot_key(bk, parity, (int64_t)(L.key[s] ^ kBias));
+            emit(bits, val);
+        } else if (threadIdx.x == 0 && bits < 32 && L.stk_n + 2 <= 40) {   // (mix64b is a bijection: distinct keys separate within 64 bits; 32 suffice for any batch)
+            const uint32_t m = L.stk_n;
+            L.stk_bits[m] = bits + 1; L.stk_val[m] = val;
+            L.stk_bits[m + 1] = bits + 1; L.stk_val[m + 1] = val | 1u << bits;
+            L.stk_n = m + 2;
+        }
+        __syncthreads();
+    }
+}
+
+struct DedupArgs {
+    uint32_t nbk, nbk_hash, part_blocks, per_block, hot_count;
+    OpCounters* op;
+    uint32_t* h_slabs;
+    int64_t* uniq; int64_t* inverse;   // dedup
+};
+
+// A hot key's own bucket (b >= nbk_hash: the partition sent exactly ONE key there) needs no table: every entry is that key.  It is cut into
+// WINDOWS of kHotWindow entries, one block each — the blocks behind the buckets in the grid —, so that a key with 80 000 occurrences in a
+// batch of 1M is 20 blocks' work, not one block's 300 dependent steps.  What the windows of a bucket must agree on costs no communication: the
+// hot keys' numbers in the unique list come FIRST — hot bucket h gets the count of non-empty hot buckets in front of it, which every block
+// reads off the same kHotCap totals —, and the hash buckets' blocks number their keys from H (the non-empty hot buckets) on.
+constexpr uint32_t kHotWindow = 4096;
+struct HotPlan { uint32_t H, units, h, win, n_win, rank, size; bool valid; };   // H, units: non-empty hot buckets and their windows in all;   // this block's window: hot bucket h, window `win` of n_win, the key's number `rank`
+__device__ __forceinline__ HotPlan hot_plan(DedupLds& L, const BucketScratch& bk, const DedupArgs& A, uint32_t parity_guess_tot0, uint32_t parity_guess_tot1, uint32_t parity, int x /* window unit, or -1: only H is wanted */) {
+    // (called by all threads; lanes 0..127 hold hot bucket `lane`'s total)
+    const uint32_t n_hot = A.nbk - A.nbk_hash;
+    const uint32_t t = threadIdx.x;
+    const uint32_t tt = t < n_hot ? (parity ? parity_guess_tot1 : parity_guess_tot0) : 0u;
+    if (t < kHotCap) { L.val[t] = tt; }
+    __syncthreads();
+    HotPlan P{0, 0, 0, 0, 0, 0, 0, false};
+    uint32_t units = 0;
+    for (uint32_t h = 0; h < n_hot; ++h) {   // (<= 128 LDS reads: every thread walks the same list)
+        const uint32_t sz = L.val[h];
+        if (sz == 0) continue;
+        const uint32_t nw = (sz + kHotWindow - 1) / kHotWindow;
+        if (x >= 0 && !P.valid && (uint32_t)x < units + nw) { P.h = h; P.win = (uint32_t)x - units; P.n_win = nw; P.rank = P.H; P.size = sz; P.valid = true; }
+        units += nw;
+        ++P.H;
+    }
+    P.units = units;
+    __syncthreads();
+    return P;
+}
+
+// the block's bucket: (size, parity) — ONE round trip brings the bucket's totals (both copies), the copy selector, the hot keys' totals, the
+// bucket's runs in the partition blocks' slices and (PREFIX: the dedup) the totals of the hash buckets in front of this one.  `P.H` = the
+// non-empty hot keys' buckets (their keys are numbered first); a block beyond the buckets (blockIdx >= nbk) gets its window of a hot key's
+// bucket in `P` instead.  `before` (PREFIX) = the positions in the hash buckets in front of this one.
+template <bool PREFIX>
+__device__ __forceinline__ uint32_t dd_bucket(DedupLds& L, const BucketScratch& bk, const DedupArgs& A, uint32_t& parity, HotPlan& P, uint32_t& before) {
+    const uint32_t b = blockIdx.x;
+    const bool own = b < A.nbk, hash = b < A.nbk_hash;
+    const uint32_t tot0 = own ? bk.tot[b] : 0u, tot1 = own ? bk.tot[bk.n_buckets_max + b] : 0u;
+    const uint32_t n_hot = A.nbk - A.nbk_hash;
+    const uint32_t ht0 = threadIdx.x < n_hot ? bk.tot[A.nbk_hash + threadIdx.x] : 0u, ht1 = threadIdx.x < n_hot ? bk.tot[bk.n_buckets_max + A.nbk_hash + threadIdx.x] : 0u;
+    const uint4 hdr = *reinterpret_cast<const uint4*>(bk.seq);
+    const DdRuns runs = hash ? dd_seg_load(bk, A.nbk, A.part_blocks, A.per_block, b, threadIdx.x) : DdRuns{{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    uint32_t s0 = 0, s1 = 0;   // this thread's share of the totals in front of the bucket (both copies: the selector is not known yet)
+    if (PREFIX && hash)
+        for (uint32_t j = threadIdx.x; j < b; j += kDedupThreads) { s0 += bk.tot[j]; s1 += bk.tot[bk.n_buckets_max + j]; }
+    parity = __builtin_amdgcn_readfirstlane(hdr.y);
+    if (b == 0 && threadIdx.x == 0) atomicAdd(&bk.seq[0], 1u);   // this partition is consumed
+    P = hot_plan(L, bk, A, ht0, ht1, parity, own ? -1 : (int)(b - A.nbk));
+    // the pinned host word the next partition sizes itself by: the units this batch has beyond its hash buckets — the hot keys' windows (they keep
+    // their buckets while they stay hot) and, added below as they turn up, the slabs an oversized hash bucket would make
+    if (b == 0 && threadIdx.x == 0) *A.h_slabs = P.units;
+    uint32_t size = __builtin_amdgcn_readfirstlane(parity ? tot1 : tot0);
+    before = 0;
+    if (!own) {   // a window of a hot key's bucket
+        if (!P.valid) return 0u;
+        size = P.size;
+        dd_seg_scan(L, dd_seg_load(bk, A.nbk, A.part_blocks, A.per_block, A.nbk_hash + P.h, threadIdx.x), threadIdx.x);
+    } else {
+        if (!hash) return 0u;   // a hot key's bucket: its windows' business (the blocks behind the buckets)
+        dd_seg_scan(L, runs, threadIdx.x);
+        if (PREFIX) {
+            uint32_t mine = parity ? s1 : s0;
+#pragma unroll
+            for (int d = 32; d; d >>= 1) mine += (uint32_t)__shfl_xor((int)mine, d);
+            if ((threadIdx.x & 63) == 0) L.stk_val[threadIdx.x >> 6] = mine;
+        }
+    }
+    if (own && size > kBucketCap && threadIdx.x == 0) { const uint32_t mine = (size + kSlab - 1) / kSlab; *A.h_slabs = P.units + atomicAdd(&bk.seq[4], mine) + mine; }   // a skewed stream: hot keys get buckets of their own next time
+    __syncthreads();
+    if (PREFIX && own) for (int w = 0; w < kDedupWaves; ++w) before += L.stk_val[w];
+    __syncthreads();
+    return size;
+}
+
+__global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs A, BucketScratch bk) {
+    __shared__ DedupLds L;
+    uint32_t parity, before;
+    HotPlan P;
+    const uint32_t size = dd_bucket<true>(L, bk, A, parity, P, before);
+    if (size == 0) return;
+    if (blockIdx.x >= A.nbk) {   // ---- a window of a hot key's own bucket: every entry is that key, its number is P.rank
+        const uint32_t lo = P.win * kHotWindow, hi = min(size, lo + kHotWindow);
+        if (P.win == 0 && threadIdx.x == 0) {
+            const int64_t key = bk.pkey[dd_entry_at(L, 0)];
+            A.uniq[P.rank] = key;
+            if (size >= A.hot_count) report_hot_key(bk, parity, key);   // stays listed while it stays hot
+        }
+        for (uint32_t e = lo + threadIdx.x; e < hi; e += kDedupThreads) A.inverse[bk.pos[dd_entry_at(L, e)]] = (int64_t)P.rank;
+        return;
+    }
+    // Where this bucket's distinct keys go in d_uniq: behind the hot keys' numbers, at the positions the hash buckets in front of it hold —
+    // every bucket owns as many entries of the list as it has positions, its distinct keys fill the front of that slice and the rest stays
+    // EMPTY.  No counter: 3 000 blocks that reserve their slices from one word take 35 us for that alone (one word serves ~88 atomics per us).
+    uint32_t slice = P.H + before;
+    dd_passes<false>(L, bk, size, parity, A.hot_count, [&](uint32_t bits, uint32_t val) {
+        const uint32_t t = threadIdx.x;
+        // the pass's distinct keys get consecutive numbers (block scan over the table's slots), its slice of the unique list one atomic
+        constexpr uint32_t per = kDedupSlots / kDedupThreads;
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < per; ++q) mine += L.key[t * per + q] != 0ull;
+        unsigned long long total;
+        uint32_t idx = (uint32_t)block_scan_u64<kDedupWaves>(mine, L.wsum, total);
+        const uint32_t base = slice;
+        slice += (uint32_t)total;   // (block-uniform: the next pass of this bucket continues behind this one's keys)
+#pragma unroll
+        for (uint32_t q = 0; q < per; ++q) {
+            const uint32_t s = t * per + q;
+            if (L.key[s] != 0ull) { A.uniq[base + idx] = (int64_t)(L.key[s] ^ kBias); L.val[s] = idx++; }
+        }
+        __syncthreads();
+        const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u;
+        for (uint32_t e0 = 0; e0 < size; e0 += 4 * kDedupThreads) {   // four entries in flight per thread
+            int64_t kq[4]; uint32_t pq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t e = e0 + (uint32_t)q * kDedupThreads + t;
+                kq[q] = kEmpty; pq[q] = 0u;
+                if (e < size) { const uint32_t at = dd_entry_at(L, e); kq[q] = bk.pkey[at]; pq[q] = bk.pos[at]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (kq[q] != kEmpty && ((uint32_t)mix64b((uint64_t)kq[q]) & mask) == val) A.inverse[pq[q]] = (int64_t)(base + L.val[dd_lookup(L, (unsigned long long)kq[q] ^ kBias)]);
+        }
+    });
+}
+
+// the partition of a dedup: the same sort as an apply's, and — while the keys are in registers anyway — the output's padding: d_uniq[i] = EMPTY
+// for every i (the dedup kernel overwrites the first n_unique of them), d_inverse[i] = miss_index for reserved keys (they are in no bucket)
+__global__ __launch_bounds__(1024) void bkt_sort_dedup_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk_hash, uint32_t nbk, uint32_t per_block, BucketScratch bk,
+                                                              uint32_t* status, OpCounters* op, int64_t* __restrict__ uniq, int64_t* __restrict__ inverse, int64_t miss_index, uint32_t tot_atomics) {
+    extern __shared__ unsigned long long part_lds[];
+    __shared__ unsigned long long wsum[1024 / 64];
+    const uint32_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        uniq[i] = kEmpty;
+        if (reserved_key(keys[i])) inverse[i] = miss_index;
+    }
+    PartHot* hot = reinterpret_cast<PartHot*>(part_lds);
+    sort_role<1024>(keys, n, nbk_hash, nbk, per_block, blockIdx.x, gridDim.x, bk, status, op, reinterpret_cast<uint32_t*>(hot + 1), wsum, hot, tot_atomics != 0);
+}
+
+// ---- assign (update-if-present): last position wins, one probe + one row copy per distinct key ---------------------------------------------
+struct AssignArgs {
+    DedupArgs d;
+    int64_t* tkeys; float4* rows; uint64_t nb; uint32_t dim4;
+    const float4* values; uint8_t* found;   // (values: the batch's rows; rows: the table plane)
+};
+
+template <int DIM4>
+__global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A, BucketScratch bk) {
+    __shared__ DedupLds L;
+    uint32_t parity;
+    HotPlan P;
+    uint32_t before;
+    const uint32_t size = dd_bucket<false>(L, bk, A.d, parity, P, before);
+    if (size == 0) return;
+    const uint32_t dim4 = DIM4 ? DIM4 : A.dim4;
+    if (blockIdx.x >= A.d.nbk) {   // ---- a window of a hot key's own bucket: every entry is that key
+        const uint32_t t = threadIdx.x, b = A.d.nbk_hash + P.h;
+        const int lane = t & 63, tile = lane >> 4, tl = lane & 15;
+        const uint32_t lo = P.win * kHotWindow, hi = min(size, lo + kHotWindow);
+        const int64_t key = bk.pkey[dd_entry_at(L, 0)];
+        // the window's last position -> the bucket's (atomicMax on the bucket's word; the partition zeroed it)
+        uint32_t pm = 0;
+        for (uint32_t e = lo + t; e < hi; e += kDedupThreads) pm = max(pm, 1u + bk.pos[dd_entry_at(L, e)]);
+#pragma unroll
+        for (int d = 32; d; d >>= 1) pm = max(pm, (uint32_t)__shfl_xor((int)pm, d));
+        if (lane == 0) L.stk_val[t >> 6] = pm;
+        // every window probes for itself (one bucket line): its entries' found bytes need no word from the other windows
+        int64_t slot = -1;
+        if (t < 64) {
+            bool is_new, full;
+            slot = tile_locate<false, false>(A.tkeys, A.nb, key, tile == 0, tile, tl, is_new, full);
+            if (t == 0) { L.base = (uint32_t)(slot >= 0); L.stk_bits[0] = (uint32_t)slot; L.stk_bits[1] = (uint32_t)((uint64_t)slot >> 32); }
+        }
+        __syncthreads();
+        if (A.found) for (uint32_t e = lo + t; e < hi; e += kDedupThreads) A.found[bk.pos[dd_entry_at(L, e)]] = (uint8_t)L.base;
+        if (t == 0) {
+            uint32_t m = 0;
+            for (int w = 0; w < kDedupWaves; ++w) m = max(m, L.stk_val[w]);
+            (void)__hip_atomic_fetch_max(&bk.pend_cnt[b], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the maximum is in before the ticket is drawn
+            const uint32_t tk = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            L.overflow = tk == P.n_win - 1;   // the window that finishes last copies the winner's row
+            if (tk == P.n_win - 1) L.n_distinct = __hip_atomic_load(&bk.pend_cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
+            if (P.win == 0 && size >= A.d.hot_count) report_hot_key(bk, parity, key);   // stays listed while it stays hot
+        }
+        __syncthreads();
+        if (L.overflow && L.base && t < 16) {
+            const uint32_t win = L.n_distinct;
+            const int64_t sl = (int64_t)((uint64_t)L.stk_bits[0] | (uint64_t)L.stk_bits[1] << 32);
+            for (uint32_t col = t; col < dim4; col += 16) A.rows[(uint64_t)sl * dim4 + col] = A.values[(uint64_t)win * dim4 + col];
+        }
+        return;
+    }
+    dd_passes<true>(L, bk, size, parity, A.d.hot_count, [&](uint32_t bits, uint32_t val) {
+        const uint32_t t = threadIdx.x;
+        const int lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6;
+        // the pass's distinct keys as a dense list (block scan over the table's slots; the occurrence counts have been read: their array holds the list)
+        constexpr uint32_t per = kDedupSlots / kDedupThreads;
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < per; ++q) mine += L.key[t * per + q] != 0ull;
+        unsigned long long total;
+        uint32_t idx = (uint32_t)block_scan_u64<kDedupWaves>(mine, L.wsum, total);
+        __syncthreads();   // (every thread has read the counts of its slots in the hot-key report)
+#pragma unroll
+        for (uint32_t q = 0; q < per; ++q) if (L.key[t * per + q] != 0ull) L.cnt[idx++] = t * per + q;
+        __syncthreads();
+        const uint32_t n_items = (uint32_t)total;
+        // two keys per tile and step: both source rows and both first bucket lines are requested before anything is waited for; a key whose
+        // first bucket neither holds it nor ends its probe (2-3 % at load 0.75) goes through the full probe afterwards
+        for (uint32_t it0 = (uint32_t)wv * 8; it0 < n_items; it0 += kDedupWaves * 8) {   // wave-uniform bound: ballots below
+            uint32_t s[2], win[2];
+            int64_t key[2], slot[2];
+            bool act[2], pend[2];
+            f32x4 row[2];
+            int64_t kb[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t item = it0 + (uint32_t)r * 4 + tile;
+                act[r] = item < n_items;
+                s[r] = act[r] ? L.cnt[item] : 0u;
+                key[r] = (int64_t)(L.key[s[r]] ^ kBias);
+                win[r] = L.val[s[r]] - 1u;
+                row[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (act[r] && (uint32_t)tl < dim4) row[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A.values) + (uint64_t)win[r] * dim4 + tl);
+                kb[r] = act[r] ? A.tkeys[bucket_of(key[r], A.nb) * kW + tl] : kEmpty;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t tm = tile_bits(__ballot(act[r] && kb[r] == key[r]), tile), te = tile_bits(__ballot(act[r] && kb[r] == kEmpty), tile);
+                slot[r] = tm ? (int64_t)(bucket_of(key[r], A.nb) * kW) + (__ffs(tm) - 1) : -1;
+                pend[r] = act[r] && !tm && !te;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (__any(pend[r])) {
+                    bool is_new, full;
+                    const int64_t s2 = tile_locate<false, false>(A.tkeys, A.nb, key[r], pend[r], tile, tl, is_new, full);
+                    if (pend[r]) slot[r] = s2;
+                }
+                if (act[r] && slot[r] >= 0) {
+                    f32x4* dst = reinterpret_cast<f32x4*>(A.rows) + (uint64_t)slot[r] * dim4;
+                    if ((uint32_t)tl < dim4) dst[tl] = row[r];
+                    for (uint32_t col = tl + 16; col < dim4; col += 16) dst[col] = reinterpret_cast<const f32x4*>(A.values)[(uint64_t)win[r] * dim4 + col];
+                }
+                if (act[r] && tl == 0) L.val[s[r]] = slot[r] >= 0;   // from here on: the key's found flag
+            }
+        }
+        __syncthreads();
+        if (A.found) {
+            const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u;
+            for (uint32_t e = t; e < size; e += kDedupThreads) {
+                const uint32_t at = dd_entry_at(L, e);
+                const int64_t key = bk.pkey[at];
+                if (((uint32_t)mix64b((uint64_t)key) & mask) != val) continue;
+                A.found[bk.pos[at]] = (uint8_t)L.val[dd_lookup(L, (unsigned long long)key ^ kBias)];
+            }
+        }
+    });
+}
+
+// found bytes of the positions that are in no bucket (reserved keys): 0
+__global__ void assign_reserved_found_kernel(const int64_t* __restrict__ keys, uint32_t n, uint8_t* __restrict__ found) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) if (reserved_key(keys[i])) found[i] = 0;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------------------------
+// blocks behind the buckets: one per window a batch of n keys can have in its hot keys' buckets (sum of ceil(size / kHotWindow) <= n / kHotWindow + hot buckets)
+static uint32_t hot_window_blocks(const DedupArgs& A, uint32_t n) { return A.nbk != A.nbk_hash ? n / kHotWindow + (A.nbk - A.nbk_hash) : 0u; }
+static int dedup_partition(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st, DedupArgs& A, int64_t* d_uniq, int64_t* d_inverse, int64_t miss_index) {
+    uint32_t grid, nbk;
+    bool full;
+    const uint32_t nbk_hash = bucket_count_for(t, n, &grid, &nbk, &full);
+    // (hot keys' buckets whenever the latest batch reported any: a dedup has no FULL / LEAN kernels, its one kernel takes buckets of any size)
+    uint32_t blocks, per_block;
+    part_geometry(n, 1024, blocks, per_block);
+    A.nbk = nbk; A.nbk_hash = nbk_hash; A.part_blocks = blocks; A.per_block = per_block; A.hot_count = hot_count_for(n); A.op = t->op; A.h_slabs = t->bk.h_slabs_dev;
+    if (!d_uniq) return bucket_apply_prepare_as(t, d_keys, n, st, nbk_hash, nbk, blocks, per_block);
+    const bool atom = bucket_totals_by_atomics(blocks, nbk);
+    bkt_sort_dedup_kernel<<<blocks, 1024, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, d_uniq, d_inverse, miss_index, atom);
+    MEE_HIP(hipGetLastError());
+    return atom ? MEE_OK : bucket_totals_launch(t, nbk, blocks, st);
+}
+
+int bucket_dedup_keys(mee_table* t, const int64_t* d_keys, uint32_t n, int64_t* d_uniq, int64_t* d_inverse, int64_t miss_index, hipStream_t st) {
+    DedupArgs A{};
+    if (int rc = dedup_partition(t, d_keys, n, st, A, d_uniq, d_inverse, miss_index)) return rc;
+    A.uniq = d_uniq; A.inverse = d_inverse;
+    bkt_dedup_keys_kernel<<<A.nbk + hot_window_blocks(A, n), kDedupThreads, 0, st>>>(A, t->bk);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+int bucket_assign(mee_table* t, float* plane, const int64_t* d_keys, const float* d_values, uint32_t n, uint8_t* d_found, hipStream_t st) {
+    AssignArgs A{};
+    if (int rc = dedup_partition(t, d_keys, n, st, A.d, nullptr, nullptr, 0)) return rc;
+    A.tkeys = t->keys; A.rows = (float4*)plane; A.nb = t->nb; A.dim4 = t->dim4; A.values = (const float4*)d_values; A.found = d_found;
+    if (d_found) assign_reserved_found_kernel<<<grid_for(n, 256, 1024), 256, 0, st>>>(d_keys, n, d_found);
+    const uint32_t grid = A.d.nbk + hot_window_blocks(A.d, n);
+    if (t->dim4 == 16) bkt_assign_kernel<16><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
+    else if (t->dim4 == 32) bkt_assign_kernel<32><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
+    else bkt_assign_kernel<0><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+}  // namespace mee

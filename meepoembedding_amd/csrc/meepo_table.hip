@@ -1962,8 +1962,8 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     t->workspace_bytes = S * (36 + 2 * kInl * 4) + mb * 25 + t->max_big * 4 + (t->bs.gacc ? t->max_part * (uint64_t)t->dim * sizeof(double) : 0) +
                          sizeof(Counters) + sizeof(OpCounters);
     t->apply_path = -1;
-    if (t->optimizer != MEE_OPT_NONE)   // the bucketed apply's scratch (adds to workspace_bytes)
-        if ((rc = bucket_scratch_alloc(t)) != MEE_OK) goto bad;
+    t->dedup_path = -1;
+    if ((rc = bucket_scratch_alloc(t)) != MEE_OK) goto bad;   // the bucketed machinery's scratch: partition (every table), pending records (tables with an optimizer); adds to workspace_bytes
     if (hipHostMalloc((void**)&t->h_ctr, sizeof(Counters)) != hipSuccess || hipHostMalloc((void**)&t->h_op, sizeof(OpCounters)) != hipSuccess) {
         rc = fail(MEE_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
         goto bad;
@@ -2012,6 +2012,7 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     else if (!strcmp(name, "apply_bucket_max")) t->bk.bucket_max = value > 0 && value <= 352 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_skew_adapt")) t->bk.skew_adapt = value != 0;
     else if (!strcmp(name, "apply_kernel")) t->bk.kernel_choice = value < 0 ? -1 : value != 0;
+    else if (!strcmp(name, "dedup_path")) t->dedup_path = value;
     else if (!strcmp(name, "apply_overlap")) (void)value;   // retired in round 2 (a side stream for the duplicate path lost to its fork/join gaps): accepted, ignored
     else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);
     return MEE_OK;
@@ -2291,7 +2292,11 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
         MEE_HIP(hipGetLastError());
         return MEE_OK;
     }
-    // assign: an election over all positions (last occurrence wins), then the winners probe and overwrite
+    // assign: the bucketed machinery (meepo_dedup.hip: partition by hash bucket, then one kernel — block-local LDS election, one probe and
+    // one row copy per distinct key, the found byte to every occurrence) ...
+    if (!skip && t->bk.pkey && n <= t->bk.fast_max && t->dedup_path != 0) return bucket_assign(t, plane, d_keys, d_values, nn, d_found, st);
+    // ... or round 2's form (tuning "dedup_path" = 0; batches beyond the partition's reach): an election over all positions in the group table
+    // (last occurrence wins), then the winners probe and overwrite
     group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, skip);
     {
         const unsigned ga = grid_for(n, 32, 1u << 16);   // two positions per tile
@@ -2499,7 +2504,7 @@ static int apply_prepare_launch(mee_table* t, const int64_t* d_keys, uint32_t nn
 // Which apply a batch of n keys takes: the bucketed one (meepo_apply.hip: partition by hash bucket, one block-local dedup + update kernel)
 // unless the caller's knob says otherwise or the batch is beyond what its partition handles well (then: the group-table apply below).
 static bool use_bucketed_apply(const mee_table* t, size_t n) {
-    if (!t->bk.pkey || n > t->bk.fast_max) return false;
+    if (t->optimizer == MEE_OPT_NONE || !t->bk.pkey || n > t->bk.fast_max) return false;
     return t->apply_path != 0;
 }
 
@@ -2851,6 +2856,8 @@ int mee_dedup_keys(mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_uni
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
+    if (t->bk.pkey && n <= t->bk.fast_max && t->dedup_path != 0)   // partition by hash bucket + one kernel of block-local LDS tables (meepo_dedup.hip)
+        return bucket_dedup_keys(t, d_keys, nn, d_uniq_out, d_inverse_out, miss_index, st);
     const unsigned gl = grid_for(n, 256, 1u << 22);
     group_kernel<kGroupCount, kApplyGroupBlock><<<grid_for(nn, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op);
     group_plan_kernel<true><<<grid_for(n, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);

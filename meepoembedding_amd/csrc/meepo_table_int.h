@@ -66,7 +66,7 @@ struct BatchScratch {          // max_batch entries, indexed by batch position u
 struct BucketScratch {
     uint32_t* pos;        // [fast_max] batch positions: partition block k's share of the batch, sorted by hash bucket, in slice k (aliases BatchScratch::occ)
     int64_t* pkey;        // [fast_max] their keys, in the same order
-    uint32_t* cnt_mat;    // [kPartBlocks][n_buckets_max] keys of each bucket held by each partition block …
+    uint32_t* cnt_mat;    // [kPartBlocksMax][n_buckets_max] keys of each bucket held by each partition block …
     uint32_t* off_mat;    // … and where that run starts inside the block's slice of pos / pkey
     uint32_t* tot;        // [2][n_buckets_max] keys per bucket (added up by the partition blocks); two copies, used alternately
     uint32_t* has_split;  // [2] some bucket holds more than one slab (the apply kernel's spare blocks have work)
@@ -129,6 +129,7 @@ struct mee_table {
                                 // dense output fits the Infinity Cache (<= 128 MB), streaming stores beyond
     mee::BucketScratch bk;      // bucketed apply (null pointers when the table has no optimizer)
     int apply_path;             // -1 = the library's choice, 0 = group-table apply, 1 = bucketed apply
+    int dedup_path;             // tuning ("dedup_path"): 0 = dedup_keys / assign elections through the group table (round 2), else the bucketed machinery
     uint32_t prepared_path;     // which path a pending mee_apply_prepare took
     bool prepared_by_forward;   // the pending partition came with a training forward (mee_find*_located_prepare): a mutator in between drops it
     uint32_t part_nbk_hash;   // ... of which the first part_nbk_hash are hash buckets (the rest: one per hot key)
@@ -172,6 +173,12 @@ int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStr
 int bucket_apply_discard(mee_table* t, hipStream_t st);
 int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const OptArgs& a, const uint32_t* d_gidx, const int64_t* d_slots, hipStream_t st,
                         const GroupDesc* d_desc = nullptr, uint32_t n_tables = 0);
+bool bucket_totals_by_atomics(uint32_t blocks, uint32_t nbk);
+int bucket_totals_launch(mee_table* t, uint32_t nbk, uint32_t blocks, hipStream_t st);
+int bucket_apply_prepare_as(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st, uint32_t nbk_hash, uint32_t nbk, uint32_t blocks, uint32_t per_block);
+// duplicate elimination and last-wins elections on the same partition (meepo_dedup.hip)
+int bucket_dedup_keys(mee_table* t, const int64_t* d_keys, uint32_t n, int64_t* d_uniq, int64_t* d_inverse, int64_t miss_index, hipStream_t st);
+int bucket_assign(mee_table* t, float* plane, const int64_t* d_keys, const float* d_values, uint32_t n, uint8_t* d_found, hipStream_t st);
 uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out = nullptr, uint32_t* nbk_total_out = nullptr, bool* full_out = nullptr);
 
 }  // namespace mee

@@ -134,7 +134,7 @@ class PeerShardedFind:
             self._barrier()
             if check_overflow:
                 self.check()
-            # positions [0, n_distinct) of the result buffers hold the distinct keys' rows; expand through the index
+            # the result buffers hold the distinct keys' rows at the keys' positions in `uniq`; expand through the index
             rows = self.router.gather_rows(self.out, inverse, n_out=n)
             found = self.router.gather_rows(self.found, inverse, n_out=n)
             return rows, found

@@ -461,7 +461,7 @@ class LookupTable:
         check(_lib.lib().mee_apply_discard(self._h, self._s()))
 
     def dedup_keys(self, keys: torch.Tensor, miss_index: int = -1):
-        """Sync-free duplicate elimination: (uniq [n] = distinct keys then EMPTY padding, inverse [n] = index into uniq, or
+        """Sync-free duplicate elimination: (uniq [n] = every distinct key once, EMPTY everywhere else — also between the keys —, inverse [n] = index into uniq, or
         miss_index for reserved keys).  How many keys are distinct stays on the device."""
         k = self._keys(keys)
         n = k.numel()
