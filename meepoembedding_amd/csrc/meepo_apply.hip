@@ -54,6 +54,8 @@ uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out, uint32_t
     if (s_prev) t->bk.skew_sticky = 64;
     else if (t->bk.skew_sticky) --t->bk.skew_sticky;
     if (full_out) *full_out = t->bk.kernel_choice >= 0 ? t->bk.kernel_choice != 0 : (s_prev != 0 || t->bk.skew_sticky != 0);
+    // (a batch with more keys than its buckets hold whole: every bucket is a list of slabs — the FULL kernel's business, whatever the knob says)
+    if (full_out && n > (uint64_t)full * (kBucketCap * 3 / 4)) *full_out = true;
     if (s_prev && n > (uint64_t)t->bk.slots * 128) {
         uint32_t adj = s_prev + s_prev / 16 + 1;
         if (adj > t->bk.slots / 2) adj = t->bk.slots / 2;
@@ -1095,13 +1097,12 @@ int bucket_scratch_alloc(mee_table* t) {
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device);
     bk.slots = (uint32_t)cus * kApplyBlocksPerCU;
-    const uint64_t most = (uint64_t)(kMaxBuckets / bk.slots ? kMaxBuckets / bk.slots * bk.slots : kMaxBuckets) * kBucketMax;   // beyond that buckets would outgrow their slabs
-    bk.fast_max = t->max_batch < most ? t->max_batch : most;
+    bk.fast_max = t->max_batch;   // every batch the table takes: beyond ~5M keys (kMaxBuckets buckets of ~700) the buckets outgrow kBucketCap and go through their slabs
     // buckets the largest batch can be cut into (+ the hot keys' own): the strides of the totals' two copies and of the run matrices
     bk.n_buckets_max = bucket_count_for_host(bk.fast_max, bk.slots) + kHotCap;
     if (bk.n_buckets_max > kMaxBuckets) bk.n_buckets_max = kMaxBuckets;
     bk.n_buckets_max = (bk.n_buckets_max + 63u) & ~63u;
-    bk.pos = t->bs.occ;   // max_batch entries; the group-table apply and this one never run at the same time on one table
+    bk.pos = t->bs.occ;   // max_batch entries; mee_dedup (the group-table reduction that also sums rows) and a partition never run at the same time on one table
     hipError_t e = hipSuccess;
     auto alloc = [&](void** p, uint64_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes); if (e == hipSuccess) t->workspace_bytes += bytes; } };
     alloc((void**)&bk.pkey, bk.fast_max * 8);

@@ -502,29 +502,18 @@ __device__ __forceinline__ uint32_t group_claim(const GroupTable& g, int64_t key
 
 constexpr int kGroupLast = 0;   // max(lo, hi) = 1 + highest batch position of the key (last occurrence wins)
 constexpr int kGroupCount = 1;  // lo + hi = occurrence count, rank[i] = arrival order (finalised by the plan pass)
-constexpr int kGroupApply = 2;  // kGroupCount + every key's occurrences chained into lists (the apply path; see group_kernel)
 constexpr uint32_t kRankRemote = 0x80000000u;  // rank was handed out by an atomic on lo: add hi to finalise
-constexpr uint32_t kRankFiled = 0x40000000u;   // apply: the occurrence's own block already saw its group outgrow the inline list (ranks stay below 2^30)
 #ifndef MEE_KCHUNK
 #define MEE_KCHUNK 32
 #endif
 constexpr uint32_t kChunk = MEE_KCHUNK;        // occurrences summed by one tile; a key with more in one batch is a "hot" key
-constexpr uint32_t kInl = 8;                    // positions per half of an entry's inline list (see GroupTable::inl)
-constexpr int kApplyGroupBlock = 1024;         // threads per block of the apply's group_kernel: a hot key costs its entry one atomic per block, so on a skewed
-                                               // batch big blocks win (Zipf(1.05), 256K keys: 33 -> 25 us, and more occurrences learn in their own block that their group is filed);
-                                               // on a batch of distinct keys the size makes no difference (20.9 vs 21.5 us)
+constexpr int kApplyGroupBlock = 1024;         // threads per block of the duplicate reduction's group_kernel: a hot key costs its entry one atomic per block
 constexpr uint32_t kEpochWrap = (1u << 31) - 16;   // batch numbers (mee_table::epoch) start over here
 
 // One lane per batch position.  Occurrences of the same key inside a 256-thread block are first combined in an
 // LDS hash table keyed by the key itself; ONE lane per (block, key) then talks to the global group table.  A hot key
 // that is 8 % of the batch costs ~n/256 global accesses instead of 0.08 n serialised on one L2 line, and the block
 // whose CAS claimed the entry needs no counting atomic at all.
-// kGroupApply additionally leaves every duplicate occurrence where the key's leader (the rank-0 occurrence: local rank 0 in the block
-// whose CAS claimed the entry) finds it with ONE 64-byte load: the claiming block's occurrences of local rank 1..kInl store their
-// position in inl[h][rank - 1], occurrences of other blocks with arrival number q < kInl (the atomicAdd on `lo` hands those out) in
-// inl[h][kInl + q].  A group with hi <= kInl + 1 and lo <= kInl therefore sits complete in its entry's line (no pointer chasing, no
-// terminators, stale words of earlier batches lie beyond the counts and are never read); larger groups are finished through their
-// ranks by the filing kernels.  A key that occurs once costs no atomic beyond its claim and no store beyond its count.
 template <int MODE, int BLOCK = 256>
 __global__ __launch_bounds__(BLOCK) void group_kernel(const int64_t* __restrict__ keys, uint32_t n, GroupTable g, BatchScratch bs,
                                                     Counters* ctr, const uint8_t* __restrict__ skip, OpCounters* op_to_zero = nullptr,
@@ -555,7 +544,7 @@ __global__ __launch_bounds__(BLOCK) void group_kernel(const int64_t* __restrict_
             if (old == bk) break;
             slot = (slot + 1) & (kLds - 1);
         }
-        if (MODE == kGroupCount || MODE == kGroupApply) r_local = atomicAdd(&lval[slot], 1u);
+        if (MODE == kGroupCount) r_local = atomicAdd(&lval[slot], 1u);
         else atomicMax(&lval[slot], i + 1);
     }
     __syncthreads();
@@ -563,11 +552,9 @@ __global__ __launch_bounds__(BLOCK) void group_kernel(const int64_t* __restrict_
         bool claimed;
         const uint32_t h = group_claim(g, key, claimed);
         lh[slot] = h;
-        if constexpr (MODE == kGroupCount || MODE == kGroupApply) {
+        if constexpr (MODE == kGroupCount) {
             const uint32_t total = lval[slot];
-            // kGroupApply keeps the claiming block's count as hi = count - 1: a key that occurs once in its block — nearly every key of
-            // a batch of distinct keys — leaves the zero the entry already holds, and its claim is the only access the entry costs here
-            if (claimed) { if (MODE != kGroupApply) sv_half(g, h)[1] = total; else if (total > 1) sv_half(g, h)[1] = total - 1; lbase[slot] = 0; }
+            if (claimed) { sv_half(g, h)[1] = total; lbase[slot] = 0; }
             else lbase[slot] = atomicAdd(&sv_half(g, h)[0], total) | kRankRemote;
         } else {
             // the block whose CAS created the entry parks its candidate in the hi half with a plain store; only later arrivals
@@ -580,23 +567,6 @@ __global__ __launch_bounds__(BLOCK) void group_kernel(const int64_t* __restrict_
     if (inb) {
         bs.hidx[i] = valid ? lh[slot] : kNoGroup;
         if (MODE == kGroupCount && valid) bs.rank[i] = lbase[slot] + r_local;
-        if constexpr (MODE == kGroupApply) {
-            bool sure = false;
-            if (valid) {
-                const uint32_t lb = lbase[slot], total = lval[slot];
-                const uint32_t q = (lb & kRankRemote) ? kInl + (lb & ~kRankRemote) + r_local : r_local - 1;   // rank 0 of the claimer: 0xFFFFFFFF, no store
-                if (q < ((lb & kRankRemote) ? 2 * kInl : kInl)) g.inl[(uint64_t)lh[slot] * (2 * kInl) + q] = i;
-                // this block alone shows that the group outgrows the inline list (the counts only grow): every occurrence here but the
-                // group's leader is marked as filed now, and the main pass will not even read the entry for it
-                sure = ((lb & kRankRemote) ? (lb & ~kRankRemote) + total > kInl : total > kInl + 1) && lb + r_local != 0;
-                bs.rank[i] = (lb + r_local) | (sure ? kRankFiled : 0u);
-            }
-            const uint64_t fm = __ballot(sure);   // the wave's 64 positions are two words of the map, and nobody else writes them in this kernel
-            if ((threadIdx.x & 31) == 0) {
-                const uint32_t bits = (uint32_t)(fm >> (threadIdx.x & 32));
-                if (bits) bs.filed_bits[i >> 5] = bits;
-            }
-        }
         if (!valid && !skipped && key == kReclaimed) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);  // EMPTY = padding, silent
     }
 }
@@ -1056,500 +1026,7 @@ __global__ __launch_bounds__(256) void ensure_direct_kernel(int64_t* tkeys, floa
     }
 }
 
-// ---- sparse optimizers (SPEC.md §4) ------------------------------------------------------------------------
-// Where the row of an apply position lives.  Plain tables: probe for the key.  GROUPED (mee_group_apply_*): the batch
-// "keys" are located rows already, member << 48 | slot (meepo_group.hip), and the planes come from the member's descriptor.
-struct RowPlanes { float4 *values, *s1, *s2; };
-template <bool GROUPED>
-__device__ __forceinline__ int64_t resolve_row(const int64_t* tkeys, uint64_t nb, const GroupDesc* __restrict__ desc, int64_t key,
-                                               bool active, int tile, int tl, RowPlanes& p) {
-    if constexpr (GROUPED) {
-        if (!active || key < 0) return -1;
-        const GroupDesc d = desc[(uint64_t)key >> kGroupSlotBits];
-        p.values = d.values; p.s1 = d.s1; p.s2 = d.s2;
-        return key & ((1ll << kGroupSlotBits) - 1);
-    } else {
-        bool is_new, full;
-        return tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, active, tile, tl, is_new, full);
-    }
-}
-
 __device__ __forceinline__ void group_release(const GroupTable& g, uint32_t h) { group_release_entry(g, h); }
-
-// Pass 1 over batch positions: a key that occurs once is updated right here from its own grad row (the common
-// case) and its group-table entry is returned to empty; occurrences of multi-keys are filed into their group's
-// occurrence list for pass 2.  R positions in flight per tile; the grad rows are requested before the probe so that
-// they travel beside the bucket lines.  DIM4 = dim/4 when it is 16 or 32 (rows held in registers), 0 = any dim.
-template <int KIND, int DIM4, int R, bool GROUPED = false>
-__global__ __launch_bounds__(256) void apply_single_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1,
-                                                           float4* s2, uint64_t nb, uint32_t dim4_rt,
-                                                           const int64_t* __restrict__ keys,
-                                                           const float4* __restrict__ grads, uint32_t n, GroupTable g,
-                                                           BatchScratch bs, OptArgs a, const GroupDesc* __restrict__ desc = nullptr,
-                                                           const uint32_t* __restrict__ gidx = nullptr) {
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
-    constexpr int C = DIM4 ? DIM4 / 16 : 1;
-    a.kind = KIND;  // lets the compiler drop the other optimizer's code
-    for (uint32_t base = wave * 4 * R; base < n; base += n_waves * 4 * R) {
-        int64_t key[R], slot[R];
-        uint32_t cnt[R], grow[R];   // grow = row of the grad array that belongs to the position
-        float4 gr[R][C];
-        RowPlanes pl[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t i = base + r * 4 + tile;
-            const bool inb = i < n;
-            key[r] = inb ? keys[i] : kEmpty;
-            cnt[r] = inb ? bs.pcnt[i] : 0;
-            grow[r] = (gidx && cnt[r] == 1) ? min(gidx[i], a.grad_rows - 1) : i;
-        }
-        if constexpr (DIM4 != 0) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    if (cnt[r] == 1) {  // the grad row is read exactly once: stream it past the caches
-                        const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grads) + (uint64_t)grow[r] * DIM4 + c * 16 + tl);
-                        gr[r][c] = make_float4(gv.x, gv.y, gv.z, gv.w);
-                    }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            pl[r] = RowPlanes{values, s1, s2};
-            slot[r] = resolve_row<GROUPED>(tkeys, nb, desc, key[r], cnt[r] == 1, tile, tl, pl[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t i = base + r * 4 + tile;
-            if (cnt[r] == 1) {
-                if (slot[r] >= 0) {
-                    if constexpr (DIM4 != 0) {
-#pragma unroll
-                        for (int c = 0; c < C; ++c) update_row(a, pl[r].values, pl[r].s1, pl[r].s2, (uint64_t)slot[r] * DIM4 + c * 16 + tl, gr[r][c]);
-                    } else {
-                        for (uint32_t c = tl; c < dim4; c += 16) update_row(a, pl[r].values, pl[r].s1, pl[r].s2, (uint64_t)slot[r] * dim4 + c, grads[(uint64_t)grow[r] * dim4 + c]);
-                    }
-                }
-                if (tl == 0) group_release(g, bs.hidx[i]);  // this tile is the only user of the entry
-            } else if (cnt[r] > 1 && tl == 0) {
-                bs.occ[g.soffs[bs.hidx[i]] + bs.rank[i]] = i;
-            }
-        }
-    }
-}
-
-// fp64 sum of `count` rows of an occurrence list, up to 8 rows in flight per lane.  All 16 lanes of the tile call it
-// with the same arguments (c differs per lane).
-__device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, const uint32_t* __restrict__ occ, uint32_t first,
-                                          uint32_t count, uint32_t dim4, uint32_t c, double& sx, double& sy, double& sz,
-                                          double& sw, const uint32_t* __restrict__ gidx = nullptr, uint32_t grad_rows = 0) {
-    // eight rows in flight per step.  The last (or only) step has no one-row-at-a-time tail: it reads the chunk's last row again in
-    // the lanes past the end (a valid address, so the loads stay unconditional and leave together) and adds +0.0 for them — a group
-    // of three occurrences costs one round trip for its grad rows, not three.  (The sums start at +0.0: adding +0.0 changes nothing.)
-    for (uint32_t o = 0; o < count; o += 8) {
-        uint32_t idx[8];
-        float4 gq[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) idx[q] = occ[first + min(o + q, count - 1)];
-        if (gidx) {  // indexed apply: position -> row of the grad array (e.g. the bag of a pooled lookup)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) idx[q] = min(gidx[idx[q]], grad_rows - 1);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) gq[q] = grads[(uint64_t)idx[q] * dim4 + c];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const bool live = o + q < count;
-            sx += live ? (double)gq[q].x : 0.0; sy += live ? (double)gq[q].y : 0.0; sz += live ? (double)gq[q].z : 0.0; sw += live ? (double)gq[q].w : 0.0;
-        }
-    }
-}
-
-// ---- the apply's main pass (SPEC.md §4) -----------------------------------------------------------------------------------------
-// Runs right behind group_kernel<kGroupApply> and needs nothing but what that kernel left: a position reads its key's occurrence
-// count from its entry (one 8-byte load) and then
-//   count == 1            (the bulk):  the tile updates the row from the position's own grad row and releases the entry;
-//   a group that fits its entry's inline list (hi <= kInl + 1, lo <= kInl: up to 17 occurrences): the rank-0 occurrence is the
-//                         group's leader and is only marked (a bit); the other occurrences do nothing.  apply_dups_kernel finishes
-//                         the group — a tile that led a group here would keep the three single-key tiles of its wave waiting through
-//                         four more dependent round trips, and its fp64 sums would cost every wave of this pass a quarter of its registers.
-//   larger groups         every occurrence is marked as filed (a bit; occurrences whose own block saw the group outgrow the line were
-//                         marked by group_kernel already and are skipped here without a look at the entry); the leader reserves the
-//                         group's slice of the occurrence list, one work item per kChunk occurrences and, beyond kChunk occurrences,
-//                         fp64 partial-sum rows.
-// No plan pass, no per-batch prefix sums, no atomics on the bulk path; three small kernels finish the duplicates afterwards.
-// R positions in flight per tile; the grad rows of single keys are requested before the probe.  LOCATED: `slots` holds each
-// position's slot (or -1) as mee_find_located of the same step saw it — no probe, no bucket line.
-template <int KIND, int DIM4, int R, bool LOCATED>
-__global__ __launch_bounds__(256) void apply_main_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1, float4* s2,
-                                                         uint64_t nb, uint32_t dim4_rt, const int64_t* __restrict__ keys,
-                                                         const int64_t* __restrict__ slots, const float4* __restrict__ grads,
-                                                         uint32_t n, GroupTable g, BatchScratch bs, OpCounters* op, OptArgs a,
-                                                         const uint32_t* __restrict__ gidx, uint64_t capacity, int64_t handle_tag, uint32_t* status) {
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
-    constexpr int C = DIM4 ? DIM4 / 16 : 1;
-    a.kind = KIND;  // lets the compiler drop the other optimizer's code
-    for (uint32_t base = wave * 4 * R; base < n; base += n_waves * 4 * R) {
-        int64_t key[R], slot[R];
-        uint32_t h[R], rk[R], cnt[R], chi[R], grow[R];
-        bool single[R], fits[R];
-        float4 gr[R][C];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t i = base + r * 4 + tile;
-            const bool inb = i < n;
-            h[r] = inb ? bs.hidx[i] : kNoGroup;
-            rk[r] = inb ? bs.rank[i] : 0u;
-            key[r] = (!LOCATED && inb) ? keys[i] : kEmpty;
-            slot[r] = -1;
-            if constexpr (LOCATED) {
-                bool stale = false;
-                if (inb) slot[r] = handle_slot(slots[i], handle_tag, capacity, stale);
-                if (stale && tl == 0) atomicOr(status, (uint32_t)MEE_STATUS_STALE_HANDLE);   // rare: the caller kept handles across a remove / clear / reserve
-            }
-            grow[r] = i;
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            uint32_t lo = 0, hi = 0;
-            if (rk[r] & kRankFiled) h[r] = kNoGroup;   // group_kernel has marked this occurrence as filed already: nothing to do here, not even the entry
-            if (h[r] != kNoGroup) cnt_load(g, h[r], lo, hi);
-            cnt[r] = lo + hi;
-            chi[r] = hi;
-            fits[r] = hi <= kInl + 1 && lo <= kInl;   // the whole group sits in the entry's inline list
-            single[r] = cnt[r] == 1;
-            if (gidx && single[r]) grow[r] = min(gidx[base + r * 4 + tile], a.grad_rows - 1);
-        }
-        if constexpr (DIM4 != 0) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    if (single[r]) {  // the grad row is read exactly once: stream it past the caches
-                        const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grads) + (uint64_t)grow[r] * DIM4 + c * 16 + tl);
-                        gr[r][c] = make_float4(gv.x, gv.y, gv.z, gv.w);
-                    }
-        }
-        // duplicates (one lane per tile acts): the leader of an inline group is marked; larger groups -> rank, mark, reservation.
-        // The marks are bits (one per batch position, two maps): a wave's four positions share a word, so ONE atomicOr per wave and map
-        // sets them — the 32 KB of a 256K-key batch's maps are all apply_dups_kernel reads to find its work (and it clears them as it goes).
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t i = base + r * 4 + tile;
-            bool lead = false, filed = false;
-            if (tl == 0 && i < n && cnt[r] > 1) {
-                const bool leader = rk[r] == 0;   // local rank 0 in the claiming block (ranks of other blocks carry kRankRemote): one per group
-                if (fits[r]) lead = leader;
-                else {
-                    filed = true;   // (apply_dups_kernel turns the rank into the arrival order over the whole batch)
-                    if (leader) {   // at most n / (kInl + 1) such groups per batch
-                        const uint32_t rows = (cnt[r] + kChunk - 1) / kChunk;
-                        // ONE atomic reserves the slice of the occurrence list (low half) and the work items (high half): the counters of
-                        // a batch with thousands of such groups are one hot line, and every atomic on it is served in turn
-                        const unsigned long long ow = atomicAdd(&op->occ_work, ((unsigned long long)rows << 32) | cnt[r]);
-                        g.soffs[h[r]] = (uint32_t)ow;
-                        uint32_t w0 = (uint32_t)(ow >> 32);           // rows <= cnt: the work items of a batch add up to at most n
-                        if (w0 + rows > n) w0 = 0;                    // (only keeps a violated invariant from writing out of bounds)
-                        g.sgrp[h[r]] = w0;
-                        for (uint32_t c = 0; c < rows; ++c) bs.work[w0 + c] = h[r];   // work item -> its group
-                        if (cnt[r] > kChunk) {   // more than one chunk: fp64 partial-sum rows + a place in apply_big_kernel's list
-                            uint32_t p0 = atomicAdd(&op->n_part, rows);   // sum of ceil(cnt / kChunk) over such groups <= n / kChunk + n / (kChunk + 1) = max_part: fits
-                            if (p0 + rows > bs.max_part) p0 = 0;
-                            g.sbig[h[r]] = p0;
-                            bs.bigh[atomicAdd(&op->n_big, 1u)] = h[r];
-                        }
-                    }
-                }
-            }
-            const uint64_t lm = __ballot(lead), fm = __ballot(filed);   // bits 0, 16, 32, 48: the wave's four tiles
-            if ((lm | fm) && lane == 0) {
-                const uint32_t p0 = base + r * 4, sh = p0 & 31;   // p0 is a multiple of 4: the four bits stay inside one word
-                const uint32_t lbits = (uint32_t)(lm & 1) | (uint32_t)((lm >> 16) & 1) << 1 | (uint32_t)((lm >> 32) & 1) << 2 | (uint32_t)((lm >> 48) & 1) << 3;
-                const uint32_t fbits = (uint32_t)(fm & 1) | (uint32_t)((fm >> 16) & 1) << 1 | (uint32_t)((fm >> 32) & 1) << 2 | (uint32_t)((fm >> 48) & 1) << 3;
-                if (lbits) atomicOr(&bs.lead_bits[p0 >> 5], lbits << sh);
-                if (fbits) atomicOr(&bs.filed_bits[p0 >> 5], fbits << sh);
-            }
-        }
-        if constexpr (!LOCATED) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                bool is_new, full;
-                slot[r] = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key[r], single[r], tile, tl, is_new, full);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool ok = slot[r] >= 0;
-            if (single[r]) {
-                if (ok) {
-                    if constexpr (DIM4 != 0) {
-#pragma unroll
-                        for (int c = 0; c < C; ++c) update_row(a, values, s1, s2, (uint64_t)slot[r] * DIM4 + c * 16 + tl, gr[r][c]);
-                    } else {
-                        for (uint32_t c = tl; c < dim4; c += 16) update_row(a, values, s1, s2, (uint64_t)slot[r] * dim4 + c, grads[(uint64_t)grow[r] * dim4 + c]);
-                    }
-                }
-                if (tl == 0) group_release(g, h[r]);  // this tile is the only user of the entry
-            }
-        }
-    }
-}
-
-// Duplicates, first kernel after the main pass; one lane per batch position reads the position's two mark bits (and the wave clears
-// the words it has read: the maps are all-zero again when this kernel ends).
-//   filed: an occurrence of a filed group stores its position at its rank in the group's slice of the occurrence list;
-//   lead:  the leader of a group that sits in its entry's inline list: a tile (the wave's four tiles take the wave's
-//                      leaders four at a time) reads the other positions with ONE 64-byte load, sums the grad rows in fp64, locates the
-//                      row (or takes the forward's slot), updates once and releases the entry.
-__global__ __launch_bounds__(256) void apply_dups_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1, float4* s2, uint64_t nb,
-                                                         uint32_t dim4, const int64_t* __restrict__ keys, const int64_t* __restrict__ slots,
-                                                         const float4* __restrict__ grads, uint32_t n, GroupTable g, BatchScratch bs,
-                                                         OptArgs a, const uint32_t* __restrict__ gidx, uint64_t capacity, int64_t handle_tag) {
-    __shared__ uint32_t lpos[16][2 * kInl + 2];   // the positions of the group a tile finishes (one row per tile of the block)
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const int bt = (threadIdx.x >> 6) * 4 + tile;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t base = wave * 64; base < n; base += n_waves * 64) {   // wave-uniform
-        const uint32_t i = base + lane, word = (base >> 5) + (lane >> 5);   // base is a multiple of 64: two words of each map per wave
-        const bool in_map = (uint64_t)word * 32 < n;
-        const uint32_t fw = in_map ? bs.filed_bits[word] : 0u, lw = in_map ? bs.lead_bits[word] : 0u;
-        if ((lane & 31) == 0) {
-            if (fw) bs.filed_bits[word] = 0u;
-            if (lw) bs.lead_bits[word] = 0u;
-        }
-        // everything a marked position needs that does not depend on its entry is requested together with the marks, one coalesced load
-        // per array for the whole wave (4 MB more traffic per 256K positions, one dependent round trip less)
-        const uint32_t my_h = i < n ? bs.hidx[i] : 0u;
-        const uint32_t my_rank = i < n ? bs.rank[i] : 0u;
-        const int64_t my_key = i < n ? (slots ? slots[i] : keys[i]) : kEmpty;   // the forward's slot when the caller passed them
-        const bool is_filed = (fw >> (lane & 31)) & 1u, is_lead = (lw >> (lane & 31)) & 1u;
-        if (is_filed) {   // arrival order over the whole batch: the claiming block's occurrences first, then the others in the order of their atomics
-            uint32_t lo, hi;
-            cnt_load(g, my_h, lo, hi);
-            const uint32_t at = g.soffs[my_h] + (my_rank & ~(kRankRemote | kRankFiled)) + ((my_rank & kRankRemote) ? hi : 0u);
-            if (at < n) bs.occ[at] = i;   // always true (the slices add up to at most n); a violated invariant must not write out of bounds
-        }
-        uint64_t leads = __ballot(is_lead);
-        while (leads) {   // wave-uniform: tile t takes the t-th leader still waiting
-            uint64_t m = leads;
-            int src = -1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int b = m ? __builtin_ctzll(m) : -1;
-                if (q == tile) src = b;
-                if (m) m &= m - 1;
-            }
-            leads = m;
-            const bool act = src >= 0;
-            const uint32_t p = base + (uint32_t)(act ? src : 0);
-            const uint32_t h = __shfl(my_h, act ? src : 0);
-            const int64_t ks = (int64_t)(((unsigned long long)(uint32_t)__shfl((int)((unsigned long long)my_key >> 32), act ? src : 0) << 32) |
-                                         (uint32_t)__shfl((int)(uint32_t)my_key, act ? src : 0));
-            uint32_t lo = 0, hi = 0;
-            if (act) cnt_load(g, h, lo, hi);
-            const uint32_t other = act ? g.inl[(uint64_t)h * (2 * kInl) + tl] : 0u;   // one 64-byte line for the tile
-            int64_t slot;
-            if (slots) { bool stale; slot = act ? handle_slot(ks, handle_tag, capacity, stale) : -1; }   // (a stale handle was reported by the main pass)
-            else {
-                bool is_new, full;
-                slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, act ? ks : kEmpty, act, tile, tl, is_new, full);
-            }
-            if (act) {
-                if (tl == 0) lpos[bt][0] = p;   // the leader's own position, then the claiming block's others, then the other blocks'
-                if (tl < (int)kInl ? (uint32_t)tl + 1 < hi : (uint32_t)tl - kInl < lo) lpos[bt][tl < (int)kInl ? 1 + tl : hi + (tl - kInl)] = other;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the tile's LDS writes before its reads (same wave: in order)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (act) {
-                if (slot >= 0)
-                    for (uint32_t c = tl; c < dim4; c += 16) {
-                        const uint64_t o = (uint64_t)slot * dim4 + c;   // the row is requested before the grad rows, not after their sum
-                        float4 w = values[o], x1 = s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (a.kind == MEE_OPT_ADAM) x2 = s2[o];
-                        double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-                        chunk_sum(grads, lpos[bt], 0, lo + hi, dim4, c, sx, sy, sz, sw, gidx, a.grad_rows);
-                        opt_update4(a, w, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
-                        values[o] = w; s1[o] = x1;
-                        if (a.kind == MEE_OPT_ADAM) s2[o] = x2;
-                    }
-                if (tl == 0) group_release(g, h);
-            }
-        }
-    }
-}
-
-// Pass 2 over the work list (chunk leaders: the occurrences with rank 0, kChunk, 2*kChunk, ... of each multi-key).
-// A tile sums its chunk of the group's occurrence list in fp64.  Groups of <= kChunk occurrences are finished here
-// (one update, entry released); a chunk of a larger group stores its fp64 sums as one row of the group's partial-sum
-// block (plain stores: f64 atomics on a hot key's row serialise on four L2 lines) and apply_big_kernel finishes it.
-template <bool GROUPED = false>
-__global__ __launch_bounds__(256) void apply_chunk_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1,
-                                                          float4* s2, uint64_t nb, uint32_t dim4,
-                                                          const int64_t* __restrict__ keys,
-                                                          const float4* __restrict__ grads, GroupTable g, BatchScratch bs,
-                                                          const OpCounters* op, OptArgs a, const GroupDesc* __restrict__ desc = nullptr,
-                                                          const uint32_t* __restrict__ gidx = nullptr) {
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t n_work = op->n_work;
-    for (uint32_t base = wave * 4; base < n_work; base += n_waves * 4) {
-        const uint32_t w = base + tile;
-        const bool inb = w < n_work;
-        const uint32_t i = inb ? bs.work[w] : 0;
-        const uint32_t cnt = inb ? bs.pcnt[i] : 0;
-        const uint32_t r = inb ? bs.rank[i] : 0;
-        const bool small = inb && cnt <= kChunk;  // then r == 0
-        const int64_t key = small ? keys[i] : kEmpty;
-        RowPlanes pl{values, s1, s2};
-        const int64_t slot = resolve_row<GROUPED>(tkeys, nb, desc, key, small, tile, tl, pl);
-        if (!inb) continue;
-        const uint32_t h = bs.hidx[i];
-        const uint32_t first = g.soffs[h] + r;
-        const uint32_t count = min(kChunk, cnt - r);
-        const uint32_t part = small ? 0 : g.sbig[h] + r / kChunk;  // this chunk's row in the group's partial-sum block
-        for (uint32_t c = tl; c < dim4; c += 16) {
-            double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-            chunk_sum(grads, bs.occ, first, count, dim4, c, sx, sy, sz, sw, gidx, a.grad_rows);
-            if (small) {
-                if (slot >= 0) update_row(a, pl.values, pl.s1, pl.s2, (uint64_t)slot * dim4 + c, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
-            } else {
-                double* dst = bs.gacc + ((uint64_t)part * dim4 + c) * 4;
-                dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = sw;
-            }
-        }
-        if (small && tl == 0) group_release(g, h);
-    }
-}
-
-// filed groups, second kernel: one tile per work item w (= one chunk of kChunk occurrences of one group): work[w] names the group, the
-// chunk index is w - sgrp[group].  A group of one chunk is finished here (locate the key's row, one update, entry released); a chunk
-// of a larger group stores its fp64 sums as one row of the group's partial-sum block (plain stores: f64 atomics on a hot key's row
-// would serialise) and apply_big_kernel finishes the group.
-__global__ __launch_bounds__(256) void apply_filed_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1, float4* s2, uint64_t nb,
-                                                          uint32_t dim4, const float4* __restrict__ grads, uint32_t n, GroupTable g, BatchScratch bs,
-                                                          const OpCounters* op, OptArgs a, const uint32_t* __restrict__ gidx) {
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t n_work = min((uint32_t)(op->occ_work >> 32), n);
-    for (uint32_t base = wave * 4; base < n_work; base += n_waves * 4) {   // wave-uniform trip count
-        const uint32_t w = base + tile;
-        const bool inb = w < n_work;
-        const uint32_t h = inb ? bs.work[w] : 0;
-        uint32_t lo = 0, hi = 0;
-        if (inb) cnt_load(g, h, lo, hi);
-        const uint32_t cnt = lo + hi;
-        const bool whole = inb && cnt <= kChunk;   // the group's only chunk
-        const int64_t key = whole ? (int64_t)(g.ent[2 * (uint64_t)h] ^ kBias) : kEmpty;
-        bool is_new, full;
-        const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, whole, tile, tl, is_new, full);
-        if (!inb) continue;
-        const uint32_t c_idx = w - g.sgrp[h];
-        const uint32_t first = g.soffs[h] + c_idx * kChunk, count = min(kChunk, cnt - c_idx * kChunk);
-        // the chunk's (at most 32) positions: two coalesced loads for the whole tile, handed round by shuffle below — not a dependent
-        // index load in front of every eight grad rows
-        static_assert(kChunk == 32, "apply_filed_kernel: two positions per lane");
-        uint32_t pa = bs.occ[first + min((uint32_t)tl, count - 1)], pb = bs.occ[first + min(16u + (uint32_t)tl, count - 1)];
-        if (gidx) { pa = min(gidx[pa], a.grad_rows - 1); pb = min(gidx[pb], a.grad_rows - 1); }   // indexed apply: position -> row of the grad array
-        for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {   // same trip count in every lane: the shuffles need their source lanes
-            const uint32_t c = c0 + tl;
-            const bool live = c < dim4;
-            const uint64_t o_row = whole && slot >= 0 && live ? (uint64_t)slot * dim4 + c : 0;
-            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f), x1 = wv, x2 = wv;
-            if (whole && slot >= 0 && live) {   // the row is requested before the grad rows, not after their sum
-                wv = values[o_row]; x1 = s1[o_row];
-                if (a.kind == MEE_OPT_ADAM) x2 = s2[o_row];
-            }
-            double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-            for (uint32_t o = 0; o < count; o += 8) {
-                float4 gq[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const uint32_t row = __shfl(o < 16 ? pa : pb, tile * 16 + (int)((o + q) & 15));   // past the end: the chunk's last row again
-                    gq[q] = grads[(uint64_t)row * dim4 + (live ? c : 0)];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const bool on = o + q < count;
-                    sx += on ? (double)gq[q].x : 0.0; sy += on ? (double)gq[q].y : 0.0; sz += on ? (double)gq[q].z : 0.0; sw += on ? (double)gq[q].w : 0.0;
-                }
-            }
-            if (!live) continue;
-            if (whole) {
-                if (slot >= 0) {
-                    opt_update4(a, wv, x1, x2, make_float4((float)sx, (float)sy, (float)sz, (float)sw));
-                    values[o_row] = wv; s1[o_row] = x1;
-                    if (a.kind == MEE_OPT_ADAM) s2[o_row] = x2;
-                }
-            } else {
-                double* dst = bs.gacc + ((uint64_t)(g.sbig[h] + c_idx) * dim4 + c) * 4;
-                dst[0] = sx; dst[1] = sy; dst[2] = sz; dst[3] = sw;
-            }
-        }
-        if (whole && tl == 0) group_release(g, h);
-    }
-}
-
-// Pass 3, one 256-thread block per group with more than kChunk occurrences: the 16 tiles sum the group's partial-sum
-// rows (tile t takes rows t, t+16, ...; 4 rows in flight), the tile totals are combined through LDS in fixed order
-// (so the result does not depend on scheduling), then one rounding, one update, and the entry is released.
-template <bool GROUPED = false>
-__global__ __launch_bounds__(256) void apply_big_kernel(const int64_t* __restrict__ tkeys, float4* values, float4* s1,
-                                                        float4* s2, uint64_t nb, uint32_t dim4, GroupTable g, BatchScratch bs,
-                                                        const OpCounters* op, OptArgs a, const GroupDesc* __restrict__ desc = nullptr) {
-    __shared__ double lsum[16][16][4];
-    __shared__ long long lslot;
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const int bt = (threadIdx.x >> 6) * 4 + tile;  // tile index inside the block, 0..15
-    const uint32_t n_big = op->n_big;
-    for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {  // block-uniform
-        const uint32_t h = bs.bigh[b];
-        uint32_t cnt_lo, cnt_hi;
-        if (GROUPED) sv_load(g, h, cnt_lo, cnt_hi); else cnt_load(g, h, cnt_lo, cnt_hi);   // the plan-free flow's entries (kGroupApply) hold hi - 1
-        const uint32_t cnt = cnt_lo + cnt_hi;
-        const uint32_t n_rows = (cnt + kChunk - 1) / kChunk, row0 = g.sbig[h];
-        const int64_t key = (int64_t)(g.ent[2 * (uint64_t)h] ^ kBias);
-        RowPlanes pl{values, s1, s2};   // GROUPED: every thread decodes the same (member, slot); else tile 0 probes
-        const int64_t slot = resolve_row<GROUPED>(tkeys, nb, desc, key, GROUPED || threadIdx.x < 16, tile, tl, pl);
-        if (threadIdx.x == 0) lslot = slot;
-        for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {  // block-uniform trip count: there are barriers inside
-            const uint32_t c = c0 + tl;
-            const bool live = c < dim4;
-            double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-            for (uint32_t rr = bt; live && rr < n_rows; rr += 64) {
-                double v[4][4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t row = rr + q * 16;
-                    const double* src = bs.gacc + ((uint64_t)(row0 + row) * dim4 + c) * 4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[q][e] = row < n_rows ? src[e] : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { sx += v[q][0]; sy += v[q][1]; sz += v[q][2]; sw += v[q][3]; }
-            }
-            lsum[bt][tl][0] = sx; lsum[bt][tl][1] = sy; lsum[bt][tl][2] = sz; lsum[bt][tl][3] = sw;
-            __syncthreads();
-            if (bt == 0) {
-                double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) { t0 += lsum[q][tl][0]; t1 += lsum[q][tl][1]; t2 += lsum[q][tl][2]; t3 += lsum[q][tl][3]; }
-                if (live && lslot >= 0) update_row(a, pl.values, pl.s1, pl.s2, (uint64_t)lslot * dim4 + c, make_float4((float)t0, (float)t1, (float)t2, (float)t3));
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) group_release(g, h);
-        __syncthreads();
-    }
-}
 
 // ---- standalone duplicate-key reduction (SPEC.md §4) -------------------------------------------------------
 __global__ __launch_bounds__(256) void dedup_fill_kernel(uint32_t n, GroupTable g, BatchScratch bs, int64_t* inverse, int64_t miss = -1) {
@@ -1572,6 +1049,26 @@ __global__ __launch_bounds__(256) void dedup_keys_emit_kernel(uint32_t n, GroupT
             group_release(g, h);
         } else {
             uniq_out[u] = kEmpty;
+        }
+    }
+}
+
+// fp64 sum of `count` rows of an occurrence list, up to 8 rows in flight per lane.  All 16 lanes of the tile call it with the same
+// arguments (c differs per lane).  The last (or only) step reads the list's last row again in the lanes past the end (a valid
+// address, so the loads stay unconditional and leave together) and adds +0.0 for them.
+__device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, const uint32_t* __restrict__ occ, uint32_t first,
+                                          uint32_t count, uint32_t dim4, uint32_t c, double& sx, double& sy, double& sz, double& sw) {
+    for (uint32_t o = 0; o < count; o += 8) {
+        uint32_t idx[8];
+        float4 gq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) idx[q] = occ[first + min(o + q, count - 1)];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gq[q] = grads[(uint64_t)idx[q] * dim4 + c];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool live = o + q < count;
+            sx += live ? (double)gq[q].x : 0.0; sy += live ? (double)gq[q].y : 0.0; sz += live ? (double)gq[q].z : 0.0; sw += live ? (double)gq[q].w : 0.0;
         }
     }
 }
@@ -1853,8 +1350,8 @@ int mee_table_destroy(mee_table* t) {
     float* planes[] = {t->values, t->s1, t->s2};
     for (float* p : planes)
         if (p) { if (t->value_memory == MEE_MEM_HOST_PINNED) (void)hipHostFree(p); else (void)hipFree(p); }
-    void* dev[] = {t->keys, t->hits, t->sketch, t->g.ent, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres, t->g.inl,
-                   t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.lead_bits, t->bs.filed_bits, t->bs.work, t->bs.fmask, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
+    void* dev[] = {t->keys, t->hits, t->sketch, t->g.ent, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
+                   t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.work, t->bs.fmask, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
     for (void* p : dev) if (p) (void)hipFree(p);
     bucket_scratch_free(t);
     if (t->h_ctr) (void)hipHostFree(t->h_ctr);
@@ -1904,7 +1401,6 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     t->S = S; t->g.smask = S - 1;
     t->find_rounds = 0;  // auto: 2 for dim 64, 1 for wider rows
     t->find_grid_cap = 0;
-    t->apply_rounds = 0;
     t->find_nt = -1;  // auto
 
     const uint64_t plane = t->capacity * (uint64_t)t->dim * sizeof(float);
@@ -1944,9 +1440,8 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     if (t->optimizer == MEE_OPT_ADAM) ALLOC_PLANE(t->s2);
 #undef ALLOC_PLANE
     ALLOC(t->g.ent, S * 16); ALLOC(t->g.soffs, S * 4); ALLOC(t->g.sgrp, S * 4);
-    ALLOC(t->g.sbig, S * 4); ALLOC(t->g.sres, S * 8); ALLOC(t->g.inl, S * 2 * kInl * 4);
+    ALLOC(t->g.sbig, S * 4); ALLOC(t->g.sres, S * 8);
     ALLOC(t->bs.hidx, mb * 4); ALLOC(t->bs.rank, mb * 4); ALLOC(t->bs.pcnt, mb * 4); ALLOC(t->bs.occ, mb * 4); ALLOC(t->bs.uniq_h, mb * 4);
-    ALLOC(t->bs.lead_bits, (mb / 32 + 16) * 4); ALLOC(t->bs.filed_bits, (mb / 32 + 16) * 4);
     ALLOC(t->bs.work, mb * 4); ALLOC(t->bs.fmask, mb);
     t->max_big = mb / kChunk + 1;  // a batch of n keys has at most n / (kChunk + 1) groups larger than kChunk
     // ... and those groups need ceil(cnt / kChunk) partial-sum rows each: at most n / kChunk + n / (kChunk + 1) rows in all
@@ -1959,9 +1454,8 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     if (t->optimizer != MEE_OPT_NONE) ALLOC(t->bs.gacc, t->max_part * (uint64_t)t->dim * sizeof(double));
     ALLOC(t->ctr, sizeof(Counters)); ALLOC(t->op, sizeof(OpCounters));
 #undef ALLOC
-    t->workspace_bytes = S * (36 + 2 * kInl * 4) + mb * 25 + t->max_big * 4 + (t->bs.gacc ? t->max_part * (uint64_t)t->dim * sizeof(double) : 0) +
+    t->workspace_bytes = S * 36 + mb * 25 + t->max_big * 4 + (t->bs.gacc ? t->max_part * (uint64_t)t->dim * sizeof(double) : 0) +
                          sizeof(Counters) + sizeof(OpCounters);
-    t->apply_path = -1;
     t->dedup_path = -1;
     if ((rc = bucket_scratch_alloc(t)) != MEE_OK) goto bad;   // the bucketed machinery's scratch: partition (every table), pending records (tables with an optimizer); adds to workspace_bytes
     if (hipHostMalloc((void**)&t->h_ctr, sizeof(Counters)) != hipSuccess || hipHostMalloc((void**)&t->h_op, sizeof(OpCounters)) != hipSuccess) {
@@ -1976,8 +1470,6 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
         if (e == hipSuccess && t->sketch) e = hipMemsetAsync(t->sketch, 0, 3ull * sizeof(uint32_t) << t->sketch_log2w, 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.ent, 0, S * 16, 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->g.sres, 0, S * 8, 0);
-        if (e == hipSuccess) e = hipMemsetAsync(t->bs.lead_bits, 0, (mb / 32 + 16) * 4, 0);
-        if (e == hipSuccess) e = hipMemsetAsync(t->bs.filed_bits, 0, (mb / 32 + 16) * 4, 0);
         if (e == hipSuccess && t->bs.gacc) e = hipMemsetAsync(t->bs.gacc, 0, t->max_part * (uint64_t)t->dim * sizeof(double), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->ctr, 0, sizeof(Counters), 0);
         if (e == hipSuccess) e = hipMemsetAsync(t->op, 0, sizeof(OpCounters), 0);
@@ -2006,13 +1498,12 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     else if (!strcmp(name, "find_block")) t->find_block = value;
     else if (!strcmp(name, "prepare_debug")) t->prepare_debug = value;
     else if (!strcmp(name, "find_nt")) t->find_nt = value;
-    else if (!strcmp(name, "apply_rounds")) t->apply_rounds = value;
-    else if (!strcmp(name, "apply_path")) t->apply_path = value;
     else if (!strcmp(name, "apply_spare_blocks")) t->bk.spare_blocks = value > 0 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_bucket_max")) t->bk.bucket_max = value > 0 && value <= 352 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_skew_adapt")) t->bk.skew_adapt = value != 0;
     else if (!strcmp(name, "apply_kernel")) t->bk.kernel_choice = value < 0 ? -1 : value != 0;
     else if (!strcmp(name, "dedup_path")) t->dedup_path = value;
+    else if (!strcmp(name, "apply_rounds") || !strcmp(name, "apply_path")) (void)value;   // retired in round 4 with the group-table apply: accepted, ignored
     else if (!strcmp(name, "apply_overlap")) (void)value;   // retired in round 2 (a side stream for the duplicate path lost to its fork/join gaps): accepted, ignored
     else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);
     return MEE_OK;
@@ -2494,24 +1985,10 @@ int mee_clear_status(mee_table* t, void* stream) {
 }
 
 // group the batch's keys and plan the duplicate reduction (everything that does not need the grads)
-static int apply_prepare_launch(mee_table* t, const int64_t* d_keys, uint32_t nn, hipStream_t st) {
-    group_kernel<kGroupCount, kApplyGroupBlock><<<grid_for(nn, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op);
-    group_plan_kernel<false><<<grid_for(nn, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
-    MEE_HIP(hipGetLastError());
-    return MEE_OK;
-}
-
-// Which apply a batch of n keys takes: the bucketed one (meepo_apply.hip: partition by hash bucket, one block-local dedup + update kernel)
-// unless the caller's knob says otherwise or the batch is beyond what its partition handles well (then: the group-table apply below).
-static bool use_bucketed_apply(const mee_table* t, size_t n) {
-    if (t->optimizer == MEE_OPT_NONE || !t->bk.pkey || n > t->bk.fast_max) return false;
-    return t->apply_path != 0;
-}
-
-// One sparse-optimizer step (group-table path): group_kernel (occurrence counts + inline position lists; skipped after mee_apply_prepare) ->
-// apply_main_kernel (every key that occurs once; duplicates are marked) -> three small kernels for the duplicates (groups that fit
-// their entry's inline list are finished by the first, which also files the occurrences of larger groups; fp64 chunk sums; tree +
-// update).  `d_slots` (nullable): the slot of every position as mee_find_located of the same step reported it.
+// One sparse-optimizer step: the bucketed apply (meepo_apply.hip) — partition by hash bucket (skipped after mee_apply_prepare / a training
+// forward that carried it), then ONE kernel of block-local LDS dedup + update.  (Rounds 1-3 kept a second implementation beside it, a global
+// group table with five launches per step; it is gone: batches of any size up to max_batch take this path.)
+// `d_slots` (nullable): the slot of every position as mee_find_located of the same step reported it.
 static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, const OptArgs& a, void* stream,
                         const char* name, const uint32_t* d_gidx = nullptr, const int64_t* d_slots = nullptr) {
     if (!t || (n && (!d_keys || !d_grads))) return fail(MEE_ERR_INVALID_ARG, "%s: null argument", name);
@@ -2521,45 +1998,12 @@ static int apply_common(mee_table* t, const int64_t* d_keys, const float* d_grad
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
     const uint32_t nn = (uint32_t)n;
-    bool bucketed = use_bucketed_apply(t, n);
     if (t->prepared_n) {  // the grad-independent half was done ahead of time (mee_apply_prepare), possibly on another stream
         if (t->prepared_n != n || t->prepared_keys != d_keys)
             return fail(MEE_ERR_INVALID_ARG, "%s: keys/n differ from the pending mee_apply_prepare", name);
-        bucketed = t->prepared_path == 1;
-        t->prepared_n = 0; t->prepared_keys = nullptr; t->prepared_path = 0;
-    } else if (bucketed) {
-        if (int rc = bucket_apply_prepare(t, d_keys, nn, st)) return rc;
-    } else {
-        next_epoch(t, st);
-        group_kernel<kGroupApply, kApplyGroupBlock><<<grid_for(nn, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
-    }
-    if (bucketed) return bucket_apply_launch(t, d_grads, nn, a, d_gidx, d_slots, st);
-    {
-        const int R = t->apply_rounds > 0 ? t->apply_rounds : 1;   // one position per tile: more waves per SIMD beat more loads per wave here
-        const unsigned gs = grid_for(n, 16u * (R >= 2 ? 2u : 1u), 1u << 16);
-#define MAIN(K, D4, RR, LOC) apply_main_kernel<K, D4, RR, LOC><<<gs, 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, \
-                                                                                  d_keys, d_slots, (const float4*)d_grads, nn, t->g, t->bs, t->op, a, d_gidx, t->capacity, handle_tag_of(t), &t->ctr->status)
-#define MAIN_R(K, D4) do { if (d_slots) { if (R >= 2) MAIN(K, D4, 2, true); else MAIN(K, D4, 1, true); } \
-                           else { if (R >= 2) MAIN(K, D4, 2, false); else MAIN(K, D4, 1, false); } } while (0)
-#define MAIN_D(K) do { if (t->dim4 == 16) MAIN_R(K, 16); else if (t->dim4 == 32) MAIN_R(K, 32); else MAIN_R(K, 0); } while (0)
-        if (a.kind == MEE_OPT_ADAGRAD) MAIN_D(MEE_OPT_ADAGRAD); else MAIN_D(MEE_OPT_ADAM);
-#undef MAIN_D
-#undef MAIN_R
-#undef MAIN
-    }
-    // duplicates only (device-side lengths: fixed small grids that loop; on a batch of distinct keys the first reads 32 KB of marks
-    // per 256K positions and all three leave).  Tried and dropped: the three as ONE launch with grid barriers between the steps (3.5 us
-    // less without duplicates, 33 us more on a Zipf(1.05) batch); the main pass requesting grad rows / bucket lines before a position's count is known (no faster: the pass is
-    // bound by bytes, the extra registers cost occupancy); the grouping folded into the forward find (its claim atomics do not overlap
-    // with the row traffic: same total).
-    apply_dups_kernel<<<grid_for(nn, 256, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4, d_keys, d_slots,
-                                                             (const float4*)d_grads, nn, t->g, t->bs, a, d_gidx, t->capacity, handle_tag_of(t));
-    apply_filed_kernel<<<grid_for(n / (kInl + 1) + 1, 16, 1024), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb, t->dim4,
-                                                                              (const float4*)d_grads, nn, t->g, t->bs, t->op, a, d_gidx);
-    apply_big_kernel<false><<<grid_for(n / kChunk + 1, 1, 256), 256, 0, st>>>(t->keys, (float4*)t->values, (float4*)t->s1, (float4*)t->s2, t->nb,
-                                                                      t->dim4, t->g, t->bs, t->op, a);
-    MEE_HIP(hipGetLastError());
-    return MEE_OK;
+        t->prepared_n = 0; t->prepared_keys = nullptr;
+    } else if (int rc = bucket_apply_prepare(t, d_keys, nn, st)) return rc;
+    return bucket_apply_launch(t, d_grads, nn, a, d_gidx, d_slots, st);
 }
 
 static OptArgs adam_args(float lr, float beta1, float beta2, float eps, uint64_t step);
@@ -2590,22 +2034,8 @@ static int group_apply_common(mee_group* g, const int64_t* d_keys, const uint64_
     // the located rows are perfect keys (member << 48 | slot; absent positions EMPTY): the bucketed apply takes them as the batch's keys AND as
     // its slot handles — partition, then one dedup + update kernel whose work items fetch their member's planes from the descriptors (r1-r2: a
     // plan pass over a group table + three kernels; 5 launches, 26 tables x 8192 keys 158 us)
-    if (use_bucketed_apply(t, n) && !t->prepared_n) {
-        if (int rc = bucket_apply_prepare(t, gslot, nn, st)) return rc;
-        return bucket_apply_launch(t, d_grads, nn, a, d_gidx, gslot, st, g->d_desc, g->n_tables);
-    }
-    if (int rc = apply_prepare_launch(t, gslot, nn, st)) return rc;
-    const unsigned gs = grid_for(n, 32, 1u << 16);
-#define GSINGLE(K, D4) apply_single_kernel<K, D4, 2, true><<<gs, 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, gslot, (const float4*)d_grads, nn, t->g, t->bs, a, g->d_desc, d_gidx)
-#define GSINGLE_D(K) do { if (g->dim4 == 16) GSINGLE(K, 16); else if (g->dim4 == 32) GSINGLE(K, 32); else GSINGLE(K, 0); } while (0)
-    if (a.kind == MEE_OPT_ADAGRAD) GSINGLE_D(MEE_OPT_ADAGRAD); else GSINGLE_D(MEE_OPT_ADAM);
-#undef GSINGLE_D
-#undef GSINGLE
-    apply_chunk_kernel<true><<<grid_for(n, 16, 2048), 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, gslot, (const float4*)d_grads,
-                                                                  t->g, t->bs, t->op, a, g->d_desc, d_gidx);
-    apply_big_kernel<true><<<grid_for(n / kChunk + 1, 1, 1024), 256, 0, st>>>(nullptr, nullptr, nullptr, nullptr, 0, g->dim4, t->g, t->bs, t->op, a, g->d_desc);
-    MEE_HIP(hipGetLastError());
-    return MEE_OK;
+    if (int rc = bucket_apply_prepare(t, gslot, nn, st)) return rc;
+    return bucket_apply_launch(t, d_grads, nn, a, d_gidx, gslot, st, g->d_desc, g->n_tables);
 }
 
 int mee_group_apply_adagrad(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr,
@@ -2673,32 +2103,19 @@ int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* strea
     if (n > t->max_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_apply_prepare: n=%zu exceeds config.max_batch=%llu", n, (unsigned long long)t->max_batch);
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
-    if (use_bucketed_apply(t, n)) {   // the partition half of the bucketed apply: positions and keys in bucket order, the work-unit list
-        if (int rc = bucket_apply_prepare(t, d_keys, (uint32_t)n, as_stream(stream))) return rc;
-        t->prepared_path = 1;
-    } else {
-        next_epoch(t, as_stream(stream));
-        group_kernel<kGroupApply, kApplyGroupBlock><<<grid_for(n, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, as_stream(stream)>>>(d_keys, (uint32_t)n, t->g, t->bs, t->ctr, nullptr, t->op, t->epoch);
-        MEE_HIP(hipGetLastError());
-        t->prepared_path = 2;
-    }
+    if (int rc = bucket_apply_prepare(t, d_keys, (uint32_t)n, as_stream(stream))) return rc;   // the partition half of the apply: positions and keys in bucket order
     t->prepared_n = n; t->prepared_keys = d_keys; t->prepared_by_forward = false;
     return MEE_OK;
 }
 
 // The training forward: mee_find_located whose launch also carries mee_apply_prepare for the SAME keys (the partition half of the bucketed
-// apply, run by the launch's first blocks beside the row gather).  Falls back to the two separate launches when the batch is not one the
-// bucketed apply takes (table without optimizer: plain mee_find_located).
+// apply, run by the launch's first blocks beside the row gather).  (Table without optimizer: plain mee_find_located.)
 int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
     if (!t || (n && (!d_keys || !d_out || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_located_prepare: null argument");
     if (t->prepared_n) return fail(MEE_ERR_INVALID_ARG, "mee_find_located_prepare: a prepared apply is already pending");
     if (n == 0) return MEE_OK;
     if (t->optimizer == MEE_OPT_NONE) return mee_find_located(t, d_keys, n, d_out, d_found, d_slots_out, stream);
     if (n > t->max_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_find_located_prepare: n=%zu exceeds config.max_batch=%llu", n, (unsigned long long)t->max_batch);
-    if (!use_bucketed_apply(t, n)) {
-        if (int rc = mee_find_located(t, d_keys, n, d_out, d_found, d_slots_out, stream)) return rc;
-        return mee_apply_prepare(t, d_keys, n, stream);
-    }
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
     uint32_t apply_grid, nbk;
@@ -2721,7 +2138,7 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
     MEE_HIP(hipGetLastError());
     if (separate) { if (int rc = bucket_apply_prepare(t, d_keys, (uint32_t)n, st)) return rc; }
     else { t->part_blocks = part_blocks; t->part_per_block = per_block; t->part_nbk = nbk; t->part_nbk_hash = nbk_hash; t->part_grid = apply_grid; t->part_full = apply_full; }
-    t->prepared_n = n; t->prepared_keys = d_keys; t->prepared_path = 1; t->prepared_by_forward = true;
+    t->prepared_n = n; t->prepared_keys = d_keys; t->prepared_by_forward = true;
     return MEE_OK;
 }
 
@@ -2760,14 +2177,9 @@ int mee_apply_discard(mee_table* t, void* stream) {
     if (!t->prepared_n) return MEE_OK;
     DeviceGuard g(t->device);
     const uint32_t nn = (uint32_t)t->prepared_n;
-    if (t->prepared_path == 2) {   // a group table to give back (the bucketed partition leaves nothing behind)
-        group_reset_kernel<<<grid_for(nn, 256, 1u << 22), 256, 0, as_stream(stream)>>>(t->bs.hidx, nn, t->g);
-        MEE_HIP(hipGetLastError());
-        zero_words(t->bs.filed_bits, ((size_t)nn / 32 + 16) * 4, as_stream(stream));   // the prepare pass may have marked filed occurrences (a kernel, not a memset node: see zero_words)
-    } else if (t->prepared_path == 1) {
-        if (int rc = bucket_apply_discard(t, as_stream(stream))) return rc;
-    }
-    t->prepared_n = 0; t->prepared_keys = nullptr; t->prepared_path = 0;
+    (void)nn;
+    if (int rc = bucket_apply_discard(t, as_stream(stream))) return rc;   // (counts the partition as consumed; it leaves nothing else behind)
+    t->prepared_n = 0; t->prepared_keys = nullptr;
     return MEE_OK;
 }
 

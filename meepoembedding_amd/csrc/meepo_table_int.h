@@ -34,8 +34,6 @@ struct GroupTable {            // S entries, indexed by h
     uint32_t* sbig;            // first fp64 partial-sum row of a group with more than kChunk occurrences
     uint32_t* sgrp;            // index of the group in the unique list (standalone dedup)
     long long* sres;           // lent out as a per-position slot list by insert / remove
-    uint32_t* inl;             // apply: 16 batch positions per entry (one 64-byte line): [0..7] the claiming block's occurrences of ranks 1..8,
-                               // [8..15] the first 8 occurrences other blocks added — a group that fits is finished by its leader from this one line
     uint64_t smask;
 };
 __device__ __forceinline__ uint32_t* sv_half(const GroupTable& g, uint32_t h) { return reinterpret_cast<uint32_t*>(g.ent + 2 * (uint64_t)h + 1); }   // [0] = lo, [1] = hi
@@ -43,17 +41,11 @@ __device__ __forceinline__ void sv_load(const GroupTable& g, uint32_t h, uint32_
     const unsigned long long w = g.ent[2 * (uint64_t)h + 1];
     lo = (uint32_t)w; hi = (uint32_t)(w >> 32);
 }
-// kGroupApply entries (read while claimed): hi holds the claiming block's count - 1
-__device__ __forceinline__ void cnt_load(const GroupTable& g, uint32_t h, uint32_t& lo, uint32_t& hi) {
-    sv_load(g, h, lo, hi);
-    ++hi;
-}
 __device__ __forceinline__ void group_release_entry(const GroupTable& g, uint32_t h) {
     reinterpret_cast<ulonglong2*>(g.ent)[h] = make_ulonglong2(0ull, 0ull);
 }
 struct BatchScratch {          // max_batch entries, indexed by batch position unless noted
     uint32_t *hidx, *rank, *pcnt, *occ, *uniq_h, *work;
-    uint32_t *lead_bits, *filed_bits;   // apply: one bit per batch position (leader of an inline group | occurrence of a filed group); all-zero between applies
     uint8_t* fmask;            // found mask of find_or_insert's first pass when the caller passes none
     uint32_t* bigh;            // [max_big] group-table index of each big group
     double* gacc;              // [max_part][dim] fp64 partial-sum rows: one per chunk of a big group, a group's rows contiguous
@@ -123,14 +115,11 @@ struct mee_table {
     int find_grid_cap;          // max blocks of the find grid (0 = one pass, no grid-stride loop)
     int find_block;             // threads per block of the find launch (64 / 128; anything else: 256)
     int prepare_debug;          // experiments on the training forward: bit 0 = partition as a launch of its own behind it, bits 8.. = cap on its find blocks
-    int apply_rounds;           // batch positions in flight per tile in the apply's main pass: 1 or 2 (0 = auto)
     int find_nt;                // bit0: non-temporal row loads, bit1: non-temporal bucket loads, bit2: plain (cached) out stores;
                                 // -1 = auto: cached loads (hot rows of skewed streams stay in L2), cached stores while the
                                 // dense output fits the Infinity Cache (<= 128 MB), streaming stores beyond
     mee::BucketScratch bk;      // bucketed apply (null pointers when the table has no optimizer)
-    int apply_path;             // -1 = the library's choice, 0 = group-table apply, 1 = bucketed apply
     int dedup_path;             // tuning ("dedup_path"): 0 = dedup_keys / assign elections through the group table (round 2), else the bucketed machinery
-    uint32_t prepared_path;     // which path a pending mee_apply_prepare took
     bool prepared_by_forward;   // the pending partition came with a training forward (mee_find*_located_prepare): a mutator in between drops it
     uint32_t part_nbk_hash;   // ... of which the first part_nbk_hash are hash buckets (the rest: one per hot key)
     bool part_full;           // ... and the apply kernel chosen for it (FULL | LEAN: meepo_apply.hip)

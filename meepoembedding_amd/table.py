@@ -522,7 +522,7 @@ class TableGroup:
             pass
 
     def set_tuning(self, name: str, value: int) -> None:
-        """Performance knobs of the group's own apply ("apply_path" 0 = group-table apply, -1 / 1 = bucketed apply, …); never change results."""
+        """Performance knobs of the group's own apply ("apply_kernel", "apply_skew_adapt", …: mee_set_tuning); never change results."""
         check(_lib.lib().mee_group_set_tuning(self._h, name.encode(), int(value)))
 
     def _check_offsets(self, offsets: torch.Tensor) -> None:

@@ -321,13 +321,11 @@ def test_dedup_sum(dev):
 
 @pytest.mark.parametrize("opt", ["adagrad", "adam"])
 @pytest.mark.parametrize("dim", [16, 64, 128])
-@pytest.mark.parametrize("apply_path", [-1, 0], ids=["bucketed", "group_table"])
-def test_optimizer_parity(dev, opt, dim, apply_path):
+def test_optimizer_parity(dev, opt, dim):
     n_keys, steps, batch = 20000, 4, 30000
     keys = synth.keys_np(31, 0, n_keys); rows = synth.rows_np(keys, dim, 2)
     kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
     t = LookupTable(32768, dim, device=dev, optimizer=kind, max_batch=batch, initial_accumulator=0.1)
-    t.set_tuning("apply_path", apply_path)
     o = oracle.OracleTable(32768, dim, optimizer=okind, initial_accumulator=0.1)
     t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
     rng = np.random.default_rng(41)
@@ -352,8 +350,7 @@ def test_optimizer_parity(dev, opt, dim, apply_path):
 
 
 @pytest.mark.parametrize("opt", ["adagrad", "adam"])
-@pytest.mark.parametrize("apply_path", [-1, 0], ids=["bucketed", "group_table"])
-def test_optimizer_full_batch_of_medium_groups(dev, opt, apply_path):
+def test_optimizer_full_batch_of_medium_groups(dev, opt):
     """n == max_batch and EVERY key repeated 33..40 times: each group is 'big' (> 32 occurrences) and needs TWO fp64
     partial-sum rows, the worst case for the partial-sum block (about n/32 + n/33 rows; a block sized for n/32 + 1 rows
     was overrun by exactly this shape)."""
@@ -369,7 +366,6 @@ def test_optimizer_full_batch_of_medium_groups(dev, opt, apply_path):
     assert bk.size == batch
     kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
     t = LookupTable(8192, dim, device=dev, optimizer=kind, max_batch=batch, initial_accumulator=0.1)
-    t.set_tuning("apply_path", apply_path)
     o = oracle.OracleTable(8192, dim, optimizer=okind, initial_accumulator=0.1)
     t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
     # a canary table allocated right behind the first one's scratch: an overrun of the partial-sum block would land in it
@@ -395,8 +391,7 @@ def test_optimizer_full_batch_of_medium_groups(dev, opt, apply_path):
 
 @pytest.mark.parametrize("opt,dim,layout", [("adagrad", 64, "clustered"), ("adagrad", 64, "spread"), ("adam", 128, "mixed"),
                                             ("adagrad", 16, "mixed"), ("adam", 24, "spread")])
-@pytest.mark.parametrize("apply_path", [-1, 0], ids=["bucketed", "group_table"])
-def test_optimizer_every_group_size(dev, opt, dim, layout, apply_path):
+def test_optimizer_every_group_size(dev, opt, dim, layout):
     """One batch holds a key of EVERY multiplicity 1..44 plus 64, 65, 100, 333 and 2100, so that each way a duplicate group can be
     finished is taken and its edges are crossed: the inline list of a group-table entry (the claiming block's occurrences 1..8, eight
     of other blocks), the filed groups of one chunk (up to 32), the groups with fp64 partial-sum rows (33 and more).  'clustered'
@@ -427,8 +422,6 @@ def test_optimizer_every_group_size(dev, opt, dim, layout, apply_path):
     kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
     mk = lambda: LookupTable(4096, dim, device=dev, optimizer=kind, max_batch=n, initial_accumulator=0.1)
     ta, tb, tc = mk(), mk(), mk()
-    for t in (ta, tb, tc):
-        t.set_tuning("apply_path", apply_path)
     o = oracle.OracleTable(4096, dim, optimizer=okind, initial_accumulator=0.1)
     for t in (ta, tb, tc):
         t.insert(T(keys[:n_keys + 400], dev), T(rows[:n_keys + 400], dev))
@@ -560,17 +553,19 @@ def test_bucketed_apply_extremes(dev, case, opt, kernel):
     np.testing.assert_allclose(got.cpu().numpy(), exp, rtol=RTOL, atol=ATOL)
 
 
-def test_apply_beyond_the_bucketed_limit(dev):
-    """A batch larger than the bucketed apply takes (8192 buckets x 352 positions = 2.7M keys) goes through the group-table apply, also behind
-    the training forward (mee_find_located_prepare then prepares THAT path); same results as the oracle, and the next small batch is back
-    on the bucketed path with clean scratch."""
-    dim, n_keys, n = 4, 400_000, 2_900_000
+@pytest.mark.parametrize("n", [2_900_000, 9_500_000], ids=["2.9M", "9.5M"])
+def test_apply_beyond_the_bucketed_limit(dev, n):
+    """Batches beyond what round 3's bucketed apply took (8192 buckets x 352 positions = 2.7M keys; the group-table apply behind it is gone):
+    2.9M keys = buckets of ~380 positions, still one block each; 9.5M keys = every bucket holds more than a block takes whole (1024) and goes
+    through its slabs, pending records and merge passes.  Also behind the training forward (mee_find_located_prepare); same results as the
+    oracle, and the next small batch finds the scratch clean."""
+    dim, n_keys = 4, 400_000
     keys = synth.keys_np(171, 0, n_keys); rows = synth.rows_np(keys, dim, 2)
     rng = np.random.default_rng(8)
     bk = keys[rng.integers(0, n_keys, n)]           # ~7 occurrences per key
     bk[:50_000] = keys[3]                            # and one hot key
     bk[rng.integers(0, n, 100)] = synth.keys_np(172, 0, 100)   # absent
-    t = LookupTable(1 << 20, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=3_000_000, initial_accumulator=0.1)
+    t = LookupTable(1 << 20, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=n + 100_000, initial_accumulator=0.1)
     o = oracle.OracleTable(1 << 20, dim, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
     t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
     bkt = T(bk, dev)
@@ -648,8 +643,7 @@ def test_find_or_insert_located(dev, dim):
 
 
 @pytest.mark.parametrize("opt,dim", [("adagrad", 64), ("adam", 128), ("adagrad", 24)])
-@pytest.mark.parametrize("apply_path", [-1, 0], ids=["bucketed", "group_table"])
-def test_located_apply_equals_plain_apply(dev, opt, dim, apply_path):
+def test_located_apply_equals_plain_apply(dev, opt, dim):
     """find_located + apply_*(slots=…) — the forward's slot handles instead of a probe — must give the table the plain apply
     gives (and the oracle's), with duplicates, absent keys (handle -1), reserved keys and both settings of the side-stream knob."""
     n_keys, batch = 30000, 20000
@@ -657,8 +651,6 @@ def test_located_apply_equals_plain_apply(dev, opt, dim, apply_path):
     kind, okind = (OPT_ADAGRAD, oracle.OPT_ADAGRAD) if opt == "adagrad" else (OPT_ADAM, oracle.OPT_ADAM)
     mk = lambda: LookupTable(65536, dim, device=dev, optimizer=kind, max_batch=n_keys, initial_accumulator=0.1)
     ta, tb = mk(), mk()
-    for t in (ta, tb):
-        t.set_tuning("apply_path", apply_path)
     o = oracle.OracleTable(65536, dim, optimizer=okind, initial_accumulator=0.1)
     for t in (ta, tb):
         t.insert(T(keys, dev), T(rows, dev))
@@ -1234,9 +1226,8 @@ def test_grouped_find_equals_per_table_find(dev, dim):
     grp.close()
 
 
-@pytest.mark.parametrize("apply_path", [-1, 0], ids=["bucketed", "group_table"])
 @pytest.mark.parametrize("opt,dim", [("adagrad", 64), ("adam", 128), ("adagrad", 24)])
-def test_grouped_apply_equals_per_table_apply(dev, opt, dim, apply_path):
+def test_grouped_apply_equals_per_table_apply(dev, opt, dim):
     """mee_group_apply_*: one optimizer step over the jagged batch of a group == apply per table == the oracle, with
     duplicate-heavy segments (hot keys beyond the chunk and big-group thresholds), absent and reserved keys, the SAME key
     value stored in several tables, and empty segments."""
@@ -1257,7 +1248,6 @@ def test_grouped_apply_equals_per_table_apply(dev, opt, dim, apply_path):
         a.insert(T(u, dev), T(rows, dev)); b.insert(T(u, dev), T(rows, dev)); o.insert(u, rows)
         grouped.append(a); solo.append(b); oracles.append(o); universes.append(u)
     grp = TableGroup(grouped, max_apply_batch=1 << 15)
-    grp.set_tuning("apply_path", apply_path)
     for step in range(1, 4):
         segs = []
         for j in range(n_tables):
@@ -1432,9 +1422,8 @@ def test_indexed_apply_is_apply_of_gathered_grads(dev, opt):
             np.testing.assert_allclose(x.cpu()[ia].numpy(), z[io], rtol=RTOL, atol=ATOL)
 
 
-@pytest.mark.parametrize("apply_path", [-1, 0], ids=["bucketed", "group_table"])
 @pytest.mark.parametrize("dim,mode,opt", [(64, "sum", "adagrad"), (128, "mean", "adam"), (24, "sum", "adagrad")])
-def test_group_pooled_equals_per_table_pooled(dev, dim, mode, opt, apply_path):
+def test_group_pooled_equals_per_table_pooled(dev, dim, mode, opt):
     """The embedding-bag collection: mee_group_find_pooled == find_pooled per member (bit-exact), and its backward
     (mee_group_apply_*_pooled) == apply_*_indexed per member == the oracle."""
     from meepoembedding_amd import TableGroup
@@ -1453,7 +1442,6 @@ def test_group_pooled_equals_per_table_pooled(dev, dim, mode, opt, apply_path):
         x.insert(T(u, dev), T(rows, dev)); y.insert(T(u, dev), T(rows, dev)); z.insert(u, rows)
         a.append(x); b.append(y); o.append(z); univ.append(u)
     grp = TableGroup(a, max_apply_batch=1 << 14)
-    grp.set_tuning("apply_path", apply_path)
     for step, long_bags in ((1, False), (2, True)):          # both launch shapes of the pooled kernel
         lens = rng.integers(8, 40, n_tables * bpt) if long_bags else rng.integers(0, 7, n_tables * bpt)
         lens[3] = 0; lens[bpt] = 25
@@ -1644,7 +1632,6 @@ def test_random_group_sequences(dev, seed):
         orcs.append(oracle.OracleTable(1 << 14, dim, optimizer=okind, **kw))
         univ.append(synth.keys_np(7000 + seed * 10 + j, 0, 400))
     grp = TableGroup(tabs, max_apply_batch=1 << 14)
-    grp.set_tuning("apply_path", 0 if seed % 4 == 3 else -1)   # every fourth seed: the group-table apply (the fallback for huge batches)
     step = 0
 
     def batch(pooled):

@@ -21,13 +21,11 @@ out = torch.empty((b, dim), dtype=torch.float32, device=dev); found = torch.empt
 slots = torch.empty(b, dtype=torch.int64, device=dev)
 g = torch.randn(b, dim, device=dev) * 0.01
 for i in range(8): t.find(small[i], out=out, found=found)             # find (headline)
-for path in (1, 0):                                                   # 1 = bucketed apply (the default), 0 = round 2's group-table apply
-    t.set_tuning("apply_path", path)
+for _ in (0,):
     for i in range(8):
         t.find_located(small[i], out=out, found=found, slots=slots)
         t.apply_adagrad(small[i], g, lr=0.01, slots=slots)            # located apply
     for i in range(8): t.apply_adagrad(small[i], g, lr=0.01)          # plain apply
-t.set_tuning("apply_path", -1)
 for i in range(8):
     t.find_located(small[i], out=out, found=found, slots=slots, prepare_apply=True)   # the training forward: find + the apply's partition in one launch
     t.apply_adagrad(small[i], g, lr=0.01, slots=slots)

@@ -1,5 +1,5 @@
-"""applies per apply path under rocprofv3 --kernel-trace / --pmc: per-kernel times of the apply alone and of the find_located + apply step.
-usage: apply_trace.py [keys] [uniform|zipf] [paths e.g. 0,1] [adagrad|adam]     (apply_path 0 = group-table apply, 1 = bucketed apply)"""
+"""applies under rocprofv3 --kernel-trace / --pmc: per-kernel times of the apply alone and of the find_located + apply step.
+usage: apply_trace.py [keys] [uniform|zipf] [ignored: round 3 took a list of apply paths here] [adagrad|adam]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,6 @@ from meepoembedding_amd import LookupTable, OPT_ADAGRAD, OPT_ADAM, synth
 dev = torch.device("cuda", 0)
 keys_n, batch, dim = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000, 1 << 18, 64
 dist_name = sys.argv[2] if len(sys.argv) > 2 else "uniform"
-paths = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "0,1").split(",")]
 adam = len(sys.argv) > 4 and sys.argv[4] == "adam"
 bmax = int(os.environ.get("MEE_BUCKET_MAX", "0"))
 spare = int(os.environ.get("MEE_SPARE", "0"))
@@ -29,8 +28,7 @@ def apply(k, **kw):
         t.apply_adagrad(k, grads, lr=0.01, **kw)
 
 
-for path in paths:
-    t.set_tuning("apply_path", path)
+for _ in (0,):
     if bmax:
         t.set_tuning("apply_bucket_max", bmax)
     if spare:
@@ -52,5 +50,5 @@ for path in paths:
             step(i)
         e1.record()
         torch.cuda.synchronize()
-        print(f"apply_path {path} {dist_name} {'adam' if adam else 'adagrad'}: {label}: {e0.elapsed_time(e1) * 1e3 / 50:.1f} us per step", flush=True)
+        print(f"apply_path 1 {dist_name} {'adam' if adam else 'adagrad'}: {label}: {e0.elapsed_time(e1) * 1e3 / 50:.1f} us per step", flush=True)
 assert t.status() == 0

@@ -49,10 +49,7 @@ for B in BS:
             o = out[j * B:(j + 1) * B]; o.zero_(); o.index_add_(0, bag_of1, rows)
         for j, t in enumerate(tables):
             t.apply_adagrad(segs[j], bag_grads[j * B:(j + 1) * B][bag_of1], lr=0.01)
-    grp.set_tuning("apply_path", 0)
-    tgt = timed(grouped)
-    grp.set_tuning("apply_path", -1)
     tg, tl, tu = timed(grouped), timed(looped), timed(unfused)
-    print(f"batch {B:5d} ({n} ids per step): unfused per-table {tu:.0f} us, pooled per-table {tl:.0f} us, grouped + pooled with the group-table apply {tgt:.1f} us, grouped + pooled {tg:.1f} us "
+    print(f"batch {B:5d} ({n} ids per step): unfused per-table {tu:.0f} us, pooled per-table {tl:.0f} us, grouped + pooled {tg:.1f} us "
           f"({tu / tg:.1f}x / {tl / tg:.1f}x; {n / tg / 1e3:.2f} G ids/s)", flush=True)
     grp.close()

@@ -34,9 +34,7 @@ for per in PERS:
         grp.find(cat[i % 4], offs, out=out, found=found)
         grp.apply_adagrad(cat[i % 4], offs, grads, lr=0.01)
     res = {}
-    for name, fn in (("looped", looped), ("grouped_gt", grouped), ("grouped", grouped)):
-        if name.startswith("grouped"):
-            grp.set_tuning("apply_path", 0 if name == "grouped_gt" else -1)
+    for name, fn in (("looped", looped), ("grouped", grouped)):
         for i in range(3): fn(i)
         torch.cuda.synchronize(); e0.record()
         for i in range(20): fn(i)
@@ -44,6 +42,6 @@ for per in PERS:
         res[name] = e0.elapsed_time(e1) * 1e3 / 20
     uniq = sum(int(torch.unique(c).numel()) for c in cat) / 4
     bytes_ = (528 + 264) * n + 1032 * uniq
-    print(f"{per:6d} keys/table ({n} per step): per-table loop {res['looped']:.0f} us, grouped with the group-table apply {res['grouped_gt']:.1f} us, grouped {res['grouped']:.1f} us "
+    print(f"{per:6d} keys/table ({n} per step): per-table loop {res['looped']:.0f} us, grouped {res['grouped']:.1f} us "
           f"({res['looped'] / res['grouped']:.1f}x; {n / res['grouped'] / 1e3:.2f} G keys/s, {bytes_ / res['grouped'] / 1e3 / 8000:.2f} of the HBM roofline)", flush=True)
     grp.close()
