@@ -57,7 +57,7 @@ struct TableView {
     uint32_t* hits;
 };
 TableView table_view(const mee_table* t);
-int find_skip_padding(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);   // meepo_table.hip
+int find_skip_padding(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream);   // meepo_find.hip
 
 // ---- table groups (meepo_group.hip: grouped find / locate; meepo_table.hip: grouped apply) ---------------------------------
 struct GroupDesc {   // 48 bytes per member table, device resident

@@ -1,4 +1,7 @@
-// meepo_table.hip — HBM-resident open-addressing table for gfx950: kernels + the table half of the C-ABI.
+// meepo_table.hip — HBM-resident open-addressing table for gfx950: life cycle (create / destroy / tuning / clear), the mutators (insert,
+// assign, remove, find_or_insert and their kernels), the entry points of the sparse optimizers (the kernels: meepo_apply.hip) and the
+// standalone duplicate reduction — the table half of the C-ABI.  The lookups: meepo_find.hip; export, size, rehash, statistics:
+// meepo_export.hip; dedup_keys and assign's elections: meepo_dedup.hip.
 //
 // Reference anchor: /root/reference/README.md:2 ("dynamic lookuptable-style Embedding … Supports GPU …"); the
 // snapshot has no code, so semantics come from SPEC.md (§2 table, §3 operators, §4 optimizers).
@@ -7,9 +10,9 @@
 //   keys   int64[capacity]          16 keys = one 128-B line = one bucket
 //   values fp32 [capacity][dim]     row of slot s at values + s*dim  (256 B for dim 64)
 //   s1,s2  fp32 [capacity][dim]     optimizer planes (acc | m, v), only if configured
-// Per-batch scratch ("group table"): an open-addressing set of the batch's distinct keys sized ≥ 2·max_batch
-// (stays in L2 / Infinity Cache), used to give every distinct key one owner tile: duplicate-key reduction
-// for the optimizers, last-wins for insert/assign, single insertion for find_or_insert.
+// Per-batch scratch ("group table"): an open-addressing set of the batch's distinct keys sized ≥ 2·max_batch (stays in L2 / Infinity
+// Cache): single insertion and last-wins for insert / find_or_insert, and mee_dedup_sum.  (The optimizers, dedup_keys and assign left it
+// in rounds 3-4 for the partition + block-local LDS tables of meepo_apply.hip / meepo_dedup.hip.)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -41,452 +44,13 @@ namespace mee {
 __global__ void zero_words_kernel(uint32_t* p, uint32_t n_words) {
     for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) p[i] = 0u;
 }
-static inline void zero_words(void* p, size_t bytes, hipStream_t st) { zero_words_kernel<<<1, 64, 0, st>>>((uint32_t*)p, (uint32_t)(bytes / 4)); }
+void zero_words(void* p, size_t bytes, hipStream_t st) { zero_words_kernel<<<1, 64, 0, st>>>((uint32_t*)p, (uint32_t)(bytes / 4)); }
 
 __global__ void fill_i64_kernel(int64_t* p, uint64_t n, int64_t v) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
-// ---- find (SPEC.md §3) — the headline kernel --------------------------------------------------------------
-// One tile per key, R keys in flight per tile: the R bucket lines are requested back to back, then the R rows.
-// DIM4 = dim/4 when it is a multiple of 16 (each lane moves DIM4/16 float4 per row), 0 = any dim at run time.
-
-// the find of n positions by `n_waves` waves of which this is wave `wave` (each wave step takes 4R consecutive positions)
-template <int DIM4, int R, int NT>
-__device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
-                                          const int64_t* __restrict__ keys, uint64_t n, f32x4* __restrict__ out,
-                                          uint8_t* __restrict__ found, float defv, uint32_t dim4_rt, uint32_t* hits,
-                                          int64_t* __restrict__ slots_out, uint64_t wave, uint64_t n_waves, int64_t handle_tag = 0) {
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
-    constexpr int KPW = 4 * R;
-    const f32x4 def4 = {defv, defv, defv, defv};
-
-    for (uint64_t base = wave * KPW; base < n; base += n_waves * KPW) {
-        int64_t key[R];
-        int64_t slot[R];
-        uint64_t b[R];
-        int64_t kb[R];
-        bool inb[R], act[R];
-        // ONE coalesced load brings the wave step's 4R keys (lane j reads keys[base + j]); the tiles take theirs by shuffle.  (A load per
-        // tile and round made the compiler wait for round r's key before it requested round r + 1's: a dependent memory round trip per round.)
-        const int64_t kmine = (lane < KPW && base + lane < n) ? keys[base + lane] : kEmpty;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint64_t i = base + r * 4 + tile;
-            inb[r] = i < n;
-            key[r] = __shfl(kmine, r * 4 + tile);
-            act[r] = inb[r] && !reserved_key(key[r]);
-            if constexpr ((NT & 8) != 0) {  // second-tier pass: only positions an earlier find left as missing
-                inb[r] = act[r] = act[r] && found[i] == 0;
-            }
-            if constexpr ((NT & 128) != 0) {  // owner side of a padded sharded exchange: EMPTY positions are padding nobody reads — no row; their
-                // found byte says "served" so that a second-tier pass over the same buffers (mee_find_missing / mee_find_or_insert_missing on the
-                // cold table of a tiered shard) leaves them alone instead of reading a byte nobody wrote
-                if (inb[r] && !act[r] && tl == 0 && found) found[i] = 1;
-                inb[r] = act[r];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            b[r] = bucket_of(key[r], nb);
-            kb[r] = act[r] ? ((NT & 2) ? __builtin_nontemporal_load(&tkeys[b[r] * kW + tl]) : tkeys[b[r] * kW + tl]) : kEmpty;
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            slot[r] = -1;
-            bool pend = act[r];
-            uint64_t bb = b[r], steps = 0;
-            int64_t k = kb[r];
-            while (true) {
-                const uint32_t tm = tile_bits(__ballot(pend && k == key[r]), tile);
-                const uint32_t te = tile_bits(__ballot(pend && k == kEmpty), tile);
-                if (pend) {
-                    if (tm) { slot[r] = (int64_t)(bb * kW) + (__ffs(tm) - 1); pend = false; }
-                    else if (te || ++steps >= nb) pend = false;
-                    else bb = next_bucket(bb, step_of(key[r], nb), nb);
-                }
-                if (!__any(pend)) break;
-                k = pend ? tkeys[bb * kW + tl] : kEmpty;
-            }
-        }
-        if constexpr ((NT & 16) != 0) {  // access statistics for the hot/cold policy (sampled calls only)
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (slot[r] >= 0 && tl == 0) atomicAdd(&hits[slot[r]], 1u);
-        }
-        if constexpr (DIM4 != 0) {
-            constexpr int C = DIM4 / 16;
-            f32x4 row[R][C];
-            // Common case, decided per wave: every position of the wave step is inside the batch and was found.  Then the R row loads
-            // and the R stores are straight-line code and leave back to back; with a per-lane condition around each load the compiler
-            // waited for round r's row before it requested round r + 1's (seen in the ISA of the located variant: +8 us per 256K keys).
-            bool all_hit = true;
-#pragma unroll
-            for (int r = 0; r < R; ++r) all_hit = all_hit && inb[r] && slot[r] >= 0;
-            if (__all(all_hit)) {
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        row[r][c] = (NT & 1) ? __builtin_nontemporal_load(&values[(uint64_t)slot[r] * DIM4 + c * 16 + tl]) : values[(uint64_t)slot[r] * DIM4 + c * 16 + tl];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint64_t i = base + r * 4 + tile;
-#pragma unroll
-                    for (int c = 0; c < C; ++c) { if (NT & 4) out[i * DIM4 + c * 16 + tl] = row[r][c]; else __builtin_nontemporal_store(row[r][c], &out[i * DIM4 + c * 16 + tl]); }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        row[r][c] = slot[r] >= 0 ? ((NT & 1) ? __builtin_nontemporal_load(&values[(uint64_t)slot[r] * DIM4 + c * 16 + tl]) : values[(uint64_t)slot[r] * DIM4 + c * 16 + tl]) : def4;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint64_t i = base + r * 4 + tile;
-                    if (inb[r] && (!(NT & 8) || slot[r] >= 0)) {
-#pragma unroll
-                        for (int c = 0; c < C; ++c) { if (NT & 4) out[i * DIM4 + c * 16 + tl] = row[r][c]; else __builtin_nontemporal_store(row[r][c], &out[i * DIM4 + c * 16 + tl]); }
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint64_t i = base + r * 4 + tile;
-                if (inb[r] && (!(NT & 8) || slot[r] >= 0))
-                    for (uint32_t c = tl; c < dim4; c += 16)
-                        out[i * dim4 + c] = slot[r] >= 0 ? values[(uint64_t)slot[r] * dim4 + c] : def4;
-            }
-        }
-        if constexpr ((NT & 64) != 0) {  // mee_find_located: the slot of every position (-1 = absent), for the apply of the same step
-            // lane j < 4R collects the slot of position base + j (round j / 4, tile j % 4): ONE coalesced store per wave step
-            int64_t mine = -1;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int64_t v = __shfl(slot[r], (lane & 3) * kW);
-                if ((lane >> 2) == r) mine = v;
-            }
-            if (lane < KPW && base + lane < n) slots_out[base + lane] = mine >= 0 ? (mine | handle_tag) : mine;   // tag: the table's layout epoch (see handle_tag_of)
-        }
-        if (found && !(NT & 32)) {  // NT&32: rows only (last pass of find_or_insert: found keeps meaning "present before")
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint64_t i0 = base + r * 4;
-                if ((NT & (8 | 128)) == 0 && i0 + 4 <= n && (reinterpret_cast<uintptr_t>(found) & 3) == 0) {
-                    // the four tiles' found bytes of this round leave as ONE aligned 4-byte store
-                    const uint64_t m = __ballot(slot[r] >= 0);
-                    const uint32_t w = (uint32_t)(m & 1) | ((uint32_t)((m >> 16) & 1) << 8) | ((uint32_t)((m >> 32) & 1) << 16) |
-                                       ((uint32_t)((m >> 48) & 1) << 24);
-                    if (lane == 0) *reinterpret_cast<uint32_t*>(found + i0) = w;
-                } else {
-                    const uint64_t i = i0 + tile;
-                    if (inb[r] && tl == 0 && (!(NT & 8) || slot[r] >= 0)) found[i] = slot[r] >= 0;   // (NT & 128: inb excludes padding)
-                }
-            }
-        }
-    }
-}
-
-#ifndef MEE_FIND_TIMELINE
-#define MEE_FIND_TIMELINE 0
-#endif
-#if MEE_FIND_TIMELINE
-__device__ unsigned long long* g_find_dbg = nullptr;
-#endif
-template <int DIM4, int R, int NT>
-__global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values,
-                                                   uint64_t nb, const int64_t* __restrict__ keys, uint64_t n,
-                                                   f32x4* __restrict__ out, uint8_t* __restrict__ found, float defv,
-                                                   uint32_t dim4_rt, uint32_t* hits, int64_t* __restrict__ slots_out = nullptr, int64_t handle_tag = 0) {
-#if MEE_FIND_TIMELINE   // diagnostic builds only (tools/find_timeline.py): wave 0 of every block stamps its start, its end and the XCD it ran on
-    unsigned long long t0_ = 0;
-    if (threadIdx.x == 0) t0_ = wall_clock64();
-#endif
-    find_span<DIM4, R, NT>(tkeys, values, nb, keys, n, out, found, defv, dim4_rt, hits, slots_out,
-                           (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), (uint64_t)gridDim.x * (blockDim.x >> 6), handle_tag);
-#if MEE_FIND_TIMELINE
-    if (threadIdx.x == 0 && g_find_dbg && blockIdx.x < 16384) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_find_dbg[blockIdx.x * 4 + 0] = t0_; g_find_dbg[blockIdx.x * 4 + 1] = wall_clock64(); g_find_dbg[blockIdx.x * 4 + 2] = xcc & 0xf;
-    }
-#endif
-}
-
-// The training forward (mee_find_located_prepare): the located find whose launch gives its first `part_blocks` blocks the partition role of
-// the bucketed apply (meepo_apply_part.h).  The partition of the step's backward — a latency-bound 15-18 us of LDS histograms for a 256K-key
-// batch — runs beside the forward's row gather, which is bound by bytes and takes twice as long: the backward starts with its update kernel.
-// Block size = the find's own 256 threads.  The first version used 1024-thread blocks for the sake of the partition role (64 blocks x 1024
-// threads); measured with the role switched off, the FIND in 1024-thread blocks takes 47 us against 39 us in 256-thread blocks (a block's 16
-// waves each do one short pass, the block holds its 16 wave slots until the slowest of them is done; 512-thread blocks: 42 us) — the launch
-// took as long as its slow find and hid nothing.  With 256-thread blocks the role runs as 128 blocks x 256 threads x 8 keys, each making two
-// round trips to memory (meepo_apply_part.h): 42.5 us for the launch against 40 us with the role switched off.
-#ifndef MEE_FPT
-#define MEE_FPT 256
-#endif
-constexpr int kFindPrepareThreads = MEE_FPT;
-template <int DIM4, int R, int NT>
-__global__ __launch_bounds__(kFindPrepareThreads, kFindPrepareThreads <= 256 ? 8 : 4) void find_prepare_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
-                                                           const int64_t* __restrict__ keys, uint64_t n, f32x4* __restrict__ out,
-                                                           uint8_t* __restrict__ found, float defv, uint32_t dim4_rt, int64_t* __restrict__ slots_out,
-                                                           int64_t handle_tag, uint32_t part_blocks, uint32_t nbk_hash, uint32_t nbk, uint32_t per_block,
-                                                           BucketScratch bk, uint32_t* status, OpCounters* op) {
-    extern __shared__ unsigned long long part_lds[];   // PartHot, then one counter per bucket (meepo_apply_part.h)
-    __shared__ unsigned long long part_wsum[kFindPrepareThreads / 64];
-    if (blockIdx.x < part_blocks) {   // block-uniform
-        PartHot* hot = reinterpret_cast<PartHot*>(part_lds);
-        sort_role<kFindPrepareThreads>(keys, (uint32_t)n, nbk_hash, nbk, per_block, blockIdx.x, part_blocks, bk, status, op, reinterpret_cast<uint32_t*>(hot + 1), part_wsum, hot);
-        return;
-    }
-    find_span<DIM4, R, NT>(tkeys, values, nb, keys, n, out, found, defv, dim4_rt, nullptr, slots_out,
-                           (uint64_t)(blockIdx.x - part_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6), (uint64_t)(gridDim.x - part_blocks) * (blockDim.x >> 6),
-                           handle_tag);
-}
-
-// Several lookup requests of one table in ONE launch (mee_find_many): the per-launch latency floor (~5 us: dispatch + the dependent
-// chain of the first and last waves) is paid once for all of them, so four queued 256K-key requests run at the rate of one 1M-key
-// launch.  The request descriptors travel in the kernel argument; a block finds its request by its index (<= kMaxFindRequests entries).
-constexpr int kMaxFindRequests = 16;
-struct FindMany {
-    const int64_t* keys[kMaxFindRequests];
-    f32x4* out[kMaxFindRequests];
-    uint8_t* found[kMaxFindRequests];
-    uint64_t n[kMaxFindRequests];
-    uint32_t first_block[kMaxFindRequests + 1];
-    uint32_t count;
-};
-template <int DIM4, int R, int NT>
-__global__ __launch_bounds__(256) void find_many_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
-                                                        FindMany m, float defv, uint32_t dim4_rt) {
-    uint32_t q = 0;
-    while (q + 1 < m.count && blockIdx.x >= m.first_block[q + 1]) ++q;   // block-uniform
-    find_span<DIM4, R, NT>(tkeys, values, nb, m.keys[q], m.n[q], m.out[q], m.found[q], defv, dim4_rt, nullptr, nullptr,
-                           (uint64_t)(blockIdx.x - m.first_block[q]) * (blockDim.x >> 6) + (threadIdx.x >> 6),
-                           (uint64_t)(m.first_block[q + 1] - m.first_block[q]) * (blockDim.x >> 6));
-}
-
-// ---- sparse second pass (SPEC.md §3 find_missing; last pass of find_or_insert): only positions whose found byte is 0 -----
-// A wave reads 64 keys + found bytes with one coalesced load each and leaves at once when nothing is missing (the common
-// case: a hot tier that holds the working set, a trained vocabulary); the missing ones are probed four at a time.
-// FLAGS bit 0: set found[i] = 1 where the key is stored here (tier pass; off = rows only), bit 1: count the hit.
-template <int FLAGS>
-__global__ __launch_bounds__(256) void find_missing_kernel(const int64_t* __restrict__ tkeys, const float4* __restrict__ values,
-                                                           uint64_t nb, uint32_t dim4, const int64_t* __restrict__ keys, uint64_t n,
-                                                           float4* __restrict__ out, uint8_t* __restrict__ found, uint32_t* hits) {
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    for (uint64_t base = wave * 64; base < n; base += n_waves * 64) {
-        const uint64_t i = base + lane;
-        const int64_t k = i < n ? keys[i] : kEmpty;
-        uint64_t rest = __ballot(i < n && found[i] == 0 && !reserved_key(k));
-        while (rest) {  // wave-uniform
-            uint64_t mm = rest;
-            int p = -1;
-            for (int q = 0; q <= tile; ++q) {
-                if (mm) { p = __ffsll((unsigned long long)mm) - 1; mm &= mm - 1; } else p = -1;
-            }
-            const int64_t key = __shfl(k, p >= 0 ? p : 0);
-            bool is_new, full;
-            const int64_t slot = tile_locate<false, false>(const_cast<int64_t*>(tkeys), nb, key, p >= 0, tile, tl, is_new, full);
-            if (p >= 0 && slot >= 0) {
-                const uint64_t dst = (base + (uint64_t)p) * dim4, src = (uint64_t)slot * dim4;
-                for (uint32_t c = tl; c < dim4; c += 16) out[dst + c] = values[src + c];
-                if (tl == 0) {
-                    if (FLAGS & 1) found[base + p] = 1;
-                    if (FLAGS & 2) atomicAdd(&hits[slot], 1u);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rest &= rest - 1;
-        }
-    }
-}
-
-// ---- pooled find (SPEC.md §3): out[b,:] = the rows of bag b's keys added up in position order (sum | mean) ----------------
-// The partial sum of a bag lives in registers, so a bag costs ONE output row instead of one per key: with L keys per bag
-// the write traffic of the lookup drops from 256 B per key to 256/L.  Additions happen in position order (bit-exact
-// against a sequential sum).  A wave takes four consecutive bags.  Short bags: one tile per bag, U keys of the bag in
-// flight (all bucket lines requested, then all rows).  Bags of kPoolLong keys or more: the four tiles work on ONE bag
-// together — tile t probes positions i + 4u + t — and every tile then adds the 4U rows in position order out of the
-// other tiles' registers (shuffles), so a long bag has 4U keys in flight instead of U.
-constexpr uint32_t kPoolLong = 16;
-
-// probe + row load of up to U keys per tile (the find_kernel pattern); row[u] is only defined where inb[u]
-template <int DIM4, int U, int C>
-__device__ __forceinline__ void pooled_fetch(const int64_t* __restrict__ tkeys, const float4* __restrict__ values, uint64_t nb,
-                                             uint32_t dim4, const int64_t (&key)[U], const uint64_t (&pos)[U],
-                                             const bool (&inb)[U], int tile, int tl, float4 def4, float4 (&row)[U][C],
-                                             uint8_t* __restrict__ found, int64_t* __restrict__ located = nullptr, uint64_t member = 0) {
-    int64_t slot[U], kb[U];
-    uint64_t bk[U];
-    bool act[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        act[u] = inb[u] && !reserved_key(key[u]);
-        bk[u] = bucket_of(key[u], nb);
-        kb[u] = act[u] ? tkeys[bk[u] * kW + tl] : kEmpty;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        slot[u] = -1;
-        bool pend = act[u];
-        uint64_t bb = bk[u], steps = 0;
-        int64_t k = kb[u];
-        while (true) {
-            const uint32_t tm = tile_bits(__ballot(pend && k == key[u]), tile);
-            const uint32_t te = tile_bits(__ballot(pend && k == kEmpty), tile);
-            if (pend) {
-                if (tm) { slot[u] = (int64_t)(bb * kW) + (__ffs(tm) - 1); pend = false; }
-                else if (te || ++steps >= nb) pend = false;
-                else bb = next_bucket(bb, step_of(key[u], nb), nb);
-            }
-            if (!__any(pend)) break;
-            k = pend ? tkeys[bb * kW + tl] : kEmpty;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-            if (DIM4 != 0 || (uint32_t)(c * 16 + tl) < dim4)
-                row[u][c] = slot[u] >= 0 ? values[(uint64_t)slot[u] * dim4 + c * 16 + tl] : def4;
-        if (found && inb[u] && tl == 0) found[pos[u]] = slot[u] >= 0;
-        // the located row (member << 48 | slot, EMPTY when absent): lets the backward skip its own probe pass
-        if (located && inb[u] && tl == 0) located[pos[u]] = slot[u] >= 0 ? (int64_t)((member << kGroupSlotBits) | (uint64_t)slot[u]) : kEmpty;
-    }
-}
-
-// BPW = bags per wave: 4 = the hybrid above (batches of mostly short bags), 1 = every bag gets a whole wave (batches whose
-// AVERAGE bag is long: a wave that had to walk four long bags one after the other would be latency-bound).
-// GROUPED (mee_group_find_pooled): bag b belongs to member table b / bags_per_table; the planes come from its descriptor.
-template <int DIM4, int U, int BPW, bool GROUPED = false>
-__global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restrict__ tkeys_, const float4* __restrict__ values_,
-                                                          uint64_t nb_, const int64_t* __restrict__ keys,
-                                                          const uint64_t* __restrict__ offsets, uint64_t n_bags,
-                                                          float4* __restrict__ out, uint8_t* __restrict__ found, float defv,
-                                                          uint32_t dim4_rt, int mean, const GroupDesc* __restrict__ desc = nullptr,
-                                                          uint64_t bags_per_table = 1, int64_t* __restrict__ located = nullptr,
-                                                          uint64_t n_keys = ~0ull) {
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
-    constexpr int C = DIM4 ? DIM4 / 16 : 16;   // float4 per lane per row (any dim: up to 1024 floats = 16 per lane)
-    for (uint64_t b0 = wave * BPW; b0 < n_bags; b0 += n_waves * BPW) {
-        const uint64_t bag = BPW == 4 ? b0 + tile : b0;
-        const bool has = bag < n_bags;
-        uint64_t begin = has ? offsets[bag] : 0, end = has ? offsets[bag + 1] : 0;
-        end = end < n_keys ? end : n_keys;          // offsets are the caller's: never read past the key array,
-        begin = begin < end ? begin : end;          // and a decreasing pair is an empty bag
-        const int64_t* tkeys = tkeys_;
-        const float4* values = values_;
-        uint64_t nb = nb_;
-        float4 def4 = make_float4(defv, defv, defv, defv);
-        uint64_t member = 0;
-        if constexpr (GROUPED) {
-            member = (has ? bag : 0) / bags_per_table;
-            const GroupDesc d = desc[member];
-            tkeys = d.tkeys; values = d.values; nb = d.nb; def4 = make_float4(d.defv, d.defv, d.defv, d.defv);
-        }
-        const bool is_long = BPW == 1 || end - begin >= kPoolLong;
-        float4 acc[C];
-        float4 row[U][C];
-        // ---- short bags: one tile per bag ----
-        if constexpr (BPW == 4) {
-            uint64_t i = is_long ? end : begin;
-            bool first = true;
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            // a short bag has fewer than 16 keys: its tile fetches them all with one coalesced load, lane tl holds key begin + tl
-            const int64_t kpre = (!is_long && begin + tl < end) ? keys[begin + tl] : kEmpty;
-            while (__any(i < end)) {  // wave-uniform; tiles whose bag is done idle through the ballots
-                uint64_t pos[U];
-                int64_t kv[U];
-                bool inb[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    pos[u] = i + u; inb[u] = pos[u] < end;
-                    kv[u] = __shfl(kpre, tile * 16 + (int)((pos[u] - begin) & 15));
-                }
-                pooled_fetch<DIM4, U, C>(tkeys, values, nb, dim4, kv, pos, inb, tile, tl, def4, row, found, located, member);
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (!inb[u]) continue;
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        if (DIM4 != 0 || (uint32_t)(c * 16 + tl) < dim4) {
-                            if (first) acc[c] = row[u][c];
-                            else { acc[c].x += row[u][c].x; acc[c].y += row[u][c].y; acc[c].z += row[u][c].z; acc[c].w += row[u][c].w; }
-                        }
-                    first = false;
-                }
-                i += U;
-            }
-            if (has && !is_long) {
-                const float len = (float)(end - begin);
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    if (DIM4 != 0 || (uint32_t)(c * 16 + tl) < dim4) {
-                        float4 v = acc[c];
-                        if (mean && end > begin) { v.x = v.x / len; v.y = v.y / len; v.z = v.z / len; v.w = v.w / len; }
-                        out[bag * dim4 + c * 16 + tl] = v;
-                    }
-            }
-        }
-        // ---- long bags: the four tiles share one bag at a time ----
-        const uint64_t long_mask = __ballot(is_long && has);
-        if (!long_mask) continue;   // wave-uniform
-        for (int q = 0; q < BPW; ++q) {
-            if (!((long_mask >> (q * 16)) & 1)) continue;   // wave-uniform
-            const uint64_t bq = __shfl(begin, q * 16), eq = __shfl(end, q * 16);
-            if constexpr (GROUPED && BPW == 4) {   // all four tiles work for bag q's table now
-                member = (b0 + q) / bags_per_table;
-                const GroupDesc d = desc[member];
-                tkeys = d.tkeys; values = d.values; nb = d.nb; def4 = make_float4(d.defv, d.defv, d.defv, d.defv);
-            }
-            bool first = true;
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (uint64_t i = bq; i < eq; i += 4 * U) {   // wave-uniform
-                uint64_t pos[U];
-                int64_t kv[U];
-                bool inb[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) { pos[u] = i + (uint64_t)u * 4 + tile; inb[u] = pos[u] < eq; kv[u] = inb[u] ? keys[pos[u]] : kEmpty; }
-                pooled_fetch<DIM4, U, C>(tkeys, values, nb, dim4, kv, pos, inb, tile, tl, def4, row, found, located, member);
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int src = 0; src < 4; ++src) {
-                        if (i + (uint64_t)u * 4 + src >= eq) continue;   // wave-uniform
-#pragma unroll
-                        for (int c = 0; c < C; ++c) {
-                            float4 v;   // every tile reads the row tile `src` fetched: all four keep the same running sum
-                            v.x = __shfl(row[u][c].x, src * 16 + tl); v.y = __shfl(row[u][c].y, src * 16 + tl);
-                            v.z = __shfl(row[u][c].z, src * 16 + tl); v.w = __shfl(row[u][c].w, src * 16 + tl);
-                            if (first) acc[c] = v;
-                            else { acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w; }
-                        }
-                        first = false;
-                    }
-            }
-            if (tile == 0) {
-                const float len = (float)(eq - bq);
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    if (DIM4 != 0 || (uint32_t)(c * 16 + tl) < dim4) {
-                        float4 v = acc[c];
-                        if (mean && eq > bq) { v.x = v.x / len; v.y = v.y / len; v.z = v.z / len; v.w = v.w / len; }
-                        out[(b0 + q) * dim4 + c * 16 + tl] = v;
-                    }
-            }
-        }
-    }
-}
+void fill_keys(int64_t* p, uint64_t n, int64_t v, hipStream_t st) { fill_i64_kernel<<<2048, 256, 0, st>>>(p, n, v); }
 
 // ---- group table: one entry per distinct key of the batch ---------------------------------------------------
 __device__ __forceinline__ uint32_t group_claim(const GroupTable& g, int64_t key, bool& claimed) {
@@ -1103,204 +667,16 @@ __global__ __launch_bounds__(256) void dedup_emit_kernel(uint32_t dim4, const fl
     }
 }
 
-// ---- access statistics for the hot/cold policy: keys whose hit counter lies in [lo, hi], optional reset ---------------
-__global__ __launch_bounds__(256) void hits_scan_kernel(const int64_t* __restrict__ tkeys, uint32_t* hits, uint64_t capacity, uint32_t lo,
-                                                        uint32_t hi, int reset, int64_t* keys_out, uint64_t cap, OpCounters* op) {
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    constexpr uint64_t kSpan = 64ull * 16;
-    for (uint64_t c0 = wave * kSpan; c0 < capacity; c0 += n_waves * kSpan) {
-        int64_t k[16];
-        uint64_t m[16];
-        uint32_t total = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint64_t s = c0 + (uint64_t)j * 64 + lane;
-            k[j] = s < capacity ? tkeys[s] : kEmpty;
-            const uint32_t hcount = s < capacity ? hits[s] : 0;
-            if (reset && s < capacity && hcount) hits[s] = 0;
-            m[j] = __ballot(!reserved_key(k[j]) && hcount >= lo && hcount <= hi);
-            total += (uint32_t)__popcll(m[j]);
-        }
-        if (!total) continue;  // wave-uniform
-        unsigned long long pos0 = 0;
-        if (lane == 0) pos0 = atomicAdd(&op->n_export, (unsigned long long)total);
-        pos0 = __shfl(pos0, 0);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if ((m[j] >> lane) & 1) {
-                const uint64_t pos = pos0 + (uint64_t)__popcll(m[j] & ((1ull << lane) - 1));
-                if (pos < cap) keys_out[pos] = k[j];
-            }
-            pos0 += (uint64_t)__popcll(m[j]);
-        }
-    }
-}
-
-// ---- probe-length statistics (SURVEY.md §8d "mean probe length"): buckets visited per lookup, summed over the batch ----
-__global__ __launch_bounds__(256) void probe_length_kernel(const int64_t* __restrict__ tkeys, uint64_t nb, const int64_t* __restrict__ keys,
-                                                           uint64_t n, OpCounters* op) {
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    unsigned long long visited = 0;
-    for (uint64_t base = wave * 4; base < n; base += n_waves * 4) {
-        const uint64_t i = base + tile;
-        const int64_t key = i < n ? keys[i] : kEmpty;
-        bool pend = i < n && !reserved_key(key);
-        uint64_t b = bucket_of(key, nb), steps = 0;
-        while (__any(pend)) {
-            const int64_t k = pend ? tkeys[b * kW + tl] : kEmpty;
-            const uint32_t tm = tile_bits(__ballot(pend && k == key), tile);
-            const uint32_t te = tile_bits(__ballot(pend && k == kEmpty), tile);
-            if (pend) {
-                if (tl == 0) ++visited;
-                if (tm || te || ++steps >= nb) pend = false;
-                else b = next_bucket(b, step_of(key, nb), nb);
-            }
-        }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) visited += __shfl_down(visited, d);
-    if (lane == 0 && visited) atomicAdd(&op->n_export, visited);
-}
-
-// ---- size (SPEC.md §3): count stored keys by scanning the key plane (keeps every atomic off the insert path) ----
-__global__ __launch_bounds__(256) void count_kernel(const int64_t* __restrict__ tkeys, uint64_t capacity, OpCounters* op) {
-    __shared__ uint32_t wsum[4];
-    uint32_t c = 0;
-    for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < capacity; s += (uint64_t)gridDim.x * blockDim.x)
-        c += !reserved_key(tkeys[s]);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (tot) atomicAdd(&op->n_export, (unsigned long long)tot);
-    }
-}
-
-// ---- reserve / rehash (SPEC.md §3): every stored pair moves, device to device, into key/row planes of another capacity ----
-// A wave reads 64 consecutive old slots (one coalesced key load), then its four tiles take the stored keys four at a
-// time: claim a slot in the new key plane (same CAS protocol as insert: all keys are distinct, claims of different
-// waves race for slots) and copy the row, the optimizer planes and the hit counter.
-__global__ __launch_bounds__(256) void rehash_kernel(const int64_t* __restrict__ okeys, const float4* __restrict__ ov,
-                                                     const float4* __restrict__ o1, const float4* __restrict__ o2,
-                                                     const uint32_t* __restrict__ ohits, uint64_t old_capacity, int64_t* nkeys,
-                                                     float4* nv, float4* n1, float4* n2, uint32_t* nhits, uint64_t nnb,
-                                                     uint32_t dim4, Counters* ctr) {
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    for (uint64_t c0 = wave * 64; c0 < old_capacity; c0 += n_waves * 64) {
-        const uint64_t s = c0 + lane;
-        const int64_t k = s < old_capacity ? okeys[s] : kEmpty;
-        uint64_t rest = __ballot(!reserved_key(k));
-        while (rest) {  // wave-uniform
-            uint64_t mm = rest;
-            int p = -1;
-            for (int q = 0; q <= tile; ++q) {
-                if (mm) { p = __ffsll((unsigned long long)mm) - 1; mm &= mm - 1; } else p = -1;
-            }
-            const int64_t key = __shfl(k, p >= 0 ? p : 0);
-            bool is_new, full;
-            const int64_t slot = tile_locate<true, true>(nkeys, nnb, key, p >= 0, tile, tl, is_new, full);
-            if (p >= 0) {
-                if (slot >= 0) {
-                    const uint64_t src = (c0 + (uint64_t)p) * dim4, dst = (uint64_t)slot * dim4;
-                    for (uint32_t c = tl; c < dim4; c += 16) {
-                        nv[dst + c] = ov[src + c];
-                        if (n1) n1[dst + c] = o1[src + c];
-                        if (n2) n2[dst + c] = o2[src + c];
-                    }
-                    if (nhits && tl == 0) nhits[slot] = ohits[c0 + p];
-                } else if (tl == 0) {
-                    atomicOr(&ctr->status, (uint32_t)MEE_STATUS_TABLE_FULL);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rest &= rest - 1;
-        }
-    }
-}
-
-// ---- export (SPEC.md §3) -----------------------------------------------------------------------------------
-// A wave owns a chunk of 1024 consecutive slots.  Pass A: 16 coalesced key loads, ballot + popcount -> occupied
-// count, ONE atomic reserves the chunk's output range.  Pass B: per 64-slot group, ranks from the ballot mask;
-// keys are written by their own lane, rows are copied four at a time (one per 16-lane tile).
-constexpr int kExportGroups = 16;
-
-__global__ __launch_bounds__(256) void export_kernel(const int64_t* __restrict__ tkeys, const float4* __restrict__ values,
-                                                     const float4* __restrict__ s1, const float4* __restrict__ s2,
-                                                     uint64_t begin, uint64_t capacity /* = end of the slot range */, uint32_t dim4,
-                                                     int64_t* keys_out, float4* values_out,
-                                                     float4* s1_out, float4* s2_out, uint64_t cap, OpCounters* op) {
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    constexpr uint64_t kSpan = 64ull * kExportGroups;
-    for (uint64_t c0 = begin + wave * kSpan; c0 < capacity; c0 += n_waves * kSpan) {
-        int64_t k[kExportGroups];
-        uint64_t m[kExportGroups];
-        uint32_t total = 0;
-#pragma unroll
-        for (int j = 0; j < kExportGroups; ++j) {
-            const uint64_t s = c0 + (uint64_t)j * 64 + lane;
-            k[j] = s < capacity ? tkeys[s] : kEmpty;
-            m[j] = __ballot(!reserved_key(k[j]));
-            total += (uint32_t)__popcll(m[j]);
-        }
-        if (!total) continue;  // wave-uniform
-        unsigned long long pos0 = 0;
-        if (lane == 0) pos0 = atomicAdd(&op->n_export, (unsigned long long)total);
-        pos0 = __shfl(pos0, 0);
-#pragma unroll
-        for (int j = 0; j < kExportGroups; ++j) {
-            if (!reserved_key(k[j])) {
-                const uint64_t pos = pos0 + (uint64_t)__popcll(m[j] & ((1ull << lane) - 1));
-                if (keys_out && pos < cap) keys_out[pos] = k[j];
-            }
-            uint64_t rest = m[j];
-            uint64_t done = 0;
-            while (rest) {  // wave-uniform
-                uint64_t mm = rest;
-                int p = -1;
-                for (int q = 0; q <= tile; ++q) {
-                    if (mm) { p = __ffsll((unsigned long long)mm) - 1; mm &= mm - 1; } else p = -1;
-                }
-                const uint64_t pos = pos0 + done + tile;
-                if (p >= 0 && pos < cap) {
-                    const uint64_t src = (c0 + (uint64_t)j * 64 + p) * dim4, dst = pos * dim4;
-                    for (uint32_t c = tl; c < dim4; c += 16) {
-                        if (values_out) values_out[dst + c] = values[src + c];
-                        if (s1_out) s1_out[dst + c] = s1[src + c];
-                        if (s2_out) s2_out[dst + c] = s2[src + c];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rest &= rest - 1;  // x & (x-1) of 0 stays 0
-                done += 4;
-            }
-            pos0 += (uint64_t)__popcll(m[j]);
-        }
-    }
-}
-
 // =========================================================================================================
 // host side
 // =========================================================================================================
-static hipStream_t as_stream(void* s) { return (hipStream_t)s; }
-static int64_t handle_tag_of(const mee_table* t) { return (int64_t)(t->handle_epoch & kHandleEpochMask) << kHandleSlotBits; }
-
 TableView table_view(const mee_table* t) {
     return TableView{t->device, t->keys, t->values, t->nb, t->dim, t->dim4, t->default_value, t->generation, t->s1, t->s2, t->optimizer,
                      t->initializer, t->init_scale, t->init_acc, t->init_seed, &t->ctr->status, t->hits};
 }
 
 // SPEC.md §2: the bucket count is prime, so every double-hashing stride visits all buckets
-static uint64_t next_prime(uint64_t n) {
+uint64_t next_prime(uint64_t n) {
     if (n <= 2) return 2;
     if (!(n & 1)) ++n;
     for (;; n += 2) {
@@ -1311,7 +687,6 @@ static uint64_t next_prime(uint64_t n) {
     }
 }
 
-// `needs_group_table`: the op would overwrite the group table, which a pending mee_apply_prepare still owns
 // the next batch number (insert's election flag carries it: a flag left by an earlier batch reads as "not raised")
 static void next_epoch(mee_table* t, hipStream_t) {
     if (++t->epoch >= kEpochWrap) t->epoch = 1;
@@ -1323,7 +698,7 @@ namespace mee {
 // pending — its backward has not come yet; an eviction, a growth step or a second lookup in between — drops that partition itself: the apply
 // that follows finds nothing prepared and partitions its batch again (same results, one partition launch more).  `stream`: where the mutator
 // runs.  A partition the caller asked for explicitly (mee_apply_prepare, perhaps on another stream) is the caller's to finish or discard.
-static int check_batch(mee_table* t, size_t n, const char* op, void* stream, bool needs_group_table = true, bool drop_pending = true) {
+int check_batch(mee_table* t, size_t n, const char* op, void* stream, bool needs_group_table, bool drop_pending) {
     if (t->prepared_n && needs_group_table) {
         if (!drop_pending || !t->prepared_by_forward)
             return fail(MEE_ERR_INVALID_ARG, "%s: a prepared apply is pending on this table (finish it with mee_apply_* or mee_apply_discard)", op);
@@ -1518,247 +893,6 @@ int mee_clear(mee_table* t, void* stream) {
     return MEE_OK;
 }
 
-// Allocation of one value/state plane in the table's value memory (HBM, or pinned device-mapped host DRAM for a cold tier)
-static hipError_t plane_alloc(uint32_t value_memory, float** p, uint64_t bytes) {
-    return value_memory == MEE_MEM_HOST_PINNED ? hipHostMalloc((void**)p, bytes, hipHostMallocMapped | hipHostMallocPortable)
-                                               : hipMalloc((void**)p, bytes);
-}
-static void plane_free(uint32_t value_memory, float* p) {
-    if (p) { if (value_memory == MEE_MEM_HOST_PINNED) (void)hipHostFree(p); else (void)hipFree(p); }
-}
-
-int mee_reserve(mee_table* t, uint64_t new_capacity, void* stream) {
-    if (!t || new_capacity == 0) return fail(MEE_ERR_INVALID_ARG, "mee_reserve: null table or zero capacity");
-    if (t->prepared_n) {
-        if (!t->prepared_by_forward) return fail(MEE_ERR_INVALID_ARG, "mee_reserve: a prepared apply is pending on this table (finish it with mee_apply_* or mee_apply_discard)");
-        if (int rc = mee_apply_discard(t, stream)) return rc;   // a training forward's partition: the apply that follows partitions its batch again
-    }
-    size_t stored = 0;
-    if (int rc = mee_size(t, &stored, stream)) return rc;
-    const uint64_t nnb = next_prime((new_capacity + kW - 1) / kW), ncap = nnb * kW;
-    if (ncap < stored) return fail(MEE_ERR_INVALID_ARG, "mee_reserve: capacity %llu is below the %zu stored keys", (unsigned long long)ncap, stored);
-    if (nnb == t->nb) return MEE_OK;
-    DeviceGuard g(t->device);
-    hipStream_t st = as_stream(stream);
-    int64_t* nkeys = nullptr; uint32_t* nhits = nullptr;
-    float *nv = nullptr, *n1 = nullptr, *n2 = nullptr;
-    const uint64_t plane = ncap * (uint64_t)t->dim * sizeof(float);
-    hipError_t e = hipMalloc((void**)&nkeys, ncap * sizeof(int64_t));
-    if (e == hipSuccess && t->hits) e = hipMalloc((void**)&nhits, ncap * sizeof(uint32_t));
-    if (e == hipSuccess) e = plane_alloc(t->value_memory, &nv, plane);
-    if (e == hipSuccess && t->s1) e = plane_alloc(t->value_memory, &n1, plane);
-    if (e == hipSuccess && t->s2) e = plane_alloc(t->value_memory, &n2, plane);
-    if (e == hipSuccess) {
-        fill_i64_kernel<<<2048, 256, 0, st>>>(nkeys, ncap, kEmpty);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess && nhits) e = hipMemsetAsync(nhits, 0, ncap * sizeof(uint32_t), st);
-    if (e == hipSuccess) {
-        rehash_kernel<<<grid_for(t->capacity, 256, 1u << 16), 256, 0, st>>>(t->keys, (const float4*)t->values, (const float4*)t->s1, (const float4*)t->s2,
-                                                                          t->hits, t->capacity, nkeys, (float4*)nv, (float4*)n1, (float4*)n2, nhits, nnb,
-                                                                          t->dim4, t->ctr);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) {   // the table is untouched
-        (void)hipFree(nkeys); (void)hipFree(nhits);
-        plane_free(t->value_memory, nv); plane_free(t->value_memory, n1); plane_free(t->value_memory, n2);
-        return fail(e == hipErrorOutOfMemory ? MEE_ERR_OUT_OF_MEMORY : MEE_ERR_HIP, "mee_reserve(%llu slots): %s (old and new planes must fit together)",
-                    (unsigned long long)ncap, hipGetErrorString(e));
-    }
-    (void)hipFree(t->keys); (void)hipFree(t->hits);
-    plane_free(t->value_memory, t->values); plane_free(t->value_memory, t->s1); plane_free(t->value_memory, t->s2);
-    t->keys = nkeys; t->hits = nhits; t->values = nv; t->s1 = n1; t->s2 = n2;
-    t->nb = nnb; t->capacity = ncap;
-    t->table_bytes = ncap * sizeof(int64_t) + (nhits ? ncap * sizeof(uint32_t) : 0) + plane * (1 + (n1 != nullptr) + (n2 != nullptr));
-    ++t->generation;
-    ++t->handle_epoch;
-    return MEE_OK;
-}
-
-static const float* plane_of(const mee_table* t, uint32_t plane) {
-    return plane == 0 ? t->values : plane == 1 ? t->s1 : plane == 2 ? t->s2 : nullptr;
-}
-
-static int find_plane(const mee_table* t, const float* plane, float miss_value, const int64_t* d_keys, size_t n, float* d_out,
-                      uint8_t* d_found, void* stream, bool missing_only = false, bool counted = false, bool rows_only = false,
-                      int64_t* d_slots_out = nullptr, bool unordered = false, bool skip_padding = false, int nt_call = -1 /* this call's cache policy (mee_find_ex); -1: the table's */) {
-    if (n == 0) return MEE_OK;
-    DeviceGuard g(t->device);
-    hipStream_t st = as_stream(stream);
-    int R = t->find_rounds > 0 ? t->find_rounds : (t->dim4 == 16 ? 2 : 1);
-    if (t->dim4 != 16 && R > 4) R = 4;
-    if (t->dim4 != 16 && t->dim4 != 32 && R > 2) R = 2;
-    R = R >= 8 ? 8 : R >= 4 ? 4 : R >= 2 ? 2 : 1;
-    const unsigned fblock = t->find_block == 64 || t->find_block == 128 ? (unsigned)t->find_block : 256u;   // (launch bound of find_kernel: 256)
-    const unsigned grid = grid_for(n, (fblock / 64u) * 4u * (unsigned)R, t->find_grid_cap > 0 ? (unsigned)t->find_grid_cap : (1u << 22));
-#define FIND1(D4, RR, NT) do { if (unordered) hipExtLaunchKernelGGL((find_kernel<D4, RR, NT>), dim3(grid), dim3(256), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, \
-                                        (const int64_t*)t->keys, (const f32x4*)plane, t->nb, d_keys, (uint64_t)n, (f32x4*)d_out, d_found, miss_value, t->dim4, (uint32_t*)nullptr, (int64_t*)nullptr, (int64_t)0); \
-                               else find_kernel<D4, RR, NT><<<grid, fblock, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr); } while (0)
-    const int nt = nt_call >= 0 ? nt_call : t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
-#define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
-    if (skip_padding) {   // owner pass of a padded sharded exchange: EMPTY positions get neither a row nor a found byte (nobody reads them)
-        const bool cached = nt & 4;
-#define FINDP(D4, RR) do { if (cached) find_kernel<D4, RR, 132><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr); \
-                           else find_kernel<D4, RR, 128><<<grid, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr); } while (0)
-        if (t->dim4 == 16) { if (R >= 2) FINDP(16, 2); else FINDP(16, 1); }
-        else if (t->dim4 == 32) { if (R >= 2) FINDP(32, 2); else FINDP(32, 1); }
-        else { if (R >= 2) FINDP(0, 2); else FINDP(0, 1); }
-#undef FINDP
-    } else
-    if (d_slots_out) {   // located find: the plain kernel + one 8-byte store per key
-        // cache policy of `out`: this is the forward of a TRAINING step — the apply that follows sweeps the Infinity Cache before the next
-        // forward, so keeping the dense output cached buys nothing and streaming stores win (136.9 -> 132.5 us per find + Adagrad step)
-        const bool cached_out = t->find_nt >= 0 && (t->find_nt & 4);
-#define FINDL(D4, RR) do { if (cached_out) find_kernel<D4, RR, 68><<<grid, fblock, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out, handle_tag_of(t)); \
-                           else find_kernel<D4, RR, 64><<<grid, fblock, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr, d_slots_out, handle_tag_of(t)); } while (0)
-        if (t->dim4 == 16) { if (R >= 2) FINDL(16, 2); else FINDL(16, 1); }
-        else if (t->dim4 == 32) { if (R >= 2) FINDL(32, 2); else FINDL(32, 1); }
-        else { if (R >= 2) FINDL(0, 2); else FINDL(0, 1); }
-#undef FINDL
-    } else
-    if (missing_only) {
-        const unsigned gm = grid_for(n, 256, 8192);
-#define FMISS(F) find_missing_kernel<F><<<gm, 256, 0, st>>>(t->keys, (const float4*)plane, t->nb, t->dim4, d_keys, n, (float4*)d_out, d_found, t->hits)
-        if (rows_only) FMISS(0); else if (counted) FMISS(3); else FMISS(1);
-#undef FMISS
-    } else if (counted) {  // sampled statistics pass: one key in flight per tile
-        const unsigned g1 = grid_for(n, 16, 1u << 22);
-#define FINDX(D4, NT) find_kernel<D4, 1, NT><<<g1, 256, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, t->hits)
-#define FINDX_D(NT) do { if (t->dim4 == 16) FINDX(16, NT); else if (t->dim4 == 32) FINDX(32, NT); else FINDX(0, NT); } while (0)
-        FINDX_D(20);
-#undef FINDX_D
-#undef FINDX
-    } else
-    if (t->dim4 == 16) { if (R == 8) FIND(16, 8); else if (R == 4) FIND(16, 4); else if (R == 2) FIND(16, 2); else FIND(16, 1); }
-    else if (t->dim4 == 32) { if (R == 4) FIND(32, 4); else if (R == 2) FIND(32, 2); else FIND(32, 1); }
-    else { if (R == 2) FIND(0, 2); else FIND(0, 1); }
-#undef FIND
-#undef FIND1
-    MEE_HIP(hipGetLastError());
-    return MEE_OK;
-}
-
-int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
-    if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find: null argument");
-    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream);
-}
-
-int mee_find_ex(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, uint32_t flags, void* stream) {
-    if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_ex: null argument");
-    if (flags & ~(uint32_t)(MEE_FIND_STREAM_STORES | MEE_FIND_CACHED_STORES | MEE_FIND_STREAM_ROWS | MEE_FIND_STREAM_BUCKETS))
-        return fail(MEE_ERR_INVALID_ARG, "mee_find_ex: unknown flag bits 0x%x", flags);
-    if ((flags & MEE_FIND_STREAM_STORES) && (flags & MEE_FIND_CACHED_STORES))
-        return fail(MEE_ERR_INVALID_ARG, "mee_find_ex: MEE_FIND_STREAM_STORES and MEE_FIND_CACHED_STORES exclude each other");
-    if (flags == MEE_FIND_DEFAULT) return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream);
-    // the kernel's policy bits: 1 = streaming row loads, 2 = streaming bucket loads, 4 = cached stores of the dense output
-    const bool cached_out = (flags & MEE_FIND_CACHED_STORES) || (!(flags & MEE_FIND_STREAM_STORES) && (uint64_t)n * t->dim * 4 <= (128ull << 20));
-    const int nt = (flags & MEE_FIND_STREAM_ROWS ? 1 : 0) | (flags & MEE_FIND_STREAM_BUCKETS ? 2 : 0) | (cached_out ? 4 : 0);
-    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, false, false, false, nullptr, false, false, nt);
-}
-
-}  // extern "C"
-namespace mee {
-// mee_find for the owner side of a padded sharded exchange (meepo_sharded.hip): MEE_EMPTY_KEY positions are padding that nobody reads —
-// they get neither a default row nor a found byte
-int find_skip_padding(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
-    if (!t || (n && (!d_keys || !d_out || !d_found))) return fail(MEE_ERR_INVALID_ARG, "find_skip_padding: null argument");
-    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, false, false, false, nullptr, false, /*skip_padding=*/true);
-}
-}  // namespace mee
-extern "C" {
-
-int mee_find_located(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
-    if (!t || (n && (!d_keys || !d_out || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_located: null argument");
-    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, false, false, false, d_slots_out);
-}
-
-int mee_find_many(const mee_table* t, const mee_find_request* reqs, uint32_t count, void* stream) {
-    if (!t || !reqs) return fail(MEE_ERR_INVALID_ARG, "mee_find_many: null argument");
-    if (count == 0) return MEE_OK;
-    if (count > (uint32_t)kMaxFindRequests) return fail(MEE_ERR_INVALID_ARG, "mee_find_many: %u requests (at most %d per call)", count, kMaxFindRequests);
-    FindMany m{};
-    const int R = t->dim4 == 16 ? 2 : 1;
-    uint64_t blocks = 0, out_bytes = 0;
-    uint32_t used = 0;
-    for (uint32_t q = 0; q < count; ++q) {
-        if (reqs[q].n == 0) continue;
-        if (!reqs[q].d_keys || !reqs[q].d_out) return fail(MEE_ERR_INVALID_ARG, "mee_find_many: request %u has a null buffer", q);
-        m.keys[used] = reqs[q].d_keys; m.out[used] = (f32x4*)reqs[q].d_out; m.found[used] = reqs[q].d_found; m.n[used] = reqs[q].n;
-        m.first_block[used] = (uint32_t)blocks;
-        blocks += (reqs[q].n + 16ull * R - 1) / (16ull * R);
-        out_bytes += (uint64_t)reqs[q].n * t->dim * 4;
-        ++used;
-    }
-    if (used == 0) return MEE_OK;
-    if (blocks > (1ull << 31)) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_find_many: %llu blocks", (unsigned long long)blocks);
-    m.first_block[used] = (uint32_t)blocks; m.count = used;
-    DeviceGuard g(t->device);
-    hipStream_t st = as_stream(stream);
-    const bool cached_out = out_bytes <= (128ull << 20);   // same policy as mee_find, on the total output of the launch
-#define FM(D4, RR) do { if (cached_out) find_many_kernel<D4, RR, 4><<<(unsigned)blocks, 256, 0, st>>>(t->keys, (const f32x4*)t->values, t->nb, m, t->default_value, t->dim4); \
-                        else find_many_kernel<D4, RR, 0><<<(unsigned)blocks, 256, 0, st>>>(t->keys, (const f32x4*)t->values, t->nb, m, t->default_value, t->dim4); } while (0)
-    if (t->dim4 == 16) FM(16, 2); else if (t->dim4 == 32) FM(32, 1); else FM(0, 1);
-#undef FM
-    MEE_HIP(hipGetLastError());
-    return MEE_OK;
-}
-
-int mee_find_unordered(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
-    if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_unordered: null argument");
-    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, false, false, false, nullptr, /*unordered=*/true);
-}
-
-int mee_find_missing(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
-    if (!t || (n && (!d_keys || !d_out || !d_found))) return fail(MEE_ERR_INVALID_ARG, "mee_find_missing: null argument");
-    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, true);
-}
-
-int mee_find_counted(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int missing_only, void* stream) {
-    if (!t || (n && (!d_keys || !d_out || !d_found))) return fail(MEE_ERR_INVALID_ARG, "mee_find_counted: null argument");
-    if (!t->hits) return fail(MEE_ERR_UNSUPPORTED, "mee_find_counted: table was created without MEE_FLAG_TRACK_HITS");
-    return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, missing_only != 0, true);
-}
-
-int mee_find_pooled(const mee_table* t, const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t n_bags, float* d_out,
-                    uint8_t* d_found, int mode, void* stream) {
-    if (!t || (n_bags && (!d_bag_offsets || !d_out)) || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_find_pooled: null argument");
-    if (mode != MEE_POOL_SUM && mode != MEE_POOL_MEAN) return fail(MEE_ERR_INVALID_ARG, "mee_find_pooled: mode must be MEE_POOL_SUM or MEE_POOL_MEAN");
-    if (n_bags == 0) return MEE_OK;
-    DeviceGuard g(t->device);
-    hipStream_t st = as_stream(stream);
-    // n (the number of keys, a host value) only picks the launch shape: mostly short bags -> four bags per wave, long average -> one
-    const bool wave_per_bag = n / n_bags >= 12;
-#define POOLED(D4, U1, U4) do { if (wave_per_bag) find_pooled_kernel<D4, U1, 1><<<grid_for(n_bags, 4, 1u << 20), 256, 0, st>>>(t->keys, (const float4*)t->values, t->nb, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, t->default_value, t->dim4, mode == MEE_POOL_MEAN, nullptr, 1, nullptr, n); \
-                                else find_pooled_kernel<D4, U4, 4><<<grid_for(n_bags, 16, 1u << 20), 256, 0, st>>>(t->keys, (const float4*)t->values, t->nb, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, t->default_value, t->dim4, mode == MEE_POOL_MEAN, nullptr, 1, nullptr, n); } while (0)
-    if (t->dim4 == 16) POOLED(16, 4, 2); else if (t->dim4 == 32) POOLED(32, 2, 1); else POOLED(0, 1, 1);
-#undef POOLED
-    MEE_HIP(hipGetLastError());
-    return MEE_OK;
-}
-
-int mee_hits_scan(mee_table* t, uint32_t min_hits, uint32_t max_hits, int reset, int64_t* d_keys_out, size_t cap, size_t* n_out,
-                  void* stream) {
-    if (!t || !n_out || (cap && !d_keys_out)) return fail(MEE_ERR_INVALID_ARG, "mee_hits_scan: null argument");
-    if (!t->hits) return fail(MEE_ERR_UNSUPPORTED, "mee_hits_scan: table was created without MEE_FLAG_TRACK_HITS");
-    DeviceGuard g(t->device);
-    hipStream_t st = as_stream(stream);
-    zero_words(&t->op->n_export, sizeof(unsigned long long), st);
-    hits_scan_kernel<<<grid_for(t->capacity, 4 * 1024, 4096), 256, 0, st>>>(t->keys, t->hits, t->capacity, min_hits, max_hits, reset, d_keys_out, cap, t->op);
-    MEE_HIP(hipGetLastError());
-    MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
-    MEE_HIP(hipStreamSynchronize(st));
-    *n_out = (size_t)t->h_op->n_export;  // how many keys qualified; min(*n_out, cap) were written
-    return MEE_OK;
-}
-
-int mee_find_plane(const mee_table* t, uint32_t plane, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
-    if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_plane: null argument");
-    const float* p = plane_of(t, plane);
-    if (!p) return fail(MEE_ERR_UNSUPPORTED, "mee_find_plane: plane %u does not exist (optimizer=%u)", plane, t->optimizer);
-    return find_plane(t, p, plane == 0 ? t->default_value : 0.0f, d_keys, n, d_out, d_found, stream);
-}
-
 // `skip` (nullable): positions whose byte is non-zero take no part (they were served by another table of a tiered pair)
 static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found,
                          void* stream, bool claim, const char* name, const uint8_t* skip = nullptr) {
@@ -1895,48 +1029,6 @@ int mee_find_or_insert_missing(mee_table* t, const int64_t* d_keys, size_t n, fl
     return find_or_insert_common(t, d_keys, n, d_out, const_cast<uint8_t*>(d_found), stream, false, "mee_find_or_insert_missing");
 }
 
-int mee_export(const mee_table* t, int64_t* d_keys_out, float* d_values_out, float* d_state1_out, float* d_state2_out,
-               size_t cap, size_t* n_out, void* stream) {
-    if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_export: null argument");
-    return mee_export_range(t, 0, t->capacity, d_keys_out, d_values_out, d_state1_out, d_state2_out, cap, n_out, stream);
-}
-
-int mee_export_range(const mee_table* t, uint64_t slot_begin, uint64_t slot_end, int64_t* d_keys_out, float* d_values_out,
-                     float* d_state1_out, float* d_state2_out, size_t cap, size_t* n_out, void* stream) {
-    if (!t || !n_out) return fail(MEE_ERR_INVALID_ARG, "mee_export: null argument");
-    if (slot_end > t->capacity) slot_end = t->capacity;
-    if (slot_begin > slot_end) return fail(MEE_ERR_INVALID_ARG, "mee_export_range: slot_begin %llu > slot_end %llu", (unsigned long long)slot_begin, (unsigned long long)slot_end);
-    DeviceGuard g(t->device);
-    hipStream_t st = as_stream(stream);
-    zero_words(&t->op->n_export, sizeof(unsigned long long), st);
-    export_kernel<<<grid_for(slot_end - slot_begin, 4 * 64 * kExportGroups, 256 * 16), 256, 0, st>>>(
-        t->keys, (const float4*)t->values, (const float4*)t->s1, (const float4*)t->s2, slot_begin, slot_end, t->dim4, d_keys_out,
-        (float4*)d_values_out, t->s1 ? (float4*)d_state1_out : nullptr, t->s2 ? (float4*)d_state2_out : nullptr, cap, t->op);
-    MEE_HIP(hipGetLastError());
-    MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
-    MEE_HIP(hipStreamSynchronize(st));
-    *n_out = (size_t)t->h_op->n_export;
-    return MEE_OK;
-}
-
-static int read_counters(const mee_table* t, void* stream) {
-    DeviceGuard g(t->device);
-    MEE_HIP(hipMemcpyAsync(t->h_ctr, t->ctr, sizeof(Counters), hipMemcpyDeviceToHost, as_stream(stream)));
-    MEE_HIP(hipStreamSynchronize(as_stream(stream)));
-    return MEE_OK;
-}
-int mee_size(const mee_table* t, size_t* n_out, void* stream) {
-    if (!t || !n_out) return fail(MEE_ERR_INVALID_ARG, "mee_size: null argument");
-    DeviceGuard g(t->device);
-    hipStream_t st = as_stream(stream);
-    zero_words(&t->op->n_export, sizeof(unsigned long long), st);
-    count_kernel<<<grid_for(t->capacity, 256 * 16, 2048), 256, 0, st>>>(t->keys, t->capacity, t->op);
-    MEE_HIP(hipGetLastError());
-    MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
-    MEE_HIP(hipStreamSynchronize(st));
-    *n_out = (size_t)t->h_op->n_export;
-    return MEE_OK;
-}
 int mee_locate(const mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_slots_out, uint8_t* d_found, void* stream) {
     if (!t || (n && (!d_keys || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_locate: null argument");
     if (n > 0xFFFFFFFFull) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_locate: n=%zu exceeds 2^32 - 1", n);
@@ -1944,43 +1036,6 @@ int mee_locate(const mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_s
     DeviceGuard g(t->device);
     remove_locate_kernel<4><<<grid_for(n, 64, 1u << 16), 256, 0, as_stream(stream)>>>(t->keys, t->nb, d_keys, (uint32_t)n, (long long*)d_slots_out, d_found, t->ctr);
     MEE_HIP(hipGetLastError());
-    return MEE_OK;
-}
-
-int mee_table_plane(const mee_table* t, uint32_t plane, void** ptr_out, uint64_t* row_stride_bytes, uint32_t* value_memory) {
-    if (!t || !ptr_out) return fail(MEE_ERR_INVALID_ARG, "mee_table_plane: null argument");
-    const float* p = plane_of(t, plane);
-    if (!p) return fail(MEE_ERR_UNSUPPORTED, "mee_table_plane: plane %u does not exist (optimizer=%u)", plane, t->optimizer);
-    *ptr_out = const_cast<float*>(p);
-    if (row_stride_bytes) *row_stride_bytes = (uint64_t)t->dim * sizeof(float);
-    if (value_memory) *value_memory = t->value_memory;
-    return MEE_OK;
-}
-
-int mee_probe_length(const mee_table* t, const int64_t* d_keys, size_t n, uint64_t* buckets_visited_out, void* stream) {
-    if (!t || !buckets_visited_out || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_probe_length: null argument");
-    *buckets_visited_out = 0;
-    if (n == 0) return MEE_OK;
-    DeviceGuard g(t->device);
-    hipStream_t st = as_stream(stream);
-    zero_words(&t->op->n_export, sizeof(unsigned long long), st);
-    probe_length_kernel<<<grid_for(n, 16, 4096), 256, 0, st>>>(t->keys, t->nb, d_keys, n, t->op);
-    MEE_HIP(hipGetLastError());
-    MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
-    MEE_HIP(hipStreamSynchronize(st));
-    *buckets_visited_out = (uint64_t)t->h_op->n_export;
-    return MEE_OK;
-}
-int mee_status(const mee_table* t, uint32_t* bits_out, void* stream) {
-    if (!t || !bits_out) return fail(MEE_ERR_INVALID_ARG, "mee_status: null argument");
-    if (int rc = read_counters(t, stream)) return rc;
-    *bits_out = t->h_ctr->status;
-    return MEE_OK;
-}
-int mee_clear_status(mee_table* t, void* stream) {
-    if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_clear_status: null table");
-    DeviceGuard g(t->device);
-    zero_words(&t->ctr->status, sizeof(uint32_t), as_stream(stream));
     return MEE_OK;
 }
 
@@ -2055,25 +1110,6 @@ int mee_group_apply_adam(mee_group* g, const int64_t* d_keys, const uint64_t* d_
     return group_apply_common(g, d_keys, d_offsets, d_grads, n, a, stream, "mee_group_apply_adam");
 }
 
-// ---- the embedding-bag collection: pooled lookups of a whole group in one launch, and their backward -----------------------
-int mee_group_find_pooled(mee_group* g, const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t bags_per_table,
-                          float* d_out, uint8_t* d_found, int64_t* d_located_out, int mode, void* stream) {
-    if (!g || (bags_per_table && (!d_bag_offsets || !d_out)) || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_group_find_pooled: null argument");
-    if (mode != MEE_POOL_SUM && mode != MEE_POOL_MEAN) return fail(MEE_ERR_INVALID_ARG, "mee_group_find_pooled: mode must be MEE_POOL_SUM or MEE_POOL_MEAN");
-    if (bags_per_table == 0) return MEE_OK;
-    if (int rc = group_refresh(g, stream)) return rc;
-    DeviceGuard guard(g->device);
-    hipStream_t st = as_stream(stream);
-    const uint64_t n_bags = (uint64_t)g->n_tables * bags_per_table;
-    const bool wave_per_bag = n / n_bags >= 12;
-#define GPOOLED(D4, U1, U4) do { if (wave_per_bag) find_pooled_kernel<D4, U1, 1, true><<<grid_for(n_bags, 4, 1u << 20), 256, 0, st>>>(nullptr, nullptr, 0, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, 0.f, g->dim4, mode == MEE_POOL_MEAN, g->d_desc, bags_per_table, d_located_out, n); \
-                                 else find_pooled_kernel<D4, U4, 4, true><<<grid_for(n_bags, 16, 1u << 20), 256, 0, st>>>(nullptr, nullptr, 0, d_keys, d_bag_offsets, n_bags, (float4*)d_out, d_found, 0.f, g->dim4, mode == MEE_POOL_MEAN, g->d_desc, bags_per_table, d_located_out, n); } while (0)
-    if (g->dim4 == 16) GPOOLED(16, 4, 2); else if (g->dim4 == 32) GPOOLED(32, 2, 1); else GPOOLED(0, 1, 1);
-#undef GPOOLED
-    MEE_HIP(hipGetLastError());
-    return MEE_OK;
-}
-
 int mee_group_apply_adagrad_pooled(mee_group* g, const int64_t* d_keys, const uint64_t* d_bag_offsets, size_t bags_per_table,
                                    const float* d_bag_grads, const uint32_t* d_grad_index, const int64_t* d_located, size_t n, float lr,
                                    float eps, void* stream) {
@@ -2108,40 +1144,6 @@ int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* strea
     return MEE_OK;
 }
 
-// The training forward: mee_find_located whose launch also carries mee_apply_prepare for the SAME keys (the partition half of the bucketed
-// apply, run by the launch's first blocks beside the row gather).  (Table without optimizer: plain mee_find_located.)
-int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
-    if (!t || (n && (!d_keys || !d_out || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_located_prepare: null argument");
-    if (t->prepared_n) return fail(MEE_ERR_INVALID_ARG, "mee_find_located_prepare: a prepared apply is already pending");
-    if (n == 0) return MEE_OK;
-    if (t->optimizer == MEE_OPT_NONE) return mee_find_located(t, d_keys, n, d_out, d_found, d_slots_out, stream);
-    if (n > t->max_batch) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_find_located_prepare: n=%zu exceeds config.max_batch=%llu", n, (unsigned long long)t->max_batch);
-    DeviceGuard g(t->device);
-    hipStream_t st = as_stream(stream);
-    uint32_t apply_grid, nbk;
-    bool apply_full;
-    const uint32_t nbk_hash = bucket_count_for(t, n, &apply_grid, &nbk, &apply_full);
-    uint32_t part_blocks, per_block;
-    part_geometry((uint32_t)n, kFindPrepareThreads, part_blocks, per_block);
-    const int R = t->dim4 == 16 || t->dim4 == 32 ? 2 : 1;
-    const unsigned find_cap = t->prepare_debug >> 8;
-    const unsigned find_blocks = grid_for(n, (kFindPrepareThreads / 64) * 4u * (unsigned)R, find_cap ? find_cap : 1u << 22);
-    const bool separate = t->prepare_debug & 1;
-    if (separate) part_blocks = 0;
-    const bool cached_out = t->find_nt >= 0 && (t->find_nt & 4);
-#define FINDLP1(D4, RR, NT) find_prepare_kernel<D4, RR, NT><<<part_blocks + find_blocks, kFindPrepareThreads, sizeof(PartHot) + nbk * 4, st>>>(t->keys, (const f32x4*)t->values, t->nb, d_keys, n, (f32x4*)d_out, d_found, \
-        t->default_value, t->dim4, d_slots_out, handle_tag_of(t), part_blocks, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op)
-#define FINDLP(D4, RR) do { if (cached_out) FINDLP1(D4, RR, 68); else FINDLP1(D4, RR, 64); } while (0)
-    if (t->dim4 == 16) FINDLP(16, 2); else if (t->dim4 == 32) FINDLP(32, 2); else FINDLP(0, 1);
-#undef FINDLP
-#undef FINDLP1
-    MEE_HIP(hipGetLastError());
-    if (separate) { if (int rc = bucket_apply_prepare(t, d_keys, (uint32_t)n, st)) return rc; }
-    else { t->part_blocks = part_blocks; t->part_per_block = per_block; t->part_nbk = nbk; t->part_nbk_hash = nbk_hash; t->part_grid = apply_grid; t->part_full = apply_full; }
-    t->prepared_n = n; t->prepared_keys = d_keys; t->prepared_by_forward = true;
-    return MEE_OK;
-}
-
 int mee_find_or_insert_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
     if (!t || (n && (!d_keys || !d_out || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_or_insert_located_prepare: null argument");
     if (t->optimizer == MEE_OPT_NONE) return mee_find_or_insert_located(t, d_keys, n, d_out, d_found, d_slots_out, stream);
@@ -2160,18 +1162,6 @@ int mee_find_or_insert_located_prepare(mee_table* t, const int64_t* d_keys, size
     return MEE_OK;
 }
 
-#if MEE_FIND_TIMELINE
-int mee_debug_find_timeline(unsigned long long* host_out, uint64_t n_words) {   // first call arms the buffer, later calls read it
-    static unsigned long long* buf = nullptr;
-    if (!buf) {
-        if (hipMalloc((void**)&buf, 16384 * 4 * 8) != hipSuccess) return 1;
-        (void)hipMemset(buf, 0, 16384 * 4 * 8);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_find_dbg), &buf, sizeof buf);
-        return 0;
-    }
-    return hipMemcpy(host_out, buf, n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
-}
-#endif
 int mee_apply_discard(mee_table* t, void* stream) {
     if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_apply_discard: null table");
     if (!t->prepared_n) return MEE_OK;
@@ -2280,3 +1270,4 @@ int mee_dedup_keys(mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_uni
 }
 
 }  // extern "C"
+

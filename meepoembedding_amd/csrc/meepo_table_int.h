@@ -170,4 +170,26 @@ int bucket_dedup_keys(mee_table* t, const int64_t* d_keys, uint32_t n, int64_t* 
 int bucket_assign(mee_table* t, float* plane, const int64_t* d_keys, const float* d_values, uint32_t n, uint8_t* d_found, hipStream_t st);
 uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out = nullptr, uint32_t* nbk_total_out = nullptr, bool* full_out = nullptr);
 
+// ---- host helpers the table's translation units share (meepo_table.hip, meepo_find.hip, meepo_export.hip) ------------------------------
+inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+inline int64_t handle_tag_of(const mee_table* t) { return (int64_t)(t->handle_epoch & kHandleEpochMask) << kHandleSlotBits; }
+inline const float* plane_of(const mee_table* t, uint32_t plane) { return plane == 0 ? t->values : plane == 1 ? t->s1 : plane == 2 ? t->s2 : nullptr; }
+// Allocation of one value/state plane in the table's value memory (HBM, or pinned device-mapped host DRAM for a cold tier)
+inline hipError_t plane_alloc(uint32_t value_memory, float** p, uint64_t bytes) {
+    return value_memory == MEE_MEM_HOST_PINNED ? hipHostMalloc((void**)p, bytes, hipHostMallocMapped | hipHostMallocPortable)
+                                               : hipMalloc((void**)p, bytes);
+}
+inline void plane_free(uint32_t value_memory, float* p) {
+    if (p) { if (value_memory == MEE_MEM_HOST_PINNED) (void)hipHostFree(p); else (void)hipFree(p); }
+}
+// (meepo_table.hip)
+uint64_t next_prime(uint64_t n);                                   // SPEC.md §2: the bucket count is prime
+void zero_words(void* p, size_t bytes, hipStream_t st);            // zeroing of the small device-side counter blocks (a kernel, not a memset node)
+void fill_keys(int64_t* p, uint64_t n, int64_t v, hipStream_t st); // a key plane set to one value
+int check_batch(mee_table* t, size_t n, const char* op, void* stream, bool needs_group_table = true, bool drop_pending = true);
+// (meepo_find.hip)
+int find_plane(const mee_table* t, const float* plane, float miss_value, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream,
+               bool missing_only = false, bool counted = false, bool rows_only = false, int64_t* d_slots_out = nullptr, bool unordered = false,
+               bool skip_padding = false, int nt_call = -1);
+
 }  // namespace mee
