@@ -330,6 +330,165 @@ def tier_1b_point(synth, dim, dev, batch, log, hot_keys=800_000_000, cold_keys=2
     return res
 
 
+def _host_ram_available_gb() -> float:
+    """what this process may still take of the host's RAM: MemAvailable, cut by the cgroup's limit when there is one"""
+    avail = 0.0
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = float(ln.split()[1]) * 1024 / 1e9
+    except OSError:
+        pass
+    for mx, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                    ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            m = open(mx).read().strip()
+            if m != "max" and int(m) < (1 << 60):
+                left = (int(m) - int(open(cur).read().strip())) / 1e9
+                avail = min(avail, left) if avail else left
+        except (OSError, ValueError):
+            pass
+    return avail
+
+
+def tier_share_point(synth, dim, dev, batch, log, keys=1_250_000_000, hot_keys=800_000_000, train_cold_cap=220_000_000, load=0.85, rounds=8):
+    """configs[4]'s per-GPU share on ONE GPU: 10B keys over 8 GPUs = 1.25B keys, dim 64: 800M of them in an HBM table, 450M with their rows in
+    pinned host DRAM (115 GB; their key plane stays in HBM), both with hit counters.  A Zipf(1.05) stream whose popular ranks are scattered
+    over ALL key indices (a third of the popular keys start cold); observe -> rebalance() rounds until the cold share of the lookups stops
+    falling; lookups/s, cold share and PCIe rate before and after.  Then one find + sparse-Adagrad step on a training pair — rows AND
+    accumulators: 520 B per slot, so the pair that fits the same HBM holds 380M hot keys, and as many cold keys as the host RAM left."""
+    from meepoembedding_amd import LookupTable, OPT_ADAGRAD, _lib
+    from meepoembedding_amd.tiered import TieredLookupTable
+    chunk = 1 << 20
+    cold_keys = keys - hot_keys
+    res = {"keys_wanted": keys, "hot_keys_in_hbm": hot_keys, "load_factor": load, "batch": batch, "dim": dim}
+    ram = _host_ram_available_gb()
+    need = cold_keys * dim * 4 / 1e9
+    res["host_ram_available_gb"] = round(ram, 1)
+    res["cold_rows_wanted_gb"] = round(need, 1)
+    if ram and need > ram * 0.5:   # never pin more than half of what the box may take: pinned pages cannot be reclaimed, and a box that runs out of memory dies
+        cold_keys = max(chunk, int(ram * 0.5 * 1e9 / (dim * 4)) // chunk * chunk)
+        res["scaled_down"] = f"the box offers {ram:.0f} GB of host RAM: {cold_keys} cold keys ({cold_keys * dim * 4 / 1e9:.0f} GB pinned) instead of {keys - hot_keys}"
+        log("tier share: " + res["scaled_down"])
+    keys = hot_keys + cold_keys
+    res["keys"] = keys
+    res["cold_keys_in_pinned_host"] = cold_keys
+    t0 = time.time()
+    hot = LookupTable(int(hot_keys / load), dim, device=dev, max_batch=4 * chunk, track_hits=True)
+    cold = LookupTable(int(cold_keys / load), dim, device=dev, max_batch=4 * chunk, value_memory=_lib.MEM_HOST_PINNED, track_hits=True)
+    for tab, lo, hi_ in ((hot, 0, hot_keys), (cold, hot_keys, keys)):   # key index i: the first hot_keys indices land in HBM, the rest in the cold tier
+        for s_ in range(lo, hi_, chunk):
+            k = synth.keys_t(1, s_, min(chunk, hi_ - s_), dev)
+            tab.insert(k, synth.rows_t(k, dim, 2))
+            if (s_ - lo) // chunk % 128 == 127:
+                torch.cuda.synchronize(dev)
+                log(f"tier share: {s_ + chunk - lo} of {hi_ - lo} keys of the {'HBM' if tab is hot else 'host-DRAM'} tier placed ({time.time() - t0:.0f}s)")
+    torch.cuda.synchronize(dev)
+    res["populate_s"] = round(time.time() - t0, 1)
+    res["hbm_gb"] = round((hot.table_bytes + cold_keys / load * 8 + (hot_keys + cold_keys) / load * 4) / 1e9, 1)
+    log(f"tier share: {keys} keys placed in {res['populate_s']}s (hot {hot.table_bytes / 1e9:.0f} GB HBM, cold rows {cold_keys * dim * 4 / 1e9:.0f} GB pinned host)")
+    t = TieredLookupTable(hot, cold, hot_key_limit=hot_keys, sample_every=4, promote_threshold=2)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    mult = 2_654_435_761   # odd: popular ranks are scattered over all key indices (where two ranks collide they merge)
+
+    def zipf_batch(n_keys):
+        al = 1.05
+        u = torch.rand(batch, device=dev, generator=g, dtype=torch.float64)
+        hi = float(n_keys) ** (1 - al)
+        r = ((1 + u * (hi - 1)) ** (1 / (1 - al))).floor().to(torch.int64).clamp_(1, n_keys) - 1
+        idx = (r * mult + 12345) % n_keys
+        return synth.mix64_t((idx + 1) * synth._s64(synth._GOLDEN) + synth._s64(1))
+
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def measure(tt, hot_t, n_keys, n=20):
+        bs = [zipf_batch(n_keys) for _ in range(n)]
+        o_, f_ = tt.find(bs[0])
+        assert bool(f_.all()) and torch.equal(o_[:2048], synth.rows_t(bs[0][:2048], dim, 2)), "tier lookup returned wrong rows"
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for b in bs:
+            tt.find(b)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        cs = sum(1.0 - float(hot_t.find(b)[1].float().mean()) for b in bs[:4]) / 4
+        us = e0.elapsed_time(e1) * 1e3 / n
+        return {"us_per_find": us, "lookups_per_s": batch / us * 1e6, "cold_fraction": cs, "cold_rows_over_pcie_GBps": batch * cs * dim * 4 / us / 1e3}
+
+    res["before_rebalance"] = measure(t, hot, keys)
+    log(f"tier share: before rebalance {res['before_rebalance']}")
+    hist = []
+    for rnd in range(1, rounds + 1):
+        for _ in range(24):
+            t.find(zipf_batch(keys))          # observation window (every 4th hot lookup sampled, all cold hits counted)
+        t1 = time.time()
+        p_, d_ = t.rebalance(max_moves=4 * chunk)
+        torch.cuda.synchronize(dev)
+        row = measure(t, hot, keys)
+        row.update({"round": rnd, "promoted": int(p_), "demoted": int(d_), "rebalance_ms": round((time.time() - t1) * 1e3, 1)})
+        hist.append(row)
+        log(f"tier share: round {rnd}: {row}")
+        if len(hist) >= 3 and hist[-2]["cold_fraction"] - row["cold_fraction"] < 0.02 * max(row["cold_fraction"], 1e-9):
+            break   # plateau: less than 2 % (relative) off the cold share in a round
+    res["rebalance_rounds"] = hist
+    res["after_rebalance"] = {k: v for k, v in hist[-1].items() if k not in ("round", "promoted", "demoted", "rebalance_ms")}
+    assert hot.status() == 0 and cold.status() == 0
+    hot.close(); cold.close()
+    del t, hot, cold
+    torch.cuda.empty_cache()
+    # ---- the training pair: values + Adagrad accumulators ----
+    th_keys = min(380_000_000, hot_keys * 19 // 40)
+    ram = _host_ram_available_gb()
+    tc_keys = min(keys - th_keys, max(chunk, int(ram * 0.5 * 1e9 / (dim * 8)) // chunk * chunk)) if ram else 120_000_000
+    if train_cold_cap:   # (default: no more pinned host memory than the lookup tables above took — a box shares its host with seven others)
+        tc_keys = min(tc_keys, train_cold_cap)
+    t0 = time.time()
+    hot = LookupTable(int(th_keys / load), dim, device=dev, max_batch=chunk, optimizer=OPT_ADAGRAD)
+    cold = LookupTable(int(tc_keys / load), dim, device=dev, max_batch=chunk, optimizer=OPT_ADAGRAD, value_memory=_lib.MEM_HOST_PINNED)
+    tk = th_keys + tc_keys
+    for tab, lo, hi_ in ((hot, 0, th_keys), (cold, th_keys, tk)):
+        for s_ in range(lo, hi_, chunk):
+            k = synth.keys_t(1, s_, min(chunk, hi_ - s_), dev)
+            tab.insert(k, synth.rows_t(k, dim, 2))
+            if (s_ - lo) // chunk % 128 == 127:
+                torch.cuda.synchronize(dev)
+                log(f"tier share: {s_ + chunk - lo} of {hi_ - lo} keys of the {'HBM' if tab is hot else 'host-DRAM'} tier placed ({time.time() - t0:.0f}s)")
+    torch.cuda.synchronize(dev)
+    tt = TieredLookupTable(hot, cold, hot_key_limit=th_keys)
+    tr = {"hot_keys_in_hbm": th_keys, "cold_keys_in_pinned_host": tc_keys, "bytes_per_slot": 8 + 2 * dim * 4, "populate_s": round(time.time() - t0, 1),
+          "cold_rows_and_accumulators_gb": round(tc_keys * dim * 8 / 1e9, 1),
+          "note": ("the whole share" if th_keys + tc_keys >= keys else f"rows + accumulators of the whole share need {(keys - th_keys) * dim * 8 / 1e9:.0f} GB of host RAM; this is the pair that fits")}
+    grads = torch.randn(batch, dim, device=dev) * 0.01
+    for name, sk in (("zipf_scattered", True), ("zipf_hot_first", False)):
+        if sk:
+            bs = [zipf_batch(tk) for _ in range(8)]
+        else:
+            bs = lookup_batches(synth, tk, batch, 8, "zipf", dev, seed=5)   # popular ranks = the first key indices = the HBM tier
+        cs = sum(1.0 - float(hot.find(b)[1].float().mean()) for b in bs[:4]) / 4
+        cold_distinct = sum(int(torch.unique(b[hot.find(b)[1] == 0]).numel()) for b in bs[:4]) / 4
+        per = []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for i in range(10):
+                tt.find(bs[i % 8])
+                tt.apply_adagrad(bs[i % 8], grads, lr=0.01)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            per.append(e0.elapsed_time(e1) * 1e3 / 10)
+        us = sorted(per)[1]
+        tr[name] = {"us_per_find_plus_adagrad_step": us, "keys_per_s": batch / us * 1e6, "cold_fraction": cs,
+                    "cold_distinct_keys_per_batch": cold_distinct,
+                    # the find reads a row per cold occurrence; the update reads and writes row + accumulator once per distinct cold key
+                    "cold_bytes_over_pcie_GBps": (batch * cs + 4 * cold_distinct) * dim * 4 / us / 1e3}
+        log(f"tier share: training pair, {name}: {tr[name]}")
+    assert hot.status() == 0 and cold.status() == 0
+    res["train_pair"] = tr
+    hot.close(); cold.close()
+    return res
+
+
 def two_stream_extra(table, batches, dim, dev, bpl, launches=400):
     """The same find launches issued round-robin on TWO caller streams (two independent request queues, own output
     buffers): consecutive launches may overlap each other's latency floor.  Informational — the headline keeps every
@@ -593,6 +752,10 @@ def main():
     ap.add_argument("--tier-1b", action="store_true",
                     help="N=1 only: after the headline, also measure the LITERAL 1B-key dim-64 table on this one GPU through the hot/cold tier "
                          "(800M keys in HBM + 200M keys with rows in pinned host DRAM; needs ~270 GB of HBM and ~55 GB of pinned host memory); result under `also`")
+    ap.add_argument("--tier-share", action="store_true",
+                    help="N=1: also run configs[4]'s per-GPU share (1.25B keys: 800M in HBM + 450M rows in pinned host DRAM, Zipf, rebalance rounds; "
+                         "needs ~260 GB of HBM and ~115 GB of host RAM — scaled to what the box has) -> also.tier_share_one_gpu")
+    ap.add_argument("--tier-share-keys", type=str, default="1250000000,800000000", help="--tier-share: total keys, keys in HBM[, cap on the cold keys of the training pair] (smaller = a rehearsal)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -664,6 +827,7 @@ def main():
     outs = [out] + [torch.empty_like(out) for _ in range(n_out - 1)]
     founds = [found] + [torch.empty_like(found) for _ in range(n_out - 1)]
     store_hint = None   # the caller's cache-policy hint for the rotating case, chosen by a short probe below
+    find_flags = None   # the cache policy this request queue passes with every call (mee_find_ex); None = the library's default rule
 
     if sharded:
         # each in-flight step owns a stream and a Router (partition workspace); the local find is workspace-free, so
@@ -828,7 +992,6 @@ def main():
             table.apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10, slots=slots)
             return o_, f_
     else:
-        find_flags = None   # the cache policy this request queue passes with every call (mee_find_ex); None = the library's default rule
         if n_out > 1:
             # a caller whose result buffers rotate knows that nothing re-reads them from cache: MEE_FIND_STREAM_STORES with every call is its hint
             # — the library's own rule only sees one call's size (64 MB: cached stores) — and one whose keys are uniform over a table far larger
@@ -1143,6 +1306,14 @@ def main():
                 res.setdefault("also", {})["tier_1b_keys_one_gpu"] = tier_1b_point(synth, dim, dev, batch, log)
             except Exception as e:  # noqa: BLE001
                 res.setdefault("also", {})["tier_1b_keys_one_gpu"] = {"error": repr(e)}
+        if not sharded and args.tier_share:
+            try:
+                table.close()
+                batches = None
+                torch.cuda.empty_cache()
+                res.setdefault("also", {})["tier_share_one_gpu"] = tier_share_point(synth, dim, dev, 1 << 20, log, *[int(x) for x in args.tier_share_keys.split(",")])
+            except Exception as e:  # noqa: BLE001
+                res.setdefault("also", {})["tier_share_one_gpu"] = {"error": repr(e)}
         os.write(result_fd, (json.dumps(res) + "\n").encode())
     if sharded:
         torch.cuda.synchronize(dev)
