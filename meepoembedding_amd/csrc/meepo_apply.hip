@@ -927,13 +927,21 @@ __device__ __forceinline__ uint32_t bucket_entry_at(const ApplyLds& L, uint32_t 
     return L.seg_at[k] + (gi - L.seg_first[k]);
 }
 
-// A split bucket in the LEAN kernel (below): its own block takes it, one key at a time in increasing key order — pick the smallest key not yet
+// how many blocks share a split bucket of the LEAN kernel (its own block and the helpers behind it), and which of them takes a key
+constexpr uint32_t kSlowHelpers = 64;
+__device__ __forceinline__ uint32_t slow_shares(uint32_t size, uint32_t nbk) { return min(min(kSlowHelpers + 1, nbk), (size + 255u) / 256u); }
+__device__ __forceinline__ uint32_t slow_share_of(int64_t key, uint32_t n_sub) { return (uint32_t)__umul64hi(mix64b((uint64_t)key), (uint64_t)n_sub); }
+
+// A split bucket in the LEAN kernel (below): its own block and up to 64 helpers — the blocks of the buckets behind it, once they are done with
+// their own — share its KEYS by a second hash (slow_share_of); each takes its keys one at a time in increasing key order — pick the smallest key not yet
 // done (one scan of the bucket's keys), add up its gradient rows (a second scan finds them, 1024 entries at a time; 32 tiles sum, shuffles and
 // LDS combine), update its row once.  O(distinct keys x bucket size) key reads from L2: a bucket of 15 000 positions around one hot key
-// takes ~2 ms.  This is the price of the first skewed batch of a stream, paid once: the keys it reports as hot and the slab count it leaves in
+// took 2-4 ms with ONE block (and every batch the host had queued before the first one's report came back paid it again); shared, the hot
+// key's block sets the time: ~0.1-0.3 ms.  This is the price of the first skewed batches of a stream: the keys they report as hot and the slab count left in
 // the pinned host word switch the following batches to the FULL kernel.  No pending records, no merge, no scratch.
 template <int KIND, int DIM4, bool LOCATED, bool GROUPED>
-__device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t size, const uint32_t parity, const GroupDesc* gdesc) {
+__device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t size, const uint32_t parity, const GroupDesc* gdesc,
+                                            const uint32_t sub, const uint32_t n_sub) {
     static_assert(!GROUPED || LOCATED, "a group's batch names rows, not keys");
     const uint32_t t = threadIdx.x;
     const int lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6;
@@ -949,8 +957,9 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
         __syncthreads();
         unsigned long long mn = ~0ull;
         for (uint32_t e = t; e < size; e += kApplyThreads) {
-            const unsigned long long bkey = (unsigned long long)bk.pkey[bucket_entry_at(L, e)] ^ kBias;
-            if ((!have_last || bkey > last) && bkey < mn) mn = bkey;
+            const int64_t k = bk.pkey[bucket_entry_at(L, e)];
+            const unsigned long long bkey = (unsigned long long)k ^ kBias;
+            if ((!have_last || bkey > last) && bkey < mn && slow_share_of(k, n_sub) == sub) mn = bkey;
         }
         if (mn != ~0ull) atomicMin(&L.kmin, mn);
         __syncthreads();
@@ -1084,9 +1093,25 @@ __global__ __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES) void bkt_apply_kern
             run_units<KIND, DIM4, LOCATED, GROUPED, false>(L, A, bk, parity, runs, size0, 0u, 0u, gdesc);
         } else {
             seg_scan(L, runs, threadIdx.x);
-            slow_bucket<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, size0, parity, gdesc);
+            slow_bucket<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, size0, parity, gdesc, 0u, slow_shares(size0, A.nbk));
             // the stream is skewed: the FULL kernel from now on, with as many agents as this batch had slabs (the block that finishes last leaves the sum)
             if (threadIdx.x == 0) { const uint32_t mine = (size0 + kSlab - 1) / kSlab; *A.h_slabs = atomicAdd(&bk.seq[4], mine) + mine; }
+        }
+        if (__builtin_amdgcn_readfirstlane(parity ? hdr.w : hdr.z) != 0) {   // (block-uniform) the batch has a split bucket somewhere
+            // helper duty: block x is share j >= 1 of the split bucket x - j (mod nbk).  Every wave looks at the same 64 buckets in front of
+            // the block's own (one load per lane, L2-resident), so the ballot is the same in every wave and the loop below is block-uniform.
+            const uint32_t nbk = A.nbk, j = (threadIdx.x & 63u) + 1u;
+            const uint32_t y = (blockIdx.x + nbk - j % nbk) % nbk;
+            const uint32_t ty = j < nbk ? bk.tot[parity * bk.n_buckets_max + y] : 0u;
+            unsigned long long duty = __ballot(ty > kBucketCap && j < slow_shares(ty, nbk));
+            while (duty) {
+                const uint32_t jj = (uint32_t)__builtin_ctzll(duty);
+                duty &= duty - 1;
+                const uint32_t yy = __builtin_amdgcn_readlane(y, jj), tyy = __builtin_amdgcn_readlane(ty, jj);
+                __syncthreads();   // (whatever this block did before is done with the LDS)
+                seg_scan(L, seg_load(A, bk, yy, threadIdx.x), threadIdx.x);
+                slow_bucket<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, tyy, parity, gdesc, jj + 1u, slow_shares(tyy, nbk));
+            }
         }
     }
 }

@@ -31,7 +31,7 @@ def timeit(fn, reps=30):
     return sorted(ts)[1]
 
 
-for dist in ("uniform", "zipf"):
+for dist in os.environ.get("MEE_DEDUP_DIST", "uniform,zipf").split(","):
     bs = bench.lookup_batches(synth, keys_n, batch, 8, dist, dev, seed=3)
     for path, label in (((-1, "bucketed"),) if os.environ.get("MEE_DEDUP_ONLY_NEW") else ((-1, "bucketed"), (0, "group table (round 2)"))):
         t.set_tuning("dedup_path", path)
