@@ -22,6 +22,10 @@
 
 namespace mee {
 
+#ifndef MEE_DD_BLOCKS_FROM
+#define MEE_DD_BLOCKS_FROM 100000   // (x 512K keys) batches from this size on are partitioned by 256 blocks instead of 128.  Measured at 1M keys (= 2): the partition
+// gets faster (23.4 -> 20.8 us uniform, 27.4 -> 22.6 Zipf) and the consumers lose more than that to twice the runs per bucket (dedup_keys 70.2 -> 75.6 us): off
+#endif
 constexpr int kDedupThreads = 256;
 constexpr int kDedupWaves = kDedupThreads / 64;
 constexpr uint32_t kDedupSlots = 1024;        // LDS hash table of one pass
@@ -166,6 +170,7 @@ struct DedupArgs {
     OpCounters* op;
     uint32_t* h_slabs;
     int64_t* uniq; int64_t* inverse;   // dedup
+    uint32_t size_from_runs;           // the bucket totals were not computed (assign without hot keys' buckets): a bucket's size is the sum of its runs
 };
 
 // A hot key's own bucket (b >= nbk_hash: the partition sent exactly ONE key there) needs no table: every entry is that key.  It is cut into
@@ -197,13 +202,20 @@ __device__ __forceinline__ HotPlan hot_plan(DedupLds& L, const BucketScratch& bk
     return P;
 }
 
+// which unit a block takes: the windows of the hot keys' buckets — the longest units: 4096 entries each — are the FIRST blocks of the grid, the
+// buckets follow (unit numbers: buckets [0, nbk), windows from nbk on)
+__device__ __forceinline__ uint32_t dd_unit(const DedupArgs& A) {
+    const uint32_t w = gridDim.x - A.nbk;
+    return blockIdx.x < w ? A.nbk + blockIdx.x : blockIdx.x - w;
+}
+
 // the block's bucket: (size, parity) — ONE round trip brings the bucket's totals (both copies), the copy selector, the hot keys' totals, the
 // bucket's runs in the partition blocks' slices and (PREFIX: the dedup) the totals of the hash buckets in front of this one.  `P.H` = the
 // non-empty hot keys' buckets (their keys are numbered first); a block beyond the buckets (blockIdx >= nbk) gets its window of a hot key's
 // bucket in `P` instead.  `before` (PREFIX) = the positions in the hash buckets in front of this one.
 template <bool PREFIX>
 __device__ __forceinline__ uint32_t dd_bucket(DedupLds& L, const BucketScratch& bk, const DedupArgs& A, uint32_t& parity, HotPlan& P, uint32_t& before) {
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = dd_unit(A);
     const bool own = b < A.nbk, hash = b < A.nbk_hash;
     const uint32_t tot0 = own ? bk.tot[b] : 0u, tot1 = own ? bk.tot[bk.n_buckets_max + b] : 0u;
     const uint32_t n_hot = A.nbk - A.nbk_hash;
@@ -235,8 +247,9 @@ __device__ __forceinline__ uint32_t dd_bucket(DedupLds& L, const BucketScratch& 
             if ((threadIdx.x & 63) == 0) L.stk_val[threadIdx.x >> 6] = mine;
         }
     }
-    if (own && size > kBucketCap && threadIdx.x == 0) { const uint32_t mine = (size + kSlab - 1) / kSlab; *A.h_slabs = P.units + atomicAdd(&bk.seq[4], mine) + mine; }   // a skewed stream: hot keys get buckets of their own next time
     __syncthreads();
+    if (A.size_from_runs && own) size = __builtin_amdgcn_readfirstlane(L.seg_first[kPartBlocksMax]);   // (dd_seg_scan left the sum of the runs there)
+    if (own && size > kBucketCap && threadIdx.x == 0) { const uint32_t mine = (size + kSlab - 1) / kSlab; *A.h_slabs = P.units + atomicAdd(&bk.seq[4], mine) + mine; }   // a skewed stream: hot keys get buckets of their own next time
     if (PREFIX && own) for (int w = 0; w < kDedupWaves; ++w) before += L.stk_val[w];
     __syncthreads();
     return size;
@@ -248,7 +261,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
     HotPlan P;
     const uint32_t size = dd_bucket<true>(L, bk, A, parity, P, before);
     if (size == 0) return;
-    if (blockIdx.x >= A.nbk) {   // ---- a window of a hot key's own bucket: every entry is that key, its number is P.rank
+    if (dd_unit(A) >= A.nbk) {   // ---- a window of a hot key's own bucket: every entry is that key, its number is P.rank
         const uint32_t lo = P.win * kHotWindow, hi = min(size, lo + kHotWindow);
         if (P.win == 0 && threadIdx.x == 0) {
             const int64_t key = bk.pkey[dd_entry_at(L, 0)];
@@ -295,16 +308,21 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
     });
 }
 
-// the partition of a dedup: the same sort as an apply's, and — while the keys are in registers anyway — the output's padding: d_uniq[i] = EMPTY
+// the partition of a dedup or an assign: the same sort as an apply's, and — while the keys are at hand anyway — the output's padding: d_uniq[i] = EMPTY
 // for every i (the dedup kernel overwrites the first n_unique of them), d_inverse[i] = miss_index for reserved keys (they are in no bucket)
 __global__ __launch_bounds__(1024) void bkt_sort_dedup_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk_hash, uint32_t nbk, uint32_t per_block, BucketScratch bk,
-                                                              uint32_t* status, OpCounters* op, int64_t* __restrict__ uniq, int64_t* __restrict__ inverse, int64_t miss_index, uint32_t tot_atomics) {
+                                                              uint32_t* status, OpCounters* op, int64_t* __restrict__ uniq, int64_t* __restrict__ inverse, int64_t miss_index,
+                                                              uint8_t* __restrict__ found, uint32_t tot_atomics) {
     extern __shared__ unsigned long long part_lds[];
     __shared__ unsigned long long wsum[1024 / 64];
     const uint32_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
-        uniq[i] = kEmpty;
-        if (reserved_key(keys[i])) inverse[i] = miss_index;
+    if (uniq) {
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+            uniq[i] = kEmpty;
+            if (reserved_key(keys[i])) inverse[i] = miss_index;
+        }
+    } else if (found) {   // assign: the found bytes of the positions that are in no bucket (reserved keys): 0
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) if (reserved_key(keys[i])) found[i] = 0;
     }
     PartHot* hot = reinterpret_cast<PartHot*>(part_lds);
     sort_role<1024>(keys, n, nbk_hash, nbk, per_block, blockIdx.x, gridDim.x, bk, status, op, reinterpret_cast<uint32_t*>(hot + 1), wsum, hot, tot_atomics != 0);
@@ -326,7 +344,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
     const uint32_t size = dd_bucket<false>(L, bk, A.d, parity, P, before);
     if (size == 0) return;
     const uint32_t dim4 = DIM4 ? DIM4 : A.dim4;
-    if (blockIdx.x >= A.d.nbk) {   // ---- a window of a hot key's own bucket: every entry is that key
+    if (dd_unit(A.d) >= A.d.nbk) {   // ---- a window of a hot key's own bucket: every entry is that key
         const uint32_t t = threadIdx.x, b = A.d.nbk_hash + P.h;
         const int lane = t & 63, tile = lane >> 4, tl = lane & 15;
         const uint32_t lo = P.win * kHotWindow, hi = min(size, lo + kHotWindow);
@@ -432,32 +450,28 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
     });
 }
 
-// found bytes of the positions that are in no bucket (reserved keys): 0
-__global__ void assign_reserved_found_kernel(const int64_t* __restrict__ keys, uint32_t n, uint8_t* __restrict__ found) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) if (reserved_key(keys[i])) found[i] = 0;
-}
-
 // ---- host side ----------------------------------------------------------------------------------------------------------------------------
 // blocks behind the buckets: one per window a batch of n keys can have in its hot keys' buckets (sum of ceil(size / kHotWindow) <= n / kHotWindow + hot buckets)
 static uint32_t hot_window_blocks(const DedupArgs& A, uint32_t n) { return A.nbk != A.nbk_hash ? n / kHotWindow + (A.nbk - A.nbk_hash) : 0u; }
-static int dedup_partition(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st, DedupArgs& A, int64_t* d_uniq, int64_t* d_inverse, int64_t miss_index) {
+static int dedup_partition(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st, DedupArgs& A, int64_t* d_uniq, int64_t* d_inverse, int64_t miss_index, uint8_t* d_found) {
     uint32_t grid, nbk;
     bool full;
     const uint32_t nbk_hash = bucket_count_for(t, n, &grid, &nbk, &full);
     // (hot keys' buckets whenever the latest batch reported any: a dedup has no FULL / LEAN kernels, its one kernel takes buckets of any size)
     uint32_t blocks, per_block;
-    part_geometry(n, 1024, blocks, per_block);
+    part_geometry(n, 1024, blocks, per_block, n >= (1u << 19) * (uint32_t)MEE_DD_BLOCKS_FROM ? kPartBlocksMax : kPartBlocks);
     A.nbk = nbk; A.nbk_hash = nbk_hash; A.part_blocks = blocks; A.per_block = per_block; A.hot_count = hot_count_for(n); A.op = t->op; A.h_slabs = t->bk.h_slabs_dev;
-    if (!d_uniq) return bucket_apply_prepare_as(t, d_keys, n, st, nbk_hash, nbk, blocks, per_block);
     const bool atom = bucket_totals_by_atomics(blocks, nbk);
-    bkt_sort_dedup_kernel<<<blocks, 1024, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, d_uniq, d_inverse, miss_index, atom);
+    // an assign without hot keys' buckets needs no bucket totals: nobody numbers anything across buckets, and a bucket's size is the sum of its runs
+    A.size_from_runs = !atom && !d_uniq && nbk == nbk_hash;
+    bkt_sort_dedup_kernel<<<blocks, 1024, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, d_uniq, d_inverse, miss_index, d_found, atom);
     MEE_HIP(hipGetLastError());
-    return atom ? MEE_OK : bucket_totals_launch(t, nbk, blocks, st);
+    return atom || A.size_from_runs ? MEE_OK : bucket_totals_launch(t, nbk, blocks, st);
 }
 
 int bucket_dedup_keys(mee_table* t, const int64_t* d_keys, uint32_t n, int64_t* d_uniq, int64_t* d_inverse, int64_t miss_index, hipStream_t st) {
     DedupArgs A{};
-    if (int rc = dedup_partition(t, d_keys, n, st, A, d_uniq, d_inverse, miss_index)) return rc;
+    if (int rc = dedup_partition(t, d_keys, n, st, A, d_uniq, d_inverse, miss_index, nullptr)) return rc;
     A.uniq = d_uniq; A.inverse = d_inverse;
     bkt_dedup_keys_kernel<<<A.nbk + hot_window_blocks(A, n), kDedupThreads, 0, st>>>(A, t->bk);
     MEE_HIP(hipGetLastError());
@@ -466,9 +480,8 @@ int bucket_dedup_keys(mee_table* t, const int64_t* d_keys, uint32_t n, int64_t* 
 
 int bucket_assign(mee_table* t, float* plane, const int64_t* d_keys, const float* d_values, uint32_t n, uint8_t* d_found, hipStream_t st) {
     AssignArgs A{};
-    if (int rc = dedup_partition(t, d_keys, n, st, A.d, nullptr, nullptr, 0)) return rc;
+    if (int rc = dedup_partition(t, d_keys, n, st, A.d, nullptr, nullptr, 0, d_found)) return rc;
     A.tkeys = t->keys; A.rows = (float4*)plane; A.nb = t->nb; A.dim4 = t->dim4; A.values = (const float4*)d_values; A.found = d_found;
-    if (d_found) assign_reserved_found_kernel<<<grid_for(n, 256, 1024), 256, 0, st>>>(d_keys, n, d_found);
     const uint32_t grid = A.d.nbk + hot_window_blocks(A.d, n);
     if (t->dim4 == 16) bkt_assign_kernel<16><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
     else if (t->dim4 == 32) bkt_assign_kernel<32><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
