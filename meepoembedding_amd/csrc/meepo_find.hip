@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
 #endif
 constexpr int kFindPrepareThreads = MEE_FPT;
 template <int DIM4, int R, int NT>
-__global__ __launch_bounds__(kFindPrepareThreads, kFindPrepareThreads <= 256 ? 8 : 4) void find_prepare_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
+#ifndef MEE_FP_WAVES
+#define MEE_FP_WAVES 8
+#endif
+__global__ __launch_bounds__(kFindPrepareThreads, kFindPrepareThreads <= 256 ? MEE_FP_WAVES : 4) void find_prepare_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
                                                            const int64_t* __restrict__ keys, uint64_t n, f32x4* __restrict__ out,
                                                            uint8_t* __restrict__ found, float defv, uint32_t dim4_rt, int64_t* __restrict__ slots_out,
                                                            int64_t handle_tag, uint32_t part_blocks, uint32_t nbk_hash, uint32_t nbk, uint32_t per_block,

@@ -21,15 +21,15 @@ out = torch.empty((b, dim), dtype=torch.float32, device=dev); found = torch.empt
 slots = torch.empty(b, dtype=torch.int64, device=dev)
 g = torch.randn(b, dim, device=dev) * 0.01
 for i in range(8): t.find(small[i], out=out, found=found)             # find (headline)
-for _ in (0,):
-    for i in range(8):
-        t.find_located(small[i], out=out, found=found, slots=slots)
-        t.apply_adagrad(small[i], g, lr=0.01, slots=slots)            # located apply
-    for i in range(8): t.apply_adagrad(small[i], g, lr=0.01)          # plain apply
+for i in range(8):
+    t.find_located(small[i], out=out, found=found, slots=slots)
+    t.apply_adagrad(small[i], g, lr=0.01, slots=slots)                # located apply
+for i in range(8): t.apply_adagrad(small[i], g, lr=0.01)              # plain apply
 for i in range(8):
     t.find_located(small[i], out=out, found=found, slots=slots, prepare_apply=True)   # the training forward: find + the apply's partition in one launch
     t.apply_adagrad(small[i], g, lr=0.01, slots=slots)
-for i in range(4): t.dedup_sum(small[i], g)                           # standalone duplicate-key reduction
+for i in range(4): t.dedup_sum(small[i], g)                           # standalone duplicate-key reduction with row sums
+for k in old: t.dedup_keys(k)                                         # sync-free duplicate elimination (what the sharded lookup runs in front of its exchange)
 r = Router(8, B, device=dev)
 for k in old: r.partition(k)                                          # shard partition (8 owners)
 for k in new[:4]: t.remove(k)                                         # remove

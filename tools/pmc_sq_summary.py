@@ -1,13 +1,13 @@
 """rocprofv3 --pmc CSVs of tools/pmc_sq.sh -> a markdown table per key stream: per kernel the median of every counter over its dispatches, and
 the ratios that say where the wave-time goes (SQ counters are summed over all waves of a dispatch; *_CYCLES in quad-cycles: MI355X_MICROARCH.md).
-usage: python tools/pmc_sq_summary.py gpurun_out/pmc_sq > profiles/r03_apply_sq.md"""
+usage: python tools/pmc_sq_summary.py gpurun_out/pmc_sq > profiles/r04_apply_sq.md"""
 import csv, glob, os, statistics, sys
 root = sys.argv[1]
-KERNELS = ["bkt_sort_kernel", "bkt_apply_kernel<1, 16, false>", "bkt_apply_kernel<1, 16, true>", "find_kernel<16, 2, 64>", "group_kernel<2", "apply_main_kernel<1, 16, 1, false>",
-           "apply_main_kernel<1, 16, 1, true>", "apply_dups_kernel", "apply_filed_kernel", "apply_big_kernel"]
-print("# SQ counters of the apply path's kernels (round 3)\n")
+KERNELS = ["bkt_sort_kernel", "bkt_apply_kernel<1, 16, false, false, false>", "bkt_apply_kernel<1, 16, true, false, false>", "bkt_apply_kernel<1, 16, false, false, true>",
+           "bkt_apply_kernel<1, 16, true, false, true>", "find_kernel<16, 2, 64>", "find_prepare_kernel<16, 2, 64>"]
+print("# SQ counters of the apply path's kernels (round 4; `…, false>` = the LEAN kernel of uniform streams, `…, true>` = the FULL kernel of skewed streams)\n")
 print("`tools/pmc_sq.sh`: one `rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE "
-      "--kernel-trace` pass per key stream over `tools/apply_trace.py 100000000 <stream> 1,0` (100M keys, dim 64, 256K-key batches; apply_path 1 = bucketed, 0 = group table). "
+      "--kernel-trace` pass per key stream over `tools/apply_trace.py 100000000 <stream>` (100M keys, dim 64, 256K-key batches). "
       "Medians over a kernel's dispatches.  SQ counters are sums over all waves; `wait` = SQ_WAIT_ANY / SQ_WAVE_CYCLES (share of wave-time parked on s_waitcnt / barriers), "
       "`issue` = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES, `stall` = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, `waves in flight` = SQ_WAVE_CYCLES / (SQ_BUSY_CYCLES per SE-summed busy) "
       "is not derivable without per-SE data and is left out; `occupancy` below = mean resident waves per CU = 4 x SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE / 256 CUs.\n")
