@@ -176,7 +176,10 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). meepoembedding_amd has no CPU fallback.")
         L = C.CDLL(LIB_PATH)
+        older = os.environ.get("MEE_LIB_OLDER_BUILD") == "1"   # A/B runs of tools/ against an earlier round's library (MEE_LIB_PATH): entry points it lacks stay unbound
         for name, (res, args) in PROTOTYPES.items():
+            if older and not hasattr(L, name):
+                continue
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args

@@ -5,7 +5,7 @@ out=$1; shift
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for lib in "$@"; do
-  if [ "$lib" != "-" ]; then export MEE_LIB_PATH=$GRAFT_REPO_ROOT/$lib; else unset MEE_LIB_PATH; fi
+  if [ "$lib" != "-" ]; then export MEE_LIB_PATH=$GRAFT_REPO_ROOT/$lib MEE_LIB_OLDER_BUILD=1; else unset MEE_LIB_PATH MEE_LIB_OLDER_BUILD; fi
   tag=$(basename "$lib" .so)
   echo "== $tag" >> $out/times.txt
   for d in uniform zipf; do timeout -k 10 120 python3 tools/apply_trace.py 100000000 $d 1 2>&1 | grep apply_path >> $out/times.txt || exit 1; done
