@@ -718,7 +718,7 @@ __device__ __forceinline__ void run_units(ApplyLds& L, const ApplyArgs& A, const
         if (threadIdx.x == 0) { L.pre_slabs[kApplyThreads] = (uint32_t)total; L.pre_pos[kApplyThreads] = (uint32_t)(total >> 32); }
         S = (uint32_t)total & 0xFFFFFu; H = ((uint32_t)total >> 20) & 0xFFFu;
         // (pinned host word: the units this batch had beyond its hash buckets — the next partition sizes its bucket count by it)
-        if (blockIdx.x == 0 && threadIdx.x == 0) *A.h_slabs = S + H;
+        if (blockIdx.x == 0 && threadIdx.x == 0) report_units(bk, A.h_slabs, S + H);
         MEE_TLS(A, blockIdx.x, 0, wall_clock64());
     }
     // Who takes what.  nbk_hash hash buckets, then one bucket per hot key; G = the grid = one round of the resident block slots.  The blocks
@@ -1084,18 +1084,18 @@ __global__ __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES) void bkt_apply_kern
         if (__builtin_amdgcn_readfirstlane(parity ? hdr.w : hdr.z) != 0 || A.nbk != A.nbk_hash) {
             run_units<KIND, DIM4, LOCATED, GROUPED, true>(L, A, bk, parity, runs, size0, parity ? pa1 : pa0, parity ? pb1 : pb0, gdesc);
         } else {
-            if (blockIdx.x == 0 && threadIdx.x == 0) *A.h_slabs = 0u;
+            if (blockIdx.x == 0 && threadIdx.x == 0) report_units(bk, A.h_slabs, 0u);
             if (own) run_units<KIND, DIM4, LOCATED, GROUPED, false>(L, A, bk, parity, runs, size0, 0u, 0u, gdesc);
         }
     } else {   // LEAN: the batch was partitioned into hash buckets only, block = bucket
         if (size0 <= kBucketCap) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) *A.h_slabs = 0u;   // (a block with a split bucket overwrites it when it is done, much later)
+            if (blockIdx.x == 0 && threadIdx.x == 0) report_units(bk, A.h_slabs, 0u);   // (a block with a split bucket overwrites it when it is done, much later)
             run_units<KIND, DIM4, LOCATED, GROUPED, false>(L, A, bk, parity, runs, size0, 0u, 0u, gdesc);
         } else {
             seg_scan(L, runs, threadIdx.x);
             slow_bucket<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, size0, parity, gdesc, 0u, slow_shares(size0, A.nbk));
             // the stream is skewed: the FULL kernel from now on, with as many agents as this batch had slabs (the block that finishes last leaves the sum)
-            if (threadIdx.x == 0) { const uint32_t mine = (size0 + kSlab - 1) / kSlab; *A.h_slabs = atomicAdd(&bk.seq[4], mine) + mine; }
+            if (threadIdx.x == 0) { const uint32_t mine = (size0 + kSlab - 1) / kSlab, v = atomicAdd(&bk.seq[4], mine) + mine; bk.seq[5] = v; *A.h_slabs = v; }
         }
         if (__builtin_amdgcn_readfirstlane(parity ? hdr.w : hdr.z) != 0) {   // (block-uniform) the batch has a split bucket somewhere
             // helper duty: block x is share j >= 1 of the split bucket x - j (mod nbk).  Every wave looks at the same 64 buckets in front of

@@ -57,6 +57,12 @@ inline void part_geometry(uint32_t n, uint32_t threads, uint32_t& blocks, uint32
 
 // the same bits, scaled the same way, as the key's table bucket (bucket_of): a block's keys live in one contiguous 1/nbk slice of the table
 __device__ __forceinline__ uint32_t apply_bucket_of(int64_t key, uint32_t nbk) { return (uint32_t)__umul64hi(mix64((uint64_t)key), (uint64_t)nbk); }
+// The pinned host word that tells the next partition how many units the latest batch had beyond its hash buckets (bucket_count_for).  It is written
+// only when the value CHANGES (bk.seq[5] shadows it on the device): a uniform stream reports 0 with every batch and need not cross PCIe for that
+// (measured: no difference in step time either way, 85.9-88.0 against 87.5-87.7 us per uniform apply; it just keeps the bus quiet).
+__device__ __forceinline__ void report_units(const BucketScratch& bk, uint32_t* h_units, uint32_t v) {
+    if (bk.seq[5] != v) { bk.seq[5] = v; *h_units = v; }
+}
 // LDS the partition role needs beside its bucket counters: the copy of the hot-key set
 struct PartHot { unsigned long long key[kHotSlots]; uint16_t idx[kHotSlots]; };
 // a key's bucket: its own if the key is listed as hot (nbk_total > nbk_hash: hot buckets exist), else by hash

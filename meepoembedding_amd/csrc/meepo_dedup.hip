@@ -230,7 +230,7 @@ __device__ __forceinline__ uint32_t dd_bucket(DedupLds& L, const BucketScratch& 
     P = hot_plan(L, bk, A, ht0, ht1, parity, own ? -1 : (int)(b - A.nbk));
     // the pinned host word the next partition sizes itself by: the units this batch has beyond its hash buckets — the hot keys' windows (they keep
     // their buckets while they stay hot) and, added below as they turn up, the slabs an oversized hash bucket would make
-    if (b == 0 && threadIdx.x == 0) *A.h_slabs = P.units;
+    if (b == 0 && threadIdx.x == 0) report_units(bk, A.h_slabs, P.units);
     uint32_t size = __builtin_amdgcn_readfirstlane(parity ? tot1 : tot0);
     before = 0;
     if (!own) {   // a window of a hot key's bucket
@@ -249,7 +249,7 @@ __device__ __forceinline__ uint32_t dd_bucket(DedupLds& L, const BucketScratch& 
     }
     __syncthreads();
     if (A.size_from_runs && own) size = __builtin_amdgcn_readfirstlane(L.seg_first[kPartBlocksMax]);   // (dd_seg_scan left the sum of the runs there)
-    if (own && size > kBucketCap && threadIdx.x == 0) { const uint32_t mine = (size + kSlab - 1) / kSlab; *A.h_slabs = P.units + atomicAdd(&bk.seq[4], mine) + mine; }   // a skewed stream: hot keys get buckets of their own next time
+    if (own && size > kBucketCap && threadIdx.x == 0) { const uint32_t mine = (size + kSlab - 1) / kSlab, v = P.units + atomicAdd(&bk.seq[4], mine) + mine; bk.seq[5] = v; *A.h_slabs = v; }   // a skewed stream: hot keys get buckets of their own next time
     if (PREFIX && own) for (int w = 0; w < kDedupWaves; ++w) before += L.stk_val[w];
     __syncthreads();
     return size;

@@ -10,6 +10,10 @@
 
 #include "meepo_apply_part.h"
 
+#ifndef MEE_AB_SLOT
+#define MEE_AB_SLOT 0   // A/B of the located find's slot store: 0 = after the rows (default), 1 = the same as a streaming store, 2 = before the row loads, 3 = none (timing only)
+#endif
+
 namespace mee {
 
 // ---- find (SPEC.md §3) — the headline kernel --------------------------------------------------------------
@@ -80,6 +84,17 @@ __device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, con
             for (int r = 0; r < R; ++r)
                 if (slot[r] >= 0 && tl == 0) atomicAdd(&hits[slot[r]], 1u);
         }
+#if MEE_AB_SLOT == 2
+        if constexpr ((NT & 64) != 0) {
+            int64_t mine = -1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t v = __shfl(slot[r], (lane & 3) * kW);
+                if ((lane >> 2) == r) mine = v;
+            }
+            if (lane < KPW && base + lane < n) slots_out[base + lane] = mine >= 0 ? (mine | handle_tag) : mine;
+        }
+#endif
         if constexpr (DIM4 != 0) {
             constexpr int C = DIM4 / 16;
             f32x4 row[R][C];
@@ -125,6 +140,15 @@ __device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, con
                         out[i * dim4 + c] = slot[r] >= 0 ? values[(uint64_t)slot[r] * dim4 + c] : def4;
             }
         }
+#if MEE_AB_SLOT == 4
+        if constexpr ((NT & 64) != 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint64_t i = base + r * 4 + tile;
+                if (tl == 0 && i < n) slots_out[i] = slot[r] >= 0 ? (slot[r] | handle_tag) : slot[r];
+            }
+        }
+#elif MEE_AB_SLOT != 2
         if constexpr ((NT & 64) != 0) {  // mee_find_located: the slot of every position (-1 = absent), for the apply of the same step
             // lane j < 4R collects the slot of position base + j (round j / 4, tile j % 4): ONE coalesced store per wave step
             int64_t mine = -1;
@@ -133,8 +157,15 @@ __device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, con
                 const int64_t v = __shfl(slot[r], (lane & 3) * kW);
                 if ((lane >> 2) == r) mine = v;
             }
+#if MEE_AB_SLOT == 1
+            if (lane < KPW && base + lane < n) __builtin_nontemporal_store(mine >= 0 ? (mine | handle_tag) : mine, &slots_out[base + lane]);
+#elif MEE_AB_SLOT == 3
+            if (lane < KPW && base + lane < n && mine == -12345) slots_out[base + lane] = mine;
+#else
             if (lane < KPW && base + lane < n) slots_out[base + lane] = mine >= 0 ? (mine | handle_tag) : mine;   // tag: the table's layout epoch (see handle_tag_of)
+#endif
         }
+#endif
         if (found && !(NT & 32)) {  // NT&32: rows only (last pass of find_or_insert: found keeps meaning "present before")
 #pragma unroll
             for (int r = 0; r < R; ++r) {
