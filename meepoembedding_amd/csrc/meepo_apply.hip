@@ -25,6 +25,10 @@
 
 #include "meepo_apply_part.h"
 
+#ifndef MEE_FULL_ONE_PATH
+#define MEE_FULL_ONE_PATH 1
+#endif
+
 namespace mee {
 
 #ifndef MEE_PT
@@ -1081,12 +1085,19 @@ __global__ __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES) void bkt_apply_kern
     if constexpr (FULL) {
         // (block-uniform) the unit list: a batch with a split bucket | a batch partitioned with buckets for hot keys (more buckets than blocks,
         // most of them empty)
+#if MEE_FULL_ONE_PATH
+        // (a batch without a split bucket and without hot keys' buckets takes the same path: S = H = 0, every block its own bucket.  A second
+        // instance of the bucket path for it made the kernel 66-72 KB of code — more than the 64 KB instruction cache two CUs share, with bucket,
+        // slab and merge units running side by side on them)
+        run_units<KIND, DIM4, LOCATED, GROUPED, true>(L, A, bk, parity, runs, size0, parity ? pa1 : pa0, parity ? pb1 : pb0, gdesc);
+#else
         if (__builtin_amdgcn_readfirstlane(parity ? hdr.w : hdr.z) != 0 || A.nbk != A.nbk_hash) {
             run_units<KIND, DIM4, LOCATED, GROUPED, true>(L, A, bk, parity, runs, size0, parity ? pa1 : pa0, parity ? pb1 : pb0, gdesc);
         } else {
             if (blockIdx.x == 0 && threadIdx.x == 0) report_units(bk, A.h_slabs, 0u);
             if (own) run_units<KIND, DIM4, LOCATED, GROUPED, false>(L, A, bk, parity, runs, size0, 0u, 0u, gdesc);
         }
+#endif
     } else {   // LEAN: the batch was partitioned into hash buckets only, block = bucket
         if (size0 <= kBucketCap) {
             if (blockIdx.x == 0 && threadIdx.x == 0) report_units(bk, A.h_slabs, 0u);   // (a block with a split bucket overwrites it when it is done, much later)
