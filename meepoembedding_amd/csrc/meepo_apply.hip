@@ -28,6 +28,9 @@
 #ifndef MEE_FULL_ONE_PATH
 #define MEE_FULL_ONE_PATH 1
 #endif
+#ifndef MEE_AB_VECTOR_SCHED
+#define MEE_AB_VECTOR_SCHED 1
+#endif
 
 namespace mee {
 
@@ -720,7 +723,15 @@ __device__ __forceinline__ void run_units(ApplyLds& L, const ApplyArgs& A, const
         const unsigned long long ex = block_scan_u64<kApplyWaves>(mine, L.wsum, total);
         L.pre_slabs[threadIdx.x] = (uint32_t)ex; L.pre_pos[threadIdx.x] = (uint32_t)(ex >> 32); L.pre_a[threadIdx.x] = pre_a;   // (pre_slabs: slabs | hot keys' whole buckets << 20)
         if (threadIdx.x == 0) { L.pre_slabs[kApplyThreads] = (uint32_t)total; L.pre_pos[kApplyThreads] = (uint32_t)(total >> 32); }
+        // (block-uniform.  As vector values the dozen schedule numbers derived from them below are spilled to scratch and reloaded one by one in front
+        // of every block's first unit — 3-5 us in the timeline; forced into SGPRs (MEE_AB_VECTOR_SCHED=0) the blocks start their units 5 us
+        // earlier, the kernel has 28 B less scratch, and the located kernel is SLOWER, 59.1 against 54.7 us, same box: the allocation of the hot
+        // loops changes with it.  Measured, kept as it was.)
+#if MEE_AB_VECTOR_SCHED
         S = (uint32_t)total & 0xFFFFFu; H = ((uint32_t)total >> 20) & 0xFFFu;
+#else
+        S = __builtin_amdgcn_readfirstlane((uint32_t)total & 0xFFFFFu); H = __builtin_amdgcn_readfirstlane(((uint32_t)total >> 20) & 0xFFFu);
+#endif
         // (pinned host word: the units this batch had beyond its hash buckets — the next partition sizes its bucket count by it)
         if (blockIdx.x == 0 && threadIdx.x == 0) report_units(bk, A.h_slabs, S + H);
         MEE_TLS(A, blockIdx.x, 0, wall_clock64());
@@ -764,8 +775,10 @@ __device__ __forceinline__ void run_units(ApplyLds& L, const ApplyArgs& A, const
             }
         }
         ++tl_units;
+        if (skew && round == 0) MEE_TLS(A, blockIdx.x, 2, wall_clock64());   // (timeline) the block knows its first unit's kind
         if (SKEW && is_slab) {   // ---- a slab of a split bucket (block-uniform) ----
             __syncthreads();   // (the scan's LDS stores; L.u_* of the unit before)
+            if (skew && round == 0) MEE_TLS(A, blockIdx.x, 126, wall_clock64());
             {   // the thread whose buckets hold slab u publishes (bucket, slab of the bucket, size, first pending record)
                 const uint32_t lo = L.pre_slabs[tx] & 0xFFFFFu, hi = L.pre_slabs[tx + 1] & 0xFFFFFu;
                 if (u >= lo && u < hi) {   // exactly one thread

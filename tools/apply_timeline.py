@@ -58,10 +58,11 @@ if skew:
         for i in range(min(n_un - n_sl, 6)):
             w = spare[e, 100 + 4 * i: 104 + 4 * i]
             bks.append(dict(start=us(w[0]), end=us(w[1]), b=int(w[2]) & 0xffffffff, size=int(w[2]) >> 32))
-        blocks.append(dict(e=e, scan=us(spare[e, 0]), end=us(spare[e, 3]), slabs=slabs, buckets=bks, units=n_un))
+        blocks.append(dict(e=e, scan=us(spare[e, 0]), end=us(spare[e, 3]), slabs=slabs, buckets=bks, units=n_un, sched=us(spare[e, 2]), bar1=us(spare[e, 126])))
     end = np.array([b_['end'] for b_ in blocks]); units = np.array([b_['units'] for b_ in blocks])
     print(f"skewed batch: {len(blocks)} blocks, {units.sum()} units ({sum(len(b_['slabs']) for b_ in blocks)} slabs); totals scanned {np.median([b_['scan'] for b_ in blocks]):.2f} us (median) after the first block; "
           f"units per block median {np.median(units):.0f}, max {units.max()}; block end median {np.median(end):.2f} us, p90 {np.percentile(end, 90):.2f}, max {end.max():.2f}")
+    print(f"  first unit known: median {np.nanmedian([b_['sched'] for b_ in blocks]):.2f} us, p90 {np.nanpercentile([b_['sched'] for b_ in blocks], 90):.2f}; slab blocks: known {np.nanmedian([b_['sched'] for b_ in blocks if b_['slabs']]):.2f}, past the first barrier {np.nanmedian([b_['bar1'] for b_ in blocks if b_['slabs']]):.2f}")
     rows = [r for b_ in blocks for r in b_['slabs']]
     f = lambda k: np.array([r[k] for r in rows])
     if rows:
