@@ -765,7 +765,7 @@ def main():
     if args.gpus > 1 and world == 1 and "LOCAL_RANK" not in os.environ:
         # no launcher around us: become the launcher.  Nothing in this process has touched the GPU yet (the GPUs are counted from sysfs).
         have = visible_gpu_count()
-        if args.backend == "nccl" and have < args.gpus:
+        if args.backend == "nccl" and 0 < have < args.gpus:   # (0 = sysfs told nothing: let the ranks find out)
             raise SystemExit(f"--gpus {args.gpus} over RCCL needs {args.gpus} GPUs, {have} visible "
                              f"(--backend gloo rehearses the N>1 flow with ranks sharing the GPUs there are)")
         raise SystemExit(self_launch(args.gpus))
