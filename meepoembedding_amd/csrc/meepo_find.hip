@@ -235,14 +235,30 @@ __global__ __launch_bounds__(kFindPrepareThreads, kFindPrepareThreads <= 256 ? M
                                                            BucketScratch bk, uint32_t* status, OpCounters* op) {
     extern __shared__ unsigned long long part_lds[];   // PartHot, then one counter per bucket (meepo_apply_part.h)
     __shared__ unsigned long long part_wsum[kFindPrepareThreads / 64];
+#if MEE_FIND_TIMELINE   // diagnostic builds only (tools/prepare_timeline.py): thread 0 of every block stamps its start, its end and its role
+    unsigned long long t0_ = 0;
+    if (threadIdx.x == 0) t0_ = wall_clock64();
+#endif
     if (blockIdx.x < part_blocks) {   // block-uniform
         PartHot* hot = reinterpret_cast<PartHot*>(part_lds);
         sort_role<kFindPrepareThreads>(keys, (uint32_t)n, nbk_hash, nbk, per_block, blockIdx.x, part_blocks, bk, status, op, reinterpret_cast<uint32_t*>(hot + 1), part_wsum, hot);
+#if MEE_FIND_TIMELINE
+        if (threadIdx.x == 0 && g_find_dbg && blockIdx.x < 16384) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            g_find_dbg[blockIdx.x * 4 + 0] = t0_; g_find_dbg[blockIdx.x * 4 + 1] = wall_clock64(); g_find_dbg[blockIdx.x * 4 + 2] = 100;
+        }
+#endif
         return;
     }
     find_span<DIM4, R, NT>(tkeys, values, nb, keys, n, out, found, defv, dim4_rt, nullptr, slots_out,
                            (uint64_t)(blockIdx.x - part_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6), (uint64_t)(gridDim.x - part_blocks) * (blockDim.x >> 6),
                            handle_tag);
+#if MEE_FIND_TIMELINE
+    if (threadIdx.x == 0 && g_find_dbg && blockIdx.x < 16384) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g_find_dbg[blockIdx.x * 4 + 0] = t0_; g_find_dbg[blockIdx.x * 4 + 1] = wall_clock64(); g_find_dbg[blockIdx.x * 4 + 2] = 1;
+    }
+#endif
 }
 
 // Several lookup requests of one table in ONE launch (mee_find_many): the per-launch latency floor (~5 us: dispatch + the dependent
