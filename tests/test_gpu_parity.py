@@ -553,6 +553,64 @@ def test_bucketed_apply_extremes(dev, case, opt, kernel):
     np.testing.assert_allclose(got.cpu().numpy(), exp, rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("sync_every_step", [True, False], ids=["host_in_step", "host_runs_ahead"])
+def test_hot_key_set_churn_across_operators(dev, sync_every_step):
+    """The hot-key set is state that one operator's kernel leaves for the NEXT partition of the same table, whichever operator that is: ten steps that
+    alternate plain applies, located applies behind the training forward, dedup_keys and assign, each on a batch of 300K positions with ~200 hot keys
+    (more than the 128 the set holds) drawn from a pool that rotates from step to step (keys enter and leave the set; the set's two copies alternate with the
+    batch parity), with and without a host synchronisation between the steps (with: the next partition is sized by what the last kernel reported; without:
+    by whatever stale report the host word holds).  Every step's results against the oracle."""
+    dim, n_bg, n_pool = 16, 60_000, 400
+    rng = np.random.default_rng(77)
+    bg = synth.keys_np(611, 0, n_bg)
+    pool = synth.keys_np(612, 0, n_pool)
+    keys = np.concatenate([bg, pool]); rows = synth.rows_np(keys, dim, 2)
+    t = LookupTable(1 << 18, dim, device=dev, optimizer=OPT_ADAGRAD, max_batch=400_000, initial_accumulator=0.1)
+    o = oracle.OracleTable(1 << 18, dim, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
+    t.insert(T(keys, dev), T(rows, dev)); o.insert(keys, rows)
+    ops = ["apply", "located", "dedup", "assign", "apply", "dedup", "located", "assign", "apply", "located"]
+    for s, op in enumerate(ops):
+        hot = pool[(np.arange(200) + 57 * s) % n_pool]                      # the pool rotates: a third of the hot keys are new each step
+        reps = rng.integers(280, 900, size=200); reps[:3] = (20_000, 9_000, 1_100)   # a few VERY hot ones: split buckets even in their own bucket
+        bk = np.concatenate([np.repeat(hot, reps), bg[rng.integers(0, n_bg, 60_000)], synth.keys_np(613 + s, 0, 40)])   # + 40 absent keys
+        bk = bk[:300_000] if bk.size > 300_000 else bk
+        rng.shuffle(bk)
+        bk[5] = oracle.EMPTY_KEY
+        n = bk.size
+        bkt = T(bk, dev)
+        if op in ("apply", "located"):
+            g = (rng.standard_normal((n, dim)) * 0.01).astype(np.float32)
+            if op == "apply":
+                t.apply_adagrad(bkt, T(g, dev), lr=0.05)
+            else:
+                _, _, slots = t.find_located(bkt, prepare_apply=True)
+                t.apply_adagrad(bkt, T(g, dev), lr=0.05, slots=slots)
+            o.apply_adagrad(bk, g, 0.05, 1e-10)
+        elif op == "dedup":
+            uniq, inverse = t.dedup_keys(bkt, miss_index=-7)
+            uniq, inverse = uniq.cpu().numpy(), inverse.cpu().numpy()
+            ou = oracle.dedup_sum(bk, None, dim)[0]
+            at = np.flatnonzero(uniq != oracle.EMPTY_KEY)
+            assert at.size == ou.size and np.array_equal(np.sort(uniq[at]), np.sort(ou)), f"step {s}: distinct keys"
+            valid = bk != oracle.EMPTY_KEY
+            assert np.array_equal(uniq[inverse[valid]], bk[valid]) and (inverse[~valid] == -7).all(), f"step {s}: inverse"
+        else:
+            v = rng.standard_normal((n, dim)).astype(np.float32)
+            f = t.assign(bkt, T(v, dev)).cpu().numpy()
+            fo = o.assign(bk, v)
+            assert np.array_equal(f.astype(bool), np.asarray(fo).astype(bool)), f"step {s}: assign found mask"
+        if sync_every_step:
+            torch.cuda.synchronize()
+    assert t.status() == 0
+    e = [x.cpu().numpy() if x is not None else None for x in t.export(with_state=True)]
+    eo = o.export(with_state=True)
+    it, io = np.argsort(e[0]), np.argsort(eo[0])
+    assert np.array_equal(e[0][it], eo[0][io])
+    for x, z in zip(e[1:], eo[1:]):
+        if z is not None:
+            np.testing.assert_allclose(x[it], z[io], rtol=RTOL, atol=ATOL)
+
+
 @pytest.mark.parametrize("n", [2_900_000, 9_500_000], ids=["2.9M", "9.5M"])
 def test_apply_beyond_the_bucketed_limit(dev, n):
     """Batches beyond what round 3's bucketed apply took (8192 buckets x 352 positions = 2.7M keys; the group-table apply behind it is gone):
