@@ -52,8 +52,10 @@ constexpr uint32_t kLdsPartRows = 16;     // fp64 partial rows a slab keeps in L
 // instead of ~50).  Key streams keep their skew from batch to batch, so the next batch gets S (+ 1/16) fewer, larger buckets and as many
 // blocks as before: slabs and buckets together fill the slots once.  S comes back through a pinned host word the apply kernel writes — read
 // here without any synchronisation (a stale or zero value costs time, never results: the kernel works through whatever units there are).
-uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out, uint32_t* nbk_total_out, bool* full_out) {
-    const uint32_t full = bucket_count_for_host(n, t->bk.slots, t->bk.bucket_max ? t->bk.bucket_max : kBucketMax);
+uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out, uint32_t* nbk_total_out, bool* full_out, uint32_t slots_of, uint32_t bucket_max_of) {
+    // (slots_of / bucket_max_of: the geometry of another consumer of the partition — meepo_dedup.hip's 256-thread blocks, 8 per CU)
+    const uint32_t slots = slots_of ? slots_of : t->bk.slots;
+    const uint32_t full = bucket_count_for_host(n, slots, bucket_max_of ? bucket_max_of : t->bk.bucket_max ? t->bk.bucket_max : kBucketMax);
     uint32_t nbk = full;
     const uint32_t s_prev = t->bk.h_slabs && t->bk.skew_adapt ? *(volatile uint32_t*)t->bk.h_slabs : 0u;
     // which kernel (bkt_apply_kernel): FULL behind a skewed batch — and for the 64 batches after the last one: a stream whose skew comes and
@@ -63,9 +65,9 @@ uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out, uint32_t
     if (full_out) *full_out = t->bk.kernel_choice >= 0 ? t->bk.kernel_choice != 0 : (s_prev != 0 || t->bk.skew_sticky != 0);
     // (a batch with more keys than its buckets hold whole: every bucket is a list of slabs — the FULL kernel's business, whatever the knob says)
     if (full_out && n > (uint64_t)full * (kBucketCap * 3 / 4)) *full_out = true;
-    if (s_prev && n > (uint64_t)t->bk.slots * 128) {
+    if (s_prev && n > (uint64_t)slots * 128) {
         uint32_t adj = s_prev + s_prev / 16 + 1;
-        if (adj > t->bk.slots / 2) adj = t->bk.slots / 2;
+        if (adj > slots / 2) adj = slots / 2;
         if (adj > full / 2) adj = full / 2;
         nbk = full - adj;
         while ((uint64_t)nbk * 2 * kBucketMax < n && nbk < full) ++nbk;   // (never more than ~700 positions per bucket on average: kBucketCap stays 12 sigma away)
@@ -1148,7 +1150,10 @@ int bucket_scratch_alloc(mee_table* t) {
     bk.slots = (uint32_t)cus * kApplyBlocksPerCU;
     bk.fast_max = t->max_batch;   // every batch the table takes: beyond ~5M keys (kMaxBuckets buckets of ~700) the buckets outgrow kBucketCap and go through their slabs
     // buckets the largest batch can be cut into (+ the hot keys' own): the strides of the totals' two copies and of the run matrices
-    bk.n_buckets_max = bucket_count_for_host(bk.fast_max, bk.slots) + kHotCap;
+    bk.n_buckets_max = bucket_count_for_host(bk.fast_max, bk.slots);
+    const uint32_t dd = bucket_count_for_host(bk.fast_max, (uint32_t)cus * kDedupBlocksPerCU, kDedupBucketMax);   // the dedup / assign geometry (meepo_dedup.hip)
+    if (dd > bk.n_buckets_max) bk.n_buckets_max = dd;
+    bk.n_buckets_max += kHotCap;
     if (bk.n_buckets_max > kMaxBuckets) bk.n_buckets_max = kMaxBuckets;
     bk.n_buckets_max = (bk.n_buckets_max + 63u) & ~63u;
     bk.pos = t->bs.occ;   // max_batch entries; mee_dedup (the group-table reduction that also sums rows) and a partition never run at the same time on one table

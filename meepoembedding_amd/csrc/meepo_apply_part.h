@@ -23,6 +23,11 @@ constexpr uint32_t kMaxBuckets = 8192;    // the partition keeps one LDS counter
 // costs time, never results (a listed key that turns out rare is a small bucket of one key).  What it buys: the hash buckets of a skewed
 // batch hold no hot key any more — they are not split, their cold keys need no pending records and no merge — and a hot key's own bucket is
 // split into slabs of ONE key whose merge adds up one record per slab.
+#ifndef MEE_DD_BUCKET_MAX
+#define MEE_DD_BUCKET_MAX 512
+#endif
+constexpr uint32_t kDedupBlocksPerCU = 8;      // 256-thread blocks of meepo_dedup.hip resident per CU (19 KB of LDS, 2048 threads)
+constexpr uint32_t kDedupBucketMax = MEE_DD_BUCKET_MAX;   // positions per bucket of a dedup / assign partition with a geometry of its own (MEE_DD_OWN_GEOMETRY, meepo_dedup.hip: measured, off)
 constexpr uint32_t kHotCount = 256;       // occurrences (in one bucket or one slab) that make a key hot: half a slab ...
 // ... or n / 1024 of a larger batch: the set numbers the first kHotCap comers, so the bar must leave fewer candidates than that (Zipf(1.05):
 // ~68 keys reach 256 occurrences in a batch of 256K, ~250 do in a batch of 1M — but only ~66 reach 1024)

@@ -22,6 +22,10 @@
 
 namespace mee {
 
+#ifndef MEE_DD_OWN_GEOMETRY
+#define MEE_DD_OWN_GEOMETRY 0   // 1: bucket count by this file's block slots (8 x 256 CUs = 2048, buckets of <= 512: ONE round for 1M keys) instead of the apply's
+// (3072 buckets of 341: a round and a half).  Measured per 1M keys, same box: uniform dedup_keys 70.9 -> 75.7 us, assign 182 -> 188-200; Zipf 87.4 -> 85 / 118 -> 120: off
+#endif
 #ifndef MEE_DD_BLOCKS_FROM
 #define MEE_DD_BLOCKS_FROM 100000   // (x 512K keys) batches from this size on are partitioned by 256 blocks instead of 128.  Measured at 1M keys (= 2): the partition
 // gets faster (23.4 -> 20.8 us uniform, 27.4 -> 22.6 Zipf) and the consumers lose more than that to twice the runs per bucket (dedup_keys 70.2 -> 75.6 us): off
@@ -456,7 +460,7 @@ static uint32_t hot_window_blocks(const DedupArgs& A, uint32_t n) { return A.nbk
 static int dedup_partition(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st, DedupArgs& A, int64_t* d_uniq, int64_t* d_inverse, int64_t miss_index, uint8_t* d_found) {
     uint32_t grid, nbk;
     bool full;
-    const uint32_t nbk_hash = bucket_count_for(t, n, &grid, &nbk, &full);
+    const uint32_t nbk_hash = bucket_count_for(t, n, &grid, &nbk, &full, MEE_DD_OWN_GEOMETRY ? t->bk.slots / kApplyBlocksPerCU * kDedupBlocksPerCU : 0u, MEE_DD_OWN_GEOMETRY ? kDedupBucketMax : 0u);
     // (hot keys' buckets whenever the latest batch reported any: a dedup has no FULL / LEAN kernels, its one kernel takes buckets of any size)
     uint32_t blocks, per_block;
     part_geometry(n, 1024, blocks, per_block, n >= (1u << 19) * (uint32_t)MEE_DD_BLOCKS_FROM ? kPartBlocksMax : kPartBlocks);
