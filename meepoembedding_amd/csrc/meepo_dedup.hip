@@ -85,9 +85,16 @@ __device__ __forceinline__ uint32_t dd_lookup(const DedupLds& L, unsigned long l
 // One pass over the bucket: every entry whose key has `val` in the low `bits` bits of mix64b goes into the LDS table.  LAST: the table keeps
 // 1 + the key's highest batch position.  A wave whose 64 entries all carry ONE key (a hot key's own bucket, 15 000 entries of one key) inserts
 // it once.  Returns false if the pass holds more distinct keys than the table takes (the caller splits it on one more bit).
+// A bucket of up to 4 x 256 entries — nearly every hash bucket — is held in registers from the build pass on (key and batch position of the thread's four
+// entries): the pass that writes each position's result afterwards does not fetch them a second time (one dependent round trip less per block).
+struct DdHeld { int64_t k[4]; uint32_t p[4]; bool valid; };
+#ifndef MEE_DD_HOLD
+#define MEE_DD_HOLD 1
+#endif
 template <bool LAST>
-__device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, uint32_t size, uint32_t bits, uint32_t val) {
+__device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, uint32_t size, uint32_t bits, uint32_t val, DdHeld& H) {
     const uint32_t t = threadIdx.x;
+    H.valid = MEE_DD_HOLD && size <= 4u * kDedupThreads;   // (block-uniform)
     for (uint32_t j = t; j < kDedupSlots; j += kDedupThreads) { L.key[j] = 0ull; L.val[j] = 0u; L.cnt[j] = 0u; }
     if (t == 0) { L.n_distinct = 0u; L.overflow = 0u; }
     __syncthreads();
@@ -103,8 +110,12 @@ __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, u
             if (e < size) {
                 const uint32_t at = dd_entry_at(L, e);
                 kq[q] = bk.pkey[at];
-                if (LAST) pq[q] = bk.pos[at];
+                if (LAST || H.valid) pq[q] = bk.pos[at];
             }
+        }
+        if (H.valid) {
+#pragma unroll
+            for (int q = 0; q < kIn; ++q) { H.k[q] = kq[q]; H.p[q] = pq[q]; }
         }
 #pragma unroll
         for (int q = 0; q < kIn; ++q) {
@@ -154,11 +165,12 @@ __device__ __forceinline__ void dd_passes(DedupLds& L, const BucketScratch& bk, 
         const uint32_t bits = __builtin_amdgcn_readfirstlane(L.stk_bits[n - 1]), val = __builtin_amdgcn_readfirstlane(L.stk_val[n - 1]);
         __syncthreads();
         if (threadIdx.x == 0) L.stk_n = n - 1;
-        if (dd_build<LAST>(L, bk, size, bits, val)) {
+        DdHeld held;
+        if (dd_build<LAST>(L, bk, size, bits, val, held)) {
             // keys with enough occurrences to fill half a slab get a bucket of their own in the next batch (meepo_apply_part.h)
             for (uint32_t s = threadIdx.x; s < kDedupSlots; s += kDedupThreads)
                 if (L.cnt[s] >= hot_count) report_hot_key(bk, parity, (int64_t)(L.key[s] ^ kBias));
-            emit(bits, val);
+            emit(bits, val, held);
         } else if (threadIdx.x == 0 && bits < 32 && L.stk_n + 2 <= 40) {   // (mix64b is a bijection: distinct keys separate within 64 bits; 32 suffice for any batch)
             const uint32_t m = L.stk_n;
             L.stk_bits[m] = bits + 1; L.stk_val[m] = val;
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
     // every bucket owns as many entries of the list as it has positions, its distinct keys fill the front of that slice and the rest stays
     // EMPTY.  No counter: 3 000 blocks that reserve their slices from one word take 35 us for that alone (one word serves ~88 atomics per us).
     uint32_t slice = P.H + before;
-    dd_passes<false>(L, bk, size, parity, A.hot_count, [&](uint32_t bits, uint32_t val) {
+    dd_passes<false>(L, bk, size, parity, A.hot_count, [&](uint32_t bits, uint32_t val, const DdHeld& held) {
         const uint32_t t = threadIdx.x;
         // the pass's distinct keys get consecutive numbers (block scan over the table's slots), its slice of the unique list one atomic
         constexpr uint32_t per = kDedupSlots / kDedupThreads;
@@ -297,6 +309,12 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
         }
         __syncthreads();
         const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u;
+        if (held.valid) {   // (block-uniform) the entries are still in registers
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (held.k[q] != kEmpty && ((uint32_t)mix64b((uint64_t)held.k[q]) & mask) == val) A.inverse[held.p[q]] = (int64_t)(base + L.val[dd_lookup(L, (unsigned long long)held.k[q] ^ kBias)]);
+            return;
+        }
         for (uint32_t e0 = 0; e0 < size; e0 += 4 * kDedupThreads) {   // four entries in flight per thread
             int64_t kq[4]; uint32_t pq[4];
 #pragma unroll
@@ -386,7 +404,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
         }
         return;
     }
-    dd_passes<true>(L, bk, size, parity, A.d.hot_count, [&](uint32_t bits, uint32_t val) {
+    dd_passes<true>(L, bk, size, parity, A.d.hot_count, [&](uint32_t bits, uint32_t val, const DdHeld& held) {
         const uint32_t t = threadIdx.x;
         const int lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6;
         // the pass's distinct keys as a dense list (block scan over the table's slots; the occurrence counts have been read: their array holds the list)
@@ -442,7 +460,12 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
             }
         }
         __syncthreads();
-        if (A.found) {
+        if (A.found && held.valid) {   // (block-uniform) the entries are still in registers
+            const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (held.k[q] != kEmpty && ((uint32_t)mix64b((uint64_t)held.k[q]) & mask) == val) A.found[held.p[q]] = (uint8_t)L.val[dd_lookup(L, (unsigned long long)held.k[q] ^ kBias)];
+        } else if (A.found) {
             const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u;
             for (uint32_t e = t; e < size; e += kDedupThreads) {
                 const uint32_t at = dd_entry_at(L, e);
