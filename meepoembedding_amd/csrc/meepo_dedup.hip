@@ -284,7 +284,13 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
             A.uniq[P.rank] = key;
             if (size >= A.hot_count) report_hot_key(bk, parity, key);   // stays listed while it stays hot
         }
-        for (uint32_t e = lo + threadIdx.x; e < hi; e += kDedupThreads) A.inverse[bk.pos[dd_entry_at(L, e)]] = (int64_t)P.rank;
+        for (uint32_t e0 = lo; e0 < hi; e0 += 4 * kDedupThreads) {   // four positions in flight per thread (a window is 16 per thread: 4 round trips, not 16)
+            uint32_t pp[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = e0 + q * kDedupThreads + threadIdx.x; pp[q] = e < hi ? bk.pos[dd_entry_at(L, e)] : 0xFFFFFFFFu; }
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) if (pp[q] != 0xFFFFFFFFu) A.inverse[pp[q]] = (int64_t)P.rank;
+        }
         return;
     }
     // Where this bucket's distinct keys go in d_uniq: behind the hot keys' numbers, at the positions the hash buckets in front of it hold —
@@ -373,7 +379,13 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
         const int64_t key = bk.pkey[dd_entry_at(L, 0)];
         // the window's last position -> the bucket's (atomicMax on the bucket's word; the partition zeroed it)
         uint32_t pm = 0;
-        for (uint32_t e = lo + t; e < hi; e += kDedupThreads) pm = max(pm, 1u + bk.pos[dd_entry_at(L, e)]);
+        for (uint32_t e0 = lo; e0 < hi; e0 += 4 * kDedupThreads) {   // four positions in flight per thread
+            uint32_t pp[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = e0 + q * kDedupThreads + t; pp[q] = e < hi ? 1u + bk.pos[dd_entry_at(L, e)] : 0u; }
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) pm = max(pm, pp[q]);
+        }
 #pragma unroll
         for (int d = 32; d; d >>= 1) pm = max(pm, (uint32_t)__shfl_xor((int)pm, d));
         if (lane == 0) L.stk_val[t >> 6] = pm;
@@ -385,7 +397,15 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
             if (t == 0) { L.base = (uint32_t)(slot >= 0); L.stk_bits[0] = (uint32_t)slot; L.stk_bits[1] = (uint32_t)((uint64_t)slot >> 32); }
         }
         __syncthreads();
-        if (A.found) for (uint32_t e = lo + t; e < hi; e += kDedupThreads) A.found[bk.pos[dd_entry_at(L, e)]] = (uint8_t)L.base;
+        if (A.found) {
+            for (uint32_t e0 = lo; e0 < hi; e0 += 4 * kDedupThreads) {
+                uint32_t pp[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = e0 + q * kDedupThreads + t; pp[q] = e < hi ? bk.pos[dd_entry_at(L, e)] : 0xFFFFFFFFu; }
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) if (pp[q] != 0xFFFFFFFFu) A.found[pp[q]] = (uint8_t)L.base;
+            }
+        }
         if (t == 0) {
             uint32_t m = 0;
             for (int w = 0; w < kDedupWaves; ++w) m = max(m, L.stk_val[w]);
