@@ -197,24 +197,29 @@ struct DedupArgs {
 constexpr uint32_t kHotWindow = 4096;
 struct HotPlan { uint32_t H, units, h, win, n_win, rank, size; bool valid; };   // H, units: non-empty hot buckets and their windows in all;   // this block's window: hot bucket h, window `win` of n_win, the key's number `rank`
 __device__ __forceinline__ HotPlan hot_plan(DedupLds& L, const BucketScratch& bk, const DedupArgs& A, uint32_t parity_guess_tot0, uint32_t parity_guess_tot1, uint32_t parity, int x /* window unit, or -1: only H is wanted */) {
-    // (called by all threads; lanes 0..127 hold hot bucket `lane`'s total)
+    // (called by all threads; thread h < n_hot <= 128 holds hot bucket h's total.)  Waves 0 and 1 scan their 64 buckets' window counts and non-empty
+    // flags (DPP), LDS carries wave 0's sums to wave 1, the thread whose bucket holds window x publishes it: a dozen instructions per thread
+    // instead of every thread walking all 128 totals (2-3 us of every block's life on a skewed stream).
     const uint32_t n_hot = A.nbk - A.nbk_hash;
     const uint32_t t = threadIdx.x;
-    const uint32_t tt = t < n_hot ? (parity ? parity_guess_tot1 : parity_guess_tot0) : 0u;
-    if (t < kHotCap) { L.val[t] = tt; }
-    __syncthreads();
     HotPlan P{0, 0, 0, 0, 0, 0, 0, false};
-    uint32_t units = 0;
-    for (uint32_t h = 0; h < n_hot; ++h) {   // (<= 128 LDS reads: every thread walks the same list)
-        const uint32_t sz = L.val[h];
-        if (sz == 0) continue;
-        const uint32_t nw = (sz + kHotWindow - 1) / kHotWindow;
-        if (x >= 0 && !P.valid && (uint32_t)x < units + nw) { P.h = h; P.win = (uint32_t)x - units; P.n_win = nw; P.rank = P.H; P.size = sz; P.valid = true; }
-        units += nw;
-        ++P.H;
-    }
-    P.units = units;
+    if (n_hot == 0) return P;   // (block-uniform)
+    const uint32_t sz = t < n_hot ? (parity ? parity_guess_tot1 : parity_guess_tot0) : 0u;
+    const uint32_t nw = (sz + kHotWindow - 1) / kHotWindow, ne = sz != 0;
+    uint32_t iw = 0, ie = 0;
+    if (t < 128) { iw = wave_incl_scan_u32(nw); ie = wave_incl_scan_u32(ne); }
+    if (t == 63) { L.stk_val[32] = iw; L.stk_val[33] = ie; }
+    if (t == 0) L.stk_val[38] = 0xFFFFFFFFu;
     __syncthreads();
+    if (t >= 64 && t < 128) { iw += L.stk_val[32]; ie += L.stk_val[33]; }
+    if (t == 127) { L.stk_val[34] = iw; L.stk_val[35] = ie; }
+    if (x >= 0 && t < 128 && nw != 0 && (uint32_t)x >= iw - nw && (uint32_t)x < iw) {   // exactly one thread (the windows' ranges are disjoint)
+        L.stk_val[36] = (uint32_t)x - (iw - nw); L.stk_val[37] = nw; L.stk_val[38] = t; L.stk_val[39] = ie - 1u; L.stk_bits[39] = sz;
+    }
+    __syncthreads();
+    P.units = L.stk_val[34]; P.H = L.stk_val[35];
+    if (x >= 0 && L.stk_val[38] != 0xFFFFFFFFu) { P.win = L.stk_val[36]; P.n_win = L.stk_val[37]; P.h = L.stk_val[38]; P.rank = L.stk_val[39]; P.size = L.stk_bits[39]; P.valid = true; }
+    __syncthreads();   // (the stack words are the pass driver's afterwards)
     return P;
 }
 
