@@ -99,10 +99,11 @@ int mee_clear(mee_table* t, void* stream);
 /* performance knobs; never change results.  "find_rounds" (keys in flight per 16-lane tile: 1/2/4/8), "find_grid_cap" (max blocks of
  * the find grid, 0 = unbounded), "find_nt" (cache policy of a find: bit 0 streaming row loads, bit 1 streaming bucket loads, bit 2 cached
  * stores of the dense output; -1 = the library's rule: cached loads, cached stores while one call's output is <= 128 MB.  A caller whose
- * result buffers rotate — nothing re-reads them from cache — sets 0: cached loads, streaming stores), "apply_rounds" (1/2),
- * "apply_path" (0 = group-table apply, 1 = bucketed apply, -1 = the library's choice), "apply_bucket_max" (target positions per
- * bucket of the bucketed apply, 1..352; 0 = the library's rule: one bucket per resident block slot, as many rounds as the batch needs).
- * "apply_overlap" is retired (accepted, ignored). */
+ * result buffers rotate — nothing re-reads them from cache — sets 0: cached loads, streaming stores; prefer mee_find_ex: the hint with the CALL),
+ * "apply_bucket_max" (target positions per bucket of the apply, 1..352; 0 = the library's rule: one bucket per resident block slot, as many
+ * rounds as the batch needs), "apply_kernel" (-1 = the library's choice by the stream's skew, 0 = LEAN, 1 = FULL: meepo_apply.hip),
+ * "apply_skew_adapt" (0: the partition ignores the latest batch's skew report), "dedup_path" (0 = round 2's group table for mee_dedup_keys /
+ * mee_assign, else the bucketed machinery).  "apply_path", "apply_rounds", "apply_overlap" and "apply_spare_blocks" are retired (accepted, ignored). */
 int mee_set_tuning(mee_table* t, const char* name, int value);
 
 /* ---- lookup-table operators (README.md:2 "lookuptable-style"; SPEC.md §3) ------------------------------ */
@@ -237,7 +238,7 @@ int mee_probe_length(const mee_table* t, const int64_t* d_keys, size_t n, uint64
 typedef struct mee_group mee_group;
 int mee_group_create(mee_table* const* tables, uint32_t n_tables, uint64_t max_apply_batch, mee_group** out);
 int mee_group_destroy(mee_group* g);
-/* mee_set_tuning for the group's own apply ("apply_path", "apply_bucket_max", "apply_spare_blocks": as for a table; groups created with
+/* mee_set_tuning for the group's own apply ("apply_bucket_max", "apply_kernel", …: as for a table; groups created with
  * max_apply_batch = 0 have nothing to tune: MEE_ERR_UNSUPPORTED). */
 int mee_group_set_tuning(mee_group* g, const char* name, int value);
 int mee_find_grouped(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found,

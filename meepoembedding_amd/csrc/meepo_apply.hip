@@ -3,21 +3,22 @@
 // Reference anchor: /root/reference/README.md:2 (no code upstream); BASELINE.json north_star: "the sparse-optimizer (Adagrad/Adam)
 // scatter-update … wavefront ballot/prefix-sum for duplicate-key reduction".
 //
-// The group-table apply (meepo_table.hip) pays, per key of a batch, one scattered atomic to claim an entry of a global table, one scattered
-// read of that entry in the main pass and one scattered store to release it — ~30 us of a 256K-key batch that has (almost) no duplicates —
-// plus three dependent launches for the duplicates.  Here the batch is first PARTITIONED by the top bits of mix64(key) into buckets of
-// 128..352 positions (one small kernel, LDS histograms, no per-key global atomic), and then ONE kernel gives every bucket to one 512-thread
-// block: all occurrences of a key are in the same bucket, so the block finds the batch's duplicates in an LDS hash table, sorts the
-// bucket's positions by key with LDS prefix sums, and its 32 tiles update each distinct key once — a key that occurs once straight from
-// its gradient row (bit-exact), a key that occurs c times from the fp64 sum of its c rows (runs of more than 32 are cut into chunks
-// whose fp64 partial rows the block combines itself).  Two launches per apply whatever the key distribution (one behind the training
-// forward, whose launch carries the partition), no per-key global atomic, nothing to clean up afterwards.
+// Rounds 1-2 paid, per key of a batch, one scattered atomic to claim an entry of a global group table, one scattered read of that entry in the main
+// pass and one scattered store to release it — ~30 us of a 256K-key batch that has (almost) no duplicates — plus three dependent launches for the
+// duplicates (that apply is gone since round 4).  Here the batch is first PARTITIONED by the top bits of mix64(key) into buckets of 128..352 positions
+// on average (one small kernel, LDS histograms, no per-key global atomic), and then ONE kernel gives every bucket to one 512-thread block: all
+// occurrences of a key are in the same bucket, so the block finds the batch's duplicates in an LDS hash table, sorts the bucket's positions by key with
+// LDS prefix sums, and its 32 tiles update each distinct key once — a key that occurs once straight from its gradient row (bit-exact), a key that occurs
+// c times from the fp64 sum of its c rows (runs of more than 8 are cut into chunks whose fp64 partial rows the block combines itself).  Two launches
+// per apply whatever the key distribution (one behind the training forward, whose launch carries the partition), no per-key global atomic, nothing to
+// clean up afterwards.
 //
-// A bucket that a hot key makes larger than one block's LDS (512 positions) is SPLIT: its slabs of 512 positions go to blocks of their
-// own (the spare blocks at the head of the grid, so they start first), each slab emits one pending record per distinct key (key + fp64 partial sum), and the slab
-// that finishes last — an agent-scope release / ticket / acquire hand-off, no block ever waits for another — merges the bucket's records
-// with the same LDS machinery and applies the updates.  A key with 21 000 occurrences in a 256K-key batch (Zipf 1.05) is summed by 41
-// blocks on 41 CUs, not by one.
+// Skewed streams (round 4).  A bucket of up to 1024 positions is one block's; a larger one is SPLIT into slabs of 512 that go to blocks of their own —
+// the AGENTS: the partition of a skewed stream makes as many fewer hash buckets as the latest batch had units beyond them, so that buckets, slabs and the
+// hot keys' own buckets together fill one round of the resident block slots and every unit starts with the kernel.  Each slab emits one pending record per
+// distinct key (key + fp64 partial sum; write-through stores, a ticket, no fence and no waiting), the slab that draws the last ticket merges the bucket's
+// records with the same LDS machinery and applies the updates.  Keys a batch reports as hot get buckets of their own in the next one (meepo_apply_part.h).
+// Two kernels: LEAN (block = bucket, no scratch: uniform streams) and FULL (the unit list); see bkt_apply_kernel.
 //
 // Bucket = top bits of mix64(key) = the bits that pick the key's table bucket (mulhi64): a block's keys live in one contiguous 1/n_buckets
 // slice of the table.
@@ -687,17 +688,16 @@ __device__ __forceinline__ void seg_scan(ApplyLds& L, const SegRuns& r, uint32_t
 }
 
 // A batch WITHOUT a split bucket (every batch of a uniform key stream): block = bucket, and the kernel's first lines are all there is to it.
-// A SKEWED batch (some bucket holds more than kBucketCap positions: a key with >= ~700 occurrences) is a list of units — first the slabs of the
-// split buckets (kSlab positions each; long chains: slab, hand-off, merge — so they come first), then the buckets.  Block i starts with unit
-// i; a block that has finished its unit claims the next one beyond the grid from a counter (bk.claim), so that whatever the sizes of the units
-// every resident block slot has work until the list is exhausted.  (Before: 256 spare blocks at the head of the grid looped over the slabs with
-// a stride and re-scanned the bucket totals for every slab, while the buckets' blocks waited for their slots: on Zipf(1.05) the last quarter of
-// the bucket blocks started 30 us into the kernel, and the chains of the spare blocks ended at 70-79 us.)
+// A SKEWED batch (some bucket holds more than kBucketCap positions, or the partition made buckets for hot keys) is a list of units with a STATIC
+// schedule (run_units): blocks [0, n_hash) own a hash bucket, the agents behind them take slab a, then hot bucket a - S; what the agents cannot
+// take runs in later rounds over the bucket blocks, last block first.  History: round 3 had 256 spare blocks at the head of the grid that looped over
+// the slabs with a stride and re-scanned the bucket totals for every slab (chains ended at 70-79 us on Zipf(1.05)); a claim counter for the next
+// unit cost 768 blocks ~15 us of waiting on one word.
 //
-// The slab machinery needs more registers (107-119) than the bucket path (77); the kernel is bounded to 80 (MEE_APPLY_WAVES = 6: three 512-thread
-// blocks per CU) and what does not fit spills in the skewed path only.  Tried instead: two kernels, the second launched with
-// hipExtAnyOrderLaunch so that they share the device — the flag is not supported on gfx9, the launches serialise; the slab path as a
-// __noinline__ function — a kernel's register allocation covers its callees (400-500 B of stack per lane).
+// The slab machinery needs more registers (111-128) than the bucket path (74-78); the FULL kernel is bounded to 80 (MEE_APPLY_WAVES = 6: three
+// 512-thread blocks per CU) and what does not fit spills there only; the LEAN kernel has no scratch at all.  Tried instead: two launches, the second with
+// hipExtAnyOrderLaunch so that they share the device — the launches serialise; the slab path as a __noinline__ function — a kernel's register
+// allocation covers its callees (400-600 B of stack per lane).
 constexpr uint32_t kGroupDescLds = 64;   // members whose descriptors a GROUPED kernel stages in LDS (3 KB): larger groups read them from device memory
 // The units of one block.  SKEW = false (a batch without a split bucket): block = bucket, straight-line code, everything the block needs came
 // with the kernel's first round trip (runs0, size0).  SKEW = true: the unit list, slabs first; the two are separate instances so that the

@@ -153,7 +153,7 @@ __device__ __forceinline__ void report_hot_key(const BucketScratch& bk, uint32_t
 // kernel in front.)  Per (block, bucket) it leaves the run's length and its start inside the slice: the apply kernel pulls a bucket's
 // entries out of the <= 64 slices (short contiguous reads).  It also adds its run lengths to the buckets' totals (one atomic per non-empty
 // (block, bucket) pair, spread over nbk words); the add that takes a total beyond what one block holds (kBucketCap) raises `has_split`, which is all the apply kernel's
-// spare blocks look at when no bucket needs them.  Nothing is handed from block to block in here: the kernel boundary publishes everything.
+// apply blocks look at to know whether the batch has slab units.  Nothing is handed from block to block in here: the kernel boundary publishes everything.
 // (Two earlier forms: a units kernel of its own behind this one — a dependent launch, 6.5 us for one block's worth of work; the block that
 // finished last building the unit list — release fence, ticket, acquire, then the list: the same 6 us at the end of this kernel, and under
 // the training forward's row traffic every one of those dependent steps cost microseconds.)

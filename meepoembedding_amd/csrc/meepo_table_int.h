@@ -61,7 +61,7 @@ struct BucketScratch {
     uint32_t* cnt_mat;    // [kPartBlocksMax][n_buckets_max] keys of each bucket held by each partition block …
     uint32_t* off_mat;    // … and where that run starts inside the block's slice of pos / pkey
     uint32_t* tot;        // [2][n_buckets_max] keys per bucket (added up by the partition blocks); two copies, used alternately
-    uint32_t* has_split;  // [2] some bucket holds more than one slab (the apply kernel's spare blocks have work)
+    uint32_t* has_split;  // [2] some bucket holds more than a block takes whole (kBucketCap): the batch has slab units
     uint32_t* seq;        // [2] [0] partitions consumed so far (its low bit picks the copy the next partition fills), [1] the copy the latest partition filled
     uint32_t* pend_cnt;   // [n_buckets_max] split buckets: pending records appended so far
     uint32_t* ticket;     // [n_buckets_max] split buckets: slabs finished
