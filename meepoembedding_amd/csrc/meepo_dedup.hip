@@ -354,8 +354,9 @@ __global__ __launch_bounds__(1024) void bkt_sort_dedup_kernel(const int64_t* __r
             uniq[i] = kEmpty;
             if (reserved_key(keys[i])) inverse[i] = miss_index;
         }
-    } else if (found) {   // assign: the found bytes of the positions that are in no bucket (reserved keys): 0
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) if (reserved_key(keys[i])) found[i] = 0;
+    } else if (found) {   // assign: every position's found byte starts as 1 (0 for reserved keys: they are in no bucket) — coalesced stores here; the assign
+        // kernel then writes only the bytes of keys it does NOT find (1M scattered byte stores cost 10-17 us of a 180 us assign: a partial-line fill each)
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) found[i] = reserved_key(keys[i]) ? 0 : 1;
     }
     PartHot* hot = reinterpret_cast<PartHot*>(part_lds);
     sort_role<1024>(keys, n, nbk_hash, nbk, per_block, blockIdx.x, gridDim.x, bk, status, op, reinterpret_cast<uint32_t*>(hot + 1), wsum, hot, tot_atomics != 0);
@@ -402,13 +403,13 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
             if (t == 0) { L.base = (uint32_t)(slot >= 0); L.stk_bits[0] = (uint32_t)slot; L.stk_bits[1] = (uint32_t)((uint64_t)slot >> 32); }
         }
         __syncthreads();
-        if (A.found) {
+        if (A.found && !L.base) {   // (block-uniform; the partition's launch wrote the 1s)
             for (uint32_t e0 = lo; e0 < hi; e0 += 4 * kDedupThreads) {
                 uint32_t pp[4];
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = e0 + q * kDedupThreads + t; pp[q] = e < hi ? bk.pos[dd_entry_at(L, e)] : 0xFFFFFFFFu; }
 #pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) if (pp[q] != 0xFFFFFFFFu) A.found[pp[q]] = (uint8_t)L.base;
+                for (uint32_t q = 0; q < 4; ++q) if (pp[q] != 0xFFFFFFFFu) A.found[pp[q]] = 0;
             }
         }
         if (t == 0) {
@@ -489,14 +490,14 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
             const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (held.k[q] != kEmpty && ((uint32_t)mix64b((uint64_t)held.k[q]) & mask) == val) A.found[held.p[q]] = (uint8_t)L.val[dd_lookup(L, (unsigned long long)held.k[q] ^ kBias)];
+                if (held.k[q] != kEmpty && ((uint32_t)mix64b((uint64_t)held.k[q]) & mask) == val && L.val[dd_lookup(L, (unsigned long long)held.k[q] ^ kBias)] == 0u) A.found[held.p[q]] = 0;   // (the partition's launch wrote the 1s)
         } else if (A.found) {
             const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u;
             for (uint32_t e = t; e < size; e += kDedupThreads) {
                 const uint32_t at = dd_entry_at(L, e);
                 const int64_t key = bk.pkey[at];
                 if (((uint32_t)mix64b((uint64_t)key) & mask) != val) continue;
-                A.found[bk.pos[at]] = (uint8_t)L.val[dd_lookup(L, (unsigned long long)key ^ kBias)];
+                if (L.val[dd_lookup(L, (unsigned long long)key ^ kBias)] == 0u) A.found[bk.pos[at]] = 0;
             }
         }
     });
