@@ -10,6 +10,9 @@
 
 #include "meepo_apply_part.h"
 
+#ifndef MEE_FP_R
+#define MEE_FP_R 2   // keys in flight per tile in the training forward at dim 64 (4: a wave step's slot handles are one full 128-byte line)
+#endif
 #ifndef MEE_AB_SLOT
 #define MEE_AB_SLOT 0   // A/B of the located find's slot store: 0 = after the rows (default), 1 = the same as a streaming store, 2 = before the row loads, 3 = none (timing only)
 #endif
@@ -710,7 +713,7 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
     const uint32_t nbk_hash = bucket_count_for(t, n, &apply_grid, &nbk, &apply_full);
     uint32_t part_blocks, per_block;
     part_geometry((uint32_t)n, kFindPrepareThreads, part_blocks, per_block);
-    const int R = t->dim4 == 16 || t->dim4 == 32 ? 2 : 1;
+    const int R = t->dim4 == 16 ? MEE_FP_R : t->dim4 == 32 ? 2 : 1;
     const unsigned find_cap = t->prepare_debug >> 8;
     const unsigned find_blocks = grid_for(n, (kFindPrepareThreads / 64) * 4u * (unsigned)R, find_cap ? find_cap : 1u << 22);
     const bool separate = t->prepare_debug & 1;
@@ -719,7 +722,7 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
 #define FINDLP1(D4, RR, NT) find_prepare_kernel<D4, RR, NT><<<part_blocks + find_blocks, kFindPrepareThreads, sizeof(PartHot) + nbk * 4, st>>>(t->keys, (const f32x4*)t->values, t->nb, d_keys, n, (f32x4*)d_out, d_found, \
         t->default_value, t->dim4, d_slots_out, handle_tag_of(t), part_blocks, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op)
 #define FINDLP(D4, RR) do { if (cached_out) FINDLP1(D4, RR, 68); else FINDLP1(D4, RR, 64); } while (0)
-    if (t->dim4 == 16) FINDLP(16, 2); else if (t->dim4 == 32) FINDLP(32, 2); else FINDLP(0, 1);
+    if (t->dim4 == 16) FINDLP(16, MEE_FP_R); else if (t->dim4 == 32) FINDLP(32, 2); else FINDLP(0, 1);
 #undef FINDLP
 #undef FINDLP1
     MEE_HIP(hipGetLastError());
