@@ -1065,8 +1065,19 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
 // latest batches of the table were (bucket_apply_launch); both are correct for any batch.  One kernel for both was the first form: the
 // scratch it declares for the skewed path — never touched by a uniform batch — cost the uniform batches 4-5 us of their 63 (the same bucket
 // path: 0 B of scratch 62.5 us, 56 B 63.1, 128-160 B 67-68, 600 B 94: resident waves are limited by the scratch the queue has for them).
+#ifndef MEE_FULL_BK_BY_POINTER
+#define MEE_FULL_BK_BY_POINTER 1
+#endif
+// How a kernel gets the table's BucketScratch: LEAN by value (kernel arguments: there when the first instruction runs); FULL through a pointer to the copy
+// bucket_scratch_alloc left in device memory — the struct never changes after mee_table_create, and as kernel arguments its ~20 pointers were 40 of the
+// 106 SGPRs the FULL kernel has (it spilled SGPRs into VGPR lanes from its first instruction on).
+template <bool FULL> struct BkArg { using type = BucketScratch; static __device__ __forceinline__ const BucketScratch& ref(const BucketScratch& a) { return a; } };
+#if MEE_FULL_BK_BY_POINTER
+template <> struct BkArg<true> { using type = const BucketScratch* __restrict__; static __device__ __forceinline__ const BucketScratch& ref(const BucketScratch* a) { return *a; } };
+#endif
 template <int KIND, int DIM4, bool LOCATED, bool GROUPED, bool FULL>
-__global__ __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES) void bkt_apply_kernel(ApplyArgs A, BucketScratch bk) {
+__global__ __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES) void bkt_apply_kernel(ApplyArgs A, typename BkArg<FULL>::type bk_arg) {
+    const BucketScratch& bk = BkArg<FULL>::ref(bk_arg);
     __shared__ ApplyLds L;
     const GroupDesc* gdesc = nullptr;
     if constexpr (GROUPED) {   // the members' planes: needed once per work item, so they come out of LDS (the first barrier inside process_slab publishes them)
@@ -1181,6 +1192,10 @@ int bucket_scratch_alloc(mee_table* t) {
     if (e == hipSuccess) e = hipHostMalloc((void**)&bk.h_slabs, 64, hipHostMallocMapped | hipHostMallocPortable);
     if (e == hipSuccess) { *bk.h_slabs = 0u; e = hipHostGetDevicePointer((void**)&bk.h_slabs_dev, bk.h_slabs, 0); }
     bk.skew_adapt = 1; bk.skew_sticky = 0; bk.kernel_choice = -1;
+    // the device-resident copy the FULL apply kernel reads (everything the DEVICE uses of this struct is fixed from here on; the tuning fields are the host's)
+    bk.dev_copy = nullptr;
+    alloc((void**)&bk.dev_copy, sizeof(BucketScratch));
+    if (e == hipSuccess) e = hipMemcpy(bk.dev_copy, &bk, sizeof(BucketScratch), hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail(MEE_ERR_OUT_OF_MEMORY, "hipMalloc for the apply scratch: %s", hipGetErrorString(e));
     return MEE_OK;
 }
@@ -1189,6 +1204,7 @@ void bucket_scratch_free(mee_table* t) {
     void* dev[] = {bk.pkey, bk.cnt_mat, bk.off_mat, bk.tot, bk.seq, bk.hot_key, bk.hot_idx, bk.hot_n, bk.pend_cnt, bk.ticket, bk.pend_key, bk.pend_slot, bk.pend_row};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (bk.h_slabs) (void)hipHostFree(bk.h_slabs);
+    if (bk.dev_copy) (void)hipFree(bk.dev_copy);
 }
 
 #if MEE_APPLY_TIMELINE
@@ -1248,14 +1264,20 @@ int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const Op
     // split buckets first (run_units)
     const bool full = t->part_full;   // as the partition decided: FULL = a skewed stream (hot keys' buckets may exist, the grid is one round of the block slots)
     const uint32_t grid = full ? t->part_grid : A.nbk;   // LEAN: block = bucket
-#define BKT(K, D4, LOC) do { if (full) bkt_apply_kernel<K, D4, LOC, false, true><<<grid, kApplyThreads, 0, st>>>(A, t->bk); else bkt_apply_kernel<K, D4, LOC, false, false><<<grid, kApplyThreads, 0, st>>>(A, t->bk); } while (0)
-#define BKT_L(K, D4) do { if (d_desc) { if (full) bkt_apply_kernel<K, D4, true, true, true><<<grid, kApplyThreads, 0, st>>>(A, t->bk); else bkt_apply_kernel<K, D4, true, true, false><<<grid, kApplyThreads, 0, st>>>(A, t->bk); } \
+#if MEE_FULL_BK_BY_POINTER
+#define BK_FULL (t->bk.dev_copy)
+#else
+#define BK_FULL (t->bk)
+#endif
+#define BKT(K, D4, LOC) do { if (full) bkt_apply_kernel<K, D4, LOC, false, true><<<grid, kApplyThreads, 0, st>>>(A, BK_FULL); else bkt_apply_kernel<K, D4, LOC, false, false><<<grid, kApplyThreads, 0, st>>>(A, t->bk); } while (0)
+#define BKT_L(K, D4) do { if (d_desc) { if (full) bkt_apply_kernel<K, D4, true, true, true><<<grid, kApplyThreads, 0, st>>>(A, BK_FULL); else bkt_apply_kernel<K, D4, true, true, false><<<grid, kApplyThreads, 0, st>>>(A, t->bk); } \
                           else if (d_slots) BKT(K, D4, true); else BKT(K, D4, false); } while (0)
 #define BKT_D(K) do { if (t->dim4 == 16) BKT_L(K, 16); else if (t->dim4 == 32) BKT_L(K, 32); else BKT_L(K, 0); } while (0)
     if (a.kind == MEE_OPT_ADAGRAD) BKT_D(MEE_OPT_ADAGRAD); else BKT_D(MEE_OPT_ADAM);
 #undef BKT_D
 #undef BKT_L
 #undef BKT
+#undef BK_FULL
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
