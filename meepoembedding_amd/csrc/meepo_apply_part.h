@@ -72,9 +72,10 @@ __device__ __forceinline__ void report_units(const BucketScratch& bk, uint32_t* 
 struct PartHot { unsigned long long key[kHotSlots]; uint16_t idx[kHotSlots]; };
 // a key's bucket: its own if the key is listed as hot (nbk_total > nbk_hash: hot buckets exist), else by hash
 __device__ __forceinline__ uint32_t part_bucket_of(int64_t key, uint32_t nbk_hash, uint32_t nbk_total, const PartHot* hot) {
+    const uint64_t m = mix64((uint64_t)key);   // ONE mixer per key: its top bits pick the hash bucket, bits 20..28 the slot of the hot set (hot_slot_of)
     if (nbk_total != nbk_hash) {
         const unsigned long long bkey = (unsigned long long)key ^ kBias;
-        uint32_t h = (uint32_t)(mix64b((uint64_t)key) >> 20) & (kHotSlots - 1);
+        uint32_t h = (uint32_t)(m >> 20) & (kHotSlots - 1);
         for (uint32_t tries = 0; tries < kHotSlots; ++tries) {   // (bounded: a set without an empty slot must not trap the probe)
             const unsigned long long k = hot->key[h];
             if (k == bkey) { const uint32_t i = hot->idx[h]; if (i < nbk_total - nbk_hash) return nbk_hash + i; break; }
@@ -82,7 +83,7 @@ __device__ __forceinline__ uint32_t part_bucket_of(int64_t key, uint32_t nbk_has
             h = (h + 1) & (kHotSlots - 1);
         }
     }
-    return apply_bucket_of(key, nbk_hash);
+    return (uint32_t)__umul64hi(m, (uint64_t)nbk_hash);
 }
 
 // Inclusive prefix sums over the 64 lanes of a wave on the DPP path (row_shr 1 / 2 / 4 / 8 inside each row of 16 lanes, then row_bcast:15 into rows
@@ -132,7 +133,7 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
 __device__ __forceinline__ void report_hot_key(const BucketScratch& bk, uint32_t parity, int64_t key) {
     if (__hip_atomic_load(&bk.hot_n[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kHotCap) return;
     const unsigned long long bkey = (unsigned long long)key ^ kBias;
-    uint32_t h = (uint32_t)(mix64b((uint64_t)key) >> 20) & (kHotSlots - 1);
+    uint32_t h = (uint32_t)(mix64((uint64_t)key) >> 20) & (kHotSlots - 1);   // (the slot part_bucket_of looks at first)
     unsigned long long* set = bk.hot_key + parity * kHotSlots;
     for (uint32_t tries = 0; tries < kHotSlots / 2; ++tries) {
         const unsigned long long old = atomicCAS(&set[h], 0ull, bkey);
