@@ -102,7 +102,8 @@ int mee_clear(mee_table* t, void* stream);
  * result buffers rotate — nothing re-reads them from cache — sets 0: cached loads, streaming stores; prefer mee_find_ex: the hint with the CALL),
  * "apply_bucket_max" (target positions per bucket of the apply, 1..352; 0 = the library's rule: one bucket per resident block slot, as many
  * rounds as the batch needs), "apply_kernel" (-1 = the library's choice by the stream's skew, 0 = LEAN, 1 = FULL: meepo_apply.hip),
- * "apply_skew_adapt" (0: the partition ignores the latest batch's skew report), "dedup_path" (0 = round 2's group table for mee_dedup_keys /
+ * "apply_skew_adapt" (0: the partition ignores the latest batch's skew report), "apply_xcd_split" (1..1023: share per 1024 of a bucket pair's hash range that
+ * goes to the even bucket — even and odd XCDs differ in read-modify-write rate —, 0 = even halves; default 548), "dedup_path" (0 = round 2's group table for mee_dedup_keys /
  * mee_assign, else the bucketed machinery).  "apply_path", "apply_rounds", "apply_overlap" and "apply_spare_blocks" are retired (accepted, ignored). */
 int mee_set_tuning(mee_table* t, const char* name, int value);
 

@@ -26,6 +26,11 @@
 
 #include "meepo_apply_part.h"
 
+#ifndef MEE_XCD_SPLIT
+#define MEE_XCD_SPLIT 548   // share (per 1024) of a bucket pair's hash range that goes to the even bucket; 0 = even halves (tuning "apply_xcd_split").  Apply block b runs on
+// XCD b % 8 and the odd XCDs' read-modify-write streams are ~15 % slower (timeline: 42.8 vs 38.0 us for a block's items).  Located LEAN kernel, uniform 256K keys, same box:
+// 0: 63.1-63.4 us, 530: 62.8, 540: 61.7, 550: 60.8, 560: 61.5, 580: 62.4, 600: 64.0, 620: 64.8; the probing kernel and the Zipf (FULL) kernels do not move.
+#endif
 #ifndef MEE_FULL_ONE_PATH
 #define MEE_FULL_ONE_PATH 1
 #endif
@@ -83,11 +88,11 @@ uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out, uint32_t
 
 // ---- the partition kernel of an apply (the role itself: meepo_apply_part.h) ----------------------------------------------------------------
 __global__ __launch_bounds__(kPartThreads) void bkt_sort_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk_hash, uint32_t nbk,
-                                                                uint32_t per_block, BucketScratch bk, uint32_t* status, OpCounters* op, uint32_t tot_atomics) {
+                                                                uint32_t per_block, BucketScratch bk, uint32_t* status, OpCounters* op, uint32_t tot_atomics, uint32_t xcd_split) {
     extern __shared__ unsigned long long part_lds[];   // PartHot, then one counter per bucket
     __shared__ unsigned long long wsum[kPartThreads / 64];
     PartHot* hot = reinterpret_cast<PartHot*>(part_lds);
-    sort_role<kPartThreads>(keys, n, nbk_hash, nbk, per_block, blockIdx.x, gridDim.x, bk, status, op, reinterpret_cast<uint32_t*>(hot + 1), wsum, hot, tot_atomics != 0);
+    sort_role<kPartThreads>(keys, n, nbk_hash, nbk, per_block, blockIdx.x, gridDim.x, bk, status, op, reinterpret_cast<uint32_t*>(hot + 1), wsum, hot, tot_atomics != 0, xcd_split);
 }
 
 // the bucket totals of a large batch: column sums of the run-length matrix (one thread per bucket, coalesced along the buckets), and the
@@ -1191,7 +1196,7 @@ int bucket_scratch_alloc(mee_table* t) {
     }
     if (e == hipSuccess) e = hipHostMalloc((void**)&bk.h_slabs, 64, hipHostMallocMapped | hipHostMallocPortable);
     if (e == hipSuccess) { *bk.h_slabs = 0u; e = hipHostGetDevicePointer((void**)&bk.h_slabs_dev, bk.h_slabs, 0); }
-    bk.skew_adapt = 1; bk.skew_sticky = 0; bk.kernel_choice = -1;
+    bk.skew_adapt = 1; bk.skew_sticky = 0; bk.kernel_choice = -1; bk.xcd_split = MEE_XCD_SPLIT;
     // the device-resident copy the FULL apply kernel reads (everything the DEVICE uses of this struct is fixed from here on; the tuning fields are the host's)
     bk.dev_copy = nullptr;
     alloc((void**)&bk.dev_copy, sizeof(BucketScratch));
@@ -1223,7 +1228,7 @@ int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStr
     part_geometry(n, kPartThreads, blocks, per_block);
     t->part_blocks = blocks; t->part_per_block = per_block; t->part_nbk = nbk; t->part_nbk_hash = nbk_hash; t->part_grid = grid;
     const bool atom = bucket_totals_by_atomics(blocks, nbk);
-    bkt_sort_kernel<<<blocks, kPartThreads, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, atom);
+    bkt_sort_kernel<<<blocks, kPartThreads, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, atom, t->bk.xcd_split);
     MEE_HIP(hipGetLastError());
     return atom ? MEE_OK : bucket_totals_launch(t, nbk, blocks, st);
 }
@@ -1231,7 +1236,7 @@ int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStr
 // the same partition for another consumer (meepo_dedup.hip: last-wins elections), with the geometry the caller chose
 int bucket_apply_prepare_as(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st, uint32_t nbk_hash, uint32_t nbk, uint32_t blocks, uint32_t per_block) {
     const bool atom = bucket_totals_by_atomics(blocks, nbk);
-    bkt_sort_kernel<<<blocks, kPartThreads, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, atom);
+    bkt_sort_kernel<<<blocks, kPartThreads, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, atom, 0u);
     MEE_HIP(hipGetLastError());
     return atom ? MEE_OK : bucket_totals_launch(t, nbk, blocks, st);
 }

@@ -71,7 +71,7 @@ __device__ __forceinline__ void report_units(const BucketScratch& bk, uint32_t* 
 // LDS the partition role needs beside its bucket counters: the copy of the hot-key set
 struct PartHot { unsigned long long key[kHotSlots]; uint16_t idx[kHotSlots]; };
 // a key's bucket: its own if the key is listed as hot (nbk_total > nbk_hash: hot buckets exist), else by hash
-__device__ __forceinline__ uint32_t part_bucket_of(int64_t key, uint32_t nbk_hash, uint32_t nbk_total, const PartHot* hot) {
+__device__ __forceinline__ uint32_t part_bucket_of(int64_t key, uint32_t nbk_hash, uint32_t nbk_total, const PartHot* hot, uint32_t xcd_split = 0) {
     const uint64_t m = mix64((uint64_t)key);   // ONE mixer per key: its top bits pick the hash bucket, bits 20..28 the slot of the hot set (hot_slot_of)
     if (nbk_total != nbk_hash) {
         const unsigned long long bkey = (unsigned long long)key ^ kBias;
@@ -82,6 +82,12 @@ __device__ __forceinline__ uint32_t part_bucket_of(int64_t key, uint32_t nbk_has
             if (k == 0ull) break;
             h = (h + 1) & (kHotSlots - 1);
         }
+    }
+    if (xcd_split != 0 && !(nbk_hash & 1u)) {
+        // buckets 2j and 2j + 1 share their pair's hash range unevenly: the apply block of bucket b runs on XCD b % 8, and the read-modify-write stream of the
+        // odd XCDs gets ~15 % less of the fabric: xcd_split / 1024 of the range goes to the even bucket
+        const uint64_t half = nbk_hash >> 1;
+        return 2u * (uint32_t)__umul64hi(m, half) + (uint32_t)(((m * half) >> 54) >= xcd_split);
     }
     return (uint32_t)__umul64hi(m, (uint64_t)nbk_hash);
 }
@@ -169,7 +175,8 @@ template <int THREADS>
 __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk_hash, uint32_t nbk /* hash buckets + hot buckets */, uint32_t per_block, uint32_t blk,
                                           uint32_t n_blocks, const BucketScratch& bk, uint32_t* status, OpCounters* op, uint32_t* cursor /*[nbk]*/,
                                           unsigned long long* wsum /*[THREADS / 64]*/, PartHot* hot,
-                                          bool tot_atomics = true /* false: the bucket totals are summed up by a small kernel behind this one (bkt_totals_kernel) */) {
+                                          bool tot_atomics = true /* false: the bucket totals are summed up by a small kernel behind this one (bkt_totals_kernel) */,
+                                          uint32_t xcd_split = 0 /* part_bucket_of */) {
     // Dependent round trips to memory are what this role costs (beside the training forward's row gather every one of them waits in the same
     // queues as the gather's requests: microseconds each), so it makes two: the keys together with the copy selector, and — at the very end —
     // the returns of the bucket-total atomics, which travel while the entries are scattered.
@@ -213,7 +220,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
 #pragma unroll
         for (int q = 0; q < kKeyGroup; ++q) {
             uint32_t bq = 0xFFFFu;
-            if (!reserved_key(kr[q])) { bq = part_bucket_of(kr[q], nbk_hash, nbk, hot); atomicAdd(&cursor[bq], 1u); }
+            if (!reserved_key(kr[q])) { bq = part_bucket_of(kr[q], nbk_hash, nbk, hot, xcd_split); atomicAdd(&cursor[bq], 1u); }
             else bad = bad || kr[q] == kReclaimed;   // EMPTY = padding, silent (SPEC.md §2)
             if (kKeepBuckets) bid[q / 2] = q & 1 ? bid[q / 2] | bq << 16 : bq;
         }
@@ -224,7 +231,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
             for (int q = 0; q < kKeyGroup; ++q) k[q] = i0 + q * THREADS < hi ? keys[i0 + q * THREADS] : kEmpty;
 #pragma unroll
             for (int q = 0; q < kKeyGroup; ++q) {
-                if (!reserved_key(k[q])) atomicAdd(&cursor[part_bucket_of(k[q], nbk_hash, nbk, hot)], 1u);
+                if (!reserved_key(k[q])) atomicAdd(&cursor[part_bucket_of(k[q], nbk_hash, nbk, hot, xcd_split)], 1u);
                 else bad = bad || k[q] == kReclaimed;
             }
         }
@@ -265,7 +272,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
 #pragma unroll
         for (int q = 0; q < kKeyGroup; ++q) {
             if (reserved_key(kr[q])) continue;
-            const uint32_t r = lo + atomicAdd(&cursor[kKeepBuckets ? (bid[q / 2] >> (q & 1 ? 16 : 0)) & 0xFFFFu : part_bucket_of(kr[q], nbk_hash, nbk, hot)], 1u);
+            const uint32_t r = lo + atomicAdd(&cursor[kKeepBuckets ? (bid[q / 2] >> (q & 1 ? 16 : 0)) & 0xFFFFu : part_bucket_of(kr[q], nbk_hash, nbk, hot, xcd_split)], 1u);
             bk.pos[r] = lo + threadIdx.x + q * THREADS;
             bk.pkey[r] = kr[q];
         }
@@ -277,7 +284,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
 #pragma unroll
             for (int q = 0; q < kKeyGroup; ++q) {
                 if (reserved_key(k[q])) continue;
-                const uint32_t r = lo + atomicAdd(&cursor[part_bucket_of(k[q], nbk_hash, nbk, hot)], 1u);
+                const uint32_t r = lo + atomicAdd(&cursor[part_bucket_of(k[q], nbk_hash, nbk, hot, xcd_split)], 1u);
                 bk.pos[r] = i0 + q * THREADS;
                 bk.pkey[r] = k[q];
             }

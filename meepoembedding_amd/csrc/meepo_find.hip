@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kFindPrepareThreads, kFindPrepareThreads <= 256 ? M
                                                            const int64_t* __restrict__ keys, uint64_t n, f32x4* __restrict__ out,
                                                            uint8_t* __restrict__ found, float defv, uint32_t dim4_rt, int64_t* __restrict__ slots_out,
                                                            int64_t handle_tag, uint32_t part_blocks, uint32_t nbk_hash, uint32_t nbk, uint32_t per_block,
-                                                           BucketScratch bk, uint32_t* status, OpCounters* op) {
+                                                           BucketScratch bk, uint32_t* status, OpCounters* op, uint32_t xcd_split) {
     extern __shared__ unsigned long long part_lds[];   // PartHot, then one counter per bucket (meepo_apply_part.h)
     __shared__ unsigned long long part_wsum[kFindPrepareThreads / 64];
 #if MEE_FIND_TIMELINE   // diagnostic builds only (tools/prepare_timeline.py): thread 0 of every block stamps its start, its end and its role
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kFindPrepareThreads, kFindPrepareThreads <= 256 ? M
 #endif
     if (blockIdx.x < part_blocks) {   // block-uniform
         PartHot* hot = reinterpret_cast<PartHot*>(part_lds);
-        sort_role<kFindPrepareThreads>(keys, (uint32_t)n, nbk_hash, nbk, per_block, blockIdx.x, part_blocks, bk, status, op, reinterpret_cast<uint32_t*>(hot + 1), part_wsum, hot);
+        sort_role<kFindPrepareThreads>(keys, (uint32_t)n, nbk_hash, nbk, per_block, blockIdx.x, part_blocks, bk, status, op, reinterpret_cast<uint32_t*>(hot + 1), part_wsum, hot, true, xcd_split);
 #if MEE_FIND_TIMELINE
         if (threadIdx.x == 0 && g_find_dbg && blockIdx.x < 16384) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -720,7 +720,7 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
     if (separate) part_blocks = 0;
     const bool cached_out = t->find_nt >= 0 && (t->find_nt & 4);
 #define FINDLP1(D4, RR, NT) find_prepare_kernel<D4, RR, NT><<<part_blocks + find_blocks, kFindPrepareThreads, sizeof(PartHot) + nbk * 4, st>>>(t->keys, (const f32x4*)t->values, t->nb, d_keys, n, (f32x4*)d_out, d_found, \
-        t->default_value, t->dim4, d_slots_out, handle_tag_of(t), part_blocks, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op)
+        t->default_value, t->dim4, d_slots_out, handle_tag_of(t), part_blocks, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, t->bk.xcd_split)
 #define FINDLP(D4, RR) do { if (cached_out) FINDLP1(D4, RR, 68); else FINDLP1(D4, RR, 64); } while (0)
     if (t->dim4 == 16) FINDLP(16, MEE_FP_R); else if (t->dim4 == 32) FINDLP(32, 2); else FINDLP(0, 1);
 #undef FINDLP

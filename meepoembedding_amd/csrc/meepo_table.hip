@@ -876,6 +876,7 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     else if (!strcmp(name, "apply_spare_blocks")) t->bk.spare_blocks = value > 0 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_bucket_max")) t->bk.bucket_max = value > 0 && value <= 352 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_skew_adapt")) t->bk.skew_adapt = value != 0;
+    else if (!strcmp(name, "apply_xcd_split")) t->bk.xcd_split = value > 0 && value < 1024 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_kernel")) t->bk.kernel_choice = value < 0 ? -1 : value != 0;
     else if (!strcmp(name, "dedup_path")) t->dedup_path = value;
     else if (!strcmp(name, "apply_rounds") || !strcmp(name, "apply_path")) (void)value;   // retired in round 4 with the group-table apply: accepted, ignored

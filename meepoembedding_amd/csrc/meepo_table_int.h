@@ -79,6 +79,7 @@ struct BucketScratch {
     uint32_t bucket_max;  // tuning ("apply_bucket_max"): positions per bucket aimed at, at most (0 = the default)
     uint32_t n_buckets_max, slots;   // slots: apply blocks the device keeps resident at once (CUs x blocks per CU): bucket counts are multiples of it
     uint64_t fast_max;    // largest n the bucketed path takes
+    uint32_t xcd_split;   // tuning ("apply_xcd_split"): see part_bucket_of
     BucketScratch* dev_copy;   // this struct in device memory (what the FULL apply kernel reads instead of 40 SGPRs of kernel arguments)
 };
 

@@ -35,6 +35,8 @@ for _ in (0,):
         t.set_tuning("apply_spare_blocks", spare)
     if pdbg:
         t.set_tuning("prepare_debug", pdbg)
+    if os.environ.get("MEE_XCD_SPLIT"):
+        t.set_tuning("apply_xcd_split", int(os.environ["MEE_XCD_SPLIT"]))
     for label, located in (("apply alone (probing)", False), ("find_located + apply (located)", True), ("find_located_prepare + apply (located)", 2)):
         def step(i):
             if located:
