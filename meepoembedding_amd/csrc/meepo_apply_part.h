@@ -28,10 +28,16 @@ constexpr uint32_t kMaxBuckets = 8192;    // the partition keeps one LDS counter
 #endif
 constexpr uint32_t kDedupBlocksPerCU = 8;      // 256-thread blocks of meepo_dedup.hip resident per CU (19 KB of LDS, 2048 threads)
 constexpr uint32_t kDedupBucketMax = MEE_DD_BUCKET_MAX;   // positions per bucket of a dedup / assign partition with a geometry of its own (MEE_DD_OWN_GEOMETRY, meepo_dedup.hip: measured, off)
-constexpr uint32_t kHotCount = 256;       // occurrences (in one bucket or one slab) that make a key hot: half a slab ...
+#ifndef MEE_HOT_MIN
+#define MEE_HOT_MIN 256
+#endif
+constexpr uint32_t kHotCount = MEE_HOT_MIN;       // occurrences (in one bucket or one slab) that make a key hot: half a slab ...
 // ... or n / 1024 of a larger batch: the set numbers the first kHotCap comers, so the bar must leave fewer candidates than that (Zipf(1.05):
 // ~68 keys reach 256 occurrences in a batch of 256K, ~250 do in a batch of 1M — but only ~66 reach 1024)
-inline uint32_t hot_count_for(uint64_t n) { const uint64_t c = n / 1024; return c > kHotCount ? (uint32_t)c : kHotCount; }
+#ifndef MEE_HOT_DIV
+#define MEE_HOT_DIV 1024   // (a lower bar — 160 or 200 occurrences per 256K keys — lists more keys and gains nothing: Zipf located kernel 56.4 / 55.1 against 54.7-54.9 us)
+#endif
+inline uint32_t hot_count_for(uint64_t n) { const uint64_t c = n / MEE_HOT_DIV; return c > kHotCount ? (uint32_t)c : kHotCount; }
 constexpr uint32_t kHotSlots = 512;       // slots of the hot-key set
 constexpr uint32_t kHotCap = 128;         // hot keys that get a bucket (the set takes no more keys once that many are numbered: its load stays ~0.25); a Zipf(1.05) batch of 256K keys lists ~50, one of 1M keys ~120
 // MEE_APPLY_WAVES: waves per SIMD the register allocator must leave room for in the bucket kernel (meepo_apply.hip): 8 = 64 VGPRs, four
