@@ -124,3 +124,19 @@ def test_bench_two_rank_rehearsal_native_transport(dev):
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
     assert res["n_gpus"] == 2 and res["value"] > 0 and "fallback" in res["config"]["workload"], res["config"]["workload"]
+
+
+def test_bench_host_probes_run_without_a_gpu():
+    """The two probes bench.py makes BEFORE any HIP call — GPUs visible (sysfs, cut by *_VISIBLE_DEVICES) and host RAM this process may still take (MemAvailable cut by
+    the cgroup limit) — are plain file reads: they must work (and stay sane) on a box without a GPU."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n = bench.visible_gpu_count()
+    assert isinstance(n, int) and 0 <= n <= 64
+    os.environ["HIP_VISIBLE_DEVICES"] = "0"
+    try:
+        assert bench.visible_gpu_count() <= 1
+    finally:
+        del os.environ["HIP_VISIBLE_DEVICES"]
+    ram = bench._host_ram_available_gb()
+    assert 0.0 <= ram < 1e6
