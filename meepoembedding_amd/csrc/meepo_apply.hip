@@ -34,6 +34,10 @@
 #ifndef MEE_FULL_ONE_PATH
 #define MEE_FULL_ONE_PATH 1
 #endif
+#ifndef MEE_SCHED_FROM_LDS
+#define MEE_SCHED_FROM_LDS 0   // 1: the FULL kernel's schedule numbers recomputed from LDS at the head of every round (24-40 B less scratch; located kernel 55.0-55.2 against 54.3-54.7 us,
+// probing 61 against 57.5: not kept)
+#endif
 #ifndef MEE_AB_VECTOR_SCHED
 #define MEE_AB_VECTOR_SCHED 1
 #endif
@@ -751,14 +755,33 @@ __device__ __forceinline__ void run_units(ApplyLds& L, const ApplyArgs& A, const
     // batch of a stream has none — : slabs first go to the blocks [0, O) INSTEAD of their buckets, and everything left over (more slabs, hot
     // keys' buckets, the displaced buckets [0, O)) follows in later rounds over the hash buckets' blocks, from the last one downwards.  A static
     // schedule: 768 blocks that claim their next unit from one word within a few microseconds of each other wait ~15 us for it (measured).
+#if MEE_SCHED_FROM_LDS
+    if constexpr (SKEW) __syncthreads();   // (thread 0's store of the scan's total: every round re-reads S and H from there)
+#endif
     const uint32_t G = gridDim.x, NH = min(A.nbk_hash, G), n_agents = G - NH;
+#if !MEE_SCHED_FROM_LDS
     const uint32_t s_agents = min(S, n_agents), O = min(S - s_agents, NH);        // slabs [0, s_agents): agents; [s_agents, s_agents + O): blocks [0, O)
     const uint32_t h_agents = min(H, n_agents - s_agents);                        // hot keys' whole buckets [0, h_agents): agents
     const uint32_t late_slabs = S - s_agents - O, late_hot = H - h_agents, n_late = late_slabs + late_hot + O + (A.nbk_hash > G ? A.nbk_hash - G : 0u);
+#endif
     [[maybe_unused]] uint32_t tl_i = 0, tl_units = 0;
     for (uint32_t round = 0;; ++round) {
         // (the thread index is re-read through an empty asm in every turn, as in process_slab: hoisted out of this loop, the per-thread addresses
         // of everything below stayed live across the whole loop and were spilled to scratch — a memory round trip in front of every use)
+#if MEE_SCHED_FROM_LDS
+        // the schedule numbers are recomputed from the two totals in LDS at the head of every round (scalar, short-lived): held across the rounds as
+        // vector values they were spilled to scratch right behind the scan and reloaded one by one in front of the block's first unit
+        uint32_t S_ = S, H_ = H;
+        if constexpr (SKEW) {
+            uint32_t sh = L.pre_slabs[kApplyThreads];
+            asm volatile("" : "+v"(sh));
+            sh = __builtin_amdgcn_readfirstlane(sh);
+            S_ = sh & 0xFFFFFu; H_ = (sh >> 20) & 0xFFFu;
+        }
+        const uint32_t s_agents = min(S_, n_agents), O = min(S_ - s_agents, NH);
+        const uint32_t h_agents = min(H_, n_agents - s_agents);
+        const uint32_t late_slabs = S_ - s_agents - O, late_hot = H_ - h_agents, n_late = late_slabs + late_hot + O + (A.nbk_hash > G ? A.nbk_hash - G : 0u);
+#endif
         uint32_t tx = threadIdx.x;
         asm volatile("" : "+v"(tx));
         bool is_slab = false, is_hot = false;

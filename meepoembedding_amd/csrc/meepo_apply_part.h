@@ -74,14 +74,17 @@ __device__ __forceinline__ uint32_t apply_bucket_of(int64_t key, uint32_t nbk) {
 __device__ __forceinline__ void report_units(const BucketScratch& bk, uint32_t* h_units, uint32_t v) {
     if (bk.seq[5] != v) { bk.seq[5] = v; *h_units = v; }
 }
+// where a key sits in the hot-key set: Fibonacci hashing, ONE multiply — a full mixer here cost the apply kernels (which report hot keys) registers: with
+// mix64 the grouped LEAN kernel spilled 12 B to scratch
+__device__ __forceinline__ uint32_t hot_slot_of(int64_t key) { return (uint32_t)(((uint64_t)key * 0x9E3779B97F4A7C15ull) >> 40) & (kHotSlots - 1); }
 // LDS the partition role needs beside its bucket counters: the copy of the hot-key set
 struct PartHot { unsigned long long key[kHotSlots]; uint16_t idx[kHotSlots]; };
 // a key's bucket: its own if the key is listed as hot (nbk_total > nbk_hash: hot buckets exist), else by hash
 __device__ __forceinline__ uint32_t part_bucket_of(int64_t key, uint32_t nbk_hash, uint32_t nbk_total, const PartHot* hot, uint32_t xcd_split = 0) {
-    const uint64_t m = mix64((uint64_t)key);   // ONE mixer per key: its top bits pick the hash bucket, bits 20..28 the slot of the hot set (hot_slot_of)
+    const uint64_t m = mix64((uint64_t)key);   // ONE mixer per key (its top bits pick the hash bucket); the hot set's slot costs one multiply more (hot_slot_of)
     if (nbk_total != nbk_hash) {
         const unsigned long long bkey = (unsigned long long)key ^ kBias;
-        uint32_t h = (uint32_t)(m >> 20) & (kHotSlots - 1);
+        uint32_t h = hot_slot_of(key);
         for (uint32_t tries = 0; tries < kHotSlots; ++tries) {   // (bounded: a set without an empty slot must not trap the probe)
             const unsigned long long k = hot->key[h];
             if (k == bkey) { const uint32_t i = hot->idx[h]; if (i < nbk_total - nbk_hash) return nbk_hash + i; break; }
@@ -145,7 +148,7 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
 __device__ __forceinline__ void report_hot_key(const BucketScratch& bk, uint32_t parity, int64_t key) {
     if (__hip_atomic_load(&bk.hot_n[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kHotCap) return;
     const unsigned long long bkey = (unsigned long long)key ^ kBias;
-    uint32_t h = (uint32_t)(mix64((uint64_t)key) >> 20) & (kHotSlots - 1);   // (the slot part_bucket_of looks at first)
+    uint32_t h = hot_slot_of(key);   // (the slot part_bucket_of looks at first)
     unsigned long long* set = bk.hot_key + parity * kHotSlots;
     for (uint32_t tries = 0; tries < kHotSlots / 2; ++tries) {
         const unsigned long long old = atomicCAS(&set[h], 0ull, bkey);
