@@ -17,8 +17,9 @@
  *    mee_table_create() (safe for hipGraph capture except the [syncs] ones).
  *  - Return value: MEE_OK or a negative error code; mee_last_error() gives a thread-local message.
  *    Device-side conditions (table full, reserved key in a batch) set sticky bits read by mee_status().
- *  - Mutators (insert/assign/find_or_insert/apply_*) AND the [syncs] calls (size/status/export/hits_scan/dedup_sum/
- *    probe_length: they share the table's counter block and its pinned read-back word) on ONE table must be ordered
+ *  - Mutators (insert/assign/find_or_insert/apply_*), the duplicate reductions (dedup_keys/dedup_sum: they use the table's per-batch
+ *    scratch) AND the [syncs] calls (size/status/export/hits_scan/probe_length: they share the table's counter block and its pinned
+ *    read-back word) on ONE table must be ordered
  *    by the caller (same stream or events; from several host threads: one such call at a time per table);
  *    concurrent mee_find* calls on different streams / threads are safe.  n must be ≤ config.max_batch for
  *    every op except mee_find (any n).
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MEE_ABI_VERSION 1
+#define MEE_ABI_VERSION 2   /* 2: mee_dedup_sum is sync-free and padded (round 5) */
 
 #define MEE_EMPTY_KEY     INT64_MIN       /* SPEC.md §2: reserved, never stored; in a batch it is padding (skipped silently) */
 #define MEE_RECLAIMED_KEY (INT64_MIN + 1) /* SPEC.md §2: reserved, the tombstone mee_remove leaves */
@@ -101,10 +102,11 @@ int mee_clear(mee_table* t, void* stream);
  * stores of the dense output; -1 = the library's rule: cached loads, cached stores while one call's output is <= 128 MB.  A caller whose
  * result buffers rotate — nothing re-reads them from cache — sets 0: cached loads, streaming stores; prefer mee_find_ex: the hint with the CALL),
  * "apply_bucket_max" (target positions per bucket of the apply, 1..352; 0 = the library's rule: one bucket per resident block slot, as many
- * rounds as the batch needs), "apply_kernel" (-1 = the library's choice by the stream's skew, 0 = LEAN, 1 = FULL: meepo_apply.hip),
- * "apply_skew_adapt" (0: the partition ignores the latest batch's skew report), "apply_xcd_split" (1..1023: share per 1024 of a bucket pair's hash range that
- * goes to the even bucket — even and odd XCDs differ in read-modify-write rate —, 0 = even halves; default 548), "dedup_path" (0 = round 2's group table for mee_dedup_keys /
- * mee_assign, else the bucketed machinery).  "apply_path", "apply_rounds", "apply_overlap" and "apply_spare_blocks" are retired (accepted, ignored). */
+ * rounds as the batch needs; the bucket COUNT never exceeds what the table's scratch was sized for at creation — the default rule at max_batch —, so a
+ * small value on a batch near max_batch gives larger buckets than asked for), "apply_kernel" (-1 = the library's choice by the stream's skew, 0 = LEAN,
+ * 1 = FULL: meepo_apply.hip), "apply_skew_adapt" (0: the partition ignores the latest batch's skew report), "apply_xcd_split" (1..1023: share per 1024 of a
+ * bucket pair's hash range that goes to the even bucket — even and odd XCDs differ in read-modify-write rate —, 0 = even halves; -1 = as calibrated on this
+ * device when its first table was created).  Unknown names: MEE_ERR_INVALID_ARG. */
 int mee_set_tuning(mee_table* t, const char* name, int value);
 
 /* ---- lookup-table operators (README.md:2 "lookuptable-style"; SPEC.md §3) ------------------------------ */
@@ -301,11 +303,18 @@ int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_g
  * it itself, and the apply that follows partitions its batch again.) */
 int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* stream);
 int mee_apply_discard(mee_table* t, void* stream);
-/* [syncs] duplicate-key reduction on its own (SPEC.md §4): unique keys (unspecified order), their summed
- * grads (nullable with d_grads), occurrence counts (nullable) and inverse[i] = index into the unique list
- * (nullable; -1 for reserved keys).  Outputs sized for n.  *n_unique_out on the host. */
+/* Duplicate-key reduction on its own (SPEC.md §4), sync-free: what a rank runs on its gradients before they travel to the keys' owners, so that
+ * one (key, summed row) pair per DISTINCT key crosses xGMI instead of one row per occurrence.  Outputs sized for n, padded like mee_dedup_keys' (below):
+ *   d_uniq_out[n]          every distinct non-reserved key exactly once, at an unspecified position; MEE_EMPTY_KEY elsewhere (padding, possibly BETWEEN keys)
+ *   d_gsum_out[n, dim]     at a key's position: the rows of its occurrences added up in fp64 and rounded once to fp32 (a key that occurs once: its row, bit for
+ *                          bit); rows at padding positions are NOT written.  d_grads / d_gsum_out are nullable together (keys, counts and inverse only);
+ *                          dim = the table's dim
+ *   d_counts_out[n]        (nullable) occurrences of the key; 0 at padding positions
+ *   d_inverse_out[n]       (nullable) index of d_keys[i] in d_uniq_out, or miss_index for reserved keys
+ * The number of distinct keys never travels to the host; consumers take the padded arrays at their fixed length n (every operator and
+ * mee_partition_padded skip MEE_EMPTY_KEY).  Uses the table's per-batch scratch only (no table row is read): n <= config.max_batch. */
 int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, int64_t* d_uniq_out,
-                  float* d_gsum_out, uint32_t* d_counts_out, int64_t* d_inverse_out, size_t* n_unique_out,
+                  float* d_gsum_out, uint32_t* d_counts_out, int64_t* d_inverse_out, int64_t miss_index,
                   void* stream);
 
 /* The keys-only, sync-free form (what a sharded lookup of a skewed batch needs before the exchange): every distinct non-reserved
@@ -420,8 +429,11 @@ int mee_sharded_create(mee_table* local, void* nccl_comm, uint64_t max_batch /* 
  *          else in the cold one.  Which keys are hot is the caller's policy (mee_find_plane / mee_assign_plane move a key with its state).
  *   MEE_SHARDED_DEDUP   lookups (find, find_or_insert) exchange only the batch's DISTINCT keys: mee_dedup_keys on a scratch table of the
  *          context's own -> the padded unique list is partitioned (padding belongs to no shard) -> keys out, rows back -> every occurrence
- *          takes its key's row.  On skewed key streams the bytes on xGMI scale with the distinct keys while the result counts lookups.
- *          Costs ~0.2 ms of local work per 1M keys: it pays where the saved link time exceeds that. */
+ *          takes its key's row.  Optimizer applies (apply_adagrad, apply_adam) send ONE (key, summed gradient row) pair per distinct key of the
+ *          rank's batch: mee_dedup_sum adds the rank's rows of a key up in fp64 and rounds once, the owner's apply adds the ranks' partial sums
+ *          up in fp64 again — within 1e-6 (relative) of the un-aggregated update, not bit-identical to it (one extra rounding per rank and key).
+ *          On skewed key streams the bytes on xGMI then scale with the distinct keys, in both directions of a training step, while the result
+ *          counts lookups.  Costs ~0.1-0.2 ms of local work per 1M keys: it pays where the saved link time exceeds that. */
 enum { MEE_SHARDED_DEDUP = 1u };
 typedef struct mee_sharded_options {
     uint32_t struct_size;     /* = sizeof(mee_sharded_options); ABI guard */

@@ -110,8 +110,10 @@ public:
     size_t export_range(uint64_t slot_begin, uint64_t slot_end, int64_t* d_keys_out, float* d_values_out, size_t cap, float* d_state1_out = nullptr, float* d_state2_out = nullptr, void* stream = nullptr) const {
         size_t n = 0; check(mee_export_range(t_, slot_begin, slot_end, d_keys_out, d_values_out, d_state1_out, d_state2_out, cap, &n, stream)); return n;
     }
-    size_t dedup_sum(const int64_t* d_keys, const float* d_grads, size_t n, int64_t* d_uniq_out, float* d_gsum_out, uint32_t* d_counts_out, int64_t* d_inverse_out, void* stream = nullptr) {
-        size_t u = 0; check(mee_dedup_sum(t_, d_keys, d_grads, n, d_uniq_out, d_gsum_out, d_counts_out, d_inverse_out, &u, stream)); return u;
+    // sync-free: padded outputs of length n (MEE_EMPTY_KEY between the distinct keys, counts 0 there); see mee_dedup_sum
+    void dedup_sum(const int64_t* d_keys, const float* d_grads, size_t n, int64_t* d_uniq_out, float* d_gsum_out, uint32_t* d_counts_out, int64_t* d_inverse_out,
+                   int64_t miss_index = -1, void* stream = nullptr) {
+        check(mee_dedup_sum(t_, d_keys, d_grads, n, d_uniq_out, d_gsum_out, d_counts_out, d_inverse_out, miss_index, stream));
     }
     // sync-free: d_uniq_out[n] = every distinct key once, EMPTY everywhere else (also between the keys), d_inverse_out[i] = index into it (miss_index for reserved keys)
     void dedup_keys(const int64_t* d_keys, size_t n, int64_t* d_uniq_out, int64_t* d_inverse_out, int64_t miss_index = -1, void* stream = nullptr) {

@@ -24,6 +24,7 @@ FIND_DEFAULT, FIND_STREAM_STORES, FIND_CACHED_STORES, FIND_STREAM_ROWS, FIND_STR
 HANDLE_SLOT_MASK = (1 << 40) - 1   # a located-find handle: bits 0..39 the slot (as mee_locate reports it), bits 40..61 the table's layout epoch
 MEM_HBM, MEM_HOST_PINNED = 0, 1
 FLAG_TRACK_HITS, FLAG_ADMISSION = 1, 2
+ABI_VERSION = 2   # MEE_ABI_VERSION of include/meepo_embedding.h this loader was written against
 EMPTY_KEY = -(1 << 63)
 RECLAIMED_KEY = EMPTY_KEY + 1
 BUCKET_WIDTH = 16
@@ -124,7 +125,7 @@ PROTOTYPES = {
     "mee_apply_adam": (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
     "mee_apply_prepare": (C.c_int, [_vp, _vp, _sz, _vp]),
     "mee_apply_discard": (C.c_int, [_vp, _vp]),
-    "mee_dedup_sum": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_sz), _vp]),
+    "mee_dedup_sum": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "mee_hash_batch": (C.c_int, [_vp, _sz, _u64, _u32, _vp, _vp, _vp, _vp]),
     "mee_router_create": (C.c_int, [_i32, _u64, _u32, C.POINTER(_vp)]),
     "mee_router_destroy": (C.c_int, [_vp]),
@@ -183,8 +184,8 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if L.mee_abi_version() != 1:  # noqa: PLR2004
-            raise ImportError(f"{LIB_PATH}: ABI version {L.mee_abi_version()} != 1")
+        if L.mee_abi_version() != ABI_VERSION:  # noqa: PLR2004
+            raise ImportError(f"{LIB_PATH}: ABI version {L.mee_abi_version()} != {ABI_VERSION}")
         _lib = L
     return _lib
 

@@ -26,28 +26,13 @@
 
 #include "meepo_apply_part.h"
 
-#ifndef MEE_XCD_SPLIT
-#define MEE_XCD_SPLIT 548   // share (per 1024) of a bucket pair's hash range that goes to the even bucket; 0 = even halves (tuning "apply_xcd_split").  Apply block b runs on
-// XCD b % 8 and the odd XCDs' read-modify-write streams are ~15 % slower (timeline: 42.8 vs 38.0 us for a block's items).  Located LEAN kernel, uniform 256K keys, same box:
-// 0: 63.1-63.4 us, 530: 62.8, 540: 61.7, 550: 60.8, 560: 61.5, 580: 62.4, 600: 64.0, 620: 64.8; the probing kernel and the Zipf (FULL) kernels do not move.
-#endif
-#ifndef MEE_FULL_ONE_PATH
-#define MEE_FULL_ONE_PATH 1
-#endif
-#ifndef MEE_SCHED_FROM_LDS
-#define MEE_SCHED_FROM_LDS 0   // 1: the FULL kernel's schedule numbers recomputed from LDS at the head of every round (24-40 B less scratch; located kernel 55.0-55.2 against 54.3-54.7 us,
-// probing 61 against 57.5: not kept)
-#endif
-#ifndef MEE_AB_VECTOR_SCHED
-#define MEE_AB_VECTOR_SCHED 1
-#endif
-
 namespace mee {
 
-#ifndef MEE_PT
-#define MEE_PT 1024
-#endif
-constexpr int kPartThreads = MEE_PT;
+// share (per 1024) of a bucket pair's hash range that goes to the even bucket; 0 = even halves (tuning "apply_xcd_split").  Apply block b runs on
+// XCD b % 8 and the odd XCDs' read-modify-write streams are ~15 % slower (timeline: 42.8 vs 38.0 us for a block's items).  Located LEAN kernel, uniform 256K keys, same box:
+// 0: 63.1-63.4 us, 530: 62.8, 540: 61.7, 550: 60.8, 560: 61.5, 580: 62.4, 600: 64.0, 620: 64.8; the probing kernel and the Zipf (FULL) kernels do not move.
+constexpr uint32_t kXcdSplit = 548;
+constexpr int kPartThreads = 1024;
 constexpr int kApplyThreads = 512;
 constexpr int kApplyWaves = kApplyThreads / 64;
 constexpr uint32_t kLdsSlots = kBucketCap;   // the LDS hash table: as many slots as a block holds sources (a bucket of kBucketCap DISTINCT keys fills it to the
@@ -62,10 +47,13 @@ constexpr uint32_t kLdsPartRows = 16;     // fp64 partial rows a slab keeps in L
 // instead of ~50).  Key streams keep their skew from batch to batch, so the next batch gets S (+ 1/16) fewer, larger buckets and as many
 // blocks as before: slabs and buckets together fill the slots once.  S comes back through a pinned host word the apply kernel writes — read
 // here without any synchronisation (a stale or zero value costs time, never results: the kernel works through whatever units there are).
-uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out, uint32_t* nbk_total_out, bool* full_out, uint32_t slots_of, uint32_t bucket_max_of) {
-    // (slots_of / bucket_max_of: the geometry of another consumer of the partition — meepo_dedup.hip's 256-thread blocks, 8 per CU)
-    const uint32_t slots = slots_of ? slots_of : t->bk.slots;
-    const uint32_t full = bucket_count_for_host(n, slots, bucket_max_of ? bucket_max_of : t->bk.bucket_max ? t->bk.bucket_max : kBucketMax);
+uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out, uint32_t* nbk_total_out, bool* full_out) {
+    const uint32_t slots = t->bk.slots;
+    uint32_t full = bucket_count_for_host(n, slots, t->bk.bucket_max ? t->bk.bucket_max : kBucketMax);
+    // The scratch (totals, run matrices, pending counters, tickets) is strided for n_buckets_max buckets, sized at creation for the DEFAULT bucket size at
+    // max_batch (+ the hot keys' buckets): a smaller "apply_bucket_max" must not ask for more buckets than that — it gets larger buckets instead.
+    const uint32_t room = t->bk.n_buckets_max - kHotCap;
+    if (full > room) full = room >= slots ? room / slots * slots : room;
     uint32_t nbk = full;
     const uint32_t s_prev = t->bk.h_slabs && t->bk.skew_adapt ? *(volatile uint32_t*)t->bk.h_slabs : 0u;
     // which kernel (bkt_apply_kernel): FULL behind a skewed batch — and for the 64 batches after the last one: a stream whose skew comes and
@@ -85,7 +73,7 @@ uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out, uint32_t
     if (grid_out) *grid_out = full;
     // behind a skewed batch the keys that batch reported as hot get buckets of their own, behind the hash buckets (meepo_apply_part.h) — the
     // FULL kernel's business
-    const bool hot = s_prev && nbk + kHotCap <= kMaxBuckets && (!full_out || *full_out);
+    const bool hot = s_prev && nbk + kHotCap <= t->bk.n_buckets_max && (!full_out || *full_out);
     if (nbk_total_out) *nbk_total_out = hot ? nbk + kHotCap : nbk;
     return nbk;
 }
@@ -175,20 +163,8 @@ struct ApplyLds {
 #define MEE_TLP(A_, L_, k_) do { } while (0)
 #endif
 
-// MEE_APPLY_STORE_MODE (diagnostic builds): how an update's rows are stored — 0 plain, 1 nt, 2 sc1 (write-through, the line leaves the XCD's L2)
-#ifndef MEE_APPLY_STORE_MODE
-#define MEE_APPLY_STORE_MODE 0
-#endif
-__device__ __forceinline__ void store_row4(float4* p, const float4& v) {
-#if MEE_APPLY_STORE_MODE == 1
-    __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
-#elif MEE_APPLY_STORE_MODE == 2
-    const f32x4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
-#else
-    *p = v;
-#endif
-}
+// how an update's rows are stored: plain stores (streaming and write-through stores measured: nothing moves)
+__device__ __forceinline__ void store_row4(float4* p, const float4& v) { *p = v; }
 
 struct ApplyArgs {
     const int64_t* tkeys; float4 *values, *s1, *s2; uint64_t nb; uint32_t dim4;
@@ -306,10 +282,7 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
                                              uint32_t b, uint32_t rec_bucket0 /* split buckets: the bucket's first pending record */, uint32_t parity_rt, const GroupDesc* gdesc = nullptr) {
     constexpr bool SPLIT = MODE != kWhole, emit = MODE == kEmit, src_rec = MODE == kMerge;
     static_assert(!GROUPED || LOCATED, "a group's batch names rows, not keys");
-#ifndef MEE_AB_PPT
-#define MEE_AB_PPT (int)(kBucketCap / kApplyThreads)
-#endif
-    constexpr int PPT = SPLIT ? 1 : MEE_AB_PPT;   // sources per thread
+    constexpr int PPT = SPLIT ? 1 : (int)(kBucketCap / kApplyThreads);   // sources per thread
     // The kernel calls this from a loop (slab, then merge passes).  The thread index is re-read through an empty asm in every call so that
     // nothing derived from it looks loop-invariant: hoisted out of that loop, the per-thread address arithmetic of every array touched in
     // here stayed live across the whole kernel (110 VGPRs instead of 64: half the resident blocks per CU for every block's hot path).
@@ -440,16 +413,11 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
     // ---- 3. work items: a wave per turn — a quad (its four tiles sum one chunk each of ONE run) or four tile items ----
     [[maybe_unused]] uint32_t tl_turn = 0;
     // (a wave asks for its NEXT turn before it works on the current one: the counter's answer travels while the rows do)
-#ifndef MEE_AB_STATIC_TURNS
-#define MEE_AB_STATIC_TURNS 0
-#endif
     uint32_t turn_next = 0;
-    if (MEE_AB_STATIC_TURNS) turn_next = t >> 6;
-    else if (lane == 0) turn_next = atomicAdd(&L.next_turn, 1u);
+    if (lane == 0) turn_next = atomicAdd(&L.next_turn, 1u);
     while (true) {
         const uint32_t turn = __builtin_amdgcn_readfirstlane(turn_next);
-        if (MEE_AB_STATIC_TURNS) turn_next += kApplyWaves;
-        else if (turn < n_turns && lane == 0) turn_next = atomicAdd(&L.next_turn, 1u);
+        if (turn < n_turns && lane == 0) turn_next = atomicAdd(&L.next_turn, 1u);
 #if MEE_APPLY_TIMELINE
         if (!SPLIT && threadIdx.x == 0 && tl_turn < 16) A.dbg[16384ull * 8 + (uint64_t)blockIdx.x * 128 + 68 + 2 * tl_turn] = wall_clock64() << 8 | (turn >= n_turns ? 3u : turn < n_quads ? 1u : 2u) | (turn < n_quads ? min(255u, L.cnt[L.quad[turn] & 1023u]) : 0u) << 2 & 0xfcu;
         ++tl_turn;
@@ -735,14 +703,10 @@ __device__ __forceinline__ void run_units(ApplyLds& L, const ApplyArgs& A, const
         L.pre_slabs[threadIdx.x] = (uint32_t)ex; L.pre_pos[threadIdx.x] = (uint32_t)(ex >> 32); L.pre_a[threadIdx.x] = pre_a;   // (pre_slabs: slabs | hot keys' whole buckets << 20)
         if (threadIdx.x == 0) { L.pre_slabs[kApplyThreads] = (uint32_t)total; L.pre_pos[kApplyThreads] = (uint32_t)(total >> 32); }
         // (block-uniform.  As vector values the dozen schedule numbers derived from them below are spilled to scratch and reloaded one by one in front
-        // of every block's first unit — 3-5 us in the timeline; forced into SGPRs (MEE_AB_VECTOR_SCHED=0) the blocks start their units 5 us
+        // of every block's first unit — 3-5 us in the timeline; forced into SGPRs (readfirstlane) the blocks start their units 5 us
         // earlier, the kernel has 28 B less scratch, and the located kernel is SLOWER, 59.1 against 54.7 us, same box: the allocation of the hot
         // loops changes with it.  Measured, kept as it was.)
-#if MEE_AB_VECTOR_SCHED
         S = (uint32_t)total & 0xFFFFFu; H = ((uint32_t)total >> 20) & 0xFFFu;
-#else
-        S = __builtin_amdgcn_readfirstlane((uint32_t)total & 0xFFFFFu); H = __builtin_amdgcn_readfirstlane(((uint32_t)total >> 20) & 0xFFFu);
-#endif
         // (pinned host word: the units this batch had beyond its hash buckets — the next partition sizes its bucket count by it)
         if (blockIdx.x == 0 && threadIdx.x == 0) report_units(bk, A.h_slabs, S + H);
         MEE_TLS(A, blockIdx.x, 0, wall_clock64());
@@ -755,33 +719,14 @@ __device__ __forceinline__ void run_units(ApplyLds& L, const ApplyArgs& A, const
     // batch of a stream has none — : slabs first go to the blocks [0, O) INSTEAD of their buckets, and everything left over (more slabs, hot
     // keys' buckets, the displaced buckets [0, O)) follows in later rounds over the hash buckets' blocks, from the last one downwards.  A static
     // schedule: 768 blocks that claim their next unit from one word within a few microseconds of each other wait ~15 us for it (measured).
-#if MEE_SCHED_FROM_LDS
-    if constexpr (SKEW) __syncthreads();   // (thread 0's store of the scan's total: every round re-reads S and H from there)
-#endif
     const uint32_t G = gridDim.x, NH = min(A.nbk_hash, G), n_agents = G - NH;
-#if !MEE_SCHED_FROM_LDS
     const uint32_t s_agents = min(S, n_agents), O = min(S - s_agents, NH);        // slabs [0, s_agents): agents; [s_agents, s_agents + O): blocks [0, O)
     const uint32_t h_agents = min(H, n_agents - s_agents);                        // hot keys' whole buckets [0, h_agents): agents
     const uint32_t late_slabs = S - s_agents - O, late_hot = H - h_agents, n_late = late_slabs + late_hot + O + (A.nbk_hash > G ? A.nbk_hash - G : 0u);
-#endif
     [[maybe_unused]] uint32_t tl_i = 0, tl_units = 0;
     for (uint32_t round = 0;; ++round) {
         // (the thread index is re-read through an empty asm in every turn, as in process_slab: hoisted out of this loop, the per-thread addresses
         // of everything below stayed live across the whole loop and were spilled to scratch — a memory round trip in front of every use)
-#if MEE_SCHED_FROM_LDS
-        // the schedule numbers are recomputed from the two totals in LDS at the head of every round (scalar, short-lived): held across the rounds as
-        // vector values they were spilled to scratch right behind the scan and reloaded one by one in front of the block's first unit
-        uint32_t S_ = S, H_ = H;
-        if constexpr (SKEW) {
-            uint32_t sh = L.pre_slabs[kApplyThreads];
-            asm volatile("" : "+v"(sh));
-            sh = __builtin_amdgcn_readfirstlane(sh);
-            S_ = sh & 0xFFFFFu; H_ = (sh >> 20) & 0xFFFu;
-        }
-        const uint32_t s_agents = min(S_, n_agents), O = min(S_ - s_agents, NH);
-        const uint32_t h_agents = min(H_, n_agents - s_agents);
-        const uint32_t late_slabs = S_ - s_agents - O, late_hot = H_ - h_agents, n_late = late_slabs + late_hot + O + (A.nbk_hash > G ? A.nbk_hash - G : 0u);
-#endif
         uint32_t tx = threadIdx.x;
         asm volatile("" : "+v"(tx));
         bool is_slab = false, is_hot = false;
@@ -1093,18 +1038,13 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
 // latest batches of the table were (bucket_apply_launch); both are correct for any batch.  One kernel for both was the first form: the
 // scratch it declares for the skewed path — never touched by a uniform batch — cost the uniform batches 4-5 us of their 63 (the same bucket
 // path: 0 B of scratch 62.5 us, 56 B 63.1, 128-160 B 67-68, 600 B 94: resident waves are limited by the scratch the queue has for them).
-#ifndef MEE_FULL_BK_BY_POINTER
-#define MEE_FULL_BK_BY_POINTER 1
-#endif
 // How a kernel gets the table's BucketScratch: LEAN by value (kernel arguments: there when the first instruction runs); FULL through a pointer to the copy
 // bucket_scratch_alloc left in device memory — the struct never changes after mee_table_create, and as kernel arguments its ~20 pointers were 40 of the
 // 106 SGPRs the FULL kernel has (it spilled SGPRs into VGPR lanes from its first instruction on).
 template <bool FULL> struct BkArg { using type = BucketScratch; static __device__ __forceinline__ const BucketScratch& ref(const BucketScratch& a) { return a; } };
-#if MEE_FULL_BK_BY_POINTER
 template <> struct BkArg<true> { using type = const BucketScratch* __restrict__; static __device__ __forceinline__ const BucketScratch& ref(const BucketScratch* a) { return *a; } };
-#endif
 template <int KIND, int DIM4, bool LOCATED, bool GROUPED, bool FULL>
-__global__ __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES) void bkt_apply_kernel(ApplyArgs A, typename BkArg<FULL>::type bk_arg) {
+__global__ __launch_bounds__(kApplyThreads, kApplyWavesPerSimd) void bkt_apply_kernel(ApplyArgs A, typename BkArg<FULL>::type bk_arg) {
     const BucketScratch& bk = BkArg<FULL>::ref(bk_arg);
     __shared__ ApplyLds L;
     const GroupDesc* gdesc = nullptr;
@@ -1139,19 +1079,10 @@ __global__ __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES) void bkt_apply_kern
     if constexpr (FULL) {
         // (block-uniform) the unit list: a batch with a split bucket | a batch partitioned with buckets for hot keys (more buckets than blocks,
         // most of them empty)
-#if MEE_FULL_ONE_PATH
         // (a batch without a split bucket and without hot keys' buckets takes the same path: S = H = 0, every block its own bucket.  A second
         // instance of the bucket path for it made the kernel 66-72 KB of code — more than the 64 KB instruction cache two CUs share, with bucket,
         // slab and merge units running side by side on them)
         run_units<KIND, DIM4, LOCATED, GROUPED, true>(L, A, bk, parity, runs, size0, parity ? pa1 : pa0, parity ? pb1 : pb0, gdesc);
-#else
-        if (__builtin_amdgcn_readfirstlane(parity ? hdr.w : hdr.z) != 0 || A.nbk != A.nbk_hash) {
-            run_units<KIND, DIM4, LOCATED, GROUPED, true>(L, A, bk, parity, runs, size0, parity ? pa1 : pa0, parity ? pb1 : pb0, gdesc);
-        } else {
-            if (blockIdx.x == 0 && threadIdx.x == 0) report_units(bk, A.h_slabs, 0u);
-            if (own) run_units<KIND, DIM4, LOCATED, GROUPED, false>(L, A, bk, parity, runs, size0, 0u, 0u, gdesc);
-        }
-#endif
     } else {   // LEAN: the batch was partitioned into hash buckets only, block = bucket
         if (size0 <= kBucketCap) {
             if (blockIdx.x == 0 && threadIdx.x == 0) report_units(bk, A.h_slabs, 0u);   // (a block with a split bucket overwrites it when it is done, much later)
@@ -1160,7 +1091,7 @@ __global__ __launch_bounds__(kApplyThreads, MEE_APPLY_WAVES) void bkt_apply_kern
             seg_scan(L, runs, threadIdx.x);
             slow_bucket<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, size0, parity, gdesc, 0u, slow_shares(size0, A.nbk));
             // the stream is skewed: the FULL kernel from now on, with as many agents as this batch had slabs (the block that finishes last leaves the sum)
-            if (threadIdx.x == 0) { const uint32_t mine = (size0 + kSlab - 1) / kSlab, v = atomicAdd(&bk.seq[4], mine) + mine; bk.seq[5] = v; *A.h_slabs = v; }
+            if (threadIdx.x == 0) report_slabs(bk, A.h_slabs, (size0 + kSlab - 1) / kSlab, 0u);
         }
         if (__builtin_amdgcn_readfirstlane(parity ? hdr.w : hdr.z) != 0) {   // (block-uniform) the batch has a split bucket somewhere
             // helper duty: block x is share j >= 1 of the split bucket x - j (mod nbk).  Every wave looks at the same 64 buckets in front of
@@ -1190,8 +1121,6 @@ int bucket_scratch_alloc(mee_table* t) {
     bk.fast_max = t->max_batch;   // every batch the table takes: beyond ~5M keys (kMaxBuckets buckets of ~700) the buckets outgrow kBucketCap and go through their slabs
     // buckets the largest batch can be cut into (+ the hot keys' own): the strides of the totals' two copies and of the run matrices
     bk.n_buckets_max = bucket_count_for_host(bk.fast_max, bk.slots);
-    const uint32_t dd = bucket_count_for_host(bk.fast_max, (uint32_t)cus * kDedupBlocksPerCU, kDedupBucketMax);   // the dedup / assign geometry (meepo_dedup.hip)
-    if (dd > bk.n_buckets_max) bk.n_buckets_max = dd;
     bk.n_buckets_max += kHotCap;
     if (bk.n_buckets_max > kMaxBuckets) bk.n_buckets_max = kMaxBuckets;
     bk.n_buckets_max = (bk.n_buckets_max + 63u) & ~63u;
@@ -1202,7 +1131,7 @@ int bucket_scratch_alloc(mee_table* t) {
     alloc((void**)&bk.cnt_mat, (uint64_t)kPartBlocksMax * bk.n_buckets_max * 4);
     alloc((void**)&bk.off_mat, (uint64_t)kPartBlocksMax * bk.n_buckets_max * 4);
     alloc((void**)&bk.tot, 2ull * bk.n_buckets_max * 4);
-    alloc((void**)&bk.seq, 8 * 4);   // seq[0], seq[1], has_split[0], has_split[1]: ONE line of one page, read by every apply block with ONE load; [4]: the LEAN kernel's slab count
+    alloc((void**)&bk.seq, 8 * 4);   // seq[0], seq[1], has_split[0], has_split[1]: ONE line of one page, read by every apply block with ONE load; [4]: the LEAN kernel's slab count; [5]: shadow of the pinned host word; [6]: largest slab count published for this batch (report_slabs)
     bk.has_split = bk.seq ? bk.seq + 2 : nullptr;
     alloc((void**)&bk.hot_key, 2ull * kHotSlots * 8); alloc((void**)&bk.hot_idx, 2ull * kHotSlots * 4); alloc((void**)&bk.hot_n, 2 * 4);
     if (e == hipSuccess) e = hipMemset(bk.hot_key, 0, 2ull * kHotSlots * 8);
@@ -1217,9 +1146,12 @@ int bucket_scratch_alloc(mee_table* t) {
         alloc((void**)&bk.pend_slot, bk.fast_max * 8);
         alloc((void**)&bk.pend_row, bk.fast_max * (uint64_t)t->dim * sizeof(double));
     }
+    // mee_dedup_sum cuts a hot key's own bucket into windows of 1024 positions that leave one fp64 partial row each (meepo_dedup.hip): at most max_batch / 1024 + kHotCap
+    bk.sum_part_rows = (uint32_t)(bk.fast_max / 1024 + kHotCap + 8);
+    alloc((void**)&bk.sum_part, (uint64_t)bk.sum_part_rows * t->dim * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc((void**)&bk.h_slabs, 64, hipHostMallocMapped | hipHostMallocPortable);
     if (e == hipSuccess) { *bk.h_slabs = 0u; e = hipHostGetDevicePointer((void**)&bk.h_slabs_dev, bk.h_slabs, 0); }
-    bk.skew_adapt = 1; bk.skew_sticky = 0; bk.kernel_choice = -1; bk.xcd_split = MEE_XCD_SPLIT;
+    bk.skew_adapt = 1; bk.skew_sticky = 0; bk.kernel_choice = -1; bk.xcd_split = kXcdSplit;
     // the device-resident copy the FULL apply kernel reads (everything the DEVICE uses of this struct is fixed from here on; the tuning fields are the host's)
     bk.dev_copy = nullptr;
     alloc((void**)&bk.dev_copy, sizeof(BucketScratch));
@@ -1229,7 +1161,7 @@ int bucket_scratch_alloc(mee_table* t) {
 }
 void bucket_scratch_free(mee_table* t) {
     BucketScratch& bk = t->bk;
-    void* dev[] = {bk.pkey, bk.cnt_mat, bk.off_mat, bk.tot, bk.seq, bk.hot_key, bk.hot_idx, bk.hot_n, bk.pend_cnt, bk.ticket, bk.pend_key, bk.pend_slot, bk.pend_row};
+    void* dev[] = {bk.pkey, bk.cnt_mat, bk.off_mat, bk.tot, bk.seq, bk.hot_key, bk.hot_idx, bk.hot_n, bk.pend_cnt, bk.ticket, bk.pend_key, bk.pend_slot, bk.pend_row, bk.sum_part};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (bk.h_slabs) (void)hipHostFree(bk.h_slabs);
     if (bk.dev_copy) (void)hipFree(bk.dev_copy);
@@ -1292,11 +1224,7 @@ int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const Op
     // split buckets first (run_units)
     const bool full = t->part_full;   // as the partition decided: FULL = a skewed stream (hot keys' buckets may exist, the grid is one round of the block slots)
     const uint32_t grid = full ? t->part_grid : A.nbk;   // LEAN: block = bucket
-#if MEE_FULL_BK_BY_POINTER
 #define BK_FULL (t->bk.dev_copy)
-#else
-#define BK_FULL (t->bk)
-#endif
 #define BKT(K, D4, LOC) do { if (full) bkt_apply_kernel<K, D4, LOC, false, true><<<grid, kApplyThreads, 0, st>>>(A, BK_FULL); else bkt_apply_kernel<K, D4, LOC, false, false><<<grid, kApplyThreads, 0, st>>>(A, t->bk); } while (0)
 #define BKT_L(K, D4) do { if (d_desc) { if (full) bkt_apply_kernel<K, D4, true, true, true><<<grid, kApplyThreads, 0, st>>>(A, BK_FULL); else bkt_apply_kernel<K, D4, true, true, false><<<grid, kApplyThreads, 0, st>>>(A, t->bk); } \
                           else if (d_slots) BKT(K, D4, true); else BKT(K, D4, false); } while (0)

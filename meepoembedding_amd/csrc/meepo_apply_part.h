@@ -10,10 +10,7 @@ constexpr int kPartBlocks = 128;          // blocks that share the partition of 
 constexpr int kPartBlocksMax = 256;       // ... of a dedup / an election (meepo_dedup.hip: four runs per lane; its kernels have the registers for it): a batch of 1M keys is
                                           // partitioned by 256 blocks on 256 CUs instead of 128 (36 -> ~20 us)
 constexpr uint32_t kSlab = 512;           // positions per slab of a SPLIT bucket (= an apply block's thread count)
-#ifndef MEE_AB_BUCKET_CAP
-#define MEE_AB_BUCKET_CAP 1024
-#endif
-constexpr uint32_t kBucketCap = MEE_AB_BUCKET_CAP;     // largest bucket ONE apply block takes whole (two positions per thread; its LDS table has this many slots): only
+constexpr uint32_t kBucketCap = 1024;     // largest bucket ONE apply block takes whole (two positions per thread; its LDS table has this many slots): only
                                           // larger buckets — a key with >= ~700 occurrences in the batch — are split into slabs with pending records and a merge
 constexpr uint32_t kBucketMax = 352;      // positions per bucket aimed at, at most (Poisson(352) stays below 512 by 8 sigma: a uniform batch never needs a thread's second position)
 constexpr uint32_t kMaxBuckets = 8192;    // the partition keeps one LDS counter per bucket
@@ -23,29 +20,17 @@ constexpr uint32_t kMaxBuckets = 8192;    // the partition keeps one LDS counter
 // costs time, never results (a listed key that turns out rare is a small bucket of one key).  What it buys: the hash buckets of a skewed
 // batch hold no hot key any more — they are not split, their cold keys need no pending records and no merge — and a hot key's own bucket is
 // split into slabs of ONE key whose merge adds up one record per slab.
-#ifndef MEE_DD_BUCKET_MAX
-#define MEE_DD_BUCKET_MAX 512
-#endif
-constexpr uint32_t kDedupBlocksPerCU = 8;      // 256-thread blocks of meepo_dedup.hip resident per CU (19 KB of LDS, 2048 threads)
-constexpr uint32_t kDedupBucketMax = MEE_DD_BUCKET_MAX;   // positions per bucket of a dedup / assign partition with a geometry of its own (MEE_DD_OWN_GEOMETRY, meepo_dedup.hip: measured, off)
-#ifndef MEE_HOT_MIN
-#define MEE_HOT_MIN 256
-#endif
-constexpr uint32_t kHotCount = MEE_HOT_MIN;       // occurrences (in one bucket or one slab) that make a key hot: half a slab ...
+constexpr uint32_t kHotCount = 256;       // occurrences (in one bucket or one slab) that make a key hot: half a slab ...
 // ... or n / 1024 of a larger batch: the set numbers the first kHotCap comers, so the bar must leave fewer candidates than that (Zipf(1.05):
 // ~68 keys reach 256 occurrences in a batch of 256K, ~250 do in a batch of 1M — but only ~66 reach 1024)
-#ifndef MEE_HOT_DIV
-#define MEE_HOT_DIV 1024   // (a lower bar — 160 or 200 occurrences per 256K keys — lists more keys and gains nothing: Zipf located kernel 56.4 / 55.1 against 54.7-54.9 us)
-#endif
-inline uint32_t hot_count_for(uint64_t n) { const uint64_t c = n / MEE_HOT_DIV; return c > kHotCount ? (uint32_t)c : kHotCount; }
+// (a lower bar — 160 or 200 occurrences per 256K keys — lists more keys and gains nothing: Zipf located kernel 56.4 / 55.1 against 54.7-54.9 us)
+inline uint32_t hot_count_for(uint64_t n) { const uint64_t c = n / 1024; return c > kHotCount ? (uint32_t)c : kHotCount; }
 constexpr uint32_t kHotSlots = 512;       // slots of the hot-key set
 constexpr uint32_t kHotCap = 128;         // hot keys that get a bucket (the set takes no more keys once that many are numbered: its load stays ~0.25); a Zipf(1.05) batch of 256K keys lists ~50, one of 1M keys ~120
-// MEE_APPLY_WAVES: waves per SIMD the register allocator must leave room for in the bucket kernel (meepo_apply.hip): 8 = 64 VGPRs, four
-// 512-thread blocks per CU (6 = 80 VGPRs, three blocks)
-#ifndef MEE_APPLY_WAVES
-#define MEE_APPLY_WAVES 6
-#endif
-constexpr uint32_t kApplyBlocksPerCU = MEE_APPLY_WAVES / 2; // resident blocks of the bucket kernel per CU (512 threads = 2 waves per SIMD each)
+// waves per SIMD the register allocator must leave room for in the bucket kernel (meepo_apply.hip): 6 = 80 VGPRs, three 512-thread blocks per CU
+// (8 = 64 VGPRs, four blocks: measured slower)
+constexpr int kApplyWavesPerSimd = 6;
+constexpr uint32_t kApplyBlocksPerCU = kApplyWavesPerSimd / 2; // resident blocks of the bucket kernel per CU (512 threads = 2 waves per SIMD each)
 
 // How many buckets a batch of n keys is cut into.  One apply block per bucket, all buckets the same size (a hash), all blocks equally long:
 // with B blocks on S resident slots the kernel takes ceil(B / S) rounds, so B is made a MULTIPLE of S = CUs x kApplyBlocksPerCU — 1024
@@ -73,6 +58,13 @@ __device__ __forceinline__ uint32_t apply_bucket_of(int64_t key, uint32_t nbk) {
 // (measured: no difference in step time either way, 85.9-88.0 against 87.5-87.7 us per uniform apply; it just keeps the bus quiet).
 __device__ __forceinline__ void report_units(const BucketScratch& bk, uint32_t* h_units, uint32_t v) {
     if (bk.seq[5] != v) { bk.seq[5] = v; *h_units = v; }
+}
+// A block that met a split bucket where the host expected none (LEAN apply kernel, dedup / assign): adds the bucket's slabs to the batch's running sum (seq[4], reset by
+// the partition) and publishes the sum.  Several such blocks finish in any order: only a sum larger than everything published for this batch so far (atomicMax on seq[6])
+// reaches the shadow word and the host, so a smaller partial sum that lands late never replaces a larger one.
+__device__ __forceinline__ void report_slabs(const BucketScratch& bk, uint32_t* h_units, uint32_t mine, uint32_t base) {
+    const uint32_t v = base + atomicAdd(&bk.seq[4], mine) + mine;
+    if (atomicMax(&bk.seq[6], v) < v) { bk.seq[5] = v; *h_units = v; }
 }
 // where a key sits in the hot-key set: Fibonacci hashing, ONE multiply — a full mixer here cost the apply kernels (which report hot keys) registers: with
 // mix64 the grouped LEAN kernel spilled 12 B to scratch
@@ -218,7 +210,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
         if (j < nbk) { bk.pend_cnt[j] = 0u; bk.ticket[j] = 0u; }
         bk.tot[(parity ^ 1u) * bk.n_buckets_max + j] = 0u;
     }
-    if (blk == 0 && threadIdx.x == 0) { op->n_part = 0u; bk.has_split[parity ^ 1u] = 0u; bk.seq[1] = parity; bk.seq[4] = 0u; }
+    if (blk == 0 && threadIdx.x == 0) { op->n_part = 0u; bk.has_split[parity ^ 1u] = 0u; bk.seq[1] = parity; bk.seq[4] = 0u; bk.seq[6] = 0u; }
     __syncthreads();
     bool bad = false;
     // in_regs: the keys' buckets, two per register (< 2^16: kMaxBuckets + kHotCap), for the second pass — in the partition kernel of an apply only:

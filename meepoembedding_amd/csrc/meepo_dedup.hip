@@ -16,20 +16,16 @@
 //                           EMPTY and gives reserved keys their miss_index).
 //   bkt_assign_kernel       mee_assign: per distinct key the LAST position wins (atomicMax in the LDS table), one probe per distinct key, the
 //                           winner's row overwrites the key's row; every occurrence gets the key's found byte.
+//   bkt_dedup_sum_kernel    mee_dedup_sum (round 5): dedup_keys' outputs plus, per distinct key, its occurrence count and the fp64 sum of its rows
+//                           rounded once to fp32 — what a rank sends to a key's owner instead of one gradient row per occurrence.  Sync-free.
 #include <hip/hip_runtime.h>
 
 #include "meepo_apply_part.h"
 
 namespace mee {
 
-#ifndef MEE_DD_OWN_GEOMETRY
-#define MEE_DD_OWN_GEOMETRY 0   // 1: bucket count by this file's block slots (8 x 256 CUs = 2048, buckets of <= 512: ONE round for 1M keys) instead of the apply's
-// (3072 buckets of 341: a round and a half).  Measured per 1M keys, same box: uniform dedup_keys 70.9 -> 75.7 us, assign 182 -> 188-200; Zipf 87.4 -> 85 / 118 -> 120: off
-#endif
-#ifndef MEE_DD_BLOCKS_FROM
-#define MEE_DD_BLOCKS_FROM 100000   // (x 512K keys) batches from this size on are partitioned by 256 blocks instead of 128.  Measured at 1M keys (= 2): the partition
-// gets faster (23.4 -> 20.8 us uniform, 27.4 -> 22.6 Zipf) and the consumers lose more than that to twice the runs per bucket (dedup_keys 70.2 -> 75.6 us): off
-#endif
+// The partition's geometry is the apply's (bucket_count_for: 3072 buckets of 341 per 1M keys, 128 partition blocks).  Measured alternatives, DESIGN.md §8: a bucket count
+// by this file's own block slots (2048 buckets of <= 512: one round) — dedup_keys 70.9 -> 75.7 us per 1M keys —, 256 partition blocks — 70.2 -> 75.6 us (twice the runs per bucket).
 constexpr int kDedupThreads = 256;
 constexpr int kDedupWaves = kDedupThreads / 64;
 constexpr uint32_t kDedupSlots = 1024;        // LDS hash table of one pass
@@ -41,7 +37,10 @@ struct DedupLds {
     uint32_t cnt[kDedupSlots];                // occurrences (hot-key report)
     uint32_t seg_first[kPartBlocksMax + 1], seg_at[kPartBlocksMax];
     unsigned long long wsum[kDedupWaves];
-    uint32_t stk_bits[40], stk_val[40];       // passes still to do: (hash bits, value)
+    unsigned long long stk_val[72];           // passes still to do: (hash bits, value) — prefixes of mix64b(key), up to all 64 bits
+    uint32_t stk_bits[72];
+    uint32_t hp[8];                           // hot_plan's hand-over words; the hot windows of an assign
+    uint32_t pre[kDedupWaves];                // per-wave partial results (the totals in front of a bucket; a window's last position)
     uint32_t stk_n, n_distinct, overflow, base;
 };
 
@@ -88,17 +87,14 @@ __device__ __forceinline__ uint32_t dd_lookup(const DedupLds& L, unsigned long l
 // A bucket of up to 4 x 256 entries — nearly every hash bucket — is held in registers from the build pass on (key and batch position of the thread's four
 // entries): the pass that writes each position's result afterwards does not fetch them a second time (one dependent round trip less per block).
 struct DdHeld { int64_t k[4]; uint32_t p[4]; bool valid; };
-#ifndef MEE_DD_HOLD
-#define MEE_DD_HOLD 1
-#endif
 template <bool LAST>
-__device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, uint32_t size, uint32_t bits, uint32_t val, DdHeld& H) {
+__device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, uint32_t size, uint32_t bits, uint64_t val, DdHeld& H) {
     const uint32_t t = threadIdx.x;
-    H.valid = MEE_DD_HOLD && size <= 4u * kDedupThreads;   // (block-uniform)
+    H.valid = size <= 4u * kDedupThreads;   // (block-uniform)
     for (uint32_t j = t; j < kDedupSlots; j += kDedupThreads) { L.key[j] = 0ull; L.val[j] = 0u; L.cnt[j] = 0u; }
     if (t == 0) { L.n_distinct = 0u; L.overflow = 0u; }
     __syncthreads();
-    const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u;
+    const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
     constexpr int kIn = 4;   // entries a thread has in flight per step (one dependent round trip per step: a bucket of 4 000 entries takes 4 steps, not 16)
     for (uint32_t e0 = 0; e0 < size; e0 += kIn * kDedupThreads) {   // block-uniform trip count: the wave ballots below need whole waves
         int64_t kq[kIn];
@@ -122,7 +118,7 @@ __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, u
             const int64_t key = kq[q];
             const uint32_t p = pq[q];
             const unsigned long long bkey = (unsigned long long)key ^ kBias;
-            const bool mine = key != kEmpty && ((uint32_t)mix64b((uint64_t)key) & mask) == val;   // (EMPTY is in no bucket: it marks a lane past the end)
+            const bool mine = key != kEmpty && (mix64b((uint64_t)key) & mask) == val;   // (EMPTY is in no bucket: it marks a lane past the end)
             // all of the wave's entries in this pass carry one key: one lane speaks for the wave
             const unsigned long long act = __ballot(mine);
             if (act == 0ull) continue;
@@ -155,14 +151,18 @@ __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, u
 }
 
 // the pass driver: DFS over hash prefixes, every pass that fits is handed to `emit(bits, val)`
+// (The prefixes are 64 bits wide: mix64b is a bijection, so ANY set of distinct keys separates within 64 bits and the stack never holds more than 65 entries.
+// Round 4 stopped at 32 bits and dropped — silently — a pass of more than 896 keys that share the low 32 bits of mix64b: constructible, both mixers are public.)
 template <bool LAST, class Emit>
-__device__ __forceinline__ void dd_passes(DedupLds& L, const BucketScratch& bk, uint32_t size, uint32_t parity, uint32_t hot_count, Emit emit) {
-    if (threadIdx.x == 0) { L.stk_n = 1u; L.stk_bits[0] = 0u; L.stk_val[0] = 0u; }
+__device__ __forceinline__ void dd_passes(DedupLds& L, const BucketScratch& bk, uint32_t size, uint32_t parity, uint32_t hot_count, uint32_t* status, Emit emit) {
+    if (threadIdx.x == 0) { L.stk_n = 1u; L.stk_bits[0] = 0u; L.stk_val[0] = 0ull; }
     __syncthreads();
     while (true) {
         const uint32_t n = __builtin_amdgcn_readfirstlane(L.stk_n);
         if (n == 0) break;
-        const uint32_t bits = __builtin_amdgcn_readfirstlane(L.stk_bits[n - 1]), val = __builtin_amdgcn_readfirstlane(L.stk_val[n - 1]);
+        const uint32_t bits = __builtin_amdgcn_readfirstlane(L.stk_bits[n - 1]);
+        const unsigned long long val_v = L.stk_val[n - 1];
+        const uint64_t val = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)val_v) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(val_v >> 32)) << 32;
         __syncthreads();
         if (threadIdx.x == 0) L.stk_n = n - 1;
         DdHeld held;
@@ -171,11 +171,13 @@ __device__ __forceinline__ void dd_passes(DedupLds& L, const BucketScratch& bk, 
             for (uint32_t s = threadIdx.x; s < kDedupSlots; s += kDedupThreads)
                 if (L.cnt[s] >= hot_count) report_hot_key(bk, parity, (int64_t)(L.key[s] ^ kBias));
             emit(bits, val, held);
-        } else if (threadIdx.x == 0 && bits < 32 && L.stk_n + 2 <= 40) {   // (mix64b is a bijection: distinct keys separate within 64 bits; 32 suffice for any batch)
-            const uint32_t m = L.stk_n;
-            L.stk_bits[m] = bits + 1; L.stk_val[m] = val;
-            L.stk_bits[m + 1] = bits + 1; L.stk_val[m + 1] = val | 1u << bits;
-            L.stk_n = m + 2;
+        } else if (threadIdx.x == 0) {
+            if (bits < 64 && L.stk_n + 2 <= 72) {
+                const uint32_t m = L.stk_n;
+                L.stk_bits[m] = bits + 1; L.stk_val[m] = val;
+                L.stk_bits[m + 1] = bits + 1; L.stk_val[m + 1] = val | 1ull << bits;
+                L.stk_n = m + 2;
+            } else if (status) atomicOr(status, (uint32_t)MEE_STATUS_INTERNAL);   // cannot happen (see above); never lose keys silently
         }
         __syncthreads();
     }
@@ -187,6 +189,7 @@ struct DedupArgs {
     uint32_t* h_slabs;
     int64_t* uniq; int64_t* inverse;   // dedup
     uint32_t size_from_runs;           // the bucket totals were not computed (assign without hot keys' buckets): a bucket's size is the sum of its runs
+    uint32_t* status;                  // the table's sticky status word
 };
 
 // A hot key's own bucket (b >= nbk_hash: the partition sent exactly ONE key there) needs no table: every entry is that key.  It is cut into
@@ -195,7 +198,9 @@ struct DedupArgs {
 // hot keys' numbers in the unique list come FIRST — hot bucket h gets the count of non-empty hot buckets in front of it, which every block
 // reads off the same kHotCap totals —, and the hash buckets' blocks number their keys from H (the non-empty hot buckets) on.
 constexpr uint32_t kHotWindow = 4096;
+constexpr uint32_t kSumWindow = 1024;   // ... of a dedup that also SUMS rows (every entry of a window is a 256-byte row to fetch: 16 round trips for the block's 16 tiles)
 struct HotPlan { uint32_t H, units, h, win, n_win, rank, size; bool valid; };   // H, units: non-empty hot buckets and their windows in all;   // this block's window: hot bucket h, window `win` of n_win, the key's number `rank`
+template <uint32_t WIN>
 __device__ __forceinline__ HotPlan hot_plan(DedupLds& L, const BucketScratch& bk, const DedupArgs& A, uint32_t parity_guess_tot0, uint32_t parity_guess_tot1, uint32_t parity, int x /* window unit, or -1: only H is wanted */) {
     // (called by all threads; thread h < n_hot <= 128 holds hot bucket h's total.)  Waves 0 and 1 scan their 64 buckets' window counts and non-empty
     // flags (DPP), LDS carries wave 0's sums to wave 1, the thread whose bucket holds window x publishes it: a dozen instructions per thread
@@ -205,21 +210,21 @@ __device__ __forceinline__ HotPlan hot_plan(DedupLds& L, const BucketScratch& bk
     HotPlan P{0, 0, 0, 0, 0, 0, 0, false};
     if (n_hot == 0) return P;   // (block-uniform)
     const uint32_t sz = t < n_hot ? (parity ? parity_guess_tot1 : parity_guess_tot0) : 0u;
-    const uint32_t nw = (sz + kHotWindow - 1) / kHotWindow, ne = sz != 0;
+    const uint32_t nw = (sz + WIN - 1) / WIN, ne = sz != 0;
     uint32_t iw = 0, ie = 0;
     if (t < 128) { iw = wave_incl_scan_u32(nw); ie = wave_incl_scan_u32(ne); }
-    if (t == 63) { L.stk_val[32] = iw; L.stk_val[33] = ie; }
-    if (t == 0) L.stk_val[38] = 0xFFFFFFFFu;
+    if (t == 63) { L.hp[0] = iw; L.hp[1] = ie; }
+    if (t == 0) L.hp[6] = 0xFFFFFFFFu;
     __syncthreads();
-    if (t >= 64 && t < 128) { iw += L.stk_val[32]; ie += L.stk_val[33]; }
-    if (t == 127) { L.stk_val[34] = iw; L.stk_val[35] = ie; }
+    if (t >= 64 && t < 128) { iw += L.hp[0]; ie += L.hp[1]; }
+    if (t == 127) { L.hp[2] = iw; L.hp[3] = ie; }
     if (x >= 0 && t < 128 && nw != 0 && (uint32_t)x >= iw - nw && (uint32_t)x < iw) {   // exactly one thread (the windows' ranges are disjoint)
-        L.stk_val[36] = (uint32_t)x - (iw - nw); L.stk_val[37] = nw; L.stk_val[38] = t; L.stk_val[39] = ie - 1u; L.stk_bits[39] = sz;
+        L.hp[4] = (uint32_t)x - (iw - nw); L.hp[5] = nw; L.hp[6] = t; L.hp[7] = ie - 1u; L.base = sz;
     }
     __syncthreads();
-    P.units = L.stk_val[34]; P.H = L.stk_val[35];
-    if (x >= 0 && L.stk_val[38] != 0xFFFFFFFFu) { P.win = L.stk_val[36]; P.n_win = L.stk_val[37]; P.h = L.stk_val[38]; P.rank = L.stk_val[39]; P.size = L.stk_bits[39]; P.valid = true; }
-    __syncthreads();   // (the stack words are the pass driver's afterwards)
+    P.units = L.hp[2]; P.H = L.hp[3];
+    if (x >= 0 && L.hp[6] != 0xFFFFFFFFu) { P.win = L.hp[4]; P.n_win = L.hp[5]; P.h = L.hp[6]; P.rank = L.hp[7]; P.size = L.base; P.valid = true; }
+    __syncthreads();   // (the hand-over words are reused)
     return P;
 }
 
@@ -234,7 +239,7 @@ __device__ __forceinline__ uint32_t dd_unit(const DedupArgs& A) {
 // bucket's runs in the partition blocks' slices and (PREFIX: the dedup) the totals of the hash buckets in front of this one.  `P.H` = the
 // non-empty hot keys' buckets (their keys are numbered first); a block beyond the buckets (blockIdx >= nbk) gets its window of a hot key's
 // bucket in `P` instead.  `before` (PREFIX) = the positions in the hash buckets in front of this one.
-template <bool PREFIX>
+template <bool PREFIX, uint32_t WIN = kHotWindow>
 __device__ __forceinline__ uint32_t dd_bucket(DedupLds& L, const BucketScratch& bk, const DedupArgs& A, uint32_t& parity, HotPlan& P, uint32_t& before) {
     const uint32_t b = dd_unit(A);
     const bool own = b < A.nbk, hash = b < A.nbk_hash;
@@ -248,7 +253,7 @@ __device__ __forceinline__ uint32_t dd_bucket(DedupLds& L, const BucketScratch& 
         for (uint32_t j = threadIdx.x; j < b; j += kDedupThreads) { s0 += bk.tot[j]; s1 += bk.tot[bk.n_buckets_max + j]; }
     parity = __builtin_amdgcn_readfirstlane(hdr.y);
     if (b == 0 && threadIdx.x == 0) atomicAdd(&bk.seq[0], 1u);   // this partition is consumed
-    P = hot_plan(L, bk, A, ht0, ht1, parity, own ? -1 : (int)(b - A.nbk));
+    P = hot_plan<WIN>(L, bk, A, ht0, ht1, parity, own ? -1 : (int)(b - A.nbk));
     // the pinned host word the next partition sizes itself by: the units this batch has beyond its hash buckets — the hot keys' windows (they keep
     // their buckets while they stay hot) and, added below as they turn up, the slabs an oversized hash bucket would make
     if (b == 0 && threadIdx.x == 0) report_units(bk, A.h_slabs, P.units);
@@ -265,13 +270,13 @@ __device__ __forceinline__ uint32_t dd_bucket(DedupLds& L, const BucketScratch& 
             uint32_t mine = parity ? s1 : s0;
 #pragma unroll
             for (int d = 32; d; d >>= 1) mine += (uint32_t)__shfl_xor((int)mine, d);
-            if ((threadIdx.x & 63) == 0) L.stk_val[threadIdx.x >> 6] = mine;
+            if ((threadIdx.x & 63) == 0) L.pre[threadIdx.x >> 6] = mine;
         }
     }
     __syncthreads();
     if (A.size_from_runs && own) size = __builtin_amdgcn_readfirstlane(L.seg_first[kPartBlocksMax]);   // (dd_seg_scan left the sum of the runs there)
-    if (own && size > kBucketCap && threadIdx.x == 0) { const uint32_t mine = (size + kSlab - 1) / kSlab, v = P.units + atomicAdd(&bk.seq[4], mine) + mine; bk.seq[5] = v; *A.h_slabs = v; }   // a skewed stream: hot keys get buckets of their own next time
-    if (PREFIX && own) for (int w = 0; w < kDedupWaves; ++w) before += L.stk_val[w];
+    if (own && size > kBucketCap && threadIdx.x == 0) report_slabs(bk, A.h_slabs, (size + kSlab - 1) / kSlab, P.units);   // a skewed stream: hot keys get buckets of their own next time
+    if (PREFIX && own) for (int w = 0; w < kDedupWaves; ++w) before += L.pre[w];
     __syncthreads();
     return size;
 }
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
     // every bucket owns as many entries of the list as it has positions, its distinct keys fill the front of that slice and the rest stays
     // EMPTY.  No counter: 3 000 blocks that reserve their slices from one word take 35 us for that alone (one word serves ~88 atomics per us).
     uint32_t slice = P.H + before;
-    dd_passes<false>(L, bk, size, parity, A.hot_count, [&](uint32_t bits, uint32_t val, const DdHeld& held) {
+    dd_passes<false>(L, bk, size, parity, A.hot_count, A.status, [&](uint32_t bits, uint64_t val, const DdHeld& held) {
         const uint32_t t = threadIdx.x;
         // the pass's distinct keys get consecutive numbers (block scan over the table's slots), its slice of the unique list one atomic
         constexpr uint32_t per = kDedupSlots / kDedupThreads;
@@ -319,11 +324,11 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
             if (L.key[s] != 0ull) { A.uniq[base + idx] = (int64_t)(L.key[s] ^ kBias); L.val[s] = idx++; }
         }
         __syncthreads();
-        const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u;
+        const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
         if (held.valid) {   // (block-uniform) the entries are still in registers
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (held.k[q] != kEmpty && ((uint32_t)mix64b((uint64_t)held.k[q]) & mask) == val) A.inverse[held.p[q]] = (int64_t)(base + L.val[dd_lookup(L, (unsigned long long)held.k[q] ^ kBias)]);
+                if (held.k[q] != kEmpty && (mix64b((uint64_t)held.k[q]) & mask) == val) A.inverse[held.p[q]] = (int64_t)(base + L.val[dd_lookup(L, (unsigned long long)held.k[q] ^ kBias)]);
             return;
         }
         for (uint32_t e0 = 0; e0 < size; e0 += 4 * kDedupThreads) {   // four entries in flight per thread
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (kq[q] != kEmpty && ((uint32_t)mix64b((uint64_t)kq[q]) & mask) == val) A.inverse[pq[q]] = (int64_t)(base + L.val[dd_lookup(L, (unsigned long long)kq[q] ^ kBias)]);
+                if (kq[q] != kEmpty && (mix64b((uint64_t)kq[q]) & mask) == val) A.inverse[pq[q]] = (int64_t)(base + L.val[dd_lookup(L, (unsigned long long)kq[q] ^ kBias)]);
         }
     });
 }
@@ -345,14 +350,15 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
 // for every i (the dedup kernel overwrites the first n_unique of them), d_inverse[i] = miss_index for reserved keys (they are in no bucket)
 __global__ __launch_bounds__(1024) void bkt_sort_dedup_kernel(const int64_t* __restrict__ keys, uint32_t n, uint32_t nbk_hash, uint32_t nbk, uint32_t per_block, BucketScratch bk,
                                                               uint32_t* status, OpCounters* op, int64_t* __restrict__ uniq, int64_t* __restrict__ inverse, int64_t miss_index,
-                                                              uint8_t* __restrict__ found, uint32_t tot_atomics) {
+                                                              uint8_t* __restrict__ found, uint32_t tot_atomics, uint32_t* __restrict__ counts) {
     extern __shared__ unsigned long long part_lds[];
     __shared__ unsigned long long wsum[1024 / 64];
     const uint32_t lo = blockIdx.x * per_block, hi = min(n, lo + per_block);
     if (uniq) {
         for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
             uniq[i] = kEmpty;
-            if (reserved_key(keys[i])) inverse[i] = miss_index;
+            if (counts) counts[i] = 0u;   // (mee_dedup_sum: padding has no occurrences)
+            if (inverse && reserved_key(keys[i])) inverse[i] = miss_index;
         }
     } else if (found) {   // assign: every position's found byte starts as 1 (0 for reserved keys: they are in no bucket) — coalesced stores here; the assign
         // kernel then writes only the bytes of keys it does NOT find (1M scattered byte stores cost 10-17 us of a 180 us assign: a partial-line fill each)
@@ -394,13 +400,13 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
         }
 #pragma unroll
         for (int d = 32; d; d >>= 1) pm = max(pm, (uint32_t)__shfl_xor((int)pm, d));
-        if (lane == 0) L.stk_val[t >> 6] = pm;
+        if (lane == 0) L.pre[t >> 6] = pm;
         // every window probes for itself (one bucket line): its entries' found bytes need no word from the other windows
         int64_t slot = -1;
         if (t < 64) {
             bool is_new, full;
             slot = tile_locate<false, false>(A.tkeys, A.nb, key, tile == 0, tile, tl, is_new, full);
-            if (t == 0) { L.base = (uint32_t)(slot >= 0); L.stk_bits[0] = (uint32_t)slot; L.stk_bits[1] = (uint32_t)((uint64_t)slot >> 32); }
+            if (t == 0) { L.base = (uint32_t)(slot >= 0); L.hp[0] = (uint32_t)slot; L.hp[1] = (uint32_t)((uint64_t)slot >> 32); }
         }
         __syncthreads();
         if (A.found && !L.base) {   // (block-uniform; the partition's launch wrote the 1s)
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
         }
         if (t == 0) {
             uint32_t m = 0;
-            for (int w = 0; w < kDedupWaves; ++w) m = max(m, L.stk_val[w]);
+            for (int w = 0; w < kDedupWaves; ++w) m = max(m, L.pre[w]);
             (void)__hip_atomic_fetch_max(&bk.pend_cnt[b], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the maximum is in before the ticket is drawn
             const uint32_t tk = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -425,12 +431,12 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
         __syncthreads();
         if (L.overflow && L.base && t < 16) {
             const uint32_t win = L.n_distinct;
-            const int64_t sl = (int64_t)((uint64_t)L.stk_bits[0] | (uint64_t)L.stk_bits[1] << 32);
+            const int64_t sl = (int64_t)((uint64_t)L.hp[0] | (uint64_t)L.hp[1] << 32);
             for (uint32_t col = t; col < dim4; col += 16) A.rows[(uint64_t)sl * dim4 + col] = A.values[(uint64_t)win * dim4 + col];
         }
         return;
     }
-    dd_passes<true>(L, bk, size, parity, A.d.hot_count, [&](uint32_t bits, uint32_t val, const DdHeld& held) {
+    dd_passes<true>(L, bk, size, parity, A.d.hot_count, A.d.status, [&](uint32_t bits, uint64_t val, const DdHeld& held) {
         const uint32_t t = threadIdx.x;
         const int lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6;
         // the pass's distinct keys as a dense list (block scan over the table's slots; the occurrence counts have been read: their array holds the list)
@@ -487,37 +493,255 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
         }
         __syncthreads();
         if (A.found && held.valid) {   // (block-uniform) the entries are still in registers
-            const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u;
+            const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (held.k[q] != kEmpty && ((uint32_t)mix64b((uint64_t)held.k[q]) & mask) == val && L.val[dd_lookup(L, (unsigned long long)held.k[q] ^ kBias)] == 0u) A.found[held.p[q]] = 0;   // (the partition's launch wrote the 1s)
+                if (held.k[q] != kEmpty && (mix64b((uint64_t)held.k[q]) & mask) == val && L.val[dd_lookup(L, (unsigned long long)held.k[q] ^ kBias)] == 0u) A.found[held.p[q]] = 0;   // (the partition's launch wrote the 1s)
         } else if (A.found) {
-            const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u;
+            const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
             for (uint32_t e = t; e < size; e += kDedupThreads) {
                 const uint32_t at = dd_entry_at(L, e);
                 const int64_t key = bk.pkey[at];
-                if (((uint32_t)mix64b((uint64_t)key) & mask) != val) continue;
+                if ((mix64b((uint64_t)key) & mask) != val) continue;
                 if (L.val[dd_lookup(L, (unsigned long long)key ^ kBias)] == 0u) A.found[bk.pos[at]] = 0;
             }
         }
     });
 }
 
+// ---- duplicate-key reduction with row sums (mee_dedup_sum, SPEC.md §4): the rows of a key's occurrences added up in fp64, rounded once -------
+// What mee_dedup_keys does, and per distinct key its occurrence count and summed row.  A pass's table gives every run (distinct key) its
+// number and — block prefix sums over the table's slots — the place of its sources in a list sorted by run; the sources are filled in through an
+// LDS cursor per run; then the runs are summed by as much of the block as their length wants: a run of up to 8 sources by one 16-lane TILE (two
+// dependent round trips of four rows), up to 256 by a WAVE (its four tiles, 16 rows per round trip, combined with two shuffles), longer ones by the
+// whole BLOCK (64 rows per round trip, the four waves' sums combined through 2 KB of LDS).  The runs are numbered short ones first, so that the
+// three classes are three index ranges of one list.  A bucket of more than 1024 positions keeps its sorted sources in global scratch (one
+// max_batch-sized array, every bucket owns the range its positions own), written and re-read with agent-scope accesses by the same block.
+// A hot key's own bucket (one key) is cut into windows of kSumWindow positions, one block each; a window leaves an fp64 partial row, draws a
+// ticket, and the window that draws the last one adds the partial rows up (pending-record discipline of the apply: write-through stores, drained
+// before the ticket, agent-scope loads; no fence).
+constexpr uint32_t kSumTileMax = 8, kSumWaveMax = 256;
+struct SumLds {
+    DedupLds d;
+    uint32_t off[kDedupSlots];        // per run: where its sources begin in the sorted list (while the list is filled: the fill cursor)
+    uint32_t src[kDedupSlots];        // the sorted list (batch positions), when the unit has at most kDedupSlots positions
+    uint16_t items[kDedupSlots];      // run number -> table slot
+    alignas(16) double prow[kDedupWaves][64];   // block-level sums: one partial row (64 floats' worth) per wave
+    uint32_t is_last;
+};
+struct SumArgs {
+    DedupArgs d;
+    const float4* grads; float4* gsum; uint32_t* counts; uint32_t dim4;
+    uint32_t* src_scratch;            // [max_batch] sorted sources of buckets beyond the LDS list
+    double* part; uint32_t max_part;  // fp64 partial rows of the hot keys' windows, one per window unit
+};
+struct D4 { double x, y, z, w; };
+__device__ __forceinline__ D4 d4_tiles_sum(D4 v) {   // over the wave's four tiles (lanes l, l ^ 16, l ^ 32, l ^ 48)
+    v.x += __shfl_xor(v.x, 16); v.y += __shfl_xor(v.y, 16); v.z += __shfl_xor(v.z, 16); v.w += __shfl_xor(v.w, 16);
+    v.x += __shfl_xor(v.x, 32); v.y += __shfl_xor(v.y, 32); v.z += __shfl_xor(v.z, 32); v.w += __shfl_xor(v.w, 32);
+    return v;
+}
+// sources first, first + 1, .. first + 3, then first + step .. of a run of c: four rows in flight, added up in fp64; a lane past the end reads the run's last row
+// again and adds +0.0 (every round trip carries four rows).  load(j, col) = float4 column `col` of the run's source j as four doubles.
+template <class Load>
+__device__ __forceinline__ D4 run_sum4(uint32_t first, uint32_t step, uint32_t c, uint32_t col, Load load) {
+    D4 s{0.0, 0.0, 0.0, 0.0};
+    for (uint32_t q0 = first; q0 < c; q0 += step) {
+        D4 g[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) g[q] = load(min(q0 + q, c - 1), col);
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const bool on = q0 + q < c;
+            s.x += on ? g[q].x : 0.0; s.y += on ? g[q].y : 0.0; s.z += on ? g[q].z : 0.0; s.w += on ? g[q].w : 0.0;
+        }
+    }
+    return s;
+}
+// the whole block sums ONE run of c sources, 16 columns (64 floats) at a time; out(col, total) is called by thread tl < 16 of wave 0 for its column.
+// Block-uniform control flow (barriers inside).
+template <class Load, class Out>
+__device__ __forceinline__ void block_run_sum(SumLds& L, uint32_t dim4, uint32_t c, Load load, Out out) {
+    const uint32_t t = threadIdx.x, lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6, T = wv * 4 + tile;
+    for (uint32_t cg = 0; cg < dim4; cg += 16) {
+        const uint32_t col = cg + tl;
+        D4 v = col < dim4 ? run_sum4(4 * T, 16 * kDedupWaves, c, col, load) : D4{0.0, 0.0, 0.0, 0.0};
+        v = d4_tiles_sum(v);
+        if (tile == 0) { double* d = &L.prow[wv][tl * 4]; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+        __syncthreads();
+        if (t < 16 && col < dim4) {
+            D4 r{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int w = 0; w < kDedupWaves; ++w) { const double* d = &L.prow[w][t * 4]; r.x += d[0]; r.y += d[1]; r.z += d[2]; r.w += d[3]; }
+            out(col, r);
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ D4 grad_row4(const float4* __restrict__ grads, uint32_t row, uint32_t dim4, uint32_t col) {
+    const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grads) + (uint64_t)row * dim4 + col);   // every gradient row is read exactly once
+    return D4{(double)g.x, (double)g.y, (double)g.z, (double)g.w};
+}
+__device__ __forceinline__ void store_sum4(float4* __restrict__ gsum, uint32_t u, uint32_t dim4, uint32_t col, const D4& v) {
+    gsum[(uint64_t)u * dim4 + col] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+
+template <int DIM4>
+__global__ __launch_bounds__(kDedupThreads) void bkt_dedup_sum_kernel(SumArgs A, BucketScratch bk) {
+    __shared__ SumLds L;
+    uint32_t parity, before;
+    HotPlan P;
+    const uint32_t size = dd_bucket<true, kSumWindow>(L.d, bk, A.d, parity, P, before);
+    if (size == 0) return;
+    const uint32_t dim4 = DIM4 ? DIM4 : A.dim4;
+    const uint32_t t = threadIdx.x, lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6, T = wv * 4 + tile;
+    if (dd_unit(A.d) >= A.d.nbk) {   // ---- a window of a hot key's own bucket: every entry is that key, its number is P.rank
+        const uint32_t x = dd_unit(A.d) - A.d.nbk, b = A.d.nbk_hash + P.h;
+        const uint32_t lo = P.win * kSumWindow, c = min(size, lo + kSumWindow) - lo;
+        if (P.win == 0 && t == 0) {
+            const int64_t key = bk.pkey[dd_entry_at(L.d, 0)];
+            A.d.uniq[P.rank] = key;
+            if (A.counts) A.counts[P.rank] = size;
+            if (size >= A.d.hot_count) report_hot_key(bk, parity, key);   // stays listed while it stays hot
+        }
+        {   // the window's positions: four in flight per thread (kSumWindow = 4 x 256)
+            uint32_t pp[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = q * kDedupThreads + t; pp[q] = e < c ? bk.pos[dd_entry_at(L.d, lo + e)] : 0xFFFFFFFFu; }
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) if (pp[q] != 0xFFFFFFFFu) { L.src[q * kDedupThreads + t] = pp[q]; if (A.d.inverse) A.d.inverse[pp[q]] = (int64_t)P.rank; }
+        }
+        __syncthreads();
+        if (!A.grads) return;   // (grid-uniform)
+        if (P.n_win > 1 && x >= A.max_part) { if (t == 0) atomicOr(A.d.status, (uint32_t)MEE_STATUS_INTERNAL); return; }   // cannot happen (max_part covers every window a batch can have)
+        auto from_list = [&](uint32_t j, uint32_t col) { return grad_row4(A.grads, L.src[j], dim4, col); };
+        if (P.n_win == 1) { block_run_sum(L, dim4, c, from_list, [&](uint32_t col, const D4& v) { store_sum4(A.gsum, P.rank, dim4, col, v); }); return; }
+        block_run_sum(L, dim4, c, from_list, [&](uint32_t col, const D4& v) {
+            double* d = A.part + ((uint64_t)x * dim4 + col) * 4;
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(d), (unsigned long long)__double_as_longlong(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(d + 1), (unsigned long long)__double_as_longlong(v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(d + 2), (unsigned long long)__double_as_longlong(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(d + 3), (unsigned long long)__double_as_longlong(v.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partial row is out before the ticket is drawn
+        __syncthreads();
+        if (t == 0) L.is_last = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.n_win - 1;
+        __syncthreads();
+        if (!L.is_last) return;   // (block-uniform) the window that finishes last adds the bucket's partial rows up
+        const uint32_t x0 = x - P.win;
+        block_run_sum(L, dim4, P.n_win, [&](uint32_t j, uint32_t col) {
+            const double* d = A.part + ((uint64_t)(x0 + j) * dim4 + col) * 4;
+            auto ld = [](const double* q) { return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+            return D4{ld(d), ld(d + 1), ld(d + 2), ld(d + 3)};
+        }, [&](uint32_t col, const D4& v) { store_sum4(A.gsum, P.rank, dim4, col, v); });
+        return;
+    }
+    // ---- a hash bucket: its distinct keys go to its own slice of the outputs (as in bkt_dedup_keys_kernel: behind the hot keys' numbers, at the positions the
+    // hash buckets in front of it hold), its sorted sources — when the LDS list does not hold them — to the same range of the global source list
+    uint32_t slice = P.H + before, src_at = before;
+    dd_passes<false>(L.d, bk, size, parity, A.d.hot_count, A.d.status, [&](uint32_t bits, uint64_t val, const DdHeld& held) {
+        const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
+        // -- 1. run numbers (short runs first, then medium, then long) and the runs' places in the sorted source list: ONE block scan over the table's slots
+        constexpr uint32_t per = kDedupSlots / kDedupThreads;
+        unsigned long long mine = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < per; ++q) {
+            const uint32_t sl = t * per + q, c = L.d.key[sl] != 0ull ? L.d.cnt[sl] : 0u;
+            if (c) mine += (c <= kSumTileMax ? 1ull : c <= kSumWaveMax ? 1ull << 11 : 1ull << 22) | (unsigned long long)c << 33;   // three counts of 11 bits (<= 896 runs) | sources
+        }
+        unsigned long long total;
+        const unsigned long long ex = block_scan_u64<kDedupWaves>(mine, L.d.wsum, total);
+        const uint32_t n_s = (uint32_t)total & 0x7FFu, n_m = (uint32_t)(total >> 11) & 0x7FFu, n_l = (uint32_t)(total >> 22) & 0x7FFu, m_src = (uint32_t)(total >> 33);
+        const uint32_t base = slice;
+        slice += n_s + n_m + n_l;   // (block-uniform: the next pass of this bucket continues behind this one's keys)
+        const bool in_lds = held.valid;   // (block-uniform) a bucket of at most 1024 positions: its entries are in registers, its sorted sources fit the LDS list
+        uint32_t* __restrict__ srcg = A.src_scratch + src_at;
+        src_at += m_src;
+        {
+            uint32_t i_s = (uint32_t)ex & 0x7FFu, i_m = n_s + ((uint32_t)(ex >> 11) & 0x7FFu), i_l = n_s + n_m + ((uint32_t)(ex >> 22) & 0x7FFu), o = (uint32_t)(ex >> 33);
+#pragma unroll
+            for (uint32_t q = 0; q < per; ++q) {
+                const uint32_t sl = t * per + q;
+                if (L.d.key[sl] == 0ull) continue;
+                const uint32_t c = L.d.cnt[sl];
+                const uint32_t idx = c <= kSumTileMax ? i_s++ : c <= kSumWaveMax ? i_m++ : i_l++;
+                L.d.val[sl] = idx; L.items[idx] = (uint16_t)sl; L.off[sl] = o; o += c;
+                A.d.uniq[base + idx] = (int64_t)(L.d.key[sl] ^ kBias);
+                if (A.counts) A.counts[base + idx] = c;
+            }
+        }
+        __syncthreads();
+        // -- 2. every entry of the pass: its key's number into d_inverse, its position into its run's part of the sorted list
+        if (in_lds) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (held.k[q] == kEmpty || (mix64b((uint64_t)held.k[q]) & mask) != val) continue;
+                const uint32_t sl = dd_lookup(L.d, (unsigned long long)held.k[q] ^ kBias);
+                if (A.d.inverse) A.d.inverse[held.p[q]] = (int64_t)(base + L.d.val[sl]);
+                if (A.grads) L.src[atomicAdd(&L.off[sl], 1u)] = held.p[q];
+            }
+        } else {
+            for (uint32_t e0 = 0; e0 < size; e0 += 4 * kDedupThreads) {   // four entries in flight per thread
+                int64_t kq[4]; uint32_t pq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t e = e0 + (uint32_t)q * kDedupThreads + t;
+                    kq[q] = kEmpty; pq[q] = 0u;
+                    if (e < size) { const uint32_t at = dd_entry_at(L.d, e); kq[q] = bk.pkey[at]; pq[q] = bk.pos[at]; }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (kq[q] == kEmpty || (mix64b((uint64_t)kq[q]) & mask) != val) continue;
+                    const uint32_t sl = dd_lookup(L.d, (unsigned long long)kq[q] ^ kBias);
+                    if (A.d.inverse) A.d.inverse[pq[q]] = (int64_t)(base + L.d.val[sl]);
+                    if (A.grads) __hip_atomic_store(&srcg[atomicAdd(&L.off[sl], 1u)], pq[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (!A.grads) return;   // (grid-uniform) keys, counts and inverse only
+        __syncthreads();   // (drains the stores of the global list as well)
+        // from here on run sl's sources are [L.off[sl] - cnt, L.off[sl]) of the list
+        auto source = [&](uint32_t at) -> uint32_t { return in_lds ? L.src[at] : __hip_atomic_load(&srcg[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        // -- 3. long runs: the whole block, one after the other
+        for (uint32_t j = 0; j < n_l; ++j) {   // block-uniform
+            const uint32_t idx = n_s + n_m + j, sl = L.items[idx], c = L.d.cnt[sl], first = L.off[sl] - c;
+            block_run_sum(L, dim4, c, [&](uint32_t q, uint32_t col) { return grad_row4(A.grads, source(first + q), dim4, col); },
+                          [&](uint32_t col, const D4& v) { store_sum4(A.gsum, base + idx, dim4, col, v); });
+        }
+        // -- 4. medium runs: a wave each
+        for (uint32_t j = wv; j < n_m; j += kDedupWaves) {   // wave-uniform
+            const uint32_t idx = n_s + j, sl = L.items[idx], c = L.d.cnt[sl], first = L.off[sl] - c;
+            for (uint32_t col = tl; col < dim4 + tl; col += 16) {   // (every lane runs the same number of turns: the shuffles need whole waves)
+                D4 v = col < dim4 ? run_sum4(4 * tile, 16, c, col, [&](uint32_t q, uint32_t cc) { return grad_row4(A.grads, source(first + q), dim4, cc); }) : D4{0.0, 0.0, 0.0, 0.0};
+                v = d4_tiles_sum(v);
+                if (tile == 0 && col < dim4) store_sum4(A.gsum, base + idx, dim4, col, v);
+            }
+        }
+        // -- 5. short runs: a tile each (a key that occurs once — the bulk — is one streamed row in, one row out)
+        for (uint32_t idx = T; idx < n_s; idx += 4 * kDedupWaves) {
+            const uint32_t sl = L.items[idx], c = L.d.cnt[sl], first = L.off[sl] - c;
+            for (uint32_t col = tl; col < dim4; col += 16)
+                store_sum4(A.gsum, base + idx, dim4, col, run_sum4(0u, 4u, c, col, [&](uint32_t q, uint32_t cc) { return grad_row4(A.grads, source(first + q), dim4, cc); }));
+        }
+    });
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------------------------
 // blocks behind the buckets: one per window a batch of n keys can have in its hot keys' buckets (sum of ceil(size / kHotWindow) <= n / kHotWindow + hot buckets)
-static uint32_t hot_window_blocks(const DedupArgs& A, uint32_t n) { return A.nbk != A.nbk_hash ? n / kHotWindow + (A.nbk - A.nbk_hash) : 0u; }
-static int dedup_partition(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st, DedupArgs& A, int64_t* d_uniq, int64_t* d_inverse, int64_t miss_index, uint8_t* d_found) {
+static uint32_t hot_window_blocks(const DedupArgs& A, uint32_t n, uint32_t window = kHotWindow) { return A.nbk != A.nbk_hash ? n / window + (A.nbk - A.nbk_hash) : 0u; }
+static int dedup_partition(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st, DedupArgs& A, int64_t* d_uniq, int64_t* d_inverse, int64_t miss_index, uint8_t* d_found,
+                           uint32_t* d_counts = nullptr) {
     uint32_t grid, nbk;
     bool full;
-    const uint32_t nbk_hash = bucket_count_for(t, n, &grid, &nbk, &full, MEE_DD_OWN_GEOMETRY ? t->bk.slots / kApplyBlocksPerCU * kDedupBlocksPerCU : 0u, MEE_DD_OWN_GEOMETRY ? kDedupBucketMax : 0u);
+    const uint32_t nbk_hash = bucket_count_for(t, n, &grid, &nbk, &full);
     // (hot keys' buckets whenever the latest batch reported any: a dedup has no FULL / LEAN kernels, its one kernel takes buckets of any size)
     uint32_t blocks, per_block;
-    part_geometry(n, 1024, blocks, per_block, n >= (1u << 19) * (uint32_t)MEE_DD_BLOCKS_FROM ? kPartBlocksMax : kPartBlocks);
-    A.nbk = nbk; A.nbk_hash = nbk_hash; A.part_blocks = blocks; A.per_block = per_block; A.hot_count = hot_count_for(n); A.op = t->op; A.h_slabs = t->bk.h_slabs_dev;
+    part_geometry(n, 1024, blocks, per_block, kPartBlocks);
+    A.nbk = nbk; A.nbk_hash = nbk_hash; A.part_blocks = blocks; A.per_block = per_block; A.hot_count = hot_count_for(n); A.op = t->op; A.h_slabs = t->bk.h_slabs_dev; A.status = &t->ctr->status;
     const bool atom = bucket_totals_by_atomics(blocks, nbk);
     // an assign without hot keys' buckets needs no bucket totals: nobody numbers anything across buckets, and a bucket's size is the sum of its runs
     A.size_from_runs = !atom && !d_uniq && nbk == nbk_hash;
-    bkt_sort_dedup_kernel<<<blocks, 1024, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, d_uniq, d_inverse, miss_index, d_found, atom);
+    bkt_sort_dedup_kernel<<<blocks, 1024, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, d_uniq, d_inverse, miss_index, d_found, atom, d_counts);
     MEE_HIP(hipGetLastError());
     return atom || A.size_from_runs ? MEE_OK : bucket_totals_launch(t, nbk, blocks, st);
 }
@@ -527,6 +751,23 @@ int bucket_dedup_keys(mee_table* t, const int64_t* d_keys, uint32_t n, int64_t* 
     if (int rc = dedup_partition(t, d_keys, n, st, A, d_uniq, d_inverse, miss_index, nullptr)) return rc;
     A.uniq = d_uniq; A.inverse = d_inverse;
     bkt_dedup_keys_kernel<<<A.nbk + hot_window_blocks(A, n), kDedupThreads, 0, st>>>(A, t->bk);
+    MEE_HIP(hipGetLastError());
+    return MEE_OK;
+}
+
+// mee_dedup_sum: the distinct keys (padded like mee_dedup_keys), their occurrence counts (0 for padding), the fp64-summed rows of their occurrences (d_grads / d_gsum
+// nullable together: keys, counts and inverse only) and each position's index
+int bucket_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, uint32_t n, int64_t* d_uniq, float* d_gsum, uint32_t* d_counts, int64_t* d_inverse, int64_t miss_index,
+                     hipStream_t st) {
+    SumArgs A{};
+    if (int rc = dedup_partition(t, d_keys, n, st, A.d, d_uniq, d_inverse, miss_index, nullptr, d_counts)) return rc;
+    A.d.uniq = d_uniq; A.d.inverse = d_inverse;
+    A.grads = (const float4*)d_grads; A.gsum = (float4*)d_gsum; A.counts = d_counts; A.dim4 = t->dim4;
+    A.src_scratch = t->bs.hidx; A.part = t->bk.sum_part; A.max_part = t->bk.sum_part_rows;
+    const uint32_t grid = A.d.nbk + hot_window_blocks(A.d, n, kSumWindow);
+    if (t->dim4 == 16) bkt_dedup_sum_kernel<16><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
+    else if (t->dim4 == 32) bkt_dedup_sum_kernel<32><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
+    else bkt_dedup_sum_kernel<0><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }

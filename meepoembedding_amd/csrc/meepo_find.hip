@@ -10,12 +10,6 @@
 
 #include "meepo_apply_part.h"
 
-#ifndef MEE_FP_R
-#define MEE_FP_R 2   // keys in flight per tile in the training forward at dim 64 (4: a wave step's slot handles are one full 128-byte line)
-#endif
-#ifndef MEE_AB_SLOT
-#define MEE_AB_SLOT 0   // A/B of the located find's slot store: 0 = after the rows (default), 1 = the same as a streaming store, 2 = before the row loads, 3 = none (timing only)
-#endif
 
 namespace mee {
 
@@ -87,17 +81,6 @@ __device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, con
             for (int r = 0; r < R; ++r)
                 if (slot[r] >= 0 && tl == 0) atomicAdd(&hits[slot[r]], 1u);
         }
-#if MEE_AB_SLOT == 2
-        if constexpr ((NT & 64) != 0) {
-            int64_t mine = -1;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int64_t v = __shfl(slot[r], (lane & 3) * kW);
-                if ((lane >> 2) == r) mine = v;
-            }
-            if (lane < KPW && base + lane < n) slots_out[base + lane] = mine >= 0 ? (mine | handle_tag) : mine;
-        }
-#endif
         if constexpr (DIM4 != 0) {
             constexpr int C = DIM4 / 16;
             f32x4 row[R][C];
@@ -143,15 +126,6 @@ __device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, con
                         out[i * dim4 + c] = slot[r] >= 0 ? values[(uint64_t)slot[r] * dim4 + c] : def4;
             }
         }
-#if MEE_AB_SLOT == 4
-        if constexpr ((NT & 64) != 0) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint64_t i = base + r * 4 + tile;
-                if (tl == 0 && i < n) slots_out[i] = slot[r] >= 0 ? (slot[r] | handle_tag) : slot[r];
-            }
-        }
-#elif MEE_AB_SLOT != 2
         if constexpr ((NT & 64) != 0) {  // mee_find_located: the slot of every position (-1 = absent), for the apply of the same step
             // lane j < 4R collects the slot of position base + j (round j / 4, tile j % 4): ONE coalesced store per wave step
             int64_t mine = -1;
@@ -160,15 +134,8 @@ __device__ __forceinline__ void find_span(const int64_t* __restrict__ tkeys, con
                 const int64_t v = __shfl(slot[r], (lane & 3) * kW);
                 if ((lane >> 2) == r) mine = v;
             }
-#if MEE_AB_SLOT == 1
-            if (lane < KPW && base + lane < n) __builtin_nontemporal_store(mine >= 0 ? (mine | handle_tag) : mine, &slots_out[base + lane]);
-#elif MEE_AB_SLOT == 3
-            if (lane < KPW && base + lane < n && mine == -12345) slots_out[base + lane] = mine;
-#else
             if (lane < KPW && base + lane < n) slots_out[base + lane] = mine >= 0 ? (mine | handle_tag) : mine;   // tag: the table's layout epoch (see handle_tag_of)
-#endif
         }
-#endif
         if (found && !(NT & 32)) {  // NT&32: rows only (last pass of find_or_insert: found keeps meaning "present before")
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -223,15 +190,10 @@ __global__ __launch_bounds__(256) void find_kernel(const int64_t* __restrict__ t
 // waves each do one short pass, the block holds its 16 wave slots until the slowest of them is done; 512-thread blocks: 42 us) — the launch
 // took as long as its slow find and hid nothing.  With 256-thread blocks the role runs as 128 blocks x 256 threads x 8 keys, each making two
 // round trips to memory (meepo_apply_part.h): 42.5 us for the launch against 40 us with the role switched off.
-#ifndef MEE_FPT
-#define MEE_FPT 256
-#endif
-constexpr int kFindPrepareThreads = MEE_FPT;
+constexpr int kFindPrepareThreads = 256;
+constexpr int kFindPrepareR = 2;   // keys in flight per tile at dim 64
 template <int DIM4, int R, int NT>
-#ifndef MEE_FP_WAVES
-#define MEE_FP_WAVES 8
-#endif
-__global__ __launch_bounds__(kFindPrepareThreads, kFindPrepareThreads <= 256 ? MEE_FP_WAVES : 4) void find_prepare_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
+__global__ __launch_bounds__(kFindPrepareThreads, 8) void find_prepare_kernel(const int64_t* __restrict__ tkeys, const f32x4* __restrict__ values, uint64_t nb,
                                                            const int64_t* __restrict__ keys, uint64_t n, f32x4* __restrict__ out,
                                                            uint8_t* __restrict__ found, float defv, uint32_t dim4_rt, int64_t* __restrict__ slots_out,
                                                            int64_t handle_tag, uint32_t part_blocks, uint32_t nbk_hash, uint32_t nbk, uint32_t per_block,
@@ -713,7 +675,7 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
     const uint32_t nbk_hash = bucket_count_for(t, n, &apply_grid, &nbk, &apply_full);
     uint32_t part_blocks, per_block;
     part_geometry((uint32_t)n, kFindPrepareThreads, part_blocks, per_block);
-    const int R = t->dim4 == 16 ? MEE_FP_R : t->dim4 == 32 ? 2 : 1;
+    const int R = t->dim4 == 16 ? kFindPrepareR : t->dim4 == 32 ? 2 : 1;
     const unsigned find_cap = t->prepare_debug >> 8;
     const unsigned find_blocks = grid_for(n, (kFindPrepareThreads / 64) * 4u * (unsigned)R, find_cap ? find_cap : 1u << 22);
     const bool separate = t->prepare_debug & 1;
@@ -722,7 +684,7 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
 #define FINDLP1(D4, RR, NT) find_prepare_kernel<D4, RR, NT><<<part_blocks + find_blocks, kFindPrepareThreads, sizeof(PartHot) + nbk * 4, st>>>(t->keys, (const f32x4*)t->values, t->nb, d_keys, n, (f32x4*)d_out, d_found, \
         t->default_value, t->dim4, d_slots_out, handle_tag_of(t), part_blocks, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, t->bk.xcd_split)
 #define FINDLP(D4, RR) do { if (cached_out) FINDLP1(D4, RR, 68); else FINDLP1(D4, RR, 64); } while (0)
-    if (t->dim4 == 16) FINDLP(16, MEE_FP_R); else if (t->dim4 == 32) FINDLP(32, 2); else FINDLP(0, 1);
+    if (t->dim4 == 16) FINDLP(16, kFindPrepareR); else if (t->dim4 == 32) FINDLP(32, 2); else FINDLP(0, 1);
 #undef FINDLP
 #undef FINDLP1
     MEE_HIP(hipGetLastError());

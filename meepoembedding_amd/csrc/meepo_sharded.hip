@@ -19,7 +19,9 @@
 //
 // Options of a context (mee_sharded_create_ex): a COLD table behind the local one (BASELINE configs[4]: every shard a hot/cold pair — the
 // owner side runs mee_find + mee_find_missing and sends mutators to both tiers, as meepoembedding_amd/tiered.py does), and pre-exchange
-// DEDUP for lookups (only a batch's distinct keys cross xGMI; every occurrence is then served from its key's row: SURVEY.md §7 lever (a)).
+// DEDUP (SURVEY.md §7 lever (a)): lookups send only a batch's distinct keys (every occurrence is then served from its key's row), optimizer
+// applies send ONE (key, summed gradient row) pair per distinct key of the rank's batch (mee_dedup_sum: fp64 sums rounded once) — on a
+// skewed stream the bytes on xGMI scale with the distinct keys, in both directions of a training step.
 //
 // Errors inside a collective operator: owner-side buffers are sized once, at creation, for the most that can arrive (G x max_batch, the same
 // max_batch on every rank — checked collectively), so no rank can fail for memory between two exchange steps; an RCCL error marks the
@@ -233,6 +235,7 @@ struct mee_sharded {
     uint64_t send_slots;       // positions the requester-side buffers hold: max_batch (exact) or G*cap (padded)
     // pre-exchange dedup (MEE_SHARDED_DEDUP): a scratch-only table of our own groups the batch's keys (so that contexts sharing one
     // shard may keep lookups in flight side by side); distinct keys, each position's index into them, their rows in "unique order"
+    // (lookups: the rows that came back; applies: the rank's summed gradient rows before they leave)
     bool dedup;
     mee_table* dd;
     int64_t *uniq, *inverse;
@@ -671,7 +674,7 @@ int mee_sharded_create_ex(mee_table* local, void* nccl_comm, const mee_sharded_o
     if (rc == MEE_OK && c->dedup) {   // grouping scratch of our own: a 16-slot table whose group table / per-position arrays serve batches of max_batch keys
         mee_config dc;
         memset(&dc, 0, sizeof dc);
-        dc.struct_size = sizeof dc; dc.device = v.device; dc.capacity = 16; dc.dim = 4; dc.optimizer = MEE_OPT_NONE; dc.max_batch = max_batch;
+        dc.struct_size = sizeof dc; dc.device = v.device; dc.capacity = 16; dc.dim = v.dim /* mee_dedup_sum adds up rows of the table's dim */; dc.optimizer = MEE_OPT_NONE; dc.max_batch = max_batch;
         rc = mee_table_create(&dc, &c->dd);
         if (rc == MEE_OK) {
             shard_fill_row_kernel<<<1, 256, 0, 0>>>(c->urows + max_batch * (uint64_t)c->dim, c->dim, c->defv, c->ufound + max_batch);
@@ -788,7 +791,14 @@ static int sharded_apply(mee_sharded* c, const int64_t* d_keys, const float* d_g
     hipStream_t st = (hipStream_t)stream;
     uint64_t rt = 0;
     if (int rc = ensure_send_rows(c)) return rc;
-    if (int rc = push(c, d_keys, d_grads ? d_grads : c->send_rows, n, st, &rt)) return rc;
+    if (c->dedup) {
+        // pre-exchange aggregation: the rank's gradient rows of one key are added up (fp64, rounded once) BEFORE they travel — one (key, row) pair per distinct
+        // key of the batch crosses xGMI.  The owner's apply then sums the ranks' partial sums in fp64 again: the update differs from the un-aggregated one by
+        // the one extra rounding of each rank's partial sum (<= 1 ulp of the partial sum, far inside SPEC.md §4's 1e-6).  Sync-free: the padded unique list
+        // goes through mee_partition_padded, which gives the padding to no shard.
+        if (n) if (int rc = mee_dedup_sum(c->dd, d_keys, d_grads, n, c->uniq, c->urows, nullptr, nullptr, 0, stream)) return rc;
+        if (int rc = push(c, c->uniq, c->urows, n, st, &rt, /*skip_padding=*/true)) return rc;
+    } else if (int rc = push(c, d_keys, d_grads ? d_grads : c->send_rows, n, st, &rt)) return rc;
     if (rt == 0) return MEE_OK;
     // (from here on no collective step is left in this operator: a local failure cannot strand a peer)
     if (rt <= c->local_max_batch) return apply_tiers(c, c->recv_keys, c->recv_rows, rt, a, stream);

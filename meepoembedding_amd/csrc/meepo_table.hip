@@ -11,8 +11,8 @@
 //   values fp32 [capacity][dim]     row of slot s at values + s*dim  (256 B for dim 64)
 //   s1,s2  fp32 [capacity][dim]     optimizer planes (acc | m, v), only if configured
 // Per-batch scratch ("group table"): an open-addressing set of the batch's distinct keys sized ≥ 2·max_batch (stays in L2 / Infinity
-// Cache): single insertion and last-wins for insert / find_or_insert, and mee_dedup_sum.  (The optimizers, dedup_keys and assign left it
-// in rounds 3-4 for the partition + block-local LDS tables of meepo_apply.hip / meepo_dedup.hip.)
+// Cache): the last-wins election of insert among positions that find their key present.  (The optimizers, dedup_keys, assign and — round 5 —
+// dedup_sum left it for the partition + block-local LDS tables of meepo_apply.hip / meepo_dedup.hip.)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -64,32 +64,21 @@ __device__ __forceinline__ uint32_t group_claim(const GroupTable& g, int64_t key
     }
 }
 
-constexpr int kGroupLast = 0;   // max(lo, hi) = 1 + highest batch position of the key (last occurrence wins)
-constexpr int kGroupCount = 1;  // lo + hi = occurrence count, rank[i] = arrival order (finalised by the plan pass)
-constexpr uint32_t kRankRemote = 0x80000000u;  // rank was handed out by an atomic on lo: add hi to finalise
-#ifndef MEE_KCHUNK
-#define MEE_KCHUNK 32
-#endif
-constexpr uint32_t kChunk = MEE_KCHUNK;        // occurrences summed by one tile; a key with more in one batch is a "hot" key
-constexpr int kApplyGroupBlock = 1024;         // threads per block of the duplicate reduction's group_kernel: a hot key costs its entry one atomic per block
 constexpr uint32_t kEpochWrap = (1u << 31) - 16;   // batch numbers (mee_table::epoch) start over here
 
 // One lane per batch position.  Occurrences of the same key inside a 256-thread block are first combined in an
 // LDS hash table keyed by the key itself; ONE lane per (block, key) then talks to the global group table.  A hot key
 // that is 8 % of the batch costs ~n/256 global accesses instead of 0.08 n serialised on one L2 line, and the block
 // whose CAS claimed the entry needs no counting atomic at all.
-template <int MODE, int BLOCK = 256>
-__global__ __launch_bounds__(BLOCK) void group_kernel(const int64_t* __restrict__ keys, uint32_t n, GroupTable g, BatchScratch bs,
-                                                    Counters* ctr, const uint8_t* __restrict__ skip, OpCounters* op_to_zero = nullptr,
-                                                    uint32_t epoch = 0, const uint32_t* __restrict__ gate = nullptr) {
+// (The table holds max(lo, hi) = 1 + the highest batch position of the key: the last occurrence wins.)
+__global__ __launch_bounds__(256) void group_last_kernel(const int64_t* __restrict__ keys, uint32_t n, GroupTable g, BatchScratch bs,
+                                                         Counters* ctr, const uint8_t* __restrict__ skip, uint32_t epoch, const uint32_t* __restrict__ gate) {
     if (gate && *gate != epoch) return;   // insert: no position of this batch found its key present -> no election (grid-uniform)
-    // the per-op counters are first touched by the kernel AFTER this one (plan pass): zeroing them here saves a launch
-    if (op_to_zero && blockIdx.x == 0 && threadIdx.x < sizeof(OpCounters) / 4) reinterpret_cast<uint32_t*>(op_to_zero)[threadIdx.x] = 0u;
+    constexpr int BLOCK = 256;
     constexpr int kLds = 2 * BLOCK;   // block-local aggregation table (BLOCK threads -> at most BLOCK distinct keys: half full at worst)
-    constexpr int kLdsShift = BLOCK == 256 ? 55 : BLOCK == 512 ? 54 : 53;
-    static_assert(BLOCK == 256 || BLOCK == 512 || BLOCK == 1024, "group_kernel: block size");
+    constexpr int kLdsShift = 55;
     __shared__ unsigned long long lkey[kLds];
-    __shared__ uint32_t lval[kLds], lh[kLds], lbase[kLds];
+    __shared__ uint32_t lval[kLds], lh[kLds];
     for (int j = threadIdx.x; j < kLds; j += BLOCK) { lkey[j] = 0; lval[j] = 0; }
     __syncthreads();
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -97,7 +86,7 @@ __global__ __launch_bounds__(BLOCK) void group_kernel(const int64_t* __restrict_
     const int64_t key = inb ? keys[i] : 0;
     const bool skipped = inb && skip && skip[i];  // position already served by an earlier pass (find_or_insert)
     const bool valid = inb && !skipped && !reserved_key(key);
-    uint32_t slot = 0, r_local = 0;
+    uint32_t slot = 0;
     bool inserter = false;
     if (valid) {
         const unsigned long long bk = (unsigned long long)key ^ kBias;
@@ -108,197 +97,22 @@ __global__ __launch_bounds__(BLOCK) void group_kernel(const int64_t* __restrict_
             if (old == bk) break;
             slot = (slot + 1) & (kLds - 1);
         }
-        if (MODE == kGroupCount) r_local = atomicAdd(&lval[slot], 1u);
-        else atomicMax(&lval[slot], i + 1);
+        atomicMax(&lval[slot], i + 1);
     }
     __syncthreads();
     if (inserter) {
         bool claimed;
         const uint32_t h = group_claim(g, key, claimed);
         lh[slot] = h;
-        if constexpr (MODE == kGroupCount) {
-            const uint32_t total = lval[slot];
-            if (claimed) { sv_half(g, h)[1] = total; lbase[slot] = 0; }
-            else lbase[slot] = atomicAdd(&sv_half(g, h)[0], total) | kRankRemote;
-        } else {
-            // the block whose CAS created the entry parks its candidate in the hi half with a plain store; only later arrivals
-            // pay an atomic.  Readers take max(lo, hi).  (Unique keys: one atomic per key instead of two.)
-            if (claimed) sv_half(g, h)[1] = lval[slot];
-            else atomicMax(&sv_half(g, h)[0], lval[slot]);
-        }
+        // the block whose CAS created the entry parks its candidate in the hi half with a plain store; only later arrivals
+        // pay an atomic.  Readers take max(lo, hi).  (Unique keys: one atomic per key instead of two.)
+        if (claimed) sv_half(g, h)[1] = lval[slot];
+        else atomicMax(&sv_half(g, h)[0], lval[slot]);
     }
     __syncthreads();
     if (inb) {
         bs.hidx[i] = valid ? lh[slot] : kNoGroup;
-        if (MODE == kGroupCount && valid) bs.rank[i] = lbase[slot] + r_local;
         if (!valid && !skipped && key == kReclaimed) atomicOr(&ctr->status, (uint32_t)MEE_STATUS_RESERVED_KEY);  // EMPTY = padding, silent
-    }
-}
-
-// exclusive prefix sum of v over a 1024-thread block (wave shuffles + LDS); returns the block total in `total`
-__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* wsum /*[16]*/, uint32_t& total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
-    __syncthreads();  // wsum may still be read from the previous call
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    uint32_t pre = 0, tot = 0;
-#pragma unroll
-    for (int ww = 0; ww < 16; ++ww) { const uint32_t x = wsum[ww]; if (ww < w) pre += x; tot += x; }
-    total = tot;
-    return pre + incl - v;
-}
-
-
-// Plan pass, one lane per batch position: finalise rank and count, then (leaders only) reserve the group's slice of
-// the occurrence list, list the chunk leaders as work items, give big groups a block of fp64 partial-sum rows, and — for the
-// standalone dedup (ALL) — append the group to the unique list.  Every reservation is a block-wide prefix sum plus
-// ONE atomic per 1024-thread block.
-template <bool ALL>
-__global__ __launch_bounds__(1024) void group_plan_kernel(uint32_t n, GroupTable g, BatchScratch bs, OpCounters* op) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t base_occ, base_uniq, base_work;
-    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
-    const uint32_t h = i < n ? bs.hidx[i] : kNoGroup;
-    const bool valid = h != kNoGroup;
-    uint32_t cnt = 0, r = 0;
-    if (valid) {
-        uint32_t lo, c0;
-        sv_load(g, h, lo, c0);
-        const uint32_t rk = bs.rank[i];
-        cnt = c0 + lo;
-        r = (rk & ~kRankRemote) + ((rk & kRankRemote) ? c0 : 0);
-        bs.rank[i] = r;
-    }
-    if (i < n) bs.pcnt[i] = cnt;
-    const bool leader = valid && r == 0;
-    const uint32_t need = (leader && (ALL || cnt > 1)) ? cnt : 0;
-    uint32_t tot_occ, tot_b;
-    const uint32_t ex_occ = block_scan_1024(need, wsum, tot_occ);
-    const bool flag_b = ALL ? leader : (valid && cnt > 1 && (r % kChunk) == 0);  // unique-list entry | chunk leader
-    const uint32_t ex_b = block_scan_1024(flag_b ? 1u : 0u, wsum, tot_b);
-    if (threadIdx.x == 0) {
-        base_occ = tot_occ ? atomicAdd(&op->n_occ, tot_occ) : 0;
-        if (ALL) base_uniq = tot_b ? atomicAdd(&op->n_uniq, tot_b) : 0;
-        else base_work = tot_b ? atomicAdd(&op->n_work, tot_b) : 0;
-    }
-    __syncthreads();
-    if (need) g.soffs[h] = base_occ + ex_occ;
-    if (ALL) {
-        if (leader) { const uint32_t u = base_uniq + ex_b; bs.uniq_h[u] = h; g.sgrp[h] = u; }
-    } else {
-        if (flag_b) bs.work[base_work + ex_b] = i;
-        if (leader && cnt > kChunk) {  // rare: at most n / (kChunk + 1) groups per batch
-            bs.bigh[atomicAdd(&op->n_big, 1u)] = h;
-            // one partial-sum row per chunk: sum over big groups of ceil(cnt / kChunk) <= n / kChunk + n / (kChunk + 1) = max_part,
-            // so the reservation always fits; the clamp only keeps a violated invariant from writing out of bounds
-            const uint32_t rows = (cnt + kChunk - 1) / kChunk;
-            const uint32_t first = atomicAdd(&op->n_part, rows);
-            g.sbig[h] = first + rows <= bs.max_part ? first : 0;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void group_reset_kernel(const uint32_t* __restrict__ hidx, uint32_t n, GroupTable g) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t h = hidx[i];
-    if (h != kNoGroup) group_release_entry(g, h);
-}
-
-// assign, after the election (group_kernel<kGroupLast>): the find kernel's shape with the row traffic turned round.  4R positions per
-// wave step: keys and group indices arrive with one coalesced load each, the R entries, the R first bucket lines and the winners' R
-// source rows are requested before anything is waited for; every occurrence probes (found[] is exact for all of them), only the
-// winner — the highest position of its key — overwrites the row and releases the group-table entry.
-template <int DIM4, int R>
-__global__ __launch_bounds__(256) void assign_kernel(const int64_t* __restrict__ tkeys, f32x4* __restrict__ plane, uint64_t nb, uint32_t dim4_rt,
-                                                     const int64_t* __restrict__ keys, const f32x4* __restrict__ vals, uint32_t n,
-                                                     const uint32_t* __restrict__ hidx, GroupTable g, uint8_t* __restrict__ found) {
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t dim4 = DIM4 ? DIM4 : dim4_rt;
-    constexpr int KPW = 4 * R, C = DIM4 ? DIM4 / 16 : 1;
-    for (uint32_t base = wave * KPW; base < n; base += n_waves * KPW) {
-        int64_t key[R], slot[R], kb[R];
-        uint32_t h[R];
-        uint64_t b[R];
-        bool valid[R], winner[R];
-        f32x4 row[R][C];
-        const bool mine = lane < KPW && base + lane < n;
-        const int64_t kmine = mine ? keys[base + lane] : kEmpty;
-        const uint32_t hmine = mine ? hidx[base + lane] : kNoGroup;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            key[r] = __shfl(kmine, r * 4 + tile);
-            h[r] = __shfl(hmine, r * 4 + tile);
-            valid[r] = h[r] != kNoGroup;   // reserved keys and positions past the end have no group
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            uint32_t lo = 0, hi = 0;
-            if (valid[r]) sv_load(g, h[r], lo, hi);   // one 8-byte load: the complete pair, or zeros once the winner released it
-            winner[r] = valid[r] && max(lo, hi) == base + r * 4 + tile + 1;
-            b[r] = bucket_of(key[r], nb);
-            kb[r] = valid[r] ? tkeys[b[r] * kW + tl] : kEmpty;
-        }
-        if constexpr (DIM4 != 0) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int c = 0; c < C; ++c)   // read once: past the caches.  (Losers read their own row too: a valid address, no branch around the load.)
-                    row[r][c] = __builtin_nontemporal_load(&vals[(uint64_t)min(base + r * 4 + tile, n - 1) * DIM4 + c * 16 + tl]);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            slot[r] = -1;
-            bool pend = valid[r];
-            uint64_t bb = b[r], steps = 0;
-            int64_t k = kb[r];
-            while (true) {
-                const uint32_t tm = tile_bits(__ballot(pend && k == key[r]), tile);
-                const uint32_t te = tile_bits(__ballot(pend && k == kEmpty), tile);
-                if (pend) {
-                    if (tm) { slot[r] = (int64_t)(bb * kW) + (__ffs(tm) - 1); pend = false; }
-                    else if (te || ++steps >= nb) pend = false;
-                    else bb = next_bucket(bb, step_of(key[r], nb), nb);
-                }
-                if (!__any(pend)) break;
-                k = pend ? tkeys[bb * kW + tl] : kEmpty;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t i = base + r * 4 + tile;
-            if (winner[r] && slot[r] >= 0) {
-                if constexpr (DIM4 != 0) {
-#pragma unroll
-                    for (int c = 0; c < C; ++c) plane[(uint64_t)slot[r] * DIM4 + c * 16 + tl] = row[r][c];
-                } else {
-                    for (uint32_t c = tl; c < dim4; c += 16) plane[(uint64_t)slot[r] * dim4 + c] = vals[(uint64_t)i * dim4 + c];
-                }
-            }
-            // the winner is the last reader that needs the entry's value: an occurrence that looks later reads 0 != i + 1 (one
-            // 8-byte load: never a mixture) and is, correctly, not the winner.  The group table is clean when the kernel ends.
-            if (winner[r] && tl == 0) group_release_entry(g, h[r]);
-        }
-        if (found) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t i0 = base + r * 4;
-                if (i0 + 4 <= n && (reinterpret_cast<uintptr_t>(found) & 3) == 0) {   // the four tiles' found bytes of this round leave as ONE aligned 4-byte store
-                    const uint64_t m = __ballot(slot[r] >= 0);
-                    const uint32_t w = (uint32_t)(m & 1) | ((uint32_t)((m >> 16) & 1) << 8) | ((uint32_t)((m >> 32) & 1) << 16) |
-                                       ((uint32_t)((m >> 48) & 1) << 24);
-                    if (lane == 0) *reinterpret_cast<uint32_t*>(found + i0) = w;
-                } else if (i0 + tile < n && tl == 0) found[i0 + tile] = slot[r] >= 0;
-            }
-        }
     }
 }
 
@@ -307,7 +121,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const int64_t* __restrict__
 // row (+ initial optimizer state) at once: a batch of distinct new keys — populating a table, a growing vocabulary — is finished after
 // this one kernel with ONE atomic per key.  A position that finds its key present (stored before the batch, or created by another
 // occurrence in it) writes nothing, keeps its slot and raises the batch's election flag (ctr->election = epoch, a plain store).
-// Only then do the three gated kernels do anything: group_kernel<kGroupLast> over the "present" positions, insert_join_kernel (every
+// Only then do the three gated kernels do anything: group_last_kernel over the "present" positions, insert_join_kernel (every
 // creator looks its key up in the group table — read-only — and joins the election if other occurrences registered there), and
 // insert_settle_kernel (the highest position of each registered key rewrites the row at the slot it kept; rows are plain overwrites
 // and the kernel boundary orders them behind the creators' optimistic writes).  `made[i]` = 1 for creators (the group pass skips them).
@@ -590,83 +404,6 @@ __global__ __launch_bounds__(256) void ensure_direct_kernel(int64_t* tkeys, floa
     }
 }
 
-__device__ __forceinline__ void group_release(const GroupTable& g, uint32_t h) { group_release_entry(g, h); }
-
-// ---- standalone duplicate-key reduction (SPEC.md §4) -------------------------------------------------------
-__global__ __launch_bounds__(256) void dedup_fill_kernel(uint32_t n, GroupTable g, BatchScratch bs, int64_t* inverse, int64_t miss = -1) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t h = bs.hidx[i];
-    if (h != kNoGroup) bs.occ[g.soffs[h] + bs.rank[i]] = i;
-    if (inverse) inverse[i] = h != kNoGroup ? (int64_t)g.sgrp[h] : miss;
-}
-
-// keys-only, sync-free form of the duplicate reduction: uniq_out[0 .. n_uniq) = the distinct keys, uniq_out[n_uniq .. n) = EMPTY
-// (padding), entries released.  The count stays on the device: consumers take the padded array with the fixed length n.
-__global__ __launch_bounds__(256) void dedup_keys_emit_kernel(uint32_t n, GroupTable g, BatchScratch bs, const OpCounters* op,
-                                                              int64_t* uniq_out) {
-    const uint32_t nu = op->n_uniq;
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
-        if (u < nu) {
-            const uint32_t h = bs.uniq_h[u];
-            uniq_out[u] = (int64_t)(g.ent[2 * (uint64_t)h] ^ kBias);
-            group_release(g, h);
-        } else {
-            uniq_out[u] = kEmpty;
-        }
-    }
-}
-
-// fp64 sum of `count` rows of an occurrence list, up to 8 rows in flight per lane.  All 16 lanes of the tile call it with the same
-// arguments (c differs per lane).  The last (or only) step reads the list's last row again in the lanes past the end (a valid
-// address, so the loads stay unconditional and leave together) and adds +0.0 for them.
-__device__ __forceinline__ void chunk_sum(const float4* __restrict__ grads, const uint32_t* __restrict__ occ, uint32_t first,
-                                          uint32_t count, uint32_t dim4, uint32_t c, double& sx, double& sy, double& sz, double& sw) {
-    for (uint32_t o = 0; o < count; o += 8) {
-        uint32_t idx[8];
-        float4 gq[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) idx[q] = occ[first + min(o + q, count - 1)];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) gq[q] = grads[(uint64_t)idx[q] * dim4 + c];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const bool live = o + q < count;
-            sx += live ? (double)gq[q].x : 0.0; sy += live ? (double)gq[q].y : 0.0; sz += live ? (double)gq[q].z : 0.0; sw += live ? (double)gq[q].w : 0.0;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void dedup_emit_kernel(uint32_t dim4, const float4* __restrict__ grads, GroupTable g,
-                                                         BatchScratch bs, const OpCounters* op, int64_t* uniq_out,
-                                                         float4* gsum_out, uint32_t* counts_out) {
-    const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t nu = op->n_uniq;
-    for (uint32_t base = wave * 4; base < nu; base += n_waves * 4) {
-        const uint32_t u = base + tile;
-        if (u >= nu) continue;
-        const uint32_t h = bs.uniq_h[u];
-        uint32_t cnt_lo, cnt_hi;
-        sv_load(g, h, cnt_lo, cnt_hi);
-        const uint32_t cnt = cnt_lo + cnt_hi;
-        const uint32_t off = g.soffs[h];
-        if (grads && gsum_out) {
-            for (uint32_t c = tl; c < dim4; c += 16) {
-                double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-                chunk_sum(grads, bs.occ, off, cnt, dim4, c, sx, sy, sz, sw);
-                gsum_out[(uint64_t)u * dim4 + c] = make_float4((float)sx, (float)sy, (float)sz, (float)sw);
-            }
-        }
-        if (tl == 0) {
-            if (uniq_out) uniq_out[u] = (int64_t)(g.ent[2 * (uint64_t)h] ^ kBias);
-            if (counts_out) counts_out[u] = cnt;
-            group_release(g, h);
-        }
-    }
-}
-
 // =========================================================================================================
 // host side
 // =========================================================================================================
@@ -725,8 +462,7 @@ int mee_table_destroy(mee_table* t) {
     float* planes[] = {t->values, t->s1, t->s2};
     for (float* p : planes)
         if (p) { if (t->value_memory == MEE_MEM_HOST_PINNED) (void)hipHostFree(p); else (void)hipFree(p); }
-    void* dev[] = {t->keys, t->hits, t->sketch, t->g.ent, t->g.soffs, t->g.sgrp, t->g.sbig, t->g.sres,
-                   t->bs.hidx, t->bs.rank, t->bs.pcnt, t->bs.occ, t->bs.uniq_h, t->bs.work, t->bs.fmask, t->bs.bigh, t->bs.gacc, t->ctr, t->op};
+    void* dev[] = {t->keys, t->hits, t->sketch, t->g.ent, t->g.sres, t->bs.hidx, t->bs.occ, t->bs.fmask, t->bs.gacc, t->ctr, t->op};
     for (void* p : dev) if (p) (void)hipFree(p);
     bucket_scratch_free(t);
     if (t->h_ctr) (void)hipHostFree(t->h_ctr);
@@ -814,24 +550,16 @@ int mee_table_create(const mee_config* cfg, mee_table** out) {
     if (t->optimizer != MEE_OPT_NONE) ALLOC_PLANE(t->s1);
     if (t->optimizer == MEE_OPT_ADAM) ALLOC_PLANE(t->s2);
 #undef ALLOC_PLANE
-    ALLOC(t->g.ent, S * 16); ALLOC(t->g.soffs, S * 4); ALLOC(t->g.sgrp, S * 4);
-    ALLOC(t->g.sbig, S * 4); ALLOC(t->g.sres, S * 8);
-    ALLOC(t->bs.hidx, mb * 4); ALLOC(t->bs.rank, mb * 4); ALLOC(t->bs.pcnt, mb * 4); ALLOC(t->bs.occ, mb * 4); ALLOC(t->bs.uniq_h, mb * 4);
-    ALLOC(t->bs.work, mb * 4); ALLOC(t->bs.fmask, mb);
-    t->max_big = mb / kChunk + 1;  // a batch of n keys has at most n / (kChunk + 1) groups larger than kChunk
-    // ... and those groups need ceil(cnt / kChunk) partial-sum rows each: at most n / kChunk + n / (kChunk + 1) rows in all
-    t->max_part = mb / kChunk + mb / (kChunk + 1) + 2;
-    // the bucketed apply (meepo_apply.hip) cuts runs into chunks of 8 .. 32 sources, following the slab: sum of ceil(c / lc) over runs longer than
-    // lc <= m / 8 + m / 9 per slab of m sources, slabs and merge passes of split buckets together (+ 32 rows per single-key merge pass)
-    if (t->optimizer != MEE_OPT_NONE && t->max_part < mb / 4 + mb / 32 + 4096) t->max_part = mb / 4 + mb / 32 + 4096;
+    ALLOC(t->g.ent, S * 16); ALLOC(t->g.sres, S * 8);
+    ALLOC(t->bs.hidx, mb * 4); ALLOC(t->bs.occ, mb * 4); ALLOC(t->bs.fmask, mb);
+    // fp64 partial rows of the bucketed apply's long runs (meepo_apply.hip): it cuts runs into chunks of 8 sources and quads of four chunks — one row per quad of a
+    // run longer than 32: at most m / 32 per slab of m sources, slabs and merge passes of split buckets together (+ 32 rows per single-key merge pass); sized with room
+    t->max_part = t->optimizer != MEE_OPT_NONE ? mb / 4 + mb / 32 + 4096 : 0;
     t->bs.max_part = (uint32_t)t->max_part;
-    ALLOC(t->bs.bigh, t->max_big * 4);
     if (t->optimizer != MEE_OPT_NONE) ALLOC(t->bs.gacc, t->max_part * (uint64_t)t->dim * sizeof(double));
     ALLOC(t->ctr, sizeof(Counters)); ALLOC(t->op, sizeof(OpCounters));
 #undef ALLOC
-    t->workspace_bytes = S * 36 + mb * 25 + t->max_big * 4 + (t->bs.gacc ? t->max_part * (uint64_t)t->dim * sizeof(double) : 0) +
-                         sizeof(Counters) + sizeof(OpCounters);
-    t->dedup_path = -1;
+    t->workspace_bytes = S * 24 + mb * 9 + (t->bs.gacc ? t->max_part * (uint64_t)t->dim * sizeof(double) : 0) + sizeof(Counters) + sizeof(OpCounters);
     if ((rc = bucket_scratch_alloc(t)) != MEE_OK) goto bad;   // the bucketed machinery's scratch: partition (every table), pending records (tables with an optimizer); adds to workspace_bytes
     if (hipHostMalloc((void**)&t->h_ctr, sizeof(Counters)) != hipSuccess || hipHostMalloc((void**)&t->h_op, sizeof(OpCounters)) != hipSuccess) {
         rc = fail(MEE_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
@@ -873,14 +601,10 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     else if (!strcmp(name, "find_block")) t->find_block = value;
     else if (!strcmp(name, "prepare_debug")) t->prepare_debug = value;
     else if (!strcmp(name, "find_nt")) t->find_nt = value;
-    else if (!strcmp(name, "apply_spare_blocks")) t->bk.spare_blocks = value > 0 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_bucket_max")) t->bk.bucket_max = value > 0 && value <= 352 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_skew_adapt")) t->bk.skew_adapt = value != 0;
     else if (!strcmp(name, "apply_xcd_split")) t->bk.xcd_split = value > 0 && value < 1024 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_kernel")) t->bk.kernel_choice = value < 0 ? -1 : value != 0;
-    else if (!strcmp(name, "dedup_path")) t->dedup_path = value;
-    else if (!strcmp(name, "apply_rounds") || !strcmp(name, "apply_path")) (void)value;   // retired in round 4 with the group-table apply: accepted, ignored
-    else if (!strcmp(name, "apply_overlap")) (void)value;   // retired in round 2 (a side stream for the duplicate path lost to its fork/join gaps): accepted, ignored
     else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);
     return MEE_OK;
 }
@@ -912,26 +636,15 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
                                                                nn, skip, t->bs.fmask, slotof, t->bs.hidx, t->optimizer, t->init_acc, t->ctr, t->hits, t->epoch)
         if (t->dim4 == 16) DIRECT(16); else if (t->dim4 == 32) DIRECT(32); else DIRECT(0);
 #undef DIRECT
-        group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, t->bs.fmask, nullptr, t->epoch, &t->ctr->election);
+        group_last_kernel<<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, t->bs.fmask, t->epoch, &t->ctr->election);
         insert_join_kernel<<<grid_for(n, 256, 2048), 256, 0, st>>>(d_keys, nn, t->bs.fmask, slotof, t->g, t->bs.hidx, t->ctr, t->epoch);
         insert_settle_kernel<<<grid_for(n, 16, 2048), 256, 0, st>>>((float4*)plane, t->dim4, (const float4*)d_values, nn, slotof, t->bs.hidx, t->g, t->ctr, t->epoch);
         MEE_HIP(hipGetLastError());
         return MEE_OK;
     }
     // assign: the bucketed machinery (meepo_dedup.hip: partition by hash bucket, then one kernel — block-local LDS election, one probe and
-    // one row copy per distinct key, the found byte to every occurrence) ...
-    if (!skip && t->bk.pkey && n <= t->bk.fast_max && t->dedup_path != 0) return bucket_assign(t, plane, d_keys, d_values, nn, d_found, st);
-    // ... or round 2's form (tuning "dedup_path" = 0; batches beyond the partition's reach): an election over all positions in the group table
-    // (last occurrence wins), then the winners probe and overwrite
-    group_kernel<kGroupLast><<<gl, 256, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, skip);
-    {
-        const unsigned ga = grid_for(n, 32, 1u << 16);   // two positions per tile
-#define ASSIGN(D4) assign_kernel<D4, 2><<<ga, 256, 0, st>>>(t->keys, (f32x4*)plane, t->nb, t->dim4, d_keys, (const f32x4*)d_values, nn, t->bs.hidx, t->g, d_found)
-        if (t->dim4 == 16) ASSIGN(16); else if (t->dim4 == 32) ASSIGN(32); else ASSIGN(0);
-#undef ASSIGN
-    }
-    MEE_HIP(hipGetLastError());
-    return MEE_OK;
+    // one row copy per distinct key, the found byte to every occurrence)
+    return bucket_assign(t, plane, d_keys, d_values, nn, d_found, st);
 }
 
 int mee_insert(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, void* stream) {
@@ -1228,46 +941,26 @@ int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_g
     return apply_common(t, d_keys, d_grads, n, a, stream, "mee_apply_adam_indexed", d_grad_index);
 }
 
+/* duplicate-key reduction with row sums, sync-free (meepo_dedup.hip): see include/meepo_embedding.h */
 int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, int64_t* d_uniq_out, float* d_gsum_out,
-                  uint32_t* d_counts_out, int64_t* d_inverse_out, size_t* n_unique_out, void* stream) {
-    if (!t || !n_unique_out || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_dedup_sum: null argument");
+                  uint32_t* d_counts_out, int64_t* d_inverse_out, int64_t miss_index, void* stream) {
+    if (!t || (n && (!d_keys || !d_uniq_out))) return fail(MEE_ERR_INVALID_ARG, "mee_dedup_sum: null argument");
+    if ((d_grads == nullptr) != (d_gsum_out == nullptr)) return fail(MEE_ERR_INVALID_ARG, "mee_dedup_sum: d_grads and d_gsum_out go together (both or neither)");
     if (int rc = check_batch(t, n, "mee_dedup_sum", stream)) return rc;
-    *n_unique_out = 0;
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
-    hipStream_t st = as_stream(stream);
-    const uint32_t nn = (uint32_t)n;
-    const unsigned gl = grid_for(n, 256, 1u << 22), gt = grid_for(n, 16, 1u << 16);
-    group_kernel<kGroupCount, kApplyGroupBlock><<<grid_for(nn, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op);
-    group_plan_kernel<true><<<grid_for(n, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
-    dedup_fill_kernel<<<gl, 256, 0, st>>>(nn, t->g, t->bs, d_inverse_out);
-    dedup_emit_kernel<<<gt, 256, 0, st>>>(t->dim4, (const float4*)d_grads, t->g, t->bs, t->op, d_uniq_out, (float4*)d_gsum_out, d_counts_out);
-    MEE_HIP(hipGetLastError());
-    MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
-    MEE_HIP(hipStreamSynchronize(st));
-    *n_unique_out = t->h_op->n_uniq;
-    return MEE_OK;
+    return bucket_dedup_sum(t, d_keys, d_grads, (uint32_t)n, d_uniq_out, d_gsum_out, d_counts_out, d_inverse_out, miss_index, as_stream(stream));
 }
 
-/* sync-free duplicate elimination of a key batch: d_uniq_out[n] = the distinct non-reserved keys (unspecified order) followed by
- * EMPTY padding, d_inverse_out[i] = index of keys[i] in d_uniq_out, or miss_index for reserved keys.  Nothing returns to the host. */
+/* sync-free duplicate elimination of a key batch: d_uniq_out[n] = the distinct non-reserved keys (unspecified order) with EMPTY
+ * padding, d_inverse_out[i] = index of keys[i] in d_uniq_out, or miss_index for reserved keys.  Nothing returns to the host. */
 int mee_dedup_keys(mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_uniq_out, int64_t* d_inverse_out, int64_t miss_index,
                    void* stream) {
     if (!t || (n && (!d_keys || !d_uniq_out || !d_inverse_out))) return fail(MEE_ERR_INVALID_ARG, "mee_dedup_keys: null argument");
     if (int rc = check_batch(t, n, "mee_dedup_keys", stream)) return rc;
     if (n == 0) return MEE_OK;
     DeviceGuard g(t->device);
-    hipStream_t st = as_stream(stream);
-    const uint32_t nn = (uint32_t)n;
-    if (t->bk.pkey && n <= t->bk.fast_max && t->dedup_path != 0)   // partition by hash bucket + one kernel of block-local LDS tables (meepo_dedup.hip)
-        return bucket_dedup_keys(t, d_keys, nn, d_uniq_out, d_inverse_out, miss_index, st);
-    const unsigned gl = grid_for(n, 256, 1u << 22);
-    group_kernel<kGroupCount, kApplyGroupBlock><<<grid_for(nn, kApplyGroupBlock, 1u << 22), kApplyGroupBlock, 0, st>>>(d_keys, nn, t->g, t->bs, t->ctr, nullptr, t->op);
-    group_plan_kernel<true><<<grid_for(n, 1024, 1u << 22), 1024, 0, st>>>(nn, t->g, t->bs, t->op);
-    dedup_fill_kernel<<<gl, 256, 0, st>>>(nn, t->g, t->bs, d_inverse_out, miss_index);
-    dedup_keys_emit_kernel<<<grid_for(n, 256, 4096), 256, 0, st>>>(nn, t->g, t->bs, t->op, d_uniq_out);
-    MEE_HIP(hipGetLastError());
-    return MEE_OK;
+    return bucket_dedup_keys(t, d_keys, (uint32_t)n, d_uniq_out, d_inverse_out, miss_index, as_stream(stream));
 }
 
 }  // extern "C"

@@ -12,14 +12,9 @@ struct Counters {            // device-resident, persistent
     uint32_t pad[2];
 };
 struct OpCounters {          // device-resident, zeroed at the start of each op that uses them
-    uint32_t n_uniq;         // distinct keys appended to the unique list
-    uint32_t n_occ;          // occurrence-list entries reserved
-    uint32_t n_big;          // groups with more than kChunk occurrences
-    uint32_t n_work;         // chunk leaders listed for apply_chunk_kernel
     unsigned long long n_export;  // pairs exported / keys counted
-    uint32_t n_part;         // fp64 partial-sum rows reserved by big groups
+    uint32_t n_part;         // fp64 partial-sum rows reserved by the apply's long runs
     uint32_t pad;
-    unsigned long long occ_work;  // plan-free apply: occurrence-list entries reserved (low half) | work items listed (high half)
 };
 struct GroupTable {            // S entries, indexed by h
     // One 16-byte entry per h: ent[2h] = key ^ kBias (0 = empty), ent[2h+1] = the count word below.  Key and count share a 64-byte sector,
@@ -30,9 +25,6 @@ struct GroupTable {            // S entries, indexed by h
     // count word, high half ("hi"): the same quantity of the block whose CAS claimed the entry — a plain store, no atomic.
     // The pair is one aligned 8-byte word: readers take both halves with ONE load (sv_load), so a reader racing with a release sees
     // either the complete pair or zeros, never a mixture.
-    uint32_t* soffs;           // start of the group's slice of the occurrence list (hot keys of an apply; dedup)
-    uint32_t* sbig;            // first fp64 partial-sum row of a group with more than kChunk occurrences
-    uint32_t* sgrp;            // index of the group in the unique list (standalone dedup)
     long long* sres;           // lent out as a per-position slot list by insert / remove
     uint64_t smask;
 };
@@ -45,11 +37,11 @@ __device__ __forceinline__ void group_release_entry(const GroupTable& g, uint32_
     reinterpret_cast<ulonglong2*>(g.ent)[h] = make_ulonglong2(0ull, 0ull);
 }
 struct BatchScratch {          // max_batch entries, indexed by batch position unless noted
-    uint32_t *hidx, *rank, *pcnt, *occ, *uniq_h, *work;
+    uint32_t *hidx;            // insert: the group-table index of each position's key; mee_dedup_sum: the sorted source lists of buckets beyond the LDS list
+    uint32_t *occ;             // lent to the bucketed machinery as its position list (BucketScratch::pos); the admission pass's skip bytes
     uint8_t* fmask;            // found mask of find_or_insert's first pass when the caller passes none
-    uint32_t* bigh;            // [max_big] group-table index of each big group
-    double* gacc;              // [max_part][dim] fp64 partial-sum rows: one per chunk of a big group, a group's rows contiguous
-    uint32_t max_part;         // rows of gacc (group_plan_kernel never hands out more)
+    double* gacc;              // [max_part][dim] fp64 partial-sum rows of the bucketed apply's long runs (tables with an optimizer)
+    uint32_t max_part;         // rows of gacc
 };
 
 
@@ -75,11 +67,12 @@ struct BucketScratch {
     uint32_t skew_adapt;  // tuning ("apply_skew_adapt", default 1): size the next batch's bucket count by h_slabs
     uint32_t skew_sticky; // batches for which the FULL apply kernel stays chosen after the latest skewed batch
     int kernel_choice;    // tuning ("apply_kernel"): -1 = by the stream (default), 0 = always the LEAN kernel, 1 = always the FULL kernel
-    uint32_t spare_blocks; // tuning ("apply_spare_blocks"): accepted and ignored since round 4 (the apply kernel's blocks claim the slabs of split buckets themselves)
     uint32_t bucket_max;  // tuning ("apply_bucket_max"): positions per bucket aimed at, at most (0 = the default)
     uint32_t n_buckets_max, slots;   // slots: apply blocks the device keeps resident at once (CUs x blocks per CU): bucket counts are multiples of it
     uint64_t fast_max;    // largest n the bucketed path takes
     uint32_t xcd_split;   // tuning ("apply_xcd_split"): see part_bucket_of
+    double* sum_part;     // [sum_part_rows][dim] fp64 partial rows of mee_dedup_sum's hot-key windows (meepo_dedup.hip), one per window unit
+    uint32_t sum_part_rows;
     BucketScratch* dev_copy;   // this struct in device memory (what the FULL apply kernel reads instead of 40 SGPRs of kernel arguments)
 };
 
@@ -98,7 +91,7 @@ struct mee_table {
     uint32_t* sketch;           // admission policy (config.flags & MEE_FLAG_ADMISSION): count-min sketch, 3 rows of 2^sketch_log2w counters
     uint32_t sketch_log2w;
     // per-batch scratch: group table (S entries) and per-position arrays (max_batch entries)
-    uint64_t S, max_big, max_part;   // max_big: groups larger than kChunk; max_part: their fp64 partial-sum rows (one per chunk)
+    uint64_t S, max_part;       // S: group-table entries; max_part: fp64 partial-sum rows of the apply
     mee::GroupTable g;
     mee::BatchScratch bs;
     mee::Counters* ctr;
@@ -121,7 +114,6 @@ struct mee_table {
                                 // -1 = auto: cached loads (hot rows of skewed streams stay in L2), cached stores while the
                                 // dense output fits the Infinity Cache (<= 128 MB), streaming stores beyond
     mee::BucketScratch bk;      // bucketed apply (null pointers when the table has no optimizer)
-    int dedup_path;             // tuning ("dedup_path"): 0 = dedup_keys / assign elections through the group table (round 2), else the bucketed machinery
     bool prepared_by_forward;   // the pending partition came with a training forward (mee_find*_located_prepare): a mutator in between drops it
     uint32_t part_nbk_hash;   // ... of which the first part_nbk_hash are hash buckets (the rest: one per hot key)
     bool part_full;           // ... and the apply kernel chosen for it (FULL | LEAN: meepo_apply.hip)
@@ -170,8 +162,9 @@ int bucket_apply_prepare_as(mee_table* t, const int64_t* d_keys, uint32_t n, hip
 // duplicate elimination and last-wins elections on the same partition (meepo_dedup.hip)
 int bucket_dedup_keys(mee_table* t, const int64_t* d_keys, uint32_t n, int64_t* d_uniq, int64_t* d_inverse, int64_t miss_index, hipStream_t st);
 int bucket_assign(mee_table* t, float* plane, const int64_t* d_keys, const float* d_values, uint32_t n, uint8_t* d_found, hipStream_t st);
-uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out = nullptr, uint32_t* nbk_total_out = nullptr, bool* full_out = nullptr, uint32_t slots_of = 0,
-                          uint32_t bucket_max_of = 0);
+int bucket_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, uint32_t n, int64_t* d_uniq, float* d_gsum, uint32_t* d_counts, int64_t* d_inverse, int64_t miss_index,
+                     hipStream_t st);
+uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out = nullptr, uint32_t* nbk_total_out = nullptr, bool* full_out = nullptr);
 
 // ---- host helpers the table's translation units share (meepo_table.hip, meepo_find.hip, meepo_export.hip) ------------------------------
 inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

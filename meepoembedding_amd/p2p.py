@@ -169,7 +169,7 @@ class PeerShardedFind:
         return self.out[:n], self.found[:n]
 
     # -- mutators over the payload inboxes --------------------------------------------------------------------------
-    def _deliver(self, keys: torch.Tensor, rows: torch.Tensor) -> None:
+    def _deliver(self, keys: torch.Tensor, rows: torch.Tensor, aggregate: bool = False) -> None:
         if not self.payload:
             raise _lib.MeepoError(_lib.ERR_INVALID_ARG, "mutators need PeerShardedFind(..., payload=True)")
         keys = keys.contiguous().view(-1)
@@ -178,7 +178,13 @@ class PeerShardedFind:
         if n > self.max_batch or rows.shape[1] != self.dim or rows.dtype != torch.float32:
             raise _lib.MeepoError(_lib.ERR_INVALID_ARG, f"need n <= {self.max_batch} float32 rows of dim {self.dim}")
         s = torch.cuda.current_stream(self.device).cuda_stream
-        send_keys, counts, perm = self.router.partition(keys)
+        if aggregate:
+            # gradient rows only: one (key, fp64-summed row) pair per distinct key of this rank's batch goes to the owner (mee_dedup_sum, sync-free: the padded
+            # unique list is partitioned with the padding dropped, the push walks the counts); the owner's apply sums the ranks' partial sums in fp64 again
+            keys, rows, _, _ = self.local.dedup_sum(keys, rows)
+            send_keys, counts, perm = self.router.partition(keys, skip_padding=True)
+        else:
+            send_keys, counts, perm = self.router.partition(keys)
         check(_lib.lib().mee_p2p_push_rows(self._h, self.router._h, send_keys.data_ptr(), perm.data_ptr(), counts.data_ptr(),
                                            rows.data_ptr(), n, s))
         self._barrier()
@@ -199,14 +205,15 @@ class PeerShardedFind:
         self.local.assign(self.inbox_keys, self.inbox_rows)
         self._done(check_overflow)
 
-    def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10, check_overflow: bool = True) -> None:
-        self._deliver(keys, grads)
+    def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10, check_overflow: bool = True, dedup: bool = False) -> None:
+        """dedup=True: pre-exchange gradient aggregation (one summed row per distinct key of this rank's batch crosses the links; within 1e-6 of the plain path)."""
+        self._deliver(keys, grads, aggregate=dedup)
         self.local.apply_adagrad(self.inbox_keys, self.inbox_rows, lr, eps)
         self._done(check_overflow)
 
     def apply_adam(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999,
-                   eps: float = 1e-8, step: int = 1, check_overflow: bool = True) -> None:
-        self._deliver(keys, grads)
+                   eps: float = 1e-8, step: int = 1, check_overflow: bool = True, dedup: bool = False) -> None:
+        self._deliver(keys, grads, aggregate=dedup)
         self.local.apply_adam(self.inbox_keys, self.inbox_rows, lr, beta1, beta2, eps, step)
         self._done(check_overflow)
 

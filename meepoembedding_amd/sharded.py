@@ -73,7 +73,7 @@ class ShardedLookupTable:
         """Pre-exchange duplicate elimination: only the batch's DISTINCT keys cross xGMI (keys out, rows back); every
         occurrence is then served from its distinct key's row.  On skewed streams the link traffic scales with the
         number of unique keys while the metric counts lookups (SURVEY §7 hard part 1)."""
-        uniq, _, _, inverse = self.local.dedup_sum(keys)       # the local table's group table does the grouping
+        uniq, _, _, inverse = self.local.dedup_sum(keys, compact=True)   # (this path synchronises for its split sizes anyway)
         rows_u, found_u = self._lookup(uniq, insert_missing)
         # reserved keys have inverse -1: point them at an extra all-default "missing" row
         miss_row, _ = self.local.find(keys.new_full((1,), -(1 << 63)))
@@ -120,12 +120,24 @@ class ShardedLookupTable:
         found = torch.cat([self.local.assign(rk[s:e], rv[s:e]) for s, e in self._chunks(rk.numel())])
         return self.router.scatter_rows(self._a2a(found, rs, ss), perm)
 
-    def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10) -> None:
+    def _aggregate(self, keys: torch.Tensor, grads: torch.Tensor):
+        """Pre-exchange gradient aggregation: one (key, summed row) pair per distinct key of this rank's batch (fp64 sums rounded once, mee_dedup_sum) —
+        on skewed streams the backward's bytes on xGMI scale with the distinct keys.  The owner's apply adds the ranks' partial sums up in fp64 again:
+        within 1e-6 of the un-aggregated update (one extra rounding per rank and key)."""
+        keys = keys.contiguous().view(-1)
+        uniq, gsum, _, _ = self.local.dedup_sum(keys, grads.contiguous().view(keys.numel(), -1), compact=True)   # (this path synchronises for its split sizes anyway)
+        return uniq, gsum
+
+    def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10, dedup: bool = False) -> None:
+        if dedup:
+            keys, grads = self._aggregate(keys, grads)
         rk, rg, *_ = self._push(keys, grads)
         self.local.apply_adagrad(rk, rg, lr, eps)
 
     def apply_adam(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999,
-                   eps: float = 1e-8, step: int = 1) -> None:
+                   eps: float = 1e-8, step: int = 1, dedup: bool = False) -> None:
+        if dedup:
+            keys, grads = self._aggregate(keys, grads)
         rk, rg, *_ = self._push(keys, grads)
         self.local.apply_adam(rk, rg, lr, beta1, beta2, eps, step)
 
@@ -164,7 +176,7 @@ class RcclShardedTable:
     pad_slack = 0: exact message sizes (one host synchronisation per operator, for the split sizes).
     pad_slack >= 1: fixed-capacity EMPTY-padded segments, no host synchronisation (see include/meepo_embedding.h).
     cold: the cold table of a hot/cold pair (`local` = the hot one): BASELINE configs[4] behind the C-ABI (mee_sharded_create_ex).
-    dedup: lookups exchange only the batch's distinct keys (MEE_SHARDED_DEDUP)."""
+    dedup: lookups exchange only the batch's distinct keys, applies one summed gradient row per distinct key (MEE_SHARDED_DEDUP)."""
 
     def __init__(self, local, max_batch: int, group=None, pad_slack: float = 0.0, cold=None, dedup: bool = False, hot_key_limit: int = 0):
         import ctypes as C

@@ -89,6 +89,8 @@ class LookupTable:
         """unordered=True (mee_find_unordered): the launch is not ordered behind EARLIER work of the current stream — only for independent
         requests whose keys are complete and whose output buffers nothing earlier in the stream still touches.
         flags (mee_find_ex): this call's cache policy, an OR of _lib.FIND_* — e.g. FIND_STREAM_STORES for result buffers that rotate."""
+        if flags is not None and unordered:
+            raise ValueError("find(flags=..., unordered=True): mee_find_ex and mee_find_unordered are separate entry points; pass one of the two")
         k = self._keys(keys)
         n = k.numel()
         if out is None:
@@ -470,8 +472,11 @@ class LookupTable:
         check(_lib.lib().mee_dedup_keys(self._h, k.data_ptr(), n, uniq.data_ptr(), inverse.data_ptr(), int(miss_index), self._s()))
         return uniq, inverse
 
-    def dedup_sum(self, keys: torch.Tensor, grads: torch.Tensor | None = None):
-        """Duplicate-key reduction alone: (unique keys, summed grads | None, counts, inverse)."""
+    def dedup_sum(self, keys: torch.Tensor, grads: torch.Tensor | None = None, miss_index: int = -1, compact: bool = False):
+        """Duplicate-key reduction alone (mee_dedup_sum, sync-free): (uniq [n], summed rows [n, dim] | None, counts [n], inverse [n]), PADDED like
+        dedup_keys — every distinct key once in `uniq`, EMPTY elsewhere (also between the keys; counts 0 there, summed rows not written), inverse[i]
+        = index of keys[i] in uniq (miss_index for reserved keys).  compact=True (one host synchronisation: torch.nonzero) squeezes the padding
+        out: uniq / rows / counts of exactly the distinct keys, inverse re-indexed (reserved keys keep miss_index)."""
         k = self._keys(keys)
         n = k.numel()
         g = self._rows(grads, n) if grads is not None else None
@@ -479,12 +484,16 @@ class LookupTable:
         gs = torch.empty((n, self.dim), dtype=torch.float32, device=self.device) if g is not None else None
         cnt = torch.empty(n, dtype=torch.int32, device=self.device)
         inv = torch.empty(n, dtype=torch.int64, device=self.device)
-        nu = C.c_size_t()
         check(_lib.lib().mee_dedup_sum(self._h, k.data_ptr(), g.data_ptr() if g is not None else None, n, uniq.data_ptr(),
-                                       gs.data_ptr() if gs is not None else None, cnt.data_ptr(), inv.data_ptr(), C.byref(nu),
-                                       self._s()))
-        U = nu.value
-        return uniq[:U], (gs[:U] if gs is not None else None), cnt[:U], inv
+                                       gs.data_ptr() if gs is not None else None, cnt.data_ptr(), inv.data_ptr(), int(miss_index), self._s()))
+        if not compact:
+            return uniq, gs, cnt, inv
+        keep = cnt > 0
+        sel = torch.nonzero(keep).view(-1)
+        new_index = torch.cumsum(keep.to(torch.int64), 0) - 1           # padded index -> compact index
+        valid = k > _lib.RECLAIMED_KEY
+        inv_c = torch.where(valid, new_index[inv.clamp(0, max(n - 1, 0))], inv) if n else inv
+        return uniq[sel], (gs[sel] if gs is not None else None), cnt[sel], inv_c
 
 
 class TableGroup:

@@ -126,6 +126,13 @@ class TieredLookupTable:
         self.hot.apply_adam(keys, grads, lr, beta1, beta2, eps, step)
         self.cold.apply_adam(keys, grads, lr, beta1, beta2, eps, step)
 
+    # duplicate reductions touch no table row, only a table's per-batch scratch: the hot table lends its own
+    def dedup_keys(self, keys: torch.Tensor, miss_index: int = -1):
+        return self.hot.dedup_keys(keys, miss_index=miss_index)
+
+    def dedup_sum(self, keys: torch.Tensor, grads: torch.Tensor | None = None, **kw):
+        return self.hot.dedup_sum(keys, grads, **kw)
+
     def size(self) -> int:
         return self.hot.size() + self.cold.size()
 

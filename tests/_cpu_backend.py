@@ -32,7 +32,7 @@ class CpuTable:
     def remove(self, keys):
         return torch.from_numpy(self.o.remove(keys.numpy()))
 
-    def dedup_sum(self, keys, grads=None):
+    def dedup_sum(self, keys, grads=None, compact=True):   # (the oracle's form is the compact one)
         uniq, gs, inv, cnt = oracle.dedup_sum(keys.numpy(), None if grads is None else grads.numpy(), self.dim)
         return torch.from_numpy(uniq), (None if grads is None else torch.from_numpy(gs)), torch.from_numpy(cnt.astype(np.int32)), torch.from_numpy(inv)
 

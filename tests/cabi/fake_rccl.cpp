@@ -23,11 +23,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
-// communicators this stand-in has freed (ncclCommAbort / ncclCommDestroy below)
+// communicators this stand-in has freed (ncclCommAbort / ncclCommDestroy below); ranks may be threads of one process (sharded_mp_test … threads)
+static std::mutex g_freed_mu;
 static std::vector<void*> g_freed;
-static void forget_freed(void* c) { for (size_t i = 0; i < g_freed.size(); ++i) if (g_freed[i] == c) { g_freed.erase(g_freed.begin() + i); return; } }
+static void forget_freed(void* c) { std::lock_guard<std::mutex> lk(g_freed_mu); for (size_t i = 0; i < g_freed.size(); ++i) if (g_freed[i] == c) { g_freed.erase(g_freed.begin() + i); return; } }
 
 namespace {
 
@@ -169,6 +171,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
 // reported loudly (the test that drives the abort path fails on it)
 // (g_freed / forget_freed: defined in front of the anonymous namespace's users, above)
 static void note_free(void* c, const char* who) {
+    std::lock_guard<std::mutex> lk(g_freed_mu);
     for (void* f : g_freed)
         if (f == c) { fprintf(stderr, "fake_rccl: %s on a communicator that was already freed (double free)\n", who); abort(); }
     g_freed.push_back(c);

@@ -1,6 +1,8 @@
 // sharded_mp_test.cpp — the row-sharded table through the C-ABI with G > 1 ranks, from plain C++ (no Python, no torch).
 //
-// usage: sharded_mp_test [G]        (default 2)
+// usage: sharded_mp_test [G] [threads]        (default 2 ranks, one process each)
+// `threads`: the G ranks are THREADS of this one process, every one with a context, a table and a communicator handle of its own on device 0 (the stand-in
+// for librccl keeps its group state per thread) — how G = 8, the node's GPU count, runs on a box that lets one job keep at most 6 processes on its card.
 // The parent forks G rank processes BEFORE any HIP call (a forked child of a process that has initialised HIP is unusable); rank r uses
 // device r when the box has >= G GPUs (then the library binds the real RCCL: ranks exchange over xGMI), else every rank uses device 0 and
 // the environment must name a stand-in for librccl in MEE_RCCL_LIB (RCCL itself refuses several ranks on one device; the test suite's
@@ -9,8 +11,9 @@
 //
 // Sequence per rank (every mee_sharded_* call is collective): insert its slice of N keys with key-derived rows -> size == N -> find a
 // permutation of ALL keys (+ absent ones) -> one sparse-Adagrad step on its slice -> find again and compare with the update computed on the
-// host -> remove half of its slice -> size, found masks.  Twice: exact segments, and padded segments with pre-exchange dedup
-// (mee_sharded_create_ex).  Exit code 0 = every rank passed.
+// host -> a SKEWED step (a quarter of the slice twice more, with other gradients: with MEE_SHARDED_DEDUP the rank sends one summed row per distinct key) ->
+// remove half of its slice -> size, found masks.  Twice: exact segments, and padded segments with pre-exchange dedup (mee_sharded_create_ex).
+// Exit code 0 = every rank passed.
 #include <hip/hip_runtime.h>
 
 #include <sys/mman.h>
@@ -21,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "meepo_embedding.h"
@@ -29,7 +33,7 @@
 #define MEECK(x) do { int rc_ = (x); if (rc_ != MEE_OK) { fprintf(stderr, "[rank %d] %s -> %d: %s\n", g_rank, #x, rc_, mee_last_error()); return 3; } } while (0)
 #define CHECK(c) do { if (!(c)) { fprintf(stderr, "[rank %d] CHECK failed: %s (line %d)\n", g_rank, #c, __LINE__); return 4; } } while (0)
 
-static int g_rank = -1;
+static thread_local int g_rank = -1;
 static uint64_t mix64(uint64_t x) { x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31; return x; }
 static float row_value(int64_t key, int j, uint64_t seed) { return (float)(mix64((uint64_t)key ^ mix64(seed + j)) >> 40) * 0x1p-24f - 0.5f; }
 
@@ -139,6 +143,33 @@ static int run_rank(int rank, int G, Shared* sh) {
             }
         }
 
+        // ---- a skewed step: the first quarter of my slice THREE times in one batch (gradients g, 2g and -g/2: their sum is 2.5 g), the rest once.  The
+        // dedup context adds a key's three rows up on this rank before they travel; the owner applies one update per key either way ----
+        {
+            const size_t quarter = cnt / 4, n2 = cnt + 2 * quarter;
+            std::vector<int64_t> k2(mine);
+            std::vector<float> g2(grads);
+            k2.insert(k2.end(), mine.begin(), mine.begin() + quarter); k2.insert(k2.end(), mine.begin(), mine.begin() + quarter);
+            g2.resize(n2 * dim);
+            for (size_t i = 0; i < quarter; ++i)
+                for (uint32_t j = 0; j < dim; ++j) { g2[(cnt + i) * dim + j] = 2.0f * grads[i * dim + j]; g2[(cnt + quarter + i) * dim + j] = -0.5f * grads[i * dim + j]; }
+            Dev<int64_t> d_k2(n2); Dev<float> d_g2(n2 * dim);
+            CHECK(d_k2.p && d_g2.p);
+            d_k2.up(k2); d_g2.up(g2);
+            MEECK(mee_sharded_apply_adagrad(s, d_k2.p, d_g2.p, n2, lr, eps, nullptr));
+            MEECK(mee_sharded_size(s, &total, nullptr));
+            MEECK(mee_sharded_find(s, d_mine.p, cnt, d_out.p, d_f.p, nullptr));
+            HIPCK(hipDeviceSynchronize());
+            out = d_out.down(cnt * dim);
+            for (size_t i = 0; i < cnt; ++i)
+                for (uint32_t j = 0; j < dim; j += 5) {
+                    const float g = grads[i * dim + j], a1 = fmaf(g, g, acc0), w1 = fmaf(-lr, g / (sqrtf(a1) + eps), rows[i * dim + j]);   // after the first step
+                    const float gs = i < quarter ? (float)((double)g + (double)(2.0f * g) + (double)(-0.5f * g)) : g;
+                    const float a2 = fmaf(gs, gs, a1), w2 = fmaf(-lr, gs / (sqrtf(a2) + eps), w1);
+                    CHECK(fabsf(out[i * dim + j] - w2) <= 2e-6f * fabsf(w2) + 1e-9f);
+                }
+        }
+
         // ---- remove the first half of my slice ----
         const size_t half = cnt / 2;
         MEECK(mee_sharded_remove(s, d_mine.p, half, d_f.p, nullptr));
@@ -167,10 +198,21 @@ static int run_rank(int rank, int G, Shared* sh) {
 
 int main(int argc, char** argv) {
     const int G = argc > 1 ? atoi(argv[1]) : 2;
-    if (G < 1 || G > 8) { fprintf(stderr, "usage: sharded_mp_test [G = 1..8]\n"); return 64; }
+    const bool threads = argc > 2 && !strcmp(argv[2], "threads");
+    if (G < 1 || G > 8) { fprintf(stderr, "usage: sharded_mp_test [G = 1..8] [threads]\n"); return 64; }
     Shared* sh = (Shared*)mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
     if (sh == MAP_FAILED) { perror("mmap"); return 65; }
     memset((void*)sh, 0, sizeof *sh);
+    if (threads) {   // one process, G rank threads
+        std::vector<int> rcs(G, 0);
+        std::vector<std::thread> ts;
+        for (int r = 0; r < G; ++r) ts.emplace_back([&, r] { rcs[r] = run_rank(r, G, sh); });
+        for (auto& t : ts) t.join();
+        int worst = 0;
+        for (int rc : rcs) if (rc > worst) worst = rc;
+        if (worst == 0) printf("sharded_mp_test ok: %d rank THREADS through mee_sharded_* (exact segments; padded segments + pre-exchange dedup)\n", G);
+        return worst;
+    }
     std::vector<pid_t> kids;
     for (int r = 0; r < G; ++r) {   // fork first, HIP later: nothing in this process has touched the GPU
         const pid_t pid = fork();

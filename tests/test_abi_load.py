@@ -23,7 +23,7 @@ def test_header_symbols_exported(built):
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, f"declared in include/meepo_embedding.h but not exported: {missing}"
     assert sorted(_lib.PROTOTYPES) == names, "python prototypes out of sync with the header"
-    assert _lib.lib().mee_abi_version() == 1
+    assert _lib.lib().mee_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_header_is_plain_c():

@@ -307,15 +307,15 @@ def test_dedup_sum(dev):
     keys[123] = oracle.EMPTY_KEY
     grads = rng.standard_normal((n, dim)).astype(np.float32)
     t = LookupTable(64, dim, device=dev, max_batch=n)
-    uniq, gs, cnt, inv = t.dedup_sum(T(keys, dev), T(grads, dev))
+    uniq, gs, cnt, inv = t.dedup_sum(T(keys, dev), T(grads, dev), compact=True)
     uniq, gs, cnt, inv = uniq.cpu().numpy(), gs.cpu().numpy(), cnt.cpu().numpy(), inv.cpu().numpy()
     ou, ogs, oinv, ocnt = oracle.dedup_sum(keys, grads, dim)
     order, oorder = np.argsort(uniq), np.argsort(ou)
     assert np.array_equal(uniq[order], ou[oorder]) and np.array_equal(cnt[order], ocnt[oorder])
     np.testing.assert_allclose(gs[order], ogs[oorder], rtol=RTOL, atol=ATOL)
     assert inv[123] == -1 and np.array_equal(uniq[inv[inv >= 0]], keys[inv >= 0])
-    # group table left clean: a second, different batch gives a correct answer too
-    u2, _, c2, _ = t.dedup_sum(T(keys[:100], dev))
+    # the scratch is left clean: a second, different batch gives a correct answer too
+    u2, _, c2, _ = t.dedup_sum(T(keys[:100], dev), compact=True)
     assert int(c2.sum()) == 100 - (1 if 123 < 100 else 0) and len(np.unique(u2.cpu().numpy())) == u2.numel()
 
 
@@ -1039,7 +1039,7 @@ def test_random_op_sequences(dev, seed, dim, opt):
             else:
                 t.apply_adam(T(keys, dev), T(g, dev), lr=0.002, step=step); o.apply_adam(keys, g, 0.002, 0.9, 0.999, 1e-8, step)
         else:
-            uniq, gs, cnt, inv = t.dedup_sum(T(keys, dev), T(rows, dev))
+            uniq, gs, cnt, inv = t.dedup_sum(T(keys, dev), T(rows, dev), compact=True)
             ou, ogs, oinv, ocnt = oracle.dedup_sum(keys, rows, dim)
             a, b = np.argsort(uniq.cpu().numpy()), np.argsort(ou)
             assert np.array_equal(uniq.cpu().numpy()[a], ou[b]) and np.array_equal(cnt.cpu().numpy()[a], ocnt[b])
@@ -1177,7 +1177,7 @@ def test_apply_prepare_split(dev):
     g = (rng.standard_normal((6000, dim)) * 0.01).astype(np.float32)
     t.apply_adagrad(T(bk, dev), T(g, dev), lr=0.01, eps=1e-10); o.apply_adagrad(bk, g, 0.01, 1e-10)
     t.insert(T(keys[:10], dev), T(rows[:10], dev)); o.insert(keys[:10], rows[:10])   # accepted again, scratch is clean
-    u, _, c, _ = t.dedup_sum(T(np.concatenate([keys[:100], keys[:50]]), dev))
+    u, _, c, _ = t.dedup_sum(T(np.concatenate([keys[:100], keys[:50]]), dev), compact=True)
     assert u.numel() == 100 and int(c.sum()) == 150
     g_ = [x.cpu().numpy() for x in t.export(with_state=True)[:3]]; o_ = o.export(with_state=True)[:3]
     a, b = np.argsort(g_[0]), np.argsort(o_[0])

@@ -2,7 +2,6 @@
 # usage (GPU box): bash tools/dedup_kernels.sh OUT.txt [LIB] — dedup_keys / assign per 1M keys and their kernels, per key stream
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 [ -n "$2" ] && export MEE_LIB_PATH=$GRAFT_REPO_ROOT/$2
-export MEE_DEDUP_ONLY_NEW=1
 for d in uniform zipf; do
   echo "== $d" >> $1
   MEE_DEDUP_DIST=$d timeout -k 10 200 python3 tools/dedup_bench.py 2>&1 | grep "us per" >> $1 || exit 1
