@@ -47,7 +47,15 @@ constexpr uint32_t kLdsPartRows = 16;     // fp64 partial rows a slab keeps in L
 // instead of ~50).  Key streams keep their skew from batch to batch, so the next batch gets S (+ 1/16) fewer, larger buckets and as many
 // blocks as before: slabs and buckets together fill the slots once.  S comes back through a pinned host word the apply kernel writes — read
 // here without any synchronisation (a stale or zero value costs time, never results: the kernel works through whatever units there are).
-uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out, uint32_t* nbk_total_out, bool* full_out) {
+// A launch that is being CAPTURED into a hipGraph is replayed for batches the host never sees: what the host knows about the stream right now is frozen into
+// the graph.  Such launches take the FULL kernel (correct and quick for uniform AND skewed batches; LEAN's slow path would be replayed for ever on a stream
+// that turns skewed), keep buckets for hot keys (the hot-key set itself lives on the device and follows the stream from replay to replay), and — when the
+// host has no skew report at capture time — still leave a twelfth of the block slots to agents.
+static bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+}
+uint32_t bucket_count_for(mee_table* t, uint64_t n, hipStream_t st, uint32_t* grid_out, uint32_t* nbk_total_out, bool* full_out) {
     const uint32_t slots = t->bk.slots;
     uint32_t full = bucket_count_for_host(n, slots, t->bk.bucket_max ? t->bk.bucket_max : kBucketMax);
     // The scratch (totals, run matrices, pending counters, tickets) is strided for n_buckets_max buckets, sized at creation for the DEFAULT bucket size at
@@ -55,16 +63,18 @@ uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out, uint32_t
     const uint32_t room = t->bk.n_buckets_max - kHotCap;
     if (full > room) full = room >= slots ? room / slots * slots : room;
     uint32_t nbk = full;
+    const bool capturing = t->bk.skew_adapt && stream_is_capturing(st);
     const uint32_t s_prev = t->bk.h_slabs && t->bk.skew_adapt ? *(volatile uint32_t*)t->bk.h_slabs : 0u;
     // which kernel (bkt_apply_kernel): FULL behind a skewed batch — and for the 64 batches after the last one: a stream whose skew comes and
     // goes must not fall into the LEAN kernel's slow path every other batch —, else LEAN
     if (s_prev) t->bk.skew_sticky = 64;
     else if (t->bk.skew_sticky) --t->bk.skew_sticky;
-    if (full_out) *full_out = t->bk.kernel_choice >= 0 ? t->bk.kernel_choice != 0 : (s_prev != 0 || t->bk.skew_sticky != 0);
+    if (full_out) *full_out = t->bk.kernel_choice >= 0 ? t->bk.kernel_choice != 0 : (capturing || s_prev != 0 || t->bk.skew_sticky != 0);
     // (a batch with more keys than its buckets hold whole: every bucket is a list of slabs — the FULL kernel's business, whatever the knob says)
     if (full_out && n > (uint64_t)full * (kBucketCap * 3 / 4)) *full_out = true;
-    if (s_prev && n > (uint64_t)slots * 128) {
-        uint32_t adj = s_prev + s_prev / 16 + 1;
+    const uint32_t units = s_prev ? s_prev : capturing && full_out && *full_out ? slots / 12 : 0u;
+    if (units && n > (uint64_t)slots * 128) {
+        uint32_t adj = units + units / 16 + 1;
         if (adj > slots / 2) adj = slots / 2;
         if (adj > full / 2) adj = full / 2;
         nbk = full - adj;
@@ -73,7 +83,7 @@ uint32_t bucket_count_for(mee_table* t, uint64_t n, uint32_t* grid_out, uint32_t
     if (grid_out) *grid_out = full;
     // behind a skewed batch the keys that batch reported as hot get buckets of their own, behind the hash buckets (meepo_apply_part.h) — the
     // FULL kernel's business
-    const bool hot = s_prev && nbk + kHotCap <= t->bk.n_buckets_max && (!full_out || *full_out);
+    const bool hot = (s_prev || capturing) && nbk + kHotCap <= t->bk.n_buckets_max && (!full_out || *full_out);
     if (nbk_total_out) *nbk_total_out = hot ? nbk + kHotCap : nbk;
     return nbk;
 }
@@ -1177,7 +1187,7 @@ extern "C" int mee_debug_timeline(unsigned long long* host_out, uint64_t n_words
 int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st) {
     uint32_t grid, nbk;
     bool full;
-    const uint32_t nbk_hash = bucket_count_for(t, n, &grid, &nbk, &full);
+    const uint32_t nbk_hash = bucket_count_for(t, n, st, &grid, &nbk, &full);
     t->part_full = full;
     uint32_t blocks, per_block;
     part_geometry(n, kPartThreads, blocks, per_block);

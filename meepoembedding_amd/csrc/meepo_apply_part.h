@@ -7,8 +7,8 @@
 namespace mee {
 
 constexpr int kPartBlocks = 128;          // blocks that share the partition of one batch, at most (2 x 64: a wave of the apply kernel scans their run lengths, two per lane)
-constexpr int kPartBlocksMax = 256;       // ... of a dedup / an election (meepo_dedup.hip: four runs per lane; its kernels have the registers for it): a batch of 1M keys is
-                                          // partitioned by 256 blocks on 256 CUs instead of 128 (36 -> ~20 us)
+constexpr int kPartBlocksMax = 128;       // ... of a dedup / an election (meepo_dedup.hip).  (256 blocks for 1M-key batches were measured: the partition gets 2.6 us faster, its
+                                          // consumers 7 us slower — twice the runs per bucket: DESIGN.md §8)
 constexpr uint32_t kSlab = 512;           // positions per slab of a SPLIT bucket (= an apply block's thread count)
 constexpr uint32_t kBucketCap = 1024;     // largest bucket ONE apply block takes whole (two positions per thread; its LDS table has this many slots): only
                                           // larger buckets — a key with >= ~700 occurrences in the batch — are split into slabs with pending records and a merge

@@ -53,13 +53,14 @@ __device__ __forceinline__ uint32_t dd_entry_at(const DedupLds& L, uint32_t gi) 
 
 // the bucket's runs in the partition blocks' slices (wave 0: two runs per lane), as in the apply kernel: the loads (dd_seg_load) travel with the
 // kernel's first round trip, the scan (dd_seg_scan) puts the runs' first indices into LDS
-struct DdRuns { uint32_t len[4], at[4]; };   // lane l of wave 0: runs 4l .. 4l + 3
+constexpr uint32_t kRunsPerLane = kPartBlocksMax / 64;
+struct DdRuns { uint32_t len[kRunsPerLane], at[kRunsPerLane]; };   // lane l of wave 0: runs kRunsPerLane * l ..
 __device__ __forceinline__ DdRuns dd_seg_load(const BucketScratch& bk, uint32_t nbk, uint32_t part_blocks, uint32_t per_block, uint32_t b, uint32_t tid) {
-    DdRuns r{{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    DdRuns r{};
     if (tid < 64) {
 #pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
-            const uint32_t k = 4 * tid + q;
+        for (uint32_t q = 0; q < kRunsPerLane; ++q) {
+            const uint32_t k = kRunsPerLane * tid + q;
             if (k < part_blocks) { r.len[q] = bk.cnt_mat[(uint64_t)k * nbk + b]; r.at[q] = k * per_block + bk.off_mat[(uint64_t)k * nbk + b]; }
         }
     }
@@ -67,10 +68,13 @@ __device__ __forceinline__ DdRuns dd_seg_load(const BucketScratch& bk, uint32_t 
 }
 __device__ __forceinline__ void dd_seg_scan(DedupLds& L, const DdRuns& r, uint32_t tid) {
     if (tid >= 64) return;
-    const uint32_t all = r.len[0] + r.len[1] + r.len[2] + r.len[3], incl = wave_incl_scan_u32(all);
+    uint32_t all = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kRunsPerLane; ++q) all += r.len[q];
+    const uint32_t incl = wave_incl_scan_u32(all);
     uint32_t first = incl - all;
 #pragma unroll
-    for (uint32_t q = 0; q < 4; ++q) { L.seg_first[4 * tid + q] = first; L.seg_at[4 * tid + q] = r.at[q]; first += r.len[q]; }
+    for (uint32_t q = 0; q < kRunsPerLane; ++q) { L.seg_first[kRunsPerLane * tid + q] = first; L.seg_at[kRunsPerLane * tid + q] = r.at[q]; first += r.len[q]; }
     if (tid == 63) L.seg_first[kPartBlocksMax] = incl;
 }
 
@@ -247,7 +251,7 @@ __device__ __forceinline__ uint32_t dd_bucket(DedupLds& L, const BucketScratch& 
     const uint32_t n_hot = A.nbk - A.nbk_hash;
     const uint32_t ht0 = threadIdx.x < n_hot ? bk.tot[A.nbk_hash + threadIdx.x] : 0u, ht1 = threadIdx.x < n_hot ? bk.tot[bk.n_buckets_max + A.nbk_hash + threadIdx.x] : 0u;
     const uint4 hdr = *reinterpret_cast<const uint4*>(bk.seq);
-    const DdRuns runs = hash ? dd_seg_load(bk, A.nbk, A.part_blocks, A.per_block, b, threadIdx.x) : DdRuns{{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    const DdRuns runs = hash ? dd_seg_load(bk, A.nbk, A.part_blocks, A.per_block, b, threadIdx.x) : DdRuns{};
     uint32_t s0 = 0, s1 = 0;   // this thread's share of the totals in front of the bucket (both copies: the selector is not known yet)
     if (PREFIX && hash)
         for (uint32_t j = threadIdx.x; j < b; j += kDedupThreads) { s0 += bk.tot[j]; s1 += bk.tot[bk.n_buckets_max + j]; }
@@ -524,11 +528,17 @@ constexpr uint32_t kSumTileMax = 8, kSumWaveMax = 256;
 struct SumLds {
     DedupLds d;
     uint32_t off[kDedupSlots];        // per run: where its sources begin in the sorted list (while the list is filled: the fill cursor)
-    uint32_t src[kDedupSlots];        // the sorted list (batch positions), when the unit has at most kDedupSlots positions
-    uint16_t items[kDedupSlots];      // run number -> table slot
-    alignas(16) double prow[kDedupWaves][64];   // block-level sums: one partial row (64 floats' worth) per wave
     uint32_t is_last;
+    // Once a pass's keys have been written out and every entry has looked its key up, the key table's 8 KB are free: they hold
+    //   src   [kDedupSlots] u32  the sorted list (batch positions), when the unit has at most kDedupSlots positions      (key[0 .. 512))
+    //   items [kDedupSlots] u16  run number -> table slot                                                                 (key[512 .. 768))
+    //   prow  [kDedupWaves][64] f64  block-level sums: one partial row (64 floats' worth) per wave                        (key[768 .. 1024))
+    // — 25 KB less LDS per block than arrays of their own: 7 resident blocks per CU instead of 5.
+    __device__ __forceinline__ uint32_t* src() { return reinterpret_cast<uint32_t*>(d.key); }
+    __device__ __forceinline__ uint16_t* items() { return reinterpret_cast<uint16_t*>(d.key + 512); }
+    __device__ __forceinline__ double* prow(uint32_t w) { return reinterpret_cast<double*>(d.key + 768) + w * 64; }
 };
+static_assert(kDedupSlots * 8 == kDedupSlots * 4 + kDedupSlots * 2 + kDedupWaves * 64 * 8, "the aliases fill the key table exactly");
 struct SumArgs {
     DedupArgs d;
     const float4* grads; float4* gsum; uint32_t* counts; uint32_t dim4;
@@ -567,12 +577,12 @@ __device__ __forceinline__ void block_run_sum(SumLds& L, uint32_t dim4, uint32_t
         const uint32_t col = cg + tl;
         D4 v = col < dim4 ? run_sum4(4 * T, 16 * kDedupWaves, c, col, load) : D4{0.0, 0.0, 0.0, 0.0};
         v = d4_tiles_sum(v);
-        if (tile == 0) { double* d = &L.prow[wv][tl * 4]; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+        if (tile == 0) { double* d = L.prow(wv) + tl * 4; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
         __syncthreads();
         if (t < 16 && col < dim4) {
             D4 r{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int w = 0; w < kDedupWaves; ++w) { const double* d = &L.prow[w][t * 4]; r.x += d[0]; r.y += d[1]; r.z += d[2]; r.w += d[3]; }
+            for (int w = 0; w < kDedupWaves; ++w) { const double* d = L.prow(w) + t * 4; r.x += d[0]; r.y += d[1]; r.z += d[2]; r.w += d[3]; }
             out(col, r);
         }
         __syncthreads();
@@ -609,12 +619,12 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_sum_kernel(SumArgs A,
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = q * kDedupThreads + t; pp[q] = e < c ? bk.pos[dd_entry_at(L.d, lo + e)] : 0xFFFFFFFFu; }
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) if (pp[q] != 0xFFFFFFFFu) { L.src[q * kDedupThreads + t] = pp[q]; if (A.d.inverse) A.d.inverse[pp[q]] = (int64_t)P.rank; }
+            for (uint32_t q = 0; q < 4; ++q) if (pp[q] != 0xFFFFFFFFu) { L.src()[q * kDedupThreads + t] = pp[q]; if (A.d.inverse) A.d.inverse[pp[q]] = (int64_t)P.rank; }
         }
         __syncthreads();
         if (!A.grads) return;   // (grid-uniform)
         if (P.n_win > 1 && x >= A.max_part) { if (t == 0) atomicOr(A.d.status, (uint32_t)MEE_STATUS_INTERNAL); return; }   // cannot happen (max_part covers every window a batch can have)
-        auto from_list = [&](uint32_t j, uint32_t col) { return grad_row4(A.grads, L.src[j], dim4, col); };
+        auto from_list = [&](uint32_t j, uint32_t col) { return grad_row4(A.grads, L.src()[j], dim4, col); };
         if (P.n_win == 1) { block_run_sum(L, dim4, c, from_list, [&](uint32_t col, const D4& v) { store_sum4(A.gsum, P.rank, dim4, col, v); }); return; }
         block_run_sum(L, dim4, c, from_list, [&](uint32_t col, const D4& v) {
             double* d = A.part + ((uint64_t)x * dim4 + col) * 4;
@@ -662,23 +672,23 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_sum_kernel(SumArgs A,
 #pragma unroll
             for (uint32_t q = 0; q < per; ++q) {
                 const uint32_t sl = t * per + q;
-                if (L.d.key[sl] == 0ull) continue;
+                if (L.d.key[sl] == 0ull) { L.d.cnt[sl] = 0u; continue; }   // (cnt != 0 marks a run from here on: the key table is about to be reused)
                 const uint32_t c = L.d.cnt[sl];
                 const uint32_t idx = c <= kSumTileMax ? i_s++ : c <= kSumWaveMax ? i_m++ : i_l++;
-                L.d.val[sl] = idx; L.items[idx] = (uint16_t)sl; L.off[sl] = o; o += c;
+                L.d.val[sl] = idx; L.off[sl] = o; o += c;
                 A.d.uniq[base + idx] = (int64_t)(L.d.key[sl] ^ kBias);
                 if (A.counts) A.counts[base + idx] = c;
             }
         }
         __syncthreads();
-        // -- 2. every entry of the pass: its key's number into d_inverse, its position into its run's part of the sorted list
+        // -- 2. every entry of the pass looks its key up: the key's number into d_inverse; a bucket beyond the LDS list files its positions in the global list at once
+        uint32_t my_sl[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         if (in_lds) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (held.k[q] == kEmpty || (mix64b((uint64_t)held.k[q]) & mask) != val) continue;
-                const uint32_t sl = dd_lookup(L.d, (unsigned long long)held.k[q] ^ kBias);
-                if (A.d.inverse) A.d.inverse[held.p[q]] = (int64_t)(base + L.d.val[sl]);
-                if (A.grads) L.src[atomicAdd(&L.off[sl], 1u)] = held.p[q];
+                my_sl[q] = dd_lookup(L.d, (unsigned long long)held.k[q] ^ kBias);
+                if (A.d.inverse) A.d.inverse[held.p[q]] = (int64_t)(base + L.d.val[my_sl[q]]);
             }
         } else {
             for (uint32_t e0 = 0; e0 < size; e0 += 4 * kDedupThreads) {   // four entries in flight per thread
@@ -699,29 +709,67 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_sum_kernel(SumArgs A,
             }
         }
         if (!A.grads) return;   // (grid-uniform) keys, counts and inverse only
-        __syncthreads();   // (drains the stores of the global list as well)
+        __syncthreads();   // nobody looks a key up any more: the key table's space becomes src / items / prow (and the stores of the global list are drained)
+        // -- 2b. the LDS list (positions sorted by run, through each run's cursor) and the run list (run number -> slot)
+        if (in_lds) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (my_sl[q] != 0xFFFFFFFFu) L.src()[atomicAdd(&L.off[my_sl[q]], 1u)] = held.p[q];
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < per; ++q) { const uint32_t sl = t * per + q; if (L.d.cnt[sl]) L.items()[L.d.val[sl]] = (uint16_t)sl; }
+        __syncthreads();
         // from here on run sl's sources are [L.off[sl] - cnt, L.off[sl]) of the list
-        auto source = [&](uint32_t at) -> uint32_t { return in_lds ? L.src[at] : __hip_atomic_load(&srcg[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-        // -- 3. long runs: the whole block, one after the other
+        auto source = [&](uint32_t at) -> uint32_t { return in_lds ? L.src()[at] : __hip_atomic_load(&srcg[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        // -- 3. long runs: the whole block, one after the other (the block-level sums use prow: all threads pass the barriers inside)
         for (uint32_t j = 0; j < n_l; ++j) {   // block-uniform
-            const uint32_t idx = n_s + n_m + j, sl = L.items[idx], c = L.d.cnt[sl], first = L.off[sl] - c;
+            const uint32_t idx = n_s + n_m + j, sl = L.items()[idx], c = L.d.cnt[sl], first = L.off[sl] - c;
             block_run_sum(L, dim4, c, [&](uint32_t q, uint32_t col) { return grad_row4(A.grads, source(first + q), dim4, col); },
                           [&](uint32_t col, const D4& v) { store_sum4(A.gsum, base + idx, dim4, col, v); });
         }
         // -- 4. medium runs: a wave each
         for (uint32_t j = wv; j < n_m; j += kDedupWaves) {   // wave-uniform
-            const uint32_t idx = n_s + j, sl = L.items[idx], c = L.d.cnt[sl], first = L.off[sl] - c;
+            const uint32_t idx = n_s + j, sl = L.items()[idx], c = L.d.cnt[sl], first = L.off[sl] - c;
             for (uint32_t col = tl; col < dim4 + tl; col += 16) {   // (every lane runs the same number of turns: the shuffles need whole waves)
                 D4 v = col < dim4 ? run_sum4(4 * tile, 16, c, col, [&](uint32_t q, uint32_t cc) { return grad_row4(A.grads, source(first + q), dim4, cc); }) : D4{0.0, 0.0, 0.0, 0.0};
                 v = d4_tiles_sum(v);
                 if (tile == 0 && col < dim4) store_sum4(A.gsum, base + idx, dim4, col, v);
             }
         }
-        // -- 5. short runs: a tile each (a key that occurs once — the bulk — is one streamed row in, one row out)
-        for (uint32_t idx = T; idx < n_s; idx += 4 * kDedupWaves) {
-            const uint32_t sl = L.items[idx], c = L.d.cnt[sl], first = L.off[sl] - c;
-            for (uint32_t col = tl; col < dim4; col += 16)
-                store_sum4(A.gsum, base + idx, dim4, col, run_sum4(0u, 4u, c, col, [&](uint32_t q, uint32_t cc) { return grad_row4(A.grads, source(first + q), dim4, cc); }));
+        // -- 5. short runs: a tile each, FOUR runs in flight per tile.  Four keys that occur once — the bulk of every batch — are four streamed rows in, four rows
+        // out, bit for bit (no arithmetic); otherwise each run is summed in turn (two round trips of four rows)
+        constexpr uint32_t kTiles = 4 * kDedupWaves;
+        for (uint32_t i0 = T; i0 < n_s; i0 += 4 * kTiles) {   // tile T takes runs T, T + 16, T + 32, T + 48, then T + 64, ...
+            uint32_t idx[4], c[4], first[4];
+            bool all_once = true;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                idx[q] = i0 + q * kTiles;
+                const bool ok = idx[q] < n_s;
+                const uint32_t sl = ok ? L.items()[idx[q]] : 0u;
+                c[q] = ok ? L.d.cnt[sl] : 0u;
+                first[q] = ok ? L.off[sl] - c[q] : 0u;
+                all_once = all_once && c[q] <= 1u;
+            }
+            if (all_once) {
+                uint32_t row[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) row[q] = c[q] ? source(first[q]) : 0u;
+                for (uint32_t col = tl; col < dim4; col += 16) {
+                    f32x4 g[4];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) g[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A.grads) + (uint64_t)row[q] * dim4 + col);   // (row 0 for a missing run: a valid address)
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) if (c[q]) A.gsum[(uint64_t)(base + idx[q]) * dim4 + col] = make_float4(g[q].x, g[q].y, g[q].z, g[q].w);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) {
+                    if (!c[q]) continue;
+                    const uint32_t f0 = first[q];
+                    for (uint32_t col = tl; col < dim4; col += 16)
+                        store_sum4(A.gsum, base + idx[q], dim4, col, run_sum4(0u, 4u, c[q], col, [&](uint32_t j, uint32_t cc) { return grad_row4(A.grads, source(f0 + j), dim4, cc); }));
+                }
+            }
         }
     });
 }
@@ -733,7 +781,7 @@ static int dedup_partition(mee_table* t, const int64_t* d_keys, uint32_t n, hipS
                            uint32_t* d_counts = nullptr) {
     uint32_t grid, nbk;
     bool full;
-    const uint32_t nbk_hash = bucket_count_for(t, n, &grid, &nbk, &full);
+    const uint32_t nbk_hash = bucket_count_for(t, n, st, &grid, &nbk, &full);
     // (hot keys' buckets whenever the latest batch reported any: a dedup has no FULL / LEAN kernels, its one kernel takes buckets of any size)
     uint32_t blocks, per_block;
     part_geometry(n, 1024, blocks, per_block, kPartBlocks);

@@ -672,7 +672,7 @@ int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, floa
     hipStream_t st = as_stream(stream);
     uint32_t apply_grid, nbk;
     bool apply_full;
-    const uint32_t nbk_hash = bucket_count_for(t, n, &apply_grid, &nbk, &apply_full);
+    const uint32_t nbk_hash = bucket_count_for(t, n, st, &apply_grid, &nbk, &apply_full);
     uint32_t part_blocks, per_block;
     part_geometry((uint32_t)n, kFindPrepareThreads, part_blocks, per_block);
     const int R = t->dim4 == 16 ? kFindPrepareR : t->dim4 == 32 ? 2 : 1;

@@ -1105,11 +1105,14 @@ def test_find_parity_under_every_tuning_knob(dev, dim):
     with pytest.raises(MeepoError):
         t.set_tuning("no_such_knob", 1)
     g = (synth.rows_np(keys[:n], dim, 6) * 0.02).astype(np.float32)
-    for ar in (1, 2):
-        t.set_tuning("apply_rounds", ar)
+    for retired in ("apply_rounds", "apply_path", "apply_overlap", "apply_spare_blocks", "dedup_path"):   # knobs of deleted code paths are unknown names now
+        with pytest.raises(MeepoError):
+            t.set_tuning(retired, 1)
+    for kernel, bmax, split in ((0, 0, 0), (1, 128, 548), (-1, 352, 300)):      # the apply's knobs: never change results
+        t.set_tuning("apply_kernel", kernel); t.set_tuning("apply_bucket_max", bmax); t.set_tuning("apply_xcd_split", split)
         t.apply_adagrad(T(keys[:n], dev), T(g, dev), lr=0.01); o.apply_adagrad(keys[:n], g, 0.01, 1e-10)
         out, _ = t.find(T(keys[:n], dev)); exp, _ = o.find(keys[:n])
-        assert np.array_equal(out.cpu().numpy(), exp), ar
+        assert np.array_equal(out.cpu().numpy(), exp), (kernel, bmax, split)
 
 
 @pytest.mark.parametrize("dim", [4, 512, 1024])

@@ -10,7 +10,6 @@ keys_n, batch, dim = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000, 1 <
 dist_name = sys.argv[2] if len(sys.argv) > 2 else "uniform"
 adam = len(sys.argv) > 4 and sys.argv[4] == "adam"
 bmax = int(os.environ.get("MEE_BUCKET_MAX", "0"))
-spare = int(os.environ.get("MEE_SPARE", "0"))
 pdbg = int(os.environ.get("MEE_PREPARE_DEBUG", "0"))
 t = LookupTable(int(keys_n / 0.75), dim, device=dev, max_batch=1 << 20, optimizer=OPT_ADAM if adam else OPT_ADAGRAD)
 bench.populate(t, synth, keys_n, dim, dev, 1 << 20)
@@ -31,8 +30,6 @@ def apply(k, **kw):
 for _ in (0,):
     if bmax:
         t.set_tuning("apply_bucket_max", bmax)
-    if spare:
-        t.set_tuning("apply_spare_blocks", spare)
     if pdbg:
         t.set_tuning("prepare_debug", pdbg)
     if os.environ.get("MEE_XCD_SPLIT"):

@@ -20,7 +20,6 @@ dev = torch.device("cuda", 0)
 kind = OPT_ADAGRAD if a.opt == "adagrad" else OPT_ADAM
 t = LookupTable(int(a.keys / 0.75), a.dim, device=dev, max_batch=1 << 20, optimizer=kind)
 bench.populate(t, synth, a.keys, a.dim, dev, 1 << 20)
-t.set_tuning('apply_rounds', a.apply_rounds)
 NB = 16
 batches = bench.lookup_batches(synth, a.keys, a.batch, NB, a.dist, dev, seed=3)
 uniq = [int(torch.unique(b).numel()) for b in batches]
