@@ -99,8 +99,9 @@ int mee_table_info_get(const mee_table* t, mee_table_info* out);
 int mee_clear(mee_table* t, void* stream);
 /* performance knobs; never change results.  "find_rounds" (keys in flight per 16-lane tile: 1/2/4/8), "find_grid_cap" (max blocks of
  * the find grid, 0 = unbounded), "find_nt" (cache policy of a find: bit 0 streaming row loads, bit 1 streaming bucket loads, bit 2 cached
- * stores of the dense output; -1 = the library's rule: cached loads, cached stores while one call's output is <= 128 MB.  A caller whose
- * result buffers rotate — nothing re-reads them from cache — sets 0: cached loads, streaming stores; prefer mee_find_ex: the hint with the CALL),
+ * stores of the dense output; -1 = the library's rule: cached loads; cached stores while one call's output is <= 128 MB and the table's latest
+ * lookups wrote to one buffer, streaming stores once their output buffers rotate (the distinct buffers of the last eight calls exceed 64 MB);
+ * prefer mee_find_ex: the hint with the CALL),
  * "apply_bucket_max" (target positions per bucket of the apply, 1..352; 0 = the library's rule: one bucket per resident block slot, as many
  * rounds as the batch needs; the bucket COUNT never exceeds what the table's scratch was sized for at creation — the default rule at max_batch —, so a
  * small value on a batch near max_batch gives larger buckets than asked for), "apply_kernel" (-1 = the library's choice by the stream's skew, 0 = LEAN,
@@ -108,6 +109,20 @@ int mee_clear(mee_table* t, void* stream);
  * bucket pair's hash range that goes to the even bucket — even and odd XCDs differ in read-modify-write rate —, 0 = even halves; -1 = as calibrated on this
  * device when its first table was created).  Unknown names: MEE_ERR_INVALID_ARG. */
 int mee_set_tuning(mee_table* t, const char* name, int value);
+/* What the library measured on `device` when the first table with an optimizer was created there (or measures now): the apply's blocks run on the XCD their index
+ * picks, and one parity's read-modify-write stream can be slower than the other's.  A probe kernel with the apply's access pattern is timed by block-index parity
+ * (three launches, the first discarded); "apply_xcd_split" defaults to the share that equalises the two — 0 (even halves) unless both measured launches put the same
+ * parity at least 5 % behind and blocks b and b + 8 were seen on one XCD throughout.  The environment variable MEE_XCD_SPLIT pins the value (0..1023). */
+typedef struct mee_calibration {
+    uint32_t struct_size;                 /* = sizeof(mee_calibration) */
+    uint32_t xcd_split;                   /* the value tables on this device start with (0 = even halves) */
+    uint32_t from_env;                    /* 1: MEE_XCD_SPLIT, nothing was measured */
+    uint32_t placement_consistent;        /* 1: in both measured launches, blocks b and b + 8 ran on the same XCD */
+    float    odd_over_even[2];            /* mean block time of odd-indexed blocks / even-indexed blocks, per measured launch */
+    float    block_us_by_index_mod_8[8];  /* last launch: mean block time by block index mod 8 */
+    uint32_t xcc_of_index_mod_8[8];       /* last launch: the XCC id blocks 0..7 reported */
+} mee_calibration;
+int mee_device_calibration(int32_t device, mee_calibration* out);
 
 /* ---- lookup-table operators (README.md:2 "lookuptable-style"; SPEC.md §3) ------------------------------ */
 /* out[i,:] = row of keys[i] or default_value; found nullable. */
@@ -116,8 +131,8 @@ int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, 
  * queues with different access patterns share one table without touching anything the other one's calls read (mee_set_tuning("find_nt")
  * stays as the table's default for callers that pass MEE_FIND_DEFAULT and for mee_find).
  *   MEE_FIND_STREAM_STORES  the dense output is not re-read from cache (result buffers that rotate, outputs beyond the Infinity Cache)
- *   MEE_FIND_CACHED_STORES  the opposite: keep the output cached whatever its size (at most one of the two; neither = by size: cached
- *                           while one call's output is <= 128 MB)
+ *   MEE_FIND_CACHED_STORES  the opposite: keep the output cached whatever its size (at most one of the two; neither = the library's rule: cached
+ *                           while one call's output is <= 128 MB and the table's latest lookups did not rotate over output buffers)
  *   MEE_FIND_STREAM_ROWS    rows are not looked up again soon (uniform streams over a table far larger than the caches); a skewed stream
  *                           wants its hot rows cached and must not set it
  *   MEE_FIND_STREAM_BUCKETS the same for the 128-byte key lines */
@@ -228,6 +243,9 @@ int mee_table_plane(const mee_table* t, uint32_t plane, void** ptr_out, uint64_t
 /* [syncs] measurement aid (SURVEY.md §8d "mean probe length"): the number of buckets a find visits for d_keys, summed over
  * the batch (reserved keys visit none); divide by n for the mean.  Changes nothing. */
 int mee_probe_length(const mee_table* t, const int64_t* d_keys, size_t n, uint64_t* buckets_visited_out, void* stream);
+/* [syncs] the same as a histogram (SURVEY.md §5 "metrics"): hist_out[0 .. 3] = how many of the batch's lookups visit 1 / 2 / 3 / 4 or more buckets
+ * (reserved keys visit none and are not counted). */
+int mee_probe_histogram(const mee_table* t, const int64_t* d_keys, size_t n, uint64_t* hist_out /* [4] */, void* stream);
 
 /* ---- table groups: one launch for the lookups of many tables (a model's embedding collection) ----------------
  * All tables of a group live on one device and have the same dim.  The key batches of the tables are concatenated

@@ -49,6 +49,12 @@ class FindRequest(C.Structure):
     _fields_ = [("d_keys", C.c_void_p), ("n", C.c_size_t), ("d_out", C.c_void_p), ("d_found", C.c_void_p)]
 
 
+class Calibration(C.Structure):
+    """mee_calibration: what mee_device_calibration measured (the apply's bucket-pair split by block-index parity)"""
+    _fields_ = [("struct_size", C.c_uint32), ("xcd_split", C.c_uint32), ("from_env", C.c_uint32), ("placement_consistent", C.c_uint32),
+                ("odd_over_even", C.c_float * 2), ("block_us_by_index_mod_8", C.c_float * 8), ("xcc_of_index_mod_8", C.c_uint32 * 8)]
+
+
 class ShardedOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("max_batch", C.c_uint64), ("pad_slack", C.c_double),
                 ("cold", C.c_void_p), ("hot_key_limit", C.c_uint64)]
@@ -120,7 +126,9 @@ PROTOTYPES = {
     "mee_admission_decay": (C.c_int, [_vp, _u32, _vp]),
     "mee_locate": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "mee_table_plane": (C.c_int, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_u32)]),
+    "mee_device_calibration": (C.c_int, [C.c_int32, C.POINTER(Calibration)]),
     "mee_probe_length": (C.c_int, [_vp, _vp, _sz, C.POINTER(_u64), _vp]),
+    "mee_probe_histogram": (C.c_int, [_vp, _vp, _sz, C.POINTER(C.c_uint64), _vp]),
     "mee_apply_adagrad": (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _vp]),
     "mee_apply_adam": (C.c_int, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _u64, _vp]),
     "mee_apply_prepare": (C.c_int, [_vp, _vp, _sz, _vp]),
@@ -188,6 +196,15 @@ def lib() -> C.CDLL:
             raise ImportError(f"{LIB_PATH}: ABI version {L.mee_abi_version()} != {ABI_VERSION}")
         _lib = L
     return _lib
+
+
+def device_calibration(device: int = 0) -> dict:
+    """mee_device_calibration as a dict (runs the probe if no table with an optimizer has been created on the device yet)"""
+    c = Calibration(struct_size=C.sizeof(Calibration))
+    check(lib().mee_device_calibration(int(device), C.byref(c)))
+    return {"xcd_split": c.xcd_split, "from_env": bool(c.from_env), "placement_consistent": bool(c.placement_consistent),
+            "odd_over_even": [round(float(x), 4) for x in c.odd_over_even], "block_us_by_index_mod_8": [round(float(x), 2) for x in c.block_us_by_index_mod_8],
+            "xcc_of_index_mod_8": [int(x) for x in c.xcc_of_index_mod_8]}
 
 
 def check(rc: int) -> None:

@@ -24,14 +24,24 @@
 // slice of the table.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
 #include "meepo_apply_part.h"
 
 namespace mee {
 
-// share (per 1024) of a bucket pair's hash range that goes to the even bucket; 0 = even halves (tuning "apply_xcd_split").  Apply block b runs on
-// XCD b % 8 and the odd XCDs' read-modify-write streams are ~15 % slower (timeline: 42.8 vs 38.0 us for a block's items).  Located LEAN kernel, uniform 256K keys, same box:
-// 0: 63.1-63.4 us, 530: 62.8, 540: 61.7, 550: 60.8, 560: 61.5, 580: 62.4, 600: 64.0, 620: 64.8; the probing kernel and the Zipf (FULL) kernels do not move.
-constexpr uint32_t kXcdSplit = 548;
+// Share (per 1024) of a bucket pair's hash range that goes to the even bucket; 0 = even halves (tuning "apply_xcd_split").  Blocks are dealt round-robin over the
+// XCDs, and in round 3-4's timelines the read-modify-write stream of the blocks with an odd index ran ~15 % slower (42.8 vs 38.0 us for a block's items; the find shows
+// nothing of the kind).  Located LEAN kernel, uniform 256K keys, one box: 0: 63.1-63.4 us, 530: 62.8, 540: 61.7, 550: 60.8, 560: 61.5, 580: 62.4, 600: 64.0 — the wrong
+// side costs what the right side gains, and WHICH parity is slow is a property of the device and the driver's placement, not of the architecture.  So it is MEASURED:
+// when the first table with an optimizer is created on a device, xcd_probe_kernel runs the apply's access pattern (streamed gradient row, row + state row read, both
+// written back, random rows of a 64 MB plane pair) in a grid shaped like the apply's, three times, and the host compares the mean block time by block-index parity:
+// the same sign in both measured launches and at least 5 % apart — the even bucket gets the share that equalises the two; anything else — even halves.  ~2 ms, once
+// per device and process (mee_device_calibration reports what was measured).
 constexpr int kPartThreads = 1024;
 constexpr int kApplyThreads = 512;
 constexpr int kApplyWaves = kApplyThreads / 64;
@@ -1122,6 +1132,110 @@ __global__ __launch_bounds__(kApplyThreads, kApplyWavesPerSimd) void bkt_apply_k
     }
 }
 
+// ---- calibration of the bucket pairs' split (see kXcdSplit's successor above) -----------------------------------------------------------
+__global__ __launch_bounds__(kApplyThreads, kApplyWavesPerSimd) void xcd_probe_kernel(float4* __restrict__ w, float4* __restrict__ acc, const float4* __restrict__ g,
+                                                                                      uint32_t row_mask, uint32_t iters, unsigned long long* __restrict__ out) {
+    const uint32_t tile = threadIdx.x >> 4, tl = threadIdx.x & 15;
+    unsigned long long t0 = 0;
+    if (threadIdx.x == 0) t0 = wall_clock64();
+    uint64_t x = mix64((uint64_t)blockIdx.x * 32 + tile + 1);
+    for (uint32_t it = 0; it < iters; ++it) {
+        x = mix64(x);
+        const uint64_t row = x & row_mask, grow = (x >> 32) & row_mask;
+        const f32x4 gq = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + grow * 16 + tl);
+        float4 a = w[row * 16 + tl], b = acc[row * 16 + tl];
+        adagrad1(a.x, b.x, gq.x, 0.01f, 1e-10f); adagrad1(a.y, b.y, gq.y, 0.01f, 1e-10f);
+        adagrad1(a.z, b.z, gq.z, 0.01f, 1e-10f); adagrad1(a.w, b.w, gq.w, 0.01f, 1e-10f);
+        w[row * 16 + tl] = a; acc[row * 16 + tl] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        out[2 * blockIdx.x] = wall_clock64() - t0;
+        out[2 * blockIdx.x + 1] = xcc & 0xfu;
+    }
+}
+
+struct XcdCalibration { bool done; uint32_t split; mee_calibration rep; };
+static std::mutex g_cal_mu;
+static XcdCalibration g_cal[64];
+
+static void calibrate_device(int device, XcdCalibration& c) {
+    c.done = true; c.split = 0;
+    memset(&c.rep, 0, sizeof c.rep);
+    c.rep.struct_size = sizeof c.rep;
+    if (const char* env = getenv("MEE_XCD_SPLIT")) {   // (pin it: A/B runs, reproducing a number)
+        const int v = atoi(env);
+        c.split = v > 0 && v < 1024 ? (uint32_t)v : 0u;
+        c.rep.xcd_split = c.split; c.rep.from_env = 1;
+        return;
+    }
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    const uint32_t grid = (uint32_t)cus * kApplyBlocksPerCU, rows = 1u << 18, iters = 40;   // one round of the apply's resident block slots; 64 MB per plane
+    float4 *w = nullptr, *acc = nullptr, *g = nullptr;
+    unsigned long long* out = nullptr;
+    std::vector<unsigned long long> h(2 * grid);
+    hipError_t e = hipMalloc((void**)&w, (uint64_t)rows * 256);
+    if (e == hipSuccess) e = hipMalloc((void**)&acc, (uint64_t)rows * 256);
+    if (e == hipSuccess) e = hipMalloc((void**)&g, (uint64_t)rows * 256);
+    if (e == hipSuccess) e = hipMalloc((void**)&out, 2ull * grid * 8);
+    if (e == hipSuccess) e = hipMemset(w, 0, (uint64_t)rows * 256);
+    if (e == hipSuccess) e = hipMemset(acc, 0x3f, (uint64_t)rows * 256);   // (positive accumulators: no NaN paths)
+    if (e == hipSuccess) e = hipMemset(g, 0, (uint64_t)rows * 256);
+    double ratio[2] = {1.0, 1.0};
+    for (int rep = 0; rep < 3 && e == hipSuccess; ++rep) {   // the first launch warms caches and TLBs up and is not looked at
+        xcd_probe_kernel<<<grid, kApplyThreads, 0, 0>>>(w, acc, g, rows - 1, iters, out);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(h.data(), out, 2ull * grid * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess || rep == 0) continue;
+        double sum[2] = {0, 0}, byres[8] = {0}, cnt[2] = {0, 0}, nres[8] = {0};
+        uint32_t consistent = 1;
+        for (uint32_t b = 0; b < grid; ++b) {
+            sum[b & 1] += (double)h[2 * b]; cnt[b & 1] += 1;
+            byres[b & 7] += (double)h[2 * b]; nres[b & 7] += 1;
+            if (b >= 8 && h[2 * b + 1] != h[2 * (b - 8) + 1]) consistent = 0;   // blocks b and b + 8 share an XCD: the placement the weighting relies on
+        }
+        ratio[rep - 1] = (sum[1] / cnt[1]) / (sum[0] / cnt[0]);
+        c.rep.odd_over_even[rep - 1] = (float)ratio[rep - 1];
+        if (rep == 2) for (int r = 0; r < 8; ++r) { c.rep.block_us_by_index_mod_8[r] = (float)(byres[r] / (nres[r] ? nres[r] : 1) * 0.01); c.rep.xcc_of_index_mod_8[r] = (uint32_t)h[2 * r + 1]; }
+        c.rep.placement_consistent = c.rep.placement_consistent || rep == 1 ? (c.rep.placement_consistent || rep == 1) && consistent : consistent;
+    }
+    for (void* p : {(void*)w, (void*)acc, (void*)g, (void*)out}) if (p) (void)hipFree(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return; }   // no calibration: even halves
+    const bool same_side = (ratio[0] > 1.0) == (ratio[1] > 1.0);
+    const double lo = fmin(fabs(ratio[0] - 1.0), fabs(ratio[1] - 1.0));
+    if (same_side && lo >= 0.05 && c.rep.placement_consistent) {
+        const double r = 0.5 * (ratio[0] + ratio[1]);          // odd blocks take r times as long per position: the even bucket gets r / (1 + r) of the pair's range
+        double split = 1024.0 * r / (1.0 + r);
+        split = split < 448.0 ? 448.0 : split > 576.0 ? 576.0 : split;
+        c.split = (uint32_t)(split + 0.5);
+    }
+    c.rep.xcd_split = c.split;
+}
+
+uint32_t xcd_split_for_device(int device) {
+    std::lock_guard<std::mutex> lk(g_cal_mu);
+    if (device < 0 || device >= 64) return 0u;
+    if (!g_cal[device].done) calibrate_device(device, g_cal[device]);
+    return g_cal[device].split;
+}
+
+}  // namespace mee
+extern "C" int mee_device_calibration(int32_t device, mee_calibration* out) {
+    if (!out || out->struct_size != sizeof(mee_calibration)) return mee::fail(MEE_ERR_INVALID_ARG, "mee_device_calibration: null argument or struct_size != %zu", sizeof(mee_calibration));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || device >= 64) return mee::fail(MEE_ERR_INVALID_ARG, "mee_device_calibration: no such device %d", device);
+    mee::DeviceGuard g(device);
+    (void)mee::xcd_split_for_device(device);
+    std::lock_guard<std::mutex> lk(mee::g_cal_mu);
+    *out = mee::g_cal[device].rep;
+    return MEE_OK;
+}
+namespace mee {
+
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
 int bucket_scratch_alloc(mee_table* t) {
     BucketScratch& bk = t->bk;
@@ -1161,7 +1275,8 @@ int bucket_scratch_alloc(mee_table* t) {
     alloc((void**)&bk.sum_part, (uint64_t)bk.sum_part_rows * t->dim * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc((void**)&bk.h_slabs, 64, hipHostMallocMapped | hipHostMallocPortable);
     if (e == hipSuccess) { *bk.h_slabs = 0u; e = hipHostGetDevicePointer((void**)&bk.h_slabs_dev, bk.h_slabs, 0); }
-    bk.skew_adapt = 1; bk.skew_sticky = 0; bk.kernel_choice = -1; bk.xcd_split = kXcdSplit;
+    bk.skew_adapt = 1; bk.skew_sticky = 0; bk.kernel_choice = -1;
+    bk.xcd_split = t->optimizer != MEE_OPT_NONE && t->value_memory == MEE_MEM_HBM ? xcd_split_for_device(t->device) : 0u;   // (only the apply's blocks care)
     // the device-resident copy the FULL apply kernel reads (everything the DEVICE uses of this struct is fixed from here on; the tuning fields are the host's)
     bk.dev_copy = nullptr;
     alloc((void**)&bk.dev_copy, sizeof(BucketScratch));

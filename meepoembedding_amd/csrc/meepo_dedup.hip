@@ -517,14 +517,14 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
 // What mee_dedup_keys does, and per distinct key its occurrence count and summed row.  A pass's table gives every run (distinct key) its
 // number and — block prefix sums over the table's slots — the place of its sources in a list sorted by run; the sources are filled in through an
 // LDS cursor per run; then the runs are summed by as much of the block as their length wants: a run of up to 8 sources by one 16-lane TILE (two
-// dependent round trips of four rows), up to 256 by a WAVE (its four tiles, 16 rows per round trip, combined with two shuffles), longer ones by the
+// dependent round trips of four rows), up to 64 by a WAVE (its four tiles, 16 rows per round trip, combined with two shuffles), longer ones by the
 // whole BLOCK (64 rows per round trip, the four waves' sums combined through 2 KB of LDS).  The runs are numbered short ones first, so that the
 // three classes are three index ranges of one list.  A bucket of more than 1024 positions keeps its sorted sources in global scratch (one
 // max_batch-sized array, every bucket owns the range its positions own), written and re-read with agent-scope accesses by the same block.
 // A hot key's own bucket (one key) is cut into windows of kSumWindow positions, one block each; a window leaves an fp64 partial row, draws a
 // ticket, and the window that draws the last one adds the partial rows up (pending-record discipline of the apply: write-through stores, drained
 // before the ticket, agent-scope loads; no fence).
-constexpr uint32_t kSumTileMax = 8, kSumWaveMax = 256;
+constexpr uint32_t kSumTileMax = 8, kSumWaveMax = 64;   // (rows in flight are registers: 4 per tile everywhere — 8 in the wave- and block-level sums cost 84 B more scratch per lane, paid by every wave)
 struct SumLds {
     DedupLds d;
     uint32_t off[kDedupSlots];        // per run: where its sources begin in the sorted list (while the list is filled: the fill cursor)
@@ -551,31 +551,31 @@ __device__ __forceinline__ D4 d4_tiles_sum(D4 v) {   // over the wave's four til
     v.x += __shfl_xor(v.x, 32); v.y += __shfl_xor(v.y, 32); v.z += __shfl_xor(v.z, 32); v.w += __shfl_xor(v.w, 32);
     return v;
 }
-// sources first, first + 1, .. first + 3, then first + step .. of a run of c: four rows in flight, added up in fp64; a lane past the end reads the run's last row
-// again and adds +0.0 (every round trip carries four rows).  load(j, col) = float4 column `col` of the run's source j as four doubles.
-template <class Load>
+// sources first, first + 1, .. first + 3, then first + step .. of a run of c: four rows in flight (held as fp32: 16 registers, not 32), added up in fp64; a lane past the
+// end reads the run's last row again and adds +0.0 (every round trip carries four rows).  load(j, col) = float4 column `col` of the run's source j — f32x4 (a gradient
+// row) or D4 (an fp64 partial row).
+__device__ __forceinline__ void d4_add(D4& s, const f32x4& g, bool on) { s.x += on ? (double)g.x : 0.0; s.y += on ? (double)g.y : 0.0; s.z += on ? (double)g.z : 0.0; s.w += on ? (double)g.w : 0.0; }
+__device__ __forceinline__ void d4_add(D4& s, const D4& g, bool on) { s.x += on ? g.x : 0.0; s.y += on ? g.y : 0.0; s.z += on ? g.z : 0.0; s.w += on ? g.w : 0.0; }
+template <uint32_t NF = 4, class Load>   // NF rows in flight; `first` and `step` in sources (a cooperating tile T of nT takes first = NF * T, step = NF * nT)
 __device__ __forceinline__ D4 run_sum4(uint32_t first, uint32_t step, uint32_t c, uint32_t col, Load load) {
     D4 s{0.0, 0.0, 0.0, 0.0};
     for (uint32_t q0 = first; q0 < c; q0 += step) {
-        D4 g[4];
+        decltype(load(0u, 0u)) g[NF];
 #pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) g[q] = load(min(q0 + q, c - 1), col);
+        for (uint32_t q = 0; q < NF; ++q) g[q] = load(min(q0 + q, c - 1), col);
 #pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
-            const bool on = q0 + q < c;
-            s.x += on ? g[q].x : 0.0; s.y += on ? g[q].y : 0.0; s.z += on ? g[q].z : 0.0; s.w += on ? g[q].w : 0.0;
-        }
+        for (uint32_t q = 0; q < NF; ++q) d4_add(s, g[q], q0 + q < c);
     }
     return s;
 }
 // the whole block sums ONE run of c sources, 16 columns (64 floats) at a time; out(col, total) is called by thread tl < 16 of wave 0 for its column.
 // Block-uniform control flow (barriers inside).
-template <class Load, class Out>
+template <uint32_t NF = 4, class Load, class Out>
 __device__ __forceinline__ void block_run_sum(SumLds& L, uint32_t dim4, uint32_t c, Load load, Out out) {
     const uint32_t t = threadIdx.x, lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6, T = wv * 4 + tile;
     for (uint32_t cg = 0; cg < dim4; cg += 16) {
         const uint32_t col = cg + tl;
-        D4 v = col < dim4 ? run_sum4(4 * T, 16 * kDedupWaves, c, col, load) : D4{0.0, 0.0, 0.0, 0.0};
+        D4 v = col < dim4 ? run_sum4<NF>(NF * T, NF * 4 * kDedupWaves, c, col, load) : D4{0.0, 0.0, 0.0, 0.0};
         v = d4_tiles_sum(v);
         if (tile == 0) { double* d = L.prow(wv) + tl * 4; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
         __syncthreads();
@@ -588,16 +588,15 @@ __device__ __forceinline__ void block_run_sum(SumLds& L, uint32_t dim4, uint32_t
         __syncthreads();
     }
 }
-__device__ __forceinline__ D4 grad_row4(const float4* __restrict__ grads, uint32_t row, uint32_t dim4, uint32_t col) {
-    const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grads) + (uint64_t)row * dim4 + col);   // every gradient row is read exactly once
-    return D4{(double)g.x, (double)g.y, (double)g.z, (double)g.w};
+__device__ __forceinline__ f32x4 grad_row4(const float4* __restrict__ grads, uint32_t row, uint32_t dim4, uint32_t col) {
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grads) + (uint64_t)row * dim4 + col);   // every gradient row is read exactly once
 }
 __device__ __forceinline__ void store_sum4(float4* __restrict__ gsum, uint32_t u, uint32_t dim4, uint32_t col, const D4& v) {
     gsum[(uint64_t)u * dim4 + col] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
 }
 
 template <int DIM4>
-__global__ __launch_bounds__(kDedupThreads) void bkt_dedup_sum_kernel(SumArgs A, BucketScratch bk) {
+__global__ __launch_bounds__(kDedupThreads, 6) void bkt_dedup_sum_kernel(SumArgs A, BucketScratch bk) {   // (6 blocks per CU: 80 registers and a few dwords of scratch; unbounded: 109 and 4 blocks)
     __shared__ SumLds L;
     uint32_t parity, before;
     HotPlan P;
@@ -639,7 +638,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_sum_kernel(SumArgs A,
         __syncthreads();
         if (!L.is_last) return;   // (block-uniform) the window that finishes last adds the bucket's partial rows up
         const uint32_t x0 = x - P.win;
-        block_run_sum(L, dim4, P.n_win, [&](uint32_t j, uint32_t col) {
+        block_run_sum<4>(L, dim4, P.n_win, [&](uint32_t j, uint32_t col) {
             const double* d = A.part + ((uint64_t)(x0 + j) * dim4 + col) * 4;
             auto ld = [](const double* q) { return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
             return D4{ld(d), ld(d + 1), ld(d + 2), ld(d + 3)};
@@ -730,7 +729,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_sum_kernel(SumArgs A,
         for (uint32_t j = wv; j < n_m; j += kDedupWaves) {   // wave-uniform
             const uint32_t idx = n_s + j, sl = L.items()[idx], c = L.d.cnt[sl], first = L.off[sl] - c;
             for (uint32_t col = tl; col < dim4 + tl; col += 16) {   // (every lane runs the same number of turns: the shuffles need whole waves)
-                D4 v = col < dim4 ? run_sum4(4 * tile, 16, c, col, [&](uint32_t q, uint32_t cc) { return grad_row4(A.grads, source(first + q), dim4, cc); }) : D4{0.0, 0.0, 0.0, 0.0};
+                D4 v = col < dim4 ? run_sum4<4>(4 * tile, 16, c, col, [&](uint32_t q, uint32_t cc) { return grad_row4(A.grads, source(first + q), dim4, cc); }) : D4{0.0, 0.0, 0.0, 0.0};
                 v = d4_tiles_sum(v);
                 if (tile == 0 && col < dim4) store_sum4(A.gsum, base + idx, dim4, col, v);
             }
@@ -812,6 +811,9 @@ int bucket_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, 
     A.d.uniq = d_uniq; A.d.inverse = d_inverse;
     A.grads = (const float4*)d_grads; A.gsum = (float4*)d_gsum; A.counts = d_counts; A.dim4 = t->dim4;
     A.src_scratch = t->bs.hidx; A.part = t->bk.sum_part; A.max_part = t->bk.sum_part_rows;
+    // a key's own bucket is summed by a block per 1024 occurrences, all at once; inside a hash bucket a run of 500 occurrences is 4-8 dependent round trips of ONE
+    // block.  So the bar for a bucket of its own is half the apply's here (n / 2048, at least 256): a Zipf(1.05) batch of 1M keys lists ~120 keys
+    A.d.hot_count = n / 2048 > kHotCount ? n / 2048 : kHotCount;
     const uint32_t grid = A.d.nbk + hot_window_blocks(A.d, n, kSumWindow);
     if (t->dim4 == 16) bkt_dedup_sum_kernel<16><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
     else if (t->dim4 == 32) bkt_dedup_sum_kernel<32><<<grid, kDedupThreads, 0, st>>>(A, t->bk);

@@ -52,23 +52,39 @@ __global__ __launch_bounds__(256) void probe_length_kernel(const int64_t* __rest
     const int lane = threadIdx.x & 63, tile = lane >> 4, tl = lane & 15;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    unsigned long long visited = 0;
+    unsigned long long visited = 0, hist = 0;   // hist: four 16-bit counters (a wave takes at most 4096 keys per counter before they are flushed below)
+    uint32_t rounds = 0;
+    auto flush = [&]() {
+        unsigned long long h = hist;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {   // field-wise sums: 64 lanes x 2^10 per field stay below 2^16
+            const unsigned long long o = (unsigned long long)(uint32_t)__shfl_down((int)(uint32_t)h, d) | (unsigned long long)(uint32_t)__shfl_down((int)(uint32_t)(h >> 32), d) << 32;
+            h += o;
+        }
+        if (lane == 0)
+            for (int q = 0; q < 4; ++q) { const unsigned long long c = (h >> (16 * q)) & 0xFFFFull; if (c) atomicAdd(&op->hist[q], c); }
+        hist = 0;
+    };
     for (uint64_t base = wave * 4; base < n; base += n_waves * 4) {
         const uint64_t i = base + tile;
         const int64_t key = i < n ? keys[i] : kEmpty;
         bool pend = i < n && !reserved_key(key);
         uint64_t b = bucket_of(key, nb), steps = 0;
+        uint32_t mine = 0;
         while (__any(pend)) {
             const int64_t k = pend ? tkeys[b * kW + tl] : kEmpty;
             const uint32_t tm = tile_bits(__ballot(pend && k == key), tile);
             const uint32_t te = tile_bits(__ballot(pend && k == kEmpty), tile);
             if (pend) {
-                if (tl == 0) ++visited;
+                if (tl == 0) { ++visited; ++mine; }
                 if (tm || te || ++steps >= nb) pend = false;
                 else b = next_bucket(b, step_of(key, nb), nb);
             }
         }
+        if (mine) hist += 1ull << (16 * (min(mine, 4u) - 1u));
+        if (++rounds == 1000) { flush(); rounds = 0; }   // (wave-uniform)
     }
+    flush();
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) visited += __shfl_down(visited, d);
     if (lane == 0 && visited) atomicAdd(&op->n_export, visited);
@@ -203,6 +219,7 @@ using namespace mee;
 extern "C" {
 
 int mee_reserve(mee_table* t, uint64_t new_capacity, void* stream) {
+    MEE_RANGE("mee_reserve");
     if (!t || new_capacity == 0) return fail(MEE_ERR_INVALID_ARG, "mee_reserve: null table or zero capacity");
     if (t->prepared_n) {
         if (!t->prepared_by_forward) return fail(MEE_ERR_INVALID_ARG, "mee_reserve: a prepared apply is pending on this table (finish it with mee_apply_* or mee_apply_discard)");
@@ -253,6 +270,7 @@ int mee_reserve(mee_table* t, uint64_t new_capacity, void* stream) {
 
 int mee_hits_scan(mee_table* t, uint32_t min_hits, uint32_t max_hits, int reset, int64_t* d_keys_out, size_t cap, size_t* n_out,
                   void* stream) {
+    MEE_RANGE("mee_hits_scan");
     if (!t || !n_out || (cap && !d_keys_out)) return fail(MEE_ERR_INVALID_ARG, "mee_hits_scan: null argument");
     if (!t->hits) return fail(MEE_ERR_UNSUPPORTED, "mee_hits_scan: table was created without MEE_FLAG_TRACK_HITS");
     DeviceGuard g(t->device);
@@ -268,12 +286,14 @@ int mee_hits_scan(mee_table* t, uint32_t min_hits, uint32_t max_hits, int reset,
 
 int mee_export(const mee_table* t, int64_t* d_keys_out, float* d_values_out, float* d_state1_out, float* d_state2_out,
                size_t cap, size_t* n_out, void* stream) {
+    MEE_RANGE("mee_export");
     if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_export: null argument");
     return mee_export_range(t, 0, t->capacity, d_keys_out, d_values_out, d_state1_out, d_state2_out, cap, n_out, stream);
 }
 
 int mee_export_range(const mee_table* t, uint64_t slot_begin, uint64_t slot_end, int64_t* d_keys_out, float* d_values_out,
                      float* d_state1_out, float* d_state2_out, size_t cap, size_t* n_out, void* stream) {
+    MEE_RANGE("mee_export_range");
     if (!t || !n_out) return fail(MEE_ERR_INVALID_ARG, "mee_export: null argument");
     if (slot_end > t->capacity) slot_end = t->capacity;
     if (slot_begin > slot_end) return fail(MEE_ERR_INVALID_ARG, "mee_export_range: slot_begin %llu > slot_end %llu", (unsigned long long)slot_begin, (unsigned long long)slot_end);
@@ -297,6 +317,7 @@ static int read_counters(const mee_table* t, void* stream) {
     return MEE_OK;
 }
 int mee_size(const mee_table* t, size_t* n_out, void* stream) {
+    MEE_RANGE("mee_size");
     if (!t || !n_out) return fail(MEE_ERR_INVALID_ARG, "mee_size: null argument");
     DeviceGuard g(t->device);
     hipStream_t st = as_stream(stream);
@@ -319,6 +340,7 @@ int mee_table_plane(const mee_table* t, uint32_t plane, void** ptr_out, uint64_t
 }
 
 int mee_probe_length(const mee_table* t, const int64_t* d_keys, size_t n, uint64_t* buckets_visited_out, void* stream) {
+    MEE_RANGE("mee_probe_length");
     if (!t || !buckets_visited_out || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_probe_length: null argument");
     *buckets_visited_out = 0;
     if (n == 0) return MEE_OK;
@@ -332,13 +354,31 @@ int mee_probe_length(const mee_table* t, const int64_t* d_keys, size_t n, uint64
     *buckets_visited_out = (uint64_t)t->h_op->n_export;
     return MEE_OK;
 }
+int mee_probe_histogram(const mee_table* t, const int64_t* d_keys, size_t n, uint64_t* hist_out /* [4] */, void* stream) {
+    MEE_RANGE("mee_probe_histogram");
+    if (!t || !hist_out || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_probe_histogram: null argument");
+    for (int q = 0; q < 4; ++q) hist_out[q] = 0;
+    if (n == 0) return MEE_OK;
+    DeviceGuard g(t->device);
+    hipStream_t st = as_stream(stream);
+    zero_words(&t->op->n_export, sizeof(unsigned long long), st);
+    zero_words(t->op->hist, sizeof t->op->hist, st);
+    probe_length_kernel<<<grid_for(n, 16, 4096), 256, 0, st>>>(t->keys, t->nb, d_keys, n, t->op);
+    MEE_HIP(hipGetLastError());
+    MEE_HIP(hipMemcpyAsync(t->h_op, t->op, sizeof(OpCounters), hipMemcpyDeviceToHost, st));
+    MEE_HIP(hipStreamSynchronize(st));
+    for (int q = 0; q < 4; ++q) hist_out[q] = (uint64_t)t->h_op->hist[q];
+    return MEE_OK;
+}
 int mee_status(const mee_table* t, uint32_t* bits_out, void* stream) {
+    MEE_RANGE("mee_status");
     if (!t || !bits_out) return fail(MEE_ERR_INVALID_ARG, "mee_status: null argument");
     if (int rc = read_counters(t, stream)) return rc;
     *bits_out = t->h_ctr->status;
     return MEE_OK;
 }
 int mee_clear_status(mee_table* t, void* stream) {
+    MEE_RANGE("mee_clear_status");
     if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_clear_status: null table");
     DeviceGuard g(t->device);
     zero_words(&t->ctr->status, sizeof(uint32_t), as_stream(stream));

@@ -473,6 +473,33 @@ __global__ __launch_bounds__(256) void find_pooled_kernel(const int64_t* __restr
 using namespace mee;
 
 namespace mee {
+// The library's own store policy for a dense output (nobody gave a hint).  One call cannot tell whether its output will be re-read from cache; the last few calls
+// can: a ring of the latest calls' output buffers (base address, bytes).  The same buffer as the call before: the caller reuses one result buffer — cached stores
+// while it fits (<= 128 MB: the Infinity Cache absorbs it).  Another buffer, and the distinct buffers of the last eight calls add up to more than 64 MB: the results
+// rotate (a server's independent requests, a trainer's per-step activations), every one of them has to reach HBM and nothing re-reads it from cache — streaming
+// stores (measured into 6 x 64 MB buffers: 38.6 -> 33.2 us per 256K-key find; two alternating 64 MB buffers: 35.4 cached).  mee_find_ex / "find_nt" stay authoritative.
+static bool outputs_rotate(const mee_table* t, const void* d_out, uint64_t bytes) {
+    mee_table* m = const_cast<mee_table*>(t);   // (policy state only; see meepo_table_int.h)
+    const uint64_t p = (uint64_t)(uintptr_t)d_out;
+    const uint32_t head = __atomic_load_n(&m->out_ring_head, __ATOMIC_RELAXED);
+    if (__atomic_load_n(&m->out_ring_ptr[(head + 7u) & 7u], __ATOMIC_RELAXED) == p) return false;
+    const uint32_t slot = __atomic_fetch_add(&m->out_ring_head, 1u, __ATOMIC_RELAXED) & 7u;
+    __atomic_store_n(&m->out_ring_ptr[slot], p, __ATOMIC_RELAXED);
+    __atomic_store_n(&m->out_ring_bytes[slot], bytes, __ATOMIC_RELAXED);
+    uint64_t seen[8], total = 0;
+    int distinct = 0;
+    for (int i = 0; i < 8; ++i) {
+        const uint64_t q = __atomic_load_n(&m->out_ring_ptr[i], __ATOMIC_RELAXED);
+        if (!q) continue;
+        bool dup = false;
+        for (int j = 0; j < distinct; ++j) dup = dup || seen[j] == q;
+        if (dup) continue;
+        seen[distinct++] = q;
+        total += __atomic_load_n(&m->out_ring_bytes[i], __ATOMIC_RELAXED);
+    }
+    return distinct >= 2 && total > (64ull << 20);
+}
+
 // every dense lookup of one plane (declared with its defaults in meepo_table_int.h: find_or_insert's first pass calls it too)
 int find_plane(const mee_table* t, const float* plane, float miss_value, const int64_t* d_keys, size_t n, float* d_out,
                uint8_t* d_found, void* stream, bool missing_only, bool counted, bool rows_only,
@@ -489,7 +516,8 @@ int find_plane(const mee_table* t, const float* plane, float miss_value, const i
 #define FIND1(D4, RR, NT) do { if (unordered) hipExtLaunchKernelGGL((find_kernel<D4, RR, NT>), dim3(grid), dim3(256), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch, \
                                         (const int64_t*)t->keys, (const f32x4*)plane, t->nb, d_keys, (uint64_t)n, (f32x4*)d_out, d_found, miss_value, t->dim4, (uint32_t*)nullptr, (int64_t*)nullptr, (int64_t)0); \
                                else find_kernel<D4, RR, NT><<<grid, fblock, 0, st>>>(t->keys, (const f32x4*)plane, t->nb, d_keys, n, (f32x4*)d_out, d_found, miss_value, t->dim4, nullptr); } while (0)
-    const int nt = nt_call >= 0 ? nt_call : t->find_nt >= 0 ? (t->find_nt & 7) : ((uint64_t)n * t->dim * 4 <= (128ull << 20) ? 4 : 0);
+    const int nt = nt_call >= 0 ? nt_call : t->find_nt >= 0 ? (t->find_nt & 7)
+                 : ((uint64_t)n * t->dim * 4 <= (128ull << 20) && !outputs_rotate(t, d_out, (uint64_t)n * t->dim * 4) ? 4 : 0);
 #define FIND(D4, RR) do { switch (nt) { case 0: FIND1(D4, RR, 0); break; case 1: FIND1(D4, RR, 1); break; case 2: FIND1(D4, RR, 2); break; case 3: FIND1(D4, RR, 3); break; case 4: FIND1(D4, RR, 4); break; case 5: FIND1(D4, RR, 5); break; case 6: FIND1(D4, RR, 6); break; default: FIND1(D4, RR, 7); } } while (0)
     if (skip_padding) {   // owner pass of a padded sharded exchange: EMPTY positions get neither a row nor a found byte (nobody reads them)
         const bool cached = nt & 4;
@@ -537,11 +565,13 @@ int find_plane(const mee_table* t, const float* plane, float miss_value, const i
 extern "C" {
 
 int mee_find(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_find");
     if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find: null argument");
     return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream);
 }
 
 int mee_find_ex(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, uint32_t flags, void* stream) {
+    MEE_RANGE("mee_find_ex");
     if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_ex: null argument");
     if (flags & ~(uint32_t)(MEE_FIND_STREAM_STORES | MEE_FIND_CACHED_STORES | MEE_FIND_STREAM_ROWS | MEE_FIND_STREAM_BUCKETS))
         return fail(MEE_ERR_INVALID_ARG, "mee_find_ex: unknown flag bits 0x%x", flags);
@@ -549,7 +579,8 @@ int mee_find_ex(const mee_table* t, const int64_t* d_keys, size_t n, float* d_ou
         return fail(MEE_ERR_INVALID_ARG, "mee_find_ex: MEE_FIND_STREAM_STORES and MEE_FIND_CACHED_STORES exclude each other");
     if (flags == MEE_FIND_DEFAULT) return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream);
     // the kernel's policy bits: 1 = streaming row loads, 2 = streaming bucket loads, 4 = cached stores of the dense output
-    const bool cached_out = (flags & MEE_FIND_CACHED_STORES) || (!(flags & MEE_FIND_STREAM_STORES) && (uint64_t)n * t->dim * 4 <= (128ull << 20));
+    const bool cached_out = (flags & MEE_FIND_CACHED_STORES) ||
+                            (!(flags & MEE_FIND_STREAM_STORES) && (uint64_t)n * t->dim * 4 <= (128ull << 20) && !outputs_rotate(t, d_out, (uint64_t)n * t->dim * 4));
     const int nt = (flags & MEE_FIND_STREAM_ROWS ? 1 : 0) | (flags & MEE_FIND_STREAM_BUCKETS ? 2 : 0) | (cached_out ? 4 : 0);
     return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, false, false, false, nullptr, false, false, nt);
 }
@@ -566,11 +597,13 @@ int find_skip_padding(const mee_table* t, const int64_t* d_keys, size_t n, float
 extern "C" {
 
 int mee_find_located(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
+    MEE_RANGE("mee_find_located");
     if (!t || (n && (!d_keys || !d_out || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_located: null argument");
     return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, false, false, false, d_slots_out);
 }
 
 int mee_find_many(const mee_table* t, const mee_find_request* reqs, uint32_t count, void* stream) {
+    MEE_RANGE("mee_find_many");
     if (!t || !reqs) return fail(MEE_ERR_INVALID_ARG, "mee_find_many: null argument");
     if (count == 0) return MEE_OK;
     if (count > (uint32_t)kMaxFindRequests) return fail(MEE_ERR_INVALID_ARG, "mee_find_many: %u requests (at most %d per call)", count, kMaxFindRequests);
@@ -602,16 +635,19 @@ int mee_find_many(const mee_table* t, const mee_find_request* reqs, uint32_t cou
 }
 
 int mee_find_unordered(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_find_unordered");
     if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_unordered: null argument");
     return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, false, false, false, nullptr, /*unordered=*/true);
 }
 
 int mee_find_missing(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_find_missing");
     if (!t || (n && (!d_keys || !d_out || !d_found))) return fail(MEE_ERR_INVALID_ARG, "mee_find_missing: null argument");
     return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, true);
 }
 
 int mee_find_counted(const mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int missing_only, void* stream) {
+    MEE_RANGE("mee_find_counted");
     if (!t || (n && (!d_keys || !d_out || !d_found))) return fail(MEE_ERR_INVALID_ARG, "mee_find_counted: null argument");
     if (!t->hits) return fail(MEE_ERR_UNSUPPORTED, "mee_find_counted: table was created without MEE_FLAG_TRACK_HITS");
     return find_plane(t, t->values, t->default_value, d_keys, n, d_out, d_found, stream, missing_only != 0, true);
@@ -619,6 +655,7 @@ int mee_find_counted(const mee_table* t, const int64_t* d_keys, size_t n, float*
 
 int mee_find_pooled(const mee_table* t, const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t n_bags, float* d_out,
                     uint8_t* d_found, int mode, void* stream) {
+    MEE_RANGE("mee_find_pooled");
     if (!t || (n_bags && (!d_bag_offsets || !d_out)) || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_find_pooled: null argument");
     if (mode != MEE_POOL_SUM && mode != MEE_POOL_MEAN) return fail(MEE_ERR_INVALID_ARG, "mee_find_pooled: mode must be MEE_POOL_SUM or MEE_POOL_MEAN");
     if (n_bags == 0) return MEE_OK;
@@ -635,6 +672,7 @@ int mee_find_pooled(const mee_table* t, const int64_t* d_keys, size_t n, const u
 }
 
 int mee_find_plane(const mee_table* t, uint32_t plane, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_find_plane");
     if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_plane: null argument");
     const float* p = plane_of(t, plane);
     if (!p) return fail(MEE_ERR_UNSUPPORTED, "mee_find_plane: plane %u does not exist (optimizer=%u)", plane, t->optimizer);
@@ -644,6 +682,7 @@ int mee_find_plane(const mee_table* t, uint32_t plane, const int64_t* d_keys, si
 // ---- the embedding-bag collection: pooled lookups of a whole group in one launch, and their backward -----------------------
 int mee_group_find_pooled(mee_group* g, const int64_t* d_keys, size_t n, const uint64_t* d_bag_offsets, size_t bags_per_table,
                           float* d_out, uint8_t* d_found, int64_t* d_located_out, int mode, void* stream) {
+    MEE_RANGE("mee_group_find_pooled");
     if (!g || (bags_per_table && (!d_bag_offsets || !d_out)) || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_group_find_pooled: null argument");
     if (mode != MEE_POOL_SUM && mode != MEE_POOL_MEAN) return fail(MEE_ERR_INVALID_ARG, "mee_group_find_pooled: mode must be MEE_POOL_SUM or MEE_POOL_MEAN");
     if (bags_per_table == 0) return MEE_OK;
@@ -663,6 +702,7 @@ int mee_group_find_pooled(mee_group* g, const int64_t* d_keys, size_t n, const u
 // The training forward: mee_find_located whose launch also carries mee_apply_prepare for the SAME keys (the partition half of the bucketed
 // apply, run by the launch's first blocks beside the row gather).  (Table without optimizer: plain mee_find_located.)
 int mee_find_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
+    MEE_RANGE("mee_find_located_prepare");
     if (!t || (n && (!d_keys || !d_out || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_located_prepare: null argument");
     if (t->prepared_n) return fail(MEE_ERR_INVALID_ARG, "mee_find_located_prepare: a prepared apply is already pending");
     if (n == 0) return MEE_OK;

@@ -224,6 +224,7 @@ int group_locate(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets,
 extern "C" {
 
 int mee_group_create(mee_table* const* tables, uint32_t n_tables, uint64_t max_apply_batch, mee_group** out) {
+    MEE_RANGE("mee_group_create");
     if (!tables || !out || n_tables == 0 || n_tables > kMaxGroupTables)
         return fail(MEE_ERR_INVALID_ARG, "mee_group_create: need 1..%u tables", kMaxGroupTables);
     *out = nullptr;
@@ -271,6 +272,7 @@ int mee_group_set_tuning(mee_group* g, const char* name, int value) {
 }
 
 int mee_group_destroy(mee_group* g) {
+    MEE_RANGE("mee_group_destroy");
     if (!g) return MEE_OK;
     DeviceGuard guard(g->device);
     (void)hipDeviceSynchronize();
@@ -308,6 +310,7 @@ extern "C" {
 
 int mee_find_grouped(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found,
                      void* stream) {
+    MEE_RANGE("mee_find_grouped");
     if (!g || !d_offsets || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_grouped: null argument");
     if (n == 0) return MEE_OK;
     if (int rc = group_refresh(g, stream)) return rc;
@@ -317,6 +320,7 @@ int mee_find_grouped(mee_group* g, const int64_t* d_keys, const uint64_t* d_offs
 
 int mee_group_find_or_insert(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, size_t n, float* d_out, uint8_t* d_found,
                              void* stream) {
+    MEE_RANGE("mee_group_find_or_insert");
     if (!g || !d_offsets || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_group_find_or_insert: null argument");
     if (n == 0) return MEE_OK;
     if (!d_found) {

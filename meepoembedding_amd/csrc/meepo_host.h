@@ -26,6 +26,23 @@ inline int fail(int code, const char* fmt, ...) {
                                "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// roctx ranges around every operator of the C-ABI (tracing), so that `rocprofv3 --marker-trace --kernel-trace` groups the kernels by the
+// operator that launched them.  The marker library (librocprofiler-sdk-roctx.so.1, part of ROCm) is bound with dlopen at the first operator call; when
+// it is not there — or MEE_ROCTX=0 — a range is one predictable branch.  Without a profiler attached a push / pop pair costs ~0.1 us of host time.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+const Roctx& roctx_api();   // (meepo_table.hip)
+struct OpRange {
+    bool on;
+    explicit OpRange(const char* name) { const Roctx& r = roctx_api(); on = r.push != nullptr; if (on) (void)r.push(name); }
+    ~OpRange() { if (on) (void)roctx_api().pop(); }
+    OpRange(const OpRange&) = delete;
+    OpRange& operator=(const OpRange&) = delete;
+};
+#define MEE_RANGE(name) ::mee::OpRange mee_range_(name)
+
 // Makes `device` current for the scope of one API call and restores the caller's device afterwards.
 struct DeviceGuard {
     int prev = -1;

@@ -338,6 +338,7 @@ extern "C" {
 
 int mee_hash_batch(const int64_t* d_keys, size_t n, uint64_t n_buckets, uint32_t n_shards, uint64_t* d_mix_out,
                    uint64_t* d_bucket_out, uint32_t* d_owner_out, void* stream) {
+    MEE_RANGE("mee_hash_batch");
     if (n && !d_keys) return fail(MEE_ERR_INVALID_ARG, "mee_hash_batch: null keys");
     if (n == 0) return MEE_OK;
     hash_batch_kernel<<<grid_for(n, 256, 1u << 14), 256, 0, (hipStream_t)stream>>>(d_keys, n, n_buckets, n_shards, d_mix_out,
@@ -347,6 +348,7 @@ int mee_hash_batch(const int64_t* d_keys, size_t n, uint64_t n_buckets, uint32_t
 }
 
 int mee_router_destroy(mee_router* r) {
+    MEE_RANGE("mee_router_destroy");
     if (!r) return MEE_OK;
     DeviceGuard g(r->device);
     if (r->blockcnt) (void)hipFree(r->blockcnt);
@@ -356,6 +358,7 @@ int mee_router_destroy(mee_router* r) {
 }
 
 int mee_router_create(int32_t device, uint64_t max_batch, uint32_t n_shards, mee_router** out) {
+    MEE_RANGE("mee_router_create");
     if (!out) return fail(MEE_ERR_INVALID_ARG, "mee_router_create: null out");
     *out = nullptr;
     if (n_shards == 0 || n_shards > (uint32_t)kMaxShards || max_batch == 0 || max_batch > (1ull << 30))
@@ -400,15 +403,18 @@ static int partition_common(mee_router* r, const int64_t* d_keys, size_t n, int6
 }
 int mee_partition(mee_router* r, const int64_t* d_keys, size_t n, int64_t* d_send_keys, uint64_t* d_counts, int64_t* d_perm,
                   void* stream) {
+    MEE_RANGE("mee_partition");
     return partition_common(r, d_keys, n, d_send_keys, d_counts, d_perm, stream, false, "mee_partition");
 }
 int mee_partition_padded(mee_router* r, const int64_t* d_keys, size_t n, int64_t* d_send_keys, uint64_t* d_counts, int64_t* d_perm,
                          void* stream) {
+    MEE_RANGE("mee_partition_padded");
     return partition_common(r, d_keys, n, d_send_keys, d_counts, d_perm, stream, true, "mee_partition_padded");
 }
 
 // ---- peer-to-peer exchange: lifetime and IPC ----------------------------------------------------------------------
 int mee_p2p_destroy(mee_p2p* c) {
+    MEE_RANGE("mee_p2p_destroy");
     if (!c) return MEE_OK;
     DeviceGuard g(c->device);
     (void)hipDeviceSynchronize();
@@ -424,6 +430,7 @@ int mee_p2p_destroy(mee_p2p* c) {
 
 int mee_p2p_create(int32_t device, uint32_t n_shards, uint32_t rank, uint64_t slots_per_peer, uint64_t max_batch, uint32_t dim,
                    int with_payload, mee_p2p** out) {
+    MEE_RANGE("mee_p2p_create");
     if (!out) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_create: null out");
     *out = nullptr;
     if (n_shards == 0 || n_shards > (uint32_t)kMaxShards || rank >= n_shards || slots_per_peer == 0 || max_batch == 0 ||
@@ -469,6 +476,7 @@ static void* p2p_local(const mee_p2p* c, int b) {
 }
 
 int mee_p2p_export(mee_p2p* c, void* handles) {
+    MEE_RANGE("mee_p2p_export");
     if (!c || !handles) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_export: null argument");
     static_assert(sizeof(hipIpcMemHandle_t) == MEE_IPC_HANDLE_BYTES, "IPC handle size");
     DeviceGuard g(c->device);
@@ -483,6 +491,7 @@ int mee_p2p_export(mee_p2p* c, void* handles) {
 }
 
 int mee_p2p_connect(mee_p2p* c, const void* all_handles) {
+    MEE_RANGE("mee_p2p_connect");
     if (!c || !all_handles) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_connect: null argument");
     if (c->connected) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_connect: already connected");
     DeviceGuard g(c->device);
@@ -521,6 +530,7 @@ static P2PPeers p2p_peers(const mee_p2p* c) {
 
 int mee_p2p_push(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts, size_t n,
                  void* stream) {
+    MEE_RANGE("mee_p2p_push");
     if (!c || !r || !d_counts || (n && (!d_send_keys || !d_perm))) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push: null argument");
     if (!c->connected) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push: not connected");
     if (r->n_shards != c->n_shards || n > c->max_batch) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push: router/batch mismatch");
@@ -533,6 +543,7 @@ int mee_p2p_push(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const in
 
 int mee_p2p_push_rows(mee_p2p* c, mee_router* r, const int64_t* d_send_keys, const int64_t* d_perm, const uint64_t* d_counts,
                       const float* d_rows, size_t n, void* stream) {
+    MEE_RANGE("mee_p2p_push_rows");
     if (!c || !r || !d_counts || (n && (!d_send_keys || !d_perm))) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push_rows: null argument");
     if (!c->connected || !c->inbox_rows) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push_rows: context not connected or created without payload");
     if (r->n_shards != c->n_shards || n > c->max_batch) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_push_rows: router/batch mismatch");
@@ -557,6 +568,7 @@ int mee_p2p_inbox(mee_p2p* c, int64_t** d_keys, float** d_rows, uint64_t* n_slot
 }
 
 int mee_p2p_find(mee_p2p* c, const mee_table* t, void* stream) {
+    MEE_RANGE("mee_p2p_find");
     if (!c || !t) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_find: null argument");
     if (!c->connected) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_find: not connected");
     const TableView v = table_view(t);
@@ -573,6 +585,7 @@ int mee_p2p_find(mee_p2p* c, const mee_table* t, void* stream) {
 }
 
 int mee_p2p_barrier(mee_p2p* c, void* stream) {
+    MEE_RANGE("mee_p2p_barrier");
     if (!c) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_barrier: null argument");
     if (!c->connected) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_barrier: not connected");
     DeviceGuard g(c->device);
@@ -583,6 +596,7 @@ int mee_p2p_barrier(mee_p2p* c, void* stream) {
 }
 
 int mee_p2p_status(mee_p2p* c, uint32_t* bits_out, void* stream) {
+    MEE_RANGE("mee_p2p_status");
     if (!c || !bits_out) return fail(MEE_ERR_INVALID_ARG, "mee_p2p_status: null argument");
     DeviceGuard g(c->device);
     MEE_HIP(hipMemcpyAsync(bits_out, c->status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -591,9 +605,11 @@ int mee_p2p_status(mee_p2p* c, uint32_t* bits_out, void* stream) {
 }
 
 int mee_scatter_rows(const void* d_rows, const int64_t* d_perm, size_t n, size_t row_bytes, void* d_out, void* stream) {
+    MEE_RANGE("mee_scatter_rows");
     return permute_rows<true>(d_rows, d_perm, n, row_bytes, d_out, stream, "mee_scatter_rows");
 }
 int mee_gather_rows(const void* d_rows, const int64_t* d_perm, size_t n, size_t row_bytes, void* d_out, void* stream) {
+    MEE_RANGE("mee_gather_rows");
     return permute_rows<false>(d_rows, d_perm, n, row_bytes, d_out, stream, "mee_gather_rows");
 }
 

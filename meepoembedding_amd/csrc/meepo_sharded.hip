@@ -561,6 +561,7 @@ static int chunked_apply(mee_sharded* c, uint64_t rt, const ApplySpec& a, void* 
 extern "C" {
 
 int mee_comm_unique_id(void* id_out) {
+    MEE_RANGE("mee_comm_unique_id");
     if (!id_out) return fail(MEE_ERR_INVALID_ARG, "mee_comm_unique_id: null argument");
     static_assert(sizeof(ncclUniqueId) == MEE_COMM_ID_BYTES, "ncclUniqueId size");
     RcclApi* api = rccl_api();
@@ -572,6 +573,7 @@ int mee_comm_unique_id(void* id_out) {
 }
 
 int mee_comm_create(const void* id, uint32_t n_ranks, uint32_t rank, int32_t device, void** comm_out) {
+    MEE_RANGE("mee_comm_create");
     if (!id || !comm_out || n_ranks == 0 || rank >= n_ranks) return fail(MEE_ERR_INVALID_ARG, "mee_comm_create: bad argument");
     *comm_out = nullptr;
     RcclApi* api = rccl_api();
@@ -588,6 +590,7 @@ int mee_comm_create(const void* id, uint32_t n_ranks, uint32_t rank, int32_t dev
 }
 
 int mee_comm_destroy(void* comm) {
+    MEE_RANGE("mee_comm_destroy");
     if (!comm) return MEE_OK;
     {   // ncclCommAbort has freed an aborted communicator already: forget it, there is nothing left to destroy
         std::lock_guard<std::mutex> lk(g_abort_mu);
@@ -602,6 +605,7 @@ int mee_comm_destroy(void* comm) {
 int mee_comm_aborted(void* comm) { return comm && comm_is_aborted(comm) ? 1 : 0; }
 
 int mee_sharded_destroy(mee_sharded* c) {
+    MEE_RANGE("mee_sharded_destroy");
     if (!c) return MEE_OK;
     DeviceGuard g(c->device);
     (void)hipDeviceSynchronize();
@@ -611,6 +615,7 @@ int mee_sharded_destroy(mee_sharded* c) {
 }
 
 int mee_sharded_create_ex(mee_table* local, void* nccl_comm, const mee_sharded_options* opt, mee_sharded** out) {
+    MEE_RANGE("mee_sharded_create_ex");
     if (!out) return fail(MEE_ERR_INVALID_ARG, "mee_sharded_create_ex: null out");
     *out = nullptr;
     if (!opt || opt->struct_size != sizeof(mee_sharded_options))
@@ -706,6 +711,7 @@ int mee_sharded_create_ex(mee_table* local, void* nccl_comm, const mee_sharded_o
 }
 
 int mee_sharded_create(mee_table* local, void* nccl_comm, uint64_t max_batch, double pad_slack, mee_sharded** out) {
+    MEE_RANGE("mee_sharded_create");
     mee_sharded_options o;
     memset(&o, 0, sizeof o);
     o.struct_size = sizeof o; o.max_batch = max_batch; o.pad_slack = pad_slack;
@@ -738,13 +744,16 @@ static int sharded_lookup(mee_sharded* c, const int64_t* d_keys, size_t n, float
 }
 
 int mee_sharded_find(mee_sharded* c, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_sharded_find");
     return sharded_lookup(c, d_keys, n, d_out, d_found, stream, false, "mee_sharded_find");
 }
 int mee_sharded_find_or_insert(mee_sharded* c, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_sharded_find_or_insert");
     return sharded_lookup(c, d_keys, n, d_out, d_found, stream, true, "mee_sharded_find_or_insert");
 }
 
 int mee_sharded_insert(mee_sharded* c, const int64_t* d_keys, const float* d_values, size_t n, void* stream) {
+    MEE_RANGE("mee_sharded_insert");
     if (int rc = check_call(c, n, "mee_sharded_insert")) return rc;
     if (n && (!d_keys || !d_values)) return fail(MEE_ERR_INVALID_ARG, "mee_sharded_insert: null argument");
     DeviceGuard g(c->device);
@@ -756,6 +765,7 @@ int mee_sharded_insert(mee_sharded* c, const int64_t* d_keys, const float* d_val
 }
 
 int mee_sharded_assign(mee_sharded* c, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_sharded_assign");
     if (int rc = check_call(c, n, "mee_sharded_assign")) return rc;
     if (n && (!d_keys || !d_values)) return fail(MEE_ERR_INVALID_ARG, "mee_sharded_assign: null argument");
     DeviceGuard g(c->device);
@@ -768,6 +778,7 @@ int mee_sharded_assign(mee_sharded* c, const int64_t* d_keys, const float* d_val
 }
 
 int mee_sharded_remove(mee_sharded* c, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_sharded_remove");
     if (int rc = check_call(c, n, "mee_sharded_remove")) return rc;
     if (n && !d_keys) return fail(MEE_ERR_INVALID_ARG, "mee_sharded_remove: null argument");
     DeviceGuard g(c->device);
@@ -805,17 +816,20 @@ static int sharded_apply(mee_sharded* c, const int64_t* d_keys, const float* d_g
     return chunked_apply(c, rt, a, stream, name);
 }
 int mee_sharded_apply_adagrad(mee_sharded* c, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps, void* stream) {
+    MEE_RANGE("mee_sharded_apply_adagrad");
     ApplySpec a{false, lr, 0.f, 0.f, eps, 0};
     return sharded_apply(c, d_keys, d_grads, n, stream, "mee_sharded_apply_adagrad", a);
 }
 int mee_sharded_apply_adam(mee_sharded* c, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float beta1, float beta2, float eps,
                            uint64_t step, void* stream) {
+    MEE_RANGE("mee_sharded_apply_adam");
     if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_sharded_apply_adam: step must be >= 1");
     ApplySpec a{true, lr, beta1, beta2, eps, step};
     return sharded_apply(c, d_keys, d_grads, n, stream, "mee_sharded_apply_adam", a);
 }
 
 int mee_sharded_size(mee_sharded* c, size_t* n_out, void* stream) {
+    MEE_RANGE("mee_sharded_size");
     if (!c || !n_out) return fail(MEE_ERR_INVALID_ARG, "mee_sharded_size: null argument");
     if (c->dead || comm_is_aborted((void*)c->comm)) return fail(MEE_ERR_RCCL, "mee_sharded_size: an earlier RCCL error aborted this context's communicator");
     RcclApi* api = rccl_api();
@@ -839,6 +853,7 @@ int mee_sharded_size(mee_sharded* c, size_t* n_out, void* stream) {
 }
 
 int mee_sharded_status(mee_sharded* c, uint32_t* bits_out, void* stream) {
+    MEE_RANGE("mee_sharded_status");
     if (!c || !bits_out) return fail(MEE_ERR_INVALID_ARG, "mee_sharded_status: null argument");
     DeviceGuard g(c->device);
     MEE_HIP(hipMemcpyAsync(bits_out, c->status, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -847,6 +862,7 @@ int mee_sharded_status(mee_sharded* c, uint32_t* bits_out, void* stream) {
 }
 
 int mee_sharded_clear_status(mee_sharded* c, void* stream) {
+    MEE_RANGE("mee_sharded_clear_status");
     if (!c) return fail(MEE_ERR_INVALID_ARG, "mee_sharded_clear_status: null context");
     DeviceGuard g(c->device);
     MEE_HIP(hipMemsetAsync(c->status, 0, 4, (hipStream_t)stream));

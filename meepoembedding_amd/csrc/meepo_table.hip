@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +30,22 @@ namespace mee {
 char* last_error_buf() {
     static thread_local char buf[512] = {0};
     return buf;
+}
+
+const Roctx& roctx_api() {
+    static const Roctx api = [] {
+        Roctx r;
+        const char* env = getenv("MEE_ROCTX");
+        if (env && env[0] == '0') return r;
+        void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return r;
+        *(void**)(&r.push) = dlsym(h, "roctxRangePushA");
+        *(void**)(&r.pop) = dlsym(h, "roctxRangePop");
+        if (!r.push || !r.pop) r.push = nullptr, r.pop = nullptr;
+        return r;
+    }();
+    return api;
 }
 
 }  // namespace mee
@@ -456,6 +474,7 @@ int mee_abi_version(void) { return MEE_ABI_VERSION; }
 const char* mee_last_error(void) { return last_error_buf(); }
 
 int mee_table_destroy(mee_table* t) {
+    MEE_RANGE("mee_table_destroy");
     if (!t) return MEE_OK;
     DeviceGuard g(t->device);
     (void)hipDeviceSynchronize();
@@ -472,6 +491,7 @@ int mee_table_destroy(mee_table* t) {
 }
 
 int mee_table_create(const mee_config* cfg, mee_table** out) {
+    MEE_RANGE("mee_table_create");
     if (!cfg || !out) return fail(MEE_ERR_INVALID_ARG, "mee_table_create: null argument");
     *out = nullptr;
     if (cfg->struct_size != sizeof(mee_config))
@@ -603,13 +623,14 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     else if (!strcmp(name, "find_nt")) t->find_nt = value;
     else if (!strcmp(name, "apply_bucket_max")) t->bk.bucket_max = value > 0 && value <= 352 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_skew_adapt")) t->bk.skew_adapt = value != 0;
-    else if (!strcmp(name, "apply_xcd_split")) t->bk.xcd_split = value > 0 && value < 1024 ? (uint32_t)value : 0u;
+    else if (!strcmp(name, "apply_xcd_split")) t->bk.xcd_split = value < 0 ? xcd_split_for_device(t->device) : value < 1024 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_kernel")) t->bk.kernel_choice = value < 0 ? -1 : value != 0;
     else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);
     return MEE_OK;
 }
 
 int mee_clear(mee_table* t, void* stream) {
+    MEE_RANGE("mee_clear");
     if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_clear: null table");
     DeviceGuard g(t->device);
     ++t->handle_epoch;
@@ -648,17 +669,21 @@ static int upsert_common(mee_table* t, float* plane, const int64_t* d_keys, cons
 }
 
 int mee_insert(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, void* stream) {
+    MEE_RANGE("mee_insert");
     return upsert_common(t, t ? t->values : nullptr, d_keys, d_values, n, nullptr, stream, true, "mee_insert");
 }
 int mee_insert_missing(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, const uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_insert_missing");
     if (!d_found && n) return fail(MEE_ERR_INVALID_ARG, "mee_insert_missing: null found mask");
     return upsert_common(t, t ? t->values : nullptr, d_keys, d_values, n, nullptr, stream, true, "mee_insert_missing", d_found);
 }
 int mee_assign(mee_table* t, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_assign");
     return upsert_common(t, t ? t->values : nullptr, d_keys, d_values, n, d_found, stream, false, "mee_assign");
 }
 int mee_assign_plane(mee_table* t, uint32_t plane, const int64_t* d_keys, const float* d_values, size_t n, uint8_t* d_found,
                      void* stream) {
+    MEE_RANGE("mee_assign_plane");
     if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_assign_plane: null table");
     float* p = const_cast<float*>(plane_of(t, plane));
     if (!p) return fail(MEE_ERR_UNSUPPORTED, "mee_assign_plane: plane %u does not exist (optimizer=%u)", plane, t->optimizer);
@@ -666,6 +691,7 @@ int mee_assign_plane(mee_table* t, uint32_t plane, const int64_t* d_keys, const 
 }
 
 int mee_remove(mee_table* t, const int64_t* d_keys, size_t n, uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_remove");
     if (!t || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_remove: null argument");
     if (int rc = check_batch(t, n, "mee_remove", stream)) return rc;   // borrows group-table scratch: a pending prepared apply is dropped
     if (n == 0) return MEE_OK;
@@ -704,13 +730,16 @@ static int find_or_insert_common(mee_table* t, const int64_t* d_keys, size_t n, 
 }
 
 int mee_find_or_insert_located(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
+    MEE_RANGE("mee_find_or_insert_located");
     if (n && !d_slots_out) return fail(MEE_ERR_INVALID_ARG, "mee_find_or_insert_located: null argument");
     return find_or_insert_common(t, d_keys, n, d_out, d_found, stream, true, "mee_find_or_insert_located", d_slots_out);
 }
 int mee_find_or_insert(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_find_or_insert");
     return find_or_insert_common(t, d_keys, n, d_out, d_found, stream, true, "mee_find_or_insert");
 }
 int mee_find_or_insert_admit(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, uint32_t min_count, void* stream) {
+    MEE_RANGE("mee_find_or_insert_admit");
     if (!t || (n && (!d_keys || !d_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_or_insert_admit: null argument");
     if (!t->sketch) return fail(MEE_ERR_UNSUPPORTED, "mee_find_or_insert_admit: table was created without MEE_FLAG_ADMISSION");
     if (int rc = check_batch(t, n, "mee_find_or_insert_admit", stream)) return rc;
@@ -730,6 +759,7 @@ int mee_find_or_insert_admit(mee_table* t, const int64_t* d_keys, size_t n, floa
     return MEE_OK;
 }
 int mee_admission_decay(mee_table* t, uint32_t shift, void* stream) {
+    MEE_RANGE("mee_admission_decay");
     if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_admission_decay: null table");
     if (!t->sketch) return fail(MEE_ERR_UNSUPPORTED, "mee_admission_decay: table was created without MEE_FLAG_ADMISSION");
     DeviceGuard g(t->device);
@@ -739,11 +769,13 @@ int mee_admission_decay(mee_table* t, uint32_t shift, void* stream) {
 }
 
 int mee_find_or_insert_missing(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, const uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_find_or_insert_missing");
     if (!d_found && n) return fail(MEE_ERR_INVALID_ARG, "mee_find_or_insert_missing: null found mask");
     return find_or_insert_common(t, d_keys, n, d_out, const_cast<uint8_t*>(d_found), stream, false, "mee_find_or_insert_missing");
 }
 
 int mee_locate(const mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_slots_out, uint8_t* d_found, void* stream) {
+    MEE_RANGE("mee_locate");
     if (!t || (n && (!d_keys || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_locate: null argument");
     if (n > 0xFFFFFFFFull) return fail(MEE_ERR_BATCH_TOO_LARGE, "mee_locate: n=%zu exceeds 2^32 - 1", n);
     if (n == 0) return MEE_OK;
@@ -809,12 +841,14 @@ static int group_apply_common(mee_group* g, const int64_t* d_keys, const uint64_
 
 int mee_group_apply_adagrad(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr,
                             float eps, void* stream) {
+    MEE_RANGE("mee_group_apply_adagrad");
     OptArgs a{};
     a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps;
     return group_apply_common(g, d_keys, d_offsets, d_grads, n, a, stream, "mee_group_apply_adagrad");
 }
 int mee_group_apply_adam(mee_group* g, const int64_t* d_keys, const uint64_t* d_offsets, const float* d_grads, size_t n, float lr,
                          float beta1, float beta2, float eps, uint64_t step, void* stream) {
+    MEE_RANGE("mee_group_apply_adam");
     if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adam: step must be >= 1");
     OptArgs a{};
     a.kind = MEE_OPT_ADAM; a.eps = eps;
@@ -827,6 +861,7 @@ int mee_group_apply_adam(mee_group* g, const int64_t* d_keys, const uint64_t* d_
 int mee_group_apply_adagrad_pooled(mee_group* g, const int64_t* d_keys, const uint64_t* d_bag_offsets, size_t bags_per_table,
                                    const float* d_bag_grads, const uint32_t* d_grad_index, const int64_t* d_located, size_t n, float lr,
                                    float eps, void* stream) {
+    MEE_RANGE("mee_group_apply_adagrad_pooled");
     if (n && (!d_grad_index || !bags_per_table)) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adagrad_pooled: null index / zero bags_per_table");
     OptArgs a{};
     a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps;
@@ -838,6 +873,7 @@ int mee_group_apply_adagrad_pooled(mee_group* g, const int64_t* d_keys, const ui
 int mee_group_apply_adam_pooled(mee_group* g, const int64_t* d_keys, const uint64_t* d_bag_offsets, size_t bags_per_table,
                                 const float* d_bag_grads, const uint32_t* d_grad_index, const int64_t* d_located, size_t n, float lr,
                                 float beta1, float beta2, float eps, uint64_t step, void* stream) {
+    MEE_RANGE("mee_group_apply_adam_pooled");
     if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adam_pooled: step must be >= 1");
     if (n && (!d_grad_index || !bags_per_table)) return fail(MEE_ERR_INVALID_ARG, "mee_group_apply_adam_pooled: null index / zero bags_per_table");
     OptArgs a = adam_args(lr, beta1, beta2, eps, step);
@@ -847,6 +883,7 @@ int mee_group_apply_adam_pooled(mee_group* g, const int64_t* d_keys, const uint6
 }
 
 int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* stream) {
+    MEE_RANGE("mee_apply_prepare");
     if (!t || (n && !d_keys)) return fail(MEE_ERR_INVALID_ARG, "mee_apply_prepare: null argument");
     if (t->optimizer == MEE_OPT_NONE) return fail(MEE_ERR_UNSUPPORTED, "mee_apply_prepare: table has no optimizer");
     if (t->prepared_n) return fail(MEE_ERR_INVALID_ARG, "mee_apply_prepare: a prepared apply is already pending");
@@ -859,6 +896,7 @@ int mee_apply_prepare(mee_table* t, const int64_t* d_keys, size_t n, void* strea
 }
 
 int mee_find_or_insert_located_prepare(mee_table* t, const int64_t* d_keys, size_t n, float* d_out, uint8_t* d_found, int64_t* d_slots_out, void* stream) {
+    MEE_RANGE("mee_find_or_insert_located_prepare");
     if (!t || (n && (!d_keys || !d_out || !d_slots_out))) return fail(MEE_ERR_INVALID_ARG, "mee_find_or_insert_located_prepare: null argument");
     if (t->optimizer == MEE_OPT_NONE) return mee_find_or_insert_located(t, d_keys, n, d_out, d_found, d_slots_out, stream);
     if (int rc = check_batch(t, n, "mee_find_or_insert_located_prepare", stream, true, false)) return rc;   // (refuses while another prepared apply is pending)
@@ -877,6 +915,7 @@ int mee_find_or_insert_located_prepare(mee_table* t, const int64_t* d_keys, size
 }
 
 int mee_apply_discard(mee_table* t, void* stream) {
+    MEE_RANGE("mee_apply_discard");
     if (!t) return fail(MEE_ERR_INVALID_ARG, "mee_apply_discard: null table");
     if (!t->prepared_n) return MEE_OK;
     DeviceGuard g(t->device);
@@ -888,6 +927,7 @@ int mee_apply_discard(mee_table* t, void* stream) {
 }
 
 int mee_apply_adagrad(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float eps, void* stream) {
+    MEE_RANGE("mee_apply_adagrad");
     OptArgs a{};
     a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps;
     return apply_common(t, d_keys, d_grads, n, a, stream, "mee_apply_adagrad");
@@ -902,12 +942,14 @@ static OptArgs adam_args(float lr, float beta1, float beta2, float eps, uint64_t
 }
 int mee_apply_adam(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, float lr, float beta1, float beta2,
                    float eps, uint64_t step, void* stream) {
+    MEE_RANGE("mee_apply_adam");
     if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adam: step must be >= 1");
     return apply_common(t, d_keys, d_grads, n, adam_args(lr, beta1, beta2, eps, step), stream, "mee_apply_adam");
 }
 // the same with the slots the forward lookup of this step located (mee_find_located): the main pass skips its probe
 int mee_apply_adagrad_located(mee_table* t, const int64_t* d_keys, const int64_t* d_slots, const float* d_grads, size_t n, float lr, float eps,
                               void* stream) {
+    MEE_RANGE("mee_apply_adagrad_located");
     if (n && !d_slots) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adagrad_located: null slots");
     OptArgs a{};
     a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps;
@@ -915,6 +957,7 @@ int mee_apply_adagrad_located(mee_table* t, const int64_t* d_keys, const int64_t
 }
 int mee_apply_adam_located(mee_table* t, const int64_t* d_keys, const int64_t* d_slots, const float* d_grads, size_t n, float lr, float beta1,
                            float beta2, float eps, uint64_t step, void* stream) {
+    MEE_RANGE("mee_apply_adam_located");
     if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adam_located: step must be >= 1");
     if (n && !d_slots) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adam_located: null slots");
     return apply_common(t, d_keys, d_grads, n, adam_args(lr, beta1, beta2, eps, step), stream, "mee_apply_adam_located", nullptr, d_slots);
@@ -927,6 +970,7 @@ static int check_grad_rows(size_t n, const uint32_t* d_grad_index, size_t n_grad
 }
 int mee_apply_adagrad_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n_grad_rows, const uint32_t* d_grad_index,
                               size_t n, float lr, float eps, void* stream) {
+    MEE_RANGE("mee_apply_adagrad_indexed");
     if (int rc = check_grad_rows(n, d_grad_index, n_grad_rows, "mee_apply_adagrad_indexed")) return rc;
     OptArgs a{};
     a.kind = MEE_OPT_ADAGRAD; a.lr = lr; a.eps = eps; a.grad_rows = (uint32_t)n_grad_rows;
@@ -934,6 +978,7 @@ int mee_apply_adagrad_indexed(mee_table* t, const int64_t* d_keys, const float* 
 }
 int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n_grad_rows, const uint32_t* d_grad_index,
                            size_t n, float lr, float beta1, float beta2, float eps, uint64_t step, void* stream) {
+    MEE_RANGE("mee_apply_adam_indexed");
     if (step == 0) return fail(MEE_ERR_INVALID_ARG, "mee_apply_adam_indexed: step must be >= 1");
     if (int rc = check_grad_rows(n, d_grad_index, n_grad_rows, "mee_apply_adam_indexed")) return rc;
     OptArgs a = adam_args(lr, beta1, beta2, eps, step);
@@ -944,6 +989,7 @@ int mee_apply_adam_indexed(mee_table* t, const int64_t* d_keys, const float* d_g
 /* duplicate-key reduction with row sums, sync-free (meepo_dedup.hip): see include/meepo_embedding.h */
 int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, size_t n, int64_t* d_uniq_out, float* d_gsum_out,
                   uint32_t* d_counts_out, int64_t* d_inverse_out, int64_t miss_index, void* stream) {
+    MEE_RANGE("mee_dedup_sum");
     if (!t || (n && (!d_keys || !d_uniq_out))) return fail(MEE_ERR_INVALID_ARG, "mee_dedup_sum: null argument");
     if ((d_grads == nullptr) != (d_gsum_out == nullptr)) return fail(MEE_ERR_INVALID_ARG, "mee_dedup_sum: d_grads and d_gsum_out go together (both or neither)");
     if (int rc = check_batch(t, n, "mee_dedup_sum", stream)) return rc;
@@ -956,6 +1002,7 @@ int mee_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, siz
  * padding, d_inverse_out[i] = index of keys[i] in d_uniq_out, or miss_index for reserved keys.  Nothing returns to the host. */
 int mee_dedup_keys(mee_table* t, const int64_t* d_keys, size_t n, int64_t* d_uniq_out, int64_t* d_inverse_out, int64_t miss_index,
                    void* stream) {
+    MEE_RANGE("mee_dedup_keys");
     if (!t || (n && (!d_keys || !d_uniq_out || !d_inverse_out))) return fail(MEE_ERR_INVALID_ARG, "mee_dedup_keys: null argument");
     if (int rc = check_batch(t, n, "mee_dedup_keys", stream)) return rc;
     if (n == 0) return MEE_OK;

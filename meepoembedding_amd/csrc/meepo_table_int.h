@@ -15,6 +15,7 @@ struct OpCounters {          // device-resident, zeroed at the start of each op 
     unsigned long long n_export;  // pairs exported / keys counted
     uint32_t n_part;         // fp64 partial-sum rows reserved by the apply's long runs
     uint32_t pad;
+    unsigned long long hist[4];   // mee_probe_histogram: lookups that visit 1 / 2 / 3 / 4 or more buckets
 };
 struct GroupTable {            // S entries, indexed by h
     // One 16-byte entry per h: ent[2h] = key ^ kBias (0 = empty), ent[2h+1] = the count word below.  Key and count share a 64-byte sector,
@@ -113,6 +114,11 @@ struct mee_table {
     int find_nt;                // bit0: non-temporal row loads, bit1: non-temporal bucket loads, bit2: plain (cached) out stores;
                                 // -1 = auto: cached loads (hot rows of skewed streams stay in L2), cached stores while the
                                 // dense output fits the Infinity Cache (<= 128 MB), streaming stores beyond
+    // mee_find's own cache policy (find_nt = -1, no per-call hint): the dense outputs of the latest lookups, so that a caller whose result buffers ROTATE — nothing
+    // re-reads them from cache — gets streaming stores without having to say so (find_plane; relaxed atomics: concurrent lookups may race on it, it steers
+    // nothing but the store instruction's cache hint)
+    uint64_t out_ring_ptr[8], out_ring_bytes[8];
+    uint32_t out_ring_head;
     mee::BucketScratch bk;      // bucketed apply (null pointers when the table has no optimizer)
     bool prepared_by_forward;   // the pending partition came with a training forward (mee_find*_located_prepare): a mutator in between drops it
     uint32_t part_nbk_hash;   // ... of which the first part_nbk_hash are hash buckets (the rest: one per hot key)
@@ -150,6 +156,7 @@ __device__ __forceinline__ void update_row(const OptArgs& a, float4* values, flo
     if (a.kind == MEE_OPT_ADAM) s2[o] = x2;
 }
 // the bucketed apply path (meepo_apply.hip)
+uint32_t xcd_split_for_device(int device);   // the calibrated share of a bucket pair's hash range that goes to the even bucket (0 = even halves)
 int bucket_scratch_alloc(mee_table* t);
 void bucket_scratch_free(mee_table* t);
 int bucket_apply_prepare(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st);

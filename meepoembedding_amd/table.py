@@ -281,6 +281,13 @@ class LookupTable:
         check(_lib.lib().mee_probe_length(self._h, k.data_ptr(), k.numel(), C.byref(tot), self._s()))
         return tot.value / max(1, k.numel())
 
+    def probe_histogram(self, keys: torch.Tensor) -> list[int]:
+        """[lookups of `keys` that visit 1, 2, 3, 4-or-more buckets] (mee_probe_histogram; reserved keys visit none); synchronises."""
+        k = self._keys(keys)
+        h = (C.c_uint64 * 4)()
+        check(_lib.lib().mee_probe_histogram(self._h, k.data_ptr(), k.numel(), h, self._s()))
+        return [int(x) for x in h]
+
     def clear_status(self) -> None:
         check(_lib.lib().mee_clear_status(self._h, self._s()))
 

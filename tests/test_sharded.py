@@ -169,7 +169,9 @@ def _run_rank_body(rank, world, port, backend, q, tiered=False, DIM=DIM):
             mix = torch.cat([fresh_keys, probe[:200], fresh_keys[:50]])
             o7, f7 = pt.find_or_insert(mix)
             o8, _ = sb.find_or_insert(mix)
-            assert torch.equal(o7, o8) and bool(f7.all())
+            assert bool(f7.all())
+            torch.testing.assert_close(o7, o8, rtol=1e-6, atol=1e-9)   # (the two tables differ by the aggregated step's roundings; created rows are equal bit for bit)
+            assert torch.equal(o7[:300], o8[:300])
             dist.barrier()
             assert la.size() == lb.size()
             with pytest.raises(ValueError):
@@ -381,8 +383,8 @@ def test_sharded_tiered_gloo_cpu(built):
 
 # dims: 16 = configs[0], 64 = the metric's / configs[4]'s, 128 = configs[3]'s
 @pytest.mark.gpu
-# (6 ranks: the most processes the GPU box lets one job keep on its card at once — G = 8 runs as threads of one process: tests/cabi/sharded_mp_test.cpp)
-@pytest.mark.parametrize("world,dim", [(2, 16), (4, 16), (2, 64), (4, 128), (2, 128), (6, 64)])
+# (5 ranks + this process: the most processes the GPU box lets one job keep on its card at once — G = 8 runs as threads of one process: tests/cabi/sharded_mp_test.cpp)
+@pytest.mark.parametrize("world,dim", [(2, 16), (4, 16), (2, 64), (4, 128), (2, 128), (5, 64)])
 def test_sharded_multi_rank_on_one_gpu(dev, world, dim):
     _check(_launch(world, "gloo-gpu", dim=dim), world, dim)
 
