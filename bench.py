@@ -224,7 +224,9 @@ def stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, uniform
         rows[name] = {"us_per_launch_median": med, "us_per_launch_min": mn, "lookups_per_s": batch / med * 1e6,
                       "algorithmic_GBps": batch * bpl / med / 1e3, "frac_of_hbm_roofline": batch * bpl / med / 1e3 / HBM_PEAK_GBS,
                       "read_only_GBps": batch * (16 + 4 * dim) / med / 1e3,
-                      "mean_probe_length_buckets": table.probe_length(bs[0])}
+                      "mean_probe_length_buckets": table.probe_length(bs[0]),
+                      # SURVEY §5 "metrics": lookups of one batch that visit 1 / 2 / 3 / 4-or-more buckets (mee_probe_histogram)
+                      "probe_length_histogram": dict(zip(("1", "2", "3", "4+"), table.probe_histogram(bs[0])))}
     # the same uniform stream with the caller's per-call cache-policy hint for a stream without reuse (mee_find_ex: streaming row and bucket
     # loads, cached stores; the default keeps the loads cached because skewed streams re-read their hot rows)
     from meepoembedding_amd import _lib as _ml
@@ -969,18 +971,20 @@ def main():
 
             def step(i):
                 r_ = find_step(i)
+                # --dedup: the backward sends ONE summed gradient row per distinct key of the rank's batch (mee_dedup_sum in front of the exchange; the native
+                # context does it by its MEE_SHARDED_DEDUP flag)
                 if via_peer:
-                    peer.apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10, check_overflow=False)
+                    peer.apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10, check_overflow=False, dedup=args.dedup)
                 elif native is not None:
                     native.apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10)
                 else:
-                    shs[0].apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10)
+                    shs[0].apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10, dedup=args.dedup)
                 return r_
         # the torch.distributed path end to end: what the timed region is re-run with if the chosen transport fails its check there
         def step_fallback(i):
             r_ = step_rccl(i)
             if train:
-                shs[0].apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10)
+                shs[0].apply_adagrad(batches[i % n_batches], grads[i % 4], lr=0.01, eps=1e-10, dedup=args.dedup)
             return r_
     elif train:
         grads = [torch.randn(batch, dim, device=dev) * 0.01 for _ in range(4)]   # N(0, 1e-2), SURVEY §8d config 3
@@ -999,7 +1003,11 @@ def main():
             # The hints travel with the CALL (round 3 set them on the table, which other callers of the table share): keep whichever is fastest.
             from meepoembedding_amd import _lib as _ml
             choices = {"auto": None, "streaming_stores": _ml.FIND_STREAM_STORES, "streaming_stores_and_row_loads": _ml.FIND_STREAM_STORES | _ml.FIND_STREAM_ROWS}
-            probe = {label: kernel_window(table, batches, outs, founds, dev, launches=100, regions=3, warm=10, flags=fl)[0] for label, fl in choices.items()}
+            probe = {}
+            for _round in range(2):   # every candidate twice, interleaved (the first one measured pays for cold caches and clocks otherwise): the better of its two
+                for label, fl in choices.items():
+                    us_ = kernel_window(table, batches, outs, founds, dev, launches=100, regions=3, warm=10, flags=fl)[0]
+                    probe[label] = min(probe.get(label, us_), us_)
             best = min(probe, key=probe.get)
             find_flags = choices[best]
             store_hint = {"auto_us": probe["auto"], "streaming_stores_us": probe["streaming_stores"],
@@ -1249,7 +1257,7 @@ def main():
                        "keys_per_gpu": keys_per_gpu, "local_size": local_size, "dim": dim, "batch_per_rank": batch, "load_factor": args.load,
                        "key_distribution": args.dist, "table_gb": round(table.table_bytes / 1e9, 2), "launch": launch_mode,
                        "launch_comparison": launch_cmp, "output_buffers": (f"{n_out} x {batch * dim * 4 >> 20} MB dense result buffers in rotation" if n_out > 1 else "one reused result buffer"),
-                       "parallelism": (f"row-shard x{world}" + (f", {args.pipeline} steps in flight" if args.pipeline > 1 else "") + (", pre-exchange dedup" if args.dedup else "")) if sharded else "single GPU"},
+                       "parallelism": (f"row-shard x{world}" + (f", {args.pipeline} steps in flight" if args.pipeline > 1 else "") + (", pre-exchange dedup" + (" (lookup keys and summed gradient rows)" if train else "") if args.dedup else "")) if sharded else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic if not whole else step_traffic, "kernel": "find_kernel" if not whole else "whole step (find_prepare_kernel: the located find + the apply's partition; bkt_apply_kernel: dedup + update)",
                          "traffic_source": (("profiles/find_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 per the gfx950 correction)"

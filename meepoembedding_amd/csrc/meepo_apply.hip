@@ -65,9 +65,10 @@ static bool stream_is_capturing(hipStream_t st) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     return hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
 }
-uint32_t bucket_count_for(mee_table* t, uint64_t n, hipStream_t st, uint32_t* grid_out, uint32_t* nbk_total_out, bool* full_out) {
-    const uint32_t slots = t->bk.slots;
-    uint32_t full = bucket_count_for_host(n, slots, t->bk.bucket_max ? t->bk.bucket_max : kBucketMax);
+// (slots_of / bucket_max_of: the geometry of another consumer of the partition — mee_dedup_sum's blocks, six per CU, want ONE round of buckets of up to ~680 positions)
+uint32_t bucket_count_for(mee_table* t, uint64_t n, hipStream_t st, uint32_t* grid_out, uint32_t* nbk_total_out, bool* full_out, uint32_t slots_of, uint32_t bucket_max_of) {
+    const uint32_t slots = slots_of ? slots_of : t->bk.slots;
+    uint32_t full = bucket_count_for_host(n, slots, bucket_max_of ? bucket_max_of : t->bk.bucket_max ? t->bk.bucket_max : kBucketMax);
     // The scratch (totals, run matrices, pending counters, tickets) is strided for n_buckets_max buckets, sized at creation for the DEFAULT bucket size at
     // max_batch (+ the hot keys' buckets): a smaller "apply_bucket_max" must not ask for more buckets than that — it gets larger buckets instead.
     const uint32_t room = t->bk.n_buckets_max - kHotCap;
@@ -89,6 +90,7 @@ uint32_t bucket_count_for(mee_table* t, uint64_t n, hipStream_t st, uint32_t* gr
         if (adj > full / 2) adj = full / 2;
         nbk = full - adj;
         while ((uint64_t)nbk * 2 * kBucketMax < n && nbk < full) ++nbk;   // (never more than ~700 positions per bucket on average: kBucketCap stays 12 sigma away)
+        if (bucket_max_of) while ((uint64_t)nbk * bucket_max_of < n && nbk < full) ++nbk;   // (a consumer that asked for its own bucket size: the skewed stream's hash buckets hold fewer positions anyway)
     }
     if (grid_out) *grid_out = full;
     // behind a skewed batch the keys that batch reported as hot get buckets of their own, behind the hash buckets (meepo_apply_part.h) — the

@@ -524,6 +524,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
 // A hot key's own bucket (one key) is cut into windows of kSumWindow positions, one block each; a window leaves an fp64 partial row, draws a
 // ticket, and the window that draws the last one adds the partial rows up (pending-record discipline of the apply: write-through stores, drained
 // before the ticket, agent-scope loads; no fence).
+constexpr uint32_t kSumBlocksPerCU = 6, kSumBucketMax = 683;   // (the kernel's register bound; positions per bucket aimed at: see bucket_dedup_sum)
 constexpr uint32_t kSumTileMax = 8, kSumWaveMax = 64;   // (rows in flight are registers: 4 per tile everywhere — 8 in the wave- and block-level sums cost 84 B more scratch per lane, paid by every wave)
 struct SumLds {
     DedupLds d;
@@ -591,12 +592,12 @@ __device__ __forceinline__ void block_run_sum(SumLds& L, uint32_t dim4, uint32_t
 __device__ __forceinline__ f32x4 grad_row4(const float4* __restrict__ grads, uint32_t row, uint32_t dim4, uint32_t col) {
     return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grads) + (uint64_t)row * dim4 + col);   // every gradient row is read exactly once
 }
-__device__ __forceinline__ void store_sum4(float4* __restrict__ gsum, uint32_t u, uint32_t dim4, uint32_t col, const D4& v) {
-    gsum[(uint64_t)u * dim4 + col] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+__device__ __forceinline__ void store_sum4(float4* __restrict__ gsum, uint32_t u, uint32_t dim4, uint32_t col, const D4& v) {   // (streamed: the rows go to a peer or to an apply, not back into this kernel)
+    __builtin_nontemporal_store(f32x4{(float)v.x, (float)v.y, (float)v.z, (float)v.w}, reinterpret_cast<f32x4*>(gsum) + (uint64_t)u * dim4 + col);
 }
 
 template <int DIM4>
-__global__ __launch_bounds__(kDedupThreads, 6) void bkt_dedup_sum_kernel(SumArgs A, BucketScratch bk) {   // (6 blocks per CU: 80 registers and a few dwords of scratch; unbounded: 109 and 4 blocks)
+__global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_kernel(SumArgs A, BucketScratch bk) {   // (6 blocks per CU: 80 registers and a few dwords of scratch; unbounded: 109 and 4 blocks)
     __shared__ SumLds L;
     uint32_t parity, before;
     HotPlan P;
@@ -735,39 +736,62 @@ __global__ __launch_bounds__(kDedupThreads, 6) void bkt_dedup_sum_kernel(SumArgs
             }
         }
         // -- 5. short runs: a tile each, FOUR runs in flight per tile.  Four keys that occur once — the bulk of every batch — are four streamed rows in, four rows
-        // out, bit for bit (no arithmetic); otherwise each run is summed in turn (two round trips of four rows)
+        // out, bit for bit (no arithmetic), software-pipelined: the NEXT four rows are requested before the current four are stored, so that a step waits for its
+        // loads only (the memory counter retires in order: loads issued behind stores would wait for the stores' acknowledgement as well).  Anything else: each run
+        // summed in turn (two round trips of four rows).
         constexpr uint32_t kTiles = 4 * kDedupWaves;
-        for (uint32_t i0 = T; i0 < n_s; i0 += 4 * kTiles) {   // tile T takes runs T, T + 16, T + 32, T + 48, then T + 64, ...
-            uint32_t idx[4], c[4], first[4];
-            bool all_once = true;
+        // a step = runs i0, i0 + 16, i0 + 32, i0 + 48 of tile T's sequence.  Returns the step's kind — bit q: run q exists and is ONE source (its row is requested
+        // into g[q]); kMixed: some run has several sources (nothing requested: the step is summed when its turn comes)
+        constexpr uint32_t kMixed = 0x100u;
+        auto request = [&](uint32_t i0, f32x4 (&g)[4]) -> uint32_t {
+            uint32_t kind = 0, row[4];
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) {
-                idx[q] = i0 + q * kTiles;
-                const bool ok = idx[q] < n_s;
-                const uint32_t sl = ok ? L.items()[idx[q]] : 0u;
-                c[q] = ok ? L.d.cnt[sl] : 0u;
-                first[q] = ok ? L.off[sl] - c[q] : 0u;
-                all_once = all_once && c[q] <= 1u;
+                const uint32_t idx = i0 + q * kTiles;
+                row[q] = 0u;   // (row 0 for a missing run: a valid address, the load stays unconditional)
+                if (idx < n_s) {
+                    const uint32_t sl = L.items()[idx], c = L.d.cnt[sl];
+                    if (c == 1u) { kind |= 1u << q; row[q] = source(L.off[sl] - 1u); } else kind |= kMixed;
+                }
             }
-            if (all_once) {
-                uint32_t row[4];
+            if (kind & kMixed) return kMixed;
 #pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) row[q] = c[q] ? source(first[q]) : 0u;
-                for (uint32_t col = tl; col < dim4; col += 16) {
-                    f32x4 g[4];
+            for (uint32_t q = 0; q < 4; ++q)
+                g[q] = (uint32_t)tl < dim4 ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A.grads) + (uint64_t)row[q] * dim4 + tl) : f32x4{0.f, 0.f, 0.f, 0.f};
+            return kind;
+        };
+        if (T < n_s) {
+            f32x4 g[4];
+            uint32_t kind = request(T, g);
+            for (uint32_t i0 = T; i0 < n_s; i0 += 4 * kTiles) {
+                f32x4 gn[4] = {g[0], g[1], g[2], g[3]};
+                const uint32_t kind_next = i0 + 4 * kTiles < n_s ? request(i0 + 4 * kTiles, gn) : 0u;
+                if (!(kind & kMixed)) {
 #pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q) g[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A.grads) + (uint64_t)row[q] * dim4 + col);   // (row 0 for a missing run: a valid address)
+                    for (uint32_t q = 0; q < 4; ++q)
+                        if ((kind >> q & 1u) && (uint32_t)tl < dim4) __builtin_nontemporal_store(g[q], reinterpret_cast<f32x4*>(A.gsum) + (uint64_t)(base + i0 + q * kTiles) * dim4 + tl);
+                    for (uint32_t col = tl + 16; col < dim4; col += 16) {   // wider rows: the remaining column groups
 #pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q) if (c[q]) A.gsum[(uint64_t)(base + idx[q]) * dim4 + col] = make_float4(g[q].x, g[q].y, g[q].z, g[q].w);
+                        for (uint32_t q = 0; q < 4; ++q) {
+                            if (!(kind >> q & 1u)) continue;
+                            const uint32_t sl = L.items()[i0 + q * kTiles];
+                            const f32x4 h = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A.grads) + (uint64_t)source(L.off[sl] - 1u) * dim4 + col);
+                            __builtin_nontemporal_store(h, reinterpret_cast<f32x4*>(A.gsum) + (uint64_t)(base + i0 + q * kTiles) * dim4 + col);
+                        }
+                    }
+                } else {
+#pragma unroll 1
+                    for (uint32_t q = 0; q < 4; ++q) {
+                        const uint32_t idx = i0 + q * kTiles;
+                        if (idx >= n_s) break;
+                        const uint32_t sl = L.items()[idx], c = L.d.cnt[sl], f0 = L.off[sl] - c;
+                        for (uint32_t col = tl; col < dim4; col += 16)
+                            store_sum4(A.gsum, base + idx, dim4, col, run_sum4(0u, 4u, c, col, [&](uint32_t j, uint32_t cc) { return grad_row4(A.grads, source(f0 + j), dim4, cc); }));
+                    }
                 }
-            } else {
+                kind = kind_next;
 #pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) {
-                    if (!c[q]) continue;
-                    const uint32_t f0 = first[q];
-                    for (uint32_t col = tl; col < dim4; col += 16)
-                        store_sum4(A.gsum, base + idx[q], dim4, col, run_sum4(0u, 4u, c[q], col, [&](uint32_t j, uint32_t cc) { return grad_row4(A.grads, source(f0 + j), dim4, cc); }));
-                }
+                for (uint32_t q = 0; q < 4; ++q) g[q] = gn[q];
             }
         }
     });
@@ -777,10 +801,10 @@ __global__ __launch_bounds__(kDedupThreads, 6) void bkt_dedup_sum_kernel(SumArgs
 // blocks behind the buckets: one per window a batch of n keys can have in its hot keys' buckets (sum of ceil(size / kHotWindow) <= n / kHotWindow + hot buckets)
 static uint32_t hot_window_blocks(const DedupArgs& A, uint32_t n, uint32_t window = kHotWindow) { return A.nbk != A.nbk_hash ? n / window + (A.nbk - A.nbk_hash) : 0u; }
 static int dedup_partition(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st, DedupArgs& A, int64_t* d_uniq, int64_t* d_inverse, int64_t miss_index, uint8_t* d_found,
-                           uint32_t* d_counts = nullptr) {
+                           uint32_t* d_counts = nullptr, uint32_t slots_of = 0, uint32_t bucket_max_of = 0) {
     uint32_t grid, nbk;
     bool full;
-    const uint32_t nbk_hash = bucket_count_for(t, n, st, &grid, &nbk, &full);
+    const uint32_t nbk_hash = bucket_count_for(t, n, st, &grid, &nbk, &full, slots_of, bucket_max_of);
     // (hot keys' buckets whenever the latest batch reported any: a dedup has no FULL / LEAN kernels, its one kernel takes buckets of any size)
     uint32_t blocks, per_block;
     part_geometry(n, 1024, blocks, per_block, kPartBlocks);
@@ -807,7 +831,10 @@ int bucket_dedup_keys(mee_table* t, const int64_t* d_keys, uint32_t n, int64_t* 
 int bucket_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, uint32_t n, int64_t* d_uniq, float* d_gsum, uint32_t* d_counts, int64_t* d_inverse, int64_t miss_index,
                      hipStream_t st) {
     SumArgs A{};
-    if (int rc = dedup_partition(t, d_keys, n, st, A.d, d_uniq, d_inverse, miss_index, nullptr, d_counts)) return rc;
+    // Geometry of its own: every block pays ~20 us of dependent steps (totals, runs, entries, LDS table, scans, look-ups) before its first row moves, so the rows
+    // want FEW, FAT buckets — one round of the kernel's resident blocks (six per CU), up to kSumBucketMax positions on average (Poisson(683) stays 13 sigma below
+    // the 1024 entries a block holds in registers and LDS): 1M keys = 1536 buckets of 683 instead of the apply's 3072 of 341 in two rounds.
+    if (int rc = dedup_partition(t, d_keys, n, st, A.d, d_uniq, d_inverse, miss_index, nullptr, d_counts, t->bk.slots / kApplyBlocksPerCU * kSumBlocksPerCU, kSumBucketMax)) return rc;
     A.d.uniq = d_uniq; A.d.inverse = d_inverse;
     A.grads = (const float4*)d_grads; A.gsum = (float4*)d_gsum; A.counts = d_counts; A.dim4 = t->dim4;
     A.src_scratch = t->bs.hidx; A.part = t->bk.sum_part; A.max_part = t->bk.sum_part_rows;

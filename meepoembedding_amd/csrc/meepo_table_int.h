@@ -171,7 +171,8 @@ int bucket_dedup_keys(mee_table* t, const int64_t* d_keys, uint32_t n, int64_t* 
 int bucket_assign(mee_table* t, float* plane, const int64_t* d_keys, const float* d_values, uint32_t n, uint8_t* d_found, hipStream_t st);
 int bucket_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, uint32_t n, int64_t* d_uniq, float* d_gsum, uint32_t* d_counts, int64_t* d_inverse, int64_t miss_index,
                      hipStream_t st);
-uint32_t bucket_count_for(mee_table* t, uint64_t n, hipStream_t st, uint32_t* grid_out = nullptr, uint32_t* nbk_total_out = nullptr, bool* full_out = nullptr);
+uint32_t bucket_count_for(mee_table* t, uint64_t n, hipStream_t st, uint32_t* grid_out = nullptr, uint32_t* nbk_total_out = nullptr, bool* full_out = nullptr,
+                          uint32_t slots_of = 0, uint32_t bucket_max_of = 0);
 
 // ---- host helpers the table's translation units share (meepo_table.hip, meepo_find.hip, meepo_export.hip) ------------------------------
 inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
