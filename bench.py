@@ -446,8 +446,8 @@ def tier_share_point(synth, dim, dev, batch, log, keys=1_250_000_000, hot_keys=8
     if train_cold_cap:   # (default: no more pinned host memory than the lookup tables above took — a box shares its host with seven others)
         tc_keys = min(tc_keys, train_cold_cap)
     t0 = time.time()
-    hot = LookupTable(int(th_keys / load), dim, device=dev, max_batch=chunk, optimizer=OPT_ADAGRAD)
-    cold = LookupTable(int(tc_keys / load), dim, device=dev, max_batch=chunk, optimizer=OPT_ADAGRAD, value_memory=_lib.MEM_HOST_PINNED)
+    hot = LookupTable(int(th_keys / load), dim, device=dev, max_batch=4 * chunk, optimizer=OPT_ADAGRAD, track_hits=True)
+    cold = LookupTable(int(tc_keys / load), dim, device=dev, max_batch=4 * chunk, optimizer=OPT_ADAGRAD, value_memory=_lib.MEM_HOST_PINNED, track_hits=True)
     tk = th_keys + tc_keys
     for tab, lo, hi_ in ((hot, 0, th_keys), (cold, th_keys, tk)):
         for s_ in range(lo, hi_, chunk):
@@ -485,6 +485,46 @@ def tier_share_point(synth, dim, dev, batch, log, keys=1_250_000_000, hot_keys=8
                     # the find reads a row per cold occurrence; the update reads and writes row + accumulator once per distinct cold key
                     "cold_bytes_over_pcie_GBps": (batch * cs + 4 * cold_distinct) * dim * 4 / us / 1e3}
         log(f"tier share: training pair, {name}: {tr[name]}")
+    # ---- the training loop with the placement policy IN it (round 5): rebalance_every = 24 optimizer steps.  The scattered stream starts with half of its
+    # lookups cold; every round = 24 find + Adagrad steps (the observation window), the rebalance behind the 24th (keys move WITH their accumulators), then
+    # the step is timed again (policy off while it is timed)
+    tp = TieredLookupTable(hot, cold, hot_key_limit=th_keys, sample_every=4, promote_threshold=2, rebalance_every=24, rebalance_max_moves=4 * chunk)
+    series = []
+
+    def timed_steps(bs_):
+        tp.rebalance_every, keep = 0, tp.rebalance_every
+        per = []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for i in range(10):
+                tp.find(bs_[i % len(bs_)])
+                tp.apply_adagrad(bs_[i % len(bs_)], grads, lr=0.01)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            per.append(e0.elapsed_time(e1) * 1e3 / 10)
+        tp.rebalance_every = keep
+        return sorted(per)[1]
+
+    probe_bs = [zipf_batch(tk) for _ in range(8)]
+    for rnd in range(0, rounds + 1):
+        if rnd:
+            t1 = time.time()
+            for _ in range(24):
+                b_ = zipf_batch(tk)
+                tp.find(b_)
+                tp.apply_adagrad(b_, grads, lr=0.01)
+            torch.cuda.synchronize(dev)
+            loop_ms = (time.time() - t1) * 1e3
+        cs = sum(1.0 - float(hot.find(b)[1].float().mean()) for b in probe_bs[:4]) / 4
+        row = {"round": rnd, "us_per_find_plus_adagrad_step": timed_steps(probe_bs), "cold_fraction": cs}
+        if rnd:
+            row.update({"promoted": tp.rebalance_log[-1][1], "demoted": tp.rebalance_log[-1][2], "ms_for_24_steps_and_the_rebalance": round(loop_ms, 1)})
+        series.append(row)
+        log(f"tier share: training loop with rebalance_every=24, round {rnd}: {row}")
+        if len(series) >= 4 and series[-2]["cold_fraction"] - cs < 0.02 * max(cs, 1e-9):
+            break
+    tr["training_loop_with_policy"] = {"rebalance_every_steps": 24, "rounds": series}
     assert hot.status() == 0 and cold.status() == 0
     res["train_pair"] = tr
     hot.close(); cold.close()

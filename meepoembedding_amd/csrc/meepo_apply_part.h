@@ -137,8 +137,11 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
 // a key with enough occurrences in this batch to fill half a slab: into the hot-key set the next partition reads (copy `parity`, cleared by this
 // batch's partition).  A few hundred calls per skewed batch, none on a uniform one.  The set stops taking keys once kHotCap are numbered (a
 // batch with more hot keys than that keeps the first comers): its load stays low and every probe of it ends at an empty slot.
-__device__ __forceinline__ void report_hot_key(const BucketScratch& bk, uint32_t parity, int64_t key) {
-    if (__hip_atomic_load(&bk.hot_n[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kHotCap) return;
+// The set numbers the first comers; when a batch has more candidates than numbers, WHO is left out must not be chance: a key with 80 000 occurrences that
+// stays in a hash bucket is one block's work for milliseconds.  So the last quarter of the numbers is kept for keys that pass the bar eightfold (`giant`:
+// a Zipf(1.05) batch has ~17 of them whatever its size).
+__device__ __forceinline__ void report_hot_key(const BucketScratch& bk, uint32_t parity, int64_t key, bool giant = true) {
+    if (__hip_atomic_load(&bk.hot_n[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (giant ? kHotCap : kHotCap - kHotCap / 4)) return;
     const unsigned long long bkey = (unsigned long long)key ^ kBias;
     uint32_t h = hot_slot_of(key);   // (the slot part_bucket_of looks at first)
     unsigned long long* set = bk.hot_key + parity * kHotSlots;

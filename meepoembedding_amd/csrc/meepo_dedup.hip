@@ -173,7 +173,7 @@ __device__ __forceinline__ void dd_passes(DedupLds& L, const BucketScratch& bk, 
         if (dd_build<LAST>(L, bk, size, bits, val, held)) {
             // keys with enough occurrences to fill half a slab get a bucket of their own in the next batch (meepo_apply_part.h)
             for (uint32_t s = threadIdx.x; s < kDedupSlots; s += kDedupThreads)
-                if (L.cnt[s] >= hot_count) report_hot_key(bk, parity, (int64_t)(L.key[s] ^ kBias));
+                if (L.cnt[s] >= hot_count) report_hot_key(bk, parity, (int64_t)(L.key[s] ^ kBias), L.cnt[s] >= 8 * hot_count);
             emit(bits, val, held);
         } else if (threadIdx.x == 0) {
             if (bits < 64 && L.stk_n + 2 <= 72) {
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
         if (P.win == 0 && threadIdx.x == 0) {
             const int64_t key = bk.pkey[dd_entry_at(L, 0)];
             A.uniq[P.rank] = key;
-            if (size >= A.hot_count) report_hot_key(bk, parity, key);   // stays listed while it stays hot
+            if (size >= A.hot_count) report_hot_key(bk, parity, key, size >= 8 * A.hot_count);   // stays listed while it stays hot
         }
         for (uint32_t e0 = lo; e0 < hi; e0 += 4 * kDedupThreads) {   // four positions in flight per thread (a window is 16 per thread: 4 round trips, not 16)
             uint32_t pp[4];
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
             const uint32_t tk = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             L.overflow = tk == P.n_win - 1;   // the window that finishes last copies the winner's row
             if (tk == P.n_win - 1) L.n_distinct = __hip_atomic_load(&bk.pend_cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
-            if (P.win == 0 && size >= A.d.hot_count) report_hot_key(bk, parity, key);   // stays listed while it stays hot
+            if (P.win == 0 && size >= A.d.hot_count) report_hot_key(bk, parity, key, size >= 8 * A.d.hot_count);   // stays listed while it stays hot
         }
         __syncthreads();
         if (L.overflow && L.base && t < 16) {
@@ -546,6 +546,19 @@ struct SumArgs {
     uint32_t* src_scratch;            // [max_batch] sorted sources of buckets beyond the LDS list
     double* part; uint32_t max_part;  // fp64 partial rows of the hot keys' windows, one per window unit
 };
+// MEE_SUM_TIMELINE (diagnostic builds only: tools/sum_timeline.py): thread 0 of every block stamps the 100 MHz wall clock at its phase boundaries
+#ifndef MEE_SUM_TIMELINE
+#define MEE_SUM_TIMELINE 0
+#endif
+#if MEE_SUM_TIMELINE
+__device__ unsigned long long* g_sum_dbg = nullptr;
+#define MEE_STL(i) do { if (threadIdx.x == 0 && g_sum_dbg && blockIdx.x < 8192) g_sum_dbg[(uint64_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define MEE_STL(i) do { } while (0)
+#endif
+// a barrier that waits for this wave's LDS traffic only: __syncthreads() also drains the global stores in flight (s_waitcnt vmcnt(0)) — here the key / count /
+// inverse stores of a pass, which nothing in the block reads back; their acknowledgement is 3-5 us under load, twice per pass
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 struct D4 { double x, y, z, w; };
 __device__ __forceinline__ D4 d4_tiles_sum(D4 v) {   // over the wave's four tiles (lanes l, l ^ 16, l ^ 32, l ^ 48)
     v.x += __shfl_xor(v.x, 16); v.y += __shfl_xor(v.y, 16); v.z += __shfl_xor(v.z, 16); v.w += __shfl_xor(v.w, 16);
@@ -601,7 +614,12 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
     __shared__ SumLds L;
     uint32_t parity, before;
     HotPlan P;
+    MEE_STL(0);
     const uint32_t size = dd_bucket<true, kSumWindow>(L.d, bk, A.d, parity, P, before);
+    MEE_STL(1);   // the bucket's totals, runs and prefix are in
+#if MEE_SUM_TIMELINE
+    if (threadIdx.x == 0 && g_sum_dbg && blockIdx.x < 8192) g_sum_dbg[(uint64_t)blockIdx.x * 16 + 15] = (unsigned long long)size | (unsigned long long)(dd_unit(A.d) >= A.d.nbk) << 32;
+#endif
     if (size == 0) return;
     const uint32_t dim4 = DIM4 ? DIM4 : A.dim4;
     const uint32_t t = threadIdx.x, lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6, T = wv * 4 + tile;
@@ -612,7 +630,7 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
             const int64_t key = bk.pkey[dd_entry_at(L.d, 0)];
             A.d.uniq[P.rank] = key;
             if (A.counts) A.counts[P.rank] = size;
-            if (size >= A.d.hot_count) report_hot_key(bk, parity, key);   // stays listed while it stays hot
+            if (size >= A.d.hot_count) report_hot_key(bk, parity, key, size >= 8 * A.d.hot_count);   // stays listed while it stays hot
         }
         {   // the window's positions: four in flight per thread (kSumWindow = 4 x 256)
             uint32_t pp[4];
@@ -651,6 +669,7 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
     uint32_t slice = P.H + before, src_at = before;
     dd_passes<false>(L.d, bk, size, parity, A.d.hot_count, A.d.status, [&](uint32_t bits, uint64_t val, const DdHeld& held) {
         const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
+        MEE_STL(2);   // entries fetched, keys in the LDS table
         // -- 1. run numbers (short runs first, then medium, then long) and the runs' places in the sorted source list: ONE block scan over the table's slots
         constexpr uint32_t per = kDedupSlots / kDedupThreads;
         unsigned long long mine = 0;
@@ -680,7 +699,8 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
                 if (A.counts) A.counts[base + idx] = c;
             }
         }
-        __syncthreads();
+        lds_barrier();
+        MEE_STL(3);   // scan done, keys and counts written
         // -- 2. every entry of the pass looks its key up: the key's number into d_inverse; a bucket beyond the LDS list files its positions in the global list at once
         uint32_t my_sl[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         if (in_lds) {
@@ -709,7 +729,7 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
             }
         }
         if (!A.grads) return;   // (grid-uniform) keys, counts and inverse only
-        __syncthreads();   // nobody looks a key up any more: the key table's space becomes src / items / prow (and the stores of the global list are drained)
+        if (in_lds) lds_barrier(); else __syncthreads();   // nobody looks a key up any more: the key table's space becomes src / items / prow (beyond the LDS list: the stores of the global list are drained)
         // -- 2b. the LDS list (positions sorted by run, through each run's cursor) and the run list (run number -> slot)
         if (in_lds) {
 #pragma unroll
@@ -717,7 +737,8 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
         }
 #pragma unroll
         for (uint32_t q = 0; q < per; ++q) { const uint32_t sl = t * per + q; if (L.d.cnt[sl]) L.items()[L.d.val[sl]] = (uint16_t)sl; }
-        __syncthreads();
+        lds_barrier();
+        MEE_STL(4);   // look-ups, inverse, sorted source list
         // from here on run sl's sources are [L.off[sl] - cnt, L.off[sl]) of the list
         auto source = [&](uint32_t at) -> uint32_t { return in_lds ? L.src()[at] : __hip_atomic_load(&srcg[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         // -- 3. long runs: the whole block, one after the other (the block-level sums use prow: all threads pass the barriers inside)
@@ -735,6 +756,7 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
                 if (tile == 0 && col < dim4) store_sum4(A.gsum, base + idx, dim4, col, v);
             }
         }
+        MEE_STL(5);   // long and medium runs summed
         // -- 5. short runs: a tile each, FOUR runs in flight per tile.  Four keys that occur once — the bulk of every batch — are four streamed rows in, four rows
         // out, bit for bit (no arithmetic), software-pipelined: the NEXT four rows are requested before the current four are stored, so that a step waits for its
         // loads only (the memory counter retires in order: loads issued behind stores would wait for the stores' acknowledgement as well).  Anything else: each run
@@ -794,6 +816,10 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
                 for (uint32_t q = 0; q < 4; ++q) g[q] = gn[q];
             }
         }
+#if MEE_SUM_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        MEE_STL(6);   // thread 0's short runs done
     });
 }
 
@@ -848,6 +874,19 @@ int bucket_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, 
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
+
+#if MEE_SUM_TIMELINE
+extern "C" int mee_debug_sum_timeline(unsigned long long* host_out, uint64_t n_words) {   // first call arms the buffer, later calls read it
+    static unsigned long long* buf = nullptr;
+    if (!buf) {
+        if (hipMalloc((void**)&buf, 8192 * 16 * 8) != hipSuccess) return 1;
+        (void)hipMemset(buf, 0, 8192 * 16 * 8);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sum_dbg), &buf, sizeof buf);
+        return 0;
+    }
+    return hipMemcpy(host_out, buf, n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+#endif
 
 int bucket_assign(mee_table* t, float* plane, const int64_t* d_keys, const float* d_values, uint32_t n, uint8_t* d_found, hipStream_t st) {
     AssignArgs A{};

@@ -14,7 +14,10 @@ Design (host logic only; every row still moves through the HIP kernels):
   * placement policy (tables created with track_hits=True): every cold hit and every `sample_every`-th hot lookup bumps
     a per-slot counter inside the find kernel; `rebalance()` promotes the cold keys that were hit at least
     `promote_threshold` times in the window and, when the hot tier is full, first demotes hot keys that no sampled
-    lookup touched.  It is meant to run between steps (on a side stream if the caller wants it off the critical path).
+    lookup touched.  It runs BETWEEN steps, on the stream the steps run on: its moves are mutators of both tables (they share the tables'
+    per-batch scratch with the step's operators and read rows the next update writes), so they are ordered with them, not beside them.
+  * in a training loop (`rebalance_every` = K): the pair runs `rebalance()` itself behind every K-th optimizer step — the
+    forward lookups of those K steps are the observation window.
 
 `hot` / `cold` are any objects with the LookupTable methods, so the logic also runs on the CPU test adapters.
 """
@@ -24,7 +27,8 @@ import torch
 
 
 class TieredLookupTable:
-    def __init__(self, hot, cold, hot_key_limit: int | None = None, sample_every: int = 8, promote_threshold: int = 2):
+    def __init__(self, hot, cold, hot_key_limit: int | None = None, sample_every: int = 8, promote_threshold: int = 2,
+                 rebalance_every: int = 0, rebalance_max_moves: int = 1 << 20):
         if hot.dim != cold.dim:
             raise ValueError("hot and cold tables must have the same dim")
         self.hot, self.cold, self.dim = hot, cold, hot.dim
@@ -35,6 +39,10 @@ class TieredLookupTable:
         self.policy = bool(getattr(hot, "track_hits", False) and getattr(cold, "track_hits", False))
         self.sample_every, self.promote_threshold = max(1, sample_every), promote_threshold
         self._calls = 0
+        # the training loop's policy knob: a rebalance behind every rebalance_every-th apply_* (0 = the caller runs rebalance() itself)
+        self.rebalance_every, self.rebalance_max_moves = max(0, int(rebalance_every)), int(rebalance_max_moves)
+        self._train_steps = 0
+        self.rebalance_log: list[tuple[int, int, int]] = []   # (optimizer step, promoted, demoted)
 
     # -- helpers -----------------------------------------------------------------------------------------
     @staticmethod
@@ -116,15 +124,25 @@ class TieredLookupTable:
             self.cold.find_or_insert_missing(keys, out, found)
         return out, found
 
+    def _after_optimizer_step(self) -> None:
+        if not (self.policy and self.rebalance_every):
+            return
+        self._train_steps += 1
+        if self._train_steps % self.rebalance_every == 0:
+            p, d = self.rebalance(self.rebalance_max_moves)
+            self.rebalance_log.append((self._train_steps, int(p), int(d)))
+
     def apply_adagrad(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, eps: float = 1e-10) -> None:
         # a key lives in one tier and each table ignores keys it does not hold: both see the whole batch
         self.hot.apply_adagrad(keys, grads, lr, eps)
         self.cold.apply_adagrad(keys, grads, lr, eps)
+        self._after_optimizer_step()
 
     def apply_adam(self, keys: torch.Tensor, grads: torch.Tensor, lr: float, beta1: float = 0.9, beta2: float = 0.999,
                    eps: float = 1e-8, step: int = 1) -> None:
         self.hot.apply_adam(keys, grads, lr, beta1, beta2, eps, step)
         self.cold.apply_adam(keys, grads, lr, beta1, beta2, eps, step)
+        self._after_optimizer_step()
 
     # duplicate reductions touch no table row, only a table's per-batch scratch: the hot table lends its own
     def dedup_keys(self, keys: torch.Tensor, miss_index: int = -1):

@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -37,7 +38,7 @@ constexpr int kSlots = 4;
 constexpr double kTimeoutS = 120.0;
 
 struct Box {
-    volatile uint64_t head, tail;   // messages produced / consumed
+    uint64_t head, tail;            // messages produced / consumed (acquire / release accesses: ld / st below)
     uint64_t bytes[kSlots];
     char pad[4096 - 16 - 8 * kSlots];
 };
@@ -56,6 +57,8 @@ struct Op { bool send; void* buf; size_t bytes; int peer; FakeComm* comm; hipStr
 thread_local int g_depth = 0;
 thread_local std::vector<Op> g_ops;
 
+inline uint64_t ld(const uint64_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+inline void st(uint64_t* p, uint64_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 double now_s() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -80,34 +83,31 @@ ncclResult_t do_send(const Op& o) {
     if (o.bytes > c->slot_bytes) { fprintf(stderr, "fake_rccl: message of %zu bytes exceeds the slot (%zu): raise MEE_FAKE_RCCL_SLOT_MB\n", o.bytes, c->slot_bytes); return ncclInvalidArgument; }
     Box* b = c->box(c->rank, o.peer);
     const double t0 = now_s();
-    while (b->head - b->tail >= kSlots) {
+    while (ld(&b->head) - ld(&b->tail) >= kSlots) {
         if (now_s() - t0 > kTimeoutS) return ncclSystemError;
         usleep(50);
     }
-    const uint64_t seq = b->head;
+    const uint64_t seq = ld(&b->head);
     if (hipMemcpy(c->data(b, seq), o.buf, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
     b->bytes[seq % kSlots] = o.bytes;
-    __sync_synchronize();
-    b->head = seq + 1;
+    st(&b->head, seq + 1);
     return ncclSuccess;
 }
 ncclResult_t do_recv(const Op& o) {
     FakeComm* c = o.comm;
     Box* b = c->box(o.peer, c->rank);
     const double t0 = now_s();
-    while (b->head == b->tail) {
+    while (ld(&b->head) == ld(&b->tail)) {
         if (now_s() - t0 > kTimeoutS) return ncclSystemError;
         usleep(50);
     }
-    __sync_synchronize();
-    const uint64_t seq = b->tail;
+    const uint64_t seq = ld(&b->tail);
     if (b->bytes[seq % kSlots] != o.bytes) {
         fprintf(stderr, "fake_rccl: rank %d expects %zu bytes from rank %d, the message holds %llu\n", c->rank, o.bytes, o.peer, (unsigned long long)b->bytes[seq % kSlots]);
         return ncclInvalidUsage;
     }
     if (hipMemcpy(o.buf, c->data(b, seq), o.bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
-    __sync_synchronize();
-    b->tail = seq + 1;
+    st(&b->tail, seq + 1);
     return ncclSuccess;
 }
 ncclResult_t run(std::vector<Op>& ops) {
@@ -207,7 +207,7 @@ ncclResult_t ncclGroupEnd() {
     if (g_depth <= 0) return ncclInvalidUsage;
     if (--g_depth > 0) return ncclSuccess;
     // test hook: the MEE_FAKE_RCCL_FAIL_GROUP-th outermost ncclGroupEnd of the process (1-based) fails — the library's abort path
-    static int n_groups = 0;
+    static std::atomic<int> n_groups{0};   // (ranks may be threads of one process)
     static const int fail_at = getenv("MEE_FAKE_RCCL_FAIL_GROUP") ? atoi(getenv("MEE_FAKE_RCCL_FAIL_GROUP")) : 0;
     if (++n_groups == fail_at) { g_ops.clear(); return ncclSystemError; }
     std::vector<Op> ops;
@@ -229,7 +229,7 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, n
     FakeComm* c = reinterpret_cast<FakeComm*>(comm);
     if (datatype != ncclUint64 || op != ncclSum || count > 64) return ncclInvalidArgument;
     // test hook: the MEE_FAKE_RCCL_FAIL_ALLREDUCE-th ncclAllReduce of the process (1-based) fails — the library's abort path at world 1
-    static int n_allreduce = 0;
+    static std::atomic<int> n_allreduce{0};
     static const int fail_ar = getenv("MEE_FAKE_RCCL_FAIL_ALLREDUCE") ? atoi(getenv("MEE_FAKE_RCCL_FAIL_ALLREDUCE")) : 0;
     if (++n_allreduce == fail_ar) return ncclSystemError;
     if (!c->base) { fprintf(stderr, "fake_rccl: ncclAllReduce on an aborted communicator (use after free)\n"); abort(); }

@@ -125,3 +125,43 @@ def test_policy_moves_the_hot_set_into_hbm(dev):
     last = cold_share(batch())
     assert first > 0.99 and last < 0.35, (first, last)
     assert hot.size() <= hot_limit and hot.size() + cold.size() == n_keys
+
+
+@pytest.mark.gpu
+def test_training_loop_rebalances_itself(dev):
+    """rebalance_every = K: the pair runs its placement policy behind every K-th optimizer step of a find + sparse-Adagrad loop — keys move between
+    the tiers WITH their accumulators while the loop trains them —, the cold share of the lookups collapses, and the trained pair equals ONE oracle
+    table that saw the same steps (SPEC.md §3-§4: placement is not observable)."""
+    from meepoembedding_amd import OPT_ADAGRAD, LookupTable, _lib
+    n_keys, hot_limit, dim = 20000, 2500, 16
+    hot = LookupTable(4096, dim, device=dev, max_batch=8192, track_hits=True, optimizer=OPT_ADAGRAD, initial_accumulator=0.1)
+    cold = LookupTable(32768, dim, device=dev, max_batch=32768, value_memory=_lib.MEM_HOST_PINNED, track_hits=True, optimizer=OPT_ADAGRAD, initial_accumulator=0.1)
+    o = oracle.OracleTable(65536, dim, optimizer=oracle.OPT_ADAGRAD, initial_accumulator=0.1)
+    keys = synth.keys_np(34, 0, n_keys); rows = synth.rows_np(keys, dim, 2)
+    cold.insert(torch.from_numpy(keys).to(dev), torch.from_numpy(rows).to(dev)); o.insert(keys, rows)
+    t = TieredLookupTable(hot, cold, hot_key_limit=hot_limit, sample_every=2, promote_threshold=2, rebalance_every=5, rebalance_max_moves=4000)
+    rng = np.random.default_rng(6)
+    shares = []
+    for step in range(30):
+        b = keys[np.minimum(rng.zipf(1.2, size=6000) - 1, n_keys - 1)]
+        g = (rng.standard_normal((b.size, dim)) * 0.01).astype(np.float32)
+        bt = torch.from_numpy(b).to(dev)
+        if step % 5 == 0:
+            shares.append(1.0 - float(hot.find(bt)[1].float().mean()))
+        out, found = t.find(bt)
+        eo, ef = o.find(b)
+        assert bool(found.all()) and np.array_equal(found.cpu().numpy(), ef)
+        np.testing.assert_allclose(out.cpu().numpy(), eo, rtol=1e-6, atol=1e-9)
+        t.apply_adagrad(bt, torch.from_numpy(g).to(dev), lr=0.05)
+        o.apply_adagrad(b, g, 0.05, 1e-10)
+    assert len(t.rebalance_log) == 6 and sum(p for _, p, _ in t.rebalance_log) > 0
+    assert shares[0] > 0.99 and shares[-1] < 0.35, shares
+    assert hot.size() <= hot_limit and hot.size() + cold.size() == n_keys and hot.status() == 0 and cold.status() == 0
+    ek = torch.cat([hot.export(with_state=True)[0], cold.export(with_state=True)[0]]).cpu().numpy()
+    ev = torch.cat([hot.export(with_state=True)[1], cold.export(with_state=True)[1]]).cpu().numpy()
+    ea = torch.cat([hot.export(with_state=True)[2], cold.export(with_state=True)[2]]).cpu().numpy()
+    ok, ov, oa, _ = o.export(with_state=True)
+    a, b_ = np.argsort(ek), np.argsort(ok)
+    assert np.array_equal(ek[a], ok[b_])
+    np.testing.assert_allclose(ev[a], ov[b_], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(ea[a], oa[b_], rtol=1e-6, atol=1e-9)

@@ -1,0 +1,43 @@
+"""Phase timeline of mee_dedup_sum's blocks (diagnostic build: MEE_VARIANT_TU=meepo_dedup tools/build_variant.sh stl -DMEE_SUM_TIMELINE=1; run with
+MEE_LIB_PATH=build/libmeepo_hip_stl.so).  Stamps per block (100 MHz wall clock): 0 entry, 1 totals / runs / prefix in, 2 entries fetched + keys in the LDS
+table, 3 scan done + keys and counts written, 4 look-ups + inverse + sorted source list, 5 long and medium runs, 6 short runs (thread 0).
+usage: sum_timeline.py [uniform|zipf] [batch]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from meepoembedding_amd import LookupTable, synth, _lib
+dev = torch.device("cuda", 0)
+dist = sys.argv[1] if len(sys.argv) > 1 else "uniform"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
+keys_n, dim = 100_000_000, 64
+t = LookupTable(64, dim, device=dev, max_batch=batch)
+bs = bench.lookup_batches(synth, keys_n, batch, 4, dist, dev, seed=3)
+rows = torch.randn(batch, dim, device=dev)
+L = _lib.lib()
+L.mee_debug_sum_timeline.argtypes = [C.c_void_p, C.c_uint64]; L.mee_debug_sum_timeline.restype = C.c_int
+for i in range(6):
+    t.dedup_sum(bs[i % 4], rows)
+    torch.cuda.synchronize()
+assert L.mee_debug_sum_timeline(None, 0) == 0          # arm
+t.dedup_sum(bs[2], rows)
+torch.cuda.synchronize()
+buf = np.zeros(8192 * 16, dtype=np.uint64)
+assert L.mee_debug_sum_timeline(buf.ctypes.data, buf.size) == 0
+tl = buf.reshape(8192, 16)
+used = tl[:, 0] != 0
+size = (tl[:, 15] & 0xFFFFFFFF).astype(np.int64); window = (tl[:, 15] >> 32) != 0
+us = tl[:, :7].astype(np.float64) * 0.01
+t0 = us[used, 0].min()
+print(f"{dist}, {batch} keys: {int(used.sum())} blocks stamped, {int((used & window).sum())} of them windows of hot keys' buckets; sizes: median {np.median(size[used & ~window & (size > 0)]):.0f}, max {size[used].max()}")
+print(f"block start relative to the first: median {np.median(us[used, 0] - t0):.1f} us, p90 {np.percentile(us[used, 0] - t0, 90):.1f}, max {(us[used, 0] - t0).max():.1f}")
+names = ["totals / runs / prefix (first round trip)", "entries fetched + keys into the LDS table", "scan + keys and counts written", "look-ups + inverse + sorted source list", "long + medium runs", "short runs (thread 0's tile)"]
+hb = used & ~window & (us[:, 6] > 0)
+for k in range(6):
+    d = us[hb, k + 1] - us[hb, k]
+    print(f"  {names[k]:46s} median {np.median(d):7.2f} us   p10 {np.percentile(d, 10):7.2f}   p90 {np.percentile(d, 90):7.2f}   max {d.max():7.2f}")
+life = us[hb, 6] - us[hb, 0]
+print(f"  hash-bucket block life: median {np.median(life):.1f} us, p90 {np.percentile(life, 90):.1f}, max {life.max():.1f}; last end {us[hb, 6].max() - t0:.1f} us after the first start")
+wb = used & window
+if wb.any():
+    print(f"  window blocks: start median {np.median(us[wb, 0] - t0):.1f} us, first phase {np.median(us[wb, 1] - us[wb, 0]):.1f} us (their later phases are not stamped)")
