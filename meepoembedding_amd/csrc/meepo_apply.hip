@@ -341,8 +341,9 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
 #pragma unroll
                 for (uint32_t stp = kPartBlocks / 2; stp; stp >>= 1) if (L.seg_first[k + stp] <= gi) k += stp;
                 const uint32_t at = L.seg_at[k] + (gi - L.seg_first[k]);
-                const uint32_t p = bk.pos[at];
-                my_key[u] = bk.pkey[at];
+                const PartEntry en = bk.ent[at];
+                const uint32_t p = en.pos;
+                my_key[u] = en.key;
                 my_src[u] = A.gidx ? min(A.gidx[p], a.grad_rows - 1) : p;   // the row of the grad array that belongs to the position
                 if constexpr (LOCATED) my_tslot[u] = A.slots[p];   // the raw handle: decoded where it is first needed, so that the load travels beside the LDS work
             }
@@ -971,7 +972,7 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
         __syncthreads();
         unsigned long long mn = ~0ull;
         for (uint32_t e = t; e < size; e += kApplyThreads) {
-            const int64_t k = bk.pkey[bucket_entry_at(L, e)];
+            const int64_t k = bk.ent[bucket_entry_at(L, e)].key;
             const unsigned long long bkey = (unsigned long long)k ^ kBias;
             if ((!have_last || bkey > last) && bkey < mn && slow_share_of(k, n_sub) == sub) mn = bkey;
         }
@@ -995,8 +996,9 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
                 __syncthreads();
                 for (uint32_t e = e0 + t; e < min(size, e0 + kBucketCap); e += kApplyThreads) {
                     const uint32_t at = bucket_entry_at(L, e);
-                    if (((unsigned long long)bk.pkey[at] ^ kBias) != cur) continue;
-                    const uint32_t p = bk.pos[at];
+                    const PartEntry en = bk.ent[at];
+                    if (((unsigned long long)en.key ^ kBias) != cur) continue;
+                    const uint32_t p = en.pos;
                     const uint32_t q = atomicAdd(&L.n_cand, 1u);
                     L.src[q] = A.gidx ? min(A.gidx[p], a.grad_rows - 1) : p;
                     if constexpr (LOCATED) if (q == 0) L.slot[0] = A.slots[p];   // every occurrence of a key names the same slot
@@ -1250,10 +1252,9 @@ int bucket_scratch_alloc(mee_table* t) {
     bk.n_buckets_max += kHotCap;
     if (bk.n_buckets_max > kMaxBuckets) bk.n_buckets_max = kMaxBuckets;
     bk.n_buckets_max = (bk.n_buckets_max + 63u) & ~63u;
-    bk.pos = t->bs.occ;   // max_batch entries; mee_dedup (the group-table reduction that also sums rows) and a partition never run at the same time on one table
     hipError_t e = hipSuccess;
     auto alloc = [&](void** p, uint64_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes); if (e == hipSuccess) t->workspace_bytes += bytes; } };
-    alloc((void**)&bk.pkey, bk.fast_max * 8);
+    alloc((void**)&bk.ent, bk.fast_max * sizeof(PartEntry));
     alloc((void**)&bk.cnt_mat, (uint64_t)kPartBlocksMax * bk.n_buckets_max * 4);
     alloc((void**)&bk.off_mat, (uint64_t)kPartBlocksMax * bk.n_buckets_max * 4);
     alloc((void**)&bk.tot, 2ull * bk.n_buckets_max * 4);
@@ -1288,7 +1289,7 @@ int bucket_scratch_alloc(mee_table* t) {
 }
 void bucket_scratch_free(mee_table* t) {
     BucketScratch& bk = t->bk;
-    void* dev[] = {bk.pkey, bk.cnt_mat, bk.off_mat, bk.tot, bk.seq, bk.hot_key, bk.hot_idx, bk.hot_n, bk.pend_cnt, bk.ticket, bk.pend_key, bk.pend_slot, bk.pend_row, bk.sum_part};
+    void* dev[] = {bk.ent, bk.cnt_mat, bk.off_mat, bk.tot, bk.seq, bk.hot_key, bk.hot_idx, bk.hot_n, bk.pend_cnt, bk.ticket, bk.pend_key, bk.pend_slot, bk.pend_row, bk.sum_part};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (bk.h_slabs) (void)hipHostFree(bk.h_slabs);
     if (bk.dev_copy) (void)hipFree(bk.dev_copy);

@@ -277,8 +277,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
         for (int q = 0; q < kKeyGroup; ++q) {
             if (reserved_key(kr[q])) continue;
             const uint32_t r = lo + atomicAdd(&cursor[kKeepBuckets ? (bid[q / 2] >> (q & 1 ? 16 : 0)) & 0xFFFFu : part_bucket_of(kr[q], nbk_hash, nbk, hot, xcd_split)], 1u);
-            bk.pos[r] = lo + threadIdx.x + q * THREADS;
-            bk.pkey[r] = kr[q];
+            bk.ent[r] = PartEntry{kr[q], lo + threadIdx.x + q * THREADS, 0u};
         }
     } else {
         for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += kKeyGroup * THREADS) {
@@ -289,8 +288,7 @@ __device__ __forceinline__ void sort_role(const int64_t* __restrict__ keys, uint
             for (int q = 0; q < kKeyGroup; ++q) {
                 if (reserved_key(k[q])) continue;
                 const uint32_t r = lo + atomicAdd(&cursor[part_bucket_of(k[q], nbk_hash, nbk, hot, xcd_split)], 1u);
-                bk.pos[r] = i0 + q * THREADS;
-                bk.pkey[r] = k[q];
+                bk.ent[r] = PartEntry{k[q], i0 + q * THREADS, 0u};
             }
         }
     }

@@ -109,8 +109,9 @@ __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, u
             kq[q] = kEmpty; pq[q] = 0u;
             if (e < size) {
                 const uint32_t at = dd_entry_at(L, e);
-                kq[q] = bk.pkey[at];
-                if (LAST || H.valid) pq[q] = bk.pos[at];
+                const PartEntry en = bk.ent[at];
+                kq[q] = en.key;
+                if (LAST || H.valid) pq[q] = en.pos;
             }
         }
         if (H.valid) {
@@ -294,14 +295,14 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
     if (dd_unit(A) >= A.nbk) {   // ---- a window of a hot key's own bucket: every entry is that key, its number is P.rank
         const uint32_t lo = P.win * kHotWindow, hi = min(size, lo + kHotWindow);
         if (P.win == 0 && threadIdx.x == 0) {
-            const int64_t key = bk.pkey[dd_entry_at(L, 0)];
+            const int64_t key = bk.ent[dd_entry_at(L, 0)].key;
             A.uniq[P.rank] = key;
             if (size >= A.hot_count) report_hot_key(bk, parity, key, size >= 8 * A.hot_count);   // stays listed while it stays hot
         }
         for (uint32_t e0 = lo; e0 < hi; e0 += 4 * kDedupThreads) {   // four positions in flight per thread (a window is 16 per thread: 4 round trips, not 16)
             uint32_t pp[4];
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = e0 + q * kDedupThreads + threadIdx.x; pp[q] = e < hi ? bk.pos[dd_entry_at(L, e)] : 0xFFFFFFFFu; }
+            for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = e0 + q * kDedupThreads + threadIdx.x; pp[q] = e < hi ? bk.ent[dd_entry_at(L, e)].pos : 0xFFFFFFFFu; }
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) if (pp[q] != 0xFFFFFFFFu) A.inverse[pp[q]] = (int64_t)P.rank;
         }
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
             for (int q = 0; q < 4; ++q) {
                 const uint32_t e = e0 + (uint32_t)q * kDedupThreads + t;
                 kq[q] = kEmpty; pq[q] = 0u;
-                if (e < size) { const uint32_t at = dd_entry_at(L, e); kq[q] = bk.pkey[at]; pq[q] = bk.pos[at]; }
+                if (e < size) { const PartEntry en = bk.ent[dd_entry_at(L, e)]; kq[q] = en.key; pq[q] = en.pos; }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -392,13 +393,13 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
         const uint32_t t = threadIdx.x, b = A.d.nbk_hash + P.h;
         const int lane = t & 63, tile = lane >> 4, tl = lane & 15;
         const uint32_t lo = P.win * kHotWindow, hi = min(size, lo + kHotWindow);
-        const int64_t key = bk.pkey[dd_entry_at(L, 0)];
+        const int64_t key = bk.ent[dd_entry_at(L, 0)].key;
         // the window's last position -> the bucket's (atomicMax on the bucket's word; the partition zeroed it)
         uint32_t pm = 0;
         for (uint32_t e0 = lo; e0 < hi; e0 += 4 * kDedupThreads) {   // four positions in flight per thread
             uint32_t pp[4];
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = e0 + q * kDedupThreads + t; pp[q] = e < hi ? 1u + bk.pos[dd_entry_at(L, e)] : 0u; }
+            for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = e0 + q * kDedupThreads + t; pp[q] = e < hi ? 1u + bk.ent[dd_entry_at(L, e)].pos : 0u; }
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) pm = max(pm, pp[q]);
         }
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
             for (uint32_t e0 = lo; e0 < hi; e0 += 4 * kDedupThreads) {
                 uint32_t pp[4];
 #pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = e0 + q * kDedupThreads + t; pp[q] = e < hi ? bk.pos[dd_entry_at(L, e)] : 0xFFFFFFFFu; }
+                for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = e0 + q * kDedupThreads + t; pp[q] = e < hi ? bk.ent[dd_entry_at(L, e)].pos : 0xFFFFFFFFu; }
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q) if (pp[q] != 0xFFFFFFFFu) A.found[pp[q]] = 0;
             }
@@ -505,9 +506,10 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
             const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
             for (uint32_t e = t; e < size; e += kDedupThreads) {
                 const uint32_t at = dd_entry_at(L, e);
-                const int64_t key = bk.pkey[at];
+                const PartEntry en = bk.ent[at];
+                const int64_t key = en.key;
                 if ((mix64b((uint64_t)key) & mask) != val) continue;
-                if (L.val[dd_lookup(L, (unsigned long long)key ^ kBias)] == 0u) A.found[bk.pos[at]] = 0;
+                if (L.val[dd_lookup(L, (unsigned long long)key ^ kBias)] == 0u) A.found[en.pos] = 0;
             }
         }
     });
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
         const uint32_t x = dd_unit(A.d) - A.d.nbk, b = A.d.nbk_hash + P.h;
         const uint32_t lo = P.win * kSumWindow, c = min(size, lo + kSumWindow) - lo;
         if (P.win == 0 && t == 0) {
-            const int64_t key = bk.pkey[dd_entry_at(L.d, 0)];
+            const int64_t key = bk.ent[dd_entry_at(L.d, 0)].key;
             A.d.uniq[P.rank] = key;
             if (A.counts) A.counts[P.rank] = size;
             if (size >= A.d.hot_count) report_hot_key(bk, parity, key, size >= 8 * A.d.hot_count);   // stays listed while it stays hot
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
         {   // the window's positions: four in flight per thread (kSumWindow = 4 x 256)
             uint32_t pp[4];
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = q * kDedupThreads + t; pp[q] = e < c ? bk.pos[dd_entry_at(L.d, lo + e)] : 0xFFFFFFFFu; }
+            for (uint32_t q = 0; q < 4; ++q) { const uint32_t e = q * kDedupThreads + t; pp[q] = e < c ? bk.ent[dd_entry_at(L.d, lo + e)].pos : 0xFFFFFFFFu; }
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) if (pp[q] != 0xFFFFFFFFu) { L.src()[q * kDedupThreads + t] = pp[q]; if (A.d.inverse) A.d.inverse[pp[q]] = (int64_t)P.rank; }
         }
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t e = e0 + (uint32_t)q * kDedupThreads + t;
                     kq[q] = kEmpty; pq[q] = 0u;
-                    if (e < size) { const uint32_t at = dd_entry_at(L.d, e); kq[q] = bk.pkey[at]; pq[q] = bk.pos[at]; }
+                    if (e < size) { const PartEntry en = bk.ent[dd_entry_at(L.d, e)]; kq[q] = en.key; pq[q] = en.pos; }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {

@@ -48,9 +48,12 @@ struct BatchScratch {          // max_batch entries, indexed by batch position u
 
 
 // ---- the bucketed apply (meepo_apply.hip): per-call scratch, all device resident ----------------------------------------------------
+// One entry of a partitioned batch: a key and its batch position, 16 bytes — ONE store when the partition files it, ONE load when a consumer pulls it out of a
+// run (rounds 3-4 kept positions and keys in two arrays: a run of 2-5 entries touched a line of each; a bucket's ~128 short runs are where the consumers' first
+// phase spends its bytes — 100 MB of line fetches for the 12.6 MB of entries of a 1M-key batch, `profiles/r05_dedup.md`)
+struct alignas(16) PartEntry { int64_t key; uint32_t pos; uint32_t pad; };
 struct BucketScratch {
-    uint32_t* pos;        // [fast_max] batch positions: partition block k's share of the batch, sorted by hash bucket, in slice k (aliases BatchScratch::occ)
-    int64_t* pkey;        // [fast_max] their keys, in the same order
+    PartEntry* ent;       // [fast_max] the batch's (key, position) entries: partition block k's share of the batch, sorted by hash bucket, in slice k
     uint32_t* cnt_mat;    // [kPartBlocksMax][n_buckets_max] keys of each bucket held by each partition block …
     uint32_t* off_mat;    // … and where that run starts inside the block's slice of pos / pkey
     uint32_t* tot;        // [2][n_buckets_max] keys per bucket (added up by the partition blocks); two copies, used alternately
