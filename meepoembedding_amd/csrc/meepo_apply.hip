@@ -950,106 +950,202 @@ __device__ __forceinline__ uint32_t slow_share_of(int64_t key, uint32_t n_sub) {
 // A split bucket in the LEAN kernel (below): its own block and up to 64 helpers — the blocks of the buckets behind it, once they are done with
 // their own — share its KEYS by a second hash (slow_share_of); each takes its keys one at a time in increasing key order — pick the smallest key not yet
 // done (one scan of the bucket's keys), add up its gradient rows (a second scan finds them, 1024 entries at a time; 32 tiles sum, shuffles and
-// LDS combine), update its row once.  O(distinct keys x bucket size) key reads from L2: a bucket of 15 000 positions around one hot key
-// took 2-4 ms with ONE block (and every batch the host had queued before the first one's report came back paid it again); shared, the hot
-// key's block sets the time: ~0.1-0.3 ms.  This is the price of the first skewed batches of a stream: the keys they report as hot and the slab count left in
-// the pinned host word switch the following batches to the FULL kernel.  No pending records, no merge, no scratch.
+// LDS combine), update its row once.  O(distinct keys x bucket size) key reads from L2.  This is the price of the first skewed batches of a stream: the keys
+// they report as hot and the slab count left in the pinned host word switch the following batches to the FULL kernel.  No merge tables, no scratch.
+// Round 5: the bucket's MAJORITY key — a bucket is split because one key fills it: 14 000 of 15 000 positions — is no longer ONE share's work (15 windows of
+// 1024 entries one after the other: 0.3-0.6 ms): every share sums the key's rows in its own windows (window w belongs to share w mod n_sub), leaves ONE fp64
+// partial row, draws a ticket, and the share that draws the last one adds the <= 65 partial rows up and updates the key (the pending-record discipline of the
+// FULL kernel: write-through stores drained before the ticket, agent-scope loads, no fence).
+
+// the rows of key `cur` (biased) in the bucket's windows win0, win0 + win_step, ... (1024 entries each), columns [c0, c0 + 16): their fp64 sum is left in L.prow[8]
+// (valid for every thread after the function's last barrier); returns how many occurrences those windows held
+template <bool LOCATED>
+__device__ __forceinline__ uint32_t slow_sum_key(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t size, const unsigned long long cur, const uint32_t c0,
+                                                 const uint32_t dim4, const uint32_t win0, const uint32_t win_step, const uint32_t grad_rows) {
+    const uint32_t t = threadIdx.x;
+    const int lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6;
+    const uint32_t col = c0 + (uint32_t)tl;
+    const bool cok = col < dim4;
+    __syncthreads();
+    if (t < 16) { double* r = &L.prow[8][tl * 4]; r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; r[3] = 0.0; }
+    uint32_t total = 0;
+    for (uint32_t e0 = win0 * kBucketCap; e0 < size; e0 += win_step * kBucketCap) {
+        __syncthreads();
+        if (t == 0) L.n_cand = 0u;
+        __syncthreads();
+        for (uint32_t e = e0 + t; e < min(size, e0 + kBucketCap); e += kApplyThreads) {
+            const PartEntry en = bk.ent[bucket_entry_at(L, e)];
+            if (((unsigned long long)en.key ^ kBias) != cur) continue;
+            const uint32_t p = en.pos;
+            const uint32_t q = atomicAdd(&L.n_cand, 1u);
+            L.src[q] = A.gidx ? min(A.gidx[p], grad_rows - 1) : p;
+            if constexpr (LOCATED) if (q == 0) L.slot[0] = A.slots[p];   // every occurrence of a key names the same slot
+        }
+        __syncthreads();
+        const uint32_t nc = L.n_cand;
+        total += nc;
+        if (nc == 0) continue;   // block-uniform
+        double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+        for (uint32_t q0 = (uint32_t)wv * 4 + tile; q0 < nc; q0 += 4 * 4 * kApplyWaves) {   // four rows in flight per tile
+            float4 g[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = cok ? A.grads[(uint64_t)L.src[min(q0 + (uint32_t)q * 4 * kApplyWaves, nc - 1)] * dim4 + col] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool on = q0 + (uint32_t)q * 4 * kApplyWaves < nc;
+                sx += on ? (double)g[q].x : 0.0; sy += on ? (double)g[q].y : 0.0; sz += on ? (double)g[q].z : 0.0; sw += on ? (double)g[q].w : 0.0;
+            }
+        }
+        sx = tiles_sum(sx); sy = tiles_sum(sy); sz = tiles_sum(sz); sw = tiles_sum(sw);
+        if (tile == 0) { double* d = &L.prow[wv][tl * 4]; d[0] = sx; d[1] = sy; d[2] = sz; d[3] = sw; }
+        __syncthreads();
+        if (t < 16) {
+            double* r = &L.prow[8][tl * 4];
+            for (int w = 0; w < kApplyWaves; ++w) { const double* d = &L.prow[w][tl * 4]; r[0] += d[0]; r[1] += d[1]; r[2] += d[2]; r[3] += d[3]; }
+        }
+    }
+    __syncthreads();
+    return total;
+}
+
+// one update of columns [c0, c0 + 16) of `key`'s row from the fp64 sum in L.prow[8] (wave 0; its tile 0 holds the row)
 template <int KIND, int DIM4, bool LOCATED, bool GROUPED>
-__device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t size, const uint32_t parity, const GroupDesc* gdesc,
+__device__ __forceinline__ void slow_update(ApplyLds& L, const ApplyArgs& A, const OptArgs& a, const GroupDesc* gdesc, const int64_t key, const uint32_t c0, const uint32_t dim4) {
+    const uint32_t t = threadIdx.x;
+    const int lane = t & 63, tile = lane >> 4, tl = lane & 15;
+    if (t >= 64) return;
+    const uint32_t col = c0 + (uint32_t)tl;
+    int64_t slot = -1;
+    if constexpr (GROUPED) { const int64_t h = L.slot[0]; slot = h >= 0 && ((uint64_t)h >> kGroupSlotBits) < A.n_tables ? h : -1; }
+    else if constexpr (LOCATED) {
+        bool stale;
+        slot = handle_slot(L.slot[0], A.handle_tag, A.capacity, stale);
+        if (stale && lane == 0 && c0 == 0) atomicOr(A.status, (uint32_t)MEE_STATUS_STALE_HANDLE);
+    } else {
+        bool is_new, full;
+        slot = tile_locate<false, false>(const_cast<int64_t*>(A.tkeys), A.nb, key, tile == 0, tile, tl, is_new, full);
+    }
+    if (tile == 0 && slot >= 0 && col < dim4) {
+        const RowAt at = row_at<GROUPED>(A, gdesc, slot, true);
+        const uint64_t o = at.row * dim4 + col;
+        const double* r = &L.prow[8][tl * 4];
+        float4 w = at.values[o], x1 = at.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
+        opt_update4(a, w, x1, x2, make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]));
+        store_row4(&at.values[o], w); store_row4(&at.s1[o], x1);
+        if (KIND == MEE_OPT_ADAM) store_row4(&at.s2[o], x2);
+    }
+}
+
+constexpr uint32_t kSlowMajorityMin = 2 * kBucketCap;   // occurrences from which the bucket's majority key is shared by position instead of being one share's
+template <int KIND, int DIM4, bool LOCATED, bool GROUPED>
+__device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t b, const uint32_t size, const uint32_t parity, const GroupDesc* gdesc,
                                             const uint32_t sub, const uint32_t n_sub) {
     static_assert(!GROUPED || LOCATED, "a group's batch names rows, not keys");
     const uint32_t t = threadIdx.x;
-    const int lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6;
+    const int lane = t & 63;
     const uint32_t dim4 = DIM4 ? DIM4 : A.dim4;
     OptArgs a = A.a;
     a.kind = KIND;
+    // ---- the bucket's majority key, if it has one (Boyer-Moore votes per thread, merged across the block; then counted: every share computes the same answer)
+    if (t == 0) L.kmax = 0ull;   // the majority key (biased; 0 = none) stays in LDS: a register held across the key loop below costs the kernel scratch
+    __syncthreads();   // (the caller's wave 0 has just written L.seg_first / L.seg_at: nobody may walk the bucket's entries before that)
+    if (n_sub > 1 && ((uint64_t)b + 1) * (kSlowHelpers + 1) <= bk.fast_max) {
+        unsigned long long cand = 0ull;
+        int votes = 0;
+        for (uint32_t e = t; e < size; e += kApplyThreads) {
+            const unsigned long long bkey = (unsigned long long)bk.ent[bucket_entry_at(L, e)].key ^ kBias;
+            if (votes == 0) { cand = bkey; votes = 1; } else if (cand == bkey) ++votes; else --votes;
+        }
+#pragma unroll
+        for (int d = 32; d; d >>= 1) {
+            const unsigned long long oc = (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)cand, d) | (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(cand >> 32), d) << 32;
+            const int ov = __shfl_xor(votes, d);
+            if (oc == cand) votes += ov; else if (ov > votes) { cand = oc; votes = ov - votes; } else votes -= ov;
+        }
+        __syncthreads();
+        if (lane == 0) { L.stk_val[t >> 6] = cand; L.stk_bits[t >> 6] = (uint32_t)votes; }
+        __syncthreads();
+        cand = L.stk_val[0]; votes = (int)L.stk_bits[0];
+        for (int w = 1; w < kApplyWaves; ++w) {
+            const unsigned long long oc = L.stk_val[w];
+            const int ov = (int)L.stk_bits[w];
+            if (oc == cand) votes += ov; else if (ov > votes) { cand = oc; votes = ov - votes; } else votes -= ov;
+        }
+        // count the candidate (the votes only say who COULD be a majority), and keep one occurrence's slot handle
+        __syncthreads();
+        if (t == 0) L.n_cand = 0u;
+        __syncthreads();
+        uint32_t mine = 0;
+        for (uint32_t e = t; e < size; e += kApplyThreads) {
+            const PartEntry en = bk.ent[bucket_entry_at(L, e)];
+            if (((unsigned long long)en.key ^ kBias) != cand) continue;
+            if constexpr (LOCATED) if (mine == 0) L.slot[0] = A.slots[en.pos];   // (any occurrence: they all name the same slot, so concurrent writers agree)
+            ++mine;
+        }
+        if (mine) atomicAdd(&L.n_cand, mine);
+        __syncthreads();
+        const uint32_t n_major = L.n_cand;
+        if (n_major >= kSlowMajorityMin) {   // block-uniform, and the same in every share of the bucket
+            if (t == 0) L.kmax = cand;
+            const int64_t key = (int64_t)(cand ^ kBias);
+            const int64_t slot_handle = LOCATED ? (int64_t)L.slot[0] : 0;
+            double* prt = bk.pend_row + ((uint64_t)b * (kSlowHelpers + 1) + sub) * dim4 * 4;
+            for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {
+                (void)slow_sum_key<LOCATED>(L, A, bk, size, cand, c0, dim4, sub, n_sub, a.grad_rows);
+                if (t < 16 && c0 + t < dim4) rec_store_row4(prt + (uint64_t)(c0 + t) * 4, L.prow[8][t * 4], L.prow[8][t * 4 + 1], L.prow[8][t * 4 + 2], L.prow[8][t * 4 + 3]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partial row is out before the ticket is drawn
+            __syncthreads();
+            if (t == 0) L.is_last = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_sub - 1;
+            __syncthreads();
+            if (L.is_last) {   // block-uniform: the share that finishes last adds the partial rows up and updates the key
+                if constexpr (LOCATED) if (t == 0) L.slot[0] = slot_handle;
+                const double* all = bk.pend_row + (uint64_t)b * (kSlowHelpers + 1) * dim4 * 4;
+                for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {
+                    __syncthreads();
+                    if (t < 16 && c0 + t < dim4) {
+                        double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+                        for (uint32_t j = 0; j < n_sub; ++j) {
+                            const double* q = all + ((uint64_t)j * dim4 + c0 + t) * 4;
+                            r0 += rec_load(q); r1 += rec_load(q + 1); r2 += rec_load(q + 2); r3 += rec_load(q + 3);
+                        }
+                        double* r = &L.prow[8][t * 4];
+                        r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;
+                    }
+                    __syncthreads();
+                    slow_update<KIND, DIM4, LOCATED, GROUPED>(L, A, a, gdesc, key, c0, dim4);
+                }
+                if (t == 0 && n_major >= A.hot_count) report_hot_key(bk, parity, key);   // its own bucket next time
+            }
+        }
+    }
+    // ---- the other keys: each share takes the keys its hash gives it, one at a time in increasing key order
     bool have_last = false;
     unsigned long long last = 0;
     for (;;) {
-        // ---- the next key: the smallest (biased) key beyond the last one
+        // the next key: the smallest (biased) key beyond the last one
         __syncthreads();
         if (t == 0) L.kmin = ~0ull;
         __syncthreads();
         unsigned long long mn = ~0ull;
+        const unsigned long long major = L.kmax;
         for (uint32_t e = t; e < size; e += kApplyThreads) {
             const int64_t k = bk.ent[bucket_entry_at(L, e)].key;
             const unsigned long long bkey = (unsigned long long)k ^ kBias;
-            if ((!have_last || bkey > last) && bkey < mn && slow_share_of(k, n_sub) == sub) mn = bkey;
+            if ((!have_last || bkey > last) && bkey < mn && bkey != major && slow_share_of(k, n_sub) == sub) mn = bkey;
         }
         if (mn != ~0ull) atomicMin(&L.kmin, mn);
         __syncthreads();
         const unsigned long long cur = L.kmin;
         if (cur == ~0ull) break;   // block-uniform
         const int64_t key = (int64_t)(cur ^ kBias);
-        // ---- its gradient rows, 1024 entries of the bucket at a time: matches into L.src, 32 tiles sum them, the running total stays in LDS — one
-        // group of 64 columns at a time (the LDS rows hold 64: the update is element-wise, column groups are independent)
+        // its gradient rows, 1024 entries of the bucket at a time, one group of 64 columns at a time (the LDS rows hold 64: the update is element-wise, column
+        // groups are independent), then one update
         uint32_t total = 0;
         for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {
-            const uint32_t col = c0 + (uint32_t)tl;
-            const bool cok = col < dim4;
-            __syncthreads();
-            if (t < 16) { double* r = &L.prow[8][tl * 4]; r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; r[3] = 0.0; }
-            total = 0;
-            for (uint32_t e0 = 0; e0 < size; e0 += kBucketCap) {
-                __syncthreads();
-                if (t == 0) L.n_cand = 0u;
-                __syncthreads();
-                for (uint32_t e = e0 + t; e < min(size, e0 + kBucketCap); e += kApplyThreads) {
-                    const uint32_t at = bucket_entry_at(L, e);
-                    const PartEntry en = bk.ent[at];
-                    if (((unsigned long long)en.key ^ kBias) != cur) continue;
-                    const uint32_t p = en.pos;
-                    const uint32_t q = atomicAdd(&L.n_cand, 1u);
-                    L.src[q] = A.gidx ? min(A.gidx[p], a.grad_rows - 1) : p;
-                    if constexpr (LOCATED) if (q == 0) L.slot[0] = A.slots[p];   // every occurrence of a key names the same slot
-                }
-                __syncthreads();
-                const uint32_t nc = L.n_cand;
-                total += nc;
-                if (nc == 0) continue;   // block-uniform
-                double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
-                for (uint32_t q0 = (uint32_t)wv * 4 + tile; q0 < nc; q0 += 4 * 4 * kApplyWaves) {   // four rows in flight per tile
-                    float4 g[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g[q] = cok ? A.grads[(uint64_t)L.src[min(q0 + (uint32_t)q * 4 * kApplyWaves, nc - 1)] * dim4 + col] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool on = q0 + (uint32_t)q * 4 * kApplyWaves < nc;
-                        sx += on ? (double)g[q].x : 0.0; sy += on ? (double)g[q].y : 0.0; sz += on ? (double)g[q].z : 0.0; sw += on ? (double)g[q].w : 0.0;
-                    }
-                }
-                sx = tiles_sum(sx); sy = tiles_sum(sy); sz = tiles_sum(sz); sw = tiles_sum(sw);
-                if (tile == 0) { double* d = &L.prow[wv][tl * 4]; d[0] = sx; d[1] = sy; d[2] = sz; d[3] = sw; }
-                __syncthreads();
-                if (t < 16) {
-                    double* r = &L.prow[8][tl * 4];
-                    for (int w = 0; w < kApplyWaves; ++w) { const double* d = &L.prow[w][tl * 4]; r[0] += d[0]; r[1] += d[1]; r[2] += d[2]; r[3] += d[3]; }
-                }
-            }
-            __syncthreads();
-            // ---- one update of these columns (wave 0; its tile 0 holds the row)
-            if (wv == 0) {
-                int64_t slot = -1;
-                if constexpr (GROUPED) { const int64_t h = L.slot[0]; slot = h >= 0 && ((uint64_t)h >> kGroupSlotBits) < A.n_tables ? h : -1; }
-                else if constexpr (LOCATED) {
-                    bool stale;
-                    slot = handle_slot(L.slot[0], A.handle_tag, A.capacity, stale);
-                    if (stale && lane == 0 && c0 == 0) atomicOr(A.status, (uint32_t)MEE_STATUS_STALE_HANDLE);
-                } else {
-                    bool is_new, full;
-                    slot = tile_locate<false, false>(const_cast<int64_t*>(A.tkeys), A.nb, key, tile == 0, tile, tl, is_new, full);
-                }
-                if (tile == 0 && slot >= 0 && cok) {
-                    const RowAt at = row_at<GROUPED>(A, gdesc, slot, true);
-                    const uint64_t o = at.row * dim4 + col;
-                    const double* r = &L.prow[8][tl * 4];
-                    float4 w = at.values[o], x1 = at.s1[o], x2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (KIND == MEE_OPT_ADAM) x2 = at.s2[o];
-                    opt_update4(a, w, x1, x2, make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]));
-                    store_row4(&at.values[o], w); store_row4(&at.s1[o], x1);
-                    if (KIND == MEE_OPT_ADAM) store_row4(&at.s2[o], x2);
-                }
-            }
+            total = slow_sum_key<LOCATED>(L, A, bk, size, cur, c0, dim4, 0u, 1u, a.grad_rows);
+            slow_update<KIND, DIM4, LOCATED, GROUPED>(L, A, a, gdesc, key, c0, dim4);
         }
         if (t == 0 && total >= A.hot_count) report_hot_key(bk, parity, key);   // its own bucket next time
         last = cur; have_last = true;
@@ -1113,7 +1209,7 @@ __global__ __launch_bounds__(kApplyThreads, kApplyWavesPerSimd) void bkt_apply_k
             run_units<KIND, DIM4, LOCATED, GROUPED, false>(L, A, bk, parity, runs, size0, 0u, 0u, gdesc);
         } else {
             seg_scan(L, runs, threadIdx.x);
-            slow_bucket<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, size0, parity, gdesc, 0u, slow_shares(size0, A.nbk));
+            slow_bucket<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, blockIdx.x, size0, parity, gdesc, 0u, slow_shares(size0, A.nbk));
             // the stream is skewed: the FULL kernel from now on, with as many agents as this batch had slabs (the block that finishes last leaves the sum)
             if (threadIdx.x == 0) report_slabs(bk, A.h_slabs, (size0 + kSlab - 1) / kSlab, 0u);
         }
@@ -1130,7 +1226,7 @@ __global__ __launch_bounds__(kApplyThreads, kApplyWavesPerSimd) void bkt_apply_k
                 const uint32_t yy = __builtin_amdgcn_readlane(y, jj), tyy = __builtin_amdgcn_readlane(ty, jj);
                 __syncthreads();   // (whatever this block did before is done with the LDS)
                 seg_scan(L, seg_load(A, bk, yy, threadIdx.x), threadIdx.x);
-                slow_bucket<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, tyy, parity, gdesc, jj + 1u, slow_shares(tyy, nbk));
+                slow_bucket<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, yy, tyy, parity, gdesc, jj + 1u, slow_shares(tyy, nbk));
             }
         }
     }
