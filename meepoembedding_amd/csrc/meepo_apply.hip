@@ -944,7 +944,10 @@ __device__ __forceinline__ uint32_t bucket_entry_at(const ApplyLds& L, uint32_t 
 
 // how many blocks share a split bucket of the LEAN kernel (its own block and the helpers behind it), and which of them takes a key
 constexpr uint32_t kSlowHelpers = 64;
-__device__ __forceinline__ uint32_t slow_shares(uint32_t size, uint32_t nbk) { return min(min(kSlowHelpers + 1, nbk), (size + 255u) / 256u); }
+// (Every key of a share costs ~8 us of dependent steps — a scan for the next key, a scan for its rows, the sum, the update —, so the shares are as many as there are
+// helpers even for a bucket just beyond a block's reach: a bucket of 1400 positions around a key of 900 holds ~350 other keys — 58 per share with 6 shares (round 4:
+// size / 256), 0.5 ms; 6 per share with 65.)
+__device__ __forceinline__ uint32_t slow_shares(uint32_t size, uint32_t nbk) { return min(min(kSlowHelpers + 1, nbk), (size + 15u) / 16u); }
 __device__ __forceinline__ uint32_t slow_share_of(int64_t key, uint32_t n_sub) { return (uint32_t)__umul64hi(mix64b((uint64_t)key), (uint64_t)n_sub); }
 
 // A split bucket in the LEAN kernel (below): its own block and up to 64 helpers — the blocks of the buckets behind it, once they are done with

@@ -48,7 +48,8 @@ def test_bench_single_gpu_contract(dev):
     # the headline rotates its results over more output bytes than the Infinity Cache holds and says so; the reused-buffer figure is beside it
     assert rf["out_buffers"] >= 5 and rf["frac_out_rotating"] == rf["frac"] and rf["frac_out_reused"] > 0
     # ... with the caller's hints passed per call (mee_find_ex), and the no-hint figure (the library's own rule into the same rotating buffers) beside it
-    assert 0 < rf["frac_library_default"] <= rf["frac"] + 1e-9 and "mee_find_ex_flags" in rf["out_store_policy"]
+    # (since round 5 the library's own rule sees the rotation and streams its stores too: the two figures differ by the row-load hint and by noise)
+    assert 0 < rf["frac_library_default"] <= rf["frac"] * 1.05 and "mee_find_ex_flags" in rf["out_store_policy"]
     assert "rotating" in res["config"]["workload"] and res["config"]["launch_comparison"]["eager_us_per_step"] > 0
     # configs[2] travels in the default line: find + sparse Adagrad step and the apply alone, uniform and Zipf(1.05)
     c2 = res["configs2"]

@@ -28,7 +28,7 @@ for i in range(8): t.apply_adagrad(small[i], g, lr=0.01)              # plain ap
 for i in range(8):
     t.find_located(small[i], out=out, found=found, slots=slots, prepare_apply=True)   # the training forward: find + the apply's partition in one launch
     t.apply_adagrad(small[i], g, lr=0.01, slots=slots)
-for i in range(4): t.dedup_sum(small[i], g)                           # standalone duplicate-key reduction with row sums
+for k in old: t.dedup_sum(k, rows)                                    # duplicate-key reduction with row sums (what a sharded backward runs in front of its exchange)
 for k in old: t.dedup_keys(k)                                         # sync-free duplicate elimination (what the sharded lookup runs in front of its exchange)
 r = Router(8, B, device=dev)
 for k in old: r.partition(k)                                          # shard partition (8 owners)
