@@ -960,24 +960,26 @@ __device__ __forceinline__ uint32_t slow_share_of(int64_t key, uint32_t n_sub) {
 // partial row, draws a ticket, and the share that draws the last one adds the <= 65 partial rows up and updates the key (the pending-record discipline of the
 // FULL kernel: write-through stores drained before the ticket, agent-scope loads, no fence).
 
-// the rows of key `cur` (biased) in the bucket's windows win0, win0 + win_step, ... (1024 entries each), columns [c0, c0 + 16): their fp64 sum is left in L.prow[8]
-// (valid for every thread after the function's last barrier); returns how many occurrences those windows held
+// the rows of key `cur` (biased) among the bucket's entries, columns [c0, c0 + 16): their fp64 sum is left in L.prow[8] (valid for every thread after the function's last
+// barrier); returns how many occurrences were found.  Which entries are looked at: windows win0, win0 + win_step, ... of 1024 entries of the whole bucket (list_n = 0), or
+// the list_n <= 1024 entries whose indices L.off lists (the bucket without its majority key: one window)
 template <bool LOCATED>
 __device__ __forceinline__ uint32_t slow_sum_key(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t size, const unsigned long long cur, const uint32_t c0,
-                                                 const uint32_t dim4, const uint32_t win0, const uint32_t win_step, const uint32_t grad_rows) {
+                                                 const uint32_t dim4, const uint32_t win0, const uint32_t win_step, const uint32_t grad_rows, const uint32_t list_n = 0) {
     const uint32_t t = threadIdx.x;
     const int lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6;
     const uint32_t col = c0 + (uint32_t)tl;
     const bool cok = col < dim4;
+    const uint32_t count = list_n ? list_n : size;
     __syncthreads();
     if (t < 16) { double* r = &L.prow[8][tl * 4]; r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; r[3] = 0.0; }
     uint32_t total = 0;
-    for (uint32_t e0 = win0 * kBucketCap; e0 < size; e0 += win_step * kBucketCap) {
+    for (uint32_t e0 = win0 * kBucketCap; e0 < count; e0 += win_step * kBucketCap) {
         __syncthreads();
         if (t == 0) L.n_cand = 0u;
         __syncthreads();
-        for (uint32_t e = e0 + t; e < min(size, e0 + kBucketCap); e += kApplyThreads) {
-            const PartEntry en = bk.ent[bucket_entry_at(L, e)];
+        for (uint32_t i = e0 + t; i < min(count, e0 + kBucketCap); i += kApplyThreads) {
+            const PartEntry en = bk.ent[bucket_entry_at(L, list_n ? L.off[i] : i)];
             if (((unsigned long long)en.key ^ kBias) != cur) continue;
             const uint32_t p = en.pos;
             const uint32_t q = atomicAdd(&L.n_cand, 1u);
@@ -1040,6 +1042,13 @@ __device__ __forceinline__ void slow_update(ApplyLds& L, const ApplyArgs& A, con
     }
 }
 
+// A share of a split bucket (LEAN kernel).  What costs here is WALKING the bucket — 15 000 entries, each found through a binary search over the partition blocks'
+// runs — once per key of the share (twice: the next key, then its rows), so the bucket is walked ONCE: a candidate for its majority key comes from 64 sampled entries
+// (a bucket is split because one key fills it), and one pass — two entries in flight per thread — counts the candidate, keeps one of its slot handles and LISTS the
+// bucket's other entries in LDS (L.off: up to 1024 of them; a bucket of 15 000 positions around a key of 14 600 lists 400).  A candidate with >= kSlowMajorityMin
+// occurrences is summed by ALL shares (window w of 1024 entries belongs to share w mod n_sub; one fp64 partial row per share, a ticket, the last share adds them
+// up and updates); every other key is one share's (slow_share_of), found and summed in the list.  When the list overflows (two giant keys in one bucket) the keys
+// are found by walking the whole bucket, as in round 4.
 constexpr uint32_t kSlowMajorityMin = 2 * kBucketCap;   // occurrences from which the bucket's majority key is shared by position instead of being one share's
 template <int KIND, int DIM4, bool LOCATED, bool GROUPED>
 __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t b, const uint32_t size, const uint32_t parity, const GroupDesc* gdesc,
@@ -1050,80 +1059,80 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
     const uint32_t dim4 = DIM4 ? DIM4 : A.dim4;
     OptArgs a = A.a;
     a.kind = KIND;
-    // ---- the bucket's majority key, if it has one (Boyer-Moore votes per thread, merged across the block; then counted: every share computes the same answer)
-    if (t == 0) L.kmax = 0ull;   // the majority key (biased; 0 = none) stays in LDS: a register held across the key loop below costs the kernel scratch
     __syncthreads();   // (the caller's wave 0 has just written L.seg_first / L.seg_at: nobody may walk the bucket's entries before that)
-    if (n_sub > 1 && ((uint64_t)b + 1) * (kSlowHelpers + 1) <= bk.fast_max) {
-        unsigned long long cand = 0ull;
-        int votes = 0;
-        for (uint32_t e = t; e < size; e += kApplyThreads) {
-            const unsigned long long bkey = (unsigned long long)bk.ent[bucket_entry_at(L, e)].key ^ kBias;
-            if (votes == 0) { cand = bkey; votes = 1; } else if (cand == bkey) ++votes; else --votes;
-        }
+    // ---- the candidate: Boyer-Moore votes over 64 entries spread over the bucket (wave 0; merged pairwise with shuffles)
+    if (t < 64) {
+        unsigned long long cand = (unsigned long long)bk.ent[bucket_entry_at(L, (uint32_t)(((uint64_t)t * size) >> 6))].key ^ kBias;
+        int votes = 1;
 #pragma unroll
         for (int d = 32; d; d >>= 1) {
             const unsigned long long oc = (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)cand, d) | (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(cand >> 32), d) << 32;
             const int ov = __shfl_xor(votes, d);
             if (oc == cand) votes += ov; else if (ov > votes) { cand = oc; votes = ov - votes; } else votes -= ov;
         }
-        __syncthreads();
-        if (lane == 0) { L.stk_val[t >> 6] = cand; L.stk_bits[t >> 6] = (uint32_t)votes; }
-        __syncthreads();
-        cand = L.stk_val[0]; votes = (int)L.stk_bits[0];
-        for (int w = 1; w < kApplyWaves; ++w) {
-            const unsigned long long oc = L.stk_val[w];
-            const int ov = (int)L.stk_bits[w];
-            if (oc == cand) votes += ov; else if (ov > votes) { cand = oc; votes = ov - votes; } else votes -= ov;
-        }
-        // count the candidate (the votes only say who COULD be a majority), and keep one occurrence's slot handle
-        __syncthreads();
-        if (t == 0) L.n_cand = 0u;
-        __syncthreads();
+        if (t == 0) { L.kmax = cand; L.n_cand = 0u; L.n_items = 0u; }
+    }
+    __syncthreads();
+    const unsigned long long cand = L.kmax;
+    // ---- ONE walk: count the candidate, keep a slot handle of it, list everything else
+    {
         uint32_t mine = 0;
-        for (uint32_t e = t; e < size; e += kApplyThreads) {
-            const PartEntry en = bk.ent[bucket_entry_at(L, e)];
-            if (((unsigned long long)en.key ^ kBias) != cand) continue;
-            if constexpr (LOCATED) if (mine == 0) L.slot[0] = A.slots[en.pos];   // (any occurrence: they all name the same slot, so concurrent writers agree)
-            ++mine;
+        for (uint32_t e0 = t; e0 < size; e0 += 2 * kApplyThreads) {
+            const uint32_t e1 = e0 + kApplyThreads;
+            const PartEntry en0 = bk.ent[bucket_entry_at(L, e0)];
+            const PartEntry en1 = bk.ent[bucket_entry_at(L, min(e1, size - 1))];
+            const bool m0 = ((unsigned long long)en0.key ^ kBias) == cand, m1 = e1 < size && ((unsigned long long)en1.key ^ kBias) == cand;
+            if constexpr (LOCATED) if (mine == 0 && (m0 || m1)) L.slot[0] = A.slots[m0 ? en0.pos : en1.pos];   // (any occurrence: they all name the same slot, so concurrent writers agree)
+            mine += (uint32_t)m0 + (uint32_t)m1;
+            if (!m0) { const uint32_t q = atomicAdd(&L.n_items, 1u); if (q < kBucketCap) L.off[q] = e0; }
+            if (!m1 && e1 < size) { const uint32_t q = atomicAdd(&L.n_items, 1u); if (q < kBucketCap) L.off[q] = e1; }
         }
         if (mine) atomicAdd(&L.n_cand, mine);
-        __syncthreads();
-        const uint32_t n_major = L.n_cand;
-        if (n_major >= kSlowMajorityMin) {   // block-uniform, and the same in every share of the bucket
-            if (t == 0) L.kmax = cand;
-            const int64_t key = (int64_t)(cand ^ kBias);
-            const int64_t slot_handle = LOCATED ? (int64_t)L.slot[0] : 0;
-            double* prt = bk.pend_row + ((uint64_t)b * (kSlowHelpers + 1) + sub) * dim4 * 4;
-            for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {
-                (void)slow_sum_key<LOCATED>(L, A, bk, size, cand, c0, dim4, sub, n_sub, a.grad_rows);
-                if (t < 16 && c0 + t < dim4) rec_store_row4(prt + (uint64_t)(c0 + t) * 4, L.prow[8][t * 4], L.prow[8][t * 4 + 1], L.prow[8][t * 4 + 2], L.prow[8][t * 4 + 3]);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partial row is out before the ticket is drawn
-            __syncthreads();
-            if (t == 0) L.is_last = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_sub - 1;
-            __syncthreads();
-            if (L.is_last) {   // block-uniform: the share that finishes last adds the partial rows up and updates the key
-                if constexpr (LOCATED) if (t == 0) L.slot[0] = slot_handle;
-                const double* all = bk.pend_row + (uint64_t)b * (kSlowHelpers + 1) * dim4 * 4;
-                for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {
-                    __syncthreads();
-                    if (t < 16 && c0 + t < dim4) {
-                        double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
-                        for (uint32_t j = 0; j < n_sub; ++j) {
-                            const double* q = all + ((uint64_t)j * dim4 + c0 + t) * 4;
-                            r0 += rec_load(q); r1 += rec_load(q + 1); r2 += rec_load(q + 2); r3 += rec_load(q + 3);
-                        }
-                        double* r = &L.prow[8][t * 4];
-                        r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;
-                    }
-                    __syncthreads();
-                    slow_update<KIND, DIM4, LOCATED, GROUPED>(L, A, a, gdesc, key, c0, dim4);
-                }
-                if (t == 0 && n_major >= A.hot_count) report_hot_key(bk, parity, key);   // its own bucket next time
-            }
+    }
+    __syncthreads();
+    const uint32_t n_major = L.n_cand, n_other = L.n_items;
+    const uint32_t list_n = n_other <= kBucketCap ? n_other : 0u;   // 0: the others do not fit the list (walk the whole bucket for them)
+    const bool shared = n_sub > 1 && n_major >= kSlowMajorityMin && ((uint64_t)b + 1) * (kSlowHelpers + 1) <= bk.fast_max;   // block-uniform, and the same in every share of the bucket
+    const int64_t cand_key = (int64_t)(cand ^ kBias);
+    if (shared) {
+        const int64_t slot_handle = LOCATED ? (int64_t)L.slot[0] : 0;
+        double* prt = bk.pend_row + ((uint64_t)b * (kSlowHelpers + 1) + sub) * dim4 * 4;
+        for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {
+            (void)slow_sum_key<LOCATED>(L, A, bk, size, cand, c0, dim4, sub, n_sub, a.grad_rows);
+            if (t < 16 && c0 + t < dim4) rec_store_row4(prt + (uint64_t)(c0 + t) * 4, L.prow[8][t * 4], L.prow[8][t * 4 + 1], L.prow[8][t * 4 + 2], L.prow[8][t * 4 + 3]);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partial row is out before the ticket is drawn
+        __syncthreads();
+        if (t == 0) L.is_last = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_sub - 1;
+        __syncthreads();
+        if (L.is_last) {   // block-uniform: the share that finishes last adds the partial rows up and updates the key
+            if constexpr (LOCATED) if (t == 0) L.slot[0] = slot_handle;
+            const double* all = bk.pend_row + (uint64_t)b * (kSlowHelpers + 1) * dim4 * 4;
+            for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {
+                __syncthreads();
+                if (t < 16 && c0 + t < dim4) {
+                    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+                    for (uint32_t j = 0; j < n_sub; ++j) {
+                        const double* q = all + ((uint64_t)j * dim4 + c0 + t) * 4;
+                        r0 += rec_load(q); r1 += rec_load(q + 1); r2 += rec_load(q + 2); r3 += rec_load(q + 3);
+                    }
+                    double* r = &L.prow[8][t * 4];
+                    r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;
+                }
+                __syncthreads();
+                slow_update<KIND, DIM4, LOCATED, GROUPED>(L, A, a, gdesc, cand_key, c0, dim4);
+            }
+            if (t == 0 && n_major >= A.hot_count) report_hot_key(bk, parity, cand_key);   // its own bucket next time
+        }
+    } else if (n_major != 0 && slow_share_of(cand_key, n_sub) == sub) {   // the candidate is an ordinary key of this share (it is not in the list)
+        for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {
+            (void)slow_sum_key<LOCATED>(L, A, bk, size, cand, c0, dim4, 0u, 1u, a.grad_rows);
+            slow_update<KIND, DIM4, LOCATED, GROUPED>(L, A, a, gdesc, cand_key, c0, dim4);
+        }
+        if (t == 0 && n_major >= A.hot_count) report_hot_key(bk, parity, cand_key);
     }
     // ---- the other keys: each share takes the keys its hash gives it, one at a time in increasing key order
+    const uint32_t walk_n = list_n ? list_n : size;
     bool have_last = false;
     unsigned long long last = 0;
     for (;;) {
@@ -1132,22 +1141,20 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
         if (t == 0) L.kmin = ~0ull;
         __syncthreads();
         unsigned long long mn = ~0ull;
-        const unsigned long long major = L.kmax;
-        for (uint32_t e = t; e < size; e += kApplyThreads) {
-            const int64_t k = bk.ent[bucket_entry_at(L, e)].key;
+        for (uint32_t i = t; i < walk_n; i += kApplyThreads) {
+            const int64_t k = bk.ent[bucket_entry_at(L, list_n ? L.off[i] : i)].key;
             const unsigned long long bkey = (unsigned long long)k ^ kBias;
-            if ((!have_last || bkey > last) && bkey < mn && bkey != major && slow_share_of(k, n_sub) == sub) mn = bkey;
+            if ((!have_last || bkey > last) && bkey < mn && bkey != cand && slow_share_of(k, n_sub) == sub) mn = bkey;
         }
         if (mn != ~0ull) atomicMin(&L.kmin, mn);
         __syncthreads();
         const unsigned long long cur = L.kmin;
         if (cur == ~0ull) break;   // block-uniform
         const int64_t key = (int64_t)(cur ^ kBias);
-        // its gradient rows, 1024 entries of the bucket at a time, one group of 64 columns at a time (the LDS rows hold 64: the update is element-wise, column
-        // groups are independent), then one update
+        // its gradient rows, one group of 64 columns at a time (the LDS rows hold 64: the update is element-wise, column groups are independent), then one update
         uint32_t total = 0;
         for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {
-            total = slow_sum_key<LOCATED>(L, A, bk, size, cur, c0, dim4, 0u, 1u, a.grad_rows);
+            total = slow_sum_key<LOCATED>(L, A, bk, size, cur, c0, dim4, 0u, 1u, a.grad_rows, list_n);
             slow_update<KIND, DIM4, LOCATED, GROUPED>(L, A, a, gdesc, key, c0, dim4);
         }
         if (t == 0 && total >= A.hot_count) report_hot_key(bk, parity, key);   // its own bucket next time

@@ -645,8 +645,10 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
         if (!A.grads) return;   // (grid-uniform)
         if (P.n_win > 1 && x >= A.max_part) { if (t == 0) atomicOr(A.d.status, (uint32_t)MEE_STATUS_INTERNAL); return; }   // cannot happen (max_part covers every window a batch can have)
         auto from_list = [&](uint32_t j, uint32_t col) { return grad_row4(A.grads, L.src()[j], dim4, col); };
-        if (P.n_win == 1) { block_run_sum(L, dim4, c, from_list, [&](uint32_t col, const D4& v) { store_sum4(A.gsum, P.rank, dim4, col, v); }); return; }
-        block_run_sum(L, dim4, c, from_list, [&](uint32_t col, const D4& v) {
+        // (EIGHT rows in flight per tile here — a window is 64 rows per tile, a chain of 8 round trips instead of 16 — : this branch holds no bucket entries in
+        // registers, the kernel's register need is set elsewhere)
+        if (P.n_win == 1) { block_run_sum<8>(L, dim4, c, from_list, [&](uint32_t col, const D4& v) { store_sum4(A.gsum, P.rank, dim4, col, v); }); return; }
+        block_run_sum<8>(L, dim4, c, from_list, [&](uint32_t col, const D4& v) {
             double* d = A.part + ((uint64_t)x * dim4 + col) * 4;
             __hip_atomic_store(reinterpret_cast<unsigned long long*>(d), (unsigned long long)__double_as_longlong(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(reinterpret_cast<unsigned long long*>(d + 1), (unsigned long long)__double_as_longlong(v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -157,9 +157,8 @@ def test_training_loop_rebalances_itself(dev):
     assert len(t.rebalance_log) == 6 and sum(p for _, p, _ in t.rebalance_log) > 0
     assert shares[0] > 0.99 and shares[-1] < 0.35, shares
     assert hot.size() <= hot_limit and hot.size() + cold.size() == n_keys and hot.status() == 0 and cold.status() == 0
-    ek = torch.cat([hot.export(with_state=True)[0], cold.export(with_state=True)[0]]).cpu().numpy()
-    ev = torch.cat([hot.export(with_state=True)[1], cold.export(with_state=True)[1]]).cpu().numpy()
-    ea = torch.cat([hot.export(with_state=True)[2], cold.export(with_state=True)[2]]).cpu().numpy()
+    eh, ec = hot.export(with_state=True), cold.export(with_state=True)   # (ONE export per table: the order of an export's pairs is unspecified, call by call)
+    ek, ev, ea = (torch.cat([eh[i], ec[i]]).cpu().numpy() for i in range(3))
     ok, ov, oa, _ = o.export(with_state=True)
     a, b_ = np.argsort(ek), np.argsort(ok)
     assert np.array_equal(ek[a], ok[b_])
