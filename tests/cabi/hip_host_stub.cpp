@@ -31,6 +31,7 @@ hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSucc
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 hipError_t hipMemcpyToSymbol(const void*, const void*, size_t, size_t, hipMemcpyKind) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) { memset(a, 0, sizeof *a); return hipSuccess; }
 hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
 hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) { memset(h, 0, sizeof *h); memcpy(h, &p, sizeof p); return hipSuccess; }
 hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { memcpy(p, &h, sizeof *p); return hipSuccess; }   // (ranks are threads of one process here)
