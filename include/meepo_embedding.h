@@ -72,7 +72,8 @@ typedef struct mee_config {
     uint64_t capacity;            /* requested slots; rounded up to 16 x (smallest prime >= capacity/16) (SPEC.md §2) */
     uint32_t dim;                 /* floats per row: multiple of 4, 4..1024 */
     uint32_t optimizer;           /* MEE_OPT_*: which state planes to allocate */
-    uint64_t max_batch;           /* largest n of any mutating op (sizes the workspace) */
+    uint64_t max_batch;           /* largest n of any mutating op: sizes the workspace — with an optimizer ~(56 + 10 dim) B per position of HBM
+                                   * (0.7 GB at 1M x dim 64: the pending records of a skewed batch's worst case); see mee_table_info.workspace_bytes */
     float    default_value;       /* fill for rows of absent keys */
     float    initial_accumulator; /* Adagrad acc of a newly inserted key */
     uint32_t initializer;         /* MEE_INIT_*: initial row for find_or_insert */
@@ -435,7 +436,8 @@ int mee_p2p_status(mee_p2p* c, uint32_t* bits_out, void* stream); /* [syncs]; bi
 int mee_comm_unique_id(void* id_out /* MEE_COMM_ID_BYTES */);                    /* ncclGetUniqueId: one rank calls, all ranks share the bytes */
 int mee_comm_create(const void* id, uint32_t n_ranks, uint32_t rank, int32_t device, void** comm_out); /* ncclCommInitRank (collective) */
 int mee_comm_destroy(void* comm);
-int mee_comm_aborted(void* comm);   /* 1: this library aborted (and thereby freed) the communicator after an RCCL error */
+int mee_comm_aborted(void* comm);   /* 1: this library aborted (and thereby freed) the communicator after an RCCL error.  The mark belongs to the ADDRESS: it is cleared when a
+                                     * context is created on a communicator at that address again (mee_sharded_create*: the caller vouches that a live one is there) and by mee_comm_create */
 int mee_sharded_create(mee_table* local, void* nccl_comm, uint64_t max_batch /* largest n of a rank per call: the same on every rank */,
                        double pad_slack, mee_sharded** out);
 /* The same with options (BASELINE configs[4]; SURVEY.md §7 lever (a)):

@@ -629,6 +629,10 @@ int mee_sharded_create_ex(mee_table* local, void* nccl_comm, const mee_sharded_o
     if (!api) return fail(MEE_ERR_RCCL, "%s", rccl_load_error());
     int nranks = 0, rank = 0, cdev = -1;
     ncclComm_t comm = (ncclComm_t)nccl_comm;
+    // A caller-owned communicator that this library once aborted is FREED; the allocator may hand its address to the caller's next ncclCommInitRank.  Whoever creates
+    // a context on an address vouches that a live communicator is there now: the aborted mark of the address's previous tenant goes (it would otherwise fail every
+    // context on the new communicator with MEE_ERR_RCCL for ever, and the registry would only ever grow).
+    { std::lock_guard<std::mutex> lk(g_abort_mu); g_aborted.erase((void*)comm); }
     MEE_NCCL(api, api->CommCount(comm, &nranks));
     MEE_NCCL(api, api->CommUserRank(comm, &rank));
     MEE_NCCL(api, api->CommCuDevice(comm, &cdev));
