@@ -491,8 +491,9 @@ def tier_share_point(synth, dim, dev, batch, log, keys=1_250_000_000, hot_keys=8
     tp = TieredLookupTable(hot, cold, hot_key_limit=th_keys, sample_every=4, promote_threshold=2, rebalance_every=24, rebalance_max_moves=4 * chunk)
     series = []
 
-    def timed_steps(bs_):
+    def timed_steps(bs_):   # (policy AND observation paused: the timed batches must not vote for their own keys)
         tp.rebalance_every, keep = 0, tp.rebalance_every
+        tp.policy, keep_policy = False, tp.policy
         per = []
         for _ in range(3):
             torch.cuda.synchronize(dev)
@@ -503,11 +504,11 @@ def tier_share_point(synth, dim, dev, batch, log, keys=1_250_000_000, hot_keys=8
             e1.record()
             torch.cuda.synchronize(dev)
             per.append(e0.elapsed_time(e1) * 1e3 / 10)
-        tp.rebalance_every = keep
+        tp.rebalance_every, tp.policy = keep, keep_policy
         return sorted(per)[1]
 
-    probe_bs = [zipf_batch(tk) for _ in range(8)]
     for rnd in range(0, rounds + 1):
+        probe_bs = [zipf_batch(tk) for _ in range(8)]   # fresh draws of the stream every round: their once-seen tail keys have never been observed
         if rnd:
             t1 = time.time()
             for _ in range(24):
