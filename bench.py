@@ -1275,14 +1275,14 @@ def main():
                     traffic = tj["bytes_per_launch"]   # measured in separate rocprofv3 --pmc passes (tools/pmc_traffic.py), not in this run
             except Exception:
                 traffic = None
-        step_traffic = step_traffic_src = None   # configs[2]: the step's kernels summed, from the PMC passes of tools/final_r3.sh
-        apath = os.path.join(ROOT, "profiles", "r03_step_traffic.json")
+        step_traffic = step_traffic_src = None   # configs[2]: the step's kernels summed, from the PMC passes of the latest evidence run (tools/final_r5.sh)
+        apath = os.path.join(ROOT, "profiles", "step_traffic.json")
         if whole and not sharded and os.path.exists(apath) and args.dist == "uniform" and dim == 64 and keys_per_gpu == 100_000_000:
             try:
                 aj = json.load(open(apath))
                 if aj.get("batch") == batch:
                     step_traffic = sum(k_["bytes_per_launch"] for k_ in aj["kernels"].values())
-                    step_traffic_src = ("profiles/r03_step_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/final_r3.sh; "
+                    step_traffic_src = ("profiles/step_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/final_r5.sh; "
                                         "the step's kernels summed: " + ", ".join(aj["kernels"]) + ")")
             except Exception:
                 step_traffic = None
