@@ -31,6 +31,17 @@ constexpr int kDedupWaves = kDedupThreads / 64;
 constexpr uint32_t kDedupSlots = 1024;        // LDS hash table of one pass
 constexpr uint32_t kDedupFill = 896;          // distinct keys a pass may hold (load 0.875); beyond: the pass is split by one more hash bit
 
+// MEE_SUM_TIMELINE (diagnostic builds only: tools/sum_timeline.py): thread 0 of every block stamps the 100 MHz wall clock at its phase boundaries
+#ifndef MEE_SUM_TIMELINE
+#define MEE_SUM_TIMELINE 0
+#endif
+#if MEE_SUM_TIMELINE
+__device__ unsigned long long* g_sum_dbg = nullptr;
+#define MEE_STL(i) do { if (threadIdx.x == 0 && g_sum_dbg && blockIdx.x < 8192) g_sum_dbg[(uint64_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define MEE_STL(i) do { } while (0)
+#endif
+
 struct DedupLds {
     unsigned long long key[kDedupSlots];      // key ^ kBias, 0 = empty
     uint32_t val[kDedupSlots];                // dedup: the key's index in this pass's slice of the unique list | assign: 1 + the key's last position, later its found flag
@@ -98,6 +109,7 @@ __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, u
     for (uint32_t j = t; j < kDedupSlots; j += kDedupThreads) { L.key[j] = 0ull; L.val[j] = 0u; L.cnt[j] = 0u; }
     if (t == 0) { L.n_distinct = 0u; L.overflow = 0u; }
     __syncthreads();
+    MEE_STL(7);   // table cleared
     const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
     constexpr int kIn = 4;   // entries a thread has in flight per step (one dependent round trip per step: a bucket of 4 000 entries takes 4 steps, not 16)
     for (uint32_t e0 = 0; e0 < size; e0 += kIn * kDedupThreads) {   // block-uniform trip count: the wave ballots below need whole waves
@@ -118,6 +130,10 @@ __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, u
 #pragma unroll
             for (int q = 0; q < kIn; ++q) { H.k[q] = kq[q]; H.p[q] = pq[q]; }
         }
+#if MEE_SUM_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MEE_STL(8);   // thread 0's entries are in
+#endif
 #pragma unroll
         for (int q = 0; q < kIn; ++q) {
             const int64_t key = kq[q];
@@ -548,16 +564,6 @@ struct SumArgs {
     uint32_t* src_scratch;            // [max_batch] sorted sources of buckets beyond the LDS list
     double* part; uint32_t max_part;  // fp64 partial rows of the hot keys' windows, one per window unit
 };
-// MEE_SUM_TIMELINE (diagnostic builds only: tools/sum_timeline.py): thread 0 of every block stamps the 100 MHz wall clock at its phase boundaries
-#ifndef MEE_SUM_TIMELINE
-#define MEE_SUM_TIMELINE 0
-#endif
-#if MEE_SUM_TIMELINE
-__device__ unsigned long long* g_sum_dbg = nullptr;
-#define MEE_STL(i) do { if (threadIdx.x == 0 && g_sum_dbg && blockIdx.x < 8192) g_sum_dbg[(uint64_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
-#else
-#define MEE_STL(i) do { } while (0)
-#endif
 // a barrier that waits for this wave's LDS traffic only: __syncthreads() also drains the global stores in flight (s_waitcnt vmcnt(0)) — here the key / count /
 // inverse stores of a pass, which nothing in the block reads back; their acknowledgement is 3-5 us under load, twice per pass
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -732,6 +738,7 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
                 }
             }
         }
+        MEE_STL(9);   // thread 0's look-ups done, inverse stores issued
         if (!A.grads) return;   // (grid-uniform) keys, counts and inverse only
         if (in_lds) lds_barrier(); else __syncthreads();   // nobody looks a key up any more: the key table's space becomes src / items / prow (beyond the LDS list: the stores of the global list are drained)
         // -- 2b. the LDS list (positions sorted by run, through each run's cursor) and the run list (run number -> slot)

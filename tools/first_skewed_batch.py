@@ -36,6 +36,8 @@ for mode in ("host_in_step", "host_runs_ahead"):
     torch.cuda.synchronize()
     us = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(12)]
     print(f"{mode}: Zipf(1.05) steps behind a uniform stream, us per step (forward + apply): " + " ".join(f"{u:.0f}" for u in us), flush=True)
+    if os.environ.get("MEE_FSB_SHORT"):   # under the profiler (tools/kernel_sequence.py DIR -30): the trace ends with these 12 steps
+        break
     for i in range(70):   # back to a uniform stream long enough for the FULL kernel's stickiness (64 batches) to run out
         step(uni[i % 8])
     torch.cuda.synchronize()

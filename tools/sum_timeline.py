@@ -16,18 +16,25 @@ bs = bench.lookup_batches(synth, keys_n, batch, 4, dist, dev, seed=3)
 rows = torch.randn(batch, dim, device=dev)
 L = _lib.lib()
 L.mee_debug_sum_timeline.argtypes = [C.c_void_p, C.c_uint64]; L.mee_debug_sum_timeline.restype = C.c_int
+drop = os.environ.get("MEE_STL_NULL", "").split(",")   # outputs left out (inverse, counts): what their stores cost
+uo = torch.empty(batch, dtype=torch.int64, device=dev); go = torch.empty((batch, dim), device=dev)
+co = torch.empty(batch, dtype=torch.int32, device=dev); io = torch.empty(batch, dtype=torch.int64, device=dev)
+st = torch.cuda.current_stream(dev).cuda_stream
+def call(b):
+    _lib.check(L.mee_dedup_sum(t._h, b.data_ptr(), rows.data_ptr(), batch, uo.data_ptr(), go.data_ptr(), None if "counts" in drop else co.data_ptr(),
+                               None if "inverse" in drop else io.data_ptr(), -1, st))
 for i in range(6):
-    t.dedup_sum(bs[i % 4], rows)
+    call(bs[i % 4])
     torch.cuda.synchronize()
 assert L.mee_debug_sum_timeline(None, 0) == 0          # arm
-t.dedup_sum(bs[2], rows)
+call(bs[2])
 torch.cuda.synchronize()
 buf = np.zeros(8192 * 16, dtype=np.uint64)
 assert L.mee_debug_sum_timeline(buf.ctypes.data, buf.size) == 0
 tl = buf.reshape(8192, 16)
 used = tl[:, 0] != 0
 size = (tl[:, 15] & 0xFFFFFFFF).astype(np.int64); window = (tl[:, 15] >> 32) != 0
-us = tl[:, :7].astype(np.float64) * 0.01
+us = tl[:, :10].astype(np.float64) * 0.01
 t0 = us[used, 0].min()
 print(f"{dist}, {batch} keys: {int(used.sum())} blocks stamped, {int((used & window).sum())} of them windows of hot keys' buckets; sizes: median {np.median(size[used & ~window & (size > 0)]):.0f}, max {size[used].max()}")
 print(f"block start relative to the first: median {np.median(us[used, 0] - t0):.1f} us, p90 {np.percentile(us[used, 0] - t0, 90):.1f}, max {(us[used, 0] - t0).max():.1f}")
@@ -36,8 +43,15 @@ hb = used & ~window & (us[:, 6] > 0)
 for k in range(6):
     d = us[hb, k + 1] - us[hb, k]
     print(f"  {names[k]:46s} median {np.median(d):7.2f} us   p10 {np.percentile(d, 10):7.2f}   p90 {np.percentile(d, 90):7.2f}   max {d.max():7.2f}")
+for a, b_, nm in ((1, 7, "  .. table cleared"), (7, 8, "  .. thread 0's entries in (binary search + one load)"), (8, 2, "  .. keys into the table + barrier"), (3, 9, "  .. thread 0's look-ups + inverse stores issued"), (9, 4, "  .. barrier, list filed, barrier")):
+    d = us[hb, b_] - us[hb, a]
+    print(f"  {nm:58s} median {np.median(d):7.2f} us   p10 {np.percentile(d, 10):7.2f}   p90 {np.percentile(d, 90):7.2f}")
 life = us[hb, 6] - us[hb, 0]
 print(f"  hash-bucket block life: median {np.median(life):.1f} us, p90 {np.percentile(life, 90):.1f}, max {life.max():.1f}; last end {us[hb, 6].max() - t0:.1f} us after the first start")
+rowp = us[:, 6] - us[:, 5]
+idx = np.arange(8192)
+print("  short-run phase by blockIdx % 8 (XCD): " + "  ".join(f"{np.median(rowp[hb & (idx % 8 == x)]):.0f}" for x in range(8)) + " us;  block end by XCD: "
+      + "  ".join(f"{np.median(us[hb & (idx % 8 == x), 6] - t0):.0f}/{(us[hb & (idx % 8 == x), 6] - t0).max():.0f}" for x in range(8)))
 wb = used & window
 if wb.any():
     print(f"  window blocks: start median {np.median(us[wb, 0] - t0):.1f} us, first phase {np.median(us[wb, 1] - us[wb, 0]):.1f} us (their later phases are not stamped)")
