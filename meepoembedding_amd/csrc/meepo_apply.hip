@@ -298,11 +298,12 @@ __device__ __forceinline__ void sum_sources(const ApplyLds& L, const ApplyArgs& 
 // what its mode needs (a slab never touches a table row, a merge never reads a gradient row), which is what keeps the skewed path's register
 // need near the whole buckets' 77 — every byte of scratch the kernel declares costs the UNIFORM batches time although they never touch it
 // (measured: 0 B: 62.5 us, 56 B (round 3): 63.1, 128-160 B: 67-68, 600 B: 94 us for the same bucket path).
-constexpr int kWhole = 0, kEmit = 1, kMerge = 2;
+// kListed — kWhole over the m entries of bucket b whose indices the caller left in L.off[0 .. m) (a split bucket without its majority key: slow_bucket).
+constexpr int kWhole = 0, kEmit = 1, kMerge = 2, kListed = 3;
 template <int KIND, int DIM4, bool LOCATED, int MODE, bool GROUPED = false>
 __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, uint32_t first, uint32_t m,
                                              uint32_t b, uint32_t rec_bucket0 /* split buckets: the bucket's first pending record */, uint32_t parity_rt, const GroupDesc* gdesc = nullptr) {
-    constexpr bool SPLIT = MODE != kWhole, emit = MODE == kEmit, src_rec = MODE == kMerge;
+    constexpr bool SPLIT = MODE == kEmit || MODE == kMerge, emit = MODE == kEmit, src_rec = MODE == kMerge, listed = MODE == kListed;
     static_assert(!GROUPED || LOCATED, "a group's batch names rows, not keys");
     constexpr int PPT = SPLIT ? 1 : (int)(kBucketCap / kApplyThreads);   // sources per thread
     // The kernel calls this from a loop (slab, then merge passes).  The thread index is re-read through an empty asm in every call so that
@@ -336,7 +337,7 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
                 my_key[u] = rec_load(bk.pend_key + rec_bucket0 + my_src[u]);
                 if constexpr (LOCATED) my_tslot[u] = rec_load(bk.pend_slot + rec_bucket0 + my_src[u]);   // the table slot the record carries
             } else {
-                const uint32_t gi = first + ti;   // index within the bucket -> its run (binary search over the run starts) -> its place in pos / pkey
+                const uint32_t gi = listed ? L.off[ti] : first + ti;   // index within the bucket (listed: off is rewritten behind the barrier that ends this phase) -> its run (binary search over the run starts) -> its place in pos / pkey
                 uint32_t k = 0;
 #pragma unroll
                 for (uint32_t stp = kPartBlocks / 2; stp; stp >>= 1) if (L.seg_first[k + stp] <= gi) k += stp;
@@ -500,7 +501,7 @@ __device__ __forceinline__ void process_slab(ApplyLds& L, const ApplyArgs& A, co
         const uint32_t c = valid ? L.cnt[s] : 0u;   // <= lc: the run is this one item
         const uint32_t run0 = L.off[s];
         const bool fin = !emit && valid;            // finished here: locate the row, update it once
-        const bool single = MODE == kWhole && fin && c == 1;
+        const bool single = !SPLIT && fin && c == 1;
         const int64_t key = (int64_t)(L.key[s] ^ kBias);
         const uint32_t src0 = valid ? L.src[run0] : 0u;
         f32x4 gpre = {0.f, 0.f, 0.f, 0.f};
@@ -916,7 +917,7 @@ __device__ __forceinline__ void run_units(ApplyLds& L, const ApplyArgs& A, const
 #if MEE_APPLY_TIMELINE
                 if (threadIdx.x == 0 && !skew) { A.dbg[(uint64_t)blockIdx.x * 8 + 6] = size | (unsigned long long)b << 32; unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); A.dbg[(uint64_t)blockIdx.x * 8 + 7] = (unsigned long long)(xcc & 0xf) << 32 | hw; }
 #endif
-                seg_scan(L, runs, tx);
+                if (SKEW) seg_scan(L, runs, tx);   // (LEAN: the caller has done it)
                 process_slab<KIND, DIM4, LOCATED, kWhole, GROUPED>(L, A, bk, 0, size, b, 0, parity, gdesc);
                 MEE_TL(A, 5);
             }
@@ -965,8 +966,10 @@ __device__ __forceinline__ uint32_t slow_share_of(int64_t key, uint32_t n_sub) {
 // the list_n <= 1024 entries whose indices L.off lists (the bucket without its majority key: one window)
 template <bool LOCATED>
 __device__ __forceinline__ uint32_t slow_sum_key(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t size, const unsigned long long cur, const uint32_t c0,
-                                                 const uint32_t dim4, const uint32_t win0, const uint32_t win_step, const uint32_t grad_rows, const uint32_t list_n = 0) {
-    const uint32_t t = threadIdx.x;
+                                                 const uint32_t dim4, const uint32_t win0, const uint32_t win_step, const uint32_t grad_rows, const uint32_t list_n = 0,
+                                                 const uint32_t window = kBucketCap /* entries per window, <= kBucketCap */) {
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));   // (as in process_slab: nothing derived from the thread index may look invariant across the callers' loops)
     const int lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6;
     const uint32_t col = c0 + (uint32_t)tl;
     const bool cok = col < dim4;
@@ -974,11 +977,11 @@ __device__ __forceinline__ uint32_t slow_sum_key(ApplyLds& L, const ApplyArgs& A
     __syncthreads();
     if (t < 16) { double* r = &L.prow[8][tl * 4]; r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; r[3] = 0.0; }
     uint32_t total = 0;
-    for (uint32_t e0 = win0 * kBucketCap; e0 < count; e0 += win_step * kBucketCap) {
+    for (uint32_t e0 = win0 * window; e0 < count; e0 += win_step * window) {
         __syncthreads();
         if (t == 0) L.n_cand = 0u;
         __syncthreads();
-        for (uint32_t i = e0 + t; i < min(count, e0 + kBucketCap); i += kApplyThreads) {
+        for (uint32_t i = e0 + t; i < min(count, e0 + window); i += kApplyThreads) {
             const PartEntry en = bk.ent[bucket_entry_at(L, list_n ? L.off[i] : i)];
             if (((unsigned long long)en.key ^ kBias) != cur) continue;
             const uint32_t p = en.pos;
@@ -1016,7 +1019,8 @@ __device__ __forceinline__ uint32_t slow_sum_key(ApplyLds& L, const ApplyArgs& A
 // one update of columns [c0, c0 + 16) of `key`'s row from the fp64 sum in L.prow[8] (wave 0; its tile 0 holds the row)
 template <int KIND, int DIM4, bool LOCATED, bool GROUPED>
 __device__ __forceinline__ void slow_update(ApplyLds& L, const ApplyArgs& A, const OptArgs& a, const GroupDesc* gdesc, const int64_t key, const uint32_t c0, const uint32_t dim4) {
-    const uint32_t t = threadIdx.x;
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));   // (as in process_slab: nothing derived from the thread index may look invariant across the callers' loops)
     const int lane = t & 63, tile = lane >> 4, tl = lane & 15;
     if (t >= 64) return;
     const uint32_t col = c0 + (uint32_t)tl;
@@ -1043,25 +1047,37 @@ __device__ __forceinline__ void slow_update(ApplyLds& L, const ApplyArgs& A, con
 }
 
 // A share of a split bucket (LEAN kernel).  What costs here is WALKING the bucket — 15 000 entries, each found through a binary search over the partition blocks'
-// runs — once per key of the share (twice: the next key, then its rows), so the bucket is walked ONCE: a candidate for its majority key comes from 64 sampled entries
-// (a bucket is split because one key fills it), and one pass — two entries in flight per thread — counts the candidate, keeps one of its slot handles and LISTS the
-// bucket's other entries in LDS (L.off: up to 1024 of them; a bucket of 15 000 positions around a key of 14 600 lists 400).  A candidate with >= kSlowMajorityMin
-// occurrences is summed by ALL shares (window w of 1024 entries belongs to share w mod n_sub; one fp64 partial row per share, a ticket, the last share adds them
-// up and updates); every other key is one share's (slow_share_of), found and summed in the list.  When the list overflows (two giant keys in one bucket) the keys
-// are found by walking the whole bucket, as in round 4.
-constexpr uint32_t kSlowMajorityMin = 2 * kBucketCap;   // occurrences from which the bucket's majority key is shared by position instead of being one share's
-template <int KIND, int DIM4, bool LOCATED, bool GROUPED>
+// runs.  A bucket is split because ONE key fills it, so: a candidate for its majority key comes from 64 sampled entries (Boyer-Moore votes; every share samples the
+// same entries and gets the same answer), and when the candidate holds a quarter of the samples the bucket is worked off BY POSITION:
+//   * every share sums the candidate's rows in its own windows of 1024 entries (window w belongs to share w mod n_sub), leaves ONE fp64 partial row and draws a
+//     ticket; the share that draws the last one adds the <= 65 partial rows up and updates the key.  A helper reads nothing of the bucket but its windows;
+//   * the bucket's own block (share 0) walks the bucket ONCE, four entries in flight per thread: it counts the candidate (the hot-key report) and LISTS the other
+//     entries in LDS (L.off: a bucket of 15 000 positions around a key of 14 600 lists 400), and those go through the ordinary bucket path (process_slab<kListed>:
+//     hash table, runs, tiles — one pass for all ~350 keys instead of four dependent round trips per key and share).
+// Anything else — no dominant candidate, or more than 1024 other entries (two giant keys in one bucket) — is shared by KEY as in round 4: each share takes the keys
+// its hash gives it (slow_share_of), one at a time.
+constexpr uint32_t kSlowAgree = 16;   // samples (of 64) that must carry the candidate
+constexpr uint32_t kSlowWindow = 512;   // entries of a share's window when a bucket is worked off by position (one per thread: one round trip finds the candidate's, <= 16 rows per tile)
+#ifndef MEE_SLOW_WALK
+#define MEE_SLOW_WALK 4
+#endif
+constexpr uint32_t kWalk = MEE_SLOW_WALK;   // entries in flight per thread in the walk
+template <int KIND, int DIM4, bool LOCATED, bool GROUPED, bool OWN /* share 0: the bucket's own block */>
 __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t b, const uint32_t size, const uint32_t parity, const GroupDesc* gdesc,
-                                            const uint32_t sub, const uint32_t n_sub) {
+                                            const uint32_t sub_arg, const uint32_t n_sub) {
+    const uint32_t sub = OWN ? 0u : sub_arg;
     static_assert(!GROUPED || LOCATED, "a group's batch names rows, not keys");
-    const uint32_t t = threadIdx.x;
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));   // (as in process_slab: nothing derived from the thread index may look invariant across the callers' loops)
     const uint32_t dim4 = DIM4 ? DIM4 : A.dim4;
     OptArgs a = A.a;
     a.kind = KIND;
     __syncthreads();   // (the caller's wave 0 has just written L.seg_first / L.seg_at: nobody may walk the bucket's entries before that)
-    // ---- the candidate: Boyer-Moore votes over 64 entries spread over the bucket (wave 0; merged pairwise with shuffles)
+    // ---- the candidate: Boyer-Moore votes over 64 entries spread over the bucket (wave 0; merged pairwise with shuffles), then how many samples carry it
     if (t < 64) {
-        unsigned long long cand = (unsigned long long)bk.ent[bucket_entry_at(L, (uint32_t)(((uint64_t)t * size) >> 6))].key ^ kBias;
+        const PartEntry sm = bk.ent[bucket_entry_at(L, (uint32_t)(((uint64_t)t * size) >> 6))];
+        const unsigned long long mine = (unsigned long long)sm.key ^ kBias;
+        unsigned long long cand = mine;
         int votes = 1;
 #pragma unroll
         for (int d = 32; d; d >>= 1) {
@@ -1069,40 +1085,50 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
             const int ov = __shfl_xor(votes, d);
             if (oc == cand) votes += ov; else if (ov > votes) { cand = oc; votes = ov - votes; } else votes -= ov;
         }
-        if (t == 0) { L.kmax = cand; L.n_cand = 0u; L.n_items = 0u; }
+        // (lane 0's candidate: always one of the samples)
+        cand = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)cand, 0) | (unsigned long long)(uint32_t)__shfl((int)(uint32_t)(cand >> 32), 0) << 32;
+        const unsigned long long agree = __ballot(mine == cand);
+        if (t == 0) { L.kmax = cand; L.n_cand = 0u; L.n_items = 0u; L.stk_n = (uint32_t)__popcll(agree); }   // (stk_n: the merge passes' word, free in the LEAN kernel)
+        if constexpr (LOCATED) if ((int)t == __ffsll((long long)agree) - 1) L.slot[0] = A.slots[sm.pos];   // (any occurrence: they all name the same slot)
     }
     __syncthreads();
     const unsigned long long cand = L.kmax;
-    // ---- ONE walk: count the candidate, keep a slot handle of it, list everything else
-    {
+    const int64_t cand_key = (int64_t)(cand ^ kBias);
+    const bool by_position = n_sub > 1 && L.stk_n >= kSlowAgree && ((uint64_t)b + 1) * (kSlowHelpers + 1) <= bk.fast_max;   // block-uniform, and the same in every share of the bucket
+    // ---- ONE walk (by position: share 0 alone): count the candidate, list everything else
+    if (!by_position || OWN) {
         uint32_t mine = 0;
-        for (uint32_t e0 = t; e0 < size; e0 += 2 * kApplyThreads) {
-            const uint32_t e1 = e0 + kApplyThreads;
-            const PartEntry en0 = bk.ent[bucket_entry_at(L, e0)];
-            const PartEntry en1 = bk.ent[bucket_entry_at(L, min(e1, size - 1))];
-            const bool m0 = ((unsigned long long)en0.key ^ kBias) == cand, m1 = e1 < size && ((unsigned long long)en1.key ^ kBias) == cand;
-            if constexpr (LOCATED) if (mine == 0 && (m0 || m1)) L.slot[0] = A.slots[m0 ? en0.pos : en1.pos];   // (any occurrence: they all name the same slot, so concurrent writers agree)
-            mine += (uint32_t)m0 + (uint32_t)m1;
-            if (!m0) { const uint32_t q = atomicAdd(&L.n_items, 1u); if (q < kBucketCap) L.off[q] = e0; }
-            if (!m1 && e1 < size) { const uint32_t q = atomicAdd(&L.n_items, 1u); if (q < kBucketCap) L.off[q] = e1; }
+        for (uint32_t e0 = t; e0 < size; e0 += kWalk * kApplyThreads) {
+            PartEntry en[kWalk];
+#pragma unroll
+            for (uint32_t q = 0; q < kWalk; ++q) en[q] = bk.ent[bucket_entry_at(L, min(e0 + q * kApplyThreads, size - 1))];
+#pragma unroll
+            for (uint32_t q = 0; q < kWalk; ++q) {
+                const uint32_t e = e0 + q * kApplyThreads;
+                if (e >= size) continue;
+                if (((unsigned long long)en[q].key ^ kBias) == cand) ++mine;
+                else { const uint32_t at = atomicAdd(&L.n_items, 1u); if (at < kBucketCap) L.off[at] = e; }
+            }
         }
         if (mine) atomicAdd(&L.n_cand, mine);
     }
     __syncthreads();
     const uint32_t n_major = L.n_cand, n_other = L.n_items;
     const uint32_t list_n = n_other <= kBucketCap ? n_other : 0u;   // 0: the others do not fit the list (walk the whole bucket for them)
-    const bool shared = n_sub > 1 && n_major >= kSlowMajorityMin && ((uint64_t)b + 1) * (kSlowHelpers + 1) <= bk.fast_max;   // block-uniform, and the same in every share of the bucket
-    const int64_t cand_key = (int64_t)(cand ^ kBias);
-    if (shared) {
+    if (by_position) {
+        // windows of kSlowWindow entries, window w to share w mod n_pos; a bucket with fewer windows than shares leaves the shares behind its windows out altogether
+        // (no partial row, no ticket: most helper duties of a batch end here, two round trips in)
+        const uint32_t n_pos = min(n_sub, (size + kSlowWindow - 1) / kSlowWindow);
+        if (!OWN && sub >= n_pos) return;   // (block-uniform)
         const int64_t slot_handle = LOCATED ? (int64_t)L.slot[0] : 0;
         double* prt = bk.pend_row + ((uint64_t)b * (kSlowHelpers + 1) + sub) * dim4 * 4;
         for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {
-            (void)slow_sum_key<LOCATED>(L, A, bk, size, cand, c0, dim4, sub, n_sub, a.grad_rows);
+            (void)slow_sum_key<LOCATED>(L, A, bk, size, cand, c0, dim4, sub, n_pos, a.grad_rows, 0u, kSlowWindow);
             if (t < 16 && c0 + t < dim4) rec_store_row4(prt + (uint64_t)(c0 + t) * 4, L.prow[8][t * 4], L.prow[8][t * 4 + 1], L.prow[8][t * 4 + 2], L.prow[8][t * 4 + 3]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partial row is out before the ticket is drawn
         __syncthreads();
-        if (t == 0) L.is_last = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_sub - 1;
+        if (t == 0) L.is_last = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_pos - 1;
         __syncthreads();
         if (L.is_last) {   // block-uniform: the share that finishes last adds the partial rows up and updates the key
             if constexpr (LOCATED) if (t == 0) L.slot[0] = slot_handle;
@@ -1111,7 +1137,7 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
                 __syncthreads();
                 if (t < 16 && c0 + t < dim4) {
                     double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
-                    for (uint32_t j = 0; j < n_sub; ++j) {
+                    for (uint32_t j = 0; j < n_pos; ++j) {
                         const double* q = all + ((uint64_t)j * dim4 + c0 + t) * 4;
                         r0 += rec_load(q); r1 += rec_load(q + 1); r2 += rec_load(q + 2); r3 += rec_load(q + 3);
                     }
@@ -1121,7 +1147,15 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
                 __syncthreads();
                 slow_update<KIND, DIM4, LOCATED, GROUPED>(L, A, a, gdesc, cand_key, c0, dim4);
             }
+        }
+        if constexpr (!OWN) return;   // a helper's part ends here
+        else {
             if (t == 0 && n_major >= A.hot_count) report_hot_key(bk, parity, cand_key);   // its own bucket next time
+            if (n_other == 0) return;
+            if (list_n) {   // the rest of the bucket is an ordinary bucket's worth of entries: the ordinary path
+                process_slab<KIND, DIM4, LOCATED, kListed, GROUPED>(L, A, bk, 0, list_n, b, 0, parity, gdesc);
+                return;
+            }
         }
     } else if (n_major != 0 && slow_share_of(cand_key, n_sub) == sub) {   // the candidate is an ordinary key of this share (it is not in the list)
         for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {
@@ -1130,7 +1164,9 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
         }
         if (t == 0 && n_major >= A.hot_count) report_hot_key(bk, parity, cand_key);
     }
-    // ---- the other keys: each share takes the keys its hash gives it, one at a time in increasing key order
+    // ---- the other keys, shared by key: each share takes the keys its hash gives it, one at a time in increasing key order
+    // (by position with an overflowing list: share 0 takes them all)
+    const uint32_t k_sub = by_position ? 0u : sub, k_n = by_position ? 1u : n_sub;
     const uint32_t walk_n = list_n ? list_n : size;
     bool have_last = false;
     unsigned long long last = 0;
@@ -1143,7 +1179,7 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
         for (uint32_t i = t; i < walk_n; i += kApplyThreads) {
             const int64_t k = bk.ent[bucket_entry_at(L, list_n ? L.off[i] : i)].key;
             const unsigned long long bkey = (unsigned long long)k ^ kBias;
-            if ((!have_last || bkey > last) && bkey < mn && bkey != cand && slow_share_of(k, n_sub) == sub) mn = bkey;
+            if ((!have_last || bkey > last) && bkey < mn && bkey != cand && slow_share_of(k, k_n) == k_sub) mn = bkey;
         }
         if (mn != ~0ull) atomicMin(&L.kmin, mn);
         __syncthreads();
@@ -1190,6 +1226,7 @@ __global__ __launch_bounds__(kApplyThreads, kApplyWavesPerSimd) void bkt_apply_k
     // three dependent loads, 2-3 us of every block's life before its first useful request.)
     MEE_TL(A, 0);
     // (FULL: the grid is one round of the resident block slots; the blocks beyond the hash buckets have no bucket of their own)
+    if (FULL && A.part_blocks == 0) return;   // (grid-uniform) no batch: the launch that makes the queue hold this kernel's scratch before a skewed batch needs it (bucket_apply_launch)
     const bool own = blockIdx.x < A.nbk_hash;
     const SegRuns runs = seg_load(A, bk, own ? blockIdx.x : 0u, own ? threadIdx.x : 64u);
     const uint32_t tot0 = own ? bk.tot[blockIdx.x] : 0u, tot1 = own ? bk.tot[bk.n_buckets_max + blockIdx.x] : 0u;
@@ -1213,18 +1250,12 @@ __global__ __launch_bounds__(kApplyThreads, kApplyWavesPerSimd) void bkt_apply_k
         // slab and merge units running side by side on them)
         run_units<KIND, DIM4, LOCATED, GROUPED, true>(L, A, bk, parity, runs, size0, parity ? pa1 : pa0, parity ? pb1 : pb0, gdesc);
     } else {   // LEAN: the batch was partitioned into hash buckets only, block = bucket
-        if (size0 <= kBucketCap) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) report_units(bk, A.h_slabs, 0u);   // (a block with a split bucket overwrites it when it is done, much later)
-            run_units<KIND, DIM4, LOCATED, GROUPED, false>(L, A, bk, parity, runs, size0, 0u, 0u, gdesc);
-        } else {
-            seg_scan(L, runs, threadIdx.x);
-            slow_bucket<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, blockIdx.x, size0, parity, gdesc, 0u, slow_shares(size0, A.nbk));
-            // the stream is skewed: the FULL kernel from now on, with as many agents as this batch had slabs (the block that finishes last leaves the sum)
-            if (threadIdx.x == 0) report_slabs(bk, A.h_slabs, (size0 + kSlab - 1) / kSlab, 0u);
-        }
+        SegRuns own_runs = runs;
         if (__builtin_amdgcn_readfirstlane(parity ? hdr.w : hdr.z) != 0) {   // (block-uniform) the batch has a split bucket somewhere
-            // helper duty: block x is share j >= 1 of the split bucket x - j (mod nbk).  Every wave looks at the same 64 buckets in front of
-            // the block's own (one load per lane, L2-resident), so the ballot is the same in every wave and the loop below is block-uniform.
+            // helper duty FIRST: block x is share j >= 1 of the split bucket x - j (mod nbk) — a share is a few windows of the bucket's majority key at most (slow_bucket),
+            // and the key's update waits for the last of them: behind the blocks' own buckets (round 5's first form) that was 55 us into the kernel at the earliest.
+            // Every wave looks at the same 64 buckets in front of the block's own (one load per lane, L2-resident), so the ballot is the same in every wave and the loop
+            // below is block-uniform.
             const uint32_t nbk = A.nbk, j = (threadIdx.x & 63u) + 1u;
             const uint32_t y = (blockIdx.x + nbk - j % nbk) % nbk;
             const uint32_t ty = j < nbk ? bk.tot[parity * bk.n_buckets_max + y] : 0u;
@@ -1233,10 +1264,24 @@ __global__ __launch_bounds__(kApplyThreads, kApplyWavesPerSimd) void bkt_apply_k
                 const uint32_t jj = (uint32_t)__builtin_ctzll(duty);
                 duty &= duty - 1;
                 const uint32_t yy = __builtin_amdgcn_readlane(y, jj), tyy = __builtin_amdgcn_readlane(ty, jj);
-                __syncthreads();   // (whatever this block did before is done with the LDS)
+                __syncthreads();   // (the duty before this one is done with the LDS)
                 seg_scan(L, seg_load(A, bk, yy, threadIdx.x), threadIdx.x);
-                slow_bucket<KIND, DIM4, LOCATED, GROUPED>(L, A, bk, yy, tyy, parity, gdesc, jj + 1u, slow_shares(tyy, nbk));
+                slow_bucket<KIND, DIM4, LOCATED, GROUPED, false>(L, A, bk, yy, tyy, parity, gdesc, jj + 1u, slow_shares(tyy, nbk));
             }
+            __syncthreads();
+            own_runs = seg_load(A, bk, blockIdx.x, threadIdx.x);   // (fetched again rather than kept in four registers per thread across the duties)
+        }
+        // (the run starts go into LDS before the paths part: the runs must not stay live across the split bucket's code, which the compiler lays out in front of the
+        // ordinary path)
+        seg_scan(L, own_runs, threadIdx.x);
+        if (size0 <= kBucketCap) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) report_units(bk, A.h_slabs, 0u);   // (a block with a split bucket overwrites it when it is done, much later)
+            run_units<KIND, DIM4, LOCATED, GROUPED, false>(L, A, bk, parity, own_runs, size0, 0u, 0u, gdesc);
+        } else {
+            // the stream is skewed: the FULL kernel from now on, with as many agents as this batch had slabs (the sum over the blocks that met a split bucket; the host
+            // reads it when it launches the next batch — the sooner it is there, the better)
+            if (threadIdx.x == 0) report_slabs(bk, A.h_slabs, (size0 + kSlab - 1) / kSlab, 0u);
+            slow_bucket<KIND, DIM4, LOCATED, GROUPED, true>(L, A, bk, blockIdx.x, size0, parity, gdesc, 0u, slow_shares(size0, A.nbk));
         }
     }
 }
@@ -1355,6 +1400,7 @@ int bucket_scratch_alloc(mee_table* t) {
     bk.fast_max = t->max_batch;   // every batch the table takes: beyond ~5M keys (kMaxBuckets buckets of ~700) the buckets outgrow kBucketCap and go through their slabs
     // buckets the largest batch can be cut into (+ the hot keys' own): the strides of the totals' two copies and of the run matrices
     bk.n_buckets_max = bucket_count_for_host(bk.fast_max, bk.slots);
+    if (const char* env = getenv("MEE_EXP_NBK_SCALE")) bk.n_buckets_max *= (uint32_t)atoi(env);   // EXPERIMENT
     bk.n_buckets_max += kHotCap;
     if (bk.n_buckets_max > kMaxBuckets) bk.n_buckets_max = kMaxBuckets;
     bk.n_buckets_max = (bk.n_buckets_max + 63u) & ~63u;
@@ -1481,6 +1527,23 @@ int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const Op
                           else if (d_slots) BKT(K, D4, true); else BKT(K, D4, false); } while (0)
 #define BKT_D(K) do { if (t->dim4 == 16) BKT_L(K, 16); else if (t->dim4 == 32) BKT_L(K, 32); else BKT_L(K, 0); } while (0)
     if (a.kind == MEE_OPT_ADAGRAD) BKT_D(MEE_OPT_ADAGRAD); else BKT_D(MEE_OPT_ADAM);
+    // The FULL kernel needs scratch memory (124-192 B per lane), the LEAN kernel none.  A queue gets its scratch when the first launch that needs it arrives: the
+    // runtime allocates it on the host and re-submits — 147 us measured between a stream's forward and its first FULL apply (the second skewed step of a stream: 230-290 us
+    // against 95 from the third on).  So the first LEAN apply a table sees on a stream is followed by ONE empty launch of the FULL kernel (same instance, same grid, no batch:
+    // every block returns at its first instruction): the allocation happens behind a kernel that is running anyway, on a batch that is not waiting for it.
+    if (!full && t->bk.skew_adapt && t->bk.kernel_choice < 0 && !stream_is_capturing(st)) {
+        bool ready = false;
+        for (uint32_t i = 0; i < t->full_ready_n; ++i) ready |= t->full_ready[i] == (void*)st;
+        if (!ready) {
+            for (uint32_t i = 3; i > 0; --i) t->full_ready[i] = t->full_ready[i - 1];
+            t->full_ready[0] = (void*)st;
+            if (t->full_ready_n < 4) ++t->full_ready_n;
+            const bool full = true;
+            const uint32_t grid = t->part_grid ? t->part_grid : A.nbk;   // (the FULL kernel's grid: one round of the block slots)
+            A.part_blocks = 0;
+            if (a.kind == MEE_OPT_ADAGRAD) BKT_D(MEE_OPT_ADAGRAD); else BKT_D(MEE_OPT_ADAM);
+        }
+    }
 #undef BKT_D
 #undef BKT_L
 #undef BKT

@@ -119,14 +119,19 @@ __device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long l
 }
 #undef MEE_DPP_ADD64
 
+// a barrier that waits for this wave's LDS traffic only: __syncthreads() also drains the global stores in flight (s_waitcnt vmcnt(0)) — stores that nothing in the
+// block reads back; their acknowledgement is 2-5 us under load
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // exclusive prefix sum of a packed 64-bit value over a block of NW waves; every field of the packed value must stay below its width
-template <int NW>
+// (LDS_ONLY: the barriers inside do not wait for global stores in flight)
+template <int NW, bool LDS_ONLY = false>
 __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v, unsigned long long* wsum /*[NW]*/, unsigned long long& total) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (wave-uniform: the comparisons below are scalar)
     const unsigned long long incl = wave_incl_scan_u64(v);
-    __syncthreads();   // wsum may still be read from an earlier call
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();   // wsum may still be read from an earlier call
     if (lane == 63) wsum[w] = incl;
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     unsigned long long pre = 0, tot = 0;
 #pragma unroll
     for (int ww = 0; ww < NW; ++ww) { const unsigned long long x = wsum[ww]; if (ww < w) pre += x; tot += x; }
@@ -138,10 +143,15 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
 // batch's partition).  A few hundred calls per skewed batch, none on a uniform one.  The set stops taking keys once kHotCap are numbered (a
 // batch with more hot keys than that keeps the first comers): its load stays low and every probe of it ends at an empty slot.
 // The set numbers the first comers; when a batch has more candidates than numbers, WHO is left out must not be chance: a key with 80 000 occurrences that
-// stays in a hash bucket is one block's work for milliseconds.  So the last quarter of the numbers is kept for keys that pass the bar eightfold (`giant`:
-// a Zipf(1.05) batch has ~17 of them whatever its size).
-__device__ __forceinline__ void report_hot_key(const BucketScratch& bk, uint32_t parity, int64_t key, bool giant = true) {
-    if (__hip_atomic_load(&bk.hot_n[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (giant ? kHotCap : kHotCap - kHotCap / 4)) return;
+// stays in a hash bucket is one block's work for milliseconds, one with 3 000 for 150 us (the tail of a Zipf batch's dedup_sum: with ONE reserved quarter for keys
+// that pass the bar eightfold, 6 keys of 2-4x the bar and 3 of 4-8x were left out of every 1M-key Zipf(1.05) batch — 122 candidates for 128 numbers, 96 of them
+// open to all).  So a candidate is admitted while the set holds fewer keys than ITS class may fill (hot_cap_of): the bar itself 88, twice the bar 108, four times
+// 120, eight times all 128 — under any Zipf-like stream each class is about as large as all the classes above it together, and the ones left out are the smallest.
+__device__ __forceinline__ uint32_t hot_cap_of(uint32_t count, uint32_t bar) {
+    return count >= 8 * bar ? kHotCap : count >= 4 * bar ? kHotCap - kHotCap / 16 : count >= 2 * bar ? kHotCap - 5 * kHotCap / 32 : kHotCap - 5 * kHotCap / 16;
+}
+__device__ __forceinline__ void report_hot_key(const BucketScratch& bk, uint32_t parity, int64_t key, uint32_t cap = kHotCap) {
+    if (__hip_atomic_load(&bk.hot_n[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cap) return;
     const unsigned long long bkey = (unsigned long long)key ^ kBias;
     uint32_t h = hot_slot_of(key);   // (the slot part_bucket_of looks at first)
     unsigned long long* set = bk.hot_key + parity * kHotSlots;

@@ -89,10 +89,18 @@ __device__ __forceinline__ void dd_seg_scan(DedupLds& L, const DdRuns& r, uint32
     if (tid == 63) L.seg_first[kPartBlocksMax] = incl;
 }
 
+// The table is probed by DOUBLE hashing — first slot and (odd) stride from the TOP bits of mix64b(key); the passes split on its low bits —: a hash bucket of ~683
+// positions fills the 1024 slots to 0.67, where linear probing's clusters made the slowest of a wave's 64 lanes probe 30-40 times (the wave waits for it: 12 us of a
+// block's build, 5 of its look-ups); without clusters the slowest lane of a wave needs ~12.
+__device__ __forceinline__ uint32_t dd_slot0(uint64_t h) { return (uint32_t)(h >> 54); }
+__device__ __forceinline__ uint32_t dd_stride(uint64_t h) { return ((uint32_t)(h >> 43) & (kDedupSlots - 1)) | 1u; }
+static_assert(kDedupSlots == 1024, "dd_slot0 takes the top 10 bits");
 // slot of `bkey` in the pass's table (the key is there)
 __device__ __forceinline__ uint32_t dd_lookup(const DedupLds& L, unsigned long long bkey) {
-    uint32_t s = (uint32_t)(mix64b(bkey ^ kBias) >> 12) & (kDedupSlots - 1);
-    while (L.key[s] != bkey) s = (s + 1) & (kDedupSlots - 1);
+    const uint64_t h = mix64b(bkey ^ kBias);
+    uint32_t s = dd_slot0(h);
+    const uint32_t stride = dd_stride(h);
+    while (L.key[s] != bkey) s = (s + stride) & (kDedupSlots - 1);
     return s;
 }
 
@@ -108,7 +116,8 @@ __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, u
     H.valid = size <= 4u * kDedupThreads;   // (block-uniform)
     for (uint32_t j = t; j < kDedupSlots; j += kDedupThreads) { L.key[j] = 0ull; L.val[j] = 0u; L.cnt[j] = 0u; }
     if (t == 0) { L.n_distinct = 0u; L.overflow = 0u; }
-    __syncthreads();
+    const bool may_overflow = size > kDedupFill;   // (block-uniform) a pass over at most kDedupFill entries cannot: nobody counts its keys
+    lds_barrier();
     MEE_STL(7);   // table cleared
     const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
     constexpr int kIn = 4;   // entries a thread has in flight per step (one dependent round trip per step: a bucket of 4 000 entries takes 4 steps, not 16)
@@ -151,14 +160,21 @@ __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, u
 #pragma unroll
                 for (int d = 32; d; d >>= 1) pmax = max(pmax, (uint32_t)__shfl_xor((int)pmax, d));
             }
-            if (mine && (!uniform || (int)(t & 63) == lead) && __hip_atomic_load(&L.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
-                uint32_t s = (uint32_t)(mix64b(bkey ^ kBias) >> 12) & (kDedupSlots - 1);
+            if (mine && (!uniform || (int)(t & 63) == lead) && (!may_overflow || __hip_atomic_load(&L.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u)) {
+                const uint64_t h = mix64b((uint64_t)key);
+                uint32_t s = dd_slot0(h);
+                const uint32_t stride = dd_stride(h);
                 bool placed = false;
-                for (uint32_t probes = 0; probes < kDedupSlots; ++probes) {   // (bounded: a table that other threads fill up meanwhile must not trap this one)
-                    const unsigned long long old = atomicCAS(&L.key[s], 0ull, bkey);
-                    if (old == 0ull) { if (atomicAdd(&L.n_distinct, 1u) >= kDedupFill) __hip_atomic_store(&L.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); placed = true; break; }
+                for (uint32_t probes = 0; probes < kDedupSlots; ++probes) {   // (bounded: a table that other threads fill up meanwhile must not trap this one; an odd stride visits every slot)
+                    // a plain read first: an occupied slot (another key: next slot; this key: done) costs no compare-and-swap
+                    unsigned long long old = __hip_atomic_load(&L.key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (old == 0ull) old = atomicCAS(&L.key[s], 0ull, bkey);
+                    if (old == 0ull) {
+                        if (may_overflow && atomicAdd(&L.n_distinct, 1u) >= kDedupFill) __hip_atomic_store(&L.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        placed = true; break;
+                    }
                     if (old == bkey) { placed = true; break; }
-                    s = (s + 1) & (kDedupSlots - 1);
+                    s = (s + stride) & (kDedupSlots - 1);
                 }
                 if (placed) {
                     atomicAdd(&L.cnt[s], uniform ? (uint32_t)__popcll(act) : 1u);
@@ -167,7 +183,7 @@ __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, u
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     return L.overflow == 0u;
 }
 
@@ -177,20 +193,20 @@ __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, u
 template <bool LAST, class Emit>
 __device__ __forceinline__ void dd_passes(DedupLds& L, const BucketScratch& bk, uint32_t size, uint32_t parity, uint32_t hot_count, uint32_t* status, Emit emit) {
     if (threadIdx.x == 0) { L.stk_n = 1u; L.stk_bits[0] = 0u; L.stk_val[0] = 0ull; }
-    __syncthreads();
+    lds_barrier();
     while (true) {
         const uint32_t n = __builtin_amdgcn_readfirstlane(L.stk_n);
         if (n == 0) break;
         const uint32_t bits = __builtin_amdgcn_readfirstlane(L.stk_bits[n - 1]);
         const unsigned long long val_v = L.stk_val[n - 1];
         const uint64_t val = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)val_v) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(val_v >> 32)) << 32;
-        __syncthreads();
+        lds_barrier();
         if (threadIdx.x == 0) L.stk_n = n - 1;
         DdHeld held;
         if (dd_build<LAST>(L, bk, size, bits, val, held)) {
             // keys with enough occurrences to fill half a slab get a bucket of their own in the next batch (meepo_apply_part.h)
             for (uint32_t s = threadIdx.x; s < kDedupSlots; s += kDedupThreads)
-                if (L.cnt[s] >= hot_count) report_hot_key(bk, parity, (int64_t)(L.key[s] ^ kBias), L.cnt[s] >= 8 * hot_count);
+                if (L.cnt[s] >= hot_count) report_hot_key(bk, parity, (int64_t)(L.key[s] ^ kBias), hot_cap_of(L.cnt[s], hot_count));
             emit(bits, val, held);
         } else if (threadIdx.x == 0) {
             if (bits < 64 && L.stk_n + 2 <= 72) {
@@ -200,7 +216,7 @@ __device__ __forceinline__ void dd_passes(DedupLds& L, const BucketScratch& bk, 
                 L.stk_n = m + 2;
             } else if (status) atomicOr(status, (uint32_t)MEE_STATUS_INTERNAL);   // cannot happen (see above); never lose keys silently
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -236,16 +252,16 @@ __device__ __forceinline__ HotPlan hot_plan(DedupLds& L, const BucketScratch& bk
     if (t < 128) { iw = wave_incl_scan_u32(nw); ie = wave_incl_scan_u32(ne); }
     if (t == 63) { L.hp[0] = iw; L.hp[1] = ie; }
     if (t == 0) L.hp[6] = 0xFFFFFFFFu;
-    __syncthreads();
+    lds_barrier();
     if (t >= 64 && t < 128) { iw += L.hp[0]; ie += L.hp[1]; }
     if (t == 127) { L.hp[2] = iw; L.hp[3] = ie; }
     if (x >= 0 && t < 128 && nw != 0 && (uint32_t)x >= iw - nw && (uint32_t)x < iw) {   // exactly one thread (the windows' ranges are disjoint)
         L.hp[4] = (uint32_t)x - (iw - nw); L.hp[5] = nw; L.hp[6] = t; L.hp[7] = ie - 1u; L.base = sz;
     }
-    __syncthreads();
+    lds_barrier();
     P.units = L.hp[2]; P.H = L.hp[3];
     if (x >= 0 && L.hp[6] != 0xFFFFFFFFu) { P.win = L.hp[4]; P.n_win = L.hp[5]; P.h = L.hp[6]; P.rank = L.hp[7]; P.size = L.base; P.valid = true; }
-    __syncthreads();   // (the hand-over words are reused)
+    lds_barrier();   // (the hand-over words are reused)
     return P;
 }
 
@@ -294,15 +310,15 @@ __device__ __forceinline__ uint32_t dd_bucket(DedupLds& L, const BucketScratch& 
             if ((threadIdx.x & 63) == 0) L.pre[threadIdx.x >> 6] = mine;
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (A.size_from_runs && own) size = __builtin_amdgcn_readfirstlane(L.seg_first[kPartBlocksMax]);   // (dd_seg_scan left the sum of the runs there)
     if (own && size > kBucketCap && threadIdx.x == 0) report_slabs(bk, A.h_slabs, (size + kSlab - 1) / kSlab, P.units);   // a skewed stream: hot keys get buckets of their own next time
     if (PREFIX && own) for (int w = 0; w < kDedupWaves; ++w) before += L.pre[w];
-    __syncthreads();
+    lds_barrier();
     return size;
 }
 
-__global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs A, BucketScratch bk) {
+__global__ __launch_bounds__(kDedupThreads, 7) void bkt_dedup_keys_kernel(DedupArgs A, BucketScratch bk) {
     __shared__ DedupLds L;
     uint32_t parity, before;
     HotPlan P;
@@ -313,7 +329,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
         if (P.win == 0 && threadIdx.x == 0) {
             const int64_t key = bk.ent[dd_entry_at(L, 0)].key;
             A.uniq[P.rank] = key;
-            if (size >= A.hot_count) report_hot_key(bk, parity, key, size >= 8 * A.hot_count);   // stays listed while it stays hot
+            if (size >= A.hot_count) report_hot_key(bk, parity, key, hot_cap_of(size, A.hot_count));   // stays listed while it stays hot
         }
         for (uint32_t e0 = lo; e0 < hi; e0 += 4 * kDedupThreads) {   // four positions in flight per thread (a window is 16 per thread: 4 round trips, not 16)
             uint32_t pp[4];
@@ -336,7 +352,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
 #pragma unroll
         for (uint32_t q = 0; q < per; ++q) mine += L.key[t * per + q] != 0ull;
         unsigned long long total;
-        uint32_t idx = (uint32_t)block_scan_u64<kDedupWaves>(mine, L.wsum, total);
+        uint32_t idx = (uint32_t)block_scan_u64<kDedupWaves, true>(mine, L.wsum, total);
         const uint32_t base = slice;
         slice += (uint32_t)total;   // (block-uniform: the next pass of this bucket continues behind this one's keys)
 #pragma unroll
@@ -344,7 +360,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_dedup_keys_kernel(DedupArgs
             const uint32_t s = t * per + q;
             if (L.key[s] != 0ull) { A.uniq[base + idx] = (int64_t)(L.key[s] ^ kBias); L.val[s] = idx++; }
         }
-        __syncthreads();
+        lds_barrier();   // (the key stores are not read back)
         const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
         if (held.valid) {   // (block-uniform) the entries are still in registers
 #pragma unroll
@@ -397,7 +413,7 @@ struct AssignArgs {
 };
 
 template <int DIM4>
-__global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A, BucketScratch bk) {
+__global__ __launch_bounds__(kDedupThreads, 5) void bkt_assign_kernel(AssignArgs A, BucketScratch bk) {
     __shared__ DedupLds L;
     uint32_t parity;
     HotPlan P;
@@ -447,7 +463,7 @@ __global__ __launch_bounds__(kDedupThreads) void bkt_assign_kernel(AssignArgs A,
             const uint32_t tk = __hip_atomic_fetch_add(&bk.ticket[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             L.overflow = tk == P.n_win - 1;   // the window that finishes last copies the winner's row
             if (tk == P.n_win - 1) L.n_distinct = __hip_atomic_load(&bk.pend_cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
-            if (P.win == 0 && size >= A.d.hot_count) report_hot_key(bk, parity, key, size >= 8 * A.d.hot_count);   // stays listed while it stays hot
+            if (P.win == 0 && size >= A.d.hot_count) report_hot_key(bk, parity, key, hot_cap_of(size, A.d.hot_count));   // stays listed while it stays hot
         }
         __syncthreads();
         if (L.overflow && L.base && t < 16) {
@@ -564,9 +580,6 @@ struct SumArgs {
     uint32_t* src_scratch;            // [max_batch] sorted sources of buckets beyond the LDS list
     double* part; uint32_t max_part;  // fp64 partial rows of the hot keys' windows, one per window unit
 };
-// a barrier that waits for this wave's LDS traffic only: __syncthreads() also drains the global stores in flight (s_waitcnt vmcnt(0)) — here the key / count /
-// inverse stores of a pass, which nothing in the block reads back; their acknowledgement is 3-5 us under load, twice per pass
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 struct D4 { double x, y, z, w; };
 __device__ __forceinline__ D4 d4_tiles_sum(D4 v) {   // over the wave's four tiles (lanes l, l ^ 16, l ^ 32, l ^ 48)
     v.x += __shfl_xor(v.x, 16); v.y += __shfl_xor(v.y, 16); v.z += __shfl_xor(v.z, 16); v.w += __shfl_xor(v.w, 16);
@@ -600,14 +613,14 @@ __device__ __forceinline__ void block_run_sum(SumLds& L, uint32_t dim4, uint32_t
         D4 v = col < dim4 ? run_sum4<NF>(NF * T, NF * 4 * kDedupWaves, c, col, load) : D4{0.0, 0.0, 0.0, 0.0};
         v = d4_tiles_sum(v);
         if (tile == 0) { double* d = L.prow(wv) + tl * 4; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
-        __syncthreads();
+        lds_barrier();   // (the rows stored by out() are not read back by this block; a window's partial row is drained before its ticket)
         if (t < 16 && col < dim4) {
             D4 r{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int w = 0; w < kDedupWaves; ++w) { const double* d = L.prow(w) + t * 4; r.x += d[0]; r.y += d[1]; r.z += d[2]; r.w += d[3]; }
             out(col, r);
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 __device__ __forceinline__ f32x4 grad_row4(const float4* __restrict__ grads, uint32_t row, uint32_t dim4, uint32_t col) {
@@ -638,7 +651,7 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
             const int64_t key = bk.ent[dd_entry_at(L.d, 0)].key;
             A.d.uniq[P.rank] = key;
             if (A.counts) A.counts[P.rank] = size;
-            if (size >= A.d.hot_count) report_hot_key(bk, parity, key, size >= 8 * A.d.hot_count);   // stays listed while it stays hot
+            if (size >= A.d.hot_count) report_hot_key(bk, parity, key, hot_cap_of(size, A.d.hot_count));   // stays listed while it stays hot
         }
         {   // the window's positions: four in flight per thread (kSumWindow = 4 x 256)
             uint32_t pp[4];
@@ -647,7 +660,7 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) if (pp[q] != 0xFFFFFFFFu) { L.src()[q * kDedupThreads + t] = pp[q]; if (A.d.inverse) A.d.inverse[pp[q]] = (int64_t)P.rank; }
         }
-        __syncthreads();
+        lds_barrier();
         if (!A.grads) return;   // (grid-uniform)
         if (P.n_win > 1 && x >= A.max_part) { if (t == 0) atomicOr(A.d.status, (uint32_t)MEE_STATUS_INTERNAL); return; }   // cannot happen (max_part covers every window a batch can have)
         auto from_list = [&](uint32_t j, uint32_t col) { return grad_row4(A.grads, L.src()[j], dim4, col); };
@@ -689,7 +702,7 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
             if (c) mine += (c <= kSumTileMax ? 1ull : c <= kSumWaveMax ? 1ull << 11 : 1ull << 22) | (unsigned long long)c << 33;   // three counts of 11 bits (<= 896 runs) | sources
         }
         unsigned long long total;
-        const unsigned long long ex = block_scan_u64<kDedupWaves>(mine, L.d.wsum, total);
+        const unsigned long long ex = block_scan_u64<kDedupWaves, true>(mine, L.d.wsum, total);
         const uint32_t n_s = (uint32_t)total & 0x7FFu, n_m = (uint32_t)(total >> 11) & 0x7FFu, n_l = (uint32_t)(total >> 22) & 0x7FFu, m_src = (uint32_t)(total >> 33);
         const uint32_t base = slice;
         slice += n_s + n_m + n_l;   // (block-uniform: the next pass of this bucket continues behind this one's keys)
@@ -871,7 +884,8 @@ int bucket_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, 
     // Geometry of its own: every block pays ~20 us of dependent steps (totals, runs, entries, LDS table, scans, look-ups) before its first row moves, so the rows
     // want FEW, FAT buckets — one round of the kernel's resident blocks (six per CU), up to kSumBucketMax positions on average (Poisson(683) stays 13 sigma below
     // the 1024 entries a block holds in registers and LDS): 1M keys = 1536 buckets of 683 instead of the apply's 3072 of 341 in two rounds.
-    if (int rc = dedup_partition(t, d_keys, n, st, A.d, d_uniq, d_inverse, miss_index, nullptr, d_counts, t->bk.slots / kApplyBlocksPerCU * kSumBlocksPerCU, kSumBucketMax)) return rc;
+    static const uint32_t exp_bmax = getenv("MEE_EXP_SUM_BMAX") ? (uint32_t)atoi(getenv("MEE_EXP_SUM_BMAX")) : kSumBucketMax;   // EXPERIMENT
+    if (int rc = dedup_partition(t, d_keys, n, st, A.d, d_uniq, d_inverse, miss_index, nullptr, d_counts, t->bk.slots / kApplyBlocksPerCU * kSumBlocksPerCU, exp_bmax)) return rc;
     A.d.uniq = d_uniq; A.d.inverse = d_inverse;
     A.grads = (const float4*)d_grads; A.gsum = (float4*)d_gsum; A.counts = d_counts; A.dim4 = t->dim4;
     A.src_scratch = t->bs.hidx; A.part = t->bk.sum_part; A.max_part = t->bk.sum_part_rows;

@@ -126,6 +126,8 @@ struct mee_table {
     bool prepared_by_forward;   // the pending partition came with a training forward (mee_find*_located_prepare): a mutator in between drops it
     uint32_t part_nbk_hash;   // ... of which the first part_nbk_hash are hash buckets (the rest: one per hot key)
     bool part_full;           // ... and the apply kernel chosen for it (FULL | LEAN: meepo_apply.hip)
+    void* full_ready[4];      // streams whose queue already holds the FULL kernel's scratch (bucket_apply_launch), newest first
+    uint32_t full_ready_n;
     uint32_t part_blocks, part_per_block, part_nbk, part_grid;   // bucketed apply: how the latest partition split the batch (blocks, batch positions per block, buckets) and the apply grid that goes with it
 };
 
