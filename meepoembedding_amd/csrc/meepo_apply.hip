@@ -89,8 +89,14 @@ uint32_t bucket_count_for(mee_table* t, uint64_t n, hipStream_t st, uint32_t* gr
         if (adj > slots / 2) adj = slots / 2;
         if (adj > full / 2) adj = full / 2;
         nbk = full - adj;
-        while ((uint64_t)nbk * 2 * kBucketMax < n && nbk < full) ++nbk;   // (never more than ~700 positions per bucket on average: kBucketCap stays 12 sigma away)
-        if (bucket_max_of) while ((uint64_t)nbk * bucket_max_of < n && nbk < full) ++nbk;   // (a consumer that asked for its own bucket size: the skewed stream's hash buckets hold fewer positions anyway)
+        if (!bucket_max_of) while ((uint64_t)nbk * 2 * kBucketMax < n && nbk < full) ++nbk;   // (never more than ~700 positions per bucket on average: kBucketCap stays 12 sigma away)
+        // (a consumer that asked for its own bucket size — mee_dedup_sum, whose units beyond the hash buckets are windows of 1024 positions of the hot keys' buckets,
+        // about three quarters full on average: what is left for the hash buckets must still fit them.  The block slots the windows get this way run them beside the
+        // hash buckets from the kernel's first microsecond instead of behind them)
+        if (bucket_max_of) {
+            const uint64_t in_windows = (uint64_t)units * 768, rest = n > in_windows ? n - in_windows : 0;
+            while ((uint64_t)nbk * bucket_max_of < rest && nbk < full) ++nbk;
+        }
     }
     if (grid_out) *grid_out = full;
     // behind a skewed batch the keys that batch reported as hot get buckets of their own, behind the hash buckets (meepo_apply_part.h) — the
@@ -1400,7 +1406,6 @@ int bucket_scratch_alloc(mee_table* t) {
     bk.fast_max = t->max_batch;   // every batch the table takes: beyond ~5M keys (kMaxBuckets buckets of ~700) the buckets outgrow kBucketCap and go through their slabs
     // buckets the largest batch can be cut into (+ the hot keys' own): the strides of the totals' two copies and of the run matrices
     bk.n_buckets_max = bucket_count_for_host(bk.fast_max, bk.slots);
-    if (const char* env = getenv("MEE_EXP_NBK_SCALE")) bk.n_buckets_max *= (uint32_t)atoi(env);   // EXPERIMENT
     bk.n_buckets_max += kHotCap;
     if (bk.n_buckets_max > kMaxBuckets) bk.n_buckets_max = kMaxBuckets;
     bk.n_buckets_max = (bk.n_buckets_max + 63u) & ~63u;

@@ -107,9 +107,11 @@ __device__ __forceinline__ uint32_t dd_lookup(const DedupLds& L, unsigned long l
 // One pass over the bucket: every entry whose key has `val` in the low `bits` bits of mix64b goes into the LDS table.  LAST: the table keeps
 // 1 + the key's highest batch position.  A wave whose 64 entries all carry ONE key (a hot key's own bucket, 15 000 entries of one key) inserts
 // it once.  Returns false if the pass holds more distinct keys than the table takes (the caller splits it on one more bit).
-// A bucket of up to 4 x 256 entries — nearly every hash bucket — is held in registers from the build pass on (key and batch position of the thread's four
-// entries): the pass that writes each position's result afterwards does not fetch them a second time (one dependent round trip less per block).
-struct DdHeld { int64_t k[4]; uint32_t p[4]; bool valid; };
+// A bucket of up to 4 x 256 entries — nearly every hash bucket — is held in registers from the build pass on (batch position of the thread's four entries and the
+// table slot each one's key went to; kNoSlot: not an entry of this pass): the pass that writes each position's result afterwards neither fetches them a second time
+// (one dependent round trip less per block) nor looks their keys up again (a hash and a probe sequence per entry).
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+struct DdHeld { uint32_t s[4]; uint32_t p[4]; bool valid; };
 template <bool LAST>
 __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, uint32_t size, uint32_t bits, uint64_t val, DdHeld& H) {
     const uint32_t t = threadIdx.x;
@@ -137,7 +139,7 @@ __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, u
         }
         if (H.valid) {
 #pragma unroll
-            for (int q = 0; q < kIn; ++q) { H.k[q] = kq[q]; H.p[q] = pq[q]; }
+            for (int q = 0; q < kIn; ++q) { H.s[q] = kNoSlot; H.p[q] = pq[q]; }
         }
 #if MEE_SUM_TIMELINE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -160,6 +162,7 @@ __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, u
 #pragma unroll
                 for (int d = 32; d; d >>= 1) pmax = max(pmax, (uint32_t)__shfl_xor((int)pmax, d));
             }
+            uint32_t my_s = kNoSlot;
             if (mine && (!uniform || (int)(t & 63) == lead) && (!may_overflow || __hip_atomic_load(&L.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u)) {
                 const uint64_t h = mix64b((uint64_t)key);
                 uint32_t s = dd_slot0(h);
@@ -179,7 +182,12 @@ __device__ __forceinline__ bool dd_build(DedupLds& L, const BucketScratch& bk, u
                 if (placed) {
                     atomicAdd(&L.cnt[s], uniform ? (uint32_t)__popcll(act) : 1u);
                     if (LAST) atomicMax(&L.val[s], 1u + pmax);
+                    my_s = s;
                 } else __hip_atomic_store(&L.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (H.valid) {   // (block-uniform; every lane of the wave is here: `act` is the same in all of them)
+                if (uniform) my_s = (uint32_t)__shfl((int)my_s, lead);   // one lane spoke for the wave
+                H.s[q] = mine ? my_s : kNoSlot;
             }
         }
     }
@@ -227,6 +235,7 @@ struct DedupArgs {
     int64_t* uniq; int64_t* inverse;   // dedup
     uint32_t size_from_runs;           // the bucket totals were not computed (assign without hot keys' buckets): a bucket's size is the sum of its runs
     uint32_t* status;                  // the table's sticky status word
+    uint32_t hash_first;               // grid order (dd_unit): the hot keys' buckets (one block each: the key's report), the hash buckets, the hot keys' windows LAST
 };
 
 // A hot key's own bucket (b >= nbk_hash: the partition sent exactly ONE key there) needs no table: every entry is that key.  It is cut into
@@ -265,9 +274,16 @@ __device__ __forceinline__ HotPlan hot_plan(DedupLds& L, const BucketScratch& bk
     return P;
 }
 
-// which unit a block takes: the windows of the hot keys' buckets — the longest units: 4096 entries each — are the FIRST blocks of the grid, the
-// buckets follow (unit numbers: buckets [0, nbk), windows from nbk on)
+// which unit a block takes (unit numbers: buckets [0, nbk) — hash buckets, then the hot keys' own —, windows from nbk on).  dedup_keys / assign: the windows of the
+// hot keys' buckets — their longest units: 4096 entries each — are the FIRST blocks of the grid, the buckets follow.  hash_first (dedup_sum: a hash bucket is ~80 us
+// of a block's life, a window of 1024 rows ~35): the hash buckets start with the kernel and the windows fill the slots they free — longest units first; in front of them
+// the blocks of the hot keys' buckets, whose only job is to report their key for the next batch BEFORE the hash buckets' blocks report theirs (the set admits first
+// comers: a listed key must not lose its number to a newcomer of its own size).
 __device__ __forceinline__ uint32_t dd_unit(const DedupArgs& A) {
+    if (A.hash_first) {
+        const uint32_t n_hot = A.nbk - A.nbk_hash;
+        return blockIdx.x < n_hot ? A.nbk_hash + blockIdx.x : blockIdx.x < A.nbk ? blockIdx.x - n_hot : blockIdx.x;
+    }
     const uint32_t w = gridDim.x - A.nbk;
     return blockIdx.x < w ? A.nbk + blockIdx.x : blockIdx.x - w;
 }
@@ -284,7 +300,7 @@ __device__ __forceinline__ uint32_t dd_bucket(DedupLds& L, const BucketScratch& 
     const uint32_t n_hot = A.nbk - A.nbk_hash;
     const uint32_t ht0 = threadIdx.x < n_hot ? bk.tot[A.nbk_hash + threadIdx.x] : 0u, ht1 = threadIdx.x < n_hot ? bk.tot[bk.n_buckets_max + A.nbk_hash + threadIdx.x] : 0u;
     const uint4 hdr = *reinterpret_cast<const uint4*>(bk.seq);
-    const DdRuns runs = hash ? dd_seg_load(bk, A.nbk, A.part_blocks, A.per_block, b, threadIdx.x) : DdRuns{};
+    const DdRuns runs = hash || (own && A.hash_first) ? dd_seg_load(bk, A.nbk, A.part_blocks, A.per_block, b, threadIdx.x) : DdRuns{};
     uint32_t s0 = 0, s1 = 0;   // this thread's share of the totals in front of the bucket (both copies: the selector is not known yet)
     if (PREFIX && hash)
         for (uint32_t j = threadIdx.x; j < b; j += kDedupThreads) { s0 += bk.tot[j]; s1 += bk.tot[bk.n_buckets_max + j]; }
@@ -301,7 +317,14 @@ __device__ __forceinline__ uint32_t dd_bucket(DedupLds& L, const BucketScratch& 
         size = P.size;
         dd_seg_scan(L, dd_seg_load(bk, A.nbk, A.part_blocks, A.per_block, A.nbk_hash + P.h, threadIdx.x), threadIdx.x);
     } else {
-        if (!hash) return 0u;   // a hot key's bucket: its windows' business (the blocks behind the buckets)
+        if (!hash) {   // a hot key's bucket: its windows' business (the blocks behind the buckets)
+            if (A.hash_first && size >= A.hot_count) {   // (block-uniform) ... but for the key's report: it stays listed while it stays hot
+                dd_seg_scan(L, runs, threadIdx.x);
+                lds_barrier();
+                if (threadIdx.x == 0) report_hot_key(bk, parity, bk.ent[dd_entry_at(L, 0)].key, hot_cap_of(size, A.hot_count));
+            }
+            return 0u;
+        }
         dd_seg_scan(L, runs, threadIdx.x);
         if (PREFIX) {
             uint32_t mine = parity ? s1 : s0;
@@ -312,7 +335,10 @@ __device__ __forceinline__ uint32_t dd_bucket(DedupLds& L, const BucketScratch& 
     }
     lds_barrier();
     if (A.size_from_runs && own) size = __builtin_amdgcn_readfirstlane(L.seg_first[kPartBlocksMax]);   // (dd_seg_scan left the sum of the runs there)
-    if (own && size > kBucketCap && threadIdx.x == 0) report_slabs(bk, A.h_slabs, (size + kSlab - 1) / kSlab, P.units);   // a skewed stream: hot keys get buckets of their own next time
+    // a skewed stream: hot keys get buckets of their own next time.  (Only while the plan has none: once it has, the windows alone are what the next partition
+    // reserves block slots for — a hash bucket beyond 1024 positions is then just a large bucket, and counting its "slabs" made the next plan's hash buckets fewer
+    // and larger still)
+    if (own && size > kBucketCap && A.nbk == A.nbk_hash && threadIdx.x == 0) report_slabs(bk, A.h_slabs, (size + kSlab - 1) / kSlab, P.units);
     if (PREFIX && own) for (int w = 0; w < kDedupWaves; ++w) before += L.pre[w];
     lds_barrier();
     return size;
@@ -365,7 +391,7 @@ __global__ __launch_bounds__(kDedupThreads, 7) void bkt_dedup_keys_kernel(DedupA
         if (held.valid) {   // (block-uniform) the entries are still in registers
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (held.k[q] != kEmpty && (mix64b((uint64_t)held.k[q]) & mask) == val) A.inverse[held.p[q]] = (int64_t)(base + L.val[dd_lookup(L, (unsigned long long)held.k[q] ^ kBias)]);
+                if (held.s[q] != kNoSlot) A.inverse[held.p[q]] = (int64_t)(base + L.val[held.s[q]]);
             return;
         }
         for (uint32_t e0 = 0; e0 < size; e0 += 4 * kDedupThreads) {   // four entries in flight per thread
@@ -533,7 +559,7 @@ __global__ __launch_bounds__(kDedupThreads, 5) void bkt_assign_kernel(AssignArgs
             const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (held.k[q] != kEmpty && (mix64b((uint64_t)held.k[q]) & mask) == val && L.val[dd_lookup(L, (unsigned long long)held.k[q] ^ kBias)] == 0u) A.found[held.p[q]] = 0;   // (the partition's launch wrote the 1s)
+                if (held.s[q] != kNoSlot && L.val[held.s[q]] == 0u) A.found[held.p[q]] = 0;   // (the partition's launch wrote the 1s)
         } else if (A.found) {
             const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
             for (uint32_t e = t; e < size; e += kDedupThreads) {
@@ -579,7 +605,14 @@ struct SumArgs {
     const float4* grads; float4* gsum; uint32_t* counts; uint32_t dim4;
     uint32_t* src_scratch;            // [max_batch] sorted sources of buckets beyond the LDS list
     double* part; uint32_t max_part;  // fp64 partial rows of the hot keys' windows, one per window unit
+    // Hand-over of a hash bucket's LONG runs (skewed batches: the plan has buckets for hot keys, so the grid ends with window blocks, most of them without a window):
+    // the bucket's block leaves a long run's sorted sources in the global list and an item (number, place, length) here, kHandK per bucket at most, and publishes
+    // 1 + its item count in `hand_flag`; the window blocks — when their own window is done, or at once — take the hash buckets two at a time from `hand_head` (eight at a time left one block with ten runs: 100 us) and
+    // sum their items with the whole block, eight rows in flight per tile.  (A key of 900 occurrences that found no number in the hot-key set was 14 dependent round
+    // trips of its bucket's block — 40 us on top of the block's 70 — and the kernel ends with its slowest block: `profiles/r05_dedup.md`.)
+    uint4* hand_items; uint32_t* hand_flag; uint32_t* hand_head; uint32_t handoff;
 };
+constexpr uint32_t kHandK = 16, kHandChunk = 2;
 struct D4 { double x, y, z, w; };
 __device__ __forceinline__ D4 d4_tiles_sum(D4 v) {   // over the wave's four tiles (lanes l, l ^ 16, l ^ 32, l ^ 48)
     v.x += __shfl_xor(v.x, 16); v.y += __shfl_xor(v.y, 16); v.z += __shfl_xor(v.z, 16); v.w += __shfl_xor(v.w, 16);
@@ -641,17 +674,19 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
 #if MEE_SUM_TIMELINE
     if (threadIdx.x == 0 && g_sum_dbg && blockIdx.x < 8192) g_sum_dbg[(uint64_t)blockIdx.x * 16 + 15] = (unsigned long long)size | (unsigned long long)(dd_unit(A.d) >= A.d.nbk) << 32;
 #endif
-    if (size == 0) return;
     const uint32_t dim4 = DIM4 ? DIM4 : A.dim4;
     const uint32_t t = threadIdx.x, lane = t & 63, tile = lane >> 4, tl = lane & 15, wv = t >> 6, T = wv * 4 + tile;
-    if (dd_unit(A.d) >= A.d.nbk) {   // ---- a window of a hot key's own bucket: every entry is that key, its number is P.rank
-        const uint32_t x = dd_unit(A.d) - A.d.nbk, b = A.d.nbk_hash + P.h;
+    const uint32_t unit = dd_unit(A.d);
+    if (unit >= A.d.nbk) {   // ---- a block behind the buckets: a window of a hot key's own bucket (every entry is that key, its number is P.rank), then the hash buckets' long runs
+      auto window = [&]() {
+        if (size == 0) return;   // (block-uniform) no window for this block
+        const uint32_t x = unit - A.d.nbk, b = A.d.nbk_hash + P.h;
         const uint32_t lo = P.win * kSumWindow, c = min(size, lo + kSumWindow) - lo;
         if (P.win == 0 && t == 0) {
             const int64_t key = bk.ent[dd_entry_at(L.d, 0)].key;
             A.d.uniq[P.rank] = key;
             if (A.counts) A.counts[P.rank] = size;
-            if (size >= A.d.hot_count) report_hot_key(bk, parity, key, hot_cap_of(size, A.d.hot_count));   // stays listed while it stays hot
+            if (!A.d.hash_first && size >= A.d.hot_count) report_hot_key(bk, parity, key, hot_cap_of(size, A.d.hot_count));   // stays listed while it stays hot
         }
         {   // the window's positions: four in flight per thread (kSumWindow = 4 x 256)
             uint32_t pp[4];
@@ -685,39 +720,103 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
             auto ld = [](const double* q) { return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
             return D4{ld(d), ld(d + 1), ld(d + 2), ld(d + 3)};
         }, [&](uint32_t col, const D4& v) { store_sum4(A.gsum, P.rank, dim4, col, v); });
-        return;
+      };
+        window();
+        MEE_STL(10);   // the block's window is done
+        if (!A.handoff) return;   // (grid-uniform)
+        for (;;) {   // the hash buckets' long runs, kHandChunk buckets per turn (block-uniform control flow)
+            __syncthreads();   // (the window's / the previous item's last readers of the LDS list)
+            if (t == 0) L.d.base = __hip_atomic_fetch_add(A.hand_head, kHandChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const uint32_t j0 = L.d.base;
+            if (j0 >= A.d.nbk_hash) { MEE_STL(11); return; }   // no bucket left
+            if (t < kHandChunk) {   // a bucket's block publishes 1 + its items when its passes are done (every hash bucket's block is dispatched before the first block back here)
+                uint32_t f = 1u;
+                if (j0 + t < A.d.nbk_hash) while ((f = __hip_atomic_load(&A.hand_flag[j0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(16);
+                L.d.hp[t] = f - 1u;
+            }
+            __syncthreads();
+            for (uint32_t jj = 0; jj < kHandChunk; ++jj) {
+                const uint32_t ni = L.d.hp[jj];
+                for (uint32_t k = 0; k < ni; ++k) {
+                    const uint32_t* it = reinterpret_cast<const uint32_t*>(A.hand_items + (uint64_t)(j0 + jj) * kHandK + k);
+                    const uint32_t u = __hip_atomic_load(it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), off = __hip_atomic_load(it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                   c = __hip_atomic_load(it + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __syncthreads();
+                    if (c <= kDedupSlots) {   // (block-uniform) the run's sources into the LDS list first: one round trip for all of them
+                        for (uint32_t i = t; i < c; i += kDedupThreads) L.src()[i] = __hip_atomic_load(&A.src_scratch[off + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        lds_barrier();
+                        block_run_sum<8>(L, dim4, c, [&](uint32_t q, uint32_t col) { return grad_row4(A.grads, L.src()[q], dim4, col); },
+                                         [&](uint32_t col, const D4& v) { store_sum4(A.gsum, u, dim4, col, v); });
+                    } else if (dim4 * 4 * sizeof(double) <= sizeof(L.d.cnt)) {   // a key with thousands of occurrences and no bucket of its own (yet): the LDS list's worth of
+                        // sources at a time, the sums of the pieces added up in LDS (the counters' 4 KB: thread tl < 16 of wave 0 owns its columns)
+                        double* acc = reinterpret_cast<double*>(L.d.cnt);
+                        for (uint32_t i = t; i < dim4 * 4; i += kDedupThreads) acc[i] = 0.0;
+                        for (uint32_t c0 = 0; c0 < c; c0 += kDedupSlots) {
+                            const uint32_t cc = min(kDedupSlots, c - c0);
+                            __syncthreads();
+                            for (uint32_t i = t; i < cc; i += kDedupThreads) L.src()[i] = __hip_atomic_load(&A.src_scratch[off + c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            lds_barrier();
+                            block_run_sum<8>(L, dim4, cc, [&](uint32_t q, uint32_t col) { return grad_row4(A.grads, L.src()[q], dim4, col); },
+                                             [&](uint32_t col, const D4& v) { double* a = acc + col * 4; a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w; });
+                        }
+                        lds_barrier();
+                        if (t < 16) for (uint32_t col = t; col < dim4; col += 16) store_sum4(A.gsum, u, dim4, col, D4{acc[col * 4], acc[col * 4 + 1], acc[col * 4 + 2], acc[col * 4 + 3]});
+                    } else   // (... and rows of more than 512 floats) every row behind a load of its source
+                        block_run_sum<8>(L, dim4, c, [&](uint32_t q, uint32_t col) { return grad_row4(A.grads, __hip_atomic_load(&A.src_scratch[off + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), dim4, col); },
+                                         [&](uint32_t col, const D4& v) { store_sum4(A.gsum, u, dim4, col, v); });
+                }
+            }
+        }
     }
+    if (unit >= A.d.nbk_hash) return;   // a hot key's bucket: dd_bucket has reported the key
+    uint32_t n_handed = 0;   // (block-uniform) long runs this block has handed over
+    bool published = false;
+    auto publish = [&]() {   // ... and what tells the blocks behind the buckets that its items are complete: drained stores, then the flag (no fence: the items are written through)
+        if (!A.handoff || published) return;   // (block-uniform)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(&A.hand_flag[unit], 1u + n_handed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        published = true;
+    };
+    if (size == 0) { publish(); return; }
     // ---- a hash bucket: its distinct keys go to its own slice of the outputs (as in bkt_dedup_keys_kernel: behind the hot keys' numbers, at the positions the
     // hash buckets in front of it hold), its sorted sources — when the LDS list does not hold them — to the same range of the global source list
     uint32_t slice = P.H + before, src_at = before;
     dd_passes<false>(L.d, bk, size, parity, A.d.hot_count, A.d.status, [&](uint32_t bits, uint64_t val, const DdHeld& held) {
         const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
         MEE_STL(2);   // entries fetched, keys in the LDS table
-        // -- 1. run numbers (short runs first, then medium, then long) and the runs' places in the sorted source list: ONE block scan over the table's slots
+        // -- 1. run numbers (keys that occur ONCE first, then the other short runs, then medium, then long) and the runs' places in the sorted source list: ONE block scan
+        // over the table's slots
         constexpr uint32_t per = kDedupSlots / kDedupThreads;
         unsigned long long mine = 0;
 #pragma unroll
         for (uint32_t q = 0; q < per; ++q) {
             const uint32_t sl = t * per + q, c = L.d.key[sl] != 0ull ? L.d.cnt[sl] : 0u;
-            if (c) mine += (c <= kSumTileMax ? 1ull : c <= kSumWaveMax ? 1ull << 11 : 1ull << 22) | (unsigned long long)c << 33;   // three counts of 11 bits (<= 896 runs) | sources
+            if (c) mine += (c == 1u ? 1ull : c <= kSumTileMax ? 1ull << 10 : c <= kSumWaveMax ? 1ull << 20 : 1ull << 30) | (unsigned long long)c << 40;   // four counts of 10 bits (<= 896 runs) | sources
         }
         unsigned long long total;
         const unsigned long long ex = block_scan_u64<kDedupWaves, true>(mine, L.d.wsum, total);
-        const uint32_t n_s = (uint32_t)total & 0x7FFu, n_m = (uint32_t)(total >> 11) & 0x7FFu, n_l = (uint32_t)(total >> 22) & 0x7FFu, m_src = (uint32_t)(total >> 33);
+        const uint32_t n_1 = (uint32_t)total & 0x3FFu, n_f = (uint32_t)(total >> 10) & 0x3FFu, n_m = (uint32_t)(total >> 20) & 0x3FFu, n_l = (uint32_t)(total >> 30) & 0x3FFu, m_src = (uint32_t)(total >> 40);
+        const uint32_t n_s = n_1 + n_f;   // short runs: a tile each
         const uint32_t base = slice;
         slice += n_s + n_m + n_l;   // (block-uniform: the next pass of this bucket continues behind this one's keys)
         const bool in_lds = held.valid;   // (block-uniform) a bucket of at most 1024 positions: its entries are in registers, its sorted sources fit the LDS list
         uint32_t* __restrict__ srcg = A.src_scratch + src_at;
         src_at += m_src;
         {
-            uint32_t i_s = (uint32_t)ex & 0x7FFu, i_m = n_s + ((uint32_t)(ex >> 11) & 0x7FFu), i_l = n_s + n_m + ((uint32_t)(ex >> 22) & 0x7FFu), o = (uint32_t)(ex >> 33);
+            uint32_t i_1 = (uint32_t)ex & 0x3FFu, i_f = n_1 + ((uint32_t)(ex >> 10) & 0x3FFu), i_m = n_s + ((uint32_t)(ex >> 20) & 0x3FFu), i_l = n_s + n_m + ((uint32_t)(ex >> 30) & 0x3FFu);
+            // the sorted source list: the keys that occur once come first, in the order of their numbers — source i of the list IS the position of single i (the copy
+            // path reads one LDS word per row) —, the sources of the other runs follow in slot order
+            uint32_t o = n_1 + (uint32_t)(ex >> 40) - ((uint32_t)ex & 0x3FFu);
 #pragma unroll
             for (uint32_t q = 0; q < per; ++q) {
                 const uint32_t sl = t * per + q;
                 if (L.d.key[sl] == 0ull) { L.d.cnt[sl] = 0u; continue; }   // (cnt != 0 marks a run from here on: the key table is about to be reused)
                 const uint32_t c = L.d.cnt[sl];
-                const uint32_t idx = c <= kSumTileMax ? i_s++ : c <= kSumWaveMax ? i_m++ : i_l++;
-                L.d.val[sl] = idx; L.off[sl] = o; o += c;
+                const uint32_t idx = c == 1u ? i_1++ : c <= kSumTileMax ? i_f++ : c <= kSumWaveMax ? i_m++ : i_l++;
+                L.d.val[sl] = idx;
+                if (c == 1u) L.off[sl] = idx; else { L.off[sl] = o; o += c; }
                 A.d.uniq[base + idx] = (int64_t)(L.d.key[sl] ^ kBias);
                 if (A.counts) A.counts[base + idx] = c;
             }
@@ -729,9 +828,8 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
         if (in_lds) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (held.k[q] == kEmpty || (mix64b((uint64_t)held.k[q]) & mask) != val) continue;
-                my_sl[q] = dd_lookup(L.d, (unsigned long long)held.k[q] ^ kBias);
-                if (A.d.inverse) A.d.inverse[held.p[q]] = (int64_t)(base + L.d.val[my_sl[q]]);
+                my_sl[q] = held.s[q];
+                if (my_sl[q] != kNoSlot && A.d.inverse) A.d.inverse[held.p[q]] = (int64_t)(base + L.d.val[my_sl[q]]);
             }
         } else {
             for (uint32_t e0 = 0; e0 < size; e0 += 4 * kDedupThreads) {   // four entries in flight per thread
@@ -768,9 +866,21 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
         // -- 3. long runs: the whole block, one after the other (the block-level sums use prow: all threads pass the barriers inside)
         for (uint32_t j = 0; j < n_l; ++j) {   // block-uniform
             const uint32_t idx = n_s + n_m + j, sl = L.items()[idx], c = L.d.cnt[sl], first = L.off[sl] - c;
+            if (A.handoff && n_handed < kHandK) {   // handed over: the run's sources into the global list (there already when the bucket is beyond the LDS list), its item
+                if (in_lds) for (uint32_t i = t; i < c; i += kDedupThreads) __hip_atomic_store(&srcg[first + i], L.src()[first + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t == 0) {
+                    uint32_t* it = reinterpret_cast<uint32_t*>(A.hand_items + (uint64_t)unit * kHandK + n_handed);
+                    __hip_atomic_store(it, base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(it + 1, (uint32_t)(srcg - A.src_scratch) + first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(it + 2, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                ++n_handed;
+                continue;
+            }
             block_run_sum(L, dim4, c, [&](uint32_t q, uint32_t col) { return grad_row4(A.grads, source(first + q), dim4, col); },
                           [&](uint32_t col, const D4& v) { store_sum4(A.gsum, base + idx, dim4, col, v); });
         }
+        if (L.d.stk_n == 0u) publish();   // (block-uniform) no pass is left on the stack: the items are complete — the blocks behind the buckets need not wait for this block's rows
         // -- 4. medium runs: a wave each
         for (uint32_t j = wv; j < n_m; j += kDedupWaves) {   // wave-uniform
             const uint32_t idx = n_s + j, sl = L.items()[idx], c = L.d.cnt[sl], first = L.off[sl] - c;
@@ -781,70 +891,56 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
             }
         }
         MEE_STL(5);   // long and medium runs summed
-        // -- 5. short runs: a tile each, FOUR runs in flight per tile.  Four keys that occur once — the bulk of every batch — are four streamed rows in, four rows
-        // out, bit for bit (no arithmetic), software-pipelined: the NEXT four rows are requested before the current four are stored, so that a step waits for its
-        // loads only (the memory counter retires in order: loads issued behind stores would wait for the stores' acknowledgement as well).  Anything else: each run
-        // summed in turn (two round trips of four rows).
+        // -- 5. short runs: a tile each.  Keys that occur ONCE — the bulk of every batch, numbered first — are streamed rows in, rows out, bit for bit (no arithmetic), four
+        // in flight per tile and software-pipelined: the NEXT four rows are requested before the current four are stored, so that a step waits for its loads only (the memory
+        // counter retires in order: loads issued behind stores would wait for the stores' acknowledgement as well).  Runs of 2-8 sources follow, one run per step (one or two
+        // round trips of four rows).  (First form: all short runs in one sequence, a step of four took the copy path only when all four were single — on a Zipf batch three
+        // steps of four went the slow way, singles included.)
         constexpr uint32_t kTiles = 4 * kDedupWaves;
-        // a step = runs i0, i0 + 16, i0 + 32, i0 + 48 of tile T's sequence.  Returns the step's kind — bit q: run q exists and is ONE source (its row is requested
-        // into g[q]); kMixed: some run has several sources (nothing requested: the step is summed when its turn comes)
-        constexpr uint32_t kMixed = 0x100u;
-        auto request = [&](uint32_t i0, f32x4 (&g)[4]) -> uint32_t {
-            uint32_t kind = 0, row[4];
+        // a step = runs i0, i0 + 16, i0 + 32, i0 + 48 of the singles; a run beyond the last reads row 0 (a valid address: the load stays unconditional)
+        auto request = [&](uint32_t i0, f32x4 (&g)[4]) {
+            uint32_t row[4];
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) {
                 const uint32_t idx = i0 + q * kTiles;
-                row[q] = 0u;   // (row 0 for a missing run: a valid address, the load stays unconditional)
-                if (idx < n_s) {
-                    const uint32_t sl = L.items()[idx], c = L.d.cnt[sl];
-                    if (c == 1u) { kind |= 1u << q; row[q] = source(L.off[sl] - 1u); } else kind |= kMixed;
-                }
+                row[q] = idx < n_1 ? source(idx) : 0u;
             }
-            if (kind & kMixed) return kMixed;
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q)
                 g[q] = (uint32_t)tl < dim4 ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A.grads) + (uint64_t)row[q] * dim4 + tl) : f32x4{0.f, 0.f, 0.f, 0.f};
-            return kind;
         };
-        if (T < n_s) {
+        if (T < n_1) {
             f32x4 g[4];
-            uint32_t kind = request(T, g);
-            for (uint32_t i0 = T; i0 < n_s; i0 += 4 * kTiles) {
+            request(T, g);
+            for (uint32_t i0 = T; i0 < n_1; i0 += 4 * kTiles) {
                 f32x4 gn[4] = {g[0], g[1], g[2], g[3]};
-                const uint32_t kind_next = i0 + 4 * kTiles < n_s ? request(i0 + 4 * kTiles, gn) : 0u;
-                if (!(kind & kMixed)) {
+                if (i0 + 4 * kTiles < n_1) request(i0 + 4 * kTiles, gn);
 #pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q)
-                        if ((kind >> q & 1u) && (uint32_t)tl < dim4) __builtin_nontemporal_store(g[q], reinterpret_cast<f32x4*>(A.gsum) + (uint64_t)(base + i0 + q * kTiles) * dim4 + tl);
-                    for (uint32_t col = tl + 16; col < dim4; col += 16) {   // wider rows: the remaining column groups
+                for (uint32_t q = 0; q < 4; ++q)
+                    if (i0 + q * kTiles < n_1 && (uint32_t)tl < dim4) __builtin_nontemporal_store(g[q], reinterpret_cast<f32x4*>(A.gsum) + (uint64_t)(base + i0 + q * kTiles) * dim4 + tl);
+                for (uint32_t col = tl + 16; col < dim4; col += 16) {   // wider rows: the remaining column groups
 #pragma unroll
-                        for (uint32_t q = 0; q < 4; ++q) {
-                            if (!(kind >> q & 1u)) continue;
-                            const uint32_t sl = L.items()[i0 + q * kTiles];
-                            const f32x4 h = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A.grads) + (uint64_t)source(L.off[sl] - 1u) * dim4 + col);
-                            __builtin_nontemporal_store(h, reinterpret_cast<f32x4*>(A.gsum) + (uint64_t)(base + i0 + q * kTiles) * dim4 + col);
-                        }
-                    }
-                } else {
-#pragma unroll 1
                     for (uint32_t q = 0; q < 4; ++q) {
-                        const uint32_t idx = i0 + q * kTiles;
-                        if (idx >= n_s) break;
-                        const uint32_t sl = L.items()[idx], c = L.d.cnt[sl], f0 = L.off[sl] - c;
-                        for (uint32_t col = tl; col < dim4; col += 16)
-                            store_sum4(A.gsum, base + idx, dim4, col, run_sum4(0u, 4u, c, col, [&](uint32_t j, uint32_t cc) { return grad_row4(A.grads, source(f0 + j), dim4, cc); }));
+                        if (i0 + q * kTiles >= n_1) continue;
+                        const f32x4 h = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A.grads) + (uint64_t)source(i0 + q * kTiles) * dim4 + col);
+                        __builtin_nontemporal_store(h, reinterpret_cast<f32x4*>(A.gsum) + (uint64_t)(base + i0 + q * kTiles) * dim4 + col);
                     }
                 }
-                kind = kind_next;
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q) g[q] = gn[q];
             }
+        }
+        for (uint32_t idx = n_1 + T; idx < n_s; idx += kTiles) {
+            const uint32_t sl = L.items()[idx], c = L.d.cnt[sl], f0 = L.off[sl] - c;
+            for (uint32_t col = tl; col < dim4; col += 16)
+                store_sum4(A.gsum, base + idx, dim4, col, run_sum4(0u, 4u, c, col, [&](uint32_t j, uint32_t cc) { return grad_row4(A.grads, source(f0 + j), dim4, cc); }));
         }
 #if MEE_SUM_TIMELINE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         MEE_STL(6);   // thread 0's short runs done
     });
+    publish();
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------------
@@ -884,14 +980,18 @@ int bucket_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, 
     // Geometry of its own: every block pays ~20 us of dependent steps (totals, runs, entries, LDS table, scans, look-ups) before its first row moves, so the rows
     // want FEW, FAT buckets — one round of the kernel's resident blocks (six per CU), up to kSumBucketMax positions on average (Poisson(683) stays 13 sigma below
     // the 1024 entries a block holds in registers and LDS): 1M keys = 1536 buckets of 683 instead of the apply's 3072 of 341 in two rounds.
-    static const uint32_t exp_bmax = getenv("MEE_EXP_SUM_BMAX") ? (uint32_t)atoi(getenv("MEE_EXP_SUM_BMAX")) : kSumBucketMax;   // EXPERIMENT
-    if (int rc = dedup_partition(t, d_keys, n, st, A.d, d_uniq, d_inverse, miss_index, nullptr, d_counts, t->bk.slots / kApplyBlocksPerCU * kSumBlocksPerCU, exp_bmax)) return rc;
+    if (int rc = dedup_partition(t, d_keys, n, st, A.d, d_uniq, d_inverse, miss_index, nullptr, d_counts, t->bk.slots / kApplyBlocksPerCU * kSumBlocksPerCU, kSumBucketMax)) return rc;
     A.d.uniq = d_uniq; A.d.inverse = d_inverse;
     A.grads = (const float4*)d_grads; A.gsum = (float4*)d_gsum; A.counts = d_counts; A.dim4 = t->dim4;
     A.src_scratch = t->bs.hidx; A.part = t->bk.sum_part; A.max_part = t->bk.sum_part_rows;
     // a key's own bucket is summed by a block per 1024 occurrences, all at once; inside a hash bucket a run of 500 occurrences is 4-8 dependent round trips of ONE
     // block.  So the bar for a bucket of its own is half the apply's here (n / 2048, at least 256): a Zipf(1.05) batch of 1M keys lists ~120 keys
     A.d.hot_count = n / 2048 > kHotCount ? n / 2048 : kHotCount;
+    A.d.hash_first = 1u;
+    // the long runs' hand-over (SumArgs): the items live in the admission pass's scratch (max_batch x 4 bytes, unused by this operator), the flags and the turn counter
+    // in the pending counters of the buckets (zeroed by every partition; the apply's and the assign's, not this kernel's)
+    A.hand_items = reinterpret_cast<uint4*>(t->bs.occ); A.hand_flag = t->bk.pend_cnt; A.hand_head = t->bk.pend_cnt + A.d.nbk_hash;
+    A.handoff = d_grads && A.d.nbk != A.d.nbk_hash && (uint64_t)A.d.nbk_hash * kHandK * sizeof(uint4) <= (uint64_t)t->max_batch * 4;
     const uint32_t grid = A.d.nbk + hot_window_blocks(A.d, n, kSumWindow);
     if (t->dim4 == 16) bkt_dedup_sum_kernel<16><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
     else if (t->dim4 == 32) bkt_dedup_sum_kernel<32><<<grid, kDedupThreads, 0, st>>>(A, t->bk);

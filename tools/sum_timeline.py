@@ -34,7 +34,7 @@ assert L.mee_debug_sum_timeline(buf.ctypes.data, buf.size) == 0
 tl = buf.reshape(8192, 16)
 used = tl[:, 0] != 0
 size = (tl[:, 15] & 0xFFFFFFFF).astype(np.int64); window = (tl[:, 15] >> 32) != 0
-us = tl[:, :10].astype(np.float64) * 0.01
+us = tl[:, :12].astype(np.float64) * 0.01
 t0 = us[used, 0].min()
 print(f"{dist}, {batch} keys: {int(used.sum())} blocks stamped, {int((used & window).sum())} of them windows of hot keys' buckets; sizes: median {np.median(size[used & ~window & (size > 0)]):.0f}, max {size[used].max()}")
 print(f"block start relative to the first: median {np.median(us[used, 0] - t0):.1f} us, p90 {np.percentile(us[used, 0] - t0, 90):.1f}, max {(us[used, 0] - t0).max():.1f}")
@@ -48,10 +48,19 @@ for a, b_, nm in ((1, 7, "  .. table cleared"), (7, 8, "  .. thread 0's entries 
     print(f"  {nm:58s} median {np.median(d):7.2f} us   p10 {np.percentile(d, 10):7.2f}   p90 {np.percentile(d, 90):7.2f}")
 life = us[hb, 6] - us[hb, 0]
 print(f"  hash-bucket block life: median {np.median(life):.1f} us, p90 {np.percentile(life, 90):.1f}, max {life.max():.1f}; last end {us[hb, 6].max() - t0:.1f} us after the first start")
+lf = np.where(hb, us[:, 6] - us[:, 0], 0.0)
+for bi in np.argsort(lf)[-3:][::-1]:
+    print(f"  slowest: block {bi} size {size[bi]} start {us[bi, 0] - t0:.1f} phases " + " ".join(f"{us[bi, k + 1] - us[bi, k]:.1f}" for k in range(6)))
 rowp = us[:, 6] - us[:, 5]
 idx = np.arange(8192)
 print("  short-run phase by blockIdx % 8 (XCD): " + "  ".join(f"{np.median(rowp[hb & (idx % 8 == x)]):.0f}" for x in range(8)) + " us;  block end by XCD: "
       + "  ".join(f"{np.median(us[hb & (idx % 8 == x), 6] - t0):.0f}/{(us[hb & (idx % 8 == x), 6] - t0).max():.0f}" for x in range(8)))
 wb = used & window
+if wb.any() and (us[wb, 10] > 0).any():
+    real = wb & (size > 0)
+    for nm, m in (("blocks with a window", real), ("blocks without one", wb & ~real)):
+        if m.any():
+            print(f"  {nm}: {int(m.sum())}; start median {np.median(us[m, 0] - t0):.1f} us (p90 {np.percentile(us[m, 0] - t0, 90):.1f}); window done median {np.median(us[m, 10] - t0):.1f} (max {(us[m, 10] - t0).max():.1f}); "
+                  f"long runs of the hash buckets done median {np.median(us[m, 11] - t0):.1f} (max {(us[m, 11] - t0).max():.1f})")
 if wb.any():
     print(f"  window blocks: start median {np.median(us[wb, 0] - t0):.1f} us, first phase {np.median(us[wb, 1] - us[wb, 0]):.1f} us (their later phases are not stamped)")
