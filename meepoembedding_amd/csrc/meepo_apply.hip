@@ -66,21 +66,23 @@ static bool stream_is_capturing(hipStream_t st) {
     return hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
 }
 // (slots_of / bucket_max_of: the geometry of another consumer of the partition — mee_dedup_sum's blocks, six per CU, want ONE round of buckets of up to ~680 positions)
-uint32_t bucket_count_for(mee_table* t, uint64_t n, hipStream_t st, uint32_t* grid_out, uint32_t* nbk_total_out, bool* full_out, uint32_t slots_of, uint32_t bucket_max_of) {
-    const uint32_t slots = slots_of ? slots_of : t->bk.slots;
-    uint32_t full = bucket_count_for_host(n, slots, bucket_max_of ? bucket_max_of : t->bk.bucket_max ? t->bk.bucket_max : kBucketMax);
+uint32_t bucket_count_for(mee_table* t, uint64_t n, hipStream_t st, uint32_t* grid_out, uint32_t* nbk_total_out, bool* full_out, uint32_t slots_of, uint32_t bucket_max_of,
+                          BucketScratch* state) {
+    BucketScratch& sk = state ? *state : t->bk;
+    const uint32_t slots = slots_of ? slots_of : sk.slots;
+    uint32_t full = bucket_count_for_host(n, slots, bucket_max_of ? bucket_max_of : sk.bucket_max ? sk.bucket_max : kBucketMax);
     // The scratch (totals, run matrices, pending counters, tickets) is strided for n_buckets_max buckets, sized at creation for the DEFAULT bucket size at
     // max_batch (+ the hot keys' buckets): a smaller "apply_bucket_max" must not ask for more buckets than that — it gets larger buckets instead.
-    const uint32_t room = t->bk.n_buckets_max - kHotCap;
+    const uint32_t room = sk.n_buckets_max - kHotCap;
     if (full > room) full = room >= slots ? room / slots * slots : room;
     uint32_t nbk = full;
-    const bool capturing = t->bk.skew_adapt && stream_is_capturing(st);
-    const uint32_t s_prev = t->bk.h_slabs && t->bk.skew_adapt ? *(volatile uint32_t*)t->bk.h_slabs : 0u;
+    const bool capturing = sk.skew_adapt && stream_is_capturing(st);
+    const uint32_t s_prev = sk.h_slabs && sk.skew_adapt ? *(volatile uint32_t*)sk.h_slabs : 0u;
     // which kernel (bkt_apply_kernel): FULL behind a skewed batch — and for the 64 batches after the last one: a stream whose skew comes and
     // goes must not fall into the LEAN kernel's slow path every other batch —, else LEAN
-    if (s_prev) t->bk.skew_sticky = 64;
-    else if (t->bk.skew_sticky) --t->bk.skew_sticky;
-    if (full_out) *full_out = t->bk.kernel_choice >= 0 ? t->bk.kernel_choice != 0 : (capturing || s_prev != 0 || t->bk.skew_sticky != 0);
+    if (s_prev) sk.skew_sticky = 64;
+    else if (sk.skew_sticky) --sk.skew_sticky;
+    if (full_out) *full_out = sk.kernel_choice >= 0 ? sk.kernel_choice != 0 : (capturing || s_prev != 0 || sk.skew_sticky != 0);
     // (a batch with more keys than its buckets hold whole: every bucket is a list of slabs — the FULL kernel's business, whatever the knob says)
     if (full_out && n > (uint64_t)full * (kBucketCap * 3 / 4)) *full_out = true;
     const uint32_t units = s_prev ? s_prev : capturing && full_out && *full_out ? slots / 12 : 0u;
@@ -101,7 +103,7 @@ uint32_t bucket_count_for(mee_table* t, uint64_t n, hipStream_t st, uint32_t* gr
     if (grid_out) *grid_out = full;
     // behind a skewed batch the keys that batch reported as hot get buckets of their own, behind the hash buckets (meepo_apply_part.h) — the
     // FULL kernel's business
-    const bool hot = (s_prev || capturing) && nbk + kHotCap <= t->bk.n_buckets_max && (!full_out || *full_out);
+    const bool hot = (s_prev || capturing) && nbk + kHotCap <= sk.n_buckets_max && (!full_out || *full_out);
     if (nbk_total_out) *nbk_total_out = hot ? nbk + kHotCap : nbk;
     return nbk;
 }
@@ -141,8 +143,8 @@ __global__ __launch_bounds__(256) void bkt_totals_kernel(BucketScratch bk, uint3
     }
 }
 bool bucket_totals_by_atomics(uint32_t blocks, uint32_t nbk) { return (uint64_t)blocks * nbk <= 160000; }
-int bucket_totals_launch(mee_table* t, uint32_t nbk, uint32_t blocks, hipStream_t st) {
-    bkt_totals_kernel<<<(nbk + 63) / 64, 256, 0, st>>>(t->bk, nbk, blocks);
+int bucket_totals_launch(mee_table* t, uint32_t nbk, uint32_t blocks, hipStream_t st, const BucketScratch* bk) {
+    bkt_totals_kernel<<<(nbk + 63) / 64, 256, 0, st>>>(bk ? *bk : t->bk, nbk, blocks);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
@@ -1441,6 +1443,22 @@ int bucket_scratch_alloc(mee_table* t) {
     bk.dev_copy = nullptr;
     alloc((void**)&bk.dev_copy, sizeof(BucketScratch));
     if (e == hipSuccess) e = hipMemcpy(bk.dev_copy, &bk, sizeof(BucketScratch), hipMemcpyHostToDevice);
+    // the raw-stream operators' state (mee_table::bk_dd): the same scratch arrays, its own pinned word, hot-key set, parity words and totals
+    BucketScratch& dd = t->bk_dd;
+    dd = bk;
+    dd.dev_copy = nullptr; dd.h_slabs = nullptr; dd.h_slabs_dev = nullptr;
+    dd.tot = nullptr; dd.seq = nullptr; dd.hot_key = nullptr; dd.hot_idx = nullptr; dd.hot_n = nullptr;
+    alloc((void**)&dd.tot, 2ull * bk.n_buckets_max * 4);
+    alloc((void**)&dd.seq, 8 * 4);
+    dd.has_split = dd.seq ? dd.seq + 2 : nullptr;
+    alloc((void**)&dd.hot_key, 2ull * kHotSlots * 8); alloc((void**)&dd.hot_idx, 2ull * kHotSlots * 4); alloc((void**)&dd.hot_n, 2 * 4);
+    if (e == hipSuccess) e = hipMemset(dd.hot_key, 0, 2ull * kHotSlots * 8);
+    if (e == hipSuccess) e = hipMemset(dd.hot_idx, 0xFF, 2ull * kHotSlots * 4);
+    if (e == hipSuccess) e = hipMemset(dd.hot_n, 0, 2 * 4);
+    if (e == hipSuccess) e = hipMemset(dd.seq, 0, 8 * 4);
+    if (e == hipSuccess) e = hipMemset(dd.tot, 0, 2ull * bk.n_buckets_max * 4);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&dd.h_slabs, 64, hipHostMallocMapped | hipHostMallocPortable);
+    if (e == hipSuccess) { *dd.h_slabs = 0u; e = hipHostGetDevicePointer((void**)&dd.h_slabs_dev, dd.h_slabs, 0); }
     if (e != hipSuccess) return fail(MEE_ERR_OUT_OF_MEMORY, "hipMalloc for the apply scratch: %s", hipGetErrorString(e));
     bucket_apply_preload(t);
     return MEE_OK;
@@ -1451,6 +1469,10 @@ void bucket_scratch_free(mee_table* t) {
     for (void* p : dev) if (p) (void)hipFree(p);
     if (bk.h_slabs) (void)hipHostFree(bk.h_slabs);
     if (bk.dev_copy) (void)hipFree(bk.dev_copy);
+    BucketScratch& dd = t->bk_dd;
+    void* dev_dd[] = {dd.tot, dd.seq, dd.hot_key, dd.hot_idx, dd.hot_n};
+    for (void* p : dev_dd) if (p) (void)hipFree(p);
+    if (dd.h_slabs) (void)hipHostFree(dd.h_slabs);
 }
 
 #if MEE_APPLY_TIMELINE

@@ -950,24 +950,24 @@ static int dedup_partition(mee_table* t, const int64_t* d_keys, uint32_t n, hipS
                            uint32_t* d_counts = nullptr, uint32_t slots_of = 0, uint32_t bucket_max_of = 0) {
     uint32_t grid, nbk;
     bool full;
-    const uint32_t nbk_hash = bucket_count_for(t, n, st, &grid, &nbk, &full, slots_of, bucket_max_of);
+    const uint32_t nbk_hash = bucket_count_for(t, n, st, &grid, &nbk, &full, slots_of, bucket_max_of, &t->bk_dd);
     // (hot keys' buckets whenever the latest batch reported any: a dedup has no FULL / LEAN kernels, its one kernel takes buckets of any size)
     uint32_t blocks, per_block;
     part_geometry(n, 1024, blocks, per_block, kPartBlocks);
-    A.nbk = nbk; A.nbk_hash = nbk_hash; A.part_blocks = blocks; A.per_block = per_block; A.hot_count = hot_count_for(n); A.op = t->op; A.h_slabs = t->bk.h_slabs_dev; A.status = &t->ctr->status;
+    A.nbk = nbk; A.nbk_hash = nbk_hash; A.part_blocks = blocks; A.per_block = per_block; A.hot_count = hot_count_for(n); A.op = t->op; A.h_slabs = t->bk_dd.h_slabs_dev; A.status = &t->ctr->status;
     const bool atom = bucket_totals_by_atomics(blocks, nbk);
     // an assign without hot keys' buckets needs no bucket totals: nobody numbers anything across buckets, and a bucket's size is the sum of its runs
     A.size_from_runs = !atom && !d_uniq && nbk == nbk_hash;
-    bkt_sort_dedup_kernel<<<blocks, 1024, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk, &t->ctr->status, t->op, d_uniq, d_inverse, miss_index, d_found, atom, d_counts);
+    bkt_sort_dedup_kernel<<<blocks, 1024, sizeof(PartHot) + nbk * 4, st>>>(d_keys, n, nbk_hash, nbk, per_block, t->bk_dd, &t->ctr->status, t->op, d_uniq, d_inverse, miss_index, d_found, atom, d_counts);
     MEE_HIP(hipGetLastError());
-    return atom || A.size_from_runs ? MEE_OK : bucket_totals_launch(t, nbk, blocks, st);
+    return atom || A.size_from_runs ? MEE_OK : bucket_totals_launch(t, nbk, blocks, st, &t->bk_dd);
 }
 
 int bucket_dedup_keys(mee_table* t, const int64_t* d_keys, uint32_t n, int64_t* d_uniq, int64_t* d_inverse, int64_t miss_index, hipStream_t st) {
     DedupArgs A{};
     if (int rc = dedup_partition(t, d_keys, n, st, A, d_uniq, d_inverse, miss_index, nullptr)) return rc;
     A.uniq = d_uniq; A.inverse = d_inverse;
-    bkt_dedup_keys_kernel<<<A.nbk + hot_window_blocks(A, n), kDedupThreads, 0, st>>>(A, t->bk);
+    bkt_dedup_keys_kernel<<<A.nbk + hot_window_blocks(A, n), kDedupThreads, 0, st>>>(A, t->bk_dd);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
@@ -980,22 +980,22 @@ int bucket_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, 
     // Geometry of its own: every block pays ~20 us of dependent steps (totals, runs, entries, LDS table, scans, look-ups) before its first row moves, so the rows
     // want FEW, FAT buckets — one round of the kernel's resident blocks (six per CU), up to kSumBucketMax positions on average (Poisson(683) stays 13 sigma below
     // the 1024 entries a block holds in registers and LDS): 1M keys = 1536 buckets of 683 instead of the apply's 3072 of 341 in two rounds.
-    if (int rc = dedup_partition(t, d_keys, n, st, A.d, d_uniq, d_inverse, miss_index, nullptr, d_counts, t->bk.slots / kApplyBlocksPerCU * kSumBlocksPerCU, kSumBucketMax)) return rc;
+    if (int rc = dedup_partition(t, d_keys, n, st, A.d, d_uniq, d_inverse, miss_index, nullptr, d_counts, t->bk_dd.slots / kApplyBlocksPerCU * kSumBlocksPerCU, kSumBucketMax)) return rc;
     A.d.uniq = d_uniq; A.d.inverse = d_inverse;
     A.grads = (const float4*)d_grads; A.gsum = (float4*)d_gsum; A.counts = d_counts; A.dim4 = t->dim4;
-    A.src_scratch = t->bs.hidx; A.part = t->bk.sum_part; A.max_part = t->bk.sum_part_rows;
+    A.src_scratch = t->bs.hidx; A.part = t->bk_dd.sum_part; A.max_part = t->bk_dd.sum_part_rows;
     // a key's own bucket is summed by a block per 1024 occurrences, all at once; inside a hash bucket a run of 500 occurrences is 4-8 dependent round trips of ONE
     // block.  So the bar for a bucket of its own is half the apply's here (n / 2048, at least 256): a Zipf(1.05) batch of 1M keys lists ~120 keys
     A.d.hot_count = n / 2048 > kHotCount ? n / 2048 : kHotCount;
     A.d.hash_first = 1u;
     // the long runs' hand-over (SumArgs): the items live in the admission pass's scratch (max_batch x 4 bytes, unused by this operator), the flags and the turn counter
     // in the pending counters of the buckets (zeroed by every partition; the apply's and the assign's, not this kernel's)
-    A.hand_items = reinterpret_cast<uint4*>(t->bs.occ); A.hand_flag = t->bk.pend_cnt; A.hand_head = t->bk.pend_cnt + A.d.nbk_hash;
+    A.hand_items = reinterpret_cast<uint4*>(t->bs.occ); A.hand_flag = t->bk_dd.pend_cnt; A.hand_head = t->bk_dd.pend_cnt + A.d.nbk_hash;
     A.handoff = d_grads && A.d.nbk != A.d.nbk_hash && (uint64_t)A.d.nbk_hash * kHandK * sizeof(uint4) <= (uint64_t)t->max_batch * 4;
     const uint32_t grid = A.d.nbk + hot_window_blocks(A.d, n, kSumWindow);
-    if (t->dim4 == 16) bkt_dedup_sum_kernel<16><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
-    else if (t->dim4 == 32) bkt_dedup_sum_kernel<32><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
-    else bkt_dedup_sum_kernel<0><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
+    if (t->dim4 == 16) bkt_dedup_sum_kernel<16><<<grid, kDedupThreads, 0, st>>>(A, t->bk_dd);
+    else if (t->dim4 == 32) bkt_dedup_sum_kernel<32><<<grid, kDedupThreads, 0, st>>>(A, t->bk_dd);
+    else bkt_dedup_sum_kernel<0><<<grid, kDedupThreads, 0, st>>>(A, t->bk_dd);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }
@@ -1018,9 +1018,9 @@ int bucket_assign(mee_table* t, float* plane, const int64_t* d_keys, const float
     if (int rc = dedup_partition(t, d_keys, n, st, A.d, nullptr, nullptr, 0, d_found)) return rc;
     A.tkeys = t->keys; A.rows = (float4*)plane; A.nb = t->nb; A.dim4 = t->dim4; A.values = (const float4*)d_values; A.found = d_found;
     const uint32_t grid = A.d.nbk + hot_window_blocks(A.d, n);
-    if (t->dim4 == 16) bkt_assign_kernel<16><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
-    else if (t->dim4 == 32) bkt_assign_kernel<32><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
-    else bkt_assign_kernel<0><<<grid, kDedupThreads, 0, st>>>(A, t->bk);
+    if (t->dim4 == 16) bkt_assign_kernel<16><<<grid, kDedupThreads, 0, st>>>(A, t->bk_dd);
+    else if (t->dim4 == 32) bkt_assign_kernel<32><<<grid, kDedupThreads, 0, st>>>(A, t->bk_dd);
+    else bkt_assign_kernel<0><<<grid, kDedupThreads, 0, st>>>(A, t->bk_dd);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
 }

@@ -622,7 +622,7 @@ int mee_set_tuning(mee_table* t, const char* name, int value) {
     else if (!strcmp(name, "prepare_debug")) t->prepare_debug = value;
     else if (!strcmp(name, "find_nt")) t->find_nt = value;
     else if (!strcmp(name, "apply_bucket_max")) t->bk.bucket_max = value > 0 && value <= 352 ? (uint32_t)value : 0u;
-    else if (!strcmp(name, "apply_skew_adapt")) t->bk.skew_adapt = value != 0;
+    else if (!strcmp(name, "apply_skew_adapt")) t->bk.skew_adapt = t->bk_dd.skew_adapt = value != 0;
     else if (!strcmp(name, "apply_xcd_split")) t->bk.xcd_split = value < 0 ? xcd_split_for_device(t->device) : value < 1024 ? (uint32_t)value : 0u;
     else if (!strcmp(name, "apply_kernel")) t->bk.kernel_choice = value < 0 ? -1 : value != 0;
     else return fail(MEE_ERR_INVALID_ARG, "mee_set_tuning: unknown knob '%s'", name);

@@ -123,6 +123,10 @@ struct mee_table {
     uint64_t out_ring_ptr[8], out_ring_bytes[8];
     uint32_t out_ring_head;
     mee::BucketScratch bk;      // bucketed apply (null pointers when the table has no optimizer)
+    // ... and the same scratch with a skew state of its own (the pinned word, the hot-key set, the partition parity and the totals' two copies) for the operators that see the
+    // RAW key stream of a batch — dedup_keys, dedup_sum, assign.  A training step on one table runs them beside an apply over the batch's DISTINCT keys (the sharded paths with
+    // pre-exchange aggregation): the apply's "no skew" report sent the next dedup of the (skewed) raw stream back to its first-skewed-batch path, every step.
+    mee::BucketScratch bk_dd;
     bool prepared_by_forward;   // the pending partition came with a training forward (mee_find*_located_prepare): a mutator in between drops it
     uint32_t part_nbk_hash;   // ... of which the first part_nbk_hash are hash buckets (the rest: one per hot key)
     bool part_full;           // ... and the apply kernel chosen for it (FULL | LEAN: meepo_apply.hip)
@@ -169,7 +173,7 @@ int bucket_apply_discard(mee_table* t, hipStream_t st);
 int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const OptArgs& a, const uint32_t* d_gidx, const int64_t* d_slots, hipStream_t st,
                         const GroupDesc* d_desc = nullptr, uint32_t n_tables = 0);
 bool bucket_totals_by_atomics(uint32_t blocks, uint32_t nbk);
-int bucket_totals_launch(mee_table* t, uint32_t nbk, uint32_t blocks, hipStream_t st);
+int bucket_totals_launch(mee_table* t, uint32_t nbk, uint32_t blocks, hipStream_t st, const mee::BucketScratch* bk = nullptr /* default: the apply's */);
 int bucket_apply_prepare_as(mee_table* t, const int64_t* d_keys, uint32_t n, hipStream_t st, uint32_t nbk_hash, uint32_t nbk, uint32_t blocks, uint32_t per_block);
 // duplicate elimination and last-wins elections on the same partition (meepo_dedup.hip)
 int bucket_dedup_keys(mee_table* t, const int64_t* d_keys, uint32_t n, int64_t* d_uniq, int64_t* d_inverse, int64_t miss_index, hipStream_t st);
@@ -177,7 +181,7 @@ int bucket_assign(mee_table* t, float* plane, const int64_t* d_keys, const float
 int bucket_dedup_sum(mee_table* t, const int64_t* d_keys, const float* d_grads, uint32_t n, int64_t* d_uniq, float* d_gsum, uint32_t* d_counts, int64_t* d_inverse, int64_t miss_index,
                      hipStream_t st);
 uint32_t bucket_count_for(mee_table* t, uint64_t n, hipStream_t st, uint32_t* grid_out = nullptr, uint32_t* nbk_total_out = nullptr, bool* full_out = nullptr,
-                          uint32_t slots_of = 0, uint32_t bucket_max_of = 0);
+                          uint32_t slots_of = 0, uint32_t bucket_max_of = 0, mee::BucketScratch* state = nullptr /* whose skew state plans the batch; default: the apply's (t->bk) */);
 
 // ---- host helpers the table's translation units share (meepo_table.hip, meepo_find.hip, meepo_export.hip) ------------------------------
 inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
