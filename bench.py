@@ -284,7 +284,40 @@ def stream_table(table, synth, n_keys, batch, dim, dev, out, found, bpl, uniform
         row[label] = {"us_per_launch_median": med, "us_per_launch_min": mn, "lookups_per_s": m1 / med * 1e6,
                       "algorithmic_GBps": m1 * bpl / med / 1e3, "frac_of_hbm_roofline": m1 * bpl / med / 1e3 / HBM_PEAK_GBS}
     rows["north_star_batch_1M"] = row
-    del obig, fbig, allk
+    # the pre-exchange reductions of the sharded paths on 1M-key batches of both streams (sync-free operators, outputs preallocated): distinct keys + inverse
+    # (mee_dedup_keys: what a sharded lookup sends), distinct keys + fp64-summed gradient rows (mee_dedup_sum: what a sharded backward sends)
+    zk = torch.cat(streams["zipf_1.05"][:16])
+    zb = [zk[o:o + m1] for o in range(0, zk.numel() - m1 + 1, m1)][:4]
+    uo = torch.empty(m1, dtype=torch.int64, device=dev); co = torch.empty(m1, dtype=torch.int32, device=dev); io = torch.empty(m1, dtype=torch.int64, device=dev)
+    lib_, st_ = _ml.lib(), torch.cuda.current_stream(dev).cuda_stream
+    red = {"keys_per_batch": m1, "dim": dim}
+    for sname, bs_ in (("uniform", b1), ("zipf_1.05", zb)):
+        def dk(i):
+            _ml.check(lib_.mee_dedup_keys(table._h, bs_[i % 4].data_ptr(), m1, uo.data_ptr(), io.data_ptr(), -1, st_))
+        def dsum(i):
+            _ml.check(lib_.mee_dedup_sum(table._h, bs_[i % 4].data_ptr(), obig[:m1].data_ptr(), m1, uo.data_ptr(), obig[m1:2 * m1].data_ptr(), co.data_ptr(), io.data_ptr(), -1, st_))
+        r_ = {}
+        for label, fn in (("dedup_keys_us", dk), ("dedup_sum_us", dsum)):
+            for i in range(6):
+                fn(i)
+            per = []
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                e0.record()
+                for i in range(20):
+                    fn(i)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                per.append(e0.elapsed_time(e1) * 1e3 / 20)
+            r_[label] = sorted(per)[1]
+        nu = int((co > 0).sum())   # (of the last batch summed)
+        assert int(co.sum()) == m1 and bool((uo[io] == bs_[19 % 4]).all()), "dedup_sum: counts / inverse of the last batch"
+        r_["distinct_keys"] = nu
+        r_["dedup_sum_algorithmic_GBps"] = (m1 * (16 + 4 * dim) + nu * (12 + 4 * dim)) / r_["dedup_sum_us"] / 1e3
+        red[sname] = r_
+    assert table.status() == 0
+    rows["pre_exchange_reductions_1M"] = red
+    del obig, fbig, allk, zk
     return rows
 
 
