@@ -556,7 +556,6 @@ __global__ __launch_bounds__(kDedupThreads, 5) void bkt_assign_kernel(AssignArgs
         }
         __syncthreads();
         if (A.found && held.valid) {   // (block-uniform) the entries are still in registers
-            const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (held.s[q] != kNoSlot && L.val[held.s[q]] == 0u) A.found[held.p[q]] = 0;   // (the partition's launch wrote the 1s)
