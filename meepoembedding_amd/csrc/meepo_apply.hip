@@ -1066,10 +1066,7 @@ __device__ __forceinline__ void slow_update(ApplyLds& L, const ApplyArgs& A, con
 // its hash gives it (slow_share_of), one at a time.
 constexpr uint32_t kSlowAgree = 16;   // samples (of 64) that must carry the candidate
 constexpr uint32_t kSlowWindow = 512;   // entries of a share's window when a bucket is worked off by position (one per thread: one round trip finds the candidate's, <= 16 rows per tile)
-#ifndef MEE_SLOW_WALK
-#define MEE_SLOW_WALK 4
-#endif
-constexpr uint32_t kWalk = MEE_SLOW_WALK;   // entries in flight per thread in the walk
+constexpr uint32_t kWalk = 4;   // entries in flight per thread in the walk (2 and 4 cost the LEAN kernel the same registers: none beyond its bucket path's)
 template <int KIND, int DIM4, bool LOCATED, bool GROUPED, bool OWN /* share 0: the bucket's own block */>
 __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, const BucketScratch& bk, const uint32_t b, const uint32_t size, const uint32_t parity, const GroupDesc* gdesc,
                                             const uint32_t sub_arg, const uint32_t n_sub) {
