@@ -731,7 +731,13 @@ __global__ __launch_bounds__(kDedupThreads, kSumBlocksPerCU) void bkt_dedup_sum_
             if (j0 >= A.d.nbk_hash) { MEE_STL(11); return; }   // no bucket left
             if (t < kHandChunk) {   // a bucket's block publishes 1 + its items when its passes are done (every hash bucket's block is dispatched before the first block back here)
                 uint32_t f = 1u;
-                if (j0 + t < A.d.nbk_hash) while ((f = __hip_atomic_load(&A.hand_flag[j0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(16);
+                if (j0 + t < A.d.nbk_hash) {
+                    // (bounded: ~30 ms.  The flag always comes — the bucket's block was dispatched before this one and waits for nothing —, but a wave that could
+                    // spin for ever is a hung GPU if that reasoning ever fails: then the bucket's long runs stay unsummed and the table's status says so)
+                    uint32_t spins = 0;
+                    while ((f = __hip_atomic_load(&A.hand_flag[j0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && ++spins < (1u << 16)) __builtin_amdgcn_s_sleep(16);
+                    if (f == 0u) { atomicOr(A.d.status, (uint32_t)MEE_STATUS_INTERNAL); f = 1u; }
+                }
                 L.d.hp[t] = f - 1u;
             }
             __syncthreads();
