@@ -1396,7 +1396,6 @@ extern "C" int mee_device_calibration(int32_t device, mee_calibration* out) {
 namespace mee {
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
-void bucket_apply_preload(const mee_table* t);
 int bucket_scratch_alloc(mee_table* t) {
     BucketScratch& bk = t->bk;
     int cus = 256;
@@ -1457,7 +1456,6 @@ int bucket_scratch_alloc(mee_table* t) {
     if (e == hipSuccess) e = hipHostMalloc((void**)&dd.h_slabs, 64, hipHostMallocMapped | hipHostMallocPortable);
     if (e == hipSuccess) { *dd.h_slabs = 0u; e = hipHostGetDevicePointer((void**)&dd.h_slabs_dev, dd.h_slabs, 0); }
     if (e != hipSuccess) return fail(MEE_ERR_OUT_OF_MEMORY, "hipMalloc for the apply scratch: %s", hipGetErrorString(e));
-    bucket_apply_preload(t);
     return MEE_OK;
 }
 void bucket_scratch_free(mee_table* t) {
@@ -1507,22 +1505,6 @@ int bucket_apply_discard(mee_table* t, hipStream_t st) {
     bkt_skip_kernel<<<1, 64, 0, st>>>(t->bk);
     MEE_HIP(hipGetLastError());
     return MEE_OK;
-}
-
-// The first launch of a kernel pays for loading its code (measured: the first FULL apply of a process takes ~270 us instead of ~60 — exactly the batch behind a
-// stream's first skewed one).  bucket_scratch_alloc asks for the attributes of the table's apply kernels, which makes the runtime load them at creation.
-template <int K, int D4>
-static void preload_apply_kernels() {
-    hipFuncAttributes fa;
-    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&bkt_apply_kernel<K, D4, true, false, true>));
-    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&bkt_apply_kernel<K, D4, true, false, false>));
-    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&bkt_apply_kernel<K, D4, false, false, true>));
-    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&bkt_apply_kernel<K, D4, false, false, false>));
-    (void)hipGetLastError();
-}
-void bucket_apply_preload(const mee_table* t) {
-    if (t->optimizer == MEE_OPT_ADAGRAD) { if (t->dim4 == 16) preload_apply_kernels<MEE_OPT_ADAGRAD, 16>(); else if (t->dim4 == 32) preload_apply_kernels<MEE_OPT_ADAGRAD, 32>(); else preload_apply_kernels<MEE_OPT_ADAGRAD, 0>(); }
-    else if (t->optimizer == MEE_OPT_ADAM) { if (t->dim4 == 16) preload_apply_kernels<MEE_OPT_ADAM, 16>(); else if (t->dim4 == 32) preload_apply_kernels<MEE_OPT_ADAM, 32>(); else preload_apply_kernels<MEE_OPT_ADAM, 0>(); }
 }
 
 int bucket_apply_launch(mee_table* t, const float* d_grads, uint32_t n, const OptArgs& a, const uint32_t* d_gidx, const int64_t* d_slots, hipStream_t st,

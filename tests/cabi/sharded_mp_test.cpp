@@ -14,6 +14,9 @@
 // host -> a SKEWED step (a quarter of the slice twice more, with other gradients: with MEE_SHARDED_DEDUP the rank sends one summed row per distinct key) ->
 // remove half of its slice -> size, found masks.  Twice: exact segments, and padded segments with pre-exchange dedup (mee_sharded_create_ex).
 // Exit code 0 = every rank passed.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 
 #include <sys/mman.h>
@@ -196,7 +199,20 @@ static int run_rank(int rank, int G, Shared* sh) {
     return 0;
 }
 
+// a crash of this program must say where: the test runner only sees the exit status otherwise
+static void on_crash(int sig) {
+    void* frames[48];
+    const int n = backtrace(frames, 48);
+    const char msg[] = "sharded_mp_test: fatal signal, backtrace:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 int main(int argc, char** argv) {
+    signal(SIGSEGV, on_crash); signal(SIGBUS, on_crash); signal(SIGABRT, on_crash); signal(SIGFPE, on_crash);
+    setvbuf(stdout, nullptr, _IONBF, 0);
     const int G = argc > 1 ? atoi(argv[1]) : 2;
     const bool threads = argc > 2 && !strcmp(argv[2], "threads");
     if (G < 1 || G > 8) { fprintf(stderr, "usage: sharded_mp_test [G = 1..8] [threads]\n"); return 64; }
