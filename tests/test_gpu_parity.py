@@ -985,9 +985,9 @@ def test_full_size_configs_properties(dev):
     t.close()
 
 
-# MEE_SOAK=N appends N more seeds (a soak run on the GPU box; the default suite keeps five)
+# MEE_SOAK=N appends N more seeds (a soak run on the GPU box; the default suite keeps five); MEE_SOAK_FIRST=K: the N seeds start behind the first K (another soak, other sequences)
 _SEQ = [(0, 16, "adagrad"), (1, 64, "adam"), (2, 128, "adagrad"), (3, 8, "adam"), (4, 64, "adagrad")] + \
-       [(s, [16, 64, 128, 8][s % 4], ["adagrad", "adam"][(s // 4) % 2]) for s in range(5, 5 + int(os.environ.get("MEE_SOAK", "0")))]
+       [(s, [16, 64, 128, 8][s % 4], ["adagrad", "adam"][(s // 4) % 2]) for s in range(5 + int(os.environ.get("MEE_SOAK_FIRST", "0")), 5 + int(os.environ.get("MEE_SOAK_FIRST", "0")) + int(os.environ.get("MEE_SOAK", "0")))]
 
 
 @pytest.mark.parametrize("seed,dim,opt", _SEQ)
