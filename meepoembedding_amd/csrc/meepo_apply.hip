@@ -1100,8 +1100,13 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
     const unsigned long long cand = L.kmax;
     const int64_t cand_key = (int64_t)(cand ^ kBias);
     const bool by_position = n_sub > 1 && L.stk_n >= kSlowAgree && ((uint64_t)b + 1) * (kSlowHelpers + 1) <= bk.fast_max;   // block-uniform, and the same in every share of the bucket
-    // ---- ONE walk (by position: share 0 alone): count the candidate, list everything else
-    if (!by_position || OWN) {
+    // CROWDED: the samples say that what is left beside the candidate will not fit ONE block's list (two giant keys in one bucket: four first skewed batches in ten of
+    // a Zipf(1.05) stream have such a bucket) — then the other keys are shared by KEY among all shares (each walks the bucket once and lists ITS keys' entries), the
+    // candidate still by position.  (Share 0 alone with an overflowing list: a pass over the whole bucket per key, ~340 keys: 10 ms.)
+    const bool crowded = by_position && (uint64_t)(64u - L.stk_n) * size > 64ull * (kBucketCap * 3 / 4);
+    const bool by_key = !by_position || crowded;   // the other keys: by key among all shares | all to share 0 (one pass of the bucket path)
+    // ---- ONE walk (by position: share 0 alone): count the candidate, list everything else (by key: what this share's hash gives it)
+    if (by_key || OWN) {
         uint32_t mine = 0;
         for (uint32_t e0 = t; e0 < size; e0 += kWalk * kApplyThreads) {
             PartEntry en[kWalk];
@@ -1112,7 +1117,7 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
                 const uint32_t e = e0 + q * kApplyThreads;
                 if (e >= size) continue;
                 if (((unsigned long long)en[q].key ^ kBias) == cand) ++mine;
-                else { const uint32_t at = atomicAdd(&L.n_items, 1u); if (at < kBucketCap) L.off[at] = e; }
+                else if (!by_key || slow_share_of(en[q].key, n_sub) == sub) { const uint32_t at = atomicAdd(&L.n_items, 1u); if (at < kBucketCap) L.off[at] = e; }
             }
         }
         if (mine) atomicAdd(&L.n_cand, mine);
@@ -1124,7 +1129,8 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
         // windows of kSlowWindow entries, window w to share w mod n_pos; a bucket with fewer windows than shares leaves the shares behind its windows out altogether
         // (no partial row, no ticket: most helper duties of a batch end here, two round trips in)
         const uint32_t n_pos = min(n_sub, (size + kSlowWindow - 1) / kSlowWindow);
-        if (!OWN && sub >= n_pos) return;   // (block-uniform)
+        if (!OWN && sub >= n_pos && !crowded) return;   // (block-uniform)
+        if (sub < n_pos) {
         const int64_t slot_handle = LOCATED ? (int64_t)L.slot[0] : 0;
         double* prt = bk.pend_row + ((uint64_t)b * (kSlowHelpers + 1) + sub) * dim4 * 4;
         for (uint32_t c0 = 0; c0 < dim4; c0 += 16) {
@@ -1153,13 +1159,16 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
                 slow_update<KIND, DIM4, LOCATED, GROUPED>(L, A, a, gdesc, cand_key, c0, dim4);
             }
         }
-        if constexpr (!OWN) return;   // a helper's part ends here
-        else {
-            if (t == 0 && n_major >= A.hot_count) report_hot_key(bk, parity, cand_key);   // its own bucket next time
-            if (n_other == 0) return;
-            if (list_n) {   // the rest of the bucket is an ordinary bucket's worth of entries: the ordinary path
-                process_slab<KIND, DIM4, LOCATED, kListed, GROUPED>(L, A, bk, 0, list_n, b, 0, parity, gdesc);
-                return;
+        }
+        if (OWN && t == 0 && n_major >= A.hot_count) report_hot_key(bk, parity, cand_key);   // its own bucket next time
+        if (!crowded) {
+            if constexpr (!OWN) return;   // a helper's part ends here
+            else {
+                if (n_other == 0) return;
+                if (list_n) {   // the rest of the bucket is an ordinary bucket's worth of entries: the ordinary path
+                    process_slab<KIND, DIM4, LOCATED, kListed, GROUPED>(L, A, bk, 0, list_n, b, 0, parity, gdesc);
+                    return;
+                }
             }
         }
     } else if (n_major != 0 && slow_share_of(cand_key, n_sub) == sub) {   // the candidate is an ordinary key of this share (it is not in the list)
@@ -1170,8 +1179,8 @@ __device__ __forceinline__ void slow_bucket(ApplyLds& L, const ApplyArgs& A, con
         if (t == 0 && n_major >= A.hot_count) report_hot_key(bk, parity, cand_key);
     }
     // ---- the other keys, shared by key: each share takes the keys its hash gives it, one at a time in increasing key order
-    // (by position with an overflowing list: share 0 takes them all)
-    const uint32_t k_sub = by_position ? 0u : sub, k_n = by_position ? 1u : n_sub;
+    // (by position with a list that overflows against the samples' word: share 0 takes them all)
+    const uint32_t k_sub = by_key ? sub : 0u, k_n = by_key ? n_sub : 1u;
     const uint32_t walk_n = list_n ? list_n : size;
     bool have_last = false;
     unsigned long long last = 0;
